@@ -1,0 +1,159 @@
+"""Hot-path configuration.
+
+The shims in this package are duck-typed on ``config``: the reference's own ``Config`` object
+(`utils/config.py:14-408`, loaded by `Config.load`, `utils/config.py:410-910`) works unchanged.
+``HotPathConfig`` is a minimal stand-in that carries only the attributes the SDF-training hot path
+reads (SURVEY.md section 8 header), with the reference's defaults, and reads the same YAML
+sections/keys so `config/run_ncd128.yaml` / `run_SubT_MRS.yaml` resolve to the same values.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import yaml
+
+
+class HotPathConfig:
+    def __init__(self) -> None:
+        # setting
+        self.name = "clid_native"
+        self.device = "cuda"
+        self.dtype = torch.float32
+        self.silence = True
+        self.seed = 42
+        self.semantic_on = False
+        self.color_on = False
+        self.color_channel = 0
+        # process
+        self.min_range = 1.0
+        self.max_range = 60.0
+        self.vox_down_m = 0.1
+        # sampler (`utils/config.py:518-540`)
+        self.surface_sample_range_m = 0.25
+        self.surface_sample_n = 4
+        self.free_sample_begin_ratio = 0.5
+        self.free_sample_end_dist_m = 1.2
+        self.free_front_n = 2
+        self.free_behind_n = 1
+        # neural points (`utils/config.py:542-600`)
+        self.voxel_size_m = 0.4
+        self.buffer_size = int(5e7)
+        self.feature_dim = 8
+        self.feature_std = 0.0
+        self.query_nn_k = 6
+        self.num_nei_cells = 2
+        self.search_alpha = 0.5
+        self.weighted_first = True
+        self.layer_norm_on = False
+        self.pos_encoding_band = 0
+        self.pos_input_dim = 3
+        self.use_gaussian_pe = False
+        self.use_mid_ts = False
+        self.local_map_travel_dist_ratio = 5.0
+        self.diff_ts_local = 400.0
+        # decoder
+        self.geo_mlp_level = 1
+        self.geo_mlp_hidden_dim = 64
+        self.mlp_bias_on = True
+        self.mlp_leaky_relu = False
+        self.freeze_after_frame = 40
+        # loss (`utils/config.py:622-657`)
+        self.main_loss_type = "bce"
+        self.sigma_sigmoid_m = 0.1
+        self.logistic_gaussian_ratio = 0.55
+        self.loss_weight_on = True
+        self.dist_weight_on = True
+        self.dist_weight_scale = 0.8
+        self.behind_dropoff_on = False
+        self.ekional_loss_on = True
+        self.ekional_add_to = "all"
+        self.weight_e = 0.5
+        self.numerical_grad = True
+        self.gradient_decimation = 10
+        self.num_grad_step_ratio = 0.2
+        self.proj_correction_on = False
+        self.consistency_loss_on = False
+        # continual
+        self.bs_new_sample = 1000
+        self.pool_capacity = int(1e7)
+        # optimizer (`utils/config.py:800-835`)
+        self.iters = 10
+        self.init_iter_ratio = 40
+        self.bs = 16384
+        self.lr = 0.01
+        self.lr_pose = 1e-4
+        self.weight_decay = 0.0
+        self.adam_eps = 1e-15
+        self.opt_adam = True
+        self.adaptive_iters = True
+        self.ba_freq_frame = 0
+        self.wandb_vis_on = False
+        self._derive()
+
+    def _derive(self) -> None:
+        # `utils/config.py:903-910`
+        self.infer_bs = self.bs * 64
+        self.local_map_radius = self.max_range + 2.0
+        self.window_radius = max(self.max_range, 6.0)
+
+    def load(self, config_file: str) -> "HotPathConfig":
+        with open(os.path.abspath(config_file)) as fh:
+            args = yaml.safe_load(fh) or {}
+        g = args.get
+        s = g("setting", {})
+        self.name = s.get("name", self.name)
+        self.device = s.get("device", self.device)
+        self.seed = s.get("random_seed", self.seed)
+        p = g("process", {})
+        self.min_range = p.get("min_range_m", self.min_range)
+        self.max_range = p.get("max_range_m", self.max_range)
+        self.vox_down_m = p.get("vox_down_m", self.vox_down_m)
+        sa = g("sampler", {})
+        self.surface_sample_range_m = sa.get("surface_sample_range_m", self.surface_sample_range_m)
+        self.surface_sample_n = sa.get("surface_sample_n", self.surface_sample_n)
+        self.free_sample_begin_ratio = sa.get("free_sample_begin_ratio", self.free_sample_begin_ratio)
+        self.free_sample_end_dist_m = sa.get("free_sample_end_dist_m", self.free_sample_end_dist_m)
+        self.free_front_n = sa.get("free_front_sample_n", self.free_front_n)
+        self.free_behind_n = sa.get("free_behind_sample_n", self.free_behind_n)
+        n = g("neuralpoints", {})
+        self.voxel_size_m = n.get("voxel_size_m", self.voxel_size_m)
+        self.query_nn_k = n.get("query_nn_k", self.query_nn_k)
+        self.buffer_size = int(float(n.get("buffer_size", self.buffer_size)))
+        self.num_nei_cells = n.get("num_nei_cells", self.num_nei_cells)
+        self.layer_norm_on = n.get("layer_norm_on", self.layer_norm_on)
+        self.search_alpha = n.get("search_alpha", self.search_alpha)
+        self.feature_dim = n.get("feature_dim", self.feature_dim)
+        self.feature_std = n.get("feature_std", self.feature_std)
+        self.weighted_first = n.get("weighted_first", self.weighted_first)
+        self.use_mid_ts = n.get("use_mid_ts", self.use_mid_ts)
+        self.local_map_travel_dist_ratio = n.get(
+            "local_map_travel_dist_ratio", self.local_map_travel_dist_ratio
+        )
+        d = g("decoder", {})
+        self.geo_mlp_level = d.get("mlp_level", self.geo_mlp_level)
+        self.geo_mlp_hidden_dim = d.get("mlp_hidden_dim", self.geo_mlp_hidden_dim)
+        self.freeze_after_frame = d.get("freeze_after_frame", self.freeze_after_frame)
+        lo = g("loss", {})
+        self.main_loss_type = lo.get("main_loss_type", self.main_loss_type)
+        self.sigma_sigmoid_m = lo.get("sigma_sigmoid_m", self.sigma_sigmoid_m)
+        self.loss_weight_on = lo.get("loss_weight_on", self.loss_weight_on)
+        self.dist_weight_scale = lo.get("dist_weight_scale", self.dist_weight_scale)
+        self.ekional_loss_on = lo.get("ekional_loss_on", self.ekional_loss_on)
+        self.weight_e = float(lo.get("weight_e", self.weight_e))
+        self.numerical_grad = lo.get("numerical_grad_on", self.numerical_grad)
+        if not self.numerical_grad:  # `utils/config.py:645-646`
+            self.gradient_decimation = 1
+        else:
+            self.gradient_decimation = lo.get("grad_decimation", self.gradient_decimation)
+            self.num_grad_step_ratio = lo.get("num_grad_step_ratio", self.num_grad_step_ratio)
+        c = g("continual", {})
+        self.bs_new_sample = int(c.get("batch_size_new_sample", self.bs_new_sample))
+        self.pool_capacity = int(float(c.get("pool_capacity", self.pool_capacity)))
+        o = g("optimizer", {})
+        self.iters = o.get("iters", self.iters)
+        self.bs = o.get("batch_size", self.bs)
+        self.lr = float(o.get("learning_rate", self.lr))
+        self.adaptive_iters = o.get("adaptive_iters", self.adaptive_iters)
+        self._derive()
+        return self

@@ -1,0 +1,428 @@
+"""CPU ORACLE for CLID-SLAM's per-scan SDF training inner loop.  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch CPU (PyTorch fp32, eager) restatement of the reference algorithm on
+the hot path named by BASELINE.json `north_star`.  Only `tests/`, `__graft_entry__.smoke()` and
+`bench.py`'s `cpu_baseline` leg may import it; the product path (`clid-slam_amd/`) never does and
+fails loudly when the HIP library is missing.
+
+Parity status: PINNED.  The reference ships no tests or golden vectors, so
+the restatement is pinned against outputs of the reference itself, imported unmodified in the
+build container by `oracle/make_golden.py` (fixtures G1..G6 under `tests/golden/`, checked by
+`tests/test_oracle_golden.py`).
+
+Every function cites the reference lines it follows (paths relative to the reference root).
+State is held in a plain `MapState`; nothing here depends on the product package.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+PRIMES = (73856093, 19349669, 83492791)  # model/neural_points.py:79-81
+
+
+# --------------------------------------------------------------------------------------------------
+# state
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class MapState:
+    """The tensors the hot path reads/writes (model/neural_points.py:79-133)."""
+
+    buffer_pt_index: torch.Tensor  # [B] int64, -1 = empty slot
+    neural_points: torch.Tensor  # [Mg,3] f32
+    point_ts_create: torch.Tensor  # [Mg] int32
+    travel_dist: torch.Tensor  # [frames] f32
+    cur_ts: int
+    global2local: torch.Tensor  # [Mg+1] int64 (last = -1)
+    local_neural_points: torch.Tensor  # [M,3]
+    local_geo_features: torch.Tensor  # [M+1,F] (last row = padding)
+    local_point_certainties: torch.Tensor  # [M]
+    local_point_ts_update: torch.Tensor  # [M] int32
+    # global-map counterparts (query_locally=False)
+    geo_features: Optional[torch.Tensor] = None  # [Mg+1,F]
+    point_certainties: Optional[torch.Tensor] = None  # [Mg]
+    # search parameters
+    resolution: float = 0.4
+    buffer_size: int = int(5e7)
+    diff_travel_dist_local: float = 310.0
+    temporal_local_map_on: bool = True
+    neighbor_dx: torch.Tensor = field(default=None)  # [P,3] int64
+    max_valid_dist2: float = 4.32
+    # query parameters
+    nn_k: int = 6
+    layer_norm_on: bool = False
+    weighted_first: bool = True
+
+
+@dataclass
+class DecoderParams:
+    """model/decoder.py:12-56 with hidden_level == 1: Linear(D,H) -> ReLU -> Linear(H,1)."""
+
+    W1: torch.Tensor  # [H,D]
+    b1: torch.Tensor  # [H]
+    W2: torch.Tensor  # [1,H]
+    b2: torch.Tensor  # [1]
+    sdf_scale: float = 0.055
+
+    def tensors(self):
+        return [self.W1, self.b1, self.W2, self.b2]
+
+
+# --------------------------------------------------------------------------------------------------
+# a2: neighbourhood search
+# --------------------------------------------------------------------------------------------------
+def search_neighborhood(num_nei_cells: int, search_alpha: float, resolution: float):
+    """model/neural_points.py:931-969 -> (neighbor_dx [P,3] int64, max_valid_dist2)."""
+    r = torch.arange(-num_nei_cells, num_nei_cells + 1, dtype=torch.int64)
+    gx, gy, gz = torch.meshgrid(r, r, r, indexing="ij")
+    cube = torch.stack((gx, gy, gz), dim=-1).reshape(-1, 3)
+    keep = (cube * cube).sum(-1) < (num_nei_cells + search_alpha) ** 2
+    return cube[keep].contiguous(), 3 * ((num_nei_cells + 1) * resolution) ** 2
+
+
+def radius_neighborhood_search(st: MapState, points: torch.Tensor, time_filtering: bool = False):
+    """model/neural_points.py:971-1030 -> (dist2 [N,P] f32, neighb_idx [N,P] int64, global ids).
+
+    Voxel index = floor(x / res) with a true fp32 divide; the hash
+    `fmod(sum(cell * primes), B)` indexed with Python negative wrap-around is the non-negative
+    modulo.  Index -1 reads the LAST element of the indexed arrays and is masked afterwards.
+    """
+    primes = torch.tensor(PRIMES, dtype=torch.int64)
+    cell = torch.floor(points / st.resolution).to(torch.int64)  # [N,3]
+    cells = cell[:, None, :] + st.neighbor_dx[None, :, :]  # [N,P,3]
+    slot = torch.remainder((cells * primes).sum(-1), int(st.buffer_size))
+    idx = st.buffer_pt_index[slot]  # [N,P]
+    if time_filtering:
+        created = st.point_ts_create[idx]
+        gap = torch.abs(st.travel_dist[st.cur_ts] - st.travel_dist[created])
+        idx = torch.where(gap < st.diff_travel_dist_local, idx, torch.full_like(idx, -1))
+    diff = st.neural_points[idx] - points[:, None, :]
+    dist2 = (diff * diff).sum(-1)
+    dist2 = torch.where(idx == -1, torch.full_like(dist2, st.max_valid_dist2), dist2)
+    idx = torch.where(dist2 > st.max_valid_dist2, torch.full_like(idx, -1), idx)
+    return dist2, idx
+
+
+# --------------------------------------------------------------------------------------------------
+# a3: feature query
+# --------------------------------------------------------------------------------------------------
+def query_feature(
+    st: MapState,
+    query_points: torch.Tensor,
+    query_ts: Optional[torch.Tensor] = None,
+    training_mode: bool = True,
+    query_locally: bool = True,
+):
+    """model/neural_points.py:553-769 (geometry features only, no colour, no PGO rotation).
+
+    Returns (geo_feat [N,D] or [N,K,D], weight [N,K,1], nn_counts [N], certainty [N],
+             idx [N,K] (local or global ids, -1 invalid)).
+    Differentiable w.r.t. `query_points` (through r_k and the IDW weights) and the feature table.
+    """
+    K = st.nn_k
+    dist2, idx = radius_neighborhood_search(
+        st, query_points, time_filtering=st.temporal_local_map_on and query_locally
+    )
+    if query_locally:
+        idx = st.global2local[idx]  # :595-598
+        feats_tab, pts_tab, cert_tab = st.local_geo_features, st.local_neural_points, st.local_point_certainties
+    else:
+        feats_tab, pts_tab, cert_tab = st.geo_features, st.neural_points, st.point_certainties
+    nn_counts = (idx >= 0).sum(-1)  # :600-602 (over all P probes)
+    dist2 = torch.where(idx == -1, torch.full_like(dist2, 9e3), dist2)  # :606
+    dist2, order = torch.sort(dist2, dim=1)  # :607-609
+    idx = idx.gather(1, order)[:, :K]
+    dist2 = dist2[:, :K]
+    valid = idx >= 0
+    validf = valid.unsqueeze(-1)
+
+    feat = torch.where(validf, feats_tab[idx], torch.zeros((), dtype=feats_tab.dtype))  # :620-631
+    if st.layer_norm_on:
+        feat = F.layer_norm(feat, [feat.shape[-1]])  # :632-633 (all-zero rows stay zero)
+    cert = torch.where(valid, cert_tab[idx], torch.zeros((), dtype=cert_tab.dtype))  # :654,734
+    rel = torch.where(validf, query_points[:, None, :] - pts_tab[idx], torch.zeros(()))  # :655-674
+    vec = torch.cat((feat, rel), dim=2)  # :679-682
+
+    eps = 1e-15
+    w = torch.where(valid, 1.0 / (dist2 + eps), torch.zeros(()))  # :688-693
+    w = torch.where((nn_counts == 0)[:, None], torch.full_like(w, eps), w)  # :694-696
+    w = w / w.sum(dim=1, keepdim=True)  # :699-702
+    w = torch.where(valid, w, torch.zeros(()))  # :706
+
+    with torch.no_grad():  # :708-741
+        if training_mode:
+            tgt = torch.where(valid, idx, torch.zeros_like(idx)).flatten()
+            cert_tab.scatter_add_(0, tgt, w.detach().flatten())
+            if query_locally and query_ts is not None:
+                ts_k = torch.where(valid, query_ts.view(-1, 1).expand(-1, K), torch.zeros((), dtype=query_ts.dtype))
+                st.local_point_ts_update.scatter_reduce_(
+                    0, tgt, ts_k.flatten().to(st.local_point_ts_update.dtype), reduce="amax", include_self=True
+                )
+        certainty = (cert * w).sum(dim=1)  # uses the pre-update certainties gathered above
+
+    w = w.unsqueeze(-1)
+    if st.weighted_first:
+        vec = (vec * w).sum(dim=1)  # :745-754
+    return vec, w, nn_counts, certainty, idx
+
+
+def query_certainty(st: MapState, query_points: torch.Tensor):
+    """model/neural_points.py:1032-1051 (global certainties, max over the probed cells)."""
+    _, idx = radius_neighborhood_search(st, query_points)
+    c = torch.where(idx < 0, torch.zeros(()), st.point_certainties[idx])
+    return c.max(dim=-1).values
+
+
+# --------------------------------------------------------------------------------------------------
+# a4: decoder
+# --------------------------------------------------------------------------------------------------
+def mlp_sdf(dec: DecoderParams, features: torch.Tensor) -> torch.Tensor:
+    """model/decoder.py:58-82: sdf = scale * (W2 relu(W1 f + b1) + b2), squeezed over dim 1."""
+    h = F.relu(F.linear(features, dec.W1, dec.b1))
+    return F.linear(h, dec.W2, dec.b2).squeeze(1) * dec.sdf_scale
+
+
+def sdf_at(st: MapState, dec: DecoderParams, x: torch.Tensor) -> torch.Tensor:
+    """utils/mapper.py:968-982 (`Mapper.sdf`): default-argument query (training_mode=True,
+    query_ts=None, local map) followed by the decoder."""
+    f, w, _, _, _ = query_feature(st, x)
+    s = mlp_sdf(dec, f)
+    if not st.weighted_first:
+        s = (s * w).sum(dim=1).squeeze(1)
+    return s
+
+
+# --------------------------------------------------------------------------------------------------
+# a6 / a7: gradients of the SDF w.r.t. the query position
+# --------------------------------------------------------------------------------------------------
+def numerical_gradient(st: MapState, dec: DecoderParams, x: torch.Tensor, eps: float) -> torch.Tensor:
+    """utils/mapper.py:985-1034, two-sided: ONE `sdf_at` call on the 6N shifted copies
+    [x+ex; x-ex; x+ey; x-ey; x+ez; x-ez]; stays in the autograd graph."""
+    n = x.shape[0]
+    shifted = []
+    for a in range(3):
+        e = torch.zeros(3, dtype=x.dtype)
+        e[a] = eps
+        shifted += [x + e, x - e]
+    s = sdf_at(st, dec, torch.cat(shifted, dim=0)).unsqueeze(-1)
+    cols = [(s[2 * a * n : (2 * a + 1) * n] - s[(2 * a + 1) * n : (2 * a + 2) * n]) / (2 * eps) for a in range(3)]
+    return torch.cat(cols, dim=1)
+
+
+def autograd_gradient(inputs: torch.Tensor, outputs: torch.Tensor) -> torch.Tensor:
+    """utils/tools.py:298-311 (`get_gradient`): d outputs / d inputs with create_graph=True."""
+    return torch.autograd.grad(
+        outputs, inputs, torch.ones_like(outputs), create_graph=True, retain_graph=True, only_inputs=True
+    )[0]
+
+
+def closed_form_sdf_and_gradient(st: MapState, dec: DecoderParams, x: torch.Tensor):
+    """the same forward plus the analytic d sdf / d x written out
+    (no autograd).  Used to pin the formula the HIP kernel implements against `autograd_gradient`.
+    Returns (sdf [N], grad [N,3], nn_counts [N])."""
+    with torch.no_grad():
+        K = st.nn_k
+        dist2, idx = radius_neighborhood_search(st, x, time_filtering=st.temporal_local_map_on)
+        idx = st.global2local[idx]
+        nn_counts = (idx >= 0).sum(-1)
+        dist2 = torch.where(idx == -1, torch.full_like(dist2, 9e3), dist2)
+        dist2, order = torch.sort(dist2, dim=1)
+        idx = idx.gather(1, order)[:, :K]
+        dist2 = dist2[:, :K]
+        valid = (idx >= 0).to(x.dtype)
+        feat = st.local_geo_features[idx] * valid[..., None]
+        if st.layer_norm_on:
+            feat = F.layer_norm(feat, [feat.shape[-1]])
+        r = (x[:, None, :] - st.local_neural_points[idx]) * valid[..., None]
+        omega = valid / (dist2 + 1e-15)
+        osum = omega.sum(1, keepdim=True)
+        w = torch.where(osum > 0, omega / osum, torch.zeros(()))
+        v = torch.cat((feat, r), dim=2)  # [N,K,D]
+        f = (v * w[..., None]).sum(1)
+        pre = f @ dec.W1.T + dec.b1
+        act = (pre > 0).to(x.dtype)
+        sdf = dec.sdf_scale * ((pre * act) @ dec.W2[0] + dec.b2[0])
+        alpha = 2.0 * r * omega[..., None]  # [N,K,3]
+        abar = (w[..., None] * alpha).sum(1, keepdim=True)  # [N,1,3]
+        dw = w[..., None] * (abar - alpha)  # [N,K,3]
+        J = torch.einsum("nkd,nkc->ndc", v, dw)  # [N,D,3]
+        Fdim = feat.shape[-1]
+        J[:, Fdim:, :] += w.sum(1)[:, None, None] * torch.eye(3)
+        u = dec.sdf_scale * ((act * dec.W2[0]) @ dec.W1)  # [N,D]
+        g = torch.einsum("nd,ndc->nc", u, J)
+    return sdf, g, nn_counts
+
+
+# --------------------------------------------------------------------------------------------------
+# a8: loss
+# --------------------------------------------------------------------------------------------------
+def sdf_bce_loss(pred, label, sigma, weight, weighted=False, bce_reduction="mean"):
+    """utils/loss.py:44-62."""
+    target = torch.sigmoid(label / sigma)
+    return F.binary_cross_entropy_with_logits(
+        pred / sigma, target, weight=weight if weighted else None, reduction=bce_reduction
+    )
+
+
+def eikonal_loss(g: torch.Tensor) -> torch.Tensor:
+    """utils/mapper.py:795-797 (`ekional_add_to == "all"`)."""
+    return ((g.norm(2, dim=-1) - 1.0) ** 2).mean()
+
+
+# --------------------------------------------------------------------------------------------------
+# a9: Adam exactly as torch.optim.Adam's single-tensor path
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class AdamState:
+    m: torch.Tensor
+    v: torch.Tensor
+    step: int = 0
+
+
+def adam_step(p: torch.Tensor, g: torch.Tensor, s: AdamState, lr=0.01, b1=0.9, b2=0.99, eps=1e-15, weight_decay=0.0):
+    """utils/tools.py:205-255 -> optim.Adam(betas=(0.9,0.99), eps=adam_eps), non-amsgrad."""
+    s.step += 1
+    if weight_decay != 0.0:
+        g = g + weight_decay * p
+    s.m.lerp_(g, 1.0 - b1)
+    s.v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+    bc1 = 1.0 - b1**s.step
+    bc2 = 1.0 - b2**s.step
+    denom = (s.v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(s.m, denom, value=-(lr / bc1))
+
+
+# --------------------------------------------------------------------------------------------------
+# a1 + a11: the mapping loop
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class SamplePool:
+    """utils/mapper.py:84-97 (the tensors `get_batch` gathers from)."""
+
+    global_coord: torch.Tensor  # [S,3]
+    sdf_label: torch.Tensor  # [S]
+    time: torch.Tensor  # [S] int32
+    weight: torch.Tensor  # [S]
+
+
+@dataclass
+class LoopConfig:
+    sigma: float = 0.055  # logistic_gaussian_ratio * sigma_sigmoid_m (utils/mapper.py:71)
+    loss_weight_on: bool = True
+    ekional_loss_on: bool = True
+    weight_e: float = 0.5
+    numerical_grad: bool = True
+    gradient_decimation: int = 10
+    fd_eps: float = 0.08  # voxel_size_m * num_grad_step_ratio (utils/mapper.py:703)
+    lr: float = 0.01
+    adam_eps: float = 1e-15
+    weight_decay: float = 0.0
+    train_decoder: bool = True  # False after `freeze_model` (utils/tools.py:314, slam.py:193-196)
+    loss_scale_counts: Optional[tuple] = None  # (N_global, N'_global) for sharded runs; None = local
+
+
+def draw_batch_index(pool_count: int, new_idx: Optional[torch.Tensor], bs: int, bs_new_sample: int, gen=None):
+    """utils/mapper.py:473-500: bs-bs_new uniform over the pool, bs_new from the new samples."""
+    if bs_new_sample > 0 and new_idx is not None and new_idx.shape[0] > 0:
+        bs_new = min(new_idx.shape[0], bs_new_sample)
+        hist = torch.randint(0, pool_count, (bs - bs_new,), generator=gen)
+        pick = torch.randint(0, new_idx.shape[0], (bs_new,), generator=gen)
+        return torch.cat((hist, new_idx[pick]), dim=0)
+    return torch.randint(0, pool_count, (bs,), generator=gen)
+
+
+def loss_and_grads(st: MapState, dec: DecoderParams, pool: SamplePool, index: torch.Tensor, lc: LoopConfig):
+    """One iteration body of utils/mapper.py:642-835 up to `backward()`; returns a dict with the
+    loss triple, sdf_pred and the gradients of the feature table and decoder tensors."""
+    coord = pool.global_coord[index]
+    label = pool.sdf_label[index]
+    ts = pool.time[index]
+    weight = pool.weight[index].abs()
+    theta = st.local_geo_features
+    params = [theta] + (dec.tensors() if lc.train_decoder else [])
+    for p in params:
+        p.requires_grad_(True)
+        p.grad = None
+    analytic = lc.ekional_loss_on and not lc.numerical_grad
+    if analytic:
+        coord = coord.clone().requires_grad_(True)  # :660-661
+    f, w, _, _, _ = query_feature(st, coord, ts)
+    sdf_pred = mlp_sdf(dec, f)
+    if not st.weighted_first:
+        sdf_pred = (sdf_pred * w).sum(dim=1).squeeze(1)
+    g = None
+    if analytic:
+        g = autograd_gradient(coord, sdf_pred)
+    elif lc.ekional_loss_on and lc.numerical_grad:
+        g = numerical_gradient(st, dec, coord[:: lc.gradient_decimation], lc.fd_eps)
+    n_main = sdf_pred.shape[0]
+    l_bce = sdf_bce_loss(sdf_pred, label, lc.sigma, weight, lc.loss_weight_on)
+    total = l_bce
+    l_eik = torch.zeros(())
+    if lc.ekional_loss_on and lc.weight_e > 0 and g is not None:
+        l_eik = eikonal_loss(g)
+        total = total + lc.weight_e * l_eik
+    if lc.loss_scale_counts is not None:  # sharded: normalise by the global counts
+        n_glob, ng_glob = lc.loss_scale_counts
+        total = l_bce * (n_main / n_glob)
+        if g is not None:
+            total = total + lc.weight_e * l_eik * (g.shape[0] / ng_glob)
+    total.backward()
+    out = {
+        "loss": total.detach(),
+        "sdf_loss": l_bce.detach(),
+        "eikonal_loss": l_eik.detach(),
+        "sdf_pred": sdf_pred.detach(),
+        "g": None if g is None else g.detach(),
+        "grad_theta": theta.grad.detach().clone(),
+    }
+    if lc.train_decoder:
+        for name, t in zip(("W1", "b1", "W2", "b2"), dec.tensors()):
+            out["grad_" + name] = t.grad.detach().clone()
+    for p in params:
+        p.requires_grad_(False)
+        p.grad = None
+    return out
+
+
+def mapping_iters(st: MapState, dec: DecoderParams, pool: SamplePool, index_seq, lc: LoopConfig, record=False):
+    """utils/mapper.py:620-862 with a teacher-forced batch-index sequence (`index_seq` [iters,bs]).
+
+    A NEW Adam state is created per call (utils/mapper.py:634).  Returns the per-iteration records
+    when `record`, else the list of loss triples."""
+    theta = st.local_geo_features
+    ad_theta = AdamState(torch.zeros_like(theta), torch.zeros_like(theta))
+    ad_dec = [AdamState(torch.zeros_like(t), torch.zeros_like(t)) for t in dec.tensors()]
+    recs = []
+    for it in range(len(index_seq)):
+        out = loss_and_grads(st, dec, pool, index_seq[it], lc)
+        with torch.no_grad():
+            if lc.train_decoder:
+                for name, t, s in zip(("W1", "b1", "W2", "b2"), dec.tensors(), ad_dec):
+                    adam_step(t, out["grad_" + name], s, lc.lr, eps=lc.adam_eps)
+            adam_step(theta, out["grad_theta"], ad_theta, lc.lr, eps=lc.adam_eps, weight_decay=lc.weight_decay)
+        if record:
+            out["theta"] = theta.detach().clone()
+            out["dec"] = [t.detach().clone() for t in dec.tensors()]
+            out["adam_m_theta"] = ad_theta.m.clone()
+            out["adam_v_theta"] = ad_theta.v.clone()
+            out["certainties"] = st.local_point_certainties.clone()
+            out["ts_update"] = st.local_point_ts_update.clone()
+            recs.append(out)
+        else:
+            recs.append((float(out["loss"]), float(out["sdf_loss"]), float(out["eikonal_loss"])))
+    return recs
+
+
+# --------------------------------------------------------------------------------------------------
+# a10
+# --------------------------------------------------------------------------------------------------
+def assign_local_to_global(st: MapState, local_mask: torch.Tensor, point_ts_update: torch.Tensor):
+    """model/neural_points.py:538-549 (`local_mask` [Mg+1] bool with the padding slot True)."""
+    st.geo_features[local_mask] = st.local_geo_features.detach()
+    st.point_certainties[local_mask[:-1]] = st.local_point_certainties
+    point_ts_update[local_mask[:-1]] = st.local_point_ts_update

@@ -1,0 +1,425 @@
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Build-container only (needs /root/reference; the GPU box never runs this).  The reference's
+modules are imported unmodified with empty stub modules for the three absent third-party imports
+none of the hot-path functions touch (open3d, wandb, roma).
+What is committed are the resulting input/output tensors (small .npz files), not reference code.
+
+    python oracle/make_golden.py            # rewrites tests/golden/*.npz
+
+Fixtures: G1 search, G2 query, G3 mlp, G4 analytic gradient, G5 loss,
+G6 mapping loop (teacher-forced batch indices recorded from the reference's own `get_batch`).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("CLID_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        child = _Stub(self.__name__ + "." + name)
+        setattr(self, name, child)
+        return child
+
+    def __call__(self, *a, **k):
+        return _Stub("call")
+
+
+def import_reference():
+    for n in ("open3d", "wandb", "roma"):
+        sys.modules.setdefault(n, _Stub(n))
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    sys.path.insert(0, ROOT)
+    mods = types.SimpleNamespace()
+    from utils.config import Config
+    from model.decoder import Decoder
+    from model.neural_points import NeuralPoints
+    from utils.mapper import Mapper
+    from utils.loss import sdf_bce_loss
+    from utils.tools import get_gradient, setup_optimizer, freeze_model
+
+    mods.Config, mods.Decoder, mods.NeuralPoints, mods.Mapper = Config, Decoder, NeuralPoints, Mapper
+    mods.sdf_bce_loss, mods.get_gradient, mods.setup_optimizer, mods.freeze_model = (
+        sdf_bce_loss, get_gradient, setup_optimizer, freeze_model,
+    )
+    return mods
+
+
+def ref_config(ref, yaml_name="run_ncd128.yaml", buffer_size=100003, **over):
+    cfg = ref.Config()
+    cfg.load(os.path.join(REF, "config", yaml_name))
+    cfg.device = "cpu"
+    cfg.buffer_size = buffer_size  # small table => real hash collisions inside the fixtures
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def build_scene(ref, cfg, feature_seed=7):
+    """Three frames (sensor moved, travel distance jumps past the 310 m window after frame 0) so the
+    fixtures exercise the time filter, the local-window mapping and slot overwrites."""
+    import clid_slam_amd  # noqa: F401  (alias -> clid-slam_amd/)
+    from clid_slam_amd.synth import box_room_pool
+
+    torch.manual_seed(42)
+    np_map = ref.NeuralPoints(cfg)
+    sensors = [(0.0, 0.0, 1.5), (6.0, 2.0, 1.5), (9.0, 3.0, 1.6)]
+    travel = torch.tensor([0.0, 400.0, 403.5], dtype=torch.float32)
+    np_map.travel_dist = travel
+    pools = []
+    for fid, s in enumerate(sensors):
+        d = box_room_pool(cfg, n_elev=32, n_azim=256, seed=42 + fid, sensor=s)
+        near = d["sdf_label"].abs() < cfg.surface_sample_range_m * 0.5
+        np_map.update(d["coord"][near], d["sensor"], torch.eye(3), fid)
+        d["time"] = torch.full((d["coord"].shape[0],), fid, dtype=torch.int32)
+        pools.append(d)
+    # shrink the local window so that global2local has -1 entries; rebuild the local map
+    np_map.local_map_radius = 12.0
+    np_map.reset_local_map(pools[-1]["sensor"], torch.eye(3), 2, reboot_map=True)
+    g = torch.Generator().manual_seed(feature_seed)
+    np_map.geo_features = 0.3 * torch.randn(np_map.geo_features.shape, generator=g)
+    np_map.point_certainties = torch.rand(np_map.point_certainties.shape, generator=g) * 3.0
+    np_map.reset_local_map(pools[-1]["sensor"], torch.eye(3), 2, reboot_map=True)
+    pool = {
+        k: torch.cat([p[k] for p in pools], dim=0) for k in ("coord", "sdf_label", "weight", "time")
+    }
+    # keep the committed pool small: a fixed random subset per frame, frame order preserved
+    keep = torch.rand(pool["coord"].shape[0], generator=g) < 0.3
+    pool = {k: v[keep].contiguous() for k, v in pool.items()}
+    return np_map, pool
+
+
+def state_arrays(nm, dec=None):
+    tab = nm.buffer_pt_index
+    occ = torch.nonzero(tab >= 0).flatten()
+    out = dict(
+        table_slot=occ.to(torch.int64).numpy(),
+        table_idx=tab[occ].numpy(),
+        buffer_size=np.int64(nm.buffer_size),
+        neural_points=nm.neural_points.numpy(),
+        point_ts_create=nm.point_ts_create.numpy(),
+        point_ts_update=nm.point_ts_update.numpy(),
+        travel_dist=nm.travel_dist.numpy(),
+        cur_ts=np.int64(nm.cur_ts),
+        global2local=nm.global2local.numpy(),
+        local_mask=nm.local_mask.numpy(),
+        local_neural_points=nm.local_neural_points.numpy(),
+        local_geo_features=nm.local_geo_features.detach().numpy(),
+        local_point_certainties=nm.local_point_certainties.numpy(),
+        local_point_ts_update=nm.local_point_ts_update.numpy(),
+        geo_features=nm.geo_features.numpy(),
+        point_certainties=nm.point_certainties.numpy(),
+        neighbor_dx=nm.neighbor_dx.numpy(),
+        max_valid_dist2=np.float64(nm.max_valid_dist2),
+        resolution=np.float64(nm.resolution),
+        diff_travel_dist_local=np.float64(nm.diff_travel_dist_local),
+    )
+    if dec is not None:
+        sd = dec.state_dict()
+        out.update(
+            W1=sd["layers.0.weight"].numpy(), b1=sd["layers.0.bias"].numpy(),
+            W2=sd["lout.weight"].numpy(), b2=sd["lout.bias"].numpy(), sdf_scale=np.float64(dec.sdf_scale),
+        )
+    return {k: np.ascontiguousarray(v) for k, v in out.items()}
+
+
+def query_points(pool, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    pick = torch.randint(0, pool["coord"].shape[0], (n,), generator=g)
+    x = pool["coord"][pick].clone()
+    ts = pool["time"][pick].clone()
+    # a few far-away / empty-space queries (nn_count == 0) and exact cell-boundary coordinates
+    x[:8] = torch.tensor([[100.0, 100.0, 50.0]]) + torch.rand(8, 3, generator=g)
+    x[8:16] = torch.round(x[8:16] / 0.4) * 0.4
+    return x.contiguous(), ts.contiguous()
+
+
+def snapshot_rw(nm):
+    return nm.local_point_certainties.clone(), nm.local_point_ts_update.clone()
+
+
+def restore_rw(nm, snap):
+    nm.local_point_certainties = snap[0].clone()
+    nm.local_point_ts_update = snap[1].clone()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = import_reference()
+    cfg = ref_config(ref)
+    nm, pool = build_scene(ref, cfg)
+    torch.manual_seed(42)
+    dec = ref.Decoder(cfg, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, 1)
+    print("map: global", nm.count(), "local", nm.local_count(), "pool", pool["coord"].shape[0])
+    np.savez_compressed(os.path.join(OUT, "state.npz"), **state_arrays(nm, dec))
+
+    # ---------------- G1 search
+    x1, _ = query_points(pool, 1024, 1)
+    g1 = {"x": x1.numpy()}
+    for tf in (False, True):
+        d2, idx = nm.radius_neighborhood_search(x1, time_filtering=tf)
+        g1[f"dist2_tf{int(tf)}"] = d2.numpy()
+        g1[f"idx_tf{int(tf)}"] = idx.to(torch.int32).numpy()
+    np.savez_compressed(os.path.join(OUT, "g1_search.npz"), **g1)
+
+    # ---------------- G2 query (+G3 mlp, G4 gradient on the same points)
+    x2, ts2 = query_points(pool, 1024, 2)
+    g2 = {"x": x2.numpy(), "ts": ts2.numpy()}
+    snap = snapshot_rw(nm)
+    for ln in (False, True):
+        for wf in (True, False):
+            for tm in (True, False):
+                for loc in (True, False):
+                    if not loc and (tm or ln):
+                        continue  # global query: inference, plain features (mesher usage)
+                    cfg.layer_norm_on, cfg.weighted_first = ln, wf
+                    restore_rw(nm, snap)
+                    gc0 = nm.point_certainties.clone()
+                    f, _, w, nn, cert = nm.query_feature(
+                        x2, ts2 if loc else None, training_mode=tm, query_locally=loc
+                    )
+                    tag = f"ln{int(ln)}_wf{int(wf)}_tm{int(tm)}_loc{int(loc)}"
+                    g2[f"f_{tag}"] = f.detach().numpy()
+                    g2[f"w_{tag}"] = w.detach().numpy()
+                    g2[f"nn_{tag}"] = nn.to(torch.int32).numpy()
+                    g2[f"cert_{tag}"] = cert.numpy()
+                    if loc:
+                        g2[f"post_cert_{tag}"] = nm.local_point_certainties.numpy().copy()
+                        g2[f"post_ts_{tag}"] = nm.local_point_ts_update.numpy().copy()
+                    nm.point_certainties = gc0
+    cfg.layer_norm_on, cfg.weighted_first = False, True
+    restore_rw(nm, snap)
+    np.savez_compressed(os.path.join(OUT, "g2_query.npz"), **g2)
+
+    # ---------------- G3 mlp
+    g = torch.Generator().manual_seed(3)
+    f3 = torch.randn(1024, 11, generator=g)
+    with torch.no_grad():
+        sdf3 = dec.sdf(f3)
+        pre3 = dec.layers[0](f3)
+    np.savez_compressed(os.path.join(OUT, "g3_mlp.npz"), f=f3.numpy(), sdf=sdf3.numpy(), pre=pre3.numpy())
+
+    # ---------------- G4 analytic gradient (tracker usage: training_mode=False)
+    g4 = {"x": x2.numpy()}
+    for ln in (False, True):
+        cfg.layer_norm_on = ln
+        xg = x2.clone().requires_grad_(True)
+        f, _, w, nn, _ = nm.query_feature(xg, training_mode=False)
+        s = dec.sdf(f)
+        gr = ref.get_gradient(xg, s)
+        g4[f"sdf_ln{int(ln)}"] = s.detach().numpy()
+        g4[f"grad_ln{int(ln)}"] = gr.detach().numpy()
+        g4[f"nn_ln{int(ln)}"] = nn.to(torch.int32).numpy()
+    cfg.layer_norm_on = False
+    np.savez_compressed(os.path.join(OUT, "g4_grad.npz"), **g4)
+
+    # ---------------- G5 loss
+    g = torch.Generator().manual_seed(5)
+    pred = (torch.randn(4096, generator=g) * 0.2).requires_grad_(True)
+    label = torch.randn(4096, generator=g) * 0.3
+    wt = torch.rand(4096, generator=g) * 0.8 + 0.6
+    gv = (torch.randn(410, 3, generator=g) * 0.7).requires_grad_(True)
+    with torch.no_grad():
+        gv[:5] = 0.0  # zero-norm rows: subgradient 0
+    l_bce = ref.sdf_bce_loss(pred, label, 0.055, wt, True)
+    l_eik = ((gv.norm(2, dim=-1) - 1.0) ** 2).mean()
+    tot = l_bce + 0.5 * l_eik
+    tot.backward()
+    np.savez_compressed(
+        os.path.join(OUT, "g5_loss.npz"), pred=pred.detach().numpy(), label=label.numpy(), weight=wt.numpy(),
+        g=gv.detach().numpy(), l_bce=l_bce.item(), l_eik=l_eik.item(), total=tot.item(),
+        dpred=pred.grad.numpy(), dg=gv.grad.numpy(),
+    )
+
+    # ---------------- G6 mapping loop
+    import utils.mapper as ref_mapper_mod
+
+    class _DS:  # the four attributes `get_batch`/`mapping` read from the dataset
+        lose_track = False
+        stop_status = False
+        processed_frame = 2
+        gt_pose_provided = False
+
+    BS, ITERS = 2048, 3
+    base_state = dict(
+        geo=nm.geo_features.clone(), cert=nm.point_certainties.clone(), tsu=nm.point_ts_update.clone(),
+    )
+    sensor = torch.tensor([9.0, 3.0, 1.6])
+    g6_common = {}
+    for mode in ("numerical", "analytic"):
+        for frozen in (False, True):
+            for ln in ((False, True) if (mode == "numerical" and not frozen) else (False,)):
+                tag = f"{mode}_{'frozen' if frozen else 'train'}_ln{int(ln)}"
+                cfg6 = ref_config(ref, bs=BS, bs_new_sample=200)
+                cfg6.layer_norm_on = ln
+                if mode == "analytic":
+                    cfg6.numerical_grad = False
+                    cfg6.gradient_decimation = 1
+                # fresh map state
+                nm.config = cfg6
+                nm.geo_features = base_state["geo"].clone()
+                nm.point_certainties = base_state["cert"].clone()
+                nm.point_ts_update = base_state["tsu"].clone()
+                nm.reset_local_map(sensor, torch.eye(3), 2, reboot_map=True)
+                torch.manual_seed(42)
+                dec6 = ref.Decoder(cfg6, cfg6.geo_mlp_hidden_dim, cfg6.geo_mlp_level, 1)
+                if frozen:
+                    ref.freeze_model(dec6)
+                mp = ref.Mapper(cfg6, _DS(), nm, None, dec6)
+                mp.global_coord_pool = pool["coord"].clone()
+                mp.coord_pool = pool["coord"].clone()
+                mp.sdf_label_pool = pool["sdf_label"].clone()
+                mp.weight_pool = pool["weight"].clone()
+                mp.time_pool = pool["time"].clone()
+                mp.sem_label_pool = mp.color_pool = mp.normal_label_pool = None
+                mp.pool_sample_count = pool["coord"].shape[0]
+                mp.cur_sample_count = int((pool["time"] == 2).sum())
+                mp.used_poses = torch.eye(4, dtype=torch.float64)[None].repeat(3, 1, 1)
+                mp.adaptive_iter_offset = 0
+                new_start = mp.pool_sample_count - mp.cur_sample_count
+                gnew = torch.Generator().manual_seed(11)
+                mp.new_idx = new_start + torch.randperm(mp.cur_sample_count, generator=gnew)[:5000]
+
+                # record the reference's own random draws and batches
+                draws, batches = [], []
+                real_randint = torch.randint
+
+                def rec_randint(*a, **k):
+                    r = real_randint(*a, **k)
+                    draws.append(r.clone())
+                    return r
+
+                real_get_batch = mp.get_batch
+
+                def rec_get_batch(*a, **k):
+                    b = real_get_batch(*a, **k)
+                    batches.append(b)
+                    return b
+
+                mp.get_batch = rec_get_batch
+
+                # per-iteration capture: hook optimizer.step via the reference's setup_optimizer
+                per_iter = []
+                real_setup = ref_mapper_mod.setup_optimizer
+
+                def hooked_setup(*a, **k):
+                    opt = real_setup(*a, **k)
+                    real_step = opt.step
+
+                    def step(*sa, **sk):
+                        theta = nm.local_geo_features
+                        rec = {"grad_theta": theta.grad.detach().clone()}
+                        if not frozen:
+                            for nme, p in zip(("W1", "b1", "W2", "b2"), dec6.parameters()):
+                                rec["grad_" + nme] = p.grad.detach().clone()
+                        r = real_step(*sa, **sk)
+                        rec["theta"] = theta.detach().clone()
+                        rec["dec"] = [p.detach().clone() for p in dec6.parameters()]
+                        st_ = opt.state[theta]
+                        rec["adam_m_theta"] = st_["exp_avg"].clone()
+                        rec["adam_v_theta"] = st_["exp_avg_sq"].clone()
+                        rec["certainties"] = nm.local_point_certainties.clone()
+                        rec["ts_update"] = nm.local_point_ts_update.clone()
+                        per_iter.append(rec)
+                        return r
+
+                    opt.step = step
+                    return opt
+
+                losses = {"bce": [], "total": []}
+                real_bce = ref_mapper_mod.sdf_bce_loss
+                real_backward = torch.Tensor.backward
+
+                def rec_bce(*a, **k):
+                    v = real_bce(*a, **k)
+                    losses["bce"].append(float(v))
+                    return v
+
+                def rec_backward(self, *a, **k):
+                    losses["total"].append(float(self))
+                    return real_backward(self, *a, **k)
+
+                ref_mapper_mod.setup_optimizer = hooked_setup
+                ref_mapper_mod.sdf_bce_loss = rec_bce
+                torch.Tensor.backward = rec_backward
+                torch.randint = rec_randint
+                torch.manual_seed(1234)
+                try:
+                    mp.mapping(ITERS)
+                finally:
+                    torch.randint = real_randint
+                    torch.Tensor.backward = real_backward
+                    ref_mapper_mod.setup_optimizer = real_setup
+                    ref_mapper_mod.sdf_bce_loss = real_bce
+
+                assert len(per_iter) == ITERS and len(draws) == 2 * ITERS, (len(per_iter), len(draws))
+                index_seq = []
+                for it in range(ITERS):
+                    hist, pick = draws[2 * it], draws[2 * it + 1]
+                    index = torch.cat((hist, mp.new_idx[pick]), 0)
+                    assert torch.equal(pool["coord"][index], batches[it][0])
+                    index_seq.append(index)
+                out = {
+                    "index_seq": torch.stack(index_seq).to(torch.int32).numpy(),
+                    "draw_hist0": draws[0].numpy(), "draw_pick0": draws[1].numpy(),
+                    "new_idx": mp.new_idx.numpy(),
+                    "loss_bce": np.array(losses["bce"]), "loss_total": np.array(losses["total"]),
+                    "W1_init": None,
+                }
+                torch.manual_seed(42)
+                dec_init = ref.Decoder(cfg6, cfg6.geo_mlp_hidden_dim, cfg6.geo_mlp_level, 1)
+                out.pop("W1_init")
+                for nme, p in zip(("W1", "b1", "W2", "b2"), dec_init.parameters()):
+                    out["init_" + nme] = p.detach().numpy()
+                for it, rec in enumerate(per_iter):
+                    gt = rec["grad_theta"]
+                    rows = torch.nonzero(gt.abs().sum(1) > 0).flatten()
+                    out[f"it{it}_grad_theta_rows"] = rows.to(torch.int32).numpy()
+                    out[f"it{it}_grad_theta_vals"] = gt[rows].numpy()
+                    out[f"it{it}_theta"] = rec["theta"].numpy()
+                    if it == len(per_iter) - 1:
+                        out[f"it{it}_adam_m_theta"] = rec["adam_m_theta"].numpy()
+                        out[f"it{it}_adam_v_theta"] = rec["adam_v_theta"].numpy()
+                    out[f"it{it}_certainties"] = rec["certainties"].numpy()
+                    out[f"it{it}_ts_update"] = rec["ts_update"].numpy()
+                    for nme, t in zip(("W1", "b1", "W2", "b2"), rec["dec"]):
+                        out[f"it{it}_{nme}"] = t.numpy()
+                    if not frozen:
+                        for nme in ("W1", "b1", "W2", "b2"):
+                            out[f"it{it}_grad_{nme}"] = rec["grad_" + nme].numpy()
+                # after the loop the reference ran assign_local_to_global
+                chg = torch.nonzero((nm.geo_features != base_state["geo"]).any(dim=1)).flatten()
+                out["final_geo_rows"] = chg.to(torch.int32).numpy()  # rows that differ from the base map
+                out["final_geo_vals"] = nm.geo_features[chg].numpy().copy()
+                out["final_point_certainties"] = nm.point_certainties.numpy().copy()
+                out["final_point_ts_update"] = nm.point_ts_update.numpy().copy()
+                out["local_mask"] = nm.local_mask.numpy().copy()
+                np.savez_compressed(os.path.join(OUT, f"g6_loop_{tag}.npz"), **out)
+                print("G6", tag, "done")
+                g6_common = {"bs": BS, "iters": ITERS}
+    np.savez_compressed(
+        os.path.join(OUT, "pool.npz"),
+        coord=pool["coord"].numpy(), sdf_label=pool["sdf_label"].numpy(),
+        weight=pool["weight"].numpy(), time=pool["time"].numpy(),
+        base_geo_features=base_state["geo"].numpy(), base_point_certainties=base_state["cert"].numpy(),
+        base_point_ts_update=base_state["tsu"].numpy(), sensor=sensor.numpy(), **g6_common,
+    )
+    for fn in sorted(os.listdir(OUT)):
+        if fn.endswith(".npz"):
+            print(f"{fn:40s} {os.path.getsize(os.path.join(OUT, fn)) / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,163 @@
+"""Pin the CPU oracle (oracle/cpu_ref.py) against outputs of the reference itself (fixtures G1-G6,
+SURVEY.md section 8c).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import golden_io as gio
+from oracle import cpu_ref as O
+
+
+def close(a, b, tol=1e-6, what=""):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    err = np.abs(a.astype(np.float64) - np.asarray(b, dtype=np.float64)).max() if a.size else 0.0
+    assert err <= tol, f"{what}: max abs err {err:.3e} > {tol}"
+
+
+def test_search_neighborhood_table():
+    z = gio.load("state.npz")
+    dx, mv = O.search_neighborhood(2, 0.5, 0.4)
+    assert dx.shape == (81, 3)
+    assert np.array_equal(dx.numpy(), z["neighbor_dx"])
+    assert mv == float(gio.S(z["max_valid_dist2"]))
+
+
+@pytest.mark.parametrize("tf", [False, True])
+def test_g1_search(tf):
+    g = gio.load("g1_search.npz")
+    st = gio.map_state()
+    d2, idx = O.radius_neighborhood_search(st, gio.T(g["x"]), time_filtering=tf)
+    assert np.array_equal(idx.numpy().astype(np.int32), g[f"idx_tf{int(tf)}"])
+    assert np.array_equal(d2.numpy(), g[f"dist2_tf{int(tf)}"])  # bit-exact
+    # the fixture really contains invalid probes, collisions rejected by distance and time-filtered hits
+    assert (idx >= 0).any() and (idx < 0).any()
+    if tf:
+        assert (g["idx_tf0"] >= 0).sum() > (g["idx_tf1"] >= 0).sum()
+
+
+CASES = [(ln, wf, tm, loc) for ln in (0, 1) for wf in (1, 0) for tm in (1, 0) for loc in (1, 0) if loc or not (tm or ln)]
+
+
+@pytest.mark.parametrize("ln,wf,tm,loc", CASES)
+def test_g2_query(ln, wf, tm, loc):
+    g = gio.load("g2_query.npz")
+    st = gio.map_state(layer_norm_on=bool(ln), weighted_first=bool(wf))
+    tag = f"ln{ln}_wf{wf}_tm{tm}_loc{loc}"
+    x, ts = gio.T(g["x"]), gio.T(g["ts"])
+    f, w, nn, cert, _ = O.query_feature(st, x, ts if loc else None, training_mode=bool(tm), query_locally=bool(loc))
+    assert np.array_equal(nn.numpy().astype(np.int32), g["nn_" + tag])
+    close(f, g["f_" + tag], 1e-6, "features")
+    close(w, g["w_" + tag], 1e-6, "weights")
+    close(cert, g["cert_" + tag], 1e-5, "certainty")
+    if loc:
+        close(st.local_point_certainties, g["post_cert_" + tag], 1e-4, "post certainties")
+        assert np.array_equal(st.local_point_ts_update.numpy(), g["post_ts_" + tag])
+    assert (nn.numpy() == 0).any() and (nn.numpy() > 6).any()
+
+
+def test_g3_mlp():
+    g = gio.load("g3_mlp.npz")
+    dec = gio.decoder()
+    close(O.mlp_sdf(dec, gio.T(g["f"])), g["sdf"], 1e-7, "sdf")
+
+
+@pytest.mark.parametrize("ln", [0, 1])
+def test_g4_gradient_autograd_and_closed_form(ln):
+    g = gio.load("g4_grad.npz")
+    st = gio.map_state(layer_norm_on=bool(ln))
+    dec = gio.decoder()
+    x = gio.T(g["x"]).clone().requires_grad_(True)
+    f, _, nn, _, _ = O.query_feature(st, x, training_mode=False)[0:5]
+    s = O.mlp_sdf(dec, f)
+    gr = O.autograd_gradient(x, s)
+    close(s, g[f"sdf_ln{ln}"], 1e-6, "sdf")
+    close(gr, g[f"grad_ln{ln}"], 1e-5, "autograd gradient")
+    s2, g2, nn2 = O.closed_form_sdf_and_gradient(st, dec, gio.T(g["x"]))
+    close(s2, g[f"sdf_ln{ln}"], 1e-6, "closed-form sdf")
+    close(g2, g[f"grad_ln{ln}"], 2e-5, "closed-form gradient")
+    assert np.array_equal(nn2.numpy().astype(np.int32), g[f"nn_ln{ln}"])
+
+
+def test_g5_loss():
+    g = gio.load("g5_loss.npz")
+    pred = gio.T(g["pred"]).clone().requires_grad_(True)
+    gv = gio.T(g["g"]).clone().requires_grad_(True)
+    l_bce = O.sdf_bce_loss(pred, gio.T(g["label"]), 0.055, gio.T(g["weight"]), True)
+    l_eik = O.eikonal_loss(gv)
+    (l_bce + 0.5 * l_eik).backward()
+    close(l_bce, g["l_bce"], 1e-6)
+    close(l_eik, g["l_eik"], 1e-6)
+    close(pred.grad, g["dpred"], 1e-8)
+    close(gv.grad, g["dg"], 1e-8)
+
+
+def test_adam_matches_torch_optim():
+    torch.manual_seed(0)
+    p0 = torch.randn(50, 8)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=0.01, betas=(0.9, 0.99), eps=1e-15)
+    p = p0.clone()
+    s = O.AdamState(torch.zeros_like(p), torch.zeros_like(p))
+    for _ in range(4):
+        g = torch.randn(50, 8)
+        g[::3] = 0.0
+        p_ref.grad = g.clone()
+        opt.step()
+        O.adam_step(p, g, s)
+        assert torch.equal(p, p_ref.detach())
+
+
+G6 = [("numerical", False, 0), ("numerical", False, 1), ("numerical", True, 0), ("analytic", False, 0), ("analytic", True, 0)]
+
+
+@pytest.mark.parametrize("mode,frozen,ln", G6)
+def test_g6_mapping_loop(mode, frozen, ln):
+    tag = f"{mode}_{'frozen' if frozen else 'train'}_ln{ln}"
+    g = gio.load(f"g6_loop_{tag}.npz")
+    st = gio.map_state(layer_norm_on=bool(ln))
+    pool, praw = gio.sample_pool()
+    dec = gio.decoder(g, "init_")
+    lc = O.LoopConfig(numerical_grad=(mode == "numerical"), gradient_decimation=10 if mode == "numerical" else 1,
+                      train_decoder=not frozen)
+    index_seq = gio.T(g["index_seq"]).to(torch.int64)
+    # a1: the batch composition rule reproduces the reference's batch from its recorded draws
+    idx0 = torch.cat((gio.T(g["draw_hist0"]), gio.T(g["new_idx"])[gio.T(g["draw_pick0"])]))
+    assert torch.equal(idx0, index_seq[0])
+    recs = O.mapping_iters(st, dec, pool, index_seq, lc, record=True)
+    for it, r in enumerate(recs):
+        close(r["sdf_loss"], g["loss_bce"][it], 2e-6, f"it{it} bce")
+        close(r["loss"], g["loss_total"][it], 2e-6, f"it{it} total")
+        rows = g[f"it{it}_grad_theta_rows"].astype(np.int64)
+        gt = r["grad_theta"].numpy()
+        dense = np.zeros_like(gt)
+        dense[rows] = g[f"it{it}_grad_theta_vals"]
+        scale = max(np.abs(dense).max(), 1e-12)
+        assert np.abs(gt - dense).max() / scale < 1e-4, f"it{it} grad_theta"
+        # rows with exactly zero gradient in the reference are exactly zero here
+        untouched = np.ones(gt.shape[0], bool)
+        untouched[rows] = False
+        assert not gt[untouched].any()
+        if not frozen:
+            for n in ("W1", "b1", "W2", "b2"):
+                ref_g = g[f"it{it}_grad_{n}"]
+                sc = max(np.abs(ref_g).max(), 1e-12)
+                assert np.abs(r["grad_" + n].numpy() - ref_g).max() / sc < 1e-4, f"it{it} grad_{n}"
+        close(r["theta"], g[f"it{it}_theta"], 1e-4, f"it{it} theta")
+        for n, t in zip(("W1", "b1", "W2", "b2"), r["dec"]):
+            close(t, g[f"it{it}_{n}"], 1e-4, f"it{it} {n}")
+        close(r["certainties"], g[f"it{it}_certainties"], 1e-3, f"it{it} certainties")
+        assert np.array_equal(r["ts_update"].numpy(), g[f"it{it}_ts_update"])
+    last = len(recs) - 1
+    close(recs[last]["adam_m_theta"], g[f"it{last}_adam_m_theta"], 1e-6)
+    close(recs[last]["adam_v_theta"], g[f"it{last}_adam_v_theta"], 1e-6)
+    # a10: write-back
+    z = gio.load("state.npz")
+    st.geo_features = gio.T(praw["base_geo_features"]).clone()
+    st.point_certainties = gio.T(praw["base_point_certainties"]).clone()
+    tsu = gio.T(praw["base_point_ts_update"]).clone()
+    O.assign_local_to_global(st, gio.T(g["local_mask"]), tsu)
+    base = praw["base_geo_features"].copy()
+    base[g["final_geo_rows"].astype(np.int64)] = g["final_geo_vals"]
+    close(st.geo_features, base, 1e-4, "final geo features")
+    close(st.point_certainties, g["final_point_certainties"], 1e-3)
+    assert np.array_equal(tsu.numpy(), g["final_point_ts_update"])
