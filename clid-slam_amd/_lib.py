@@ -1,0 +1,123 @@
+"""ctypes binding of libclid_native.so (include/clid_native.h).
+
+The product path has NO fallback: if the library is missing or a call fails, a RuntimeError is
+raised.  Device pointers come from torch tensors (`.data_ptr()`), the stream from
+`torch.cuda.current_stream()`; no torch types cross the ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libclid_native.so")
+
+F, D, H, K = 8, 11, 64, 6
+MLP_PARAMS = H * D + H + H + 1  # 833
+GRAD_FEAT_OFFSET = 836
+
+_vp = C.c_void_p
+_i32 = C.c_int32
+_i64 = C.c_int64
+_f32 = C.c_float
+
+
+class MapView(C.Structure):
+    _fields_ = [
+        ("tab", _vp), ("pos4", _vp), ("feat", _vp), ("cert", _vp), ("ts_update", _vp), ("delta", _vp),
+        ("log2cap", _i32), ("M", _i32), ("P", _i32), ("buffer_size", _i32),
+        ("resolution", _f32), ("max_valid_dist2", _f32), ("layer_norm", _i32), ("reserved", _i32),
+    ]
+
+
+class TrainArgs(C.Structure):
+    _fields_ = [
+        ("pool_coord", _vp), ("pool_label", _vp), ("pool_ts", _vp), ("pool_weight", _vp), ("index", _vp),
+        ("bs", _i32), ("decimation", _i32), ("batch_offset", _i64),
+        ("fd_eps", _f32), ("inv_n_main", _f32), ("inv_n_eik", _f32), ("sigma", _f32), ("weight_e", _f32),
+        ("loss_weight_on", _i32), ("eikonal_mode", _i32), ("train_decoder", _i32),
+        ("W1", _vp), ("b1", _vp), ("W2", _vp), ("b2", _vp),
+        ("sdf_scale", _f32), ("pad0", _i32),
+        ("grad", _vp), ("ws", _vp), ("loss_out", _vp),
+    ]
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [
+        ("feat", _vp), ("grad", _vp), ("m", _vp), ("v", _vp),
+        ("W1", _vp), ("b1", _vp), ("W2", _vp), ("b2", _vp), ("m_mlp", _vp), ("v_mlp", _vp),
+        ("n_feat", _i64),
+        ("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32),
+        ("step", _i32), ("train_decoder", _i32), ("pad0", _i32),
+    ]
+
+
+_SIGS = {
+    "clid_abi_version": (C.c_int, []),
+    "clid_last_error": (C.c_char_p, []),
+    "clid_table_build": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _f32, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp, _vp]),
+    "clid_radius_search": (C.c_int, [C.POINTER(MapView), _vp, _i32, _vp, _vp, _vp]),
+    "clid_query_fwd": (C.c_int, [C.POINTER(MapView), _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clid_query_bwd": (C.c_int, [C.POINTER(MapView), _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "clid_mlp_sdf_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _vp]),
+    "clid_mlp_sdf_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "clid_sdf_grad_x": (C.c_int, [C.POINTER(MapView), _vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "clid_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _f32, _i32, _vp, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "clid_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _i32, _vp]),
+    "clid_train_workspace_floats": (_i64, [_i32, _i32, _i32]),
+    "clid_train_fwd_bwd": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), _vp]),
+    "clid_train_adam": (C.c_int, [C.POINTER(AdamArgs), _vp]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python clid-slam_amd/build.py` "
+            "(there is no CPU/PyTorch fallback for the HIP path)"
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.clid_abi_version() != 1:
+        raise RuntimeError("libclid_native.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().clid_last_error()
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t

@@ -1,0 +1,276 @@
+// Device-side building blocks shared by the gfx950 kernels.  Wave = 64 lanes; a QUERY GROUP is one
+// DPP row (16 lanes): 4 queries per wave.  Everything after the top-K selection is replicated across
+// the 16 lanes of a group except the 64 hidden units of the decoder (4 per lane).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/clid_native.h"
+
+#define CLID_G 16                 // lanes per query
+#define CLID_HPL (CLID_H / CLID_G)  // hidden units per lane = 4
+#define CLID_BLOCK 256
+#define CLID_QPB (CLID_BLOCK / CLID_G)  // queries per block per round = 16
+
+namespace clid {
+
+// ---- exact fp32 helpers (no FMA contraction where the reference's op order matters) -------------
+__device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float fsub(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+
+// ---- DPP row (16-lane) primitives ---------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+// row_ror:n == 0x120 + n : every lane of the row ends with the full reduction
+__device__ __forceinline__ float group_sum(float v) {
+  v += dpp_mov<0x128>(v);
+  v += dpp_mov<0x124>(v);
+  v += dpp_mov<0x122>(v);
+  v += dpp_mov<0x121>(v);
+  return v;
+}
+__device__ __forceinline__ float group_min(float v) {
+  v = fminf(v, dpp_mov<0x128>(v));
+  v = fminf(v, dpp_mov<0x124>(v));
+  v = fminf(v, dpp_mov<0x122>(v));
+  v = fminf(v, dpp_mov<0x121>(v));
+  return v;
+}
+__device__ __forceinline__ int group_sum_i(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false);
+  return v;
+}
+// sum over the 4 groups of a wave (lanes l, l^16, l^32, l^48)
+__device__ __forceinline__ float cross_group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  return cross_group_sum(group_sum(v));
+}
+
+// ---- voxel hashing (model/neural_points.py:984-999) ---------------------------------------------
+// cell = floor(x / res) with a TRUE fp32 divide; h = sum cell_c * prime_c in int64;
+// slot = h mod B taken non-negative (fmod + negative index wrap).
+__device__ __forceinline__ int base_slot(float x, float y, float z, float res, int B) {
+  const long long cx = (long long)floorf(fdiv(x, res));
+  const long long cy = (long long)floorf(fdiv(y, res));
+  const long long cz = (long long)floorf(fdiv(z, res));
+  long long h = cx * 73856093LL + cy * 19349669LL + cz * 83492791LL;
+  long long r = h % (long long)B;
+  if (r < 0) r += B;
+  return (int)r;
+}
+
+__device__ __forceinline__ unsigned tab_home(int slot, int log2cap) {
+  return ((unsigned)slot * 2654435761u) >> (32 - log2cap);
+}
+
+// open-addressing lookup in the compact table: {key, id}, key == -1 empty
+__device__ __forceinline__ int tab_lookup(const int2* __restrict__ tab, int log2cap, int slot) {
+  const unsigned mask = (1u << log2cap) - 1u;
+  unsigned pos = tab_home(slot, log2cap);
+  for (;;) {
+    const int2 e = tab[pos];
+    if (e.x == slot) return e.y;
+    if (e.x < 0) return -1;
+    pos = (pos + 1) & mask;
+  }
+}
+
+// ---- per-lane sorted candidate list + group top-K ------------------------------------------------
+struct Cand {
+  float d[CLID_K];
+  int j[CLID_K];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int s = 0; s < CLID_K; ++s) {
+      d[s] = __builtin_inff();
+      j[s] = -1;
+    }
+  }
+  __device__ __forceinline__ void insert(float nd, int nj) {
+#pragma unroll
+    for (int s = 0; s < CLID_K; ++s) {
+      const bool lt = nd < d[s];
+      const float td = lt ? d[s] : nd;
+      const int tj = lt ? j[s] : nj;
+      d[s] = lt ? nd : d[s];
+      j[s] = lt ? nj : j[s];
+      nd = td;
+      nj = tj;
+    }
+  }
+  __device__ __forceinline__ void pop() {
+#pragma unroll
+    for (int s = 0; s < CLID_K - 1; ++s) {
+      d[s] = d[s + 1];
+      j[s] = j[s + 1];
+    }
+    d[CLID_K - 1] = __builtin_inff();
+    j[CLID_K - 1] = -1;
+  }
+};
+
+struct TopK {  // replicated across the group
+  float d2[CLID_K];
+  int j[CLID_K];  // -1 invalid
+  int nn;         // valid probes over all P (np.py:600-602)
+};
+
+// Search the P probe cells of one query (x,y,z) with the 16 lanes of a group and select the K
+// nearest valid neighbours, ascending (np.py:971-1030 + 595-612).
+__device__ __forceinline__ void search_topk(const clid_map_view& mv, float x, float y, float z,
+                                            int lane16, int gbase, TopK& out) {
+  const int2* __restrict__ tab = reinterpret_cast<const int2*>(mv.tab);
+  const float4* __restrict__ pos4 = reinterpret_cast<const float4*>(mv.pos4);
+  const int B = mv.buffer_size;
+  const int r0 = base_slot(x, y, z, mv.resolution, B);
+  Cand c;
+  c.init();
+  int nvalid = 0;
+  for (int o0 = 0; o0 < mv.P; o0 += CLID_G * 2) {
+    // two probes per trip so their dependent loads overlap
+    int jj[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int o = o0 + u * CLID_G + lane16;
+      jj[u] = -1;
+      if (o < mv.P) {
+        int slot = r0 + mv.delta[o];
+        if (slot >= B) slot -= B;
+        jj[u] = tab_lookup(tab, mv.log2cap, slot);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (jj[u] >= 0) {
+        const float4 p = pos4[jj[u]];
+        const float ax = fsub(p.x, x), ay = fsub(p.y, y), az = fsub(p.z, z);
+        const float d2 = fadd(fadd(fmul(ax, ax), fmul(ay, ay)), fmul(az, az));
+        if (!(d2 > mv.max_valid_dist2)) {  // np.py:1016-1020
+          c.insert(d2, jj[u]);
+          ++nvalid;
+        }
+      }
+    }
+  }
+  out.nn = group_sum_i(nvalid);
+#pragma unroll
+  for (int k = 0; k < CLID_K; ++k) {
+    const float head = c.d[0];
+    const float m = group_min(head);
+    const bool mine = (head == m) && (c.j[0] >= 0);
+    const unsigned long long b = __ballot(mine);
+    const unsigned gb = (unsigned)(b >> gbase) & 0xFFFFu;
+    int owner = gb ? (__ffs(gb) - 1) : 0;
+    const int wj = __shfl(c.j[0], gbase + owner, 64);
+    out.d2[k] = gb ? m : 9e3f;  // np.py:606
+    out.j[k] = gb ? wj : -1;
+    if (gb && lane16 == owner) c.pop();
+  }
+}
+
+// IDW weights (np.py:688-706): w_k = valid_k/(d2_k+eps) normalised; all zero when no neighbour.
+__device__ __forceinline__ void idw_weights(const TopK& t, float (&w)[CLID_K], float (&omega)[CLID_K]) {
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < CLID_K; ++k) {
+    omega[k] = (t.j[k] >= 0) ? fdiv(1.0f, fadd(t.d2[k], 1e-15f)) : 0.f;
+    s = fadd(s, omega[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < CLID_K; ++k) w[k] = (t.j[k] >= 0) ? fdiv(omega[k], s) : 0.f;
+}
+
+__device__ __forceinline__ void load_feat(const float* __restrict__ feat, int j, float (&v)[CLID_F]) {
+  const float4* p = reinterpret_cast<const float4*>(feat + (size_t)j * CLID_F);
+  const float4 a = p[0], b = p[1];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// F.layer_norm over the F features, no affine, eps 1e-5, biased variance (np.py:632-633)
+__device__ __forceinline__ void layer_norm8(float (&v)[CLID_F], float& rstd) {
+  float mu = 0.f;
+#pragma unroll
+  for (int c = 0; c < CLID_F; ++c) mu += v[c];
+  mu *= (1.0f / CLID_F);
+  float var = 0.f;
+#pragma unroll
+  for (int c = 0; c < CLID_F; ++c) {
+    const float d = v[c] - mu;
+    var += d * d;
+  }
+  var *= (1.0f / CLID_F);
+  rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+  for (int c = 0; c < CLID_F; ++c) v[c] = (v[c] - mu) * rstd;
+}
+// dx = rstd * (dy - mean(dy) - xhat * mean(dy*xhat))
+__device__ __forceinline__ void layer_norm8_bwd(const float (&xhat)[CLID_F], float rstd, float (&dy)[CLID_F]) {
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < CLID_F; ++c) {
+    m1 += dy[c];
+    m2 += dy[c] * xhat[c];
+  }
+  m1 *= (1.0f / CLID_F);
+  m2 *= (1.0f / CLID_F);
+#pragma unroll
+  for (int c = 0; c < CLID_F; ++c) dy[c] = rstd * (dy[c] - m1 - xhat[c] * m2);
+}
+
+// ---- decoder weights staged in LDS ---------------------------------------------------------------
+// layout: W1 [H][D] | b1 [H] | W2 [H] | b2 [1]  (== the 833-float parameter/gradient vector)
+struct MlpLds {
+  float w[CLID_MLP_PARAMS + 3];
+};
+__device__ __forceinline__ void stage_mlp(MlpLds& s, const float* W1, const float* b1, const float* W2,
+                                          const float* b2) {
+  for (int i = threadIdx.x; i < CLID_H * CLID_D; i += blockDim.x) s.w[i] = W1[i];
+  for (int i = threadIdx.x; i < CLID_H; i += blockDim.x) {
+    s.w[CLID_H * CLID_D + i] = b1[i];
+    s.w[CLID_H * CLID_D + CLID_H + i] = W2[i];
+  }
+  if (threadIdx.x == 0) s.w[CLID_MLP_PARAMS - 1] = b2[0];
+  __syncthreads();
+}
+// lane16 owns hidden units h = lane16 + 16*u, u = 0..3
+__device__ __forceinline__ float mlp_forward(const MlpLds& s, const float (&f)[CLID_D], int lane16,
+                                             float scale, float (&pre)[CLID_HPL]) {
+  float part = 0.f;
+#pragma unroll
+  for (int u = 0; u < CLID_HPL; ++u) {
+    const int h = lane16 + CLID_G * u;
+    float a = s.w[CLID_H * CLID_D + h];
+#pragma unroll
+    for (int c = 0; c < CLID_D; ++c) a = fmaf(s.w[h * CLID_D + c], f[c], a);
+    pre[u] = a;
+    part = fmaf(s.w[CLID_H * CLID_D + CLID_H + h], fmaxf(a, 0.f), part);
+  }
+  const float tot = group_sum(part);
+  return scale * (tot + s.w[CLID_MLP_PARAMS - 1]);
+}
+
+}  // namespace clid
+
+// ---- host-side error plumbing (api.hip) -----------------------------------------------------------
+extern "C" void clid_set_error(const char* fmt, ...);
+#define CLID_CHECK_LAUNCH()                                              \
+  do {                                                                   \
+    hipError_t e__ = hipGetLastError();                                  \
+    if (e__ != hipSuccess) {                                             \
+      clid_set_error("%s:%d HIP error: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return CLID_E_HIP;                                                 \
+    }                                                                    \
+  } while (0)

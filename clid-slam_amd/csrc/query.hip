@@ -1,0 +1,350 @@
+// Neighbour search + feature interpolation kernels (NeuralPoints.radius_neighborhood_search,
+// NeuralPoints.query_feature and its autograd backward; model/neural_points.py:553-769, 971-1030)
+// and the fused inference kernel query -> Decoder.sdf -> analytic d sdf/d x
+// (utils/tools.py:298-311 as used by utils/error_state_iekf.py:209-227).
+#include "common.hpp"
+
+namespace clid {
+
+// ---- a2: raw probe results in neighbour-offset order ------------------------------------------------
+__global__ void k_radius_search(clid_map_view mv, const float* __restrict__ x, int N,
+                                float* __restrict__ dist2_out, int* __restrict__ idx_out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)N * mv.P) return;
+  const int n = (int)(t / mv.P), o = (int)(t % mv.P);
+  const float px = x[n * 3 + 0], py = x[n * 3 + 1], pz = x[n * 3 + 2];
+  int slot = base_slot(px, py, pz, mv.resolution, mv.buffer_size) + mv.delta[o];
+  if (slot >= mv.buffer_size) slot -= mv.buffer_size;
+  int j = tab_lookup(reinterpret_cast<const int2*>(mv.tab), mv.log2cap, slot);
+  float d2 = mv.max_valid_dist2;  // np.py:1013
+  if (j >= 0) {
+    const float4 p = reinterpret_cast<const float4*>(mv.pos4)[j];
+    const float ax = fsub(p.x, px), ay = fsub(p.y, py), az = fsub(p.z, pz);
+    d2 = fadd(fadd(fmul(ax, ax), fmul(ay, ay)), fmul(az, az));
+    if (d2 > mv.max_valid_dist2) j = -1;  // np.py:1016-1020 (dist2 keeps its value)
+  }
+  dist2_out[t] = d2;
+  idx_out[t] = j;
+}
+
+// ---- a3: query_feature forward ------------------------------------------------------------------------
+// One 16-lane group per query.  Writes f (weighted) or v_k (per neighbour), w, idx, nn, certainty.
+__global__ void __launch_bounds__(CLID_BLOCK)
+k_query_fwd(clid_map_view mv, const float* __restrict__ x, int N, int weighted_first,
+            float* __restrict__ feat_out, float* __restrict__ w_out, int* __restrict__ idx_out,
+            int* __restrict__ nn_out, float* __restrict__ cert_out) {
+  const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48;
+  const int q_raw = blockIdx.x * CLID_QPB + (threadIdx.x >> 4);
+  const bool live = q_raw < N;
+  const int q = live ? q_raw : (N - 1);
+  const float px = x[q * 3 + 0], py = x[q * 3 + 1], pz = x[q * 3 + 2];
+  TopK t;
+  search_topk(mv, px, py, pz, lane16, gbase, t);
+  float w[CLID_K], omega[CLID_K];
+  idw_weights(t, w, omega);
+  const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
+  float f[CLID_D];
+#pragma unroll
+  for (int c = 0; c < CLID_D; ++c) f[c] = 0.f;
+  float cert = 0.f;
+#pragma unroll
+  for (int k = 0; k < CLID_K; ++k) {
+    float v[CLID_D];
+#pragma unroll
+    for (int c = 0; c < CLID_D; ++c) v[c] = 0.f;
+    if (t.j[k] >= 0) {
+      float fe[CLID_F];
+      load_feat(mv.feat, t.j[k], fe);
+      if (mv.layer_norm) {
+        float rstd;
+        layer_norm8(fe, rstd);
+      }
+      const float4 p = pos4[t.j[k]];
+#pragma unroll
+      for (int c = 0; c < CLID_F; ++c) v[c] = fe[c];
+      v[CLID_F + 0] = fsub(px, p.x);
+      v[CLID_F + 1] = fsub(py, p.y);
+      v[CLID_F + 2] = fsub(pz, p.z);
+      cert = fadd(cert, fmul(mv.cert[t.j[k]], w[k]));
+    } else if (mv.layer_norm) {
+      // F.layer_norm of an all-zero row is all zero (np.py:632-633): nothing to do
+    }
+    if (weighted_first) {
+#pragma unroll
+      for (int c = 0; c < CLID_D; ++c) f[c] = fadd(f[c], fmul(v[c], w[k]));
+    } else if (live) {
+      // [N][K][D]: lane c writes component c
+      float mine = 0.f;
+#pragma unroll
+      for (int c = 0; c < CLID_D; ++c) mine = (lane16 == c) ? v[c] : mine;
+      if (lane16 < CLID_D) feat_out[((size_t)q * CLID_K + k) * CLID_D + lane16] = mine;
+    }
+  }
+  if (!live) return;
+  if (weighted_first) {
+    float mine = 0.f;
+#pragma unroll
+    for (int c = 0; c < CLID_D; ++c) mine = (lane16 == c) ? f[c] : mine;
+    if (lane16 < CLID_D) feat_out[(size_t)q * CLID_D + lane16] = mine;
+  }
+  {
+    float mw = 0.f;
+    int mj = -1;
+#pragma unroll
+    for (int k = 0; k < CLID_K; ++k) {
+      mw = (lane16 == k) ? w[k] : mw;
+      mj = (lane16 == k) ? t.j[k] : mj;
+    }
+    if (lane16 < CLID_K) {
+      w_out[(size_t)q * CLID_K + lane16] = mw;
+      idx_out[(size_t)q * CLID_K + lane16] = mj;
+    }
+  }
+  if (lane16 == 0) {
+    nn_out[q] = t.nn;
+    cert_out[q] = cert;
+  }
+}
+
+// training-mode side effects (np.py:708-733), run AFTER k_query_fwd so the certainties it returned
+// are the pre-update ones, as in the reference (gather at np.py:654 precedes scatter_add_ at :714).
+__global__ void k_query_side_effects(clid_map_view mv, const int* __restrict__ idx,
+                                     const float* __restrict__ w, const int* __restrict__ query_ts,
+                                     int NK) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= NK) return;
+  const int j = idx[t];
+  if (j < 0) return;
+  atomicAdd(&mv.cert[j], w[t]);
+  if (query_ts && mv.ts_update) atomicMax(&mv.ts_update[j], query_ts[t / CLID_K]);
+}
+
+// ---- autograd backward of query_feature ------------------------------------------------------------------
+// Per neighbour: ge_k = dL/d v_k (D values) and gs_k = dL/d w_k (scalar), then
+//   d theta[j_k] += LN^T ge_k[0:F];   d x = sum_k valid ge_k[F:F+3] + sum_k gs_k * dw_k/dx,
+//   dw_k/dx = w_k (abar - alpha_k), alpha_k = 2 r_k omega_k  
+__global__ void __launch_bounds__(CLID_BLOCK)
+k_query_bwd(clid_map_view mv, const float* __restrict__ x, const int* __restrict__ idx,
+            const float* __restrict__ w_in, int N, int weighted_first,
+            const float* __restrict__ g_feat, const float* __restrict__ g_w,
+            float* __restrict__ g_theta, float* __restrict__ g_x) {
+  const int lane16 = threadIdx.x & 15;
+  const int q = blockIdx.x * CLID_QPB + (threadIdx.x >> 4);
+  if (q >= N) return;  // whole groups exit together; no cross-group ops below
+  const float px = x[q * 3 + 0], py = x[q * 3 + 1], pz = x[q * 3 + 2];
+  const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
+  float gf[CLID_D];
+  if (weighted_first) {
+#pragma unroll
+    for (int c = 0; c < CLID_D; ++c) gf[c] = g_feat[(size_t)q * CLID_D + c];
+  }
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  float abx = 0.f, aby = 0.f, abz = 0.f;  // abar
+  float gs[CLID_K], wk[CLID_K], alx[CLID_K], aly[CLID_K], alz[CLID_K];
+  float wsum_valid = 0.f;
+#pragma unroll
+  for (int k = 0; k < CLID_K; ++k) {
+    const int j = idx[(size_t)q * CLID_K + k];
+    wk[k] = w_in[(size_t)q * CLID_K + k];
+    gs[k] = g_w ? g_w[(size_t)q * CLID_K + k] : 0.f;
+    alx[k] = aly[k] = alz[k] = 0.f;
+    if (j < 0) continue;
+    const float4 p = pos4[j];
+    const float rx = fsub(px, p.x), ry = fsub(py, p.y), rz = fsub(pz, p.z);
+    const float d2 = fadd(fadd(fmul(rx, rx), fmul(ry, ry)), fmul(rz, rz));
+    const float om = fdiv(1.0f, fadd(d2, 1e-15f));
+    alx[k] = 2.f * rx * om; aly[k] = 2.f * ry * om; alz[k] = 2.f * rz * om;
+    abx += wk[k] * alx[k]; aby += wk[k] * aly[k]; abz += wk[k] * alz[k];
+    float fe[CLID_F], rstd = 1.f;
+    const bool need_feat = weighted_first || mv.layer_norm;
+    if (need_feat) {
+      load_feat(mv.feat, j, fe);
+      if (mv.layer_norm) layer_norm8(fe, rstd);
+    }
+    float ge[CLID_D];
+    if (weighted_first) {
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < CLID_F; ++c) dot += gf[c] * fe[c];
+      dot += gf[CLID_F] * rx + gf[CLID_F + 1] * ry + gf[CLID_F + 2] * rz;
+      gs[k] += dot;
+#pragma unroll
+      for (int c = 0; c < CLID_D; ++c) ge[c] = wk[k] * gf[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < CLID_D; ++c) ge[c] = g_feat[((size_t)q * CLID_K + k) * CLID_D + c];
+    }
+    gx += ge[CLID_F]; gy += ge[CLID_F + 1]; gz += ge[CLID_F + 2];
+    if (g_theta) {
+      float dth[CLID_F];
+#pragma unroll
+      for (int c = 0; c < CLID_F; ++c) dth[c] = ge[c];
+      if (mv.layer_norm) layer_norm8_bwd(fe, rstd, dth);
+      float mine = 0.f;
+#pragma unroll
+      for (int c = 0; c < CLID_F; ++c) mine = (lane16 == c) ? dth[c] : mine;
+      if (lane16 < CLID_F) atomicAdd(&g_theta[(size_t)j * CLID_F + lane16], mine);
+    }
+    wsum_valid += wk[k];
+  }
+  (void)wsum_valid;
+  if (g_x && lane16 == 0) {
+#pragma unroll
+    for (int k = 0; k < CLID_K; ++k) {
+      const float c = gs[k] * wk[k];
+      gx += c * (abx - alx[k]); gy += c * (aby - aly[k]); gz += c * (abz - alz[k]);
+    }
+    g_x[q * 3 + 0] = gx; g_x[q * 3 + 1] = gy; g_x[q * 3 + 2] = gz;
+  }
+}
+
+// ---- fused inference: sdf + analytic gradient ------------------------------------------------------------
+__global__ void __launch_bounds__(CLID_BLOCK)
+k_sdf_grad_x(clid_map_view mv, const float* W1, const float* b1, const float* W2, const float* b2,
+             float scale, const float* __restrict__ x, int N, float* __restrict__ sdf_out,
+             float* __restrict__ grad_out, int* __restrict__ nn_out, float* __restrict__ cert_out) {
+  __shared__ MlpLds mlp;
+  stage_mlp(mlp, W1, b1, W2, b2);
+  const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48;
+  const int q_raw = blockIdx.x * CLID_QPB + (threadIdx.x >> 4);
+  const bool live = q_raw < N;
+  const int q = live ? q_raw : (N - 1);
+  const float px = x[q * 3 + 0], py = x[q * 3 + 1], pz = x[q * 3 + 2];
+  TopK t;
+  search_topk(mv, px, py, pz, lane16, gbase, t);
+  float w[CLID_K], omega[CLID_K];
+  idw_weights(t, w, omega);
+  const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
+  float f[CLID_D];
+#pragma unroll
+  for (int c = 0; c < CLID_D; ++c) f[c] = 0.f;
+  float fe[CLID_K][CLID_F];
+  float rx[CLID_K], ry[CLID_K], rz[CLID_K];
+  float cert = 0.f, wsum = 0.f;
+  float abx = 0.f, aby = 0.f, abz = 0.f;
+#pragma unroll
+  for (int k = 0; k < CLID_K; ++k) {
+    rx[k] = ry[k] = rz[k] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CLID_F; ++c) fe[k][c] = 0.f;
+    if (t.j[k] >= 0) {
+      load_feat(mv.feat, t.j[k], fe[k]);
+      if (mv.layer_norm) {
+        float rstd;
+        layer_norm8(fe[k], rstd);
+      }
+      const float4 p = pos4[t.j[k]];
+      rx[k] = fsub(px, p.x); ry[k] = fsub(py, p.y); rz[k] = fsub(pz, p.z);
+      cert = fadd(cert, fmul(mv.cert[t.j[k]], w[k]));
+      wsum += w[k];
+      abx += w[k] * 2.f * rx[k] * omega[k];
+      aby += w[k] * 2.f * ry[k] * omega[k];
+      abz += w[k] * 2.f * rz[k] * omega[k];
+    }
+#pragma unroll
+    for (int c = 0; c < CLID_F; ++c) f[c] = fadd(f[c], fmul(fe[k][c], w[k]));
+    f[CLID_F + 0] = fadd(f[CLID_F + 0], fmul(rx[k], w[k]));
+    f[CLID_F + 1] = fadd(f[CLID_F + 1], fmul(ry[k], w[k]));
+    f[CLID_F + 2] = fadd(f[CLID_F + 2], fmul(rz[k], w[k]));
+  }
+  float pre[CLID_HPL];
+  const float sdf = mlp_forward(mlp, f, lane16, scale, pre);
+  // u = scale * (W2 .* act) W1   (D values, replicated after the group reduction)
+  float u[CLID_D];
+#pragma unroll
+  for (int c = 0; c < CLID_D; ++c) {
+    float part = 0.f;
+#pragma unroll
+    for (int uu = 0; uu < CLID_HPL; ++uu) {
+      const int h = lane16 + CLID_G * uu;
+      const float a = pre[uu] > 0.f ? mlp.w[CLID_H * CLID_D + CLID_H + h] : 0.f;
+      part = fmaf(a, mlp.w[h * CLID_D + c], part);
+    }
+    u[c] = scale * group_sum(part);
+  }
+  // g = sum_k (u . v_k) dw_k/dx + (sum_k w_k) u[F:F+3]
+  float gx = wsum * u[CLID_F], gy = wsum * u[CLID_F + 1], gz = wsum * u[CLID_F + 2];
+#pragma unroll
+  for (int k = 0; k < CLID_K; ++k) {
+    float dot = u[CLID_F] * rx[k] + u[CLID_F + 1] * ry[k] + u[CLID_F + 2] * rz[k];
+#pragma unroll
+    for (int c = 0; c < CLID_F; ++c) dot += u[c] * fe[k][c];
+    const float cw = dot * w[k];
+    gx += cw * (abx - 2.f * rx[k] * omega[k]);
+    gy += cw * (aby - 2.f * ry[k] * omega[k]);
+    gz += cw * (abz - 2.f * rz[k] * omega[k]);
+  }
+  if (live && lane16 == 0) {
+    sdf_out[q] = sdf;
+    grad_out[q * 3 + 0] = gx; grad_out[q * 3 + 1] = gy; grad_out[q * 3 + 2] = gz;
+    if (nn_out) nn_out[q] = t.nn;
+    if (cert_out) cert_out[q] = cert;
+  }
+}
+
+}  // namespace clid
+
+static int check_view(const clid_map_view* mv, const char* who) {
+  if (!mv || !mv->tab || !mv->pos4 || !mv->delta || mv->P <= 0 || mv->log2cap < 4 ||
+      mv->buffer_size <= 0) {
+    clid_set_error("%s: incomplete map view", who);
+    return CLID_E_ARG;
+  }
+  return CLID_OK;
+}
+
+extern "C" int clid_radius_search(const clid_map_view* mv, const float* x, int32_t N, float* dist2_out,
+                                  int32_t* idx_out, void* stream) {
+  if (int e = check_view(mv, "clid_radius_search")) return e;
+  if (N <= 0) return CLID_OK;
+  const long long total = (long long)N * mv->P;
+  hipLaunchKernelGGL(clid::k_radius_search, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, *mv, x, N, dist2_out, idx_out);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+extern "C" int clid_query_fwd(const clid_map_view* mv, const float* x, const int32_t* query_ts, int32_t N,
+                              int32_t training_mode, int32_t weighted_first, float* feat_out, float* w_out,
+                              int32_t* idx_out, int32_t* nn_out, float* cert_out, void* stream) {
+  if (int e = check_view(mv, "clid_query_fwd")) return e;
+  if (!mv->feat || !mv->cert) {
+    clid_set_error("clid_query_fwd: view has no feature/certainty arrays");
+    return CLID_E_ARG;
+  }
+  if (N <= 0) return CLID_OK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(clid::k_query_fwd, dim3((N + CLID_QPB - 1) / CLID_QPB), dim3(CLID_BLOCK), 0, s, *mv, x,
+                     N, weighted_first, feat_out, w_out, idx_out, nn_out, cert_out);
+  CLID_CHECK_LAUNCH();
+  if (training_mode) {
+    const int NK = N * CLID_K;
+    hipLaunchKernelGGL(clid::k_query_side_effects, dim3((NK + 255) / 256), dim3(256), 0, s, *mv, idx_out,
+                       w_out, query_ts, NK);
+    CLID_CHECK_LAUNCH();
+  }
+  return CLID_OK;
+}
+
+extern "C" int clid_query_bwd(const clid_map_view* mv, const float* x, const int32_t* idx, const float* w,
+                              int32_t N, int32_t weighted_first, const float* g_feat, const float* g_w,
+                              float* g_theta, float* g_x_out, void* stream) {
+  if (int e = check_view(mv, "clid_query_bwd")) return e;
+  if (N <= 0) return CLID_OK;
+  hipLaunchKernelGGL(clid::k_query_bwd, dim3((N + CLID_QPB - 1) / CLID_QPB), dim3(CLID_BLOCK), 0,
+                     (hipStream_t)stream, *mv, x, idx, w, N, weighted_first, g_feat, g_w, g_theta, g_x_out);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+extern "C" int clid_sdf_grad_x(const clid_map_view* mv, const float* W1, const float* b1, const float* W2,
+                               const float* b2, float sdf_scale, const float* x, int32_t N, float* sdf_out,
+                               float* grad_out, int32_t* nn_out, float* cert_out, void* stream) {
+  if (int e = check_view(mv, "clid_sdf_grad_x")) return e;
+  if (N <= 0) return CLID_OK;
+  hipLaunchKernelGGL(clid::k_sdf_grad_x, dim3((N + CLID_QPB - 1) / CLID_QPB), dim3(CLID_BLOCK), 0,
+                     (hipStream_t)stream, *mv, W1, b1, W2, b2, sdf_scale, x, N, sdf_out, grad_out, nn_out,
+                     cert_out);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}

@@ -1,0 +1,71 @@
+// Compact probe table: the exact, cache-resident equivalent of `buffer_pt_index[hash]` ->
+// travel-distance filter -> `global2local` (model/neural_points.py:984-1009, 595-598).
+//
+// The reference probes a 5e7-slot int64 table (400 MB) 81 times per query; almost every probe
+// returns -1 or an id that is dropped again by the time filter / the local-window mapping.  Which
+// ids survive does not depend on the query, so they are resolved ONCE per map state here and stored
+// in an open-addressing table keyed by the *same slot number* the reference computes.  A probe
+// of slot s returns id j iff the reference's chain would have produced local id j for slot s, so
+// hash collisions of the big table (a foreign id returned and rejected by the distance test, a
+// point shadowed by a later insert) are reproduced exactly.
+#include "common.hpp"
+
+namespace clid {
+
+__global__ void k_table_build(const int64_t* __restrict__ ids, int n, const float* __restrict__ pts,
+                              const int64_t* __restrict__ big, int B, float res,
+                              const int* __restrict__ ts_create, const float* __restrict__ travel,
+                              int cur_ts, int time_filtering, float diff_travel, int2* tab,
+                              int log2cap, float4* pos4) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const long long gi = ids ? ids[j] : (long long)j;
+  const float x = pts[gi * 3 + 0], y = pts[gi * 3 + 1], z = pts[gi * 3 + 2];
+  pos4[j] = make_float4(x, y, z, 0.f);
+  const int slot = base_slot(x, y, z, res, B);
+  if (big[slot] != gi) return;  // shadowed by a later insert into the same slot: unreachable
+  if (time_filtering) {         // np.py:1003-1009
+    const float gap = fabsf(fsub(travel[cur_ts], travel[ts_create[gi]]));
+    if (!(gap < diff_travel)) return;
+  }
+  const unsigned mask = (1u << log2cap) - 1u;
+  unsigned pos = tab_home(slot, log2cap);
+  for (;;) {
+    const int old = atomicCAS(&tab[pos].x, -1, slot);
+    if (old == -1) {
+      tab[pos].y = j;
+      return;
+    }
+    pos = (pos + 1) & mask;
+  }
+}
+
+}  // namespace clid
+
+extern "C" int clid_table_build(const int64_t* ids, int32_t n, const float* neural_points,
+                                const int64_t* buffer_pt_index, int64_t buffer_size, float resolution,
+                                const int32_t* point_ts_create, const float* travel_dist,
+                                int32_t cur_ts, int32_t time_filtering, float diff_travel,
+                                int32_t* tab_out, int32_t log2cap, float* pos4_out, void* stream) {
+  if (n < 0 || log2cap < 4 || log2cap > 30 || buffer_size <= 0 || buffer_size >= (1LL << 30)) {
+    clid_set_error("clid_table_build: bad argument (n=%d log2cap=%d buffer_size=%lld)", n, log2cap,
+                   (long long)buffer_size);
+    return CLID_E_ARG;
+  }
+  if ((1LL << log2cap) < 2LL * n) {
+    clid_set_error("clid_table_build: table capacity 2^%d < 2*n (n=%d)", log2cap, n);
+    return CLID_E_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(tab_out, 0xFF, sizeof(int32_t) * 2 * ((size_t)1 << log2cap), s) != hipSuccess) {
+    clid_set_error("clid_table_build: memset failed");
+    return CLID_E_HIP;
+  }
+  if (n == 0) return CLID_OK;
+  hipLaunchKernelGGL(clid::k_table_build, dim3((n + 255) / 256), dim3(256), 0, s, ids, n, neural_points,
+                     buffer_pt_index, (int)buffer_size, resolution, point_ts_create, travel_dist, cur_ts,
+                     time_filtering, diff_travel, reinterpret_cast<int2*>(tab_out), log2cap,
+                     reinterpret_cast<float4*>(pos4_out));
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}

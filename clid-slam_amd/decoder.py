@@ -1,0 +1,116 @@
+"""`Decoder` with the reference's interface (model/decoder.py:12), HIP-backed `mlp` / `sdf`.
+
+Parameters stay inside child modules (`layers: ModuleList[nn.Linear]`, `lout: nn.Linear`) so that
+`freeze_model` (utils/tools.py:314-317), `state_dict()` and `vis_pin_map.py` keep working.  The
+compiled shape is the one every shipped config uses: one hidden layer 11 -> 64 -> 1, bias, ReLU.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class _MlpSdf(torch.autograd.Function):
+    """out[r] = scale * (W2 relu(W1 f_r + b1) + b2); clid_mlp_sdf_fwd / clid_mlp_sdf_bwd."""
+
+    @staticmethod
+    def forward(ctx, feat, W1, b1, W2, b2, scale):
+        lib = _lib.load()
+        f = _lib.require_cuda(feat.detach().reshape(-1, _lib.D).contiguous(), "features", torch.float32)
+        ps = [_lib.require_cuda(p.detach(), n, torch.float32) for p, n in ((W1, "W1"), (b1, "b1"), (W2, "W2"), (b2, "b2"))]
+        out = torch.empty((f.shape[0],), device=f.device, dtype=torch.float32)
+        _lib.check(
+            lib.clid_mlp_sdf_fwd(*[_lib.ptr(p) for p in ps], float(scale), _lib.ptr(f), f.shape[0], _lib.ptr(out),
+                                 _lib.stream()),
+            "clid_mlp_sdf_fwd",
+        )
+        ctx.scale, ctx.in_shape = float(scale), feat.shape
+        ctx.save_for_backward(f, *ps)
+        return out.reshape(feat.shape[:-1])
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_out):
+        lib = _lib.load()
+        f, W1, b1, W2, b2 = ctx.saved_tensors
+        g = g_out.reshape(-1).contiguous().to(torch.float32)
+        need_f = ctx.needs_input_grad[0]
+        need_p = any(ctx.needs_input_grad[1:5])
+        g_f = torch.empty_like(f) if need_f else None
+        g_mlp = torch.zeros(_lib.MLP_PARAMS, device=f.device, dtype=torch.float32) if need_p else None
+        _lib.check(
+            lib.clid_mlp_sdf_bwd(_lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2), ctx.scale, _lib.ptr(f),
+                                 _lib.ptr(g), f.shape[0], _lib.ptr(g_f), _lib.ptr(g_mlp), _lib.stream()),
+            "clid_mlp_sdf_bwd",
+        )
+        gW1 = gb1 = gW2 = gb2 = None
+        if need_p:
+            H, D = _lib.H, _lib.D
+            gW1 = g_mlp[: H * D].view(H, D)
+            gb1 = g_mlp[H * D : H * D + H]
+            gW2 = g_mlp[H * D + H : H * D + 2 * H].view(1, H)
+            gb2 = g_mlp[H * D + 2 * H :]
+        return (g_f.view(ctx.in_shape) if need_f else None), gW1, gb1, gW2, gb2, None
+
+
+class Decoder(nn.Module):
+    def __init__(self, config, hidden_dim, hidden_level, out_dim, is_time_conditioned=False):
+        super().__init__()
+        self.out_dim = out_dim
+        self.use_leaky_relu = config.mlp_leaky_relu
+        bias_on = config.mlp_bias_on
+        if getattr(config, "use_gaussian_pe", False):
+            position_dim = config.pos_input_dim + 2 * config.pos_encoding_band
+        else:
+            position_dim = config.pos_input_dim * (2 * config.pos_encoding_band + 1)
+        input_dim = config.feature_dim + position_dim
+        if is_time_conditioned:
+            raise NotImplementedError("time-conditioned decoder is dead code in the reference (model/decoder.py:38)")
+        layers = []
+        for i in range(hidden_level):
+            layers.append(nn.Linear(input_dim if i == 0 else hidden_dim, hidden_dim, bias_on))
+        self.layers = nn.ModuleList(layers)
+        self.lout = nn.Linear(hidden_dim, out_dim, bias_on)
+        self.sdf_scale = 1.0
+        if config.main_loss_type == "bce":
+            self.sdf_scale = config.logistic_gaussian_ratio * config.sigma_sigmoid_m
+        self._native_shape = (
+            hidden_level == 1 and hidden_dim == _lib.H and out_dim == 1 and input_dim == _lib.D and bias_on
+            and not self.use_leaky_relu
+        )
+        self.to(config.device)
+
+    def flat_params(self):
+        """(W1 [64,11], b1 [64], W2 [1,64], b2 [1]) as the kernels expect them."""
+        self._require_native()
+        return self.layers[0].weight, self.layers[0].bias, self.lout.weight, self.lout.bias
+
+    def _require_native(self):
+        if not self._native_shape:
+            raise NotImplementedError(
+                "libclid_native is compiled for the geometry decoder of the shipped configs "
+                "(1 hidden layer, 11 -> 64 -> 1, bias, ReLU); semantic/colour heads are outside the hot-path scope"
+            )
+
+    def mlp(self, features):
+        """model/decoder.py:58-76: [..., 11] -> [..., 1]."""
+        W1, b1, W2, b2 = self.flat_params()
+        return _MlpSdf.apply(features, W1, b1, W2, b2, 1.0).unsqueeze(-1)
+
+    def sdf(self, features):
+        """model/decoder.py:80-82: mlp(features).squeeze(1) * sdf_scale."""
+        W1, b1, W2, b2 = self.flat_params()
+        out = _MlpSdf.apply(features, W1, b1, W2, b2, float(self.sdf_scale))
+        # the reference squeezes dim 1 of [N,1] ([N,K,1] keeps its last dim when weighted_first is off)
+        return out if features.dim() == 2 else out.unsqueeze(-1)
+
+    def occupancy(self, features):
+        return torch.sigmoid(self.sdf(features) / -self.sdf_scale)
+
+    def sem_label_prob(self, features):
+        raise NotImplementedError("semantic head is outside the hot-path scope (semantic_on is off in all shipped configs)")
+
+    def regress_color(self, features):
+        raise NotImplementedError("colour head is outside the hot-path scope (color_on is off in all shipped configs)")

@@ -1,0 +1,279 @@
+"""`Mapper` with the reference's interface (utils/mapper.py:35): the online SDF training loop.
+
+`mapping(iter_count)` (utils/mapper.py:620-862) is the hot loop.  Here each iteration is the fused
+HIP sequence of csrc/train.hip (forward over batch + finite-difference points, loss, backward,
+Adam) driven through the C ABI; nothing in it runs in PyTorch autograd, and it raises if the HIP
+library or the GPU is missing.  `get_batch`, `sdf` and `get_numerical_gradient` keep the
+reference's signatures for callers that use the un-fused sequence.
+
+Multi-GPU (new; the reference is single-GPU): with `torch.distributed` initialised, `config.bs` is
+the GLOBAL batch.  Every rank draws the same index sequence (same seed), trains on its contiguous
+slice, and the fused gradient buffer [decoder | features] is all-reduced (RCCL, SUM) before the
+identical Adam step on every replica; certainty increments (SUM) and update stamps (MAX) are merged
+once per `mapping()` call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _dist():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist
+    return None
+
+
+class Mapper:
+    def __init__(self, config, dataset, neural_points, local_point_cloud_map, geo_mlp, sem_mlp=None, color_mlp=None):
+        self.config = config
+        self.silence = config.silence
+        self.dataset = dataset
+        self.neural_points = neural_points
+        self.local_point_cloud_map = local_point_cloud_map
+        self.geo_mlp = geo_mlp
+        self.sem_mlp = sem_mlp
+        self.color_mlp = color_mlp
+        self.device = config.device
+        self.dtype = config.dtype
+        self.used_poses = None
+        # utils/mapper.py:57-69: analytic gradient only when the numerical one is off
+        self.require_gradient = bool(
+            config.ekional_loss_on or getattr(config, "proj_correction_on", False) or getattr(config, "consistency_loss_on", False)
+        )
+        if config.numerical_grad and not getattr(config, "proj_correction_on", False) and not getattr(config, "consistency_loss_on", False):
+            self.require_gradient = False
+        self.total_iter: int = 0
+        self.sdf_scale = config.logistic_gaussian_ratio * config.sigma_sigmoid_m
+        self.ray_sample_count = 1 + config.surface_sample_n + config.free_behind_n + config.free_front_n
+        self.new_idx = None
+        self.ba_done_flag = False
+        self.adaptive_iter_offset = 0
+        dev, dt = self.device, self.dtype
+        # data pool (utils/mapper.py:84-97)
+        self.coord_pool = torch.empty((0, 3), device=dev, dtype=dt)
+        self.global_coord_pool = torch.empty((0, 3), device=dev, dtype=dt)
+        self.sdf_label_pool = torch.empty((0), device=dev, dtype=dt)
+        self.color_pool = None
+        self.sem_label_pool = None
+        self.normal_label_pool = None
+        self.weight_pool = torch.empty((0), device=dev, dtype=dt)
+        self.time_pool = torch.empty((0), device=dev, dtype=torch.int)
+        self.pool_sample_count = 0
+        self.cur_sample_count = 0
+        # fused-loop state
+        self.last_losses = None  # [iters,4] device tensor: total, bce, eikonal, -
+        self._ws = None
+        self._gen = None
+        self._seed = int(getattr(config, "seed", 42))
+
+    # ------------------------------------------------------------------ a1
+    def _draw_index(self, iters: int, bs: int) -> torch.Tensor:
+        """[iters, bs] int64 batch indices composed as utils/mapper.py:473-500 (device RNG)."""
+        dev = self.global_coord_pool.device
+        if self._gen is None or self._gen.device != dev:
+            self._gen = torch.Generator(device=dev)
+            self._gen.manual_seed(self._seed)
+        use_new = (
+            self.config.bs_new_sample > 0 and self.new_idx is not None and self.new_idx.shape[0] > 0
+            and not getattr(self.dataset, "lose_track", False) and not getattr(self.dataset, "stop_status", False)
+        )
+        if use_new:
+            bs_new = min(self.new_idx.shape[0], self.config.bs_new_sample)
+            hist = torch.randint(0, self.pool_sample_count, (iters, bs - bs_new), device=dev, generator=self._gen)
+            pick = torch.randint(0, self.new_idx.shape[0], (iters, bs_new), device=dev, generator=self._gen)
+            return torch.cat((hist, self.new_idx[pick]), dim=1).contiguous()
+        return torch.randint(0, self.pool_sample_count, (iters, bs), device=dev, generator=self._gen)
+
+    def get_batch(self, global_coord=False):
+        """utils/mapper.py:473-523: 7-tuple (coord, sdf_label, ts, normal, sem, color, weight)."""
+        index = self._draw_index(1, self.config.bs)[0]
+        coord = self.global_coord_pool[index, :] if global_coord else self.coord_pool[index, :]
+        sem = self.sem_label_pool[index] if self.sem_label_pool is not None else None
+        col = self.color_pool[index] if self.color_pool is not None else None
+        nrm = self.normal_label_pool[index, :] if self.normal_label_pool is not None else None
+        return coord, self.sdf_label_pool[index], self.time_pool[index], nrm, sem, col, self.weight_pool[index]
+
+    # ------------------------------------------------------------------ a11
+    def _check_fused_config(self):
+        c = self.config
+        bad = []
+        if getattr(c, "semantic_on", False):
+            bad.append("semantic_on")
+        if getattr(c, "color_on", False):
+            bad.append("color_on")
+        if getattr(c, "consistency_loss_on", False):
+            bad.append("consistency_loss_on")
+        if getattr(c, "proj_correction_on", False):
+            bad.append("proj_correction_on")
+        if c.main_loss_type != "bce":
+            bad.append(f"main_loss_type={c.main_loss_type}")
+        if not c.weighted_first:
+            bad.append("weighted_first=False")
+        if self.ba_done_flag:
+            bad.append("ba_done_flag")
+        if c.ekional_loss_on and getattr(c, "ekional_add_to", "all") != "all":
+            bad.append(f"ekional_add_to={c.ekional_add_to}")
+        if not getattr(c, "opt_adam", True):
+            bad.append("opt_adam=False")
+        if bad:
+            raise NotImplementedError("fused mapping loop: unsupported config " + ", ".join(bad) +
+                                      " (none of the shipped configs enables these)")
+
+    def mapping(self, iter_count, index_seq: torch.Tensor = None):
+        """Run `iter_count` (+ adaptive offset) training iterations on the local map
+        (utils/mapper.py:620-862).  `index_seq` [iters, bs] optionally teacher-forces the batches."""
+        lib = _lib.load()
+        self._check_fused_config()
+        cfg, nm = self.config, self.neural_points
+        iter_count = max(1, iter_count + self.adaptive_iter_offset)
+        dist = _dist()
+        world = dist.get_world_size() if dist else 1
+        rank = dist.get_rank() if dist else 0
+        bs_global = int(cfg.bs)
+        if bs_global % world != 0:
+            raise ValueError(f"batch size {bs_global} must be divisible by the world size {world}")
+        bs_local = bs_global // world
+        if index_seq is None:
+            index_seq = self._draw_index(iter_count, bs_global)
+        else:
+            iter_count = index_seq.shape[0]
+        index_seq = _lib.require_cuda(index_seq.to(torch.int64).contiguous(), "index_seq", torch.int64)
+        batch_offset = rank * bs_local
+
+        theta = nm.local_geo_features
+        _lib.require_cuda(theta.data, "local_geo_features", torch.float32)
+        dev = theta.device
+        W1, b1, W2, b2 = self.geo_mlp.flat_params()
+        # freeze_model flips requires_grad on the decoder's children (utils/tools.py:314-317)
+        train_decoder = all(p.requires_grad for p in (W1, b1, W2, b2))
+        eik_mode = 0
+        if cfg.ekional_loss_on and cfg.weight_e > 0:
+            eik_mode = 1 if cfg.numerical_grad else 2
+        decim = int(cfg.gradient_decimation) if eik_mode == 1 else 1
+        n_eik_global = (bs_global + decim - 1) // decim
+
+        n_feat = theta.numel()
+        grad = torch.zeros(_lib.GRAD_FEAT_OFFSET + n_feat, device=dev, dtype=torch.float32)
+        m = torch.zeros(n_feat, device=dev, dtype=torch.float32)
+        v = torch.zeros(n_feat, device=dev, dtype=torch.float32)
+        m_mlp = torch.zeros(_lib.MLP_PARAMS, device=dev, dtype=torch.float32)
+        v_mlp = torch.zeros(_lib.MLP_PARAMS, device=dev, dtype=torch.float32)
+        losses = torch.zeros((iter_count, 4), device=dev, dtype=torch.float32)
+        need = int(lib.clid_train_workspace_floats(bs_local, decim, eik_mode))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, device=dev, dtype=torch.float32)
+        cert0 = nm.local_point_certainties.clone() if dist else None
+
+        view, keep = nm._map_view(True)
+        pool_coord = _lib.require_cuda(self.global_coord_pool, "global_coord_pool", torch.float32)
+        pool_label = _lib.require_cuda(self.sdf_label_pool, "sdf_label_pool", torch.float32)
+        pool_ts = _lib.require_cuda(self.time_pool, "time_pool", torch.int32)
+        pool_w = _lib.require_cuda(self.weight_pool, "weight_pool", torch.float32)
+
+        ta = _lib.TrainArgs()
+        ta.pool_coord, ta.pool_label, ta.pool_ts, ta.pool_weight = (
+            pool_coord.data_ptr(), pool_label.data_ptr(), pool_ts.data_ptr(), pool_w.data_ptr())
+        ta.bs, ta.decimation, ta.batch_offset = bs_local, decim, batch_offset
+        ta.fd_eps = float(cfg.voxel_size_m * cfg.num_grad_step_ratio)
+        ta.inv_n_main, ta.inv_n_eik = 1.0 / bs_global, 1.0 / n_eik_global
+        ta.sigma, ta.weight_e = float(self.sdf_scale), float(cfg.weight_e)
+        ta.loss_weight_on, ta.eikonal_mode, ta.train_decoder = int(bool(cfg.loss_weight_on)), eik_mode, int(train_decoder)
+        ta.W1, ta.b1, ta.W2, ta.b2 = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr()
+        ta.sdf_scale = float(self.geo_mlp.sdf_scale)
+        ta.grad, ta.ws = grad.data_ptr(), self._ws.data_ptr()
+
+        aa = _lib.AdamArgs()
+        aa.feat, aa.grad, aa.m, aa.v = theta.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr()
+        aa.W1, aa.b1, aa.W2, aa.b2 = ta.W1, ta.b1, ta.W2, ta.b2
+        aa.m_mlp, aa.v_mlp = m_mlp.data_ptr(), v_mlp.data_ptr()
+        aa.n_feat = n_feat
+        aa.lr, aa.beta1, aa.beta2, aa.eps = float(cfg.lr), 0.9, 0.99, float(cfg.adam_eps)
+        aa.weight_decay = float(cfg.weight_decay)
+        aa.train_decoder = int(train_decoder)
+
+        stream = _lib.stream()
+        idx_base, row_bytes = index_seq.data_ptr(), bs_global * 8
+        loss_base = losses.data_ptr()
+        for it in range(iter_count):
+            ta.index = idx_base + it * row_bytes + batch_offset * 8
+            ta.loss_out = loss_base + it * 16
+            _lib.check(lib.clid_train_fwd_bwd(C.byref(view), C.byref(ta), stream), "clid_train_fwd_bwd")
+            if dist:
+                dist.all_reduce(grad)
+            aa.step = it + 1
+            _lib.check(lib.clid_train_adam(C.byref(aa), stream), "clid_train_adam")
+        self.total_iter += iter_count
+        if dist:
+            # merge the replicas' side effects once per call (not read inside the loop's loss)
+            inc = nm.local_point_certainties - cert0
+            dist.all_reduce(inc)
+            nm.local_point_certainties.copy_(cert0 + inc)
+            dist.all_reduce(nm.local_point_ts_update, op=dist.ReduceOp.MAX)
+            dist.all_reduce(losses)
+        self.last_losses = losses
+        self._keep = (keep, index_seq, grad, m, v, m_mlp, v_mlp)
+        nm.assign_local_to_global()
+
+    # ------------------------------------------------------------------ a5 / a6
+    def sdf(self, x, get_std=False):
+        """utils/mapper.py:968-982: default-argument query (training_mode=True) + decoder."""
+        geo_feature, _, weight_knn, _, _ = self.neural_points.query_feature(x)
+        sdf_pred = self.geo_mlp.sdf(geo_feature)
+        sdf_std = None
+        if not self.config.weighted_first:
+            sdf_pred_mean = torch.sum(sdf_pred * weight_knn, dim=1)
+            if get_std:
+                sdf_var = torch.sum(weight_knn * (sdf_pred - sdf_pred_mean.unsqueeze(-1)) ** 2, dim=1)
+                sdf_std = torch.sqrt(sdf_var).squeeze(1)
+            sdf_pred = sdf_pred_mean.squeeze(1)
+        return sdf_pred, sdf_std
+
+    def get_numerical_gradient(self, x, sdf_x=None, eps=0.02, two_side=True):
+        """utils/mapper.py:985-1034: central (or forward) differences through ONE `sdf` call."""
+        n = x.shape[0]
+        shifts = []
+        for a in range(3):
+            e = torch.zeros(3, dtype=x.dtype, device=x.device)
+            e[a] = eps
+            shifts.append(e)
+        if two_side:
+            pts = torch.cat([x + s * sg for s in shifts for sg in (1.0, -1.0)], dim=0)
+            s = self.sdf(pts)[0].unsqueeze(-1)
+            cols = [(s[2 * a * n:(2 * a + 1) * n] - s[(2 * a + 1) * n:(2 * a + 2) * n]) / (2 * eps) for a in range(3)]
+        else:
+            pts = torch.cat([x + s for s in shifts], dim=0)
+            s = self.sdf(pts)[0].unsqueeze(-1)
+            base = sdf_x.unsqueeze(-1)
+            cols = [(s[a * n:(a + 1) * n] - base) / eps for a in range(3)]
+        return torch.cat(cols, dim=1)
+
+    # ------------------------------------------------------------------ pool helpers / out of scope
+    def set_pool(self, global_coord, sdf_label, weight, time, new_idx=None):
+        """Fill the training pool directly (what `process_frame` does after sampling,
+        utils/mapper.py:297-333), for callers that generate samples themselves."""
+        dev = self.device
+        self.global_coord_pool = global_coord.to(dev, torch.float32).contiguous()
+        self.coord_pool = self.global_coord_pool
+        self.sdf_label_pool = sdf_label.to(dev, torch.float32).contiguous()
+        self.weight_pool = weight.to(dev, torch.float32).contiguous()
+        self.time_pool = time.to(dev, torch.int32).contiguous()
+        self.pool_sample_count = self.global_coord_pool.shape[0]
+        self.new_idx = None if new_idx is None else new_idx.to(dev, torch.int64).contiguous()
+
+    def free_pool(self):
+        self.coord_pool = self.global_coord_pool = self.weight_pool = None
+        self.sdf_label_pool = self.color_pool = self.sem_label_pool = self.normal_label_pool = None
+        self.time_pool = None
+
+    def process_frame(self, *a, **k):
+        raise NotImplementedError("process_frame (sampling + pool maintenance, utils/mapper.py:159-470) is a 'next' row "
+                                  "(SURVEY.md section 8f N2); fill the pool with set_pool()")
+
+    def bundle_adjustment(self, *a, **k):
+        raise NotImplementedError("bundle_adjustment is disabled in all shipped configs (ba_freq_frame=0) and out of scope")

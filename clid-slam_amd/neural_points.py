@@ -1,0 +1,441 @@
+"""`NeuralPoints` with the reference's interface (model/neural_points.py:27), HIP-backed hot methods.
+
+Same constructor, public tensor attributes (names/dtypes, so the object pickles like the
+reference's, utils/tools.py:347-367) and method signatures.  The per-iteration hot methods
+(`query_feature` :553-769, `radius_neighborhood_search` :971-1030, `query_certainty` :1032-1051)
+run hand-written gfx950 kernels through libclid_native.so and FAIL LOUDLY when it is missing or the
+tensors are not on the GPU -- there is no PyTorch fallback.  Once-per-frame map maintenance
+(`update` :324-437, `reset_local_map` :439-536, `assign_local_to_global` :538-549) is plain torch
+host logic, restated here so the object is self-contained.
+
+Device mirror: the 81-probe search does not walk the reference's 5e7-slot int64 table.  A compact
+open-addressing table keyed by the SAME slot numbers is built once per (map, local window,
+time-filter) state by `clid_table_build` (csrc/table.hip) and cached; see DESIGN.md.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .tools import voxel_down_sample_torch
+
+PRIMES = (73856093, 19349669, 83492791)  # model/neural_points.py:79-81
+
+
+class _QueryFeature(torch.autograd.Function):
+    """autograd node for `query_feature`: forward = clid_query_fwd, backward = clid_query_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, theta, owner, query_ts, training_mode, query_locally, weighted_first):
+        lib = _lib.load()
+        xc = _lib.require_cuda(x.detach().contiguous(), "query_points", torch.float32)
+        n = xc.shape[0]
+        dev = xc.device
+        view, keep = owner._map_view(query_locally)
+        ts32 = None
+        if query_ts is not None:
+            ts32 = query_ts.detach().to(torch.int32).contiguous()
+        shape = (n, _lib.D) if weighted_first else (n, _lib.K, _lib.D)
+        feat = torch.empty(shape, device=dev, dtype=torch.float32)
+        w = torch.empty((n, _lib.K), device=dev, dtype=torch.float32)
+        idx = torch.empty((n, _lib.K), device=dev, dtype=torch.int32)
+        nn_cnt = torch.empty((n,), device=dev, dtype=torch.int32)
+        cert = torch.empty((n,), device=dev, dtype=torch.float32)
+        _lib.check(
+            lib.clid_query_fwd(C.byref(view), _lib.ptr(xc), _lib.ptr(ts32), n, int(training_mode),
+                               int(weighted_first), _lib.ptr(feat), _lib.ptr(w), _lib.ptr(idx), _lib.ptr(nn_cnt),
+                               _lib.ptr(cert), _lib.stream()),
+            "clid_query_fwd",
+        )
+        ctx.owner, ctx.query_locally, ctx.weighted_first = owner, query_locally, weighted_first
+        ctx.theta_shape = theta.shape
+        ctx.save_for_backward(xc, idx, w)
+        nn64 = nn_cnt.to(torch.int64)
+        ctx.mark_non_differentiable(nn64, cert)
+        return feat, w.unsqueeze(-1), nn64, cert
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_feat, g_w, _g_nn, _g_cert):
+        lib = _lib.load()
+        xc, idx, w = ctx.saved_tensors
+        n = xc.shape[0]
+        view, keep = ctx.owner._map_view(ctx.query_locally)
+        need_x, need_theta = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_x = torch.empty_like(xc) if need_x else None
+        g_theta = torch.zeros(ctx.theta_shape, device=xc.device, dtype=torch.float32) if need_theta else None
+        gf = g_feat.contiguous() if g_feat is not None else torch.zeros(
+            (n, _lib.D) if ctx.weighted_first else (n, _lib.K, _lib.D), device=xc.device)
+        gw = g_w.reshape(n, _lib.K).contiguous() if g_w is not None else None
+        _lib.check(
+            lib.clid_query_bwd(C.byref(view), _lib.ptr(xc), _lib.ptr(idx), _lib.ptr(w), n, int(ctx.weighted_first),
+                               _lib.ptr(gf), _lib.ptr(gw), _lib.ptr(g_theta), _lib.ptr(g_x), _lib.stream()),
+            "clid_query_bwd",
+        )
+        return g_x, g_theta, None, None, None, None, None
+
+
+class NeuralPoints(nn.Module):
+    def __init__(self, config) -> None:
+        super().__init__()
+        self.config = config
+        self.silence = config.silence
+        self.geo_feature_dim = config.feature_dim
+        self.geo_feature_std = config.feature_std
+        self.color_feature_dim = config.feature_dim
+        self.color_feature_std = config.feature_std
+        if config.feature_dim != _lib.F or config.query_nn_k != _lib.K or getattr(config, "pos_encoding_band", 0) != 0:
+            raise NotImplementedError(
+                "libclid_native is compiled for feature_dim=8, query_nn_k=6, pos_encoding_band=0 "
+                f"(got {config.feature_dim}, {config.query_nn_k}, {getattr(config, 'pos_encoding_band', 0)})"
+            )
+        self.mean_grid_sampling = False
+        self.device = config.device
+        self.dtype = config.dtype
+        self.idx_dtype = torch.int64
+        self.resolution = config.voxel_size_m
+        self.buffer_size = config.buffer_size
+        self.temporal_local_map_on = True
+        self.local_map_radius = self.config.local_map_radius
+        self.diff_travel_dist_local = self.config.local_map_radius * self.config.local_map_travel_dist_ratio
+        self.diff_ts_local = self.config.diff_ts_local
+        self.reboot_ts = 0
+        self.local_orientation = torch.eye(3, device=self.device)
+        self.cur_ts = 0
+        self.max_ts = 0
+        self.travel_dist = None
+        self.est_poses = None
+        self.after_pgo = False
+        dev, dt = self.device, self.dtype
+        self.primes = torch.tensor(PRIMES, dtype=self.idx_dtype, device=dev)
+        # global map (model/neural_points.py:84-118)
+        self.buffer_pt_index = torch.full((self.buffer_size,), -1, dtype=self.idx_dtype, device=dev)
+        self.neural_points = torch.empty((0, 3), dtype=dt, device=dev)
+        self.point_orientations = torch.empty((0, 4), dtype=dt, device=dev)
+        self.geo_features = torch.empty((1, self.geo_feature_dim), dtype=dt, device=dev)
+        self.color_on = bool(getattr(config, "color_on", False))
+        self.color_features = torch.empty((1, self.color_feature_dim), dtype=dt, device=dev) if self.color_on else None
+        self.geo_feature_pca = self.color_feature_pca = None
+        self.point_ts_create = torch.empty((0), device=dev, dtype=torch.int)
+        self.point_ts_update = torch.empty((0), device=dev, dtype=torch.int)
+        self.point_certainties = torch.empty((0), dtype=dt, device=dev)
+        # local map (:119-133)
+        self.local_neural_points = torch.empty((0, 3), dtype=dt, device=dev)
+        self.local_point_orientations = torch.empty((0, 4), dtype=dt, device=dev)
+        self.local_geo_features = nn.Parameter()
+        self.local_color_features = nn.Parameter()
+        self.local_point_certainties = torch.empty((0), dtype=dt, device=dev)
+        self.local_point_ts_update = torch.empty((0), device=dev, dtype=torch.int)
+        self.local_mask = None
+        self.global2local = None
+        self._map_version = 0
+        self._local_ids = None
+        self._tables = {}
+        self.set_search_neighborhood(num_nei_cells=config.num_nei_cells, search_alpha=config.search_alpha)
+        self.cur_memory_mb = 0.0
+        self.memory_footprint = []
+        self.to(self.device)
+
+    # ------------------------------------------------------------------ bookkeeping
+    def is_empty(self):
+        return self.neural_points.shape[0] == 0
+
+    def count(self):
+        return self.neural_points.shape[0]
+
+    def local_count(self):
+        return self.local_neural_points.shape[0] if self.local_neural_points is not None else 0
+
+    def record_memory(self, verbose: bool = True, record_footprint: bool = True):
+        """model/neural_points.py:157-174."""
+        neural_point_count = self.count()
+        dim = self.config.feature_dim + 3 + 4 + (self.config.feature_dim if self.color_on else 0)
+        self.cur_memory_mb = neural_point_count * dim * 4 / 1024 / 1024
+        if verbose:
+            print("# Global neural point: %d" % self.count())
+            print("# Local  neural point: %d" % self.local_count())
+            print("memory: %f MB" % self.cur_memory_mb)
+        if record_footprint:
+            self.memory_footprint.append(self.cur_memory_mb)
+
+    def __getstate__(self):
+        # device mirrors are caches: never pickled (utils/tools.py:347-367 pickles the module)
+        st = super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__.copy()
+        st = dict(st)
+        st["_tables"] = {}
+        return st
+
+    # ------------------------------------------------------------------ search region
+    def set_search_neighborhood(self, num_nei_cells: int = 1, search_alpha: float = 1.0):
+        """model/neural_points.py:931-969 (+ the per-offset slot deltas the kernels use)."""
+        r = torch.arange(-num_nei_cells, num_nei_cells + 1, device=self.primes.device, dtype=self.primes.dtype)
+        gx, gy, gz = torch.meshgrid(r, r, r, indexing="ij")
+        cube = torch.stack((gx, gy, gz), dim=-1).reshape(-1, 3)
+        self.neighbor_dx = cube[(cube**2).sum(-1) < (num_nei_cells + search_alpha) ** 2]
+        self.neighbor_K = self.neighbor_dx.shape[0]
+        self.max_valid_dist2 = 3 * ((num_nei_cells + 1) * self.resolution) ** 2
+        self._delta = torch.remainder((self.neighbor_dx * self.primes).sum(-1), int(self.buffer_size)).to(torch.int32).contiguous()
+
+    # ------------------------------------------------------------------ map maintenance (host logic)
+    def update(self, points: torch.Tensor, sensor_position: torch.Tensor, sensor_orientation: torch.Tensor, cur_ts: int):
+        """Insert new neural points for `points` [N,3] (model/neural_points.py:324-437)."""
+        res = self.resolution
+        sample_points = points[voxel_down_sample_torch(points, res)]
+        cells = torch.floor(sample_points / res).to(self.primes)
+        slot = torch.fmod((cells * self.primes).sum(-1), int(self.buffer_size))
+        held = self.buffer_pt_index[slot]
+        if (not self.is_empty()) and (cur_ts != self.reboot_ts):
+            d2 = ((self.neural_points[held] - sample_points) ** 2).sum(-1)
+            take = (held == -1) | (d2 > 3 * res**2)
+            if self.temporal_local_map_on:
+                gap = self.travel_dist[cur_ts] - self.travel_dist[self.point_ts_update[held]]
+                take = take | (gap > self.diff_travel_dist_local)
+        else:
+            take = torch.ones(held.shape, dtype=torch.bool, device=self.device)
+        added = sample_points[take]
+        n_new = added.shape[0]
+        ratio = n_new / sample_points.shape[0]
+        base = self.neural_points.shape[0]
+        held = held.clone()
+        held[take] = torch.arange(n_new, dtype=self.idx_dtype, device=self.device) + base
+        self.buffer_pt_index[slot] = held
+        self.neural_points = torch.cat((self.neural_points, added), 0)
+        quat = torch.zeros((n_new, 4), dtype=self.dtype, device=self.device)
+        quat[:, 0] = 1.0
+        self.point_orientations = torch.cat((self.point_orientations, quat), 0)
+        stamp = torch.full((n_new,), cur_ts, device=self.device, dtype=torch.int)
+        self.point_ts_create = torch.cat((self.point_ts_create, stamp), 0)
+        self.point_ts_update = torch.cat((self.point_ts_update, stamp), 0)
+        fresh = self.geo_feature_std * torch.randn(n_new + 1, self.geo_feature_dim, device=self.device, dtype=self.dtype)
+        self.geo_features = torch.cat((self.geo_features[:-1], fresh), 0)
+        if self.color_features is not None:
+            fresh = self.color_feature_std * torch.randn(n_new + 1, self.color_feature_dim, device=self.device, dtype=self.dtype)
+            self.color_features = torch.cat((self.color_features[:-1], fresh), 0)
+        self.point_certainties = torch.cat(
+            (self.point_certainties, torch.zeros(n_new, device=self.device, dtype=self.dtype)), 0)
+        self._map_version += 1
+        self.reset_local_map(sensor_position, sensor_orientation, cur_ts, reboot_map=True)
+        return ratio
+
+    def reset_local_map(self, sensor_position, sensor_orientation, cur_ts: int, use_travel_dist: bool = True,
+                        diff_ts_local: int = 50, reboot_map: bool = False):
+        """Select the local window and (re)create the trainable local arrays
+        (model/neural_points.py:439-536)."""
+        self.cur_ts = cur_ts
+        self.max_ts = max(self.max_ts, cur_ts)
+        if self.temporal_local_map_on:
+            if self.config.use_mid_ts:
+                ts_used = ((self.point_ts_create + self.point_ts_update) / 2).int()
+            else:
+                ts_used = self.point_ts_create
+            if use_travel_dist:
+                gap = torch.abs(self.travel_dist[cur_ts] - self.travel_dist[ts_used])
+                time_mask = gap < self.diff_travel_dist_local
+            else:
+                time_mask = torch.abs(cur_ts - ts_used) < diff_ts_local
+            if reboot_map:
+                time_mask = time_mask & (ts_used >= self.reboot_ts)
+            if torch.sum(time_mask) < 100:
+                time_mask = torch.ones(self.count(), dtype=torch.bool, device=self.device)
+        else:
+            time_mask = torch.ones(self.count(), dtype=torch.bool, device=self.device)
+        cand = torch.nonzero(time_mask).flatten()
+        d2 = ((self.neural_points[cand] - sensor_position) ** 2).sum(-1)
+        local_ids = cand[d2 < self.local_map_radius**2]
+        local_mask = torch.zeros(self.count() + 1, dtype=torch.bool, device=self.device)
+        local_mask[local_ids] = True
+        self.local_neural_points = self.neural_points[local_mask[:-1]]
+        self.local_point_orientations = self.point_orientations[local_mask[:-1]]
+        self.local_point_certainties = self.point_certainties[local_mask[:-1]]
+        self.local_point_ts_update = self.point_ts_update[local_mask[:-1]]
+        local_mask[-1] = True  # padding slot
+        self.local_mask = local_mask
+        g2l = torch.full((self.count() + 1,), -1, dtype=torch.long, device=self.device)
+        g2l[local_ids] = torch.arange(local_ids.shape[0], device=self.device)
+        self.global2local = g2l
+        self.local_geo_features = nn.Parameter(self.geo_features[local_mask])
+        if self.color_features is not None:
+            self.local_color_features = nn.Parameter(self.color_features[local_mask])
+        self.local_orientation = sensor_orientation
+        self._local_ids = local_ids.contiguous()
+        self._map_version += 1
+
+    def assign_local_to_global(self):
+        """model/neural_points.py:538-549."""
+        m = self.local_mask
+        self.geo_features[m] = self.local_geo_features.data
+        if self.color_features is not None:
+            self.color_features[m] = self.local_color_features.data
+        self.point_certainties[m[:-1]] = self.local_point_certainties
+        self.point_ts_update[m[:-1]] = self.local_point_ts_update
+
+    def recreate_hash(self, sensor_position=None, sensor_orientation=None, kept_points: bool = True,
+                      with_ts: bool = True, cur_ts=0):
+        """Rebuild `buffer_pt_index` from the point positions (model/neural_points.py:878-929,
+        re-hash part only; the optional pruning of `kept_points=False` is out of scope)."""
+        if not kept_points:
+            raise NotImplementedError("recreate_hash(kept_points=False) (map merging) is outside the hot-path scope")
+        cells = torch.floor(self.neural_points / self.resolution).to(self.primes)
+        slot = torch.fmod((cells * self.primes).sum(-1), int(self.buffer_size))
+        self.buffer_pt_index = torch.full((self.buffer_size,), -1, dtype=self.idx_dtype, device=self.device)
+        self.buffer_pt_index[slot] = torch.arange(self.count(), dtype=self.idx_dtype, device=self.device)
+        self._map_version += 1
+        if with_ts and sensor_position is not None:
+            self.reset_local_map(sensor_position, sensor_orientation, cur_ts)
+
+    def clear_temp(self, clean_more: bool = False):
+        """model/neural_points.py:1053-1075."""
+        self.buffer_pt_index = None
+        self.local_neural_points = None
+        self.local_point_orientations = None
+        self.local_geo_features = nn.Parameter()
+        self.local_color_features = nn.Parameter()
+        self.local_point_certainties = None
+        self.local_point_ts_update = None
+        self.local_mask = None
+        self.global2local = None
+        self._tables = {}
+        self._local_ids = None
+        if clean_more:
+            self.point_ts_create = None
+            self.point_ts_update = None
+            self.point_certainties = None
+
+    def prune_map(self, *a, **k):
+        raise NotImplementedError("prune_map (model/neural_points.py:771-876) is map maintenance outside the hot-path scope")
+
+    def adjust_map(self, *a, **k):
+        raise NotImplementedError("adjust_map (PGO map deformation) is outside the hot-path scope")
+
+    # ------------------------------------------------------------------ device mirror
+    def _table(self, locally: bool, time_filtering: bool):
+        """Compact probe table + float4 positions for one map state (cached)."""
+        big = self.buffer_pt_index
+        if big is None:
+            raise RuntimeError("buffer_pt_index was cleared (clear_temp); call recreate_hash first")
+        key = [self._map_version, locally, time_filtering, big.data_ptr(), big._version, self.neural_points.data_ptr(),
+               self.count(), float(self.resolution), int(self.buffer_size)]
+        if locally:
+            key += [self.global2local.data_ptr(), self.global2local._version, self.local_count()]
+        if time_filtering:
+            key += [int(self.cur_ts), self.travel_dist.data_ptr(), self.travel_dist._version,
+                    self.point_ts_create.data_ptr(), float(self.diff_travel_dist_local)]
+        key = tuple(key)
+        slot = (locally, time_filtering)
+        hit = self._tables.get(slot)
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2], hit[3]
+        lib = _lib.load()
+        _lib.require_cuda(big, "buffer_pt_index", torch.int64)
+        pts = _lib.require_cuda(self.neural_points, "neural_points", torch.float32)
+        if int(self.buffer_size) >= (1 << 30):
+            raise NotImplementedError("buffer_size >= 2^30 is not supported by the int32 slot arithmetic")
+        if locally:
+            ids = self._local_ids
+            if ids is None or ids.shape[0] != self.local_count():
+                ids = torch.nonzero(self.local_mask[:-1]).flatten().contiguous()
+            n = ids.shape[0]
+        else:
+            ids, n = None, self.count()
+        log2cap = max(4, int(math.ceil(math.log2(max(4 * n, 16)))))
+        tab = torch.empty((1 << log2cap, 2), device=pts.device, dtype=torch.int32)
+        pos4 = torch.empty((max(n, 1), 4), device=pts.device, dtype=torch.float32)
+        tsc = self.point_ts_create if time_filtering else None
+        trv = self.travel_dist.to(torch.float32).contiguous() if time_filtering else None
+        _lib.check(
+            lib.clid_table_build(_lib.ptr(ids), n, _lib.ptr(pts), _lib.ptr(big), int(self.buffer_size),
+                                 float(self.resolution), _lib.ptr(tsc), _lib.ptr(trv), int(self.cur_ts),
+                                 int(time_filtering), float(self.diff_travel_dist_local), _lib.ptr(tab), log2cap,
+                                 _lib.ptr(pos4), _lib.stream()),
+            "clid_table_build",
+        )
+        self._tables[slot] = (key, tab, pos4, log2cap)
+        return tab, pos4, log2cap
+
+    def _map_view(self, query_locally: bool, time_filtering=None):
+        """Fill a clid_map_view for the current tensors.  Returns (view, keep_alive)."""
+        if time_filtering is None:
+            time_filtering = bool(self.temporal_local_map_on and query_locally)
+        tab, pos4, log2cap = self._table(query_locally, time_filtering)
+        if query_locally:
+            feat, cert, tsu = self.local_geo_features.data, self.local_point_certainties, self.local_point_ts_update
+        else:
+            feat, cert, tsu = self.geo_features, self.point_certainties, None
+        if self._delta.device != tab.device:
+            self._delta = self._delta.to(tab.device)
+        for name, t, dt in (("features", feat, torch.float32), ("certainties", cert, torch.float32)):
+            _lib.require_cuda(t, name, dt)
+        v = _lib.MapView()
+        v.tab, v.pos4, v.feat, v.cert = tab.data_ptr(), pos4.data_ptr(), feat.data_ptr(), cert.data_ptr()
+        v.ts_update = tsu.data_ptr() if tsu is not None else None
+        v.delta = self._delta.data_ptr()
+        v.log2cap, v.M, v.P = log2cap, cert.shape[0], int(self.neighbor_K)
+        v.buffer_size = int(self.buffer_size)
+        v.resolution = float(self.resolution)
+        v.max_valid_dist2 = float(self.max_valid_dist2)
+        v.layer_norm = int(bool(self.config.layer_norm_on))
+        return v, (tab, pos4, feat, cert, tsu, self._delta)
+
+    # ------------------------------------------------------------------ hot methods
+    def query_feature(self, query_points: torch.Tensor, query_ts: torch.Tensor = None, training_mode: bool = True,
+                      query_locally: bool = True, query_geo_feature: bool = True, query_color_feature: bool = False):
+        """Interpolated latent features at `query_points` (model/neural_points.py:553-769).
+
+        Returns the reference's 5-tuple (geo_features_vector [N,11] or [N,K,11], None,
+        weight_vector [N,K,1], nn_counts [N] int64, queried_certainty [N]); differentiable w.r.t.
+        `query_points` and `local_geo_features` through hand-written backward kernels."""
+        if not query_geo_feature and not query_color_feature:
+            import sys
+            sys.exit("you need to at least query one kind of feature")
+        if query_color_feature and self.color_features is not None:
+            raise NotImplementedError("colour features are outside the hot-path scope (color_on is off in all shipped configs)")
+        if self.after_pgo:
+            raise NotImplementedError("after_pgo neighbour rotation is outside the hot-path scope")
+        theta = self.local_geo_features if query_locally else self.geo_features
+        feat, w, nn_counts, cert = _QueryFeature.apply(
+            query_points, theta, self, query_ts, bool(training_mode), bool(query_locally), bool(self.config.weighted_first))
+        return feat, None, w, nn_counts, cert
+
+    def radius_neighborhood_search(self, points: torch.Tensor, time_filtering: bool = False):
+        """(dist2 [N,P], neighb_idx [N,P] int64 global ids) (model/neural_points.py:971-1030)."""
+        lib = _lib.load()
+        x = _lib.require_cuda(points.detach().contiguous(), "points", torch.float32)
+        view, keep = self._map_view(False, bool(time_filtering))
+        n, P = x.shape[0], int(self.neighbor_K)
+        d2 = torch.empty((n, P), device=x.device, dtype=torch.float32)
+        idx = torch.empty((n, P), device=x.device, dtype=torch.int32)
+        _lib.check(lib.clid_radius_search(C.byref(view), _lib.ptr(x), n, _lib.ptr(d2), _lib.ptr(idx), _lib.stream()),
+                   "clid_radius_search")
+        return d2, idx.to(torch.int64)
+
+    def query_certainty(self, query_points: torch.Tensor):
+        """model/neural_points.py:1032-1051."""
+        _, idx = self.radius_neighborhood_search(query_points)
+        c = self.point_certainties[idx]
+        c[idx < 0] = 0.0
+        return torch.max(c, dim=-1)[0]
+
+    def query_sdf_and_gradient(self, decoder, query_points: torch.Tensor):
+        """Fused inference used by tracking-style callers: query (training_mode=False, local map)
+        -> Decoder.sdf -> analytic d sdf / d x, i.e. utils/error_state_iekf.py:209-227 in ONE kernel.
+        Returns (sdf [N], grad [N,3], nn_counts [N] int64, certainty [N])."""
+        lib = _lib.load()
+        x = _lib.require_cuda(query_points.detach().contiguous(), "query_points", torch.float32)
+        view, keep = self._map_view(True)
+        n = x.shape[0]
+        W1, b1, W2, b2 = decoder.flat_params()
+        sdf = torch.empty((n,), device=x.device, dtype=torch.float32)
+        g = torch.empty((n, 3), device=x.device, dtype=torch.float32)
+        nn_cnt = torch.empty((n,), device=x.device, dtype=torch.int32)
+        cert = torch.empty((n,), device=x.device, dtype=torch.float32)
+        _lib.check(
+            lib.clid_sdf_grad_x(C.byref(view), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
+                                float(decoder.sdf_scale), _lib.ptr(x), n, _lib.ptr(sdf), _lib.ptr(g), _lib.ptr(nn_cnt),
+                                _lib.ptr(cert), _lib.stream()),
+            "clid_sdf_grad_x",
+        )
+        return sdf, g, nn_cnt.to(torch.int64), cert

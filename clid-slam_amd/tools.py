@@ -1,0 +1,89 @@
+"""Host-side helpers with the reference's names and signatures (utils/tools.py).
+
+Only the functions the SDF-training hot path and its immediate callers use are present:
+`setup_optimizer` (:205-255), `get_gradient` (:298-311), `freeze_model`/`unfreeze_model`
+(:314-325), `get_time` (:385-392), `voxel_down_sample_torch` (:639-682; needed by
+`NeuralPoints.update`).  They are torch-level plumbing; the compute of the hot path is in the HIP
+library.
+"""
+from __future__ import annotations
+
+import time
+
+import torch
+import torch.nn as nn
+from torch import optim
+from torch.autograd import grad
+
+
+def setup_optimizer(config, neural_point_feat, mlp_geo_param=None, mlp_sem_param=None, mlp_color_param=None,
+                    poses=None, lr_ratio=1.0):
+    """Same parameter groups / hyper-parameters as utils/tools.py:205-255.  `Mapper.mapping` does
+    NOT use this object (its Adam is the fused HIP kernel with identical arithmetic); it is kept for
+    callers that drive their own optimisation loop."""
+    lr_cur = config.lr * lr_ratio
+    groups = []
+    if mlp_geo_param is not None:
+        groups.append({"params": mlp_geo_param, "lr": lr_cur, "weight_decay": 0.0})
+    if getattr(config, "semantic_on", False) and mlp_sem_param is not None:
+        groups.append({"params": mlp_sem_param, "lr": lr_cur, "weight_decay": 0.0})
+    if getattr(config, "color_on", False) and mlp_color_param is not None:
+        groups.append({"params": mlp_color_param, "lr": lr_cur, "weight_decay": 0.0})
+    if poses is not None:
+        groups.append({"params": poses, "lr": config.lr_pose, "weight_decay": config.weight_decay})
+    groups.append({"params": neural_point_feat, "lr": lr_cur, "weight_decay": config.weight_decay})
+    if getattr(config, "opt_adam", True):
+        return optim.Adam(groups, betas=(0.9, 0.99), eps=config.adam_eps)
+    return optim.SGD(groups, momentum=0.9)
+
+
+def get_gradient(inputs, outputs):
+    """d outputs / d inputs through autograd (utils/tools.py:298-311).  With the HIP-backed
+    `NeuralPoints.query_feature` / `Decoder.sdf` this runs their hand-written backward kernels."""
+    d_points = torch.ones_like(outputs, requires_grad=False, device=outputs.device)
+    return grad(outputs=outputs, inputs=inputs, grad_outputs=d_points, create_graph=True, retain_graph=True,
+                only_inputs=True)[0]
+
+
+def freeze_model(model: nn.Module):
+    for child in model.children():
+        for param in child.parameters():
+            param.requires_grad = False
+
+
+def unfreeze_model(model: nn.Module):
+    for child in model.children():
+        for param in child.parameters():
+            param.requires_grad = True
+
+
+def get_time():
+    """utils/tools.py:385-392.  (The fused mapping loop does not call this: the reference's six
+    per-iteration synchronisations are replaced by stream ordering.)"""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    return time.time()
+
+
+def voxel_down_sample_torch(points: torch.Tensor, voxel_size: float):
+    """Indices of one point per voxel: the one closest to the voxel centre, distance quantised to
+    1000 levels, ties to the lowest index (same selection rule as utils/tools.py:639-682, written
+    with a sort instead of scatter_reduce so it is deterministic on the GPU)."""
+    quant = 1000
+    grid = torch.floor(points / voxel_size)
+    center = (grid + 0.5) * voxel_size
+    dist = ((points - center) ** 2).sum(dim=1) ** 0.5
+    qd = (dist / dist.max() * (quant - 1)).long()
+    cell = grid.long()
+    cell = cell - cell.min(dim=0).values
+    ext = cell.max(dim=0).values + 1
+    flat = (cell[:, 2] * ext[1] + cell[:, 1]) * ext[0] + cell[:, 0]
+    n = points.shape[0]
+    key = qd * n + torch.arange(n, device=points.device)
+    # sort by (voxel, quantised distance, index); first of each voxel wins
+    order = torch.argsort(key)
+    order = order[torch.argsort(flat[order], stable=True)]
+    fs = flat[order]
+    first = torch.ones_like(fs, dtype=torch.bool)
+    first[1:] = fs[1:] != fs[:-1]
+    return order[first]

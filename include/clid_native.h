@@ -1,0 +1,179 @@
+/* clid_native.h -- C ABI of libclid_native.so: hand-written gfx950 (MI355X / CDNA4) HIP kernels for
+ * CLID-SLAM's per-scan SDF training inner loop.
+ *
+ * The reference has NO native/FFI interface for this path: the path sits
+ * behind Python methods.  Each entry point below therefore names the reference *Python* function
+ * whose torch-op sequence it replaces (paths relative to the reference root).  The Python host
+ * (the .py files of clid-slam_amd/, same class names and signatures as the reference) binds these through
+ * ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed for the call unless the name ends in _host;
+ *     no ownership transfer, no hidden allocation (workspaces are passed in);
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); all work is
+ *     enqueued asynchronously on it, nothing synchronises;
+ *   - return value: 0 = ok, negative = error; clid_last_error() returns a message;
+ *   - indices are int32 on the device (the reference uses int64; the shim converts at the edge),
+ *     -1 = invalid neighbour, exactly as in the reference;
+ *   - compile-time shape contract (all shipped configs): feature_dim F = 8, position dim 3
+ *     (pos_encoding_band = 0) => decoder input D = 11, one hidden layer H = 64 with bias + ReLU,
+ *     query_nn_k K = 6.  Other shapes are rejected with CLID_E_SHAPE, never silently mis-computed.
+ */
+#ifndef CLID_NATIVE_H
+#define CLID_NATIVE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLID_F 8   /* config.feature_dim            (utils/config.py:127) */
+#define CLID_D 11  /* F + 3                         (model/decoder.py:27-33) */
+#define CLID_H 64  /* config.geo_mlp_hidden_dim     (utils/config.py:171) */
+#define CLID_K 6   /* config.query_nn_k             (utils/config.py:546) */
+#define CLID_MLP_PARAMS (CLID_H * CLID_D + CLID_H + CLID_H + 1) /* 833: W1|b1|W2|b2 */
+#define CLID_GRAD_FEAT_OFFSET 836 /* feature gradients start here in the fused gradient buffer (16 B aligned) */
+
+#define CLID_OK 0
+#define CLID_E_ARG (-1)
+#define CLID_E_SHAPE (-2)
+#define CLID_E_HIP (-3)
+
+const char* clid_last_error(void);
+int clid_abi_version(void);
+
+/* ---- neural-point map view ------------------------------------------------------------------
+ * What the kernels read of `NeuralPoints` (model/neural_points.py:79-133).  `tab`/`pos4` are a
+ * compact mirror built by clid_table_build(); the remaining pointers alias the shim's own torch
+ * tensors (local_* arrays for query_locally=True, global arrays otherwise). */
+typedef struct clid_map_view {
+  const int32_t* tab;      /* [cap][2] {slot key (-1 empty), point id} open-addressing, cap = 2^log2cap */
+  const float* pos4;       /* [M][4] xyz0 of the points addressed by the ids in `tab` */
+  float* feat;             /* [(M+1)][F] latent features, last row = padding (np.py:532) */
+  float* cert;             /* [M] point certainties (read; +atomicAdd when training_mode) */
+  int32_t* ts_update;      /* [M] last-update stamps (atomicMax when query_ts given), may be NULL */
+  const int32_t* delta;    /* [P] (sum_c dx_c * prime_c) mod buffer_size, non-negative */
+  int32_t log2cap;
+  int32_t M;
+  int32_t P;               /* neighbor_K, 81 for num_nei_cells=2, search_alpha=0.5 (np.py:931-969) */
+  int32_t buffer_size;     /* config.buffer_size, < 2^30 */
+  float resolution;        /* voxel_size_m */
+  float max_valid_dist2;   /* 3*((num_nei_cells+1)*res)^2 */
+  int32_t layer_norm;      /* config.layer_norm_on */
+  int32_t reserved;
+} clid_map_view;
+
+/* Builds the compact probe table for one (map, window, time-filter) state.
+ * Replaces nothing in the reference by itself: it is the exact, smaller equivalent of indexing
+ * `buffer_pt_index[hash]` followed by the travel-distance filter and `global2local`
+ * (model/neural_points.py:984-1009, 595-598): slot s keeps id j iff buffer_pt_index[s] == ids[j]
+ * and (no time filtering or |travel[cur_ts]-travel[ts_create[ids[j]]]| < diff_travel).
+ *   ids            [n] int64 global point index of local point j, or NULL for identity (global map)
+ *   neural_points  [Mg][3], buffer_pt_index [buffer_size] int64, point_ts_create [Mg] int32
+ *   tab_out        [2^log2cap][2] int32, pos4_out [n][4]            (tab_out is memset here) */
+int clid_table_build(const int64_t* ids, int32_t n, const float* neural_points,
+                     const int64_t* buffer_pt_index, int64_t buffer_size, float resolution,
+                     const int32_t* point_ts_create, const float* travel_dist, int32_t cur_ts,
+                     int32_t time_filtering, float diff_travel, int32_t* tab_out, int32_t log2cap,
+                     float* pos4_out, void* stream);
+
+/* NeuralPoints.radius_neighborhood_search (model/neural_points.py:971-1030).
+ * dist2_out [N][P] f32, idx_out [N][P] int32 (ids of the view, -1 invalid). */
+int clid_radius_search(const clid_map_view* mv, const float* x, int32_t N, float* dist2_out,
+                       int32_t* idx_out, void* stream);
+
+/* NeuralPoints.query_feature (model/neural_points.py:553-769), geometry features.
+ *   query_ts  [N] int32 or NULL;  training_mode: certainty/ts side effects (np.py:708-733)
+ *   weighted_first: feat_out [N][D] else [N][K][D]
+ *   w_out [N][K], idx_out [N][K] int32 (sorted by distance, -1 invalid), nn_out [N] int32
+ *   (count over all P probes, np.py:600-602), cert_out [N] (pre-update certainties, np.py:654). */
+int clid_query_fwd(const clid_map_view* mv, const float* x, const int32_t* query_ts, int32_t N,
+                   int32_t training_mode, int32_t weighted_first, float* feat_out, float* w_out,
+                   int32_t* idx_out, int32_t* nn_out, float* cert_out, void* stream);
+
+/* Backward of clid_query_fwd for autograd callers (what autograd does for np.py:553-769):
+ *   g_feat [N][D] (weighted_first) or [N][K][D]; g_w [N][K] or NULL
+ *   g_theta (+=, atomics) [(M+1)][F] or NULL;  g_x_out [N][3] or NULL
+ * idx/w are the tensors clid_query_fwd returned for the same x. */
+int clid_query_bwd(const clid_map_view* mv, const float* x, const int32_t* idx, const float* w,
+                   int32_t N, int32_t weighted_first, const float* g_feat, const float* g_w,
+                   float* g_theta, float* g_x_out, void* stream);
+
+/* Decoder.sdf (model/decoder.py:58-82): sdf = scale*(W2 relu(W1 f + b1) + b2); rows = N (or N*K). */
+int clid_mlp_sdf_fwd(const float* W1, const float* b1, const float* W2, const float* b2,
+                     float sdf_scale, const float* feat, int32_t rows, float* sdf_out, void* stream);
+/* its backward: g_feat_out [rows][D] or NULL; g_mlp (+=) [833] = dW1|db1|dW2|db2 or NULL. */
+int clid_mlp_sdf_bwd(const float* W1, const float* b1, const float* W2, const float* b2,
+                     float sdf_scale, const float* feat, const float* g_sdf, int32_t rows,
+                     float* g_feat_out, float* g_mlp, void* stream);
+
+/* Fused inference: query (training_mode=False) + Decoder.sdf + analytic d sdf/d x, i.e.
+ * query_feature -> sdf -> utils/tools.py:298-311 get_gradient, as used by
+ * utils/error_state_iekf.py:209-227.  grad_out [N][3], nn_out [N], cert_out [N] (may be NULL). */
+int clid_sdf_grad_x(const clid_map_view* mv, const float* W1, const float* b1, const float* W2,
+                    const float* b2, float sdf_scale, const float* x, int32_t N, float* sdf_out,
+                    float* grad_out, int32_t* nn_out, float* cert_out, void* stream);
+
+/* utils/loss.py:44-62 sdf_bce_loss (weighted, mean) + eikonal term (utils/mapper.py:779-798):
+ * loss_out[0..2] = total, bce, eikonal (+=, zero it first); d_pred_out [N]; d_g_out [Ng][3]. */
+int clid_loss_fwd_bwd(const float* pred, const float* label, const float* weight, int32_t N,
+                      float sigma, int32_t weighted, const float* g, int32_t Ng, float weight_e,
+                      float* loss_out, float* d_pred_out, float* d_g_out, void* stream);
+
+/* torch.optim.Adam single-tensor step (utils/tools.py:205-255), optionally zeroing
+ * the gradient in the same pass.  step >= 1. */
+int clid_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int32_t step, int32_t zero_grad,
+                   void* stream);
+
+/* ---- the fused mapping iteration (Mapper.mapping body, utils/mapper.py:642-836) -------------- */
+typedef struct clid_train_args {
+  /* sample pool (utils/mapper.py:84-97) and the batch indices get_batch drew (mapper.py:473-500) */
+  const float* pool_coord;   /* [S][3] global_coord_pool */
+  const float* pool_label;   /* [S] */
+  const int32_t* pool_ts;    /* [S] */
+  const float* pool_weight;  /* [S] */
+  const int64_t* index;      /* [bs] this iteration's batch (this rank's shard) */
+  int32_t bs;                /* local batch size */
+  int32_t decimation;        /* config.gradient_decimation */
+  int64_t batch_offset;      /* position of index[0] in the GLOBAL batch (multi-GPU); 0 otherwise */
+  float fd_eps;              /* voxel_size_m * num_grad_step_ratio (mapper.py:703) */
+  float inv_n_main;          /* 1 / global batch size   (BCE mean) */
+  float inv_n_eik;           /* 1 / global decimated count (eikonal mean) */
+  float sigma;               /* sdf_scale used by the loss (mapper.py:71) */
+  float weight_e;
+  int32_t loss_weight_on;
+  int32_t eikonal_mode;      /* 0 off, 1 numerical (default), 2 analytic */
+  int32_t train_decoder;     /* 0 after freeze_model (utils/tools.py:314) */
+  /* decoder (model/decoder.py) */
+  float* W1; float* b1; float* W2; float* b2;
+  float sdf_scale;
+  int32_t pad0;
+  /* gradients: one contiguous buffer [833 (+3 pad) | (M+1)*F] so a single all-reduce covers it */
+  float* grad;
+  /* workspace, sized by clid_train_workspace_floats() */
+  float* ws;
+  float* loss_out;           /* [4] total,bce,eik,unused (+=) */
+} clid_train_args;
+
+int64_t clid_train_workspace_floats(int32_t bs, int32_t decimation, int32_t eikonal_mode);
+/* forward + loss + backward of one iteration; leaves summed gradients in args->grad */
+int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args* args, void* stream);
+/* Adam on decoder (when trained) + features from args->grad; zeroes args->grad */
+typedef struct clid_adam_args {
+  float* feat; float* grad; float* m; float* v;       /* feat/m/v: [(M+1)*F]; grad as above [833|..] */
+  float* W1; float* b1; float* W2; float* b2;          /* decoder params */
+  float* m_mlp; float* v_mlp;                          /* [833] each */
+  int64_t n_feat;                                      /* (M+1)*F */
+  float lr, beta1, beta2, eps, weight_decay;
+  int32_t step;                                        /* 1-based, restarts every mapping() call */
+  int32_t train_decoder;
+  int32_t pad0;
+} clid_adam_args;
+int clid_train_adam(const clid_adam_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLID_NATIVE_H */

@@ -323,6 +323,7 @@ class LoopConfig:
     weight_decay: float = 0.0
     train_decoder: bool = True  # False after `freeze_model` (utils/tools.py:314, slam.py:193-196)
     loss_scale_counts: Optional[tuple] = None  # (N_global, N'_global) for sharded runs; None = local
+    fd_first: int = 0  # sharded runs: local position of the first decimated sample
 
 
 def draw_batch_index(pool_count: int, new_idx: Optional[torch.Tensor], bs: int, bs_new_sample: int, gen=None):
@@ -358,7 +359,7 @@ def loss_and_grads(st: MapState, dec: DecoderParams, pool: SamplePool, index: to
     if analytic:
         g = autograd_gradient(coord, sdf_pred)
     elif lc.ekional_loss_on and lc.numerical_grad:
-        g = numerical_gradient(st, dec, coord[:: lc.gradient_decimation], lc.fd_eps)
+        g = numerical_gradient(st, dec, coord[lc.fd_first :: lc.gradient_decimation], lc.fd_eps)
     n_main = sdf_pred.shape[0]
     l_bce = sdf_bce_loss(sdf_pred, label, lc.sigma, weight, lc.loss_weight_on)
     total = l_bce
@@ -369,7 +370,7 @@ def loss_and_grads(st: MapState, dec: DecoderParams, pool: SamplePool, index: to
     if lc.loss_scale_counts is not None:  # sharded: normalise by the global counts
         n_glob, ng_glob = lc.loss_scale_counts
         total = l_bce * (n_main / n_glob)
-        if g is not None:
+        if g is not None and g.shape[0] > 0:
             total = total + lc.weight_e * l_eik * (g.shape[0] / ng_glob)
     total.backward()
     out = {
