@@ -172,7 +172,7 @@ def test_adam_kernel_vs_torch(env):
         _lib.check(lib.clid_adam_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 0.01, 0.9,
                                       0.99, 1e-15, 0.0, step, 1, _lib.stream()), "adam")
         assert not gd.any()  # zeroed in the same pass
-        assert maxerr(p, pr) <= 1e-7
+        assert maxerr(p, pr) <= 5e-7  # <= 1 ulp at |p| < 4 (ATen may fuse the lerp)
     # untouched rows (always-zero gradient) are bit-identical to the start
     assert torch.equal(p.cpu()[::3] , p0[::3]) or maxerr(p.cpu()[::3], p0[::3]) == 0.0
 
