@@ -39,8 +39,9 @@ class TrainArgs(C.Structure):
         ("fd_eps", _f32), ("inv_n_main", _f32), ("inv_n_eik", _f32), ("sigma", _f32), ("weight_e", _f32),
         ("loss_weight_on", _i32), ("eikonal_mode", _i32), ("train_decoder", _i32),
         ("W1", _vp), ("b1", _vp), ("W2", _vp), ("b2", _vp),
-        ("sdf_scale", _f32), ("pad0", _i32),
+        ("sdf_scale", _f32), ("defer_reduce", _i32),
         ("grad", _vp), ("ws", _vp), ("loss_out", _vp),
+        ("debug_flags", _i32), ("pad1", _i32),
     ]
 
 
@@ -68,7 +69,9 @@ _SIGS = {
     "clid_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _i32, _vp]),
     "clid_train_workspace_floats": (_i64, [_i32, _i32, _i32]),
     "clid_train_fwd_bwd": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), _vp]),
-    "clid_train_adam": (C.c_int, [C.POINTER(AdamArgs), _vp]),
+    "clid_train_adam": (C.c_int, [C.POINTER(AdamArgs), C.POINTER(TrainArgs), _vp]),
+    "clid_profile_enable": (C.c_int, [C.c_int]),
+    "clid_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int), _vp]),
 }
 
 EXPORTS = tuple(_SIGS)

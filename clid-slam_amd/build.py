@@ -22,7 +22,7 @@ FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-munsafe-fp-atomics",      # global_atomic_add_f32 instead of a CAS loop
     "-ffp-contract=on",         # FMA only inside one expression; exact-order code uses __f*_rn
-    "-Wno-unused-result",
+    "-Wno-unused-result", "-Wno-unused-value",
 ]
 
 

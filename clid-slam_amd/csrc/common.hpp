@@ -71,20 +71,27 @@ __device__ __forceinline__ int base_slot(float x, float y, float z, float res, i
   return (int)r;
 }
 
-__device__ __forceinline__ unsigned tab_home(int slot, int log2cap) {
-  return ((unsigned)slot * 2654435761u) >> (32 - log2cap);
+// ---- compact probe table: 2-entry buckets {key0,id0,key1,id1} (one 16-byte load per probe) ---------
+// key == -1 empty; key0 is always filled before key1, overflow goes to the next bucket.
+__device__ __forceinline__ unsigned tab_home(int slot, int log2nb) {
+  return ((unsigned)slot * 2654435761u) >> (32 - log2nb);
 }
-
-// open-addressing lookup in the compact table: {key, id}, key == -1 empty
-__device__ __forceinline__ int tab_lookup(const int2* __restrict__ tab, int log2cap, int slot) {
-  const unsigned mask = (1u << log2cap) - 1u;
-  unsigned pos = tab_home(slot, log2cap);
+// resolve one probe given its home bucket content; walks on only when the bucket is full
+__device__ __forceinline__ int tab_resolve(const int4* __restrict__ tab, int log2nb, int slot, unsigned home,
+                                           int4 b) {
+  const unsigned mask = (1u << log2nb) - 1u;
   for (;;) {
-    const int2 e = tab[pos];
-    if (e.x == slot) return e.y;
-    if (e.x < 0) return -1;
-    pos = (pos + 1) & mask;
+    if (b.x == slot) return b.y;
+    if (b.x < 0) return -1;
+    if (b.z == slot) return b.w;
+    if (b.z < 0) return -1;
+    home = (home + 1) & mask;
+    b = tab[home];
   }
+}
+__device__ __forceinline__ int tab_lookup(const int4* __restrict__ tab, int log2nb, int slot) {
+  const unsigned home = tab_home(slot, log2nb);
+  return tab_resolve(tab, log2nb, slot, home, tab[home]);
 }
 
 // ---- per-lane sorted candidate list + group top-K ------------------------------------------------
@@ -127,40 +134,58 @@ struct TopK {  // replicated across the group
   int nn;         // valid probes over all P (np.py:600-602)
 };
 
+// Per-offset slot deltas staged in LDS, padded with zeros to a multiple of kProbeChunk
+constexpr int kProbesPerLane = 6;
+constexpr int kProbeChunk = CLID_G * kProbesPerLane;  // 96 >= 81
+constexpr int kMaxProbes = 4 * kProbeChunk;           // 384 >= 343 (num_nei_cells = 3)
+struct DeltaLds {
+  int d[kMaxProbes];
+};
+// call from all threads of the block BEFORE a __syncthreads()
+__device__ __forceinline__ void stage_delta(DeltaLds& s, const clid_map_view& mv) {
+  const int padded = (mv.P + kProbeChunk - 1) / kProbeChunk * kProbeChunk;
+  for (int i = threadIdx.x; i < padded; i += blockDim.x) s.d[i] = i < mv.P ? mv.delta[i] : 0;
+}
+
 // Search the P probe cells of one query (x,y,z) with the 16 lanes of a group and select the K
-// nearest valid neighbours, ascending (np.py:971-1030 + 595-612).
-__device__ __forceinline__ void search_topk(const clid_map_view& mv, float x, float y, float z,
-                                            int lane16, int gbase, TopK& out) {
-  const int2* __restrict__ tab = reinterpret_cast<const int2*>(mv.tab);
+// nearest valid neighbours, ascending (np.py:971-1030 + 595-612).  All probe loads of a chunk are
+// issued before any is consumed (the dependent chain is bucket -> position, not 6x that).
+__device__ __forceinline__ void search_topk(const clid_map_view& mv, const DeltaLds& dl, float x, float y,
+                                            float z, int lane16, int gbase, TopK& out) {
+  const int4* __restrict__ tab = reinterpret_cast<const int4*>(mv.tab);
   const float4* __restrict__ pos4 = reinterpret_cast<const float4*>(mv.pos4);
   const int B = mv.buffer_size;
   const int r0 = base_slot(x, y, z, mv.resolution, B);
   Cand c;
   c.init();
   int nvalid = 0;
-  for (int o0 = 0; o0 < mv.P; o0 += CLID_G * 2) {
-    // two probes per trip so their dependent loads overlap
-    int jj[2];
+  for (int o0 = 0; o0 < mv.P; o0 += kProbeChunk) {
+    int slot[kProbesPerLane];
+    unsigned home[kProbesPerLane];
+    int4 bk[kProbesPerLane];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int o = o0 + u * CLID_G + lane16;
-      jj[u] = -1;
-      if (o < mv.P) {
-        int slot = r0 + mv.delta[o];
-        if (slot >= B) slot -= B;
-        jj[u] = tab_lookup(tab, mv.log2cap, slot);
-      }
+    for (int t = 0; t < kProbesPerLane; ++t) {
+      const int o = o0 + t * CLID_G + lane16;
+      int sl = r0 + dl.d[o];
+      if (sl >= B) sl -= B;
+      slot[t] = (o < mv.P) ? sl : -2;  // -2 never matches a key and is not "empty"
+      home[t] = tab_home(sl, mv.log2cap);
+      bk[t] = tab[home[t]];
     }
+    int jj[kProbesPerLane];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (jj[u] >= 0) {
-        const float4 p = pos4[jj[u]];
-        const float ax = fsub(p.x, x), ay = fsub(p.y, y), az = fsub(p.z, z);
-        const float d2 = fadd(fadd(fmul(ax, ax), fmul(ay, ay)), fmul(az, az));
-        if (!(d2 > mv.max_valid_dist2)) {  // np.py:1016-1020
-          c.insert(d2, jj[u]);
-          ++nvalid;
-        }
+    for (int t = 0; t < kProbesPerLane; ++t)
+      jj[t] = (slot[t] == -2) ? -1 : tab_resolve(tab, mv.log2cap, slot[t], home[t], bk[t]);
+    float4 pp[kProbesPerLane];
+#pragma unroll
+    for (int t = 0; t < kProbesPerLane; ++t) pp[t] = pos4[jj[t] >= 0 ? jj[t] : 0];
+#pragma unroll
+    for (int t = 0; t < kProbesPerLane; ++t) {
+      const float ax = fsub(pp[t].x, x), ay = fsub(pp[t].y, y), az = fsub(pp[t].z, z);
+      const float d2 = fadd(fadd(fmul(ax, ax), fmul(ay, ay)), fmul(az, az));
+      if (jj[t] >= 0 && !(d2 > mv.max_valid_dist2)) {  // np.py:1016-1020
+        c.insert(d2, jj[t]);
+        ++nvalid;
       }
     }
   }
@@ -244,6 +269,13 @@ __device__ __forceinline__ void stage_mlp(MlpLds& s, const float* W1, const floa
   }
   if (threadIdx.x == 0) s.w[CLID_MLP_PARAMS - 1] = b2[0];
   __syncthreads();
+}
+// weights + probe deltas with ONE barrier
+__device__ __forceinline__ void stage_mlp_and_delta(MlpLds& s, DeltaLds& dl, const clid_map_view& mv,
+                                                    const float* W1, const float* b1, const float* W2,
+                                                    const float* b2) {
+  stage_delta(dl, mv);
+  stage_mlp(s, W1, b1, W2, b2);  // ends with __syncthreads()
 }
 // lane16 owns hidden units h = lane16 + 16*u, u = 0..3
 __device__ __forceinline__ float mlp_forward(const MlpLds& s, const float (&f)[CLID_D], int lane16,

@@ -15,7 +15,7 @@ __global__ void k_radius_search(clid_map_view mv, const float* __restrict__ x, i
   const float px = x[n * 3 + 0], py = x[n * 3 + 1], pz = x[n * 3 + 2];
   int slot = base_slot(px, py, pz, mv.resolution, mv.buffer_size) + mv.delta[o];
   if (slot >= mv.buffer_size) slot -= mv.buffer_size;
-  int j = tab_lookup(reinterpret_cast<const int2*>(mv.tab), mv.log2cap, slot);
+  int j = tab_lookup(reinterpret_cast<const int4*>(mv.tab), mv.log2cap, slot);
   float d2 = mv.max_valid_dist2;  // np.py:1013
   if (j >= 0) {
     const float4 p = reinterpret_cast<const float4*>(mv.pos4)[j];
@@ -33,13 +33,16 @@ __global__ void __launch_bounds__(CLID_BLOCK)
 k_query_fwd(clid_map_view mv, const float* __restrict__ x, int N, int weighted_first,
             float* __restrict__ feat_out, float* __restrict__ w_out, int* __restrict__ idx_out,
             int* __restrict__ nn_out, float* __restrict__ cert_out) {
+  __shared__ DeltaLds dl;
+  stage_delta(dl, mv);
+  __syncthreads();
   const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48;
   const int q_raw = blockIdx.x * CLID_QPB + (threadIdx.x >> 4);
   const bool live = q_raw < N;
   const int q = live ? q_raw : (N - 1);
   const float px = x[q * 3 + 0], py = x[q * 3 + 1], pz = x[q * 3 + 2];
   TopK t;
-  search_topk(mv, px, py, pz, lane16, gbase, t);
+  search_topk(mv, dl, px, py, pz, lane16, gbase, t);
   float w[CLID_K], omega[CLID_K];
   idw_weights(t, w, omega);
   const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
@@ -204,14 +207,15 @@ k_sdf_grad_x(clid_map_view mv, const float* W1, const float* b1, const float* W2
              float scale, const float* __restrict__ x, int N, float* __restrict__ sdf_out,
              float* __restrict__ grad_out, int* __restrict__ nn_out, float* __restrict__ cert_out) {
   __shared__ MlpLds mlp;
-  stage_mlp(mlp, W1, b1, W2, b2);
+  __shared__ DeltaLds dl;
+  stage_mlp_and_delta(mlp, dl, mv, W1, b1, W2, b2);
   const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48;
   const int q_raw = blockIdx.x * CLID_QPB + (threadIdx.x >> 4);
   const bool live = q_raw < N;
   const int q = live ? q_raw : (N - 1);
   const float px = x[q * 3 + 0], py = x[q * 3 + 1], pz = x[q * 3 + 2];
   TopK t;
-  search_topk(mv, px, py, pz, lane16, gbase, t);
+  search_topk(mv, dl, px, py, pz, lane16, gbase, t);
   float w[CLID_K], omega[CLID_K];
   idw_weights(t, w, omega);
   const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
@@ -285,8 +289,8 @@ k_sdf_grad_x(clid_map_view mv, const float* W1, const float* b1, const float* W2
 }  // namespace clid
 
 static int check_view(const clid_map_view* mv, const char* who) {
-  if (!mv || !mv->tab || !mv->pos4 || !mv->delta || mv->P <= 0 || mv->log2cap < 4 ||
-      mv->buffer_size <= 0) {
+  if (!mv || !mv->tab || !mv->pos4 || !mv->delta || mv->P <= 0 || mv->P > clid::kMaxProbes ||
+      mv->log2cap < 4 || mv->buffer_size <= 0) {
     clid_set_error("%s: incomplete map view", who);
     return CLID_E_ARG;
   }

@@ -15,7 +15,7 @@ namespace clid {
 __global__ void k_table_build(const int64_t* __restrict__ ids, int n, const float* __restrict__ pts,
                               const int64_t* __restrict__ big, int B, float res,
                               const int* __restrict__ ts_create, const float* __restrict__ travel,
-                              int cur_ts, int time_filtering, float diff_travel, int2* tab,
+                              int cur_ts, int time_filtering, float diff_travel, int4* tab,
                               int log2cap, float4* pos4) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
@@ -28,12 +28,18 @@ __global__ void k_table_build(const int64_t* __restrict__ ids, int n, const floa
     const float gap = fabsf(fsub(travel[cur_ts], travel[ts_create[gi]]));
     if (!(gap < diff_travel)) return;
   }
+  // 2-entry buckets: claim key0, else key1, else walk to the next bucket
   const unsigned mask = (1u << log2cap) - 1u;
   unsigned pos = tab_home(slot, log2cap);
+  int* cells = reinterpret_cast<int*>(tab);
   for (;;) {
-    const int old = atomicCAS(&tab[pos].x, -1, slot);
-    if (old == -1) {
-      tab[pos].y = j;
+    int* b = cells + (size_t)pos * 4;
+    if (atomicCAS(&b[0], -1, slot) == -1) {
+      b[1] = j;
+      return;
+    }
+    if (atomicCAS(&b[2], -1, slot) == -1) {
+      b[3] = j;
       return;
     }
     pos = (pos + 1) & mask;
@@ -52,19 +58,19 @@ extern "C" int clid_table_build(const int64_t* ids, int32_t n, const float* neur
                    (long long)buffer_size);
     return CLID_E_ARG;
   }
-  if ((1LL << log2cap) < 2LL * n) {
-    clid_set_error("clid_table_build: table capacity 2^%d < 2*n (n=%d)", log2cap, n);
+  if ((2LL << log2cap) < 2LL * n) {
+    clid_set_error("clid_table_build: table capacity 2*2^%d < 2*n (n=%d)", log2cap, n);
     return CLID_E_ARG;
   }
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(tab_out, 0xFF, sizeof(int32_t) * 2 * ((size_t)1 << log2cap), s) != hipSuccess) {
+  if (hipMemsetAsync(tab_out, 0xFF, sizeof(int32_t) * 4 * ((size_t)1 << log2cap), s) != hipSuccess) {
     clid_set_error("clid_table_build: memset failed");
     return CLID_E_HIP;
   }
   if (n == 0) return CLID_OK;
   hipLaunchKernelGGL(clid::k_table_build, dim3((n + 255) / 256), dim3(256), 0, s, ids, n, neural_points,
                      buffer_pt_index, (int)buffer_size, resolution, point_ts_create, travel_dist, cur_ts,
-                     time_filtering, diff_travel, reinterpret_cast<int2*>(tab_out), log2cap,
+                     time_filtering, diff_travel, reinterpret_cast<int4*>(tab_out), log2cap,
                      reinterpret_cast<float4*>(pos4_out));
   CLID_CHECK_LAUNCH();
   return CLID_OK;

@@ -76,7 +76,8 @@ __device__ __forceinline__ QueryId decode_query(int q, int bs, int n_fd, int fir
 __global__ void __launch_bounds__(CLID_BLOCK)
 k_train_fwd(clid_map_view mv, clid_train_args ta, TrainWs ws, int Q, int n_fd, int first) {
   __shared__ MlpLds mlp;
-  stage_mlp(mlp, ta.W1, ta.b1, ta.W2, ta.b2);
+  __shared__ DeltaLds dl;
+  stage_mlp_and_delta(mlp, dl, mv, ta.W1, ta.b1, ta.W2, ta.b2);
   const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48;
   const int q_raw = blockIdx.x * CLID_QPB + (threadIdx.x >> 4);
   const bool live = q_raw < Q;
@@ -89,7 +90,13 @@ k_train_fwd(clid_map_view mv, clid_train_args ta, TrainWs ws, int Q, int n_fd, i
   if (id.axis == 2) pz = fadd(pz, id.sign * ta.fd_eps);
 
   TopK t;
-  search_topk(mv, px, py, pz, lane16, gbase, t);
+  if (ta.debug_flags & 4) {
+    t.nn = 0;
+#pragma unroll
+    for (int k = 0; k < CLID_K; ++k) { t.j[k] = (k < 5) ? ((q * 7 + k * 131) % mv.M) : -1; t.d2[k] = 0.5f + k; }
+  } else {
+    search_topk(mv, dl, px, py, pz, lane16, gbase, t);
+  }
   float w[CLID_K], omega[CLID_K];
   idw_weights(t, w, omega);
   const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
@@ -131,7 +138,7 @@ k_train_fwd(clid_map_view mv, clid_train_args ta, TrainWs ws, int Q, int n_fd, i
     if (lane16 < CLID_K) {
       ws.w[(size_t)q * CLID_K + lane16] = mw;
       ws.idx[(size_t)q * CLID_K + lane16] = mj;
-      if (mj >= 0) {  // training_mode side effects (np.py:708-733)
+      if (mj >= 0 && !(ta.debug_flags & 1)) {  // training_mode side effects (np.py:708-733)
         atomicAdd(&mv.cert[mj], mw);
         if (id.axis < 0 && mv.ts_update) atomicMax(&mv.ts_update[mj], ta.pool_ts[s]);
       }
@@ -140,87 +147,54 @@ k_train_fwd(clid_map_view mv, clid_train_args ta, TrainWs ws, int Q, int n_fd, i
   }
 }
 
-// block-level reduction of the per-lane decoder-gradient accumulators into partial[blockIdx.x]
+// ---- decoder-gradient accumulation -------------------------------------------------------------------
+// dW1 [64 x 11] = sum_q dh_q (x) f_q is a GEMM whose reduction runs over the QUERIES, so it goes on the
+// matrix cores: v_mfma_f32_16x16x4_f32 (exact fp32, == an fmaf chain) with
+//   A[i = lane&15][k = lane>>4] = dh of hidden unit 16u + i of query k   (the lane's own dh[u])
+//   B[k = lane>>4][j = lane&15] = f_j of query k, j < 11;  1 for j == 11 (=> column 11 accumulates db1)
+// i.e. one instruction per 16-hidden tile consumes the 4 queries of the wave with no data movement, and
+// the accumulator D[row = 4*(lane>>4) + r][col = lane&15] is already summed over the wave's queries.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 struct MlpAcc {
-  float dW1[CLID_HPL][CLID_D];
-  float db1[CLID_HPL];
-  float dW2[CLID_HPL];
-  float db2;
+  f32x4 dW1[CLID_HPL];   // tile u: hidden 16u + 4*(lane>>4) + r, column lane&15 (0..10 dW1, 11 db1)
+  float dW2[CLID_HPL];   // hidden lane16 + 16u, this group's queries only
+  float db2;             // lane16 == 0 only
   __device__ __forceinline__ void zero() {
 #pragma unroll
     for (int u = 0; u < CLID_HPL; ++u) {
-#pragma unroll
-      for (int c = 0; c < CLID_D; ++c) dW1[u][c] = 0.f;
-      db1[u] = 0.f;
+      dW1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       dW2[u] = 0.f;
     }
     db2 = 0.f;
   }
 };
 
+constexpr int kRedFloats = CLID_MLP_PARAMS + 3;  // 833 grads | bce | eik | pad
+
+// accumulate the wave's values into the block's LDS sums (ds_add_f32), then one coalesced store
 __device__ __forceinline__ void flush_mlp_acc(const MlpAcc& acc, float bce, float eik, float* red /*LDS*/,
                                               float* __restrict__ out /* [kPartialStride] */) {
-  // red: [waves][16][56]
-  constexpr int kPer = 56;
-  const int lane = threadIdx.x & 63, lane16 = lane & 15, wave = threadIdx.x >> 6;
-  const int nw = blockDim.x >> 6;
-  float* mine = red + ((size_t)wave * CLID_G + lane16) * kPer;
-  int n = 0;
+  const int lane = threadIdx.x & 63, lane16 = lane & 15, grp = lane >> 4;
+  for (int i = threadIdx.x; i < kRedFloats; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
 #pragma unroll
   for (int u = 0; u < CLID_HPL; ++u) {
 #pragma unroll
-    for (int c = 0; c < CLID_D; ++c) {
-      const float v = cross_group_sum(acc.dW1[u][c]);
-      if (lane < CLID_G) mine[n] = v;
-      ++n;
+    for (int r = 0; r < 4; ++r) {
+      const int h = CLID_G * u + 4 * grp + r;
+      if (lane16 < CLID_D) atomicAdd(&red[h * CLID_D + lane16], acc.dW1[u][r]);
+      else if (lane16 == CLID_D) atomicAdd(&red[CLID_H * CLID_D + h], acc.dW1[u][r]);
     }
+    atomicAdd(&red[CLID_H * CLID_D + CLID_H + lane16 + CLID_G * u], acc.dW2[u]);
   }
-#pragma unroll
-  for (int u = 0; u < CLID_HPL; ++u) {
-    const float v = cross_group_sum(acc.db1[u]);
-    if (lane < CLID_G) mine[n] = v;
-    ++n;
-  }
-#pragma unroll
-  for (int u = 0; u < CLID_HPL; ++u) {
-    const float v = cross_group_sum(acc.dW2[u]);
-    if (lane < CLID_G) mine[n] = v;
-    ++n;
-  }
-  {
-    const float v = cross_group_sum(acc.db2);  // db2/bce/eik are carried by lane16 == 0 only
-    if (lane < CLID_G) mine[n] = v;
-    ++n;
-    const float vb = cross_group_sum(bce);
-    if (lane < CLID_G) mine[n] = vb;
-    ++n;
-    const float ve = cross_group_sum(eik);
-    if (lane < CLID_G) mine[n] = ve;
-    ++n;
+  if (lane16 == 0) {
+    atomicAdd(&red[CLID_MLP_PARAMS - 1], acc.db2);
+    atomicAdd(&red[CLID_MLP_PARAMS], bce);
+    atomicAdd(&red[CLID_MLP_PARAMS + 1], eik);
   }
   __syncthreads();
-  for (int p = threadIdx.x; p < CLID_MLP_PARAMS + 2; p += blockDim.x) {
-    int l16, slot;
-    if (p < CLID_H * CLID_D) {
-      const int h = p / CLID_D, c = p - h * CLID_D;
-      l16 = h & 15;
-      slot = (h >> 4) * CLID_D + c;
-    } else if (p < CLID_H * CLID_D + CLID_H) {
-      const int h = p - CLID_H * CLID_D;
-      l16 = h & 15;
-      slot = CLID_HPL * CLID_D + (h >> 4);
-    } else if (p < CLID_H * CLID_D + 2 * CLID_H) {
-      const int h = p - CLID_H * CLID_D - CLID_H;
-      l16 = h & 15;
-      slot = CLID_HPL * CLID_D + CLID_HPL + (h >> 4);
-    } else {
-      l16 = 0;
-      slot = CLID_HPL * CLID_D + 2 * CLID_HPL + (p - (CLID_MLP_PARAMS - 1));
-    }
-    float s = 0.f;
-    for (int wv = 0; wv < nw; ++wv) s += red[((size_t)wv * CLID_G + l16) * kPer + slot];
-    out[p] = s;
-  }
+  for (int i = threadIdx.x; i < CLID_MLP_PARAMS + 2; i += blockDim.x) out[i] = red[i];
 }
 
 // decoder backward for one query given dz = scale * dL/dsdf; returns df (replicated)
@@ -233,14 +207,17 @@ __device__ __forceinline__ void mlp_backward(const MlpLds& s, const float (&f)[C
     const int h = lane16 + CLID_G * u;
     const bool on = pre[u] > 0.f;
     dh[u] = on ? dz * s.w[CLID_H * CLID_D + CLID_H + h] : 0.f;
-    if (train_decoder) {
-      acc.dW2[u] += on ? dz * pre[u] : 0.f;
-      acc.db1[u] += dh[u];
-#pragma unroll
-      for (int c = 0; c < CLID_D; ++c) acc.dW1[u][c] = fmaf(dh[u], f[c], acc.dW1[u][c]);
-    }
+    if (train_decoder) acc.dW2[u] += on ? dz * pre[u] : 0.f;
   }
-  if (train_decoder && lane16 == 0) acc.db2 += dz;
+  if (train_decoder) {
+    float fb = (lane16 == CLID_D) ? 1.0f : 0.f;
+#pragma unroll
+    for (int c = 0; c < CLID_D; ++c) fb = (lane16 == c) ? f[c] : fb;
+#pragma unroll
+    for (int u = 0; u < CLID_HPL; ++u)
+      acc.dW1[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[u], fb, acc.dW1[u], 0, 0, 0);
+    if (lane16 == 0) acc.db2 += dz;
+  }
 #pragma unroll
   for (int c = 0; c < CLID_D; ++c) {
     float part = 0.f;
@@ -253,7 +230,7 @@ __device__ __forceinline__ void mlp_backward(const MlpLds& s, const float (&f)[C
 __global__ void __launch_bounds__(CLID_BLOCK)
 k_train_bwd(clid_map_view mv, clid_train_args ta, TrainWs ws, int Q, int n_fd, int first, int n_groups_total) {
   __shared__ MlpLds mlp;
-  __shared__ float red[(CLID_BLOCK / 64) * CLID_G * 56];
+  __shared__ float red[kRedFloats + 1];
   stage_mlp(mlp, ta.W1, ta.b1, ta.W2, ta.b2);
   const int lane = threadIdx.x & 63, lane16 = lane & 15;
   MlpAcc acc;
@@ -305,7 +282,7 @@ k_train_bwd(clid_map_view mv, clid_train_args ta, TrainWs ws, int Q, int n_fd, i
     mlp_backward(mlp, f, pre, ta.sdf_scale * delta, lane16, ta.train_decoder != 0, acc, df);
 
     // d theta[j_k] += w_k * df[0:F]  (through the layer-norm backward when on)
-    if (live && delta != 0.f) {
+    if (live && delta != 0.f && !(ta.debug_flags & 2)) {
       if (!mv.layer_norm) {
         float dfc = 0.f;
 #pragma unroll
@@ -342,100 +319,217 @@ k_train_bwd(clid_map_view mv, clid_train_args ta, TrainWs ws, int Q, int n_fd, i
       }
     }
   }
-  flush_mlp_acc(acc, bce_acc, eik_acc, red, ws.partial + (size_t)blockIdx.x * kPartialStride);
+  if (!(ta.debug_flags & 8)) flush_mlp_acc(acc, bce_acc, eik_acc, red, ws.partial + (size_t)blockIdx.x * kPartialStride);
+  else if (acc.db2 + acc.dW1[0][0] + acc.dW1[3][3] + acc.dW2[1] == 123.456f) ws.partial[0] = bce_acc + eik_acc;
 }
 
-// partial[nb][840] -> grad[0:833] (=), loss_out[0..2] (+=)
-__global__ void k_reduce_partials(const float* __restrict__ partial, int nb, float* __restrict__ grad,
-                                  float* __restrict__ loss_out, float inv_n_main, float inv_n_eik,
-                                  float weight_e, int train_decoder) {
-  __shared__ float sm[4][64];
-  const int px = threadIdx.x & 63, py = threadIdx.x >> 6;
-  const int p = blockIdx.x * 64 + px;
-  float s = 0.f;
-  if (p < CLID_MLP_PARAMS + 2)
-    for (int b = py; b < nb; b += 4) s += partial[(size_t)b * kPartialStride + p];
-  sm[py][px] = s;
-  __syncthreads();
-  if (py == 0 && p < CLID_MLP_PARAMS + 2) {
-    const float tot = sm[0][px] + sm[1][px] + sm[2][px] + sm[3][px];
-    if (p < CLID_MLP_PARAMS) {
-      if (train_decoder) grad[p] = tot;
-    } else if (p == CLID_MLP_PARAMS) {
-      const float bce = tot * inv_n_main;
-      atomicAdd(&loss_out[1], bce);
-      atomicAdd(&loss_out[0], bce);
-    } else {
-      const float eik = tot * inv_n_eik;
-      atomicAdd(&loss_out[2], eik);
-      atomicAdd(&loss_out[0], weight_e * eik);
-    }
-  }
-}
-
+// ---- partial reduction + Adam ---------------------------------------------------------------------------
 // torch.optim.Adam._single_tensor_adam, op order as ATen's:
 //   m.lerp_(g, 1-b1); v.mul_(b2).addcmul_(g, g, 1-b2); denom = sqrt(v)/sqrt(bc2) + eps;
 //   p.addcdiv_(m, denom, -lr/bc1)
-__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float one_m_b1, float b2,
-                                            float one_m_b2, float bc2_sqrt, float eps, float neg_step,
-                                            float wd) {
+struct AdamK {
+  float one_m_b1, b2, one_m_b2, bc2_sqrt, eps, neg_step, wd;
+};
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, const AdamK& k, float wd) {
   if (wd != 0.f) g = fmaf(wd, p, g);
-  m = fadd(m, fmul(one_m_b1, fsub(g, m)));
-  v = fadd(fmul(v, b2), fmul(fmul(one_m_b2, g), g));
-  const float denom = fadd(fdiv(sqrtf(v), bc2_sqrt), eps);
-  p = fadd(p, fdiv(fmul(neg_step, m), denom));
+  m = fadd(m, fmul(k.one_m_b1, fsub(g, m)));
+  v = fadd(fmul(v, k.b2), fmul(fmul(k.one_m_b2, g), g));
+  const float denom = fadd(fdiv(sqrtf(v), k.bc2_sqrt), k.eps);
+  p = fadd(p, fdiv(fmul(k.neg_step, m), denom));
 }
 
-__global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                       float* __restrict__ v, long long n, float one_m_b1, float b2, float one_m_b2,
-                       float bc2_sqrt, float eps, float neg_step, float wd, int zero_grad) {
-  const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i4 + 3 < n) {
-    float4 P = *reinterpret_cast<float4*>(p + i4), G = *reinterpret_cast<float4*>(g + i4);
-    float4 M = *reinterpret_cast<float4*>(m + i4), V = *reinterpret_cast<float4*>(v + i4);
-    adam_update(P.x, G.x, M.x, V.x, one_m_b1, b2, one_m_b2, bc2_sqrt, eps, neg_step, wd);
-    adam_update(P.y, G.y, M.y, V.y, one_m_b1, b2, one_m_b2, bc2_sqrt, eps, neg_step, wd);
-    adam_update(P.z, G.z, M.z, V.z, one_m_b1, b2, one_m_b2, bc2_sqrt, eps, neg_step, wd);
-    adam_update(P.w, G.w, M.w, V.w, one_m_b1, b2, one_m_b2, bc2_sqrt, eps, neg_step, wd);
-    *reinterpret_cast<float4*>(p + i4) = P;
-    *reinterpret_cast<float4*>(m + i4) = M;
-    *reinterpret_cast<float4*>(v + i4) = V;
-    if (zero_grad) *reinterpret_cast<float4*>(g + i4) = make_float4(0.f, 0.f, 0.f, 0.f);
-  } else {
-    for (long long i = i4; i < n; ++i) {
-      float P = p[i], M = m[i], V = v[i];
-      adam_update(P, g[i], M, V, one_m_b1, b2, one_m_b2, bc2_sqrt, eps, neg_step, wd);
-      p[i] = P; m[i] = M; v[i] = V;
-      if (zero_grad) g[i] = 0.f;
+__device__ __forceinline__ float* mlp_param_ptr(float* W1, float* b1, float* W2, float* b2, int i) {
+  if (i < CLID_H * CLID_D) return W1 + i;
+  if (i < CLID_H * CLID_D + CLID_H) return b1 + (i - CLID_H * CLID_D);
+  if (i < CLID_H * CLID_D + 2 * CLID_H) return W2 + (i - CLID_H * CLID_D - CLID_H);
+  return b2;
+}
+
+// sum of column p over the nb partial rows; 16 x 16 thread tile: threadIdx = (py, px), 16 columns / block
+__device__ __forceinline__ float column_sum16(const float* __restrict__ partial, int nb, int col0, float* sm) {
+  const int px = threadIdx.x & 15, py = threadIdx.x >> 4;
+  const int p = col0 + px;
+  float s0 = 0.f, s1 = 0.f;
+  if (p < CLID_MLP_PARAMS + 2) {
+    int b = py;
+    for (; b + 16 < nb; b += 32) {
+      s0 += partial[(size_t)b * kPartialStride + p];
+      s1 += partial[(size_t)(b + 16) * kPartialStride + p];
     }
+    if (b < nb) s0 += partial[(size_t)b * kPartialStride + p];
+  }
+  sm[threadIdx.x] = s0 + s1;
+  __syncthreads();
+  float tot = 0.f;
+  if (py == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tot += sm[r * 16 + px];
+  }
+  return tot;  // valid for py == 0
+}
+
+__device__ __forceinline__ void finish_loss(int p, float tot, float* loss_out, float inv_n_main, float inv_n_eik,
+                                            float weight_e) {
+  if (p == CLID_MLP_PARAMS) {
+    const float bce = tot * inv_n_main;
+    atomicAdd(&loss_out[1], bce);
+    atomicAdd(&loss_out[0], bce);
+  } else if (p == CLID_MLP_PARAMS + 1) {
+    const float eik = tot * inv_n_eik;
+    atomicAdd(&loss_out[2], eik);
+    atomicAdd(&loss_out[0], weight_e * eik);
   }
 }
 
-// the 833 decoder parameters live in four separate tensors (nn.Linear weights/biases)
-__global__ void k_adam_mlp(float* W1, float* b1, float* W2, float* b2, float* __restrict__ g,
-                           float* __restrict__ m, float* __restrict__ v, float one_m_b1, float b2c,
-                           float one_m_b2, float bc2_sqrt, float eps, float neg_step) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= CLID_MLP_PARAMS) return;
-  float* dst;
-  if (i < CLID_H * CLID_D) dst = W1 + i;
-  else if (i < CLID_H * CLID_D + CLID_H) dst = b1 + (i - CLID_H * CLID_D);
-  else if (i < CLID_H * CLID_D + 2 * CLID_H) dst = W2 + (i - CLID_H * CLID_D - CLID_H);
-  else dst = b2;
-  float P = *dst, M = m[i], V = v[i];
-  adam_update(P, g[i], M, V, one_m_b1, b2c, one_m_b2, bc2_sqrt, eps, neg_step, 0.f);
-  *dst = P; m[i] = M; v[i] = V;
-  g[i] = 0.f;
+// multi-GPU path: partial[nb][840] -> grad[0:833] (=), loss_out (+=), so the host can all-reduce `grad`
+__global__ void __launch_bounds__(256)
+k_reduce_partials(const float* __restrict__ partial, int nb, float* __restrict__ grad,
+                  float* __restrict__ loss_out, float inv_n_main, float inv_n_eik, float weight_e,
+                  int train_decoder) {
+  __shared__ float sm[256];
+  const int col0 = blockIdx.x * 16;
+  const float tot = column_sum16(partial, nb, col0, sm);
+  const int p = col0 + (threadIdx.x & 15);
+  if ((threadIdx.x >> 4) != 0 || p >= CLID_MLP_PARAMS + 2) return;
+  if (p < CLID_MLP_PARAMS) {
+    if (train_decoder) grad[p] = tot;
+  } else {
+    finish_loss(p, tot, loss_out, inv_n_main, inv_n_eik, weight_e);
+  }
+}
+
+struct AdamLaunch {
+  float* feat; float* grad; float* m; float* v; long long n_feat;
+  float* W1; float* b1; float* W2; float* b2; float* m_mlp; float* v_mlp;
+  const float* partial; int nb;           // non-null: decoder grads / loss sums come from the partial rows
+  float* loss_out; float inv_n_main, inv_n_eik, weight_e;
+  int train_decoder; int n_feat_blocks;
+  AdamK k;
+};
+
+// blocks [0, n_feat_blocks): dense Adam over the feature table (float4), gradient zeroed in the same pass
+// blocks [n_feat_blocks, +53):  16 decoder parameters each (reduce partial rows or read grad), Adam
+__global__ void __launch_bounds__(256) k_adam_all(AdamLaunch a) {
+  __shared__ float sm[256];
+  if ((int)blockIdx.x < a.n_feat_blocks) {
+    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    float* g = a.grad + CLID_GRAD_FEAT_OFFSET;
+    if (i4 + 3 < a.n_feat) {
+      float4 P = *reinterpret_cast<float4*>(a.feat + i4), G = *reinterpret_cast<float4*>(g + i4);
+      float4 M = *reinterpret_cast<float4*>(a.m + i4), V = *reinterpret_cast<float4*>(a.v + i4);
+      adam_update(P.x, G.x, M.x, V.x, a.k, a.k.wd);
+      adam_update(P.y, G.y, M.y, V.y, a.k, a.k.wd);
+      adam_update(P.z, G.z, M.z, V.z, a.k, a.k.wd);
+      adam_update(P.w, G.w, M.w, V.w, a.k, a.k.wd);
+      *reinterpret_cast<float4*>(a.feat + i4) = P;
+      *reinterpret_cast<float4*>(a.m + i4) = M;
+      *reinterpret_cast<float4*>(a.v + i4) = V;
+      *reinterpret_cast<float4*>(g + i4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      for (long long i = i4; i < a.n_feat; ++i) {
+        float P = a.feat[i], M = a.m[i], V = a.v[i];
+        adam_update(P, g[i], M, V, a.k, a.k.wd);
+        a.feat[i] = P; a.m[i] = M; a.v[i] = V; g[i] = 0.f;
+      }
+    }
+    return;
+  }
+  const int col0 = ((int)blockIdx.x - a.n_feat_blocks) * 16;
+  const int p = col0 + (threadIdx.x & 15);
+  float gsum;
+  if (a.partial) {
+    gsum = column_sum16(a.partial, a.nb, col0, sm);
+  } else {
+    gsum = (p < CLID_MLP_PARAMS) ? a.grad[p] : 0.f;
+  }
+  if ((threadIdx.x >> 4) != 0 || p >= CLID_MLP_PARAMS + 2) return;
+  if (p < CLID_MLP_PARAMS) {
+    if (a.train_decoder) {
+      float* dst = mlp_param_ptr(a.W1, a.b1, a.W2, a.b2, p);
+      float P = *dst, M = a.m_mlp[p], V = a.v_mlp[p];
+      adam_update(P, gsum, M, V, a.k, 0.f);
+      *dst = P; a.m_mlp[p] = M; a.v_mlp[p] = V;
+    }
+    a.grad[p] = 0.f;
+  } else if (a.partial) {
+    finish_loss(p, gsum, a.loss_out, a.inv_n_main, a.inv_n_eik, a.weight_e);
+  }
+}
+
+// stand-alone elementwise Adam (clid_adam_step)
+__global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, long long n, AdamK k, int zero_grad) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float P = p[i], M = m[i], V = v[i];
+    adam_update(P, g[i], M, V, k, k.wd);
+    p[i] = P; m[i] = M; v[i] = V;
+    if (zero_grad) g[i] = 0.f;
+  }
 }
 
 }  // namespace clid
 
 using namespace clid;
 
+// ---- optional per-kernel timing (bench.py roofline leg): hipEvents on the launch stream ------------
+#include <vector>
+namespace {
+bool g_prof = false;
+std::vector<hipEvent_t> g_ev;  // groups of 6: before fwd, after fwd, after bwd, after reduce, before adam, after adam
+hipEvent_t prof_mark(hipStream_t s) {
+  hipEvent_t e;
+  hipEventCreate(&e);
+  hipEventRecord(e, s);
+  g_ev.push_back(e);
+  return e;
+}
+}  // namespace
+
+extern "C" int clid_profile_enable(int on) {
+  for (hipEvent_t e : g_ev) hipEventDestroy(e);
+  g_ev.clear();
+  g_prof = on != 0;
+  return CLID_OK;
+}
+
+// sums of elapsed ms per kernel over all recorded iterations: out[0..3] = fwd, bwd, reduce, adam;
+// out[4] = back-to-back event-pair overhead (ms, mean) measured now; *iters = iterations recorded
+extern "C" int clid_profile_read(double* out, int* iters, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (hipStreamSynchronize(s) != hipSuccess) return CLID_E_HIP;
+  for (int i = 0; i < 5; ++i) out[i] = 0.0;
+  const size_t n = g_ev.size() / 6;
+  for (size_t i = 0; i < n; ++i) {
+    float ms;
+    const hipEvent_t* e = &g_ev[i * 6];
+    hipEventElapsedTime(&ms, e[0], e[1]); out[0] += ms;
+    hipEventElapsedTime(&ms, e[1], e[2]); out[1] += ms;
+    hipEventElapsedTime(&ms, e[2], e[3]); out[2] += ms;
+    hipEventElapsedTime(&ms, e[4], e[5]); out[3] += ms;
+  }
+  *iters = (int)n;
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  double acc = 0.0;
+  for (int r = 0; r < 32; ++r) {
+    hipEventRecord(a, s); hipEventRecord(b, s);
+    hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); acc += ms;
+  }
+  out[4] = acc / 32.0;
+  hipEventDestroy(a); hipEventDestroy(b);
+  return CLID_OK;
+}
+
 static int n_queries(const clid_train_args* a, int* n_fd, int* first) {
   *first = fd_first(a->batch_offset, a->decimation);
   *n_fd = (a->eikonal_mode == 1) ? fd_count(a->bs, a->batch_offset, a->decimation) : 0;
   return a->bs + 6 * (*n_fd);
+}
+
+static int bwd_blocks(int Q) {
+  int nb = (Q + CLID_QPB - 1) / CLID_QPB;
+  return nb > kMaxBwdBlocks ? kMaxBwdBlocks : nb;
 }
 
 extern "C" int64_t clid_train_workspace_floats(int32_t bs, int32_t decimation, int32_t eikonal_mode) {
@@ -450,12 +544,16 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
     clid_set_error("clid_train_fwd_bwd: null argument");
     return CLID_E_ARG;
   }
+  if (mv->P > kMaxProbes) {
+    clid_set_error("clid_train_fwd_bwd: neighbourhood of %d cells exceeds the supported %d", mv->P, kMaxProbes);
+    return CLID_E_SHAPE;
+  }
   if (a->bs <= 0 || a->decimation <= 0) {
     clid_set_error("clid_train_fwd_bwd: bs=%d decimation=%d", a->bs, a->decimation);
     return CLID_E_ARG;
   }
   if (a->eikonal_mode == 2) {
-    clid_set_error("clid_train_fwd_bwd: analytic eikonal mode is served by clid_train_fwd_bwd_analytic");
+    clid_set_error("clid_train_fwd_bwd: analytic eikonal mode is not served by this entry point");
     return CLID_E_ARG;
   }
   hipStream_t s = (hipStream_t)stream;
@@ -463,26 +561,38 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
   const int Q = n_queries(a, &n_fd, &first);
   TrainWs ws = carve(a->ws, Q);
   const int n_groups = (Q + CLID_QPB - 1) / CLID_QPB * CLID_QPB;  // padded to whole blocks
+  if (g_prof) prof_mark(s);
   hipLaunchKernelGGL(k_train_fwd, dim3(n_groups / CLID_QPB), dim3(CLID_BLOCK), 0, s, *mv, *a, ws, Q,
                      n_fd > 0 ? n_fd : 1, first);
   CLID_CHECK_LAUNCH();
-  int nb = n_groups / CLID_QPB;
-  if (nb > kMaxBwdBlocks) nb = kMaxBwdBlocks;
+  if (g_prof) prof_mark(s);
+  const int nb = bwd_blocks(Q);
   hipLaunchKernelGGL(k_train_bwd, dim3(nb), dim3(CLID_BLOCK), 0, s, *mv, *a, ws, Q, n_fd > 0 ? n_fd : 1,
                      first, n_groups);
   CLID_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_reduce_partials, dim3((CLID_MLP_PARAMS + 2 + 63) / 64), dim3(256), 0, s, ws.partial,
-                     nb, a->grad, a->loss_out, a->inv_n_main, a->inv_n_eik,
-                     (a->eikonal_mode && n_fd > 0) ? a->weight_e : 0.f, a->train_decoder);
-  CLID_CHECK_LAUNCH();
+  if (g_prof) prof_mark(s);
+  if (!a->defer_reduce) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3((CLID_MLP_PARAMS + 2 + 15) / 16), dim3(256), 0, s, ws.partial,
+                       nb, a->grad, a->loss_out, a->inv_n_main, a->inv_n_eik,
+                       (a->eikonal_mode && n_fd > 0) ? a->weight_e : 0.f, a->train_decoder);
+    CLID_CHECK_LAUNCH();
+  }
+  if (g_prof) prof_mark(s);
   return CLID_OK;
 }
 
-static void adam_scalars(float lr, float b1, float b2, int step, float* neg_step, float* bc2_sqrt) {
+static AdamK adam_scalars(float lr, float b1, float b2, float eps, float wd, int step) {
   const double bc1 = 1.0 - pow((double)b1, (double)step);
   const double bc2 = 1.0 - pow((double)b2, (double)step);
-  *neg_step = (float)(-((double)lr / bc1));
-  *bc2_sqrt = (float)sqrt(bc2);
+  AdamK k;
+  k.one_m_b1 = (float)(1.0 - (double)b1);
+  k.b2 = b2;
+  k.one_m_b2 = (float)(1.0 - (double)b2);
+  k.bc2_sqrt = (float)sqrt(bc2);
+  k.eps = eps;
+  k.neg_step = (float)(-((double)lr / bc1));
+  k.wd = wd;
+  return k;
 }
 
 extern "C" int clid_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1,
@@ -493,39 +603,45 @@ extern "C" int clid_adam_step(float* p, float* g, float* m, float* v, int64_t n,
     return CLID_E_ARG;
   }
   if (n == 0) return CLID_OK;
-  float neg_step, bc2_sqrt;
-  adam_scalars(lr, beta1, beta2, step, &neg_step, &bc2_sqrt);
-  const long long thr = (n + 3) / 4;
-  hipLaunchKernelGGL(k_adam, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m,
-                     v, (long long)n, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2),
-                     bc2_sqrt, eps, neg_step, weight_decay, zero_grad);
+  long long nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
+                     adam_scalars(lr, beta1, beta2, eps, weight_decay, step), zero_grad);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }
 
-extern "C" int clid_train_adam(const clid_adam_args* a, void* stream) {
+extern "C" int clid_train_adam(const clid_adam_args* a, const clid_train_args* t, void* stream) {
   if (!a || !a->feat || !a->grad || !a->m || !a->v || a->step < 1) {
     clid_set_error("clid_train_adam: bad argument");
     return CLID_E_ARG;
   }
-  hipStream_t s = (hipStream_t)stream;
-  float neg_step, bc2_sqrt;
-  adam_scalars(a->lr, a->beta1, a->beta2, a->step, &neg_step, &bc2_sqrt);
-  const float one_m_b1 = (float)(1.0 - (double)a->beta1), one_m_b2 = (float)(1.0 - (double)a->beta2);
-  if (a->train_decoder) {
-    if (!a->W1 || !a->b1 || !a->W2 || !a->b2 || !a->m_mlp || !a->v_mlp) {
-      clid_set_error("clid_train_adam: decoder tensors missing");
-      return CLID_E_ARG;
-    }
-    hipLaunchKernelGGL(k_adam_mlp, dim3((CLID_MLP_PARAMS + 255) / 256), dim3(256), 0, s, a->W1, a->b1, a->W2,
-                       a->b2, a->grad, a->m_mlp, a->v_mlp, one_m_b1, a->beta2, one_m_b2, bc2_sqrt, a->eps,
-                       neg_step);
-    CLID_CHECK_LAUNCH();
+  if (a->train_decoder && (!a->W1 || !a->b1 || !a->W2 || !a->b2 || !a->m_mlp || !a->v_mlp)) {
+    clid_set_error("clid_train_adam: decoder tensors missing");
+    return CLID_E_ARG;
   }
-  const long long thr = (a->n_feat + 3) / 4;
-  hipLaunchKernelGGL(k_adam, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, s, a->feat,
-                     a->grad + CLID_GRAD_FEAT_OFFSET, a->m, a->v, (long long)a->n_feat, one_m_b1, a->beta2, one_m_b2,
-                     bc2_sqrt, a->eps, neg_step, a->weight_decay, 1);
+  hipStream_t s = (hipStream_t)stream;
+  AdamLaunch L;
+  L.feat = a->feat; L.grad = a->grad; L.m = a->m; L.v = a->v; L.n_feat = a->n_feat;
+  L.W1 = a->W1; L.b1 = a->b1; L.W2 = a->W2; L.b2 = a->b2; L.m_mlp = a->m_mlp; L.v_mlp = a->v_mlp;
+  L.partial = nullptr; L.nb = 0; L.loss_out = nullptr; L.inv_n_main = L.inv_n_eik = L.weight_e = 0.f;
+  if (t && t->defer_reduce) {  // single-GPU: fold the partial reduction of clid_train_fwd_bwd(t) into this launch
+    int n_fd, first;
+    const int Q = n_queries(t, &n_fd, &first);
+    TrainWs ws = carve(t->ws, Q);
+    L.partial = ws.partial;
+    L.nb = bwd_blocks(Q);
+    L.loss_out = t->loss_out;
+    L.inv_n_main = t->inv_n_main;
+    L.inv_n_eik = t->inv_n_eik;
+    L.weight_e = (t->eikonal_mode && n_fd > 0) ? t->weight_e : 0.f;
+  }
+  L.train_decoder = a->train_decoder;
+  L.n_feat_blocks = (int)(((a->n_feat + 3) / 4 + 255) / 256);
+  L.k = adam_scalars(a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->step);
+  if (g_prof) prof_mark(s);
+  hipLaunchKernelGGL(k_adam_all, dim3(L.n_feat_blocks + (CLID_MLP_PARAMS + 2 + 15) / 16), dim3(256), 0, s, L);
   CLID_CHECK_LAUNCH();
+  if (g_prof) prof_mark(s);
   return CLID_OK;
 }

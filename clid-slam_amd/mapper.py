@@ -15,6 +15,7 @@ once per `mapping()` call.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -187,6 +188,8 @@ class Mapper:
         ta.W1, ta.b1, ta.W2, ta.b2 = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr()
         ta.sdf_scale = float(self.geo_mlp.sdf_scale)
         ta.grad, ta.ws = grad.data_ptr(), self._ws.data_ptr()
+        ta.defer_reduce = 0 if dist else 1
+        ta.debug_flags = int(os.environ.get('CLID_DEBUG_FLAGS', '0'))
 
         aa = _lib.AdamArgs()
         aa.feat, aa.grad, aa.m, aa.v = theta.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr()
@@ -207,7 +210,7 @@ class Mapper:
             if dist:
                 dist.all_reduce(grad)
             aa.step = it + 1
-            _lib.check(lib.clid_train_adam(C.byref(aa), stream), "clid_train_adam")
+            _lib.check(lib.clid_train_adam(C.byref(aa), C.byref(ta), stream), "clid_train_adam")
         self.total_iter += iter_count
         if dist:
             # merge the replicas' side effects once per call (not read inside the loop's loss)

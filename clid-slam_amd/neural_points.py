@@ -341,8 +341,8 @@ class NeuralPoints(nn.Module):
             n = ids.shape[0]
         else:
             ids, n = None, self.count()
-        log2cap = max(4, int(math.ceil(math.log2(max(4 * n, 16)))))
-        tab = torch.empty((1 << log2cap, 2), device=pts.device, dtype=torch.int32)
+        log2cap = max(4, int(math.ceil(math.log2(max(2 * n, 16)))))  # 2-entry buckets, load <= 0.25
+        tab = torch.empty((1 << log2cap, 4), device=pts.device, dtype=torch.int32)
         pos4 = torch.empty((max(n, 1), 4), device=pts.device, dtype=torch.float32)
         tsc = self.point_ts_create if time_filtering else None
         trv = self.travel_dist.to(torch.float32).contiguous() if time_filtering else None

@@ -48,7 +48,7 @@ int clid_abi_version(void);
  * compact mirror built by clid_table_build(); the remaining pointers alias the shim's own torch
  * tensors (local_* arrays for query_locally=True, global arrays otherwise). */
 typedef struct clid_map_view {
-  const int32_t* tab;      /* [cap][2] {slot key (-1 empty), point id} open-addressing, cap = 2^log2cap */
+  const int32_t* tab;      /* [2^log2cap][4] buckets {key0,id0,key1,id1}; key = slot number, -1 empty */
   const float* pos4;       /* [M][4] xyz0 of the points addressed by the ids in `tab` */
   float* feat;             /* [(M+1)][F] latent features, last row = padding (np.py:532) */
   float* cert;             /* [M] point certainties (read; +atomicAdd when training_mode) */
@@ -71,7 +71,7 @@ typedef struct clid_map_view {
  * and (no time filtering or |travel[cur_ts]-travel[ts_create[ids[j]]]| < diff_travel).
  *   ids            [n] int64 global point index of local point j, or NULL for identity (global map)
  *   neural_points  [Mg][3], buffer_pt_index [buffer_size] int64, point_ts_create [Mg] int32
- *   tab_out        [2^log2cap][2] int32, pos4_out [n][4]            (tab_out is memset here) */
+ *   tab_out        [2^log2cap][4] int32 (2-entry buckets, 2*2^log2cap >= 2n), pos4_out [n][4] */
 int clid_table_build(const int64_t* ids, int32_t n, const float* neural_points,
                      const int64_t* buffer_pt_index, int64_t buffer_size, float resolution,
                      const int32_t* point_ts_create, const float* travel_dist, int32_t cur_ts,
@@ -149,12 +149,16 @@ typedef struct clid_train_args {
   /* decoder (model/decoder.py) */
   float* W1; float* b1; float* W2; float* b2;
   float sdf_scale;
-  int32_t pad0;
+  int32_t defer_reduce;      /* 1: leave the per-block partials of the 833 decoder gradients / loss sums in `ws`
+                                for clid_train_adam(.., this, ..) to fold into its launch (single GPU);
+                                0: reduce here so `grad` is complete on return (needed before an all-reduce) */
   /* gradients: one contiguous buffer [833 (+3 pad) | (M+1)*F] so a single all-reduce covers it */
   float* grad;
   /* workspace, sized by clid_train_workspace_floats() */
   float* ws;
   float* loss_out;           /* [4] total,bce,eik,unused (+=) */
+  int32_t debug_flags;       /* 0 in production; ablation switches used by tools/ablate.sh */
+  int32_t pad1;
 } clid_train_args;
 
 int64_t clid_train_workspace_floats(int32_t bs, int32_t decimation, int32_t eikonal_mode);
@@ -171,7 +175,15 @@ typedef struct clid_adam_args {
   int32_t train_decoder;
   int32_t pad0;
 } clid_adam_args;
-int clid_train_adam(const clid_adam_args* a, void* stream);
+/* `t` = the args of the clid_train_fwd_bwd call this step belongs to (NULL unless t->defer_reduce) */
+int clid_train_adam(const clid_adam_args* a, const clid_train_args* t, void* stream);
+
+/* ---- measurement aid (bench.py roofline leg; not part of the reference's interface) -----------
+ * When enabled, clid_train_fwd_bwd / clid_train_adam bracket each kernel with hipEvents on the
+ * launch stream.  clid_profile_read synchronises and returns summed elapsed ms per kernel:
+ * out[0..3] = forward, backward, partial-reduce, adam; out[4] = empty event-pair overhead (ms). */
+int clid_profile_enable(int on);
+int clid_profile_read(double* out_host, int* iters_host, void* stream);
 
 #ifdef __cplusplus
 }
