@@ -53,100 +53,6 @@ __host__ inline TrainWs carve(float* ws, int Q) {
   return t;
 }
 
-// query q -> position in the local batch, shifted axis/sign for finite-difference copies
-struct QueryId {
-  int p;     // index into this rank's batch
-  int axis;  // -1 main sample, else 0..2
-  float sign;
-};
-__device__ __forceinline__ QueryId decode_query(int q, int bs, int n_fd, int first, int decim) {
-  QueryId r;
-  if (q < bs) {
-    r.p = q; r.axis = -1; r.sign = 0.f;
-  } else {
-    const int e = q - bs;
-    const int a = e / n_fd;  // 0..5 : +x,-x,+y,-y,+z,-z  (mapper.py:1001)
-    r.p = first + (e - a * n_fd) * decim;
-    r.axis = a >> 1;
-    r.sign = (a & 1) ? -1.f : 1.f;
-  }
-  return r;
-}
-
-__global__ void __launch_bounds__(CLID_BLOCK)
-k_train_fwd(clid_map_view mv, clid_train_args ta, TrainWs ws, int Q, int n_fd, int first) {
-  __shared__ MlpLds mlp;
-  __shared__ DeltaLds dl;
-  stage_mlp_and_delta(mlp, dl, mv, ta.W1, ta.b1, ta.W2, ta.b2);
-  const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48;
-  const int q_raw = blockIdx.x * CLID_QPB + (threadIdx.x >> 4);
-  const bool live = q_raw < Q;
-  const int q = live ? q_raw : (Q - 1);
-  const QueryId id = decode_query(q, ta.bs, n_fd, first, ta.decimation);
-  const long long s = ta.index[id.p];
-  float px = ta.pool_coord[s * 3 + 0], py = ta.pool_coord[s * 3 + 1], pz = ta.pool_coord[s * 3 + 2];
-  if (id.axis == 0) px = fadd(px, id.sign * ta.fd_eps);  // x + [eps,0,0] in fp32 (mapper.py:988-999)
-  if (id.axis == 1) py = fadd(py, id.sign * ta.fd_eps);
-  if (id.axis == 2) pz = fadd(pz, id.sign * ta.fd_eps);
-
-  TopK t;
-  if (ta.debug_flags & 4) {
-    t.nn = 0;
-#pragma unroll
-    for (int k = 0; k < CLID_K; ++k) { t.j[k] = (k < 5) ? ((q * 7 + k * 131) % mv.M) : -1; t.d2[k] = 0.5f + k; }
-  } else {
-    search_topk(mv, dl, px, py, pz, lane16, gbase, t);
-  }
-  float w[CLID_K], omega[CLID_K];
-  idw_weights(t, w, omega);
-  const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
-  float f[CLID_D];
-#pragma unroll
-  for (int c = 0; c < CLID_D; ++c) f[c] = 0.f;
-#pragma unroll
-  for (int k = 0; k < CLID_K; ++k) {
-    if (t.j[k] >= 0) {
-      float fe[CLID_F];
-      load_feat(mv.feat, t.j[k], fe);
-      if (mv.layer_norm) {
-        float rstd;
-        layer_norm8(fe, rstd);
-      }
-      const float4 p = pos4[t.j[k]];
-#pragma unroll
-      for (int c = 0; c < CLID_F; ++c) f[c] = fadd(f[c], fmul(fe[c], w[k]));
-      f[CLID_F + 0] = fadd(f[CLID_F + 0], fmul(fsub(px, p.x), w[k]));
-      f[CLID_F + 1] = fadd(f[CLID_F + 1], fmul(fsub(py, p.y), w[k]));
-      f[CLID_F + 2] = fadd(f[CLID_F + 2], fmul(fsub(pz, p.z), w[k]));
-    }
-  }
-  float pre[CLID_HPL];
-  const float sdf = mlp_forward(mlp, f, lane16, ta.sdf_scale, pre);
-  if (!live) return;
-  {
-    float mine = 0.f;
-#pragma unroll
-    for (int c = 0; c < CLID_D; ++c) mine = (lane16 == c) ? f[c] : mine;
-    if (lane16 < 12) ws.fvec[(size_t)q * 12 + lane16] = mine;
-    float mw = 0.f;
-    int mj = -1;
-#pragma unroll
-    for (int k = 0; k < CLID_K; ++k) {
-      mw = (lane16 == k) ? w[k] : mw;
-      mj = (lane16 == k) ? t.j[k] : mj;
-    }
-    if (lane16 < CLID_K) {
-      ws.w[(size_t)q * CLID_K + lane16] = mw;
-      ws.idx[(size_t)q * CLID_K + lane16] = mj;
-      if (mj >= 0 && !(ta.debug_flags & 1)) {  // training_mode side effects (np.py:708-733)
-        atomicAdd(&mv.cert[mj], mw);
-        if (id.axis < 0 && mv.ts_update) atomicMax(&mv.ts_update[mj], ta.pool_ts[s]);
-      }
-    }
-    if (lane16 == 0) ws.sdf[q] = sdf;
-  }
-}
-
 // ---- decoder-gradient accumulation -------------------------------------------------------------------
 // dW1 [64 x 11] = sum_q dh_q (x) f_q is a GEMM whose reduction runs over the QUERIES, so it goes on the
 // matrix cores: v_mfma_f32_16x16x4_f32 (exact fp32, == an fmaf chain) with
@@ -172,29 +78,39 @@ struct MlpAcc {
 
 constexpr int kRedFloats = CLID_MLP_PARAMS + 3;  // 833 grads | bce | eik | pad
 
-// accumulate the wave's values into the block's LDS sums (ds_add_f32), then one coalesced store
-__device__ __forceinline__ void flush_mlp_acc(const MlpAcc& acc, float bce, float eik, float* red /*LDS*/,
+// Block reduction of the waves' accumulators: plain LDS stores into per-wave rows, one barrier, then
+// a 4-way sum and one coalesced global store.  (LDS float atomics -- ds_add_f32 -- retire at ~1-2
+// lanes/clk on gfx950: measured 20 us for this flush, so they are avoided.)
+__device__ __forceinline__ void flush_mlp_acc(const MlpAcc& acc, float bce, float eik, float* red /*LDS [4][kRedFloats]*/,
                                               float* __restrict__ out /* [kPartialStride] */) {
-  const int lane = threadIdx.x & 63, lane16 = lane & 15, grp = lane >> 4;
-  for (int i = threadIdx.x; i < kRedFloats; i += blockDim.x) red[i] = 0.f;
-  __syncthreads();
+  const int lane = threadIdx.x & 63, lane16 = lane & 15, grp = lane >> 4, wave = threadIdx.x >> 6;
+  float* mine = red + wave * kRedFloats;
 #pragma unroll
   for (int u = 0; u < CLID_HPL; ++u) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int h = CLID_G * u + 4 * grp + r;
-      if (lane16 < CLID_D) atomicAdd(&red[h * CLID_D + lane16], acc.dW1[u][r]);
-      else if (lane16 == CLID_D) atomicAdd(&red[CLID_H * CLID_D + h], acc.dW1[u][r]);
+      if (lane16 < CLID_D) mine[h * CLID_D + lane16] = acc.dW1[u][r];
+      else if (lane16 == CLID_D) mine[CLID_H * CLID_D + h] = acc.dW1[u][r];
     }
-    atomicAdd(&red[CLID_H * CLID_D + CLID_H + lane16 + CLID_G * u], acc.dW2[u]);
+    const float w2 = cross_group_sum(acc.dW2[u]);
+    if (lane < CLID_G) mine[CLID_H * CLID_D + CLID_H + lane16 + CLID_G * u] = w2;
   }
-  if (lane16 == 0) {
-    atomicAdd(&red[CLID_MLP_PARAMS - 1], acc.db2);
-    atomicAdd(&red[CLID_MLP_PARAMS], bce);
-    atomicAdd(&red[CLID_MLP_PARAMS + 1], eik);
+  {
+    const float v0 = cross_group_sum(acc.db2), v1 = cross_group_sum(bce), v2 = cross_group_sum(eik);
+    if (lane == 0) {
+      mine[CLID_MLP_PARAMS - 1] = v0;
+      mine[CLID_MLP_PARAMS] = v1;
+      mine[CLID_MLP_PARAMS + 1] = v2;
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < CLID_MLP_PARAMS + 2; i += blockDim.x) out[i] = red[i];
+  const int nw = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < CLID_MLP_PARAMS + 2; i += blockDim.x) {
+    float s = 0.f;
+    for (int wv = 0; wv < nw; ++wv) s += red[wv * kRedFloats + i];
+    out[i] = s;
+  }
 }
 
 // decoder backward for one query given dz = scale * dL/dsdf; returns df (replicated)
@@ -202,9 +118,10 @@ __device__ __forceinline__ void mlp_backward(const MlpLds& s, const float (&f)[C
                                              const float (&pre)[CLID_HPL], float dz, int lane16,
                                              bool train_decoder, MlpAcc& acc, float (&df)[CLID_D]) {
   float dh[CLID_HPL];
+  const int l16 = lane16 + opaque_zero();  // keep the weights in LDS (see opaque_zero)
 #pragma unroll
   for (int u = 0; u < CLID_HPL; ++u) {
-    const int h = lane16 + CLID_G * u;
+    const int h = l16 + CLID_G * u;
     const bool on = pre[u] > 0.f;
     dh[u] = on ? dz * s.w[CLID_H * CLID_D + CLID_H + h] : 0.f;
     if (train_decoder) acc.dW2[u] += on ? dz * pre[u] : 0.f;
@@ -222,17 +139,211 @@ __device__ __forceinline__ void mlp_backward(const MlpLds& s, const float (&f)[C
   for (int c = 0; c < CLID_D; ++c) {
     float part = 0.f;
 #pragma unroll
-    for (int u = 0; u < CLID_HPL; ++u) part = fmaf(s.w[(lane16 + CLID_G * u) * CLID_D + c], dh[u], part);
+    for (int u = 0; u < CLID_HPL; ++u) part = fmaf(s.w[(l16 + CLID_G * u) * CLID_D + c], dh[u], part);
     df[c] = group_sum(part);
   }
 }
 
-__global__ void __launch_bounds__(CLID_BLOCK)
-k_train_bwd(clid_map_view mv, clid_train_args ta, TrainWs ws, int Q, int n_fd, int first, int n_groups_total) {
+// ---- the fused iteration kernel ---------------------------------------------------------------------------
+// A wave (4 query groups) executes TASKS of 2 rounds x 4 queries:
+//   bundle task j (j < n_fd):  round A = the x+,x-,y+,y- shifted copies of decimated sample j,
+//                              round B = z+, z-, the sample itself, and one non-decimated sample;
+//   plain task:                8 non-decimated samples.
+// All six finite-difference SDFs of a bundle therefore live in one wave, so the eikonal term, its
+// backward, the BCE term and the decoder / feature gradients are produced without a grid-wide hand-off
+// and without writing per-query state to HBM.
+struct QDesc {
+  int p;      // position in this rank's batch, -1 = padding
+  int axis;   // -1 batch sample, 0..2 shifted copy
+  float sign;
+};
+
+// n-th sample of the local batch that is NOT on the decimation lattice {first, first+decim, ...}
+__device__ __forceinline__ int nondecimated(int n, int bs, int n_fd, int first, int decim) {
+  if (n_fd == 0) return n < bs ? n : -1;
+  const int total = bs - n_fd;
+  if (n >= total) return -1;
+  const int tail = total - first;  // samples behind `first` that are off the lattice
+  if (n < tail) {
+    const int per = decim - 1;
+    const int b = n / per;
+    return first + b * decim + 1 + (n - b * per);
+  }
+  return n - tail;  // the (< decim) samples in front of `first`
+}
+
+// Per-round query state kept between the forward and the backward of a task.  The group-uniform part
+// (f, w, j, sdf: 24 words) is stashed in LDS by lane 0 of the group with 6 x ds_write_b128 and read back
+// (broadcast) with 6 x ds_read_b128; the lane's 4 pre-activations take one b128 each way.  This keeps the
+// two rounds of a task out of each other's registers (the fully unrolled version needed 201 VGPRs).
+struct RoundState {
+  float f[CLID_D];
+  float sdf;
+  float w[CLID_K];
+  int j[CLID_K];
+  float pre[CLID_HPL];
+};
+struct StashLds {
+  float4 grp[CLID_BLOCK / CLID_G][2][6];  // [group in block][round][6 x 16 B]
+  float4 pre[2][CLID_BLOCK];              // [round][thread]
+};
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void stash_put(StashLds& sl, int round, int lane16, const RoundState& st) {
+  float4* g = sl.grp[threadIdx.x >> 4][round];
+  if (lane16 == 0) {
+    g[0] = make_float4(st.f[0], st.f[1], st.f[2], st.f[3]);
+    g[1] = make_float4(st.f[4], st.f[5], st.f[6], st.f[7]);
+    g[2] = make_float4(st.f[8], st.f[9], st.f[10], st.sdf);
+    g[3] = make_float4(st.w[0], st.w[1], st.w[2], st.w[3]);
+    g[4] = make_float4(st.w[4], st.w[5], __int_as_float(st.j[0]), __int_as_float(st.j[1]));
+    g[5] = make_float4(__int_as_float(st.j[2]), __int_as_float(st.j[3]), __int_as_float(st.j[4]),
+                       __int_as_float(st.j[5]));
+  }
+  sl.pre[round][threadIdx.x] = make_float4(st.pre[0], st.pre[1], st.pre[2], st.pre[3]);
+}
+__device__ __forceinline__ void stash_get(const StashLds& sl, int round, RoundState& st) {
+  const float4* g = sl.grp[threadIdx.x >> 4][round];
+  const float4 a = g[0], b = g[1], c = g[2], d = g[3], e = g[4], f = g[5];
+  st.f[0] = a.x; st.f[1] = a.y; st.f[2] = a.z; st.f[3] = a.w;
+  st.f[4] = b.x; st.f[5] = b.y; st.f[6] = b.z; st.f[7] = b.w;
+  st.f[8] = c.x; st.f[9] = c.y; st.f[10] = c.z; st.sdf = c.w;
+  st.w[0] = d.x; st.w[1] = d.y; st.w[2] = d.z; st.w[3] = d.w;
+  st.w[4] = e.x; st.w[5] = e.y;
+  st.j[0] = __float_as_int(e.z); st.j[1] = __float_as_int(e.w);
+  st.j[2] = __float_as_int(f.x); st.j[3] = __float_as_int(f.y);
+  st.j[4] = __float_as_int(f.z); st.j[5] = __float_as_int(f.w);
+  const float4 p = sl.pre[round][threadIdx.x];
+  st.pre[0] = p.x; st.pre[1] = p.y; st.pre[2] = p.z; st.pre[3] = p.w;
+}
+__device__ __forceinline__ float stash_sdf(const StashLds& sl, int wave, int round, int grp) {
+  return sl.grp[wave * 4 + grp][round][2].w;
+}
+
+__device__ __forceinline__ QDesc task_query(int task, int round, int grp, int bs, int n_fd, int first, int decim) {
+  QDesc q;
+  q.axis = -1;
+  q.sign = 0.f;
+  if (task < n_fd) {  // bundle: A = x+,x-,y+,y- ; B = z+, z-, sample, one off-lattice sample
+    const int pj = first + task * decim;
+    if (round == 0) {
+      q.p = pj; q.axis = grp >> 1; q.sign = (grp & 1) ? -1.f : 1.f;
+    } else if (grp < 2) {
+      q.p = pj; q.axis = 2; q.sign = grp ? -1.f : 1.f;
+    } else if (grp == 2) {
+      q.p = pj;
+    } else {
+      q.p = nondecimated(task, bs, n_fd, first, decim);
+    }
+  } else {
+    q.p = nondecimated(n_fd + (task - n_fd) * 8 + round * 4 + grp, bs, n_fd, first, decim);
+  }
+  return q;
+}
+
+__device__ __forceinline__ void forward_round(const clid_map_view& mv, const clid_train_args& ta, const MlpLds& mlp,
+                                              const DeltaLds& dl, const QDesc& qd, int lane16, int gbase,
+                                              RoundState& st) {
+  const bool live = qd.p >= 0;
+  const long long s = ta.index[live ? qd.p : 0];
+  float px = ta.pool_coord[s * 3 + 0], py = ta.pool_coord[s * 3 + 1], pz = ta.pool_coord[s * 3 + 2];
+  if (qd.axis == 0) px = fadd(px, qd.sign * ta.fd_eps);  // x + [eps,0,0] in fp32 (mapper.py:988-999)
+  if (qd.axis == 1) py = fadd(py, qd.sign * ta.fd_eps);
+  if (qd.axis == 2) pz = fadd(pz, qd.sign * ta.fd_eps);
+  TopK t;
+  search_topk(mv, dl, px, py, pz, lane16, gbase, t);
+  float omega[CLID_K];
+  idw_weights(t, st.w, omega);
+  const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
+#pragma unroll
+  for (int c = 0; c < CLID_D; ++c) st.f[c] = 0.f;
+#pragma unroll
+  for (int k = 0; k < CLID_K; ++k) {
+    st.j[k] = live ? t.j[k] : -1;
+    if (t.j[k] >= 0) {
+      float fe[CLID_F];
+      load_feat(mv.feat, t.j[k], fe);
+      if (mv.layer_norm) {
+        float rstd;
+        layer_norm8(fe, rstd);
+      }
+      const float4 p = pos4[t.j[k]];
+#pragma unroll
+      for (int c = 0; c < CLID_F; ++c) st.f[c] = fmaf(fe[c], st.w[k], st.f[c]);
+      st.f[CLID_F + 0] = fmaf(fsub(px, p.x), st.w[k], st.f[CLID_F + 0]);
+      st.f[CLID_F + 1] = fmaf(fsub(py, p.y), st.w[k], st.f[CLID_F + 1]);
+      st.f[CLID_F + 2] = fmaf(fsub(pz, p.z), st.w[k], st.f[CLID_F + 2]);
+    }
+  }
+  st.sdf = mlp_forward(mlp, st.f, lane16, ta.sdf_scale, st.pre);
+  // training_mode side effects (np.py:708-733): certainty += w, last-update stamp = max(., ts)
+  if (live && !(ta.debug_flags & 1)) {
+    float mw = 0.f;
+    int mj = -1;
+#pragma unroll
+    for (int k = 0; k < CLID_K; ++k) {
+      mw = (lane16 == k) ? st.w[k] : mw;
+      mj = (lane16 == k) ? st.j[k] : mj;
+    }
+    if (lane16 < CLID_K && mj >= 0) {
+      atomicAdd(&mv.cert[mj], mw);
+      if (qd.axis < 0 && mv.ts_update) atomicMax(&mv.ts_update[mj], ta.pool_ts[s]);
+    }
+  }
+}
+
+__device__ __forceinline__ void backward_round(const clid_map_view& mv, const clid_train_args& ta, const MlpLds& mlp,
+                                               const RoundState& st, float delta, int lane16, MlpAcc& acc,
+                                               float* __restrict__ g_theta) {
+  float df[CLID_D];
+  mlp_backward(mlp, st.f, st.pre, ta.sdf_scale * delta, lane16, ta.train_decoder != 0, acc, df);
+  if (delta == 0.f || (ta.debug_flags & 2)) return;  // (whole-group predicate; no cross-lane ops below)
+  if (!mv.layer_norm) {
+    float dfc = 0.f;
+#pragma unroll
+    for (int c = 0; c < CLID_F; ++c) dfc = ((lane16 & 7) == c) ? df[c] : dfc;
+#pragma unroll
+    for (int r = 0; r < (CLID_K * CLID_F + CLID_G - 1) / CLID_G; ++r) {
+      const int k0 = 2 * r, k1 = 2 * r + 1;  // lane16 < 8 -> neighbour 2r, else 2r+1
+      const bool hi = lane16 >= 8;
+      const int j = hi ? st.j[k1] : st.j[k0];
+      const float wk = hi ? st.w[k1] : st.w[k0];
+      if (j >= 0) atomicAdd(&g_theta[(size_t)j * CLID_F + (lane16 & 7)], wk * dfc);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < CLID_K; ++k) {
+      const int j = st.j[k];
+      if (j < 0) continue;
+      float fe[CLID_F], rstd, dth[CLID_F];
+      load_feat(mv.feat, j, fe);
+      layer_norm8(fe, rstd);
+#pragma unroll
+      for (int c = 0; c < CLID_F; ++c) dth[c] = st.w[k] * df[c];
+      layer_norm8_bwd(fe, rstd, dth);
+      float mine = 0.f;
+#pragma unroll
+      for (int c = 0; c < CLID_F; ++c) mine = (lane16 == c) ? dth[c] : mine;
+      if (lane16 < CLID_F) atomicAdd(&g_theta[(size_t)j * CLID_F + lane16], mine);
+    }
+  }
+}
+
+#ifndef CLID_FUSED_WAVES
+#define CLID_FUSED_WAVES 4
+#endif
+__global__ void __launch_bounds__(CLID_BLOCK, CLID_FUSED_WAVES)
+k_train_fused(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, int n_tasks, int n_fd, int first) {
   __shared__ MlpLds mlp;
-  __shared__ float red[kRedFloats + 1];
-  stage_mlp(mlp, ta.W1, ta.b1, ta.W2, ta.b2);
-  const int lane = threadIdx.x & 63, lane16 = lane & 15;
+  __shared__ DeltaLds dl;
+  __shared__ StashLds stash;
+  __shared__ float red[(CLID_BLOCK / 64) * kRedFloats];
+  stage_mlp_and_delta(mlp, dl, mv, ta.W1, ta.b1, ta.W2, ta.b2);
+  const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48, grp = lane >> 4;
+  const int wave = threadIdx.x >> 6, waves_per_block = CLID_BLOCK / 64;
   MlpAcc acc;
   acc.zero();
   float bce_acc = 0.f, eik_acc = 0.f;
@@ -240,87 +351,53 @@ k_train_bwd(clid_map_view mv, clid_train_args ta, TrainWs ws, int Q, int n_fd, i
   const float inv_sigma = fdiv(1.0f, ta.sigma);
   const float two_eps = 2.0f * ta.fd_eps;
 
-  for (int g0 = blockIdx.x * CLID_QPB; g0 < n_groups_total; g0 += gridDim.x * CLID_QPB) {
-    const int q_raw = g0 + (threadIdx.x >> 4);
-    const bool live = q_raw < Q;
-    const int q = live ? q_raw : (Q - 1);
-    const QueryId id = decode_query(q, ta.bs, n_fd, first, ta.decimation);
-    float delta = 0.f;  // dL/dsdf of this query
-    if (id.axis < 0) {
-      const long long s = ta.index[id.p];
-      const float label = ta.pool_label[s];
-      const float wt = ta.loss_weight_on ? fabsf(ta.pool_weight[s]) : 1.0f;  // mapper.py:747-749
-      const float z = ws.sdf[q] * inv_sigma;
-      const float tgt = 1.0f / (1.0f + expf(-label * inv_sigma));            // loss.py:60
-      const float sg = 1.0f / (1.0f + expf(-z));
-      const float li = fmaxf(z, 0.f) - z * tgt + log1pf(expf(-fabsf(z)));    // BCEWithLogits
-      if (live && lane16 == 0) bce_acc += wt * li;
-      delta = wt * (sg - tgt) * inv_sigma * ta.inv_n_main;
-    } else {
-      const int e = q - ta.bs;
-      const int a = e / n_fd, jj = e - a * n_fd;
-      float sv[6];
-#pragma unroll
-      for (int b = 0; b < 6; ++b) sv[b] = ws.sdf[ta.bs + b * n_fd + jj];
-      const float gx = fdiv(sv[0] - sv[1], two_eps), gy = fdiv(sv[2] - sv[3], two_eps),
-                  gz = fdiv(sv[4] - sv[5], two_eps);                          // mapper.py:1011-1013
-      const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
-      if (live && lane16 == 0 && a == 0) eik_acc += (nrm - 1.f) * (nrm - 1.f);
-      const float gc = (id.axis == 0) ? gx : (id.axis == 1 ? gy : gz);
-      // d/dg of weight_e * mean((|g|-1)^2); 0 at |g| == 0 (torch norm subgradient)
-      const float dLdg = nrm > 0.f ? ta.weight_e * 2.f * (nrm - 1.f) * ta.inv_n_eik * (gc / nrm) : 0.f;
-      delta = id.sign * dLdg / two_eps;
+  for (int task = blockIdx.x * waves_per_block + wave; task < n_tasks; task += gridDim.x * waves_per_block) {
+    const bool bundle = task < n_fd;
+#pragma unroll 1
+    for (int round = 0; round < 2; ++round) {
+      const QDesc qd = task_query(task, round, grp, ta.bs, n_fd, first, ta.decimation);
+      RoundState st;
+      forward_round(mv, ta, mlp, dl, qd, lane16, gbase, st);
+      stash_put(stash, round, lane16, st);
     }
-    if (!live) delta = 0.f;
-
-    float f[CLID_D];
-#pragma unroll
-    for (int c = 0; c < CLID_D; ++c) f[c] = ws.fvec[(size_t)q * 12 + c];
-    float pre[CLID_HPL];
-    (void)mlp_forward(mlp, f, lane16, ta.sdf_scale, pre);
-    float df[CLID_D];
-    mlp_backward(mlp, f, pre, ta.sdf_scale * delta, lane16, ta.train_decoder != 0, acc, df);
-
-    // d theta[j_k] += w_k * df[0:F]  (through the layer-norm backward when on)
-    if (live && delta != 0.f && !(ta.debug_flags & 2)) {
-      if (!mv.layer_norm) {
-        float dfc = 0.f;
-#pragma unroll
-        for (int c = 0; c < CLID_F; ++c) dfc = ((lane16 & 7) == c) ? df[c] : dfc;
-#pragma unroll
-        for (int r = 0; r < (CLID_K * CLID_F + CLID_G - 1) / CLID_G; ++r) {
-          const int e = lane16 + CLID_G * r;
-          const int k = e >> 3;
-          if (k < CLID_K) {
-            const int j = ws.idx[(size_t)q * CLID_K + k];
-            if (j >= 0) {
-              const float wk = ws.w[(size_t)q * CLID_K + k];
-              atomicAdd(&g_theta[(size_t)j * CLID_F + (e & 7)], wk * dfc);
-            }
-          }
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < CLID_K; ++k) {
-          const int j = ws.idx[(size_t)q * CLID_K + k];
-          if (j < 0) continue;
-          const float wk = ws.w[(size_t)q * CLID_K + k];
-          float fe[CLID_F], rstd, dth[CLID_F];
-          load_feat(mv.feat, j, fe);
-          layer_norm8(fe, rstd);
-#pragma unroll
-          for (int c = 0; c < CLID_F; ++c) dth[c] = wk * df[c];
-          layer_norm8_bwd(fe, rstd, dth);
-          float mine = 0.f;
-#pragma unroll
-          for (int c = 0; c < CLID_F; ++c) mine = (lane16 == c) ? dth[c] : mine;
-          if (lane16 < CLID_F) atomicAdd(&g_theta[(size_t)j * CLID_F + lane16], mine);
+    wave_lds_fence();
+    float ecoef = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+    if (bundle) {
+      gx = fdiv(stash_sdf(stash, wave, 0, 0) - stash_sdf(stash, wave, 0, 1), two_eps);  // mapper.py:1011-1013
+      gy = fdiv(stash_sdf(stash, wave, 0, 2) - stash_sdf(stash, wave, 0, 3), two_eps);
+      gz = fdiv(stash_sdf(stash, wave, 1, 0) - stash_sdf(stash, wave, 1, 1), two_eps);
+      const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
+      if (lane == 0) eik_acc += (nrm - 1.f) * (nrm - 1.f);
+      // d/dg of weight_e * mean((|g|-1)^2); 0 at |g| == 0 (torch norm subgradient)
+      ecoef = nrm > 0.f ? ta.weight_e * 2.f * (nrm - 1.f) * ta.inv_n_eik / (nrm * two_eps) : 0.f;
+    }
+#pragma unroll 1
+    for (int round = 0; round < 2; ++round) {
+      const QDesc qd = task_query(task, round, grp, ta.bs, n_fd, first, ta.decimation);
+      RoundState st;
+      stash_get(stash, round, st);
+      float delta = 0.f;
+      if (qd.p >= 0) {
+        if (qd.axis < 0) {
+          const long long s = ta.index[qd.p];
+          const float label = ta.pool_label[s];
+          const float wt = ta.loss_weight_on ? fabsf(ta.pool_weight[s]) : 1.0f;  // mapper.py:747-749
+          const float z = st.sdf * inv_sigma;
+          const float tgt = 1.0f / (1.0f + expf(-label * inv_sigma));            // loss.py:60
+          const float sg = 1.0f / (1.0f + expf(-z));
+          const float li = fmaxf(z, 0.f) - z * tgt + log1pf(expf(-fabsf(z)));    // BCEWithLogits
+          if (lane16 == 0) bce_acc += wt * li;
+          delta = wt * (sg - tgt) * inv_sigma * ta.inv_n_main;
+        } else {
+          const float ga = qd.axis == 0 ? gx : (qd.axis == 1 ? gy : gz);
+          delta = qd.sign * ecoef * ga;
         }
       }
+      backward_round(mv, ta, mlp, st, delta, lane16, acc, g_theta);
     }
+    wave_lds_fence();
   }
-  if (!(ta.debug_flags & 8)) flush_mlp_acc(acc, bce_acc, eik_acc, red, ws.partial + (size_t)blockIdx.x * kPartialStride);
-  else if (acc.db2 + acc.dW1[0][0] + acc.dW1[3][3] + acc.dW2[1] == 123.456f) ws.partial[0] = bce_acc + eik_acc;
+  flush_mlp_acc(acc, bce_acc, eik_acc, red, partial + (size_t)blockIdx.x * kPartialStride);
 }
 
 // ---- partial reduction + Adam ---------------------------------------------------------------------------
@@ -527,9 +604,10 @@ static int n_queries(const clid_train_args* a, int* n_fd, int* first) {
   return a->bs + 6 * (*n_fd);
 }
 
-static int bwd_blocks(int Q) {
-  int nb = (Q + CLID_QPB - 1) / CLID_QPB;
-  return nb > kMaxBwdBlocks ? kMaxBwdBlocks : nb;
+static int train_tasks(int bs, int n_fd) { return n_fd + (bs - 2 * n_fd > 0 ? (bs - 2 * n_fd + 7) / 8 : 0); }
+static int fused_blocks(int n_tasks) {
+  int nb = (n_tasks + CLID_BLOCK / 64 - 1) / (CLID_BLOCK / 64);
+  return nb > kMaxBwdBlocks ? kMaxBwdBlocks : (nb < 1 ? 1 : nb);
 }
 
 extern "C" int64_t clid_train_workspace_floats(int32_t bs, int32_t decimation, int32_t eikonal_mode) {
@@ -560,16 +638,12 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
   int n_fd, first;
   const int Q = n_queries(a, &n_fd, &first);
   TrainWs ws = carve(a->ws, Q);
-  const int n_groups = (Q + CLID_QPB - 1) / CLID_QPB * CLID_QPB;  // padded to whole blocks
+  const int n_tasks = train_tasks(a->bs, n_fd);
+  const int nb = fused_blocks(n_tasks);
   if (g_prof) prof_mark(s);
-  hipLaunchKernelGGL(k_train_fwd, dim3(n_groups / CLID_QPB), dim3(CLID_BLOCK), 0, s, *mv, *a, ws, Q,
-                     n_fd > 0 ? n_fd : 1, first);
+  hipLaunchKernelGGL(k_train_fused, dim3(nb), dim3(CLID_BLOCK), 0, s, *mv, *a, ws.partial, n_tasks, n_fd, first);
   CLID_CHECK_LAUNCH();
   if (g_prof) prof_mark(s);
-  const int nb = bwd_blocks(Q);
-  hipLaunchKernelGGL(k_train_bwd, dim3(nb), dim3(CLID_BLOCK), 0, s, *mv, *a, ws, Q, n_fd > 0 ? n_fd : 1,
-                     first, n_groups);
-  CLID_CHECK_LAUNCH();
   if (g_prof) prof_mark(s);
   if (!a->defer_reduce) {
     hipLaunchKernelGGL(k_reduce_partials, dim3((CLID_MLP_PARAMS + 2 + 15) / 16), dim3(256), 0, s, ws.partial,
@@ -630,7 +704,7 @@ extern "C" int clid_train_adam(const clid_adam_args* a, const clid_train_args* t
     const int Q = n_queries(t, &n_fd, &first);
     TrainWs ws = carve(t->ws, Q);
     L.partial = ws.partial;
-    L.nb = bwd_blocks(Q);
+    L.nb = fused_blocks(train_tasks(t->bs, n_fd));
     L.loss_out = t->loss_out;
     L.inv_n_main = t->inv_n_main;
     L.inv_n_eik = t->inv_n_eik;
