@@ -14,6 +14,19 @@
 
 namespace clid {
 
+// ---- optional in-kernel phase timing (tools/phase_timing.py builds with -DCLID_TIMING) -----------------
+#ifdef CLID_TIMING
+static __device__ long long clid_stamps[256 * 32];
+#define CLID_STAMP(k)                                                                   \
+  do {                                                                                  \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                          \
+    if (threadIdx.x == 0 && blockIdx.x < 256 && (k) >= 0 && (k) < 32)                    \
+      clid_stamps[blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memtime();                 \
+  } while (0)
+#else
+#define CLID_STAMP(k) do { } while (0)
+#endif
+
 // ---- exact fp32 helpers (no FMA contraction where the reference's op order matters) -------------
 __device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
@@ -77,27 +90,27 @@ __device__ __forceinline__ int base_slot(float x, float y, float z, float res, i
   return (int)r;
 }
 
-// ---- compact probe table: 2-entry buckets {key0,id0,key1,id1} (one 16-byte load per probe) ---------
-// key == -1 empty; key0 is always filled before key1, overflow goes to the next bucket.
+// ---- compact probe table: 4-key buckets (one 16-byte load per probe) ------------------------------------
+// keys[bucket] = 4 slot numbers, -1 empty, filled in order; tab_pos[bucket][m] = {x, y, z, id bits} of key m,
+// so a hit costs ONE more 16-byte load that returns the position and the id together.  At <= 0.5 keys per
+// bucket the chance that a bucket is full (>= 4 keys) without a match is ~2e-4 per probe, so the walk to
+// the next bucket is a rare slow path instead of an extra dependent latency for every wave.
 __device__ __forceinline__ unsigned tab_home(int slot, int log2nb) {
   return ((unsigned)slot * 2654435761u) >> (32 - log2nb);
 }
-// resolve one probe given its home bucket content; walks on only when the bucket is full
-__device__ __forceinline__ int tab_resolve(const int4* __restrict__ tab, int log2nb, int slot, unsigned home,
-                                           int4 b) {
+__device__ __forceinline__ int bucket_match(const int4 b, int slot) {
+  return (b.x == slot) ? 0 : ((b.y == slot) ? 1 : ((b.z == slot) ? 2 : ((b.w == slot) ? 3 : -1)));
+}
+// cell index (bucket*4 + m) of `slot`, or -1
+__device__ __forceinline__ int tab_find(const int4* __restrict__ tab, int log2nb, int slot, unsigned home, int4 b) {
   const unsigned mask = (1u << log2nb) - 1u;
   for (;;) {
-    if (b.x == slot) return b.y;
-    if (b.x < 0) return -1;
-    if (b.z == slot) return b.w;
-    if (b.z < 0) return -1;
+    const int m = bucket_match(b, slot);
+    if (m >= 0) return (int)(home * 4u) + m;
+    if (b.w < 0) return -1;  // not full: the key would have been here
     home = (home + 1) & mask;
     b = tab[home];
   }
-}
-__device__ __forceinline__ int tab_lookup(const int4* __restrict__ tab, int log2nb, int slot) {
-  const unsigned home = tab_home(slot, log2nb);
-  return tab_resolve(tab, log2nb, slot, home, tab[home]);
 }
 
 // ---- per-lane sorted candidate list + group top-K ------------------------------------------------
@@ -157,14 +170,14 @@ __device__ __forceinline__ void stage_delta(DeltaLds& s, const clid_map_view& mv
 // nearest valid neighbours, ascending (np.py:971-1030 + 595-612).  All probe loads of a chunk are
 // issued before any is consumed (the dependent chain is bucket -> position, not 6x that).
 __device__ __forceinline__ void search_topk(const clid_map_view& mv, const DeltaLds& dl, float x, float y,
-                                            float z, int lane16, int gbase, TopK& out) {
+                                            float z, int lane16, int gbase, TopK& out, int tm = -100) {
   const int4* __restrict__ tab = reinterpret_cast<const int4*>(mv.tab);
-  const float4* __restrict__ pos4 = reinterpret_cast<const float4*>(mv.pos4);
   const int B = mv.buffer_size;
   const int r0 = base_slot(x, y, z, mv.resolution, B);
   Cand c;
   c.init();
   int nvalid = 0;
+  const float4* __restrict__ tpos = reinterpret_cast<const float4*>(mv.tab_pos);
   for (int o0 = 0; o0 < mv.P; o0 += kProbeChunk) {
     int slot[kProbesPerLane];
     unsigned home[kProbesPerLane];
@@ -174,37 +187,40 @@ __device__ __forceinline__ void search_topk(const clid_map_view& mv, const Delta
       const int o = o0 + t * CLID_G + lane16;
       int sl = r0 + dl.d[o];
       if (sl >= B) sl -= B;
-      slot[t] = (o < mv.P) ? sl : -2;  // -2 never matches a key and is not "empty"
+      slot[t] = (o < mv.P) ? sl : -2;  // -2 never matches a key
       home[t] = tab_home(sl, mv.log2cap);
       bk[t] = tab[home[t]];
     }
-    int jj[kProbesPerLane];
-    bool more = false;
+    int cell[kProbesPerLane];
+    bool walk = false;
 #pragma unroll
-    for (int t = 0; t < kProbesPerLane; ++t) {  // fast path: the home bucket decides (almost always)
-      const int4 b = bk[t];
-      jj[t] = (b.x == slot[t]) ? b.y : ((b.z == slot[t]) ? b.w : -1);
-      more |= (jj[t] < 0) && (b.x >= 0) && (b.z >= 0) && (slot[t] != -2);
+    for (int t = 0; t < kProbesPerLane; ++t) {
+      const int m = bucket_match(bk[t], slot[t]);
+      cell[t] = m >= 0 ? (int)(home[t] * 4u) + m : -1;
+      walk |= (m < 0) && (bk[t].w >= 0) && (slot[t] != -2);
     }
-    if (__any(more)) {  // a full home bucket without a match: walk on (rare at load <= 0.25)
+    CLID_STAMP(tm + 1);
+    if (__any(walk)) {  // rare: a full bucket without a match
 #pragma unroll
       for (int t = 0; t < kProbesPerLane; ++t)
-        if (jj[t] < 0 && slot[t] != -2) jj[t] = tab_resolve(tab, mv.log2cap, slot[t], home[t], bk[t]);
+        if (cell[t] < 0 && slot[t] != -2 && bk[t].w >= 0) cell[t] = tab_find(tab, mv.log2cap, slot[t], home[t], bk[t]);
     }
     float4 pp[kProbesPerLane];
 #pragma unroll
-    for (int t = 0; t < kProbesPerLane; ++t) pp[t] = pos4[jj[t] >= 0 ? jj[t] : 0];
+    for (int t = 0; t < kProbesPerLane; ++t) pp[t] = tpos[cell[t] >= 0 ? cell[t] : 0];
+    CLID_STAMP(tm + 2);
 #pragma unroll
     for (int t = 0; t < kProbesPerLane; ++t) {
       const float ax = fsub(pp[t].x, x), ay = fsub(pp[t].y, y), az = fsub(pp[t].z, z);
       const float d2 = fadd(fadd(fmul(ax, ax), fmul(ay, ay)), fmul(az, az));
-      if (jj[t] >= 0 && !(d2 > mv.max_valid_dist2)) {  // np.py:1016-1020
-        c.insert(d2, jj[t]);
+      if (cell[t] >= 0 && !(d2 > mv.max_valid_dist2)) {  // np.py:1016-1020
+        c.insert(d2, __float_as_int(pp[t].w));
         ++nvalid;
       }
     }
   }
   out.nn = group_sum_i(nvalid);
+  CLID_STAMP(tm + 3);
 #pragma unroll
   for (int k = 0; k < CLID_K; ++k) {
     const float head = c.d[0];

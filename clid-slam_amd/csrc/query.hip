@@ -15,10 +15,14 @@ __global__ void k_radius_search(clid_map_view mv, const float* __restrict__ x, i
   const float px = x[n * 3 + 0], py = x[n * 3 + 1], pz = x[n * 3 + 2];
   int slot = base_slot(px, py, pz, mv.resolution, mv.buffer_size) + mv.delta[o];
   if (slot >= mv.buffer_size) slot -= mv.buffer_size;
-  int j = tab_lookup(reinterpret_cast<const int4*>(mv.tab), mv.log2cap, slot);
+  const int4* tab = reinterpret_cast<const int4*>(mv.tab);
+  const unsigned home = tab_home(slot, mv.log2cap);
+  const int cell = tab_find(tab, mv.log2cap, slot, home, tab[home]);
+  int j = -1;
   float d2 = mv.max_valid_dist2;  // np.py:1013
-  if (j >= 0) {
-    const float4 p = reinterpret_cast<const float4*>(mv.pos4)[j];
+  if (cell >= 0) {
+    const float4 p = reinterpret_cast<const float4*>(mv.tab_pos)[cell];
+    j = __float_as_int(p.w);
     const float ax = fsub(p.x, px), ay = fsub(p.y, py), az = fsub(p.z, pz);
     d2 = fadd(fadd(fmul(ax, ax), fmul(ay, ay)), fmul(az, az));
     if (d2 > mv.max_valid_dist2) j = -1;  // np.py:1016-1020 (dist2 keeps its value)
@@ -289,7 +293,7 @@ k_sdf_grad_x(clid_map_view mv, const float* W1, const float* b1, const float* W2
 }  // namespace clid
 
 static int check_view(const clid_map_view* mv, const char* who) {
-  if (!mv || !mv->tab || !mv->pos4 || !mv->delta || mv->P <= 0 || mv->P > clid::kMaxProbes ||
+  if (!mv || !mv->tab || !mv->tab_pos || !mv->pos4 || !mv->delta || mv->P <= 0 || mv->P > clid::kMaxProbes ||
       mv->log2cap < 4 || mv->buffer_size <= 0) {
     clid_set_error("%s: incomplete map view", who);
     return CLID_E_ARG;

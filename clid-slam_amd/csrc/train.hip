@@ -246,7 +246,8 @@ __device__ __forceinline__ QDesc task_query(int task, int round, int grp, int bs
 
 __device__ __forceinline__ void forward_round(const clid_map_view& mv, const clid_train_args& ta, const MlpLds& mlp,
                                               const DeltaLds& dl, const QDesc& qd, int lane16, int gbase,
-                                              RoundState& st) {
+                                              RoundState& st, int tm = -100) {
+  CLID_STAMP(tm);
   const bool live = qd.p >= 0;
   const long long s = ta.index[live ? qd.p : 0];
   float px = ta.pool_coord[s * 3 + 0], py = ta.pool_coord[s * 3 + 1], pz = ta.pool_coord[s * 3 + 2];
@@ -254,31 +255,56 @@ __device__ __forceinline__ void forward_round(const clid_map_view& mv, const cli
   if (qd.axis == 1) py = fadd(py, qd.sign * ta.fd_eps);
   if (qd.axis == 2) pz = fadd(pz, qd.sign * ta.fd_eps);
   TopK t;
-  search_topk(mv, dl, px, py, pz, lane16, gbase, t);
+  asm volatile("" ::"v"(px), "v"(py), "v"(pz));
+  CLID_STAMP(tm + 0 + 100 * (tm < 0));
+  search_topk(mv, dl, px, py, pz, lane16, gbase, t, tm);
+  CLID_STAMP(tm + 4);
   float omega[CLID_K];
   idw_weights(t, st.w, omega);
   const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
+  // Gather + blend with ONE 16-byte feature load and one position load per lane: lane16 = 2k + half
+  // handles half `half` of neighbour k's feature row (lanes 12..15 idle), the weighted rows are summed
+  // over k with a DPP butterfly (row_ror 8/4/2 keeps even and odd lanes apart), and the two halves are
+  // exchanged between lane pairs.  (The replicated version needed 72 live VGPRs and 110 instructions.)
+  {
+    const int my_k = lane16 >> 1;
+    const bool odd = lane16 & 1;
+    int my_j = -1;
+    float my_w = 0.f;
 #pragma unroll
-  for (int c = 0; c < CLID_D; ++c) st.f[c] = 0.f;
-#pragma unroll
-  for (int k = 0; k < CLID_K; ++k) {
-    st.j[k] = live ? t.j[k] : -1;
-    if (t.j[k] >= 0) {
-      float fe[CLID_F];
-      load_feat(mv.feat, t.j[k], fe);
-      if (mv.layer_norm) {
-        float rstd;
-        layer_norm8(fe, rstd);
-      }
-      const float4 p = pos4[t.j[k]];
-#pragma unroll
-      for (int c = 0; c < CLID_F; ++c) st.f[c] = fmaf(fe[c], st.w[k], st.f[c]);
-      st.f[CLID_F + 0] = fmaf(fsub(px, p.x), st.w[k], st.f[CLID_F + 0]);
-      st.f[CLID_F + 1] = fmaf(fsub(py, p.y), st.w[k], st.f[CLID_F + 1]);
-      st.f[CLID_F + 2] = fmaf(fsub(pz, p.z), st.w[k], st.f[CLID_F + 2]);
+    for (int k = 0; k < CLID_K; ++k) {
+      my_j = (my_k == k) ? t.j[k] : my_j;
+      my_w = (my_k == k) ? st.w[k] : my_w;
+      st.j[k] = live ? t.j[k] : -1;
     }
+    const int jc = my_j >= 0 ? my_j : 0;
+    float4 v = reinterpret_cast<const float4*>(mv.feat)[(size_t)jc * 2 + (odd ? 1 : 0)];
+    const float4 p = pos4[jc];
+    if (mv.layer_norm) {  // F.layer_norm over the 8 features of the row = both halves (np.py:632-633)
+      float s1 = (v.x + v.y) + (v.z + v.w);
+      s1 += dpp_mov<0xB1>(s1);  // quad_perm [1,0,3,2]: the other half of the row
+      const float mu = s1 * (1.0f / CLID_F);
+      v.x -= mu; v.y -= mu; v.z -= mu; v.w -= mu;
+      float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      s2 += dpp_mov<0xB1>(s2);
+      const float rstd = 1.0f / sqrtf(s2 * (1.0f / CLID_F) + 1e-5f);
+      v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
+    }
+    float a0 = v.x * my_w, a1 = v.y * my_w, a2 = v.z * my_w, a3 = v.w * my_w;
+    const float wr = odd ? 0.f : my_w;  // the relative position is carried by the even lane of the pair
+    float r0 = fsub(px, p.x) * wr, r1 = fsub(py, p.y) * wr, r2 = fsub(pz, p.z) * wr;
+#define CLID_BFLY(x) x += dpp_mov<0x128>(x); x += dpp_mov<0x124>(x); x += dpp_mov<0x122>(x);
+    CLID_BFLY(a0) CLID_BFLY(a1) CLID_BFLY(a2) CLID_BFLY(a3) CLID_BFLY(r0) CLID_BFLY(r1) CLID_BFLY(r2)
+#undef CLID_BFLY
+    const float b0 = dpp_mov<0xB1>(a0), b1 = dpp_mov<0xB1>(a1), b2 = dpp_mov<0xB1>(a2), b3 = dpp_mov<0xB1>(a3);
+    const float q0 = dpp_mov<0xB1>(r0), q1 = dpp_mov<0xB1>(r1), q2 = dpp_mov<0xB1>(r2);
+    st.f[0] = odd ? b0 : a0; st.f[1] = odd ? b1 : a1; st.f[2] = odd ? b2 : a2; st.f[3] = odd ? b3 : a3;
+    st.f[4] = odd ? a0 : b0; st.f[5] = odd ? a1 : b1; st.f[6] = odd ? a2 : b2; st.f[7] = odd ? a3 : b3;
+    st.f[8] = odd ? q0 : r0; st.f[9] = odd ? q1 : r1; st.f[10] = odd ? q2 : r2;
   }
+  CLID_STAMP(tm + 5);
   st.sdf = mlp_forward(mlp, st.f, lane16, ta.sdf_scale, st.pre);
+  CLID_STAMP(tm + 6);
   // training_mode side effects (np.py:708-733): certainty += w, last-update stamp = max(., ts)
   if (live && !(ta.debug_flags & 1)) {
     float mw = 0.f;
@@ -341,6 +367,26 @@ k_train_fused(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
   __shared__ DeltaLds dl;
   __shared__ StashLds stash;
   __shared__ float red[(CLID_BLOCK / 64) * kRedFloats];
+  if (ta.debug_flags & 128) {
+    // L2 warm-up: the blocks that land on one XCD (observed: blockIdx % 8) stream that XCD's copy of the
+    // probe table, positions and features once, coalesced, before the random probes start.
+    const int xslot = blockIdx.x >> 3, xcount = (gridDim.x + 7) >> 3;
+    float4 sink = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto warm = [&](const void* base, size_t bytes) {
+      const size_t n16 = bytes >> 4;
+      const size_t per = (n16 + xcount - 1) / xcount;
+      const size_t lo = (size_t)xslot * per, hi = lo + per < n16 ? lo + per : n16;
+      const float4* p = reinterpret_cast<const float4*>(base);
+      for (size_t i = lo + threadIdx.x; i < hi; i += CLID_BLOCK) {
+        const float4 v = p[i];
+        sink.x += v.x; sink.y += v.y; sink.z += v.z; sink.w += v.w;
+      }
+    };
+    warm(mv.tab, (size_t)16 << mv.log2cap);
+    warm(mv.pos4, (size_t)16 * mv.M);
+    warm(mv.feat, (size_t)32 * mv.M);
+    asm volatile("" ::"v"(sink.x), "v"(sink.y), "v"(sink.z), "v"(sink.w));
+  }
   stage_mlp_and_delta(mlp, dl, mv, ta.W1, ta.b1, ta.W2, ta.b2);
   const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48, grp = lane >> 4;
   const int wave = threadIdx.x >> 6, waves_per_block = CLID_BLOCK / 64;
@@ -357,10 +403,11 @@ k_train_fused(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
     for (int round = 0; round < 2; ++round) {
       const QDesc qd = task_query(task, round, grp, ta.bs, n_fd, first, ta.decimation);
       RoundState st;
-      forward_round(mv, ta, mlp, dl, qd, lane16, gbase, st);
+      forward_round(mv, ta, mlp, dl, qd, lane16, gbase, st, round * 8);
       stash_put(stash, round, lane16, st);
     }
     wave_lds_fence();
+    CLID_STAMP(16);
     float ecoef = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
     if (bundle) {
       gx = fdiv(stash_sdf(stash, wave, 0, 0) - stash_sdf(stash, wave, 0, 1), two_eps);  // mapper.py:1011-1013
@@ -393,11 +440,15 @@ k_train_fused(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
           delta = qd.sign * ecoef * ga;
         }
       }
+      CLID_STAMP(17 + round * 3);
       backward_round(mv, ta, mlp, st, delta, lane16, acc, g_theta);
+      CLID_STAMP(18 + round * 3);
     }
     wave_lds_fence();
   }
+  CLID_STAMP(24);
   flush_mlp_acc(acc, bce_acc, eik_acc, red, partial + (size_t)blockIdx.x * kPartialStride);
+  CLID_STAMP(25);
 }
 
 // ---- partial reduction + Adam ---------------------------------------------------------------------------
@@ -561,6 +612,12 @@ hipEvent_t prof_mark(hipStream_t s) {
   return e;
 }
 }  // namespace
+
+#ifdef CLID_TIMING
+extern "C" int clid_debug_read_stamps(long long* out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(clid::clid_stamps), sizeof(long long) * 256 * 32) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int clid_profile_enable(int on) {
   for (hipEvent_t e : g_ev) hipEventDestroy(e);

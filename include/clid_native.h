@@ -48,7 +48,8 @@ int clid_abi_version(void);
  * compact mirror built by clid_table_build(); the remaining pointers alias the shim's own torch
  * tensors (local_* arrays for query_locally=True, global arrays otherwise). */
 typedef struct clid_map_view {
-  const int32_t* tab;      /* [2^log2cap][4] buckets {key0,id0,key1,id1}; key = slot number, -1 empty */
+  const int32_t* tab;      /* [2^log2cap][4] buckets of 4 keys (slot numbers, -1 empty, filled in order) */
+  const float* tab_pos;    /* [2^log2cap][4][4] per key: x, y, z, point id (int bits) -> one load per hit */
   const float* pos4;       /* [M][4] xyz0 of the points addressed by the ids in `tab` */
   float* feat;             /* [(M+1)][F] latent features, last row = padding (np.py:532) */
   float* cert;             /* [M] point certainties (read; +atomicAdd when training_mode) */
@@ -71,12 +72,13 @@ typedef struct clid_map_view {
  * and (no time filtering or |travel[cur_ts]-travel[ts_create[ids[j]]]| < diff_travel).
  *   ids            [n] int64 global point index of local point j, or NULL for identity (global map)
  *   neural_points  [Mg][3], buffer_pt_index [buffer_size] int64, point_ts_create [Mg] int32
- *   tab_out        [2^log2cap][4] int32 (2-entry buckets, 2*2^log2cap >= 2n), pos4_out [n][4] */
+ *   tab_out        [2^log2cap][4] int32 keys (4-key buckets, 2^log2cap >= n/2 ... load <= 0.5 keys/bucket
+ *                  recommended), tab_pos_out [2^log2cap][4][4] f32, pos4_out [n][4] */
 int clid_table_build(const int64_t* ids, int32_t n, const float* neural_points,
                      const int64_t* buffer_pt_index, int64_t buffer_size, float resolution,
                      const int32_t* point_ts_create, const float* travel_dist, int32_t cur_ts,
-                     int32_t time_filtering, float diff_travel, int32_t* tab_out, int32_t log2cap,
-                     float* pos4_out, void* stream);
+                     int32_t time_filtering, float diff_travel, int32_t* tab_out, float* tab_pos_out,
+                     int32_t log2cap, float* pos4_out, void* stream);
 
 /* NeuralPoints.radius_neighborhood_search (model/neural_points.py:971-1030).
  * dist2_out [N][P] f32, idx_out [N][P] int32 (ids of the view, -1 invalid). */
