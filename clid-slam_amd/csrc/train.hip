@@ -158,20 +158,6 @@ struct QDesc {
   float sign;
 };
 
-// n-th sample of the local batch that is NOT on the decimation lattice {first, first+decim, ...}
-__device__ __forceinline__ int nondecimated(int n, int bs, int n_fd, int first, int decim) {
-  if (n_fd == 0) return n < bs ? n : -1;
-  const int total = bs - n_fd;
-  if (n >= total) return -1;
-  const int tail = total - first;  // samples behind `first` that are off the lattice
-  if (n < tail) {
-    const int per = decim - 1;
-    const int b = n / per;
-    return first + b * decim + 1 + (n - b * per);
-  }
-  return n - tail;  // the (< decim) samples in front of `first`
-}
-
 // Per-round query state kept between the forward and the backward of a task.  The group-uniform part
 // (f, w, j, sdf: 24 words) is stashed in LDS by lane 0 of the group with 6 x ds_write_b128 and read back
 // (broadcast) with 6 x ds_read_b128; the lane's 4 pre-activations take one b128 each way.  This keeps the
@@ -223,12 +209,42 @@ __device__ __forceinline__ float stash_sdf(const StashLds& sl, int wave, int rou
   return sl.grp[wave * 4 + grp][round][2].w;
 }
 
-__device__ __forceinline__ QDesc task_query(int task, int round, int grp, int bs, int n_fd, int first, int decim) {
+// Task -> query mapping (no integer division on the common path).  The local batch is cut into lattice
+// blocks of `decim` positions starting at a decimated sample pj = first + j*decim:
+//   bundle task j        : the 6 shifted copies of pj, pj itself, and pj - 1 (the sample in front of it)
+//   plain task (b, c)    : positions pj_b + 1 + 8c .. pj_b + 8 + 8c of block b (offsets <= decim - 2),
+//                          b = -1 covers the samples in front of the first decimated one
+//   tail task            : the last position of the last block (nobody's "pj - 1")
+// n_fd == 0 (no eikonal term): task t simply covers positions 8t .. 8t+7.
+struct TaskMap {
+  int bs, n_fd, first, decim;
+  int chunks;   // plain tasks per lattice block = ceil((decim - 2) / 8)
+  int n_plain;  // (n_fd + 1) * chunks
+  int n_tasks;
+};
+__host__ __device__ inline TaskMap make_task_map(int bs, int n_fd, int first, int decim) {
+  TaskMap m;
+  m.bs = bs; m.n_fd = n_fd; m.first = first; m.decim = decim;
+  if (n_fd == 0) {
+    m.chunks = 1; m.n_plain = (bs + 7) / 8; m.n_tasks = m.n_plain;
+  } else {
+    m.chunks = decim > 2 ? (decim - 2 + 7) / 8 : 0;
+    m.n_plain = (n_fd + 1) * m.chunks;
+    m.n_tasks = n_fd + m.n_plain + 1;  // + tail task
+  }
+  return m;
+}
+__device__ __forceinline__ QDesc task_query(const TaskMap& tm, int task, int round, int grp) {
   QDesc q;
   q.axis = -1;
   q.sign = 0.f;
-  if (task < n_fd) {  // bundle: A = x+,x-,y+,y- ; B = z+, z-, sample, one off-lattice sample
-    const int pj = first + task * decim;
+  q.p = -1;
+  const int slot = round * 4 + grp;
+  if (tm.n_fd == 0) {
+    const int p = task * 8 + slot;
+    q.p = p < tm.bs ? p : -1;
+  } else if (task < tm.n_fd) {  // bundle: A = x+,x-,y+,y- ; B = z+, z-, sample, the sample in front of it
+    const int pj = tm.first + task * tm.decim;
     if (round == 0) {
       q.p = pj; q.axis = grp >> 1; q.sign = (grp & 1) ? -1.f : 1.f;
     } else if (grp < 2) {
@@ -236,17 +252,25 @@ __device__ __forceinline__ QDesc task_query(int task, int round, int grp, int bs
     } else if (grp == 2) {
       q.p = pj;
     } else {
-      q.p = nondecimated(task, bs, n_fd, first, decim);
+      q.p = pj - 1;  // -1 for the very first sample: padding
     }
+  } else if (task < tm.n_fd + tm.n_plain) {
+    const int t = task - tm.n_fd;
+    const int b = (tm.chunks == 1) ? t : t / tm.chunks;
+    const int c = t - b * tm.chunks;
+    const int off = 1 + c * 8 + slot;
+    const int p = tm.first + (b - 1) * tm.decim + off;
+    q.p = (off <= tm.decim - 2 && p >= 0 && p < tm.bs) ? p : -1;
   } else {
-    q.p = nondecimated(n_fd + (task - n_fd) * 8 + round * 4 + grp, bs, n_fd, first, decim);
+    const int p = tm.first + tm.n_fd * tm.decim - 1;
+    q.p = (slot == 0 && p < tm.bs) ? p : -1;
   }
   return q;
 }
 
 __device__ __forceinline__ void forward_round(const clid_map_view& mv, const clid_train_args& ta, const MlpLds& mlp,
-                                              const DeltaLds& dl, const QDesc& qd, int lane16, int gbase,
-                                              RoundState& st, int tm = -100) {
+                                              const DeltaLds& dl, const OccLds* occ, const QDesc& qd, int lane16,
+                                              int gbase, RoundState& st, int tm = -100) {
   CLID_STAMP(tm);
   const bool live = qd.p >= 0;
   const long long s = ta.index[live ? qd.p : 0];
@@ -257,11 +281,23 @@ __device__ __forceinline__ void forward_round(const clid_map_view& mv, const cli
   TopK t;
   asm volatile("" ::"v"(px), "v"(py), "v"(pz));
   CLID_STAMP(tm + 0 + 100 * (tm < 0));
-  search_topk(mv, dl, px, py, pz, lane16, gbase, t, tm);
+  if (ta.debug_flags & 4) {
+    t.nn = 5;
+#pragma unroll
+    for (int k = 0; k < CLID_K; ++k) { t.j[k] = (k < 5) ? (int)(((unsigned)(qd.p * 7 + k * 131 + lane16 / 16)) % (unsigned)mv.M) : -1; t.d2[k] = 0.5f + k; }
+  } else {
+    search_topk(mv, dl, px, py, pz, lane16, gbase, t, tm, occ);
+  }
   CLID_STAMP(tm + 4);
   float omega[CLID_K];
   idw_weights(t, st.w, omega);
   const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
+  if (ta.debug_flags & 512) {
+#pragma unroll
+    for (int c = 0; c < CLID_D; ++c) st.f[c] = 0.01f * c + px;
+#pragma unroll
+    for (int k = 0; k < CLID_K; ++k) st.j[k] = live ? t.j[k] : -1;
+  } else
   // Gather + blend with ONE 16-byte feature load and one position load per lane: lane16 = 2k + half
   // handles half `half` of neighbour k's feature row (lanes 12..15 idle), the weighted rows are summed
   // over k with a DPP butterfly (row_ror 8/4/2 keeps even and odd lanes apart), and the two halves are
@@ -303,7 +339,13 @@ __device__ __forceinline__ void forward_round(const clid_map_view& mv, const cli
     st.f[8] = odd ? q0 : r0; st.f[9] = odd ? q1 : r1; st.f[10] = odd ? q2 : r2;
   }
   CLID_STAMP(tm + 5);
-  st.sdf = mlp_forward(mlp, st.f, lane16, ta.sdf_scale, st.pre);
+  if (ta.debug_flags & 1024) {
+    st.sdf = st.f[0];
+#pragma unroll
+    for (int u = 0; u < CLID_HPL; ++u) st.pre[u] = st.f[u] - 0.5f;
+  } else {
+    st.sdf = mlp_forward(mlp, st.f, lane16, ta.sdf_scale, st.pre);
+  }
   CLID_STAMP(tm + 6);
   // training_mode side effects (np.py:708-733): certainty += w, last-update stamp = max(., ts)
   if (live && !(ta.debug_flags & 1)) {
@@ -362,11 +404,12 @@ __device__ __forceinline__ void backward_round(const clid_map_view& mv, const cl
 #define CLID_FUSED_WAVES 4
 #endif
 __global__ void __launch_bounds__(CLID_BLOCK, CLID_FUSED_WAVES)
-k_train_fused(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, int n_tasks, int n_fd, int first) {
+k_train_fused(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap) {
   __shared__ MlpLds mlp;
   __shared__ DeltaLds dl;
   __shared__ StashLds stash;
   __shared__ float red[(CLID_BLOCK / 64) * kRedFloats];
+  const OccLds* occ = nullptr;  // LDS occupancy prefilter: measured no gain (kernel is VALU/latency bound), off
   if (ta.debug_flags & 128) {
     // L2 warm-up: the blocks that land on one XCD (observed: blockIdx % 8) stream that XCD's copy of the
     // probe table, positions and features once, coalesced, before the random probes start.
@@ -397,13 +440,13 @@ k_train_fused(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
   const float inv_sigma = fdiv(1.0f, ta.sigma);
   const float two_eps = 2.0f * ta.fd_eps;
 
-  for (int task = blockIdx.x * waves_per_block + wave; task < n_tasks; task += gridDim.x * waves_per_block) {
-    const bool bundle = task < n_fd;
+  for (int task = blockIdx.x * waves_per_block + wave; task < tmap.n_tasks; task += gridDim.x * waves_per_block) {
+    const bool bundle = task < tmap.n_fd;
 #pragma unroll 1
     for (int round = 0; round < 2; ++round) {
-      const QDesc qd = task_query(task, round, grp, ta.bs, n_fd, first, ta.decimation);
+      const QDesc qd = task_query(tmap, task, round, grp);
       RoundState st;
-      forward_round(mv, ta, mlp, dl, qd, lane16, gbase, st, round * 8);
+      forward_round(mv, ta, mlp, dl, occ, qd, lane16, gbase, st, round * 8);
       stash_put(stash, round, lane16, st);
     }
     wave_lds_fence();
@@ -420,7 +463,7 @@ k_train_fused(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
     }
 #pragma unroll 1
     for (int round = 0; round < 2; ++round) {
-      const QDesc qd = task_query(task, round, grp, ta.bs, n_fd, first, ta.decimation);
+      const QDesc qd = task_query(tmap, task, round, grp);
       RoundState st;
       stash_get(stash, round, st);
       float delta = 0.f;
@@ -430,9 +473,11 @@ k_train_fused(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
           const float label = ta.pool_label[s];
           const float wt = ta.loss_weight_on ? fabsf(ta.pool_weight[s]) : 1.0f;  // mapper.py:747-749
           const float z = st.sdf * inv_sigma;
-          const float tgt = 1.0f / (1.0f + expf(-label * inv_sigma));            // loss.py:60
-          const float sg = 1.0f / (1.0f + expf(-z));
-          const float li = fmaxf(z, 0.f) - z * tgt + log1pf(expf(-fabsf(z)));    // BCEWithLogits
+          // hardware exp/log/rcp (<= 2 ulp): the loss terms stay within 1e-6 of the fp32 reference
+          const float tgt = __frcp_rn(1.0f + __expf(-label * inv_sigma));         // loss.py:60
+          const float ez = __expf(-fabsf(z));
+          const float sg = (z >= 0.f ? 1.0f : ez) * __frcp_rn(1.0f + ez);
+          const float li = fmaxf(z, 0.f) - z * tgt + __logf(1.0f + ez);           // BCEWithLogits
           if (lane16 == 0) bce_acc += wt * li;
           delta = wt * (sg - tgt) * inv_sigma * ta.inv_n_main;
         } else {
@@ -441,7 +486,8 @@ k_train_fused(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
         }
       }
       CLID_STAMP(17 + round * 3);
-      backward_round(mv, ta, mlp, st, delta, lane16, acc, g_theta);
+      if (!(ta.debug_flags & 2048)) backward_round(mv, ta, mlp, st, delta, lane16, acc, g_theta);
+      else bce_acc += delta;
       CLID_STAMP(18 + round * 3);
     }
     wave_lds_fence();
@@ -661,7 +707,6 @@ static int n_queries(const clid_train_args* a, int* n_fd, int* first) {
   return a->bs + 6 * (*n_fd);
 }
 
-static int train_tasks(int bs, int n_fd) { return n_fd + (bs - 2 * n_fd > 0 ? (bs - 2 * n_fd + 7) / 8 : 0); }
 static int fused_blocks(int n_tasks) {
   int nb = (n_tasks + CLID_BLOCK / 64 - 1) / (CLID_BLOCK / 64);
   return nb > kMaxBwdBlocks ? kMaxBwdBlocks : (nb < 1 ? 1 : nb);
@@ -695,10 +740,10 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
   int n_fd, first;
   const int Q = n_queries(a, &n_fd, &first);
   TrainWs ws = carve(a->ws, Q);
-  const int n_tasks = train_tasks(a->bs, n_fd);
-  const int nb = fused_blocks(n_tasks);
+  const TaskMap tmap = make_task_map(a->bs, n_fd, first, a->decimation);
+  const int nb = fused_blocks(tmap.n_tasks);
   if (g_prof) prof_mark(s);
-  hipLaunchKernelGGL(k_train_fused, dim3(nb), dim3(CLID_BLOCK), 0, s, *mv, *a, ws.partial, n_tasks, n_fd, first);
+  hipLaunchKernelGGL(k_train_fused, dim3(nb), dim3(CLID_BLOCK), 0, s, *mv, *a, ws.partial, tmap);
   CLID_CHECK_LAUNCH();
   if (g_prof) prof_mark(s);
   if (g_prof) prof_mark(s);
@@ -761,7 +806,7 @@ extern "C" int clid_train_adam(const clid_adam_args* a, const clid_train_args* t
     const int Q = n_queries(t, &n_fd, &first);
     TrainWs ws = carve(t->ws, Q);
     L.partial = ws.partial;
-    L.nb = fused_blocks(train_tasks(t->bs, n_fd));
+    L.nb = fused_blocks(make_task_map(t->bs, n_fd, first, t->decimation).n_tasks);
     L.loss_out = t->loss_out;
     L.inv_n_main = t->inv_n_main;
     L.inv_n_eik = t->inv_n_eik;
@@ -774,5 +819,27 @@ extern "C" int clid_train_adam(const clid_adam_args* a, const clid_train_args* t
   hipLaunchKernelGGL(k_adam_all, dim3(L.n_feat_blocks + (CLID_MLP_PARAMS + 2 + 15) / 16), dim3(256), 0, s, L);
   CLID_CHECK_LAUNCH();
   if (g_prof) prof_mark(s);
+  return CLID_OK;
+}
+
+// The whole single-GPU loop of Mapper.mapping (utils/mapper.py:642-860) enqueued by ONE host call:
+// per iteration the fused forward/backward kernel and the reduce+Adam kernel, back to back on `stream`.
+extern "C" int clid_mapping_run(const clid_map_view* mv, const clid_train_args* t, const clid_adam_args* a,
+                                int32_t iters, const int64_t* index_base, int64_t index_stride,
+                                float* loss_base, void* stream) {
+  if (!mv || !t || !a || iters < 0 || !index_base || !loss_base) {
+    clid_set_error("clid_mapping_run: bad argument");
+    return CLID_E_ARG;
+  }
+  clid_train_args ta = *t;
+  clid_adam_args aa = *a;
+  ta.defer_reduce = 1;
+  for (int it = 0; it < iters; ++it) {
+    ta.index = index_base + (int64_t)it * index_stride;
+    ta.loss_out = loss_base + (size_t)it * 4;
+    if (int e = clid_train_fwd_bwd(mv, &ta, stream)) return e;
+    aa.step = it + 1;
+    if (int e = clid_train_adam(&aa, &ta, stream)) return e;
+  }
   return CLID_OK;
 }

@@ -203,14 +203,19 @@ class Mapper:
         stream = _lib.stream()
         idx_base, row_bytes = index_seq.data_ptr(), bs_global * 8
         loss_base = losses.data_ptr()
-        for it in range(iter_count):
-            ta.index = idx_base + it * row_bytes + batch_offset * 8
-            ta.loss_out = loss_base + it * 16
-            _lib.check(lib.clid_train_fwd_bwd(C.byref(view), C.byref(ta), stream), "clid_train_fwd_bwd")
-            if dist:
+        if not dist:
+            # single GPU: the whole loop is enqueued by one C call (2 kernel launches per iteration)
+            ta.index, ta.loss_out = idx_base, loss_base
+            _lib.check(lib.clid_mapping_run(C.byref(view), C.byref(ta), C.byref(aa), iter_count, idx_base, bs_global,
+                                            loss_base, stream), "clid_mapping_run")
+        else:
+            for it in range(iter_count):
+                ta.index = idx_base + it * row_bytes + batch_offset * 8
+                ta.loss_out = loss_base + it * 16
+                _lib.check(lib.clid_train_fwd_bwd(C.byref(view), C.byref(ta), stream), "clid_train_fwd_bwd")
                 dist.all_reduce(grad)
-            aa.step = it + 1
-            _lib.check(lib.clid_train_adam(C.byref(aa), C.byref(ta), stream), "clid_train_adam")
+                aa.step = it + 1
+                _lib.check(lib.clid_train_adam(C.byref(aa), C.byref(ta), stream), "clid_train_adam")
         self.total_iter += iter_count
         if dist:
             # merge the replicas' side effects once per call (not read inside the loop's loss)

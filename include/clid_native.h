@@ -50,6 +50,7 @@ int clid_abi_version(void);
 typedef struct clid_map_view {
   const int32_t* tab;      /* [2^log2cap][4] buckets of 4 keys (slot numbers, -1 empty, filled in order) */
   const float* tab_pos;    /* [2^log2cap][4][4] per key: x, y, z, point id (int bits) -> one load per hit */
+  const uint32_t* tab_occ; /* [2^log2cap / 32] bit b set iff bucket b holds a key (probe prefilter), may be NULL */
   const float* pos4;       /* [M][4] xyz0 of the points addressed by the ids in `tab` */
   float* feat;             /* [(M+1)][F] latent features, last row = padding (np.py:532) */
   float* cert;             /* [M] point certainties (read; +atomicAdd when training_mode) */
@@ -73,12 +74,13 @@ typedef struct clid_map_view {
  *   ids            [n] int64 global point index of local point j, or NULL for identity (global map)
  *   neural_points  [Mg][3], buffer_pt_index [buffer_size] int64, point_ts_create [Mg] int32
  *   tab_out        [2^log2cap][4] int32 keys (4-key buckets, 2^log2cap >= n/2 ... load <= 0.5 keys/bucket
- *                  recommended), tab_pos_out [2^log2cap][4][4] f32, pos4_out [n][4] */
+ *                  recommended), tab_pos_out [2^log2cap][4][4] f32, tab_occ_out [2^log2cap/32] u32,
+ *                  pos4_out [n][4] */
 int clid_table_build(const int64_t* ids, int32_t n, const float* neural_points,
                      const int64_t* buffer_pt_index, int64_t buffer_size, float resolution,
                      const int32_t* point_ts_create, const float* travel_dist, int32_t cur_ts,
                      int32_t time_filtering, float diff_travel, int32_t* tab_out, float* tab_pos_out,
-                     int32_t log2cap, float* pos4_out, void* stream);
+                     uint32_t* tab_occ_out, int32_t log2cap, float* pos4_out, void* stream);
 
 /* NeuralPoints.radius_neighborhood_search (model/neural_points.py:971-1030).
  * dist2_out [N][P] f32, idx_out [N][P] int32 (ids of the view, -1 invalid). */
@@ -179,6 +181,12 @@ typedef struct clid_adam_args {
 } clid_adam_args;
 /* `t` = the args of the clid_train_fwd_bwd call this step belongs to (NULL unless t->defer_reduce) */
 int clid_train_adam(const clid_adam_args* a, const clid_train_args* t, void* stream);
+
+/* Single-GPU Mapper.mapping loop in one call: iteration `it` uses index_base + it*index_stride (int64
+ * elements), writes its losses to loss_base + 4*it and runs Adam step it+1 (state restarts per call). */
+int clid_mapping_run(const clid_map_view* mv, const clid_train_args* t, const clid_adam_args* a,
+                     int32_t iters, const int64_t* index_base, int64_t index_stride, float* loss_base,
+                     void* stream);
 
 /* ---- measurement aid (bench.py roofline leg; not part of the reference's interface) -----------
  * When enabled, clid_train_fwd_bwd / clid_train_adam bracket each kernel with hipEvents on the
