@@ -234,7 +234,7 @@ __host__ __device__ inline TaskMap make_task_map(int bs, int n_fd, int first, in
   }
   return m;
 }
-__device__ __forceinline__ QDesc task_query(const TaskMap& tm, int task, int round, int grp) {
+__host__ __device__ __forceinline__ QDesc task_query(const TaskMap& tm, int task, int round, int grp) {
   QDesc q;
   q.axis = -1;
   q.sign = 0.f;
@@ -252,7 +252,7 @@ __device__ __forceinline__ QDesc task_query(const TaskMap& tm, int task, int rou
     } else if (grp == 2) {
       q.p = pj;
     } else {
-      q.p = pj - 1;  // -1 for the very first sample: padding
+      q.p = tm.decim >= 2 ? pj - 1 : -1;  // -1 for the very first sample: padding
     }
   } else if (task < tm.n_fd + tm.n_plain) {
     const int t = task - tm.n_fd;
@@ -263,7 +263,7 @@ __device__ __forceinline__ QDesc task_query(const TaskMap& tm, int task, int rou
     q.p = (off <= tm.decim - 2 && p >= 0 && p < tm.bs) ? p : -1;
   } else {
     const int p = tm.first + tm.n_fd * tm.decim - 1;
-    q.p = (slot == 0 && p < tm.bs) ? p : -1;
+    q.p = (slot == 0 && p < tm.bs && tm.decim >= 2) ? p : -1;
   }
   return q;
 }
@@ -841,5 +841,28 @@ extern "C" int clid_mapping_run(const clid_map_view* mv, const clid_train_args* 
     aa.step = it + 1;
     if (int e = clid_train_adam(&aa, &ta, stream)) return e;
   }
+  return CLID_OK;
+}
+
+// Host-side enumeration of the task -> query mapping the fused kernel uses (same code, compiled for the
+// host): counts how often each local batch position is trained as a batch sample (must be exactly 1)
+// and how many shifted copies it gets (6 on the decimation lattice, else 0).  CPU-only; used by tests.
+extern "C" int clid_debug_task_cover(int32_t bs, int64_t batch_offset, int32_t decimation, int32_t eikonal_mode,
+                                     int32_t* main_count_host, int32_t* fd_count_host, int32_t* n_tasks_host) {
+  if (bs <= 0 || decimation <= 0 || !main_count_host || !fd_count_host) return CLID_E_ARG;
+  const int first = fd_first(batch_offset, decimation);
+  const int n_fd = eikonal_mode == 1 ? fd_count(bs, batch_offset, decimation) : 0;
+  const TaskMap tm = make_task_map(bs, n_fd, first, decimation);
+  for (int i = 0; i < bs; ++i) main_count_host[i] = fd_count_host[i] = 0;
+  for (int task = 0; task < tm.n_tasks; ++task)
+    for (int round = 0; round < 2; ++round)
+      for (int grp = 0; grp < 4; ++grp) {
+        const QDesc q = task_query(tm, task, round, grp);
+        if (q.p < 0) continue;
+        if (q.p >= bs) return CLID_E_ARG;
+        if (q.axis < 0) main_count_host[q.p]++;
+        else fd_count_host[q.p]++;
+      }
+  if (n_tasks_host) *n_tasks_host = tm.n_tasks;
   return CLID_OK;
 }

@@ -74,10 +74,12 @@ def voxel_down_sample_torch(points: torch.Tensor, voxel_size: float):
     center = (grid + 0.5) * voxel_size
     dist = ((points - center) ** 2).sum(dim=1) ** 0.5
     qd = (dist / dist.max() * (quant - 1)).long()
-    cell = grid.long()
-    cell = cell - cell.min(dim=0).values
-    ext = cell.max(dim=0).values + 1
-    flat = (cell[:, 2] * ext[1] + cell[:, 1]) * ext[0] + cell[:, 0]
+    cell = grid.long() - torch.floor(points.min(dim=0)[0] / voxel_size).long()
+    # The reference linearises the voxel coordinates with stride v = max(coordinate) (NOT max + 1,
+    # utils/tools.py:659-661), so voxels whose coordinate equals v alias another voxel and are merged
+    # with it.  Reproduced on purpose: it decides which neural points exist.
+    v = cell.max()
+    flat = cell[:, 0] + cell[:, 1] * v + cell[:, 2] * v * v
     n = points.shape[0]
     key = qd * n + torch.arange(n, device=points.device)
     # sort by (voxel, quantised distance, index); first of each voxel wins

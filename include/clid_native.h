@@ -195,6 +195,10 @@ int clid_mapping_run(const clid_map_view* mv, const clid_train_args* t, const cl
 int clid_profile_enable(int on);
 int clid_profile_read(double* out_host, int* iters_host, void* stream);
 
+/* CPU-only test aid: enumerate the fused kernel's task -> query mapping (see csrc/train.hip). */
+int clid_debug_task_cover(int32_t bs, int64_t batch_offset, int32_t decimation, int32_t eikonal_mode,
+                          int32_t* main_count_host, int32_t* fd_count_host, int32_t* n_tasks_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -421,5 +421,39 @@ def main():
             print(f"{fn:40s} {os.path.getsize(os.path.join(OUT, fn)) / 1e6:.2f} MB")
 
 
+def map_build_fixture():
+    """G7: the map the reference's own NeuralPoints.update / reset_local_map build from three synthetic
+    frames.  Single-threaded: with colliding slots inside one frame `buffer_pt_index[hash] = ...`
+    (model/neural_points.py:392) keeps an arbitrary duplicate under multi-threaded index_put."""
+    torch.set_num_threads(1)
+    ref = import_reference()  # also puts the repository root on sys.path
+    from clid_slam_amd.synth import box_room_pool
+
+    cfg = ref_config(ref)
+    torch.manual_seed(42)
+    nm = ref.NeuralPoints(cfg)
+    nm.travel_dist = torch.tensor([0.0, 400.0, 403.5], dtype=torch.float32)
+    sensors = [(0.0, 0.0, 1.5), (6.0, 2.0, 1.5), (9.0, 3.0, 1.6)]
+    for fid, s in enumerate(sensors):
+        d = box_room_pool(cfg, n_elev=32, n_azim=256, seed=42 + fid, sensor=s)
+        near = d["sdf_label"].abs() < cfg.surface_sample_range_m * 0.5
+        nm.update(d["coord"][near], d["sensor"], torch.eye(3), fid)
+    nm.local_map_radius = 12.0
+    nm.reset_local_map(torch.tensor(sensors[-1]), torch.eye(3), 2, reboot_map=True)
+    occ = torch.nonzero(nm.buffer_pt_index >= 0).flatten()
+    np.savez_compressed(
+        os.path.join(OUT, "g7_mapbuild.npz"), neural_points=nm.neural_points.numpy(),
+        point_ts_create=nm.point_ts_create.numpy(), table_slot=occ.numpy(), table_idx=nm.buffer_pt_index[occ].numpy(),
+        global2local=nm.global2local.numpy(), local_mask=nm.local_mask.numpy(),
+        local_neural_points=nm.local_neural_points.numpy(), buffer_size=np.int64(cfg.buffer_size),
+    )
+    print("G7 map build:", nm.count(), nm.local_count())
+
+
 if __name__ == "__main__":
-    main()
+    if "--only-g7" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        map_build_fixture()
+    else:
+        main()
+        map_build_fixture()

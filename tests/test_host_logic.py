@@ -1,0 +1,130 @@
+"""CPU-only host logic: the config loader resolves the reference's YAML keys, and the torch-level map
+maintenance of the NeuralPoints shim (update / reset_local_map / assign_local_to_global) rebuilds exactly
+the map the REFERENCE built for the golden fixtures (oracle/make_golden.py:build_scene)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io as gio
+from clid_slam_amd import HotPathConfig, NeuralPoints
+from clid_slam_amd.synth import box_room_pool
+from clid_slam_amd.tools import voxel_down_sample_torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+YAML = """
+setting: {name: t}
+process: {min_range_m: 1.0, max_range_m: 60.0, vox_down_m: 0.1}
+sampler: {surface_sample_range_m: 0.25, surface_sample_n: 4, free_sample_begin_ratio: 0.8, free_front_sample_n: 2}
+neuralpoints: {voxel_size_m: 0.4, num_nei_cells: 2, search_alpha: 0.5, weighted_first: True, layer_norm_on: True}
+loss: {sigma_sigmoid_m: 0.1, loss_weight_on: True, dist_weight_scale: 0.8}
+continual: {batch_size_new_sample: 1000, pool_capacity: 1e7}
+optimizer: {iters: 10, batch_size: 16384, learning_rate: 0.01, adaptive_iters: True}
+"""
+
+
+def test_config_defaults_match_the_resolved_reference_values(tmp_path):
+    c = HotPathConfig()
+    # SURVEY.md section 8 header (printed from the reference's Config.load(run_ncd128.yaml))
+    assert (c.bs, c.bs_new_sample, c.iters, c.lr, c.adam_eps, c.weight_decay) == (16384, 1000, 10, 0.01, 1e-15, 0.0)
+    assert (c.feature_dim, c.feature_std, c.query_nn_k, c.num_nei_cells, c.search_alpha) == (8, 0.0, 6, 2, 0.5)
+    assert (c.voxel_size_m, c.buffer_size, c.weighted_first, c.layer_norm_on) == (0.4, 50000000, True, False)
+    assert (c.numerical_grad, c.gradient_decimation, c.num_grad_step_ratio, c.weight_e) == (True, 10, 0.2, 0.5)
+    assert (c.local_map_radius, c.infer_bs, c.window_radius) == (62.0, 16384 * 64, 60.0)
+    f = tmp_path / "subt.yaml"
+    f.write_text(YAML)
+    c.load(str(f))
+    assert c.layer_norm_on is True and c.free_sample_begin_ratio == 0.8
+    f.write_text(YAML.replace("loss: {", "loss: {numerical_grad_on: False, "))
+    c2 = HotPathConfig().load(str(f))
+    assert c2.numerical_grad is False and c2.gradient_decimation == 1  # utils/config.py:645-646
+
+
+def test_search_neighborhood_matches_reference():
+    z = gio.load("state.npz")
+    cfg = HotPathConfig()
+    cfg.device = "cpu"
+    cfg.buffer_size = int(gio.S(z["buffer_size"]))
+    nm = NeuralPoints(cfg)
+    assert nm.neighbor_K == 81
+    assert np.array_equal(nm.neighbor_dx.numpy(), z["neighbor_dx"])
+    assert nm.max_valid_dist2 == float(gio.S(z["max_valid_dist2"]))
+    # slot deltas: (offset . primes) mod B, non-negative
+    ref = (z["neighbor_dx"].astype(object) * np.array([73856093, 19349669, 83492791], dtype=object)).sum(1) % cfg.buffer_size
+    assert np.array_equal(nm._delta.numpy().astype(np.int64), ref.astype(np.int64))
+    nm.set_search_neighborhood(1, 0.0)  # utils/mapper.py:409-411
+    assert nm.neighbor_K == 1
+
+
+def test_voxel_down_sample_selection_rule():
+    """One point per (aliased, see clid_slam_amd.tools) voxel id: the centre-most by quantised distance,
+    lowest index on ties -- the rule of utils/tools.py:639-682."""
+    torch.manual_seed(0)
+    pts = torch.rand(5000, 3) * 4.0 - 2.0
+    idx = voxel_down_sample_torch(pts, 0.4)
+    cell = torch.floor(pts / 0.4).long()
+    cell = cell - cell.min(0).values
+    v = cell.max()
+    flat = cell[:, 0] + cell[:, 1] * v + cell[:, 2] * v * v
+    assert len(idx) == len(torch.unique(flat)) == len(torch.unique(flat[idx]))
+    d = ((pts - (torch.floor(pts / 0.4) + 0.5) * 0.4) ** 2).sum(1).sqrt()
+    q = (d / d.max() * 999).long()
+    for i in idx[:300]:
+        same = torch.nonzero(flat == flat[i]).flatten()
+        best = same[q[same] == q[same].min()].min()
+        assert i == best
+
+
+def test_map_maintenance_rebuilds_the_reference_map():
+    z = gio.load("g7_mapbuild.npz")  # built by the reference, single-threaded (oracle/make_golden.py)
+    torch.set_num_threads(1)
+    cfg = HotPathConfig()
+    cfg.device = "cpu"
+    cfg.buffer_size = int(gio.S(z["buffer_size"]))
+    torch.manual_seed(42)
+    nm = NeuralPoints(cfg)
+    nm.travel_dist = torch.tensor([0.0, 400.0, 403.5])
+    sensors = [(0.0, 0.0, 1.5), (6.0, 2.0, 1.5), (9.0, 3.0, 1.6)]
+    for fid, s in enumerate(sensors):
+        d = box_room_pool(cfg, n_elev=32, n_azim=256, seed=42 + fid, sensor=s)
+        near = d["sdf_label"].abs() < cfg.surface_sample_range_m * 0.5
+        nm.update(d["coord"][near], d["sensor"], torch.eye(3), fid)
+    assert nm.count() == z["neural_points"].shape[0]
+    assert np.array_equal(nm.neural_points.numpy(), z["neural_points"])
+    assert np.array_equal(nm.point_ts_create.numpy(), z["point_ts_create"])
+    occ = torch.nonzero(nm.buffer_pt_index >= 0).flatten()
+    assert np.array_equal(occ.numpy(), z["table_slot"])
+    assert np.array_equal(nm.buffer_pt_index[occ].numpy(), z["table_idx"])
+    nm.local_map_radius = 12.0
+    nm.reset_local_map(torch.tensor(sensors[-1]), torch.eye(3), 2, reboot_map=True)
+    assert np.array_equal(nm.global2local.numpy(), z["global2local"])
+    assert np.array_equal(nm.local_mask.numpy(), z["local_mask"])
+    assert np.array_equal(nm.local_neural_points.numpy(), z["local_neural_points"])
+    assert nm.local_geo_features.shape == (z["local_neural_points"].shape[0] + 1, 8)
+    assert isinstance(nm.local_geo_features, torch.nn.Parameter)
+    # write-back (model/neural_points.py:538-549)
+    with torch.no_grad():
+        nm.local_geo_features.add_(1.0)
+        nm.local_point_certainties += 2.0
+    nm.assign_local_to_global()
+    m = nm.local_mask
+    assert torch.equal(nm.geo_features[m], nm.local_geo_features.data)
+    assert (nm.geo_features[~m] == 0).all()
+    assert torch.equal(nm.point_certainties[m[:-1]], nm.local_point_certainties)
+
+
+def test_pickles_like_the_reference_module(tmp_path):
+    """utils/tools.py:347-367 pickles the whole NeuralPoints module; the device mirror is not part of it."""
+    import shim_io
+
+    cfg = shim_io.config(device="cpu")
+    nm = shim_io.neural_points(cfg)
+    nm._tables = {"x": object()}
+    torch.save(nm, tmp_path / "m.pth")
+    nm2 = torch.load(tmp_path / "m.pth", weights_only=False)
+    assert nm2._tables == {} and torch.equal(nm2.neural_points, nm.neural_points)
+    for name in ("neural_points", "point_orientations", "geo_features", "point_ts_create", "point_ts_update",
+                 "point_certainties", "local_neural_points", "local_geo_features", "local_point_certainties",
+                 "local_point_ts_update", "local_mask", "global2local", "buffer_pt_index"):
+        assert hasattr(nm2, name)
