@@ -77,9 +77,10 @@ class Mapper:
     def _draw_index(self, iters: int, bs: int) -> torch.Tensor:
         """[iters, bs] int64 batch indices composed as utils/mapper.py:473-500 (device RNG)."""
         dev = self.global_coord_pool.device
-        if self._gen is None or self._gen.device != dev:
+        gen = getattr(self, "_gen", None)
+        if gen is None or gen.device != torch.device(dev):
             self._gen = torch.Generator(device=dev)
-            self._gen.manual_seed(self._seed)
+            self._gen.manual_seed(int(getattr(self, "_seed", getattr(self.config, "seed", 42))))
         use_new = (
             self.config.bs_new_sample > 0 and self.new_idx is not None and self.new_idx.shape[0] > 0
             and not getattr(self.dataset, "lose_track", False) and not getattr(self.dataset, "stop_status", False)
@@ -167,7 +168,7 @@ class Mapper:
         v_mlp = torch.zeros(_lib.MLP_PARAMS, device=dev, dtype=torch.float32)
         losses = torch.zeros((iter_count, 4), device=dev, dtype=torch.float32)
         need = int(lib.clid_train_workspace_floats(bs_local, decim, eik_mode))
-        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+        if getattr(self, "_ws", None) is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(need, device=dev, dtype=torch.float32)
         cert0 = nm.local_point_certainties.clone() if dist else None
 
