@@ -13,136 +13,9 @@
 //   k_reduce      partials -> grad[0:833], loss_out
 //   (optional RCCL all-reduce of `grad` by the host between these and Adam)
 //   k_adam        dense Adam over the features and the decoder, zeroes `grad`
-#include "common.hpp"
+#include "train_common.hpp"
 
 namespace clid {
-
-constexpr int kPartialStride = 840;  // 833 decoder grads | bce sum | eik sum | pad
-constexpr int kMaxBwdBlocks = 1024;
-
-struct TrainWs {
-  float* sdf;      // [Q]
-  float* fvec;     // [Q][12]
-  float* w;        // [Q][K]
-  int* idx;        // [Q][K]
-  float* partial;  // [kMaxBwdBlocks][kPartialStride]
-};
-
-__host__ __device__ inline int fd_first(long long batch_offset, int decim) {
-  const int r = (int)(batch_offset % decim);
-  return r == 0 ? 0 : decim - r;
-}
-__host__ __device__ inline int fd_count(int bs, long long batch_offset, int decim) {
-  const int first = fd_first(batch_offset, decim);
-  return first >= bs ? 0 : (bs - first + decim - 1) / decim;
-}
-
-__host__ inline TrainWs carve(float* ws, int Q) {
-  TrainWs t;
-  size_t o = 0;
-  auto take = [&](size_t n) {
-    float* p = ws + o;
-    o += (n + 3) & ~size_t(3);
-    return p;
-  };
-  t.sdf = take(Q);
-  t.fvec = take((size_t)Q * 12);
-  t.w = take((size_t)Q * CLID_K);
-  t.idx = reinterpret_cast<int*>(take((size_t)Q * CLID_K));
-  t.partial = take((size_t)kMaxBwdBlocks * kPartialStride);
-  return t;
-}
-
-// ---- decoder-gradient accumulation -------------------------------------------------------------------
-// dW1 [64 x 11] = sum_q dh_q (x) f_q is a GEMM whose reduction runs over the QUERIES, so it goes on the
-// matrix cores: v_mfma_f32_16x16x4_f32 (exact fp32, == an fmaf chain) with
-//   A[i = lane&15][k = lane>>4] = dh of hidden unit 16u + i of query k   (the lane's own dh[u])
-//   B[k = lane>>4][j = lane&15] = f_j of query k, j < 11;  1 for j == 11 (=> column 11 accumulates db1)
-// i.e. one instruction per 16-hidden tile consumes the 4 queries of the wave with no data movement, and
-// the accumulator D[row = 4*(lane>>4) + r][col = lane&15] is already summed over the wave's queries.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct MlpAcc {
-  f32x4 dW1[CLID_HPL];   // tile u: hidden 16u + 4*(lane>>4) + r, column lane&15 (0..10 dW1, 11 db1)
-  float dW2[CLID_HPL];   // hidden lane16 + 16u, this group's queries only
-  float db2;             // lane16 == 0 only
-  __device__ __forceinline__ void zero() {
-#pragma unroll
-    for (int u = 0; u < CLID_HPL; ++u) {
-      dW1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dW2[u] = 0.f;
-    }
-    db2 = 0.f;
-  }
-};
-
-constexpr int kRedFloats = CLID_MLP_PARAMS + 3;  // 833 grads | bce | eik | pad
-
-// Block reduction of the waves' accumulators: plain LDS stores into per-wave rows, one barrier, then
-// a 4-way sum and one coalesced global store.  (LDS float atomics -- ds_add_f32 -- retire at ~1-2
-// lanes/clk on gfx950: measured 20 us for this flush, so they are avoided.)
-__device__ __forceinline__ void flush_mlp_acc(const MlpAcc& acc, float bce, float eik, float* red /*LDS [4][kRedFloats]*/,
-                                              float* __restrict__ out /* [kPartialStride] */) {
-  const int lane = threadIdx.x & 63, lane16 = lane & 15, grp = lane >> 4, wave = threadIdx.x >> 6;
-  float* mine = red + wave * kRedFloats;
-#pragma unroll
-  for (int u = 0; u < CLID_HPL; ++u) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int h = CLID_G * u + 4 * grp + r;
-      if (lane16 < CLID_D) mine[h * CLID_D + lane16] = acc.dW1[u][r];
-      else if (lane16 == CLID_D) mine[CLID_H * CLID_D + h] = acc.dW1[u][r];
-    }
-    const float w2 = cross_group_sum(acc.dW2[u]);
-    if (lane < CLID_G) mine[CLID_H * CLID_D + CLID_H + lane16 + CLID_G * u] = w2;
-  }
-  {
-    const float v0 = cross_group_sum(acc.db2), v1 = cross_group_sum(bce), v2 = cross_group_sum(eik);
-    if (lane == 0) {
-      mine[CLID_MLP_PARAMS - 1] = v0;
-      mine[CLID_MLP_PARAMS] = v1;
-      mine[CLID_MLP_PARAMS + 1] = v2;
-    }
-  }
-  __syncthreads();
-  const int nw = blockDim.x >> 6;
-  for (int i = threadIdx.x; i < CLID_MLP_PARAMS + 2; i += blockDim.x) {
-    float s = 0.f;
-    for (int wv = 0; wv < nw; ++wv) s += red[wv * kRedFloats + i];
-    out[i] = s;
-  }
-}
-
-// decoder backward for one query given dz = scale * dL/dsdf; returns df (replicated)
-__device__ __forceinline__ void mlp_backward(const MlpLds& s, const float (&f)[CLID_D],
-                                             const float (&pre)[CLID_HPL], float dz, int lane16,
-                                             bool train_decoder, MlpAcc& acc, float (&df)[CLID_D]) {
-  float dh[CLID_HPL];
-  const int l16 = lane16 + opaque_zero();  // keep the weights in LDS (see opaque_zero)
-#pragma unroll
-  for (int u = 0; u < CLID_HPL; ++u) {
-    const int h = l16 + CLID_G * u;
-    const bool on = pre[u] > 0.f;
-    dh[u] = on ? dz * s.w[CLID_H * CLID_D + CLID_H + h] : 0.f;
-    if (train_decoder) acc.dW2[u] += on ? dz * pre[u] : 0.f;
-  }
-  if (train_decoder) {
-    float fb = (lane16 == CLID_D) ? 1.0f : 0.f;
-#pragma unroll
-    for (int c = 0; c < CLID_D; ++c) fb = (lane16 == c) ? f[c] : fb;
-#pragma unroll
-    for (int u = 0; u < CLID_HPL; ++u)
-      acc.dW1[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[u], fb, acc.dW1[u], 0, 0, 0);
-    if (lane16 == 0) acc.db2 += dz;
-  }
-#pragma unroll
-  for (int c = 0; c < CLID_D; ++c) {
-    float part = 0.f;
-#pragma unroll
-    for (int u = 0; u < CLID_HPL; ++u) part = fmaf(s.w[(l16 + CLID_G * u) * CLID_D + c], dh[u], part);
-    df[c] = group_sum(part);
-  }
-}
 
 // ---- the fused iteration kernel ---------------------------------------------------------------------------
 // A wave (4 query groups) executes TASKS of 2 rounds x 4 queries:
@@ -732,25 +605,25 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
     clid_set_error("clid_train_fwd_bwd: bs=%d decimation=%d", a->bs, a->decimation);
     return CLID_E_ARG;
   }
-  if (a->eikonal_mode == 2) {
-    clid_set_error("clid_train_fwd_bwd: analytic eikonal mode is not served by this entry point");
-    return CLID_E_ARG;
-  }
   hipStream_t s = (hipStream_t)stream;
   int n_fd, first;
   const int Q = n_queries(a, &n_fd, &first);
   TrainWs ws = carve(a->ws, Q);
   const TaskMap tmap = make_task_map(a->bs, n_fd, first, a->decimation);
-  const int nb = fused_blocks(tmap.n_tasks);
+  const int nb = a->eikonal_mode == 2 ? clid_train_analytic_blocks(a->bs) : fused_blocks(tmap.n_tasks);
   if (g_prof) prof_mark(s);
-  hipLaunchKernelGGL(k_train_fused, dim3(nb), dim3(CLID_BLOCK), 0, s, *mv, *a, ws.partial, tmap);
-  CLID_CHECK_LAUNCH();
+  if (a->eikonal_mode == 2) {  // loss.numerical_grad_on: False (utils/mapper.py:57-69, 660-661, 695-696)
+    if (int e = clid_launch_train_analytic(mv, a, ws.partial, s)) return e;
+  } else {
+    hipLaunchKernelGGL(k_train_fused, dim3(nb), dim3(CLID_BLOCK), 0, s, *mv, *a, ws.partial, tmap);
+    CLID_CHECK_LAUNCH();
+  }
   if (g_prof) prof_mark(s);
   if (g_prof) prof_mark(s);
   if (!a->defer_reduce) {
     hipLaunchKernelGGL(k_reduce_partials, dim3((CLID_MLP_PARAMS + 2 + 15) / 16), dim3(256), 0, s, ws.partial,
                        nb, a->grad, a->loss_out, a->inv_n_main, a->inv_n_eik,
-                       (a->eikonal_mode && n_fd > 0) ? a->weight_e : 0.f, a->train_decoder);
+                       (a->eikonal_mode == 2 || (a->eikonal_mode == 1 && n_fd > 0)) ? a->weight_e : 0.f, a->train_decoder);
     CLID_CHECK_LAUNCH();
   }
   if (g_prof) prof_mark(s);
@@ -806,11 +679,12 @@ extern "C" int clid_train_adam(const clid_adam_args* a, const clid_train_args* t
     const int Q = n_queries(t, &n_fd, &first);
     TrainWs ws = carve(t->ws, Q);
     L.partial = ws.partial;
-    L.nb = fused_blocks(make_task_map(t->bs, n_fd, first, t->decimation).n_tasks);
+    L.nb = t->eikonal_mode == 2 ? clid_train_analytic_blocks(t->bs)
+                                : fused_blocks(make_task_map(t->bs, n_fd, first, t->decimation).n_tasks);
     L.loss_out = t->loss_out;
     L.inv_n_main = t->inv_n_main;
     L.inv_n_eik = t->inv_n_eik;
-    L.weight_e = (t->eikonal_mode && n_fd > 0) ? t->weight_e : 0.f;
+    L.weight_e = (t->eikonal_mode == 2 || (t->eikonal_mode == 1 && n_fd > 0)) ? t->weight_e : 0.f;
   }
   L.train_decoder = a->train_decoder;
   L.n_feat_blocks = (int)(((a->n_feat + 3) / 4 + 255) / 256);

@@ -1,0 +1,221 @@
+// Analytic-eikonal mapping iteration (`loss.numerical_grad_on: False`): utils/mapper.py:57-69, 660-661,
+// 695-696 -> g = get_gradient(coord, sdf_pred) (utils/tools.py:298-311, create_graph=True), eikonal loss
+// on EVERY batch sample (gradient_decimation = 1, utils/config.py:645-646), backward THROUGH g.
+//
+// Closed forms (verified against the reference's double backward by G6):
+//   alpha_k = 2 r_k omega_k,  abar = sum_j w_j alpha_j,  dw_k = w_k (abar - alpha_k)        (d w_k / d x)
+//   u = s (W2 .* a) W1  (== the decoder's d sdf / d f),   g = sum_k (u . v_k) dw_k + (sum_k w_k) u[8:11]
+//   c = dL/dg;  s_k = c . dw_k;  t = J c = sum_k v_k s_k + [0_8 ; (sum w) c]
+//   dW1[h,:] += s W2[h] a[h] t,  dW2[h] += s a[h] (W1[h,:] . t),  d feat_k += (w_k delta + s_k) u[0:8]
+// One round = 4 queries per wave, forward and backward back to back in registers (no shifted copies, so
+// no cross-query dependency).  Lane layout of the gather as in train.hip: lane16 = 2k + half.
+#include "train_common.hpp"
+
+namespace clid {
+
+#define CLID_BFLY(x) x += dpp_mov<0x128>(x); x += dpp_mov<0x124>(x); x += dpp_mov<0x122>(x);
+#define CLID_SWAP(x) dpp_mov<0xB1>(x)  // quad_perm [1,0,3,2]: the other lane of the pair
+
+__global__ void __launch_bounds__(CLID_BLOCK, 3)
+k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, int n_rounds) {
+  __shared__ MlpLds mlp;
+  __shared__ DeltaLds dl;
+  __shared__ float red[(CLID_BLOCK / 64) * kRedFloats];
+  stage_mlp_and_delta(mlp, dl, mv, ta.W1, ta.b1, ta.W2, ta.b2);
+  const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48, grp = lane >> 4;
+  const int wave = threadIdx.x >> 6, waves_per_block = CLID_BLOCK / 64;
+  const int my_k = lane16 >> 1;
+  const bool odd = lane16 & 1;
+  MlpAcc acc;
+  acc.zero();
+  float bce_acc = 0.f, eik_acc = 0.f;
+  float* g_theta = ta.grad + CLID_GRAD_FEAT_OFFSET;
+  const float inv_sigma = fdiv(1.0f, ta.sigma);
+  const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
+  const float sc = ta.sdf_scale;
+
+  for (int rd = blockIdx.x * waves_per_block + wave; rd < n_rounds; rd += gridDim.x * waves_per_block) {
+    const int p_raw = rd * 4 + grp;
+    const bool live = p_raw < ta.bs;
+    const long long s = ta.index[live ? p_raw : 0];
+    const float px = ta.pool_coord[s * 3 + 0], py = ta.pool_coord[s * 3 + 1], pz = ta.pool_coord[s * 3 + 2];
+    TopK t;
+    search_topk(mv, dl, px, py, pz, lane16, gbase, t);
+    float w[CLID_K], omega[CLID_K];
+    idw_weights(t, w, omega);
+    int my_j = -1;
+    float my_w = 0.f, my_om = 0.f;
+#pragma unroll
+    for (int k = 0; k < CLID_K; ++k) {
+      my_j = (my_k == k) ? t.j[k] : my_j;
+      my_w = (my_k == k) ? w[k] : my_w;
+      my_om = (my_k == k) ? omega[k] : my_om;
+    }
+    if (!live) my_j = -1;
+    const bool valid = my_j >= 0;
+    if (!valid) { my_w = 0.f; my_om = 0.f; }
+    const int jc = valid ? my_j : 0;
+    float4 v = reinterpret_cast<const float4*>(mv.feat)[(size_t)jc * 2 + (odd ? 1 : 0)];
+    const float4 pj = pos4[jc];
+    if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float rstd = 1.f;
+    if (mv.layer_norm) {  // np.py:632-633; an all-zero (invalid) row stays zero
+      float s1 = (v.x + v.y) + (v.z + v.w);
+      s1 += CLID_SWAP(s1);
+      const float mu = s1 * (1.0f / CLID_F);
+      v.x -= mu; v.y -= mu; v.z -= mu; v.w -= mu;
+      float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      s2 += CLID_SWAP(s2);
+      rstd = 1.0f / sqrtf(s2 * (1.0f / CLID_F) + 1e-5f);
+      v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
+    }
+    const float rx = valid ? fsub(px, pj.x) : 0.f, ry = valid ? fsub(py, pj.y) : 0.f, rz = valid ? fsub(pz, pj.z) : 0.f;
+
+    // ---- blended decoder input f (replicated)
+    float f[CLID_D];
+    {
+      float a0 = v.x * my_w, a1 = v.y * my_w, a2 = v.z * my_w, a3 = v.w * my_w;
+      float r0 = rx * my_w, r1 = ry * my_w, r2 = rz * my_w;  // carried by both lanes of the pair
+      CLID_BFLY(a0) CLID_BFLY(a1) CLID_BFLY(a2) CLID_BFLY(a3) CLID_BFLY(r0) CLID_BFLY(r1) CLID_BFLY(r2)
+      const float b0 = CLID_SWAP(a0), b1 = CLID_SWAP(a1), b2 = CLID_SWAP(a2), b3 = CLID_SWAP(a3);
+      f[0] = odd ? b0 : a0; f[1] = odd ? b1 : a1; f[2] = odd ? b2 : a2; f[3] = odd ? b3 : a3;
+      f[4] = odd ? a0 : b0; f[5] = odd ? a1 : b1; f[6] = odd ? a2 : b2; f[7] = odd ? a3 : b3;
+      f[8] = r0; f[9] = r1; f[10] = r2;
+    }
+    float pre[CLID_HPL];
+    const float sdf = mlp_forward(mlp, f, lane16, sc, pre);
+    const int l16 = lane16 + opaque_zero();
+    // ---- u = s (W2 .* a) W1   (replicated)
+    float u[CLID_D];
+    float e[CLID_HPL];
+#pragma unroll
+    for (int uu = 0; uu < CLID_HPL; ++uu)
+      e[uu] = pre[uu] > 0.f ? sc * mlp.w[CLID_H * CLID_D + CLID_H + l16 + CLID_G * uu] : 0.f;
+#pragma unroll
+    for (int c = 0; c < CLID_D; ++c) {
+      float part = 0.f;
+#pragma unroll
+      for (int uu = 0; uu < CLID_HPL; ++uu) part = fmaf(mlp.w[(l16 + CLID_G * uu) * CLID_D + c], e[uu], part);
+      u[c] = group_sum(part);
+    }
+    // ---- d w_k / d x and g = d sdf / d x
+    const float alx = 2.f * rx * my_om, aly = 2.f * ry * my_om, alz = 2.f * rz * my_om;
+    float abx = my_w * alx, aby = my_w * aly, abz = my_w * alz, wsum = my_w;
+    CLID_BFLY(abx) CLID_BFLY(aby) CLID_BFLY(abz) CLID_BFLY(wsum)
+    const float dwx = my_w * (abx - alx), dwy = my_w * (aby - aly), dwz = my_w * (abz - alz);
+    const float us0 = odd ? u[4] : u[0], us1 = odd ? u[5] : u[1], us2 = odd ? u[6] : u[2], us3 = odd ? u[7] : u[3];
+    float dot = us0 * v.x + us1 * v.y + us2 * v.z + us3 * v.w;
+    if (!odd) dot += u[8] * rx + u[9] * ry + u[10] * rz;
+    dot += CLID_SWAP(dot);
+    float gx = dot * dwx, gy = dot * dwy, gz = dot * dwz;
+    CLID_BFLY(gx) CLID_BFLY(gy) CLID_BFLY(gz)
+    gx += wsum * u[8]; gy += wsum * u[9]; gz += wsum * u[10];
+
+    // ---- training_mode side effects (np.py:708-733)
+    if (valid && !odd && lane16 < 2 * CLID_K) {
+      atomicAdd(&mv.cert[my_j], my_w);
+      if (mv.ts_update) atomicMax(&mv.ts_update[my_j], ta.pool_ts[s]);
+    }
+
+    // ---- losses and their derivatives
+    float delta = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
+    if (live) {
+      const float label = ta.pool_label[s];
+      const float wt = ta.loss_weight_on ? fabsf(ta.pool_weight[s]) : 1.0f;  // mapper.py:747-749
+      const float z = sdf * inv_sigma;
+      const float tgt = __frcp_rn(1.0f + __expf(-label * inv_sigma));         // loss.py:60
+      const float ez = __expf(-fabsf(z));
+      const float sg = (z >= 0.f ? 1.0f : ez) * __frcp_rn(1.0f + ez);
+      const float li = fmaxf(z, 0.f) - z * tgt + __logf(1.0f + ez);           // BCEWithLogits
+      if (lane16 == 0) bce_acc += wt * li;
+      delta = wt * (sg - tgt) * inv_sigma * ta.inv_n_main;
+      if (ta.weight_e > 0.f) {
+        const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
+        if (lane16 == 0) eik_acc += (nrm - 1.f) * (nrm - 1.f);
+        // d/dg of weight_e * mean((|g|-1)^2); 0 at |g| == 0 (torch norm subgradient)
+        const float coef = nrm > 0.f ? ta.weight_e * 2.f * (nrm - 1.f) * ta.inv_n_eik / nrm : 0.f;
+        cx = coef * gx; cy = coef * gy; cz = coef * gz;
+      }
+    }
+    const float sk = cx * dwx + cy * dwy + cz * dwz;  // c . dw_k
+
+    // ---- decoder gradients
+    if (ta.train_decoder) {
+      float tv[CLID_D];
+      {
+        float t0 = v.x * sk, t1 = v.y * sk, t2 = v.z * sk, t3 = v.w * sk;
+        float q0 = rx * sk, q1 = ry * sk, q2 = rz * sk;
+        CLID_BFLY(t0) CLID_BFLY(t1) CLID_BFLY(t2) CLID_BFLY(t3) CLID_BFLY(q0) CLID_BFLY(q1) CLID_BFLY(q2)
+        const float b0 = CLID_SWAP(t0), b1 = CLID_SWAP(t1), b2 = CLID_SWAP(t2), b3 = CLID_SWAP(t3);
+        tv[0] = odd ? b0 : t0; tv[1] = odd ? b1 : t1; tv[2] = odd ? b2 : t2; tv[3] = odd ? b3 : t3;
+        tv[4] = odd ? t0 : b0; tv[5] = odd ? t1 : b1; tv[6] = odd ? t2 : b2; tv[7] = odd ? t3 : b3;
+        tv[8] = q0 + wsum * cx; tv[9] = q1 + wsum * cy; tv[10] = q2 + wsum * cz;
+      }
+      const float dz = sc * delta;
+      float fb = (lane16 == CLID_D) ? 1.0f : 0.f, tb = 0.f;
+#pragma unroll
+      for (int c = 0; c < CLID_D; ++c) {
+        fb = (lane16 == c) ? f[c] : fb;
+        tb = (lane16 == c) ? tv[c] : tb;
+      }
+#pragma unroll
+      for (int uu = 0; uu < CLID_HPL; ++uu) {
+        const int h = l16 + CLID_G * uu;
+        const bool on = pre[uu] > 0.f;
+        const float dh = on ? dz * mlp.w[CLID_H * CLID_D + CLID_H + h] : 0.f;
+        float w1t = 0.f;
+#pragma unroll
+        for (int c = 0; c < CLID_D; ++c) w1t = fmaf(mlp.w[h * CLID_D + c], tv[c], w1t);
+        acc.dW2[uu] += on ? (dz * pre[uu] + sc * w1t) : 0.f;
+        acc.dW1[uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh, fb, acc.dW1[uu], 0, 0, 0);
+        acc.dW1[uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[uu], tb, acc.dW1[uu], 0, 0, 0);
+      }
+      if (lane16 == 0) acc.db2 += dz;
+    }
+
+    // ---- feature gradients: upstream (w_k delta + s_k) u[0:8] on the (normalised) row of neighbour k
+    {
+      const float ck = my_w * delta + sk;
+      float d0 = ck * us0, d1 = ck * us1, d2 = ck * us2, d3 = ck * us3;
+      if (mv.layer_norm) {  // dx = rstd (dy - mean(dy) - xhat mean(dy xhat)) over the 8 features (pair of lanes)
+        float m1 = (d0 + d1) + (d2 + d3);
+        float m2 = (d0 * v.x + d1 * v.y) + (d2 * v.z + d3 * v.w);
+        m1 += CLID_SWAP(m1);
+        m2 += CLID_SWAP(m2);
+        m1 *= (1.0f / CLID_F);
+        m2 *= (1.0f / CLID_F);
+        d0 = rstd * (d0 - m1 - v.x * m2); d1 = rstd * (d1 - m1 - v.y * m2);
+        d2 = rstd * (d2 - m1 - v.z * m2); d3 = rstd * (d3 - m1 - v.w * m2);
+      }
+      if (valid && lane16 < 2 * CLID_K && ck != 0.f) {
+        float* dst = g_theta + (size_t)my_j * CLID_F + (odd ? 4 : 0);
+        atomicAdd(dst + 0, d0); atomicAdd(dst + 1, d1); atomicAdd(dst + 2, d2); atomicAdd(dst + 3, d3);
+      }
+    }
+  }
+  flush_mlp_acc(acc, bce_acc, eik_acc, red, partial + (size_t)blockIdx.x * kPartialStride);
+}
+
+#undef CLID_BFLY
+#undef CLID_SWAP
+
+}  // namespace clid
+
+int clid_train_analytic_blocks(int bs) {
+  const int rounds = (bs + 3) / 4;
+  int nb = (rounds + CLID_BLOCK / 64 - 1) / (CLID_BLOCK / 64);
+  return nb > clid::kMaxBwdBlocks ? clid::kMaxBwdBlocks : (nb < 1 ? 1 : nb);
+}
+
+int clid_launch_train_analytic(const clid_map_view* mv, const clid_train_args* a, float* partial, hipStream_t s) {
+  if (a->decimation != 1) {
+    clid_set_error("clid_train_fwd_bwd: analytic eikonal mode expects gradient_decimation == 1 (utils/config.py:645-646), got %d",
+                   a->decimation);
+    return CLID_E_ARG;
+  }
+  const int rounds = (a->bs + 3) / 4;
+  hipLaunchKernelGGL(clid::k_train_analytic, dim3(clid_train_analytic_blocks(a->bs)), dim3(CLID_BLOCK), 0, s, *mv, *a,
+                     partial, rounds);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}

@@ -176,7 +176,7 @@ def test_adam_kernel_vs_torch(env):
     assert torch.equal(p.cpu()[::3] , p0[::3]) or maxerr(p.cpu()[::3], p0[::3]) == 0.0
 
 
-G6 = [("numerical", False, 0), ("numerical", False, 1), ("numerical", True, 0)]
+G6 = [("numerical", False, 0), ("numerical", False, 1), ("numerical", True, 0), ("analytic", False, 0), ("analytic", True, 0)]
 
 
 @pytest.mark.parametrize("mode,frozen,ln", G6)
@@ -187,6 +187,8 @@ def test_mapping_loop_g6(env, mode, frozen, ln):
     g = gio.load(f"g6_loop_{tag}.npz")
     p = gio.load("pool.npz")
     cfg = env.config(layer_norm_on=bool(ln), bs=int(g["index_seq"].shape[1]), bs_new_sample=200)
+    if mode == "analytic":
+        cfg.numerical_grad, cfg.gradient_decimation = False, 1
     nm = env.neural_points(cfg, base=p)
     dec = env.decoder(cfg, g, "init_")
     if frozen:
@@ -342,3 +344,37 @@ def test_full_size_invariants(env):
     mp.mapping(2)
     for a, b in zip(before, (nm.local_geo_features, *dec.flat_params())):
         assert torch.equal(a, b.detach())
+
+
+@pytest.mark.parametrize("mode,ln", [("analytic", 1), ("numerical", 1), ("analytic", 0)])
+def test_mapping_loop_vs_oracle_free_batches(env, mode, ln):
+    """Modes without a reference fixture (analytic + layer norm) and fresh random batches: the fused loop
+    against the pinned CPU oracle, 3 iterations, bs 4096."""
+    p = gio.load("pool.npz")
+    g = gio.load("g6_loop_numerical_train_ln0.npz")
+    bs, iters = 4096, 3
+    cfg = env.config(layer_norm_on=bool(ln), bs=bs)
+    if mode == "analytic":
+        cfg.numerical_grad, cfg.gradient_decimation = False, 1
+    gen = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, p["coord"].shape[0], (iters, bs), generator=gen)
+    nm = env.neural_points(cfg, base=p)
+    dec = env.decoder(cfg, g, "init_")
+    mp, _ = env.mapper(cfg, nm, dec)
+    mp.mapping(iters, index_seq=idx.cuda())
+    st = gio.map_state(layer_norm_on=bool(ln))
+    st.local_geo_features = gio.T(p["base_geo_features"])[gio.T(g["local_mask"])].clone()
+    st.local_point_certainties = gio.T(p["base_point_certainties"])[gio.T(g["local_mask"])[:-1]].clone()
+    st.local_point_ts_update = gio.T(p["base_point_ts_update"])[gio.T(g["local_mask"])[:-1]].clone()
+    pool, _ = gio.sample_pool()
+    od = gio.decoder(g, "init_")
+    lc = O.LoopConfig(numerical_grad=(mode == "numerical"), gradient_decimation=10 if mode == "numerical" else 1)
+    recs = O.mapping_iters(st, od, pool, idx, lc, record=True)
+    got = mp.last_losses.cpu()
+    for it, r in enumerate(recs):
+        assert abs(float(got[it, 0]) - float(r["loss"])) <= 1e-5, (it, got[it], r["loss"])
+        assert abs(float(got[it, 2]) - float(r["eikonal_loss"])) <= 1e-5
+    assert maxerr(nm.local_geo_features, recs[-1]["theta"]) <= 1e-4
+    for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
+        assert maxerr(t, o) <= 1e-4
+    assert maxerr(nm.local_point_certainties, recs[-1]["certainties"]) <= 2e-3
