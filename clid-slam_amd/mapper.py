@@ -115,8 +115,6 @@ class Mapper:
             bad.append("proj_correction_on")
         if c.main_loss_type != "bce":
             bad.append(f"main_loss_type={c.main_loss_type}")
-        if not c.weighted_first:
-            bad.append("weighted_first=False")
         if self.ba_done_flag:
             bad.append("ba_done_flag")
         if c.ekional_loss_on and getattr(c, "ekional_add_to", "all") != "all":
@@ -133,6 +131,8 @@ class Mapper:
         lib = _lib.load()
         self._check_fused_config()
         cfg, nm = self.config, self.neural_points
+        if not cfg.weighted_first:
+            return self._mapping_unfused(iter_count, index_seq)
         iter_count = max(1, iter_count + self.adaptive_iter_offset)
         dist = _dist()
         world = dist.get_world_size() if dist else 1
@@ -227,6 +227,46 @@ class Mapper:
             dist.all_reduce(losses)
         self.last_losses = losses
         self._keep = (keep, index_seq, grad, m, v, m_mlp, v_mlp)
+        nm.assign_local_to_global()
+
+    def _mapping_unfused(self, iter_count, index_seq=None):
+        """`weighted_first: False` (decode every neighbour, blend the SDFs; utils/mapper.py:679-680): the
+        reference's op sequence on the HIP-backed autograd ops (query_feature / Decoder.sdf / sdf_bce_loss
+        kernels) with torch's Adam.  Single GPU, numerical or no eikonal term."""
+        from .loss import sdf_bce_loss
+        from .tools import setup_optimizer
+
+        cfg, nm = self.config, self.neural_points
+        if _dist() is not None:
+            raise NotImplementedError("weighted_first=False is not sharded across GPUs")
+        if cfg.ekional_loss_on and cfg.weight_e > 0 and not cfg.numerical_grad:
+            raise NotImplementedError("weighted_first=False with the analytic eikonal term needs double backward")
+        iter_count = max(1, iter_count + self.adaptive_iter_offset)
+        if index_seq is None:
+            index_seq = self._draw_index(iter_count, int(cfg.bs))
+        iter_count = index_seq.shape[0]
+        opt = setup_optimizer(cfg, list(nm.parameters()), list(self.geo_mlp.parameters()))
+        losses = torch.zeros((iter_count, 4), device=self.global_coord_pool.device)
+        for it in range(iter_count):
+            index = index_seq[it].to(torch.int64)
+            coord, label = self.global_coord_pool[index], self.sdf_label_pool[index]
+            ts, weight = self.time_pool[index], self.weight_pool[index].abs()
+            feat, _, w_knn, _, _ = nm.query_feature(coord, ts)
+            sdf_pred = torch.sum(self.geo_mlp.sdf(feat) * w_knn, dim=1).squeeze(1)
+            loss = sdf_bce_loss(sdf_pred, label, self.sdf_scale, weight, cfg.loss_weight_on)
+            losses[it, 1] = loss.detach()
+            if cfg.ekional_loss_on and cfg.weight_e > 0:
+                d = cfg.gradient_decimation
+                g = self.get_numerical_gradient(coord[::d], sdf_pred[::d], cfg.voxel_size_m * cfg.num_grad_step_ratio)
+                eik = ((g.norm(2, dim=-1) - 1.0) ** 2).mean()
+                losses[it, 2] = eik.detach()
+                loss = loss + cfg.weight_e * eik
+            losses[it, 0] = loss.detach()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+        self.total_iter += iter_count
+        self.last_losses = losses
         nm.assign_local_to_global()
 
     # ------------------------------------------------------------------ a5 / a6

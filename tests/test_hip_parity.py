@@ -378,3 +378,31 @@ def test_mapping_loop_vs_oracle_free_batches(env, mode, ln):
     for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
         assert maxerr(t, o) <= 1e-4
     assert maxerr(nm.local_point_certainties, recs[-1]["certainties"]) <= 2e-3
+
+
+def test_mapping_weighted_first_false_vs_oracle(env):
+    """`weighted_first: False`: the un-fused loop over the HIP autograd ops against the oracle."""
+    p = gio.load("pool.npz")
+    g = gio.load("g6_loop_numerical_train_ln0.npz")
+    bs, iters = 2048, 2
+    cfg = env.config(weighted_first=False, bs=bs)
+    gen = torch.Generator().manual_seed(9)
+    idx = torch.randint(0, p["coord"].shape[0], (iters, bs), generator=gen)
+    nm = env.neural_points(cfg, base=p)
+    dec = env.decoder(cfg, g, "init_")
+    mp, _ = env.mapper(cfg, nm, dec)
+    mp.mapping(iters, index_seq=idx.cuda())
+    st = gio.map_state(weighted_first=False)
+    m = gio.T(g["local_mask"])
+    st.local_geo_features = gio.T(p["base_geo_features"])[m].clone()
+    st.local_point_certainties = gio.T(p["base_point_certainties"])[m[:-1]].clone()
+    st.local_point_ts_update = gio.T(p["base_point_ts_update"])[m[:-1]].clone()
+    pool, _ = gio.sample_pool()
+    od = gio.decoder(g, "init_")
+    recs = O.mapping_iters(st, od, pool, idx, O.LoopConfig(), record=True)
+    got = mp.last_losses.cpu()
+    for it, r in enumerate(recs):
+        assert abs(float(got[it, 0]) - float(r["loss"])) <= 1e-5
+    assert maxerr(nm.local_geo_features, recs[-1]["theta"]) <= 1e-4
+    for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
+        assert maxerr(t, o) <= 1e-4
