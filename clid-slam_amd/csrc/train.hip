@@ -370,6 +370,323 @@ k_train_fused(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
   CLID_STAMP(25);
 }
 
+// ---- v4 fused iteration kernel: 8-lane search groups, 16-lane decode groups ----------------------------------
+// The probe/selection phase is replicated work per lane-slot, so it runs with 8 lanes per query: one pass
+// serves all 8 queries of a task (both "rounds" at once: half the instructions per query for the selection,
+// 11 probe rows instead of 2 x 6, and the two rounds' dependent loads overlap).  Winners go to LDS; the
+// decode/backward phase keeps 16 lanes per query (4 hidden units per lane, MFMA operand layout) in the
+// lane16 = 2k + half arrangement: every lane owns half a feature row of ONE neighbour, weights and blends
+// are DPP butterflies, the feature-gradient scatter is 4 atomics per lane.
+__device__ __forceinline__ float group8_min(float v) {
+  v = fminf(v, dpp_mov<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = fminf(v, dpp_mov<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = fminf(v, dpp_mov<0x141>(v));  // row_half_mirror: the other quad of the 8-lane group
+  return v;
+}
+__device__ __forceinline__ int group8_sum_i(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
+  return v;
+}
+
+struct WaveLds {
+  float4 qinfo[8];      // per query slot: x, y, z, pool sample index (int bits, -1 = padding)
+  float2 win[8][8];     // per slot: up to K winners (d2, local id bits), ascending; (9e3, -1) = none
+  float4 st[2][64][2];  // per decode round, per lane: {f[lane16], w_k, j_k bits, sdf}, {pre[0..3]}
+};
+
+constexpr int kProbeRows8 = 6;  // probes per lane per chunk; chunk = 48 slots
+
+// 81-cell search of one query by the 8 lanes of a group; winners -> win[0..K)
+__device__ __forceinline__ void search8(const clid_map_view& mv, const DeltaLds& dl, float x, float y, float z,
+                                        int lane8, int gshift, float2* __restrict__ win, int dbg = 0,
+                                        const OccLds* occ = nullptr) {
+  const int4* __restrict__ tab = reinterpret_cast<const int4*>(mv.tab);
+  const float4* __restrict__ tpos = reinterpret_cast<const float4*>(mv.tab_pos);
+  const int B = mv.buffer_size;
+  const int r0 = base_slot(x, y, z, mv.resolution, B);
+  Cand c;
+  c.init();
+  for (int o0 = 0; o0 < mv.P; o0 += 8 * kProbeRows8) {
+    int slot[kProbeRows8];
+    unsigned home[kProbeRows8];
+    int4 bk[kProbeRows8];
+#pragma unroll
+    for (int t = 0; t < kProbeRows8; ++t) {  // straight-line (predicated) so all loads of the chunk batch
+      const int o = o0 + 8 * t + lane8;
+      int sl = r0 + dl.d[o];
+      if (sl >= B) sl -= B;
+      const bool in = o < mv.P;
+      slot[t] = in ? sl : -2;
+      home[t] = tab_home(sl, mv.log2cap);
+      bool fetch = in;
+      if (occ) fetch = fetch && ((occ->w[home[t] >> 5] >> (home[t] & 31)) & 1u);
+      bk[t] = make_int4(-1, -1, -1, -1);
+      if (fetch) bk[t] = tab[(dbg & 8192) ? (unsigned)(lane8 + 8 * t) : home[t]];
+    }
+    int cell[kProbeRows8];
+    bool walk = false;
+#pragma unroll
+    for (int t = 0; t < kProbeRows8; ++t) {
+      const int m = bucket_match(bk[t], slot[t]);
+      cell[t] = m >= 0 ? (int)(home[t] * 4u) + m : -1;
+      walk |= (m < 0) && (bk[t].w >= 0) && (slot[t] != -2);
+    }
+    if (__any(walk)) {  // rare: a full bucket without a match
+#pragma unroll
+      for (int t = 0; t < kProbeRows8; ++t)
+        if (cell[t] < 0 && slot[t] != -2 && bk[t].w >= 0) cell[t] = tab_find(tab, mv.log2cap, slot[t], home[t], bk[t]);
+    }
+    float4 pp[kProbeRows8];
+#pragma unroll
+    for (int t = 0; t < kProbeRows8; ++t) pp[t] = tpos[(cell[t] >= 0 && !(dbg & 16384)) ? cell[t] : 0];
+#pragma unroll
+    for (int t = 0; t < kProbeRows8; ++t) {
+      const float ax = fsub(pp[t].x, x), ay = fsub(pp[t].y, y), az = fsub(pp[t].z, z);
+      const float d2 = fadd(fadd(fmul(ax, ax), fmul(ay, ay)), fmul(az, az));
+      if (cell[t] >= 0 && !(d2 > mv.max_valid_dist2)) c.insert(d2, __float_as_int(pp[t].w));  // np.py:1016-1020
+    }
+  }
+  CLID_STAMP(2);
+#pragma unroll
+  for (int k = 0; k < CLID_K; ++k) {
+    const float head = c.d[0];
+    const float m = group8_min(head);
+    const bool mine = (head == m) && (c.j[0] >= 0);
+    const unsigned long long b = __ballot(mine);
+    const unsigned gb = (unsigned)(b >> gshift) & 0xFFu;
+    if (gb && lane8 == (int)(__ffs(gb) - 1)) {
+      win[k] = make_float2(m, __int_as_float(c.j[0]));
+      c.pop();
+    }
+  }
+}
+
+__global__ void __launch_bounds__(CLID_BLOCK, CLID_FUSED_WAVES)
+k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap) {
+  __shared__ MlpLds mlp;
+  __shared__ DeltaLds dl;
+  __shared__ WaveLds wlds[CLID_BLOCK / 64];
+  __shared__ float red[(CLID_BLOCK / 64) * kRedFloats];
+  const OccLds* occ = nullptr;
+  stage_mlp_and_delta(mlp, dl, mv, ta.W1, ta.b1, ta.W2, ta.b2);
+  const int lane = threadIdx.x & 63, lane16 = lane & 15, grp = lane >> 4;
+  const int lane8 = lane & 7, slot8 = lane >> 3;
+  const int wave = threadIdx.x >> 6, waves_per_block = CLID_BLOCK / 64;
+  const int my_k = lane16 >> 1;
+  const bool odd = lane16 & 1;
+  WaveLds& wl = wlds[wave];
+  MlpAcc acc;
+  acc.zero();
+  float bce_acc = 0.f, eik_acc = 0.f;
+  float* g_theta = ta.grad + CLID_GRAD_FEAT_OFFSET;
+  const float inv_sigma = fdiv(1.0f, ta.sigma);
+  const float inv_two_eps = fdiv(1.0f, 2.0f * ta.fd_eps);
+  const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
+  const float sc = ta.sdf_scale;
+
+  for (int task = blockIdx.x * waves_per_block + wave; task < tmap.n_tasks; task += gridDim.x * waves_per_block) {
+    const bool bundle = task < tmap.n_fd;
+    CLID_STAMP(0);
+    // ================= search: 8 slots x 8 lanes
+    {
+      const QDesc qd = task_query(tmap, task, slot8 >> 2, slot8 & 3);
+      const bool live = qd.p >= 0;
+      const long long s = ta.index[live ? qd.p : 0];
+      float px = ta.pool_coord[s * 3 + 0], py = ta.pool_coord[s * 3 + 1], pz = ta.pool_coord[s * 3 + 2];
+      if (qd.axis == 0) px = fadd(px, qd.sign * ta.fd_eps);  // x + [eps,0,0] in fp32 (mapper.py:988-999)
+      if (qd.axis == 1) py = fadd(py, qd.sign * ta.fd_eps);
+      if (qd.axis == 2) pz = fadd(pz, qd.sign * ta.fd_eps);
+      if (lane8 == 0) wl.qinfo[slot8] = make_float4(px, py, pz, __int_as_float(live ? (int)s : -1));
+      if (lane8 < CLID_K) wl.win[slot8][lane8] = make_float2(9e3f, __int_as_float(-1));  // np.py:606
+      asm volatile("" ::"v"(px), "v"(py), "v"(pz));
+      CLID_STAMP(1);
+      search8(mv, dl, px, py, pz, lane8, lane & 56, wl.win[slot8], ta.debug_flags, occ);
+    }
+    CLID_STAMP(3);
+    wave_lds_fence();
+    CLID_STAMP(4);
+    // ================= decode forward: 2 rounds x 4 queries x 16 lanes
+#pragma unroll 1
+    for (int round = 0; round < 2; ++round) {
+      const int s16 = round * 4 + grp;
+      const float4 qi = wl.qinfo[s16];
+      const int sidx = __float_as_int(qi.w);
+      const float2 wn = wl.win[s16][my_k];  // my_k < 8 always in range; k = 6,7 hold stale/none -> masked
+      int my_j = (lane16 < 2 * CLID_K && sidx >= 0) ? __float_as_int(wn.y) : -1;
+      const bool valid = my_j >= 0;
+      float om = valid ? fdiv(1.0f, fadd(wn.x, 1e-15f)) : 0.f;  // np.py:688-693
+      float osum = om;
+      osum += dpp_mov<0x128>(osum); osum += dpp_mov<0x124>(osum); osum += dpp_mov<0x122>(osum);
+      const float my_w = valid ? fmul(om, fdiv(1.0f, osum)) : 0.f;  // np.py:699-706
+      const int jc = valid ? my_j : 0;
+      float4 v = reinterpret_cast<const float4*>(mv.feat)[(size_t)jc * 2 + (odd ? 1 : 0)];
+      const float4 pj = pos4[jc];
+      if (mv.layer_norm) {  // np.py:632-633
+        float s1 = (v.x + v.y) + (v.z + v.w);
+        s1 += dpp_mov<0xB1>(s1);
+        const float mu = s1 * (1.0f / CLID_F);
+        v.x -= mu; v.y -= mu; v.z -= mu; v.w -= mu;
+        float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        s2 += dpp_mov<0xB1>(s2);
+        const float rstd = 1.0f / sqrtf(s2 * (1.0f / CLID_F) + 1e-5f);
+        v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
+      }
+      float f[CLID_D];
+      {
+        float a0 = v.x * my_w, a1 = v.y * my_w, a2 = v.z * my_w, a3 = v.w * my_w;
+        float r0 = fsub(qi.x, pj.x) * my_w, r1 = fsub(qi.y, pj.y) * my_w, r2 = fsub(qi.z, pj.z) * my_w;
+#define CLID_BFLY(x) x += dpp_mov<0x128>(x); x += dpp_mov<0x124>(x); x += dpp_mov<0x122>(x);
+        CLID_BFLY(a0) CLID_BFLY(a1) CLID_BFLY(a2) CLID_BFLY(a3) CLID_BFLY(r0) CLID_BFLY(r1) CLID_BFLY(r2)
+#undef CLID_BFLY
+        const float b0 = dpp_mov<0xB1>(a0), b1 = dpp_mov<0xB1>(a1), b2 = dpp_mov<0xB1>(a2), b3 = dpp_mov<0xB1>(a3);
+        f[0] = odd ? b0 : a0; f[1] = odd ? b1 : a1; f[2] = odd ? b2 : a2; f[3] = odd ? b3 : a3;
+        f[4] = odd ? a0 : b0; f[5] = odd ? a1 : b1; f[6] = odd ? a2 : b2; f[7] = odd ? a3 : b3;
+        f[8] = r0; f[9] = r1; f[10] = r2;
+      }
+      float pre[CLID_HPL];
+      const float sdf = mlp_forward(mlp, f, lane16, sc, pre);
+      if (valid && !odd && !(ta.debug_flags & 1)) {  // training_mode side effects (np.py:708-733)
+        atomicAdd(&mv.cert[my_j], my_w);
+        const QDesc qd = task_query(tmap, task, round, grp);
+        if (qd.axis < 0 && mv.ts_update) atomicMax(&mv.ts_update[my_j], ta.pool_ts[sidx]);
+      }
+      float fb = (lane16 == CLID_D) ? 1.0f : 0.f;
+#pragma unroll
+      for (int c = 0; c < CLID_D; ++c) fb = (lane16 == c) ? f[c] : fb;
+      wl.st[round][lane][0] = make_float4(fb, my_w, __int_as_float(my_j), sdf);
+      wl.st[round][lane][1] = make_float4(pre[0], pre[1], pre[2], pre[3]);
+      CLID_STAMP(5 + round);
+    }
+    wave_lds_fence();
+    CLID_STAMP(7);
+    // ================= losses
+    float ecoef = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+    if (bundle) {
+      gx = (wl.st[0][0][0].w - wl.st[0][16][0].w) * inv_two_eps;   // mapper.py:1011-1013
+      gy = (wl.st[0][32][0].w - wl.st[0][48][0].w) * inv_two_eps;
+      gz = (wl.st[1][0][0].w - wl.st[1][16][0].w) * inv_two_eps;
+      const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
+      if (lane == 0) eik_acc += (nrm - 1.f) * (nrm - 1.f);
+      // d/dg of weight_e * mean((|g|-1)^2); 0 at |g| == 0 (torch norm subgradient)
+      ecoef = nrm > 0.f ? ta.weight_e * 2.f * (nrm - 1.f) * ta.inv_n_eik * inv_two_eps / nrm : 0.f;
+    }
+    // ================= backward
+#pragma unroll 1
+    for (int round = 0; round < 2; ++round) {
+      const QDesc qd = task_query(tmap, task, round, grp);
+      const float4 s0 = wl.st[round][lane][0], s1 = wl.st[round][lane][1];
+      const float fb = s0.x, my_w = s0.y, sdf = s0.w;
+      const int my_j = __float_as_int(s0.z);
+      float delta = 0.f;
+      if (qd.p >= 0) {
+        if (qd.axis < 0) {
+          const int sidx = __float_as_int(wl.qinfo[round * 4 + grp].w);
+          const float label = ta.pool_label[sidx];
+          const float wt = ta.loss_weight_on ? fabsf(ta.pool_weight[sidx]) : 1.0f;  // mapper.py:747-749
+          const float z = sdf * inv_sigma;
+          const float tgt = __frcp_rn(1.0f + __expf(-label * inv_sigma));           // loss.py:60
+          const float ez = __expf(-fabsf(z));
+          const float sg = (z >= 0.f ? 1.0f : ez) * __frcp_rn(1.0f + ez);
+          const float li = fmaxf(z, 0.f) - z * tgt + __logf(1.0f + ez);             // BCEWithLogits
+          if (lane16 == 0) bce_acc += wt * li;
+          delta = wt * (sg - tgt) * inv_sigma * ta.inv_n_main;
+        } else {
+          const float ga = qd.axis == 0 ? gx : (qd.axis == 1 ? gy : gz);
+          delta = qd.sign * ecoef * ga;
+        }
+      }
+      // decoder backward (dz = scale * delta)
+      const float dz = sc * delta;
+      const int l16 = lane16 + opaque_zero();
+      const float pre[CLID_HPL] = {s1.x, s1.y, s1.z, s1.w};
+      float dh[CLID_HPL];
+#pragma unroll
+      for (int u = 0; u < CLID_HPL; ++u) {
+        const bool on = pre[u] > 0.f;
+        dh[u] = on ? dz * mlp.w[CLID_H * CLID_D + CLID_H + l16 + CLID_G * u] : 0.f;
+        if (ta.train_decoder) {
+          acc.dW2[u] += on ? dz * pre[u] : 0.f;
+          acc.dW1[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[u], fb, acc.dW1[u], 0, 0, 0);
+        }
+      }
+      if (ta.train_decoder && lane16 == 0) acc.db2 += dz;
+      // d f[0:8] (replicated), then the scatter d theta[j_k][c] += w_k df[c]
+      float df8[CLID_F];
+#pragma unroll
+      for (int c = 0; c < CLID_F; ++c) {
+        float part = 0.f;
+#pragma unroll
+        for (int u = 0; u < CLID_HPL; ++u) part = fmaf(mlp.w[(l16 + CLID_G * u) * CLID_D + c], dh[u], part);
+        df8[c] = group_sum(part);
+      }
+      if (!(ta.debug_flags & 2)) {
+        const int gb16 = lane & 48;
+        const bool hi = lane16 >= 8;
+        if (!mv.layer_norm) {
+          // coalesced atomics: in pass r the low / high 8 lanes of the group write the 8 consecutive floats
+          // of neighbour 2r / 2r+1 (one 32-byte segment each); its (j, w) come from the owning lane pair
+          float dfc = 0.f;
+#pragma unroll
+          for (int c = 0; c < CLID_F; ++c) dfc = ((lane16 & 7) == c) ? df8[c] : dfc;
+#pragma unroll
+          for (int r = 0; r < CLID_K / 2; ++r) {
+            const int src = gb16 + 4 * r + (hi ? 2 : 0);
+            const int jk = __shfl(my_j, src, 64);
+            const float wk = __shfl(my_w, src, 64);
+            if (jk >= 0 && delta != 0.f) atomicAdd(&g_theta[(size_t)jk * CLID_F + (lane16 & 7)], wk * dfc);
+          }
+        } else {
+          // layer-norm backward in the (neighbour, half) lane layout, then the same coalesced scatter
+          const int jc = my_j >= 0 ? my_j : 0;
+          float4 v = reinterpret_cast<const float4*>(mv.feat)[(size_t)jc * 2 + (odd ? 1 : 0)];
+          float t1 = (v.x + v.y) + (v.z + v.w);
+          t1 += dpp_mov<0xB1>(t1);
+          const float mu = t1 * (1.0f / CLID_F);
+          v.x -= mu; v.y -= mu; v.z -= mu; v.w -= mu;
+          float t2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          t2 += dpp_mov<0xB1>(t2);
+          const float rstd = 1.0f / sqrtf(t2 * (1.0f / CLID_F) + 1e-5f);
+          v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
+          float d4[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {  // explicit select: `df8[4*odd + i]` would put df8 in scratch
+            const float lo = df8[i], hi4 = df8[4 + i];
+            float sel = lo;
+            asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(sel) : "v"(lo), "v"(hi4), "s"(__ballot(odd)));
+            d4[i] = sel * my_w;
+          }
+          float m1 = (d4[0] + d4[1]) + (d4[2] + d4[3]);
+          float m2 = (d4[0] * v.x + d4[1] * v.y) + (d4[2] * v.z + d4[3] * v.w);
+          m1 += dpp_mov<0xB1>(m1);
+          m2 += dpp_mov<0xB1>(m2);
+          m1 *= (1.0f / CLID_F);
+          m2 *= (1.0f / CLID_F);
+          d4[0] = rstd * (d4[0] - m1 - v.x * m2); d4[1] = rstd * (d4[1] - m1 - v.y * m2);
+          d4[2] = rstd * (d4[2] - m1 - v.z * m2); d4[3] = rstd * (d4[3] - m1 - v.w * m2);
+#pragma unroll
+          for (int r = 0; r < CLID_K / 2; ++r) {
+            const int c = lane16 & 7;
+            const int src = gb16 + 4 * r + (hi ? 2 : 0) + (c >> 2);  // lane holding floats 4*(c>>2).. of neighbour k
+            const int jk = __shfl(my_j, src, 64);
+            const float e0 = __shfl(d4[0], src, 64), e1 = __shfl(d4[1], src, 64), e2 = __shfl(d4[2], src, 64),
+                        e3 = __shfl(d4[3], src, 64);
+            const float val = (c & 2) ? ((c & 1) ? e3 : e2) : ((c & 1) ? e1 : e0);
+            if (jk >= 0 && delta != 0.f) atomicAdd(&g_theta[(size_t)jk * CLID_F + c], val);
+          }
+        }
+      }
+      CLID_STAMP(8 + round);
+    }
+    wave_lds_fence();
+    CLID_STAMP(10);
+  }
+  CLID_STAMP(24);
+  flush_mlp_acc(acc, bce_acc, eik_acc, red, partial + (size_t)blockIdx.x * kPartialStride);
+  CLID_STAMP(25);
+}
+
 // ---- partial reduction + Adam ---------------------------------------------------------------------------
 // torch.optim.Adam._single_tensor_adam, op order as ATen's:
 //   m.lerp_(g, 1-b1); v.mul_(b2).addcmul_(g, g, 1-b2); denom = sqrt(v)/sqrt(bc2) + eps;
@@ -615,7 +932,10 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
   if (a->eikonal_mode == 2) {  // loss.numerical_grad_on: False (utils/mapper.py:57-69, 660-661, 695-696)
     if (int e = clid_launch_train_analytic(mv, a, ws.partial, s)) return e;
   } else {
-    hipLaunchKernelGGL(k_train_fused, dim3(nb), dim3(CLID_BLOCK), 0, s, *mv, *a, ws.partial, tmap);
+    if (a->debug_flags & 4096)
+      hipLaunchKernelGGL(k_train_fused, dim3(nb), dim3(CLID_BLOCK), 0, s, *mv, *a, ws.partial, tmap);
+    else
+      hipLaunchKernelGGL(k_train_fused8, dim3(nb), dim3(CLID_BLOCK), 0, s, *mv, *a, ws.partial, tmap);
     CLID_CHECK_LAUNCH();
   }
   if (g_prof) prof_mark(s);

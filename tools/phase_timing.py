@@ -24,9 +24,13 @@ lib = C.CDLL(out)
 buf = (C.c_longlong * (256 * 32))()
 assert lib.clid_debug_read_stamps(buf) == 0
 a = np.array(buf, dtype=np.int64).reshape(256, 32)
+names8 = {0: "task start", 1: "coords", 2: "probed", 3: "selected", 4: "fence", 5: "fwd r0", 6: "fwd r1", 7: "fence2", 8: "bwd r0", 9: "bwd r1", 10: "fence3", 24: "loop end", 25: "flushed"}
 names = {0: "A start", 1: "A buckets", 2: "A pos4", 3: "A inserted", 4: "A selected", 5: "A blended", 6: "A mlp",
          8: "B start", 9: "B buckets", 10: "B pos4", 11: "B inserted", 12: "B selected", 13: "B blended", 14: "B mlp",
          16: "stashed", 17: "bwdA start", 18: "bwdA end", 20: "bwdB start", 21: "bwdB end", 24: "loop end", 25: "flushed"}
+import os
+if not (int(os.environ.get('CLID_DEBUG_FLAGS', '0')) & 4096):
+    names = names8
 keys = sorted(names)
 print("phase deltas (median / p90 cycles at 100 MHz s_memtime? raw units), relative to previous stamp:")
 prev = None
