@@ -550,7 +550,12 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
       if (valid && !odd && !(ta.debug_flags & 1)) {  // training_mode side effects (np.py:708-733)
         atomicAdd(&mv.cert[my_j], my_w);
         const QDesc qd = task_query(tmap, task, round, grp);
-        if (qd.axis < 0 && mv.ts_update) atomicMax(&mv.ts_update[my_j], ta.pool_ts[sidx]);
+        if (qd.axis < 0 && mv.ts_update) {
+          // amax is idempotent: only the first touch of a point by a newer stamp needs the atomic (a scattered
+          // atomic costs ~10x a scattered load: tools/ubench_gather.hip)
+          const int ts = ta.pool_ts[sidx];
+          if (mv.ts_update[my_j] < ts) atomicMax(&mv.ts_update[my_j], ts);
+        }
       }
       float fb = (lane16 == CLID_D) ? 1.0f : 0.f;
 #pragma unroll
