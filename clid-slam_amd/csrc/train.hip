@@ -463,17 +463,18 @@ __device__ __forceinline__ void search8(const clid_map_view& mv, const DeltaLds&
   }
 }
 
-__global__ void __launch_bounds__(CLID_BLOCK, CLID_FUSED_WAVES)
+constexpr int kFusedBlock = 512;  // 8 waves share one partial row: half as many rows for k_adam_all to reduce
+__global__ void __launch_bounds__(kFusedBlock, CLID_FUSED_WAVES)
 k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap) {
   __shared__ MlpLds mlp;
   __shared__ DeltaLds dl;
-  __shared__ WaveLds wlds[CLID_BLOCK / 64];
-  __shared__ float red[(CLID_BLOCK / 64) * kRedFloats];
+  __shared__ WaveLds wlds[kFusedBlock / 64];
+  __shared__ float red[(kFusedBlock / 64) * kRedFloats];
   const OccLds* occ = nullptr;
   stage_mlp_and_delta(mlp, dl, mv, ta.W1, ta.b1, ta.W2, ta.b2);
   const int lane = threadIdx.x & 63, lane16 = lane & 15, grp = lane >> 4;
   const int lane8 = lane & 7, slot8 = lane >> 3;
-  const int wave = threadIdx.x >> 6, waves_per_block = CLID_BLOCK / 64;
+  const int wave = threadIdx.x >> 6, waves_per_block = kFusedBlock / 64;
   const int my_k = lane16 >> 1;
   const bool odd = lane16 & 1;
   WaveLds& wl = wlds[wave];
@@ -720,12 +721,16 @@ __device__ __forceinline__ float column_sum16(const float* __restrict__ partial,
   const int p = col0 + px;
   float s0 = 0.f, s1 = 0.f;
   if (p < CLID_MLP_PARAMS + 2) {
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = 0.f;
     int b = py;
-    for (; b + 16 < nb; b += 32) {
-      s0 += partial[(size_t)b * kPartialStride + p];
-      s1 += partial[(size_t)(b + 16) * kPartialStride + p];
+    for (; b + 16 * 7 < nb; b += 16 * 8) {  // 8 independent loads in flight per thread
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] += partial[(size_t)(b + 16 * i) * kPartialStride + p];
     }
-    if (b < nb) s0 += partial[(size_t)b * kPartialStride + p];
+    for (; b < nb; b += 16) s1 += partial[(size_t)b * kPartialStride + p];
+    s0 = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
   sm[threadIdx.x] = s0 + s1;
   __syncthreads();
@@ -902,8 +907,8 @@ static int n_queries(const clid_train_args* a, int* n_fd, int* first) {
   return a->bs + 6 * (*n_fd);
 }
 
-static int fused_blocks(int n_tasks) {
-  int nb = (n_tasks + CLID_BLOCK / 64 - 1) / (CLID_BLOCK / 64);
+static int fused_blocks(int n_tasks, int block = kFusedBlock) {
+  int nb = (n_tasks + block / 64 - 1) / (block / 64);
   return nb > kMaxBwdBlocks ? kMaxBwdBlocks : (nb < 1 ? 1 : nb);
 }
 
@@ -932,7 +937,8 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
   const int Q = n_queries(a, &n_fd, &first);
   TrainWs ws = carve(a->ws, Q);
   const TaskMap tmap = make_task_map(a->bs, n_fd, first, a->decimation);
-  const int nb = a->eikonal_mode == 2 ? clid_train_analytic_blocks(a->bs) : fused_blocks(tmap.n_tasks);
+  const bool v3 = (a->debug_flags & 4096) != 0;
+  const int nb = a->eikonal_mode == 2 ? clid_train_analytic_blocks(a->bs) : fused_blocks(tmap.n_tasks, v3 ? CLID_BLOCK : kFusedBlock);
   if (g_prof) prof_mark(s);
   if (a->eikonal_mode == 2) {  // loss.numerical_grad_on: False (utils/mapper.py:57-69, 660-661, 695-696)
     if (int e = clid_launch_train_analytic(mv, a, ws.partial, s)) return e;
@@ -940,7 +946,7 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
     if (a->debug_flags & 4096)
       hipLaunchKernelGGL(k_train_fused, dim3(nb), dim3(CLID_BLOCK), 0, s, *mv, *a, ws.partial, tmap);
     else
-      hipLaunchKernelGGL(k_train_fused8, dim3(nb), dim3(CLID_BLOCK), 0, s, *mv, *a, ws.partial, tmap);
+      hipLaunchKernelGGL(k_train_fused8, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap);
     CLID_CHECK_LAUNCH();
   }
   if (g_prof) prof_mark(s);
@@ -1005,7 +1011,8 @@ extern "C" int clid_train_adam(const clid_adam_args* a, const clid_train_args* t
     TrainWs ws = carve(t->ws, Q);
     L.partial = ws.partial;
     L.nb = t->eikonal_mode == 2 ? clid_train_analytic_blocks(t->bs)
-                                : fused_blocks(make_task_map(t->bs, n_fd, first, t->decimation).n_tasks);
+                                : fused_blocks(make_task_map(t->bs, n_fd, first, t->decimation).n_tasks,
+                                               (t->debug_flags & 4096) ? CLID_BLOCK : kFusedBlock);
     L.loss_out = t->loss_out;
     L.inv_n_main = t->inv_n_main;
     L.inv_n_eik = t->inv_n_eik;
