@@ -394,7 +394,21 @@ struct WaveLds {
   float4 qinfo[8];      // per query slot: x, y, z, pool sample index (int bits, -1 = padding)
   float2 win[8][8];     // per slot: up to K winners (d2, local id bits), ascending; (9e3, -1) = none
   float4 st[2][64][2];  // per decode round, per lane: {f[lane16], w_k, j_k bits, sdf}, {pre[0..3]}
+  float cacc[CLID_K][CLID_F];  // bundle tasks: gradient rows of the decimated sample's neighbours, summed in-wave
+  float ccert[8];              // ... and their certainty increments
 };
+
+// Bundle tasks: the 7 queries around one decimated sample (itself + 6 copies shifted by 0.08 m) share almost
+// all of their 6 neighbours, so their row updates are summed in LDS and leave the wave as ONE set of atomics
+// (global fp32 atomics are the second-largest cost of the kernel: ~110 G lane-atomics/s when 8 lanes hit one
+// row, 18 G/s scattered -- tools/ubench_gather.hip).  Returns the position of row j among the sample's own
+// neighbours (slot 6 of the task), or -1.
+__device__ __forceinline__ int match_base(const WaveLds& wl, int j) {
+  int m = -1;
+#pragma unroll
+  for (int k = CLID_K - 1; k >= 0; --k) m = (__float_as_int(wl.win[6][k].y) == j) ? k : m;
+  return j >= 0 ? m : -1;
+}
 
 constexpr int kProbeRows8 = 6;  // probes per lane per chunk; chunk = 48 slots
 
@@ -506,6 +520,10 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
       search8(mv, dl, px, py, pz, lane8, lane & 56, wl.win[slot8], ta.debug_flags, occ);
     }
     CLID_STAMP(3);
+    if (bundle) {
+      if (lane < CLID_K * CLID_F) (&wl.cacc[0][0])[lane] = 0.f;
+      if (lane < 8) wl.ccert[lane] = 0.f;
+    }
     wave_lds_fence();
     CLID_STAMP(4);
     // ================= decode forward: 2 rounds x 4 queries x 16 lanes
@@ -549,8 +567,11 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
       float pre[CLID_HPL];
       const float sdf = mlp_forward(mlp, f, lane16, sc, pre);
       if (valid && !odd && !(ta.debug_flags & 1)) {  // training_mode side effects (np.py:708-733)
-        atomicAdd(&mv.cert[my_j], my_w);
         const QDesc qd = task_query(tmap, task, round, grp);
+        const bool shares = bundle && !(round == 1 && grp == 3);  // every slot but the unrelated 8th sample
+        const int m = shares ? match_base(wl, my_j) : -1;
+        if (m >= 0) atomicAdd(&wl.ccert[m], my_w);
+        else atomicAdd(&mv.cert[my_j], my_w);
         if (qd.axis < 0 && mv.ts_update) {
           // amax is idempotent: only the first touch of a point by a newer stamp needs the atomic (a scattered
           // atomic costs ~10x a scattered load: tools/ubench_gather.hip)
@@ -641,7 +662,11 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
             const int src = gb16 + 4 * r + (hi ? 2 : 0);
             const int jk = __shfl(my_j, src, 64);
             const float wk = __shfl(my_w, src, 64);
-            if (jk >= 0 && delta != 0.f) atomicAdd(&g_theta[(size_t)jk * CLID_F + (lane16 & 7)], wk * dfc);
+            if (jk >= 0 && delta != 0.f) {
+              const int m = (bundle && !(round == 1 && grp == 3)) ? match_base(wl, jk) : -1;
+              if (m >= 0) atomicAdd(&wl.cacc[m][lane16 & 7], wk * dfc);
+              else atomicAdd(&g_theta[(size_t)jk * CLID_F + (lane16 & 7)], wk * dfc);
+            }
           }
         } else {
           // layer-norm backward in the (neighbour, half) lane layout, then the same coalesced scatter
@@ -679,11 +704,26 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
             const float e0 = __shfl(d4[0], src, 64), e1 = __shfl(d4[1], src, 64), e2 = __shfl(d4[2], src, 64),
                         e3 = __shfl(d4[3], src, 64);
             const float val = (c & 2) ? ((c & 1) ? e3 : e2) : ((c & 1) ? e1 : e0);
-            if (jk >= 0 && delta != 0.f) atomicAdd(&g_theta[(size_t)jk * CLID_F + c], val);
+            if (jk >= 0 && delta != 0.f) {
+              const int m = (bundle && !(round == 1 && grp == 3)) ? match_base(wl, jk) : -1;
+              if (m >= 0) atomicAdd(&wl.cacc[m][c], val);
+              else atomicAdd(&g_theta[(size_t)jk * CLID_F + c], val);
+            }
           }
         }
       }
       CLID_STAMP(8 + round);
+    }
+    if (bundle) {  // the combined rows of the decimated sample's neighbours leave the wave once
+      wave_lds_fence();
+      if (lane < CLID_K * CLID_F) {
+        const int m = lane >> 3, c = lane & 7;
+        const int j = __float_as_int(wl.win[6][m].y);
+        if (j >= 0) {
+          if (!(ta.debug_flags & 2)) atomicAdd(&g_theta[(size_t)j * CLID_F + c], wl.cacc[m][c]);
+          if (c == 0 && !(ta.debug_flags & 1) && wl.ccert[m] != 0.f) atomicAdd(&mv.cert[j], wl.ccert[m]);
+        }
+      }
     }
     wave_lds_fence();
     CLID_STAMP(10);
