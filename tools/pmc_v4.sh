@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/pmc4
-for f in 0 4096; do
+for f in 0; do
 CLID_DEBUG_FLAGS=$f timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY -d gpurun_out/pmc4 -o f$f --output-format csv -- python bench.py --no-cpu-baseline --steps 6 --warmup 2 > gpurun_out/pmc4/log$f.txt 2>&1
 CLID_DEBUG_FLAGS=$f timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS_ATOMIC SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d gpurun_out/pmc4 -o g$f --output-format csv -- python bench.py --no-cpu-baseline --steps 6 --warmup 2 > gpurun_out/pmc4/logg$f.txt 2>&1
 done

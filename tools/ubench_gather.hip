@@ -6,6 +6,27 @@
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s\n", hipGetErrorString(e)); exit(1);} } while (0)
 
+// variant: only lanes with (lane % keep_mod == 0) load from random lines, the others read line 0
+__global__ void k_gather_masked(const int4* __restrict__ tab, unsigned mask, int iters, int* out, int keep_mod, int skip) {
+  unsigned h = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u;
+  const bool keep = (threadIdx.x % keep_mod) == 0;
+  int acc = 0;
+  for (int i = 0; i < iters; ++i) {
+    int4 v[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      h = h * 1664525u + 1013904223u;
+      v[t] = make_int4(0, 0, 0, 0);
+      if (keep) v[t] = tab[(h >> 8) & mask];
+      else if (!skip) v[t] = tab[0];
+    }
+#pragma unroll
+    for (int t = 0; t < 6; ++t) acc += v[t].x + v[t].w;
+    h += acc & 1;
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 template <int DEP>
 __global__ void k_gather(const int4* __restrict__ tab, unsigned mask, int iters, int* out) {
   unsigned h = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u;
@@ -64,6 +85,18 @@ int main() {
              lanes / ms / 1e6, lanes / (ms * 1e-3) / 2.1e9 / 256);
     }
   }
+  for (int km = 1; km <= 8; km *= 2)
+    for (int skip = 0; skip < 2; ++skip) {
+      float best = 1e9;
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL(k_gather_masked, dim3(blocks), dim3(threads), 0, 0, tab, entries - 1, iters, out, km, skip);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        best = ms < best ? ms : best;
+      }
+      printf("gather 1/%d lanes random, others %s: %.1f us\n", km, skip ? "masked off" : "read line 0", best * 1e3);
+    }
   for (int co = 0; co < 2; ++co)
     for (int rep = 0; rep < 3; ++rep) {
       const int ait = 5;
