@@ -1,0 +1,63 @@
+"""GPU, world size 2 on ONE device: the sharded `Mapper.mapping` path end to end (batch slices with
+`batch_offset`, global loss normalisers, `k_reduce_partials`, gradient all-reduce, side-effect merge) must
+reproduce the single-process result.  Both ranks use cuda:0 and the gloo backend (the box has one GPU; on
+a real node the same code runs one rank per GPU over RCCL)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(rank, world, port, out_dir, mode):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_io as gio
+    import shim_io
+
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    p = gio.load("pool.npz")
+    g = gio.load("g6_loop_numerical_train_ln0.npz")
+    bs, iters = 4096, 3
+    cfg = shim_io.config(bs=bs)
+    if mode == "analytic":
+        cfg.numerical_grad, cfg.gradient_decimation = False, 1
+    nm = shim_io.neural_points(cfg, base=p)
+    dec = shim_io.decoder(cfg, g, "init_")
+    mpr, _ = shim_io.mapper(cfg, nm, dec)
+    gen = torch.Generator().manual_seed(21)
+    idx = torch.randint(0, p["coord"].shape[0], (iters, bs), generator=gen).cuda()
+    mpr.mapping(iters, index_seq=idx)
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, f"w{world}.npz"), theta=nm.local_geo_features.detach().cpu().numpy(),
+                 W1=dec.flat_params()[0].detach().cpu().numpy(), b2=dec.flat_params()[3].detach().cpu().numpy(),
+                 cert=nm.local_point_certainties.cpu().numpy(), ts=nm.local_point_ts_update.cpu().numpy(),
+                 loss=mpr.last_losses.cpu().numpy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["numerical", "analytic"])
+def test_two_ranks_equal_one(tmp_path, mode):
+    port = 29700 + (os.getpid() % 1000) + (0 if mode == "numerical" else 1)
+    _run(0, 1, port, str(tmp_path), mode)
+    mp.spawn(_run, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
+    a = np.load(os.path.join(tmp_path, "w1.npz"))
+    b = np.load(os.path.join(tmp_path, "w2.npz"))
+    assert np.abs(a["loss"] - b["loss"]).max() <= 2e-6
+    assert np.abs(a["theta"] - b["theta"]).max() <= 2e-5
+    assert np.abs(a["W1"] - b["W1"]).max() <= 2e-5 and np.abs(a["b2"] - b["b2"]).max() <= 2e-5
+    assert np.abs(a["cert"] - b["cert"]).max() <= 2e-3
+    assert np.array_equal(a["ts"], b["ts"])
