@@ -166,26 +166,11 @@ __device__ __forceinline__ void stage_delta(DeltaLds& s, const clid_map_view& mv
   for (int i = threadIdx.x; i < padded; i += blockDim.x) s.d[i] = i < mv.P ? mv.delta[i] : 0;
 }
 
-// Optional per-block copy of the bucket-occupancy bitmap: a probe whose home bucket is empty (most of the
-// 81 cells around a query are) is answered from LDS without touching the table -- the probe phase is bound
-// by L2->L1 line fills (one 128-byte line per probe for 16 useful bytes), not by arithmetic.
-constexpr int kOccWords = 2048;  // 65536 buckets = up to 32768 local neural points; larger maps skip the filter
-struct OccLds {
-  unsigned w[kOccWords];
-};
-__device__ __forceinline__ bool stage_occ(OccLds& s, const clid_map_view& mv) {  // before a __syncthreads()
-  const int words = (1 << mv.log2cap) >> 5;
-  if (!mv.tab_occ || words > kOccWords) return false;
-  for (int i = threadIdx.x; i < words; i += blockDim.x) s.w[i] = mv.tab_occ[i];
-  return true;
-}
-
 // Search the P probe cells of one query (x,y,z) with the 16 lanes of a group and select the K
 // nearest valid neighbours, ascending (np.py:971-1030 + 595-612).  All probe loads of a chunk are
 // issued before any is consumed (the dependent chain is bucket -> position, not 6x that).
 __device__ __forceinline__ void search_topk(const clid_map_view& mv, const DeltaLds& dl, float x, float y,
-                                            float z, int lane16, int gbase, TopK& out, int tm = -100,
-                                            const OccLds* occ = nullptr) {
+                                            float z, int lane16, int gbase, TopK& out, int tm = -100) {
   const int4* __restrict__ tab = reinterpret_cast<const int4*>(mv.tab);
   const int B = mv.buffer_size;
   const int r0 = base_slot(x, y, z, mv.resolution, B);
@@ -204,10 +189,7 @@ __device__ __forceinline__ void search_topk(const clid_map_view& mv, const Delta
       if (sl >= B) sl -= B;
       slot[t] = (o < mv.P) ? sl : -2;  // -2 never matches a key
       home[t] = tab_home(sl, mv.log2cap);
-      bool fetch = slot[t] != -2;
-      if (occ) fetch = fetch && ((occ->w[home[t] >> 5] >> (home[t] & 31)) & 1u);
-      bk[t] = make_int4(-1, -1, -1, -1);
-      if (fetch) bk[t] = tab[home[t]];
+      bk[t] = tab[slot[t] != -2 ? home[t] : 0];
     }
     int cell[kProbesPerLane];
     bool walk = false;

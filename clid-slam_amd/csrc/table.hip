@@ -16,7 +16,7 @@ __global__ void k_table_build(const int64_t* __restrict__ ids, int n, const floa
                               const int64_t* __restrict__ big, int B, float res,
                               const int* __restrict__ ts_create, const float* __restrict__ travel,
                               int cur_ts, int time_filtering, float diff_travel, int4* tab,
-                              float4* tab_pos, unsigned* occ, int log2cap, float4* pos4) {
+                              float4* tab_pos, int log2cap, float4* pos4) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const long long gi = ids ? ids[j] : (long long)j;
@@ -37,7 +37,6 @@ __global__ void k_table_build(const int64_t* __restrict__ ids, int n, const floa
     for (int m = 0; m < 4; ++m) {
       if (atomicCAS(&cells[(size_t)pos * 4 + m], -1, slot) == -1) {
         tab_pos[(size_t)pos * 4 + m] = make_float4(x, y, z, __int_as_float(j));
-        atomicOr(&occ[pos >> 5], 1u << (pos & 31));
         return;
       }
     }
@@ -51,14 +50,14 @@ extern "C" int clid_table_build(const int64_t* ids, int32_t n, const float* neur
                                 const int64_t* buffer_pt_index, int64_t buffer_size, float resolution,
                                 const int32_t* point_ts_create, const float* travel_dist,
                                 int32_t cur_ts, int32_t time_filtering, float diff_travel,
-                                int32_t* tab_out, float* tab_pos_out, uint32_t* tab_occ_out, int32_t log2cap,
-                                float* pos4_out, void* stream) {
+                                int32_t* tab_out, float* tab_pos_out, int32_t log2cap, float* pos4_out,
+                                void* stream) {
   if (n < 0 || log2cap < 5 || log2cap > 30 || buffer_size <= 0 || buffer_size >= (1LL << 30)) {
     clid_set_error("clid_table_build: bad argument (n=%d log2cap=%d buffer_size=%lld)", n, log2cap,
                    (long long)buffer_size);
     return CLID_E_ARG;
   }
-  if ((4LL << log2cap) < 2LL * n || !tab_out || !tab_pos_out || !tab_occ_out || !pos4_out) {
+  if ((4LL << log2cap) < 2LL * n || !tab_out || !tab_pos_out || !pos4_out) {
     clid_set_error("clid_table_build: table capacity 4*2^%d < 2*n (n=%d) or null output", log2cap, n);
     return CLID_E_ARG;
   }
@@ -67,14 +66,10 @@ extern "C" int clid_table_build(const int64_t* ids, int32_t n, const float* neur
     clid_set_error("clid_table_build: memset failed");
     return CLID_E_HIP;
   }
-  if (hipMemsetAsync(tab_occ_out, 0, sizeof(uint32_t) * (((size_t)1 << log2cap) / 32), s) != hipSuccess) {
-    clid_set_error("clid_table_build: memset failed");
-    return CLID_E_HIP;
-  }
   if (n == 0) return CLID_OK;
   hipLaunchKernelGGL(clid::k_table_build, dim3((n + 255) / 256), dim3(256), 0, s, ids, n, neural_points,
                      buffer_pt_index, (int)buffer_size, resolution, point_ts_create, travel_dist, cur_ts,
-                     time_filtering, diff_travel, reinterpret_cast<int4*>(tab_out), reinterpret_cast<float4*>(tab_pos_out), tab_occ_out, log2cap,
+                     time_filtering, diff_travel, reinterpret_cast<int4*>(tab_out), reinterpret_cast<float4*>(tab_pos_out), log2cap,
                      reinterpret_cast<float4*>(pos4_out));
   CLID_CHECK_LAUNCH();
   return CLID_OK;

@@ -5,14 +5,10 @@
 //   (loss.py:44-62, mapper.py:746-798) -> backward -> Adam (tools.py:205-255).
 //
 // Launch plan per iteration (numerical-eikonal mode, the shipped default):
-//   k_train_fwd   all Q = bs + 6*ceil(bs/decimation) query points: search, blend, decode; saves
-//                 sdf, f, (idx,w) per query; certainty / ts side effects
-//   k_train_bwd   per query: dL/dsdf (BCE for batch points, central-difference eikonal for the
-//                 shifted copies), decoder backward, feature-gradient scatter (atomics), per-block
-//                 partials of the 833 decoder gradients and the loss sums
-//   k_reduce      partials -> grad[0:833], loss_out
-//   (optional RCCL all-reduce of `grad` by the host between these and Adam)
-//   k_adam        dense Adam over the features and the decoder, zeroes `grad`
+//   k_train_fused8  all Q = bs + 6*ceil(bs/decimation) query points: search, blend, decode, loss, backward,
+//                   feature-gradient scatter (atomics), per-block partials of the 833 decoder gradients
+//   [k_reduce_partials + RCCL all-reduce of `grad` by the host when world > 1]
+//   k_adam_all      partial reduction (single GPU), dense Adam over features and decoder, zeroes `grad`
 #include "train_common.hpp"
 
 namespace clid {
@@ -31,55 +27,10 @@ struct QDesc {
   float sign;
 };
 
-// Per-round query state kept between the forward and the backward of a task.  The group-uniform part
-// (f, w, j, sdf: 24 words) is stashed in LDS by lane 0 of the group with 6 x ds_write_b128 and read back
-// (broadcast) with 6 x ds_read_b128; the lane's 4 pre-activations take one b128 each way.  This keeps the
-// two rounds of a task out of each other's registers (the fully unrolled version needed 201 VGPRs).
-struct RoundState {
-  float f[CLID_D];
-  float sdf;
-  float w[CLID_K];
-  int j[CLID_K];
-  float pre[CLID_HPL];
-};
-struct StashLds {
-  float4 grp[CLID_BLOCK / CLID_G][2][6];  // [group in block][round][6 x 16 B]
-  float4 pre[2][CLID_BLOCK];              // [round][thread]
-};
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-__device__ __forceinline__ void stash_put(StashLds& sl, int round, int lane16, const RoundState& st) {
-  float4* g = sl.grp[threadIdx.x >> 4][round];
-  if (lane16 == 0) {
-    g[0] = make_float4(st.f[0], st.f[1], st.f[2], st.f[3]);
-    g[1] = make_float4(st.f[4], st.f[5], st.f[6], st.f[7]);
-    g[2] = make_float4(st.f[8], st.f[9], st.f[10], st.sdf);
-    g[3] = make_float4(st.w[0], st.w[1], st.w[2], st.w[3]);
-    g[4] = make_float4(st.w[4], st.w[5], __int_as_float(st.j[0]), __int_as_float(st.j[1]));
-    g[5] = make_float4(__int_as_float(st.j[2]), __int_as_float(st.j[3]), __int_as_float(st.j[4]),
-                       __int_as_float(st.j[5]));
-  }
-  sl.pre[round][threadIdx.x] = make_float4(st.pre[0], st.pre[1], st.pre[2], st.pre[3]);
-}
-__device__ __forceinline__ void stash_get(const StashLds& sl, int round, RoundState& st) {
-  const float4* g = sl.grp[threadIdx.x >> 4][round];
-  const float4 a = g[0], b = g[1], c = g[2], d = g[3], e = g[4], f = g[5];
-  st.f[0] = a.x; st.f[1] = a.y; st.f[2] = a.z; st.f[3] = a.w;
-  st.f[4] = b.x; st.f[5] = b.y; st.f[6] = b.z; st.f[7] = b.w;
-  st.f[8] = c.x; st.f[9] = c.y; st.f[10] = c.z; st.sdf = c.w;
-  st.w[0] = d.x; st.w[1] = d.y; st.w[2] = d.z; st.w[3] = d.w;
-  st.w[4] = e.x; st.w[5] = e.y;
-  st.j[0] = __float_as_int(e.z); st.j[1] = __float_as_int(e.w);
-  st.j[2] = __float_as_int(f.x); st.j[3] = __float_as_int(f.y);
-  st.j[4] = __float_as_int(f.z); st.j[5] = __float_as_int(f.w);
-  const float4 p = sl.pre[round][threadIdx.x];
-  st.pre[0] = p.x; st.pre[1] = p.y; st.pre[2] = p.z; st.pre[3] = p.w;
-}
-__device__ __forceinline__ float stash_sdf(const StashLds& sl, int wave, int round, int grp) {
-  return sl.grp[wave * 4 + grp][round][2].w;
 }
 
 // Task -> query mapping (no integer division on the common path).  The local batch is cut into lattice
@@ -141,236 +92,11 @@ __host__ __device__ __forceinline__ QDesc task_query(const TaskMap& tm, int task
   return q;
 }
 
-__device__ __forceinline__ void forward_round(const clid_map_view& mv, const clid_train_args& ta, const MlpLds& mlp,
-                                              const DeltaLds& dl, const OccLds* occ, const QDesc& qd, int lane16,
-                                              int gbase, RoundState& st, int tm = -100) {
-  CLID_STAMP(tm);
-  const bool live = qd.p >= 0;
-  const long long s = ta.index[live ? qd.p : 0];
-  float px = ta.pool_coord[s * 3 + 0], py = ta.pool_coord[s * 3 + 1], pz = ta.pool_coord[s * 3 + 2];
-  if (qd.axis == 0) px = fadd(px, qd.sign * ta.fd_eps);  // x + [eps,0,0] in fp32 (mapper.py:988-999)
-  if (qd.axis == 1) py = fadd(py, qd.sign * ta.fd_eps);
-  if (qd.axis == 2) pz = fadd(pz, qd.sign * ta.fd_eps);
-  TopK t;
-  asm volatile("" ::"v"(px), "v"(py), "v"(pz));
-  CLID_STAMP(tm + 0 + 100 * (tm < 0));
-  if (ta.debug_flags & 4) {
-    t.nn = 5;
-#pragma unroll
-    for (int k = 0; k < CLID_K; ++k) { t.j[k] = (k < 5) ? (int)(((unsigned)(qd.p * 7 + k * 131 + lane16 / 16)) % (unsigned)mv.M) : -1; t.d2[k] = 0.5f + k; }
-  } else {
-    search_topk(mv, dl, px, py, pz, lane16, gbase, t, tm, occ);
-  }
-  CLID_STAMP(tm + 4);
-  float omega[CLID_K];
-  idw_weights(t, st.w, omega);
-  const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
-  if (ta.debug_flags & 512) {
-#pragma unroll
-    for (int c = 0; c < CLID_D; ++c) st.f[c] = 0.01f * c + px;
-#pragma unroll
-    for (int k = 0; k < CLID_K; ++k) st.j[k] = live ? t.j[k] : -1;
-  } else
-  // Gather + blend with ONE 16-byte feature load and one position load per lane: lane16 = 2k + half
-  // handles half `half` of neighbour k's feature row (lanes 12..15 idle), the weighted rows are summed
-  // over k with a DPP butterfly (row_ror 8/4/2 keeps even and odd lanes apart), and the two halves are
-  // exchanged between lane pairs.  (The replicated version needed 72 live VGPRs and 110 instructions.)
-  {
-    const int my_k = lane16 >> 1;
-    const bool odd = lane16 & 1;
-    int my_j = -1;
-    float my_w = 0.f;
-#pragma unroll
-    for (int k = 0; k < CLID_K; ++k) {
-      my_j = (my_k == k) ? t.j[k] : my_j;
-      my_w = (my_k == k) ? st.w[k] : my_w;
-      st.j[k] = live ? t.j[k] : -1;
-    }
-    const int jc = my_j >= 0 ? my_j : 0;
-    float4 v = reinterpret_cast<const float4*>(mv.feat)[(size_t)jc * 2 + (odd ? 1 : 0)];
-    const float4 p = pos4[jc];
-    if (mv.layer_norm) {  // F.layer_norm over the 8 features of the row = both halves (np.py:632-633)
-      float s1 = (v.x + v.y) + (v.z + v.w);
-      s1 += dpp_mov<0xB1>(s1);  // quad_perm [1,0,3,2]: the other half of the row
-      const float mu = s1 * (1.0f / CLID_F);
-      v.x -= mu; v.y -= mu; v.z -= mu; v.w -= mu;
-      float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-      s2 += dpp_mov<0xB1>(s2);
-      const float rstd = 1.0f / sqrtf(s2 * (1.0f / CLID_F) + 1e-5f);
-      v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
-    }
-    float a0 = v.x * my_w, a1 = v.y * my_w, a2 = v.z * my_w, a3 = v.w * my_w;
-    const float wr = odd ? 0.f : my_w;  // the relative position is carried by the even lane of the pair
-    float r0 = fsub(px, p.x) * wr, r1 = fsub(py, p.y) * wr, r2 = fsub(pz, p.z) * wr;
-#define CLID_BFLY(x) x += dpp_mov<0x128>(x); x += dpp_mov<0x124>(x); x += dpp_mov<0x122>(x);
-    CLID_BFLY(a0) CLID_BFLY(a1) CLID_BFLY(a2) CLID_BFLY(a3) CLID_BFLY(r0) CLID_BFLY(r1) CLID_BFLY(r2)
-#undef CLID_BFLY
-    const float b0 = dpp_mov<0xB1>(a0), b1 = dpp_mov<0xB1>(a1), b2 = dpp_mov<0xB1>(a2), b3 = dpp_mov<0xB1>(a3);
-    const float q0 = dpp_mov<0xB1>(r0), q1 = dpp_mov<0xB1>(r1), q2 = dpp_mov<0xB1>(r2);
-    st.f[0] = odd ? b0 : a0; st.f[1] = odd ? b1 : a1; st.f[2] = odd ? b2 : a2; st.f[3] = odd ? b3 : a3;
-    st.f[4] = odd ? a0 : b0; st.f[5] = odd ? a1 : b1; st.f[6] = odd ? a2 : b2; st.f[7] = odd ? a3 : b3;
-    st.f[8] = odd ? q0 : r0; st.f[9] = odd ? q1 : r1; st.f[10] = odd ? q2 : r2;
-  }
-  CLID_STAMP(tm + 5);
-  if (ta.debug_flags & 1024) {
-    st.sdf = st.f[0];
-#pragma unroll
-    for (int u = 0; u < CLID_HPL; ++u) st.pre[u] = st.f[u] - 0.5f;
-  } else {
-    st.sdf = mlp_forward(mlp, st.f, lane16, ta.sdf_scale, st.pre);
-  }
-  CLID_STAMP(tm + 6);
-  // training_mode side effects (np.py:708-733): certainty += w, last-update stamp = max(., ts)
-  if (live && !(ta.debug_flags & 1)) {
-    float mw = 0.f;
-    int mj = -1;
-#pragma unroll
-    for (int k = 0; k < CLID_K; ++k) {
-      mw = (lane16 == k) ? st.w[k] : mw;
-      mj = (lane16 == k) ? st.j[k] : mj;
-    }
-    if (lane16 < CLID_K && mj >= 0) {
-      atomicAdd(&mv.cert[mj], mw);
-      if (qd.axis < 0 && mv.ts_update) atomicMax(&mv.ts_update[mj], ta.pool_ts[s]);
-    }
-  }
-}
-
-__device__ __forceinline__ void backward_round(const clid_map_view& mv, const clid_train_args& ta, const MlpLds& mlp,
-                                               const RoundState& st, float delta, int lane16, MlpAcc& acc,
-                                               float* __restrict__ g_theta) {
-  float df[CLID_D];
-  mlp_backward(mlp, st.f, st.pre, ta.sdf_scale * delta, lane16, ta.train_decoder != 0, acc, df);
-  if (delta == 0.f || (ta.debug_flags & 2)) return;  // (whole-group predicate; no cross-lane ops below)
-  if (!mv.layer_norm) {
-    float dfc = 0.f;
-#pragma unroll
-    for (int c = 0; c < CLID_F; ++c) dfc = ((lane16 & 7) == c) ? df[c] : dfc;
-#pragma unroll
-    for (int r = 0; r < (CLID_K * CLID_F + CLID_G - 1) / CLID_G; ++r) {
-      const int k0 = 2 * r, k1 = 2 * r + 1;  // lane16 < 8 -> neighbour 2r, else 2r+1
-      const bool hi = lane16 >= 8;
-      const int j = hi ? st.j[k1] : st.j[k0];
-      const float wk = hi ? st.w[k1] : st.w[k0];
-      if (j >= 0) atomicAdd(&g_theta[(size_t)j * CLID_F + (lane16 & 7)], wk * dfc);
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < CLID_K; ++k) {
-      const int j = st.j[k];
-      if (j < 0) continue;
-      float fe[CLID_F], rstd, dth[CLID_F];
-      load_feat(mv.feat, j, fe);
-      layer_norm8(fe, rstd);
-#pragma unroll
-      for (int c = 0; c < CLID_F; ++c) dth[c] = st.w[k] * df[c];
-      layer_norm8_bwd(fe, rstd, dth);
-      float mine = 0.f;
-#pragma unroll
-      for (int c = 0; c < CLID_F; ++c) mine = (lane16 == c) ? dth[c] : mine;
-      if (lane16 < CLID_F) atomicAdd(&g_theta[(size_t)j * CLID_F + lane16], mine);
-    }
-  }
-}
-
 #ifndef CLID_FUSED_WAVES
 #define CLID_FUSED_WAVES 4
 #endif
-__global__ void __launch_bounds__(CLID_BLOCK, CLID_FUSED_WAVES)
-k_train_fused(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap) {
-  __shared__ MlpLds mlp;
-  __shared__ DeltaLds dl;
-  __shared__ StashLds stash;
-  __shared__ float red[(CLID_BLOCK / 64) * kRedFloats];
-  const OccLds* occ = nullptr;  // LDS occupancy prefilter: measured no gain (kernel is VALU/latency bound), off
-  if (ta.debug_flags & 128) {
-    // L2 warm-up: the blocks that land on one XCD (observed: blockIdx % 8) stream that XCD's copy of the
-    // probe table, positions and features once, coalesced, before the random probes start.
-    const int xslot = blockIdx.x >> 3, xcount = (gridDim.x + 7) >> 3;
-    float4 sink = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto warm = [&](const void* base, size_t bytes) {
-      const size_t n16 = bytes >> 4;
-      const size_t per = (n16 + xcount - 1) / xcount;
-      const size_t lo = (size_t)xslot * per, hi = lo + per < n16 ? lo + per : n16;
-      const float4* p = reinterpret_cast<const float4*>(base);
-      for (size_t i = lo + threadIdx.x; i < hi; i += CLID_BLOCK) {
-        const float4 v = p[i];
-        sink.x += v.x; sink.y += v.y; sink.z += v.z; sink.w += v.w;
-      }
-    };
-    warm(mv.tab, (size_t)16 << mv.log2cap);
-    warm(mv.pos4, (size_t)16 * mv.M);
-    warm(mv.feat, (size_t)32 * mv.M);
-    asm volatile("" ::"v"(sink.x), "v"(sink.y), "v"(sink.z), "v"(sink.w));
-  }
-  stage_mlp_and_delta(mlp, dl, mv, ta.W1, ta.b1, ta.W2, ta.b2);
-  const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48, grp = lane >> 4;
-  const int wave = threadIdx.x >> 6, waves_per_block = CLID_BLOCK / 64;
-  MlpAcc acc;
-  acc.zero();
-  float bce_acc = 0.f, eik_acc = 0.f;
-  float* g_theta = ta.grad + CLID_GRAD_FEAT_OFFSET;
-  const float inv_sigma = fdiv(1.0f, ta.sigma);
-  const float two_eps = 2.0f * ta.fd_eps;
 
-  for (int task = blockIdx.x * waves_per_block + wave; task < tmap.n_tasks; task += gridDim.x * waves_per_block) {
-    const bool bundle = task < tmap.n_fd;
-#pragma unroll 1
-    for (int round = 0; round < 2; ++round) {
-      const QDesc qd = task_query(tmap, task, round, grp);
-      RoundState st;
-      forward_round(mv, ta, mlp, dl, occ, qd, lane16, gbase, st, round * 8);
-      stash_put(stash, round, lane16, st);
-    }
-    wave_lds_fence();
-    CLID_STAMP(16);
-    float ecoef = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
-    if (bundle) {
-      gx = fdiv(stash_sdf(stash, wave, 0, 0) - stash_sdf(stash, wave, 0, 1), two_eps);  // mapper.py:1011-1013
-      gy = fdiv(stash_sdf(stash, wave, 0, 2) - stash_sdf(stash, wave, 0, 3), two_eps);
-      gz = fdiv(stash_sdf(stash, wave, 1, 0) - stash_sdf(stash, wave, 1, 1), two_eps);
-      const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
-      if (lane == 0) eik_acc += (nrm - 1.f) * (nrm - 1.f);
-      // d/dg of weight_e * mean((|g|-1)^2); 0 at |g| == 0 (torch norm subgradient)
-      ecoef = nrm > 0.f ? ta.weight_e * 2.f * (nrm - 1.f) * ta.inv_n_eik / (nrm * two_eps) : 0.f;
-    }
-#pragma unroll 1
-    for (int round = 0; round < 2; ++round) {
-      const QDesc qd = task_query(tmap, task, round, grp);
-      RoundState st;
-      stash_get(stash, round, st);
-      float delta = 0.f;
-      if (qd.p >= 0) {
-        if (qd.axis < 0) {
-          const long long s = ta.index[qd.p];
-          const float label = ta.pool_label[s];
-          const float wt = ta.loss_weight_on ? fabsf(ta.pool_weight[s]) : 1.0f;  // mapper.py:747-749
-          const float z = st.sdf * inv_sigma;
-          // hardware exp/log/rcp (<= 2 ulp): the loss terms stay within 1e-6 of the fp32 reference
-          const float tgt = __frcp_rn(1.0f + __expf(-label * inv_sigma));         // loss.py:60
-          const float ez = __expf(-fabsf(z));
-          const float sg = (z >= 0.f ? 1.0f : ez) * __frcp_rn(1.0f + ez);
-          const float li = fmaxf(z, 0.f) - z * tgt + __logf(1.0f + ez);           // BCEWithLogits
-          if (lane16 == 0) bce_acc += wt * li;
-          delta = wt * (sg - tgt) * inv_sigma * ta.inv_n_main;
-        } else {
-          const float ga = qd.axis == 0 ? gx : (qd.axis == 1 ? gy : gz);
-          delta = qd.sign * ecoef * ga;
-        }
-      }
-      CLID_STAMP(17 + round * 3);
-      if (!(ta.debug_flags & 2048)) backward_round(mv, ta, mlp, st, delta, lane16, acc, g_theta);
-      else bce_acc += delta;
-      CLID_STAMP(18 + round * 3);
-    }
-    wave_lds_fence();
-  }
-  CLID_STAMP(24);
-  flush_mlp_acc(acc, bce_acc, eik_acc, red, partial + (size_t)blockIdx.x * kPartialStride);
-  CLID_STAMP(25);
-}
-
-// ---- v4 fused iteration kernel: 8-lane search groups, 16-lane decode groups ----------------------------------
+// ---- the kernel: 8-lane search groups, 16-lane decode groups ----------------------------------
 // The probe/selection phase is replicated work per lane-slot, so it runs with 8 lanes per query: one pass
 // serves all 8 queries of a task (both "rounds" at once: half the instructions per query for the selection,
 // 11 probe rows instead of 2 x 6, and the two rounds' dependent loads overlap).  Winners go to LDS; the
@@ -414,8 +140,7 @@ constexpr int kProbeRows8 = 6;  // probes per lane per chunk; chunk = 48 slots
 
 // 81-cell search of one query by the 8 lanes of a group; winners -> win[0..K)
 __device__ __forceinline__ void search8(const clid_map_view& mv, const DeltaLds& dl, float x, float y, float z,
-                                        int lane8, int gshift, float2* __restrict__ win, int dbg = 0,
-                                        const OccLds* occ = nullptr) {
+                                        int lane8, int gshift, float2* __restrict__ win) {
   const int4* __restrict__ tab = reinterpret_cast<const int4*>(mv.tab);
   const float4* __restrict__ tpos = reinterpret_cast<const float4*>(mv.tab_pos);
   const int B = mv.buffer_size;
@@ -434,10 +159,7 @@ __device__ __forceinline__ void search8(const clid_map_view& mv, const DeltaLds&
       const bool in = o < mv.P;
       slot[t] = in ? sl : -2;
       home[t] = tab_home(sl, mv.log2cap);
-      bool fetch = in;
-      if (occ) fetch = fetch && ((occ->w[home[t] >> 5] >> (home[t] & 31)) & 1u);
-      bk[t] = make_int4(-1, -1, -1, -1);
-      if (fetch) bk[t] = tab[(dbg & 8192) ? (unsigned)(lane8 + 8 * t) : home[t]];
+      bk[t] = tab[in ? home[t] : 0];
     }
     int cell[kProbeRows8];
     bool walk = false;
@@ -454,7 +176,7 @@ __device__ __forceinline__ void search8(const clid_map_view& mv, const DeltaLds&
     }
     float4 pp[kProbeRows8];
 #pragma unroll
-    for (int t = 0; t < kProbeRows8; ++t) pp[t] = tpos[(cell[t] >= 0 && !(dbg & 16384)) ? cell[t] : 0];
+    for (int t = 0; t < kProbeRows8; ++t) pp[t] = tpos[cell[t] >= 0 ? cell[t] : 0];
 #pragma unroll
     for (int t = 0; t < kProbeRows8; ++t) {
       const float ax = fsub(pp[t].x, x), ay = fsub(pp[t].y, y), az = fsub(pp[t].z, z);
@@ -484,10 +206,6 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
   __shared__ DeltaLds dl;
   __shared__ WaveLds wlds[kFusedBlock / 64];
   __shared__ float red[(kFusedBlock / 64) * kRedFloats];
-  // An LDS bucket-occupancy prefilter (stage_occ) removes 33 % of the L2 read requests of this kernel
-  // (TCP_TCC_READ_REQ 2.08 M -> 1.39 M per launch) and changes its duration by < 1 %: the kernel is bound by
-  // dependent-load latency and instruction issue, not by request throughput.  Kept off.
-  const OccLds* occ = nullptr;
   stage_mlp_and_delta(mlp, dl, mv, ta.W1, ta.b1, ta.W2, ta.b2);
   const int lane = threadIdx.x & 63, lane16 = lane & 15, grp = lane >> 4;
   const int lane8 = lane & 7, slot8 = lane >> 3;
@@ -520,7 +238,7 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
       if (lane8 < CLID_K) wl.win[slot8][lane8] = make_float2(9e3f, __int_as_float(-1));  // np.py:606
       asm volatile("" ::"v"(px), "v"(py), "v"(pz));
       CLID_STAMP(1);
-      search8(mv, dl, px, py, pz, lane8, lane & 56, wl.win[slot8], ta.debug_flags, occ);
+      search8(mv, dl, px, py, pz, lane8, lane & 56, wl.win[slot8]);
     }
     CLID_STAMP(3);
     if (bundle) {
@@ -985,16 +703,12 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
   const int Q = n_queries(a, &n_fd, &first);
   TrainWs ws = carve(a->ws, Q);
   const TaskMap tmap = make_task_map(a->bs, n_fd, first, a->decimation);
-  const bool v3 = (a->debug_flags & 4096) != 0;
-  const int nb = a->eikonal_mode == 2 ? clid_train_analytic_blocks(a->bs) : fused_blocks(tmap.n_tasks, v3 ? CLID_BLOCK : kFusedBlock);
+  const int nb = a->eikonal_mode == 2 ? clid_train_analytic_blocks(a->bs) : fused_blocks(tmap.n_tasks);
   if (g_prof) prof_mark(s);
   if (a->eikonal_mode == 2) {  // loss.numerical_grad_on: False (utils/mapper.py:57-69, 660-661, 695-696)
     if (int e = clid_launch_train_analytic(mv, a, ws.partial, s)) return e;
   } else {
-    if (a->debug_flags & 4096)
-      hipLaunchKernelGGL(k_train_fused, dim3(nb), dim3(CLID_BLOCK), 0, s, *mv, *a, ws.partial, tmap);
-    else
-      hipLaunchKernelGGL(k_train_fused8, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap);
+    hipLaunchKernelGGL(k_train_fused8, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap);
     CLID_CHECK_LAUNCH();
   }
   if (g_prof) prof_mark(s);
@@ -1059,8 +773,7 @@ extern "C" int clid_train_adam(const clid_adam_args* a, const clid_train_args* t
     TrainWs ws = carve(t->ws, Q);
     L.partial = ws.partial;
     L.nb = t->eikonal_mode == 2 ? clid_train_analytic_blocks(t->bs)
-                                : fused_blocks(make_task_map(t->bs, n_fd, first, t->decimation).n_tasks,
-                                               (t->debug_flags & 4096) ? CLID_BLOCK : kFusedBlock);
+                                : fused_blocks(make_task_map(t->bs, n_fd, first, t->decimation).n_tasks);
     L.loss_out = t->loss_out;
     L.inv_n_main = t->inv_n_main;
     L.inv_n_eik = t->inv_n_eik;

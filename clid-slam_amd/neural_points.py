@@ -344,7 +344,6 @@ class NeuralPoints(nn.Module):
         log2cap = max(5, int(math.ceil(math.log2(max(2 * n, 32)))))  # 4-key buckets, <= 0.5 keys per bucket
         tab = torch.empty((1 << log2cap, 4), device=pts.device, dtype=torch.int32)
         tab_pos = torch.zeros((1 << log2cap, 4, 4), device=pts.device, dtype=torch.float32)
-        tab_occ = torch.empty(((1 << log2cap) // 32,), device=pts.device, dtype=torch.int32)
         pos4 = torch.empty((max(n, 1), 4), device=pts.device, dtype=torch.float32)
         tsc = self.point_ts_create if time_filtering else None
         trv = self.travel_dist.to(torch.float32).contiguous() if time_filtering else None
@@ -352,18 +351,18 @@ class NeuralPoints(nn.Module):
             lib.clid_table_build(_lib.ptr(ids), n, _lib.ptr(pts), _lib.ptr(big), int(self.buffer_size),
                                  float(self.resolution), _lib.ptr(tsc), _lib.ptr(trv), int(self.cur_ts),
                                  int(time_filtering), float(self.diff_travel_dist_local), _lib.ptr(tab), _lib.ptr(tab_pos),
-                                 _lib.ptr(tab_occ), log2cap,
+                                 log2cap,
                                  _lib.ptr(pos4), _lib.stream()),
             "clid_table_build",
         )
-        self._tables[slot] = (key, (tab, tab_pos, tab_occ), pos4, log2cap)
-        return (tab, tab_pos, tab_occ), pos4, log2cap
+        self._tables[slot] = (key, (tab, tab_pos), pos4, log2cap)
+        return (tab, tab_pos), pos4, log2cap
 
     def _map_view(self, query_locally: bool, time_filtering=None):
         """Fill a clid_map_view for the current tensors.  Returns (view, keep_alive)."""
         if time_filtering is None:
             time_filtering = bool(self.temporal_local_map_on and query_locally)
-        (tab, tab_pos, tab_occ), pos4, log2cap = self._table(query_locally, time_filtering)
+        (tab, tab_pos), pos4, log2cap = self._table(query_locally, time_filtering)
         if query_locally:
             feat, cert, tsu = self.local_geo_features.data, self.local_point_certainties, self.local_point_ts_update
         else:
@@ -374,7 +373,6 @@ class NeuralPoints(nn.Module):
             _lib.require_cuda(t, name, dt)
         v = _lib.MapView()
         v.tab, v.tab_pos, v.pos4 = tab.data_ptr(), tab_pos.data_ptr(), pos4.data_ptr()
-        v.tab_occ = tab_occ.data_ptr()
         v.feat, v.cert = feat.data_ptr(), cert.data_ptr()
         v.ts_update = tsu.data_ptr() if tsu is not None else None
         v.delta = self._delta.data_ptr()
@@ -383,7 +381,7 @@ class NeuralPoints(nn.Module):
         v.resolution = float(self.resolution)
         v.max_valid_dist2 = float(self.max_valid_dist2)
         v.layer_norm = int(bool(self.config.layer_norm_on))
-        return v, (tab, tab_pos, tab_occ, pos4, feat, cert, tsu, self._delta)
+        return v, (tab, tab_pos, pos4, feat, cert, tsu, self._delta)
 
     # ------------------------------------------------------------------ hot methods
     def query_feature(self, query_points: torch.Tensor, query_ts: torch.Tensor = None, training_mode: bool = True,

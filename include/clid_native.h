@@ -50,7 +50,6 @@ int clid_abi_version(void);
 typedef struct clid_map_view {
   const int32_t* tab;      /* [2^log2cap][4] buckets of 4 keys (slot numbers, -1 empty, filled in order) */
   const float* tab_pos;    /* [2^log2cap][4][4] per key: x, y, z, point id (int bits) -> one load per hit */
-  const uint32_t* tab_occ; /* [2^log2cap / 32] bit b set iff bucket b holds a key (probe prefilter), may be NULL */
   const float* pos4;       /* [M][4] xyz0 of the points addressed by the ids in `tab` */
   float* feat;             /* [(M+1)][F] latent features, last row = padding (np.py:532) */
   float* cert;             /* [M] point certainties (read; +atomicAdd when training_mode) */
@@ -74,13 +73,12 @@ typedef struct clid_map_view {
  *   ids            [n] int64 global point index of local point j, or NULL for identity (global map)
  *   neural_points  [Mg][3], buffer_pt_index [buffer_size] int64, point_ts_create [Mg] int32
  *   tab_out        [2^log2cap][4] int32 keys (4-key buckets, 2^log2cap >= n/2 ... load <= 0.5 keys/bucket
- *                  recommended), tab_pos_out [2^log2cap][4][4] f32, tab_occ_out [2^log2cap/32] u32,
- *                  pos4_out [n][4] */
+ *                  recommended), tab_pos_out [2^log2cap][4][4] f32, pos4_out [n][4] */
 int clid_table_build(const int64_t* ids, int32_t n, const float* neural_points,
                      const int64_t* buffer_pt_index, int64_t buffer_size, float resolution,
                      const int32_t* point_ts_create, const float* travel_dist, int32_t cur_ts,
                      int32_t time_filtering, float diff_travel, int32_t* tab_out, float* tab_pos_out,
-                     uint32_t* tab_occ_out, int32_t log2cap, float* pos4_out, void* stream);
+                     int32_t log2cap, float* pos4_out, void* stream);
 
 /* NeuralPoints.radius_neighborhood_search (model/neural_points.py:971-1030).
  * dist2_out [N][P] f32, idx_out [N][P] int32 (ids of the view, -1 invalid). */
@@ -161,7 +159,7 @@ typedef struct clid_train_args {
   /* workspace, sized by clid_train_workspace_floats() */
   float* ws;
   float* loss_out;           /* [4] total,bce,eik,unused (+=) */
-  int32_t debug_flags;       /* 0 in production; ablation switches used by tools/ablate.sh */
+  int32_t debug_flags;       /* 0 in production; bit 0 / bit 1 suppress the certainty / gradient atomics (timing ablation) */
   int32_t pad1;
 } clid_train_args;
 

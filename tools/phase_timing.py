@@ -29,8 +29,7 @@ names = {0: "A start", 1: "A buckets", 2: "A pos4", 3: "A inserted", 4: "A selec
          8: "B start", 9: "B buckets", 10: "B pos4", 11: "B inserted", 12: "B selected", 13: "B blended", 14: "B mlp",
          16: "stashed", 17: "bwdA start", 18: "bwdA end", 20: "bwdB start", 21: "bwdB end", 24: "loop end", 25: "flushed"}
 import os
-if not (int(os.environ.get('CLID_DEBUG_FLAGS', '0')) & 4096):
-    names = names8
+names = names8
 keys = sorted(names)
 print("phase deltas (median / p90 cycles at 100 MHz s_memtime? raw units), relative to previous stamp:")
 prev = None
