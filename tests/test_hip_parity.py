@@ -406,3 +406,65 @@ def test_mapping_weighted_first_false_vs_oracle(env):
     assert maxerr(nm.local_geo_features, recs[-1]["theta"]) <= 1e-4
     for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
         assert maxerr(t, o) <= 1e-4
+
+
+def test_default_buffer_size_scene_vs_oracle(env):
+    """The shipped configuration end to end (buffer_size = 5e7, 128x1024-ray synthetic scan, map built by
+    the product's own NeuralPoints.update on the GPU): 5 free-running fused iterations at bs = 16384 against
+    the CPU oracle on the same state.  Exercises the exact fp64 hash modulo and int32 slot arithmetic at the
+    real table size."""
+    import bench
+    from clid_slam_amd import HotPathConfig
+
+    cfg = HotPathConfig()
+    cfg.device = "cuda:0"
+    nm, dec, mp, scene = bench.build_scene(cfg, "cuda:0")
+    gen = torch.Generator().manual_seed(77)
+    iters, bs = 5, cfg.bs
+    idx = torch.randint(0, mp.pool_sample_count, (iters, bs), generator=gen)
+    cpu = lambda t: t.detach().cpu().clone()
+    dx, mvd = O.search_neighborhood(cfg.num_nei_cells, cfg.search_alpha, cfg.voxel_size_m)
+    st = O.MapState(
+        buffer_pt_index=cpu(nm.buffer_pt_index), neural_points=cpu(nm.neural_points),
+        point_ts_create=cpu(nm.point_ts_create), travel_dist=cpu(nm.travel_dist), cur_ts=int(nm.cur_ts),
+        global2local=cpu(nm.global2local), local_neural_points=cpu(nm.local_neural_points),
+        local_geo_features=cpu(nm.local_geo_features.data), local_point_certainties=cpu(nm.local_point_certainties),
+        local_point_ts_update=cpu(nm.local_point_ts_update), resolution=cfg.voxel_size_m, buffer_size=cfg.buffer_size,
+        diff_travel_dist_local=nm.diff_travel_dist_local, neighbor_dx=dx, max_valid_dist2=mvd)
+    od = O.DecoderParams(*[cpu(p) for p in dec.flat_params()], sdf_scale=dec.sdf_scale)
+    pool = O.SamplePool(cpu(mp.global_coord_pool), cpu(mp.sdf_label_pool), cpu(mp.time_pool), cpu(mp.weight_pool))
+    # the search itself, bit-exact, on a slice of the first batch
+    x = pool.global_coord[idx[0, :4096]]
+    d2o, io = O.radius_neighborhood_search(st, x)
+    d2h, ih = nm.radius_neighborhood_search(x.cuda())
+    assert torch.equal(ih.cpu(), io) and torch.equal(d2h.cpu(), d2o)
+    mp.mapping(iters, index_seq=idx.cuda())
+    recs = O.mapping_iters(st, od, pool, idx, O.LoopConfig(sigma=mp.sdf_scale), record=True)
+    got = mp.last_losses.cpu()
+    for it, r in enumerate(recs):
+        assert abs(float(got[it, 0]) - float(r["loss"])) <= 2e-5, (it, got[it], r["loss"])
+    assert maxerr(nm.local_geo_features, recs[-1]["theta"]) <= 1e-4
+    for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
+        assert maxerr(t, o) <= 1e-4
+    assert maxerr(nm.local_point_certainties, recs[-1]["certainties"]) <= 5e-3
+
+
+def test_sharded_gradients_at_65536(env):
+    """BASELINE config 3/4 batch size: 65536 samples, 4 shards through the C ABI sum to the full batch."""
+    p = gio.load("pool.npz")
+    g = gio.load("g6_loop_numerical_train_ln0.npz")
+    bs = 65536
+    cfg = env.config(bs=bs)
+    gen = torch.Generator().manual_seed(4)
+    index = torch.randint(0, p["coord"].shape[0], (bs,), generator=gen)
+    full, loss_full, _, _ = _fused_grads(env, cfg, p, g, index)
+    acc = torch.zeros_like(full)
+    loss = torch.zeros(4)
+    per = bs // 4
+    for r in range(4):
+        gr, lo, _, _ = _fused_grads(env, cfg, p, g, index[r * per : (r + 1) * per], batch_offset=r * per, n_main=bs,
+                                    n_eik=(bs + 9) // 10)
+        acc += gr
+        loss += lo
+    assert float((acc - full).abs().max()) <= 5e-5 * float(full.abs().max())
+    assert float((loss - loss_full).abs().max()) <= 2e-6
