@@ -95,8 +95,11 @@ __device__ __forceinline__ int base_slot(float x, float y, float z, float res, i
 // so a hit costs ONE more 16-byte load that returns the position and the id together.  At <= 0.5 keys per
 // bucket the chance that a bucket is full (>= 4 keys) without a match is ~2e-4 per probe, so the walk to
 // the next bucket is a rare slow path instead of an extra dependent latency for every wave.
+// bucket of a slot: xor-fold instead of a multiplicative hash (v_mul_lo_u32 is a quarter-rate instruction and
+// this runs 81 times per query); slot = (sum cell*prime) mod B is already well mixed
 __device__ __forceinline__ unsigned tab_home(int slot, int log2nb) {
-  return ((unsigned)slot * 2654435761u) >> (32 - log2nb);
+  const unsigned u = (unsigned)slot;
+  return (u ^ (u >> 13) ^ (u >> 7)) & ((1u << log2nb) - 1u);
 }
 __device__ __forceinline__ int bucket_match(const int4 b, int slot) {
   return (b.x == slot) ? 0 : ((b.y == slot) ? 1 : ((b.z == slot) ? 2 : ((b.w == slot) ? 3 : -1)));

@@ -118,6 +118,7 @@ __device__ __forceinline__ int group8_sum_i(int v) {
 
 struct WaveLds {
   float4 qinfo[8];      // per query slot: x, y, z, pool sample index (int bits, -1 = padding)
+  float4 qdesc[8];      // per query slot: batch position (int bits, -1 = padding), axis (int bits), sign, -
   float2 win[8][8];     // per slot: up to K winners (d2, local id bits), ascending; (9e3, -1) = none
   float4 st[2][64][2];  // per decode round, per lane: {f[lane16], w_k, j_k bits, sdf}, {pre[0..3]}
   float cacc[CLID_K][CLID_F];  // bundle tasks: gradient rows of the decimated sample's neighbours, summed in-wave
@@ -234,7 +235,10 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
       if (qd.axis == 0) px = fadd(px, qd.sign * ta.fd_eps);  // x + [eps,0,0] in fp32 (mapper.py:988-999)
       if (qd.axis == 1) py = fadd(py, qd.sign * ta.fd_eps);
       if (qd.axis == 2) pz = fadd(pz, qd.sign * ta.fd_eps);
-      if (lane8 == 0) wl.qinfo[slot8] = make_float4(px, py, pz, __int_as_float(live ? (int)s : -1));
+      if (lane8 == 0) {
+        wl.qinfo[slot8] = make_float4(px, py, pz, __int_as_float(live ? (int)s : -1));
+        wl.qdesc[slot8] = make_float4(__int_as_float(qd.p), __int_as_float(qd.axis), qd.sign, 0.f);
+      }
       if (lane8 < CLID_K) wl.win[slot8][lane8] = make_float2(9e3f, __int_as_float(-1));  // np.py:606
       asm volatile("" ::"v"(px), "v"(py), "v"(pz));
       CLID_STAMP(1);
@@ -288,12 +292,12 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
       float pre[CLID_HPL];
       const float sdf = mlp_forward(mlp, f, lane16, sc, pre);
       if (valid && !odd && !(ta.debug_flags & 1)) {  // training_mode side effects (np.py:708-733)
-        const QDesc qd = task_query(tmap, task, round, grp);
+        const int q_axis = __float_as_int(wl.qdesc[s16].y);
         const bool shares = bundle && !(round == 1 && grp == 3);  // every slot but the unrelated 8th sample
         const int m = shares ? match_base(wl, my_j) : -1;
         if (m >= 0) atomicAdd(&wl.ccert[m], my_w);
         else atomicAdd(&mv.cert[my_j], my_w);
-        if (qd.axis < 0 && mv.ts_update) {
+        if (q_axis < 0 && mv.ts_update) {
           // amax is idempotent: only the first touch of a point by a newer stamp needs the atomic (a scattered
           // atomic costs ~10x a scattered load: tools/ubench_gather.hip)
           const int ts = ta.pool_ts[sidx];
@@ -323,7 +327,11 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
     // ================= backward
 #pragma unroll 1
     for (int round = 0; round < 2; ++round) {
-      const QDesc qd = task_query(tmap, task, round, grp);
+      QDesc qd;
+      {
+        const float4 qq = wl.qdesc[round * 4 + grp];
+        qd.p = __float_as_int(qq.x); qd.axis = __float_as_int(qq.y); qd.sign = qq.z;
+      }
       const float4 s0 = wl.st[round][lane][0], s1 = wl.st[round][lane][1];
       const float fb = s0.x, my_w = s0.y, sdf = s0.w;
       const int my_j = __float_as_int(s0.z);
