@@ -89,6 +89,13 @@ class HotPathConfig:
         self.adaptive_iters = True
         self.ba_freq_frame = 0
         self.wandb_vis_on = False
+        # tracker keys read by the measurement model (`utils/config.py:264-274`)
+        self.tran_dtype = torch.float64
+        self.reg_min_grad_norm = 0.5
+        self.reg_max_grad_norm = 1.5
+        self.track_mask_query_nn_k = self.query_nn_k
+        self.max_sdf_std_ratio = 1.0
+        self.reg_iter_n = 50
         self._derive()
 
     def _derive(self) -> None:

@@ -206,18 +206,13 @@ k_query_bwd(clid_map_view mv, const float* __restrict__ x, const int* __restrict
 }
 
 // ---- fused inference: sdf + analytic gradient ------------------------------------------------------------
-__global__ void __launch_bounds__(CLID_BLOCK)
-k_sdf_grad_x(clid_map_view mv, const float* W1, const float* b1, const float* W2, const float* b2,
-             float scale, const float* __restrict__ x, int N, float* __restrict__ sdf_out,
-             float* __restrict__ grad_out, int* __restrict__ nn_out, float* __restrict__ cert_out) {
-  __shared__ MlpLds mlp;
-  __shared__ DeltaLds dl;
-  stage_mlp_and_delta(mlp, dl, mv, W1, b1, W2, b2);
-  const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48;
-  const int q_raw = blockIdx.x * CLID_QPB + (threadIdx.x >> 4);
-  const bool live = q_raw < N;
-  const int q = live ? q_raw : (N - 1);
-  const float px = x[q * 3 + 0], py = x[q * 3 + 1], pz = x[q * 3 + 2];
+struct PointEval {  // replicated across the 16 lanes of the group
+  float sdf, gx, gy, gz, cert;
+  int nn;
+};
+// query (training_mode=False) -> Decoder.sdf -> analytic d sdf / d x of ONE point per 16-lane group
+__device__ __forceinline__ PointEval eval_point(const clid_map_view& mv, const MlpLds& mlp, const DeltaLds& dl,
+                                                float scale, float px, float py, float pz, int lane16, int gbase) {
   TopK t;
   search_topk(mv, dl, px, py, pz, lane16, gbase, t);
   float w[CLID_K], omega[CLID_K];
@@ -256,7 +251,8 @@ k_sdf_grad_x(clid_map_view mv, const float* W1, const float* b1, const float* W2
     f[CLID_F + 2] = fadd(f[CLID_F + 2], fmul(rz[k], w[k]));
   }
   float pre[CLID_HPL];
-  const float sdf = mlp_forward(mlp, f, lane16, scale, pre);
+  PointEval r;
+  r.sdf = mlp_forward(mlp, f, lane16, scale, pre);
   // u = scale * (W2 .* act) W1   (D values, replicated after the group reduction)
   float u[CLID_D];
 #pragma unroll
@@ -282,11 +278,96 @@ k_sdf_grad_x(clid_map_view mv, const float* W1, const float* b1, const float* W2
     gy += cw * (aby - 2.f * ry[k] * omega[k]);
     gz += cw * (abz - 2.f * rz[k] * omega[k]);
   }
+  r.gx = gx; r.gy = gy; r.gz = gz;
+  r.cert = cert;
+  r.nn = t.nn;
+  return r;
+}
+
+__global__ void __launch_bounds__(CLID_BLOCK)
+k_sdf_grad_x(clid_map_view mv, const float* W1, const float* b1, const float* W2, const float* b2,
+             float scale, const float* __restrict__ x, int N, float* __restrict__ sdf_out,
+             float* __restrict__ grad_out, int* __restrict__ nn_out, float* __restrict__ cert_out) {
+  __shared__ MlpLds mlp;
+  __shared__ DeltaLds dl;
+  stage_mlp_and_delta(mlp, dl, mv, W1, b1, W2, b2);
+  const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48;
+  const int q_raw = blockIdx.x * CLID_QPB + (threadIdx.x >> 4);
+  const bool live = q_raw < N;
+  const int q = live ? q_raw : (N - 1);
+  const PointEval r = eval_point(mv, mlp, dl, scale, x[q * 3 + 0], x[q * 3 + 1], x[q * 3 + 2], lane16, gbase);
   if (live && lane16 == 0) {
-    sdf_out[q] = sdf;
-    grad_out[q * 3 + 0] = gx; grad_out[q * 3 + 1] = gy; grad_out[q * 3 + 2] = gz;
-    if (nn_out) nn_out[q] = t.nn;
-    if (cert_out) cert_out[q] = cert;
+    sdf_out[q] = r.sdf;
+    grad_out[q * 3 + 0] = r.gx; grad_out[q * 3 + 1] = r.gy; grad_out[q * 3 + 2] = r.gz;
+    if (nn_out) nn_out[q] = r.nn;
+    if (cert_out) cert_out[q] = r.cert;
+  }
+}
+
+// ---- tracking measurement model -----------------------------------------------
+// IEKFOM.h_model (utils/error_state_iekf.py:176-264) in one launch: p_map = R p + t (fp32, as transform_torch
+// with the fp32 T of :182-186), sdf + analytic gradient at p_map, validity mask (:233-241), Jacobian rows
+// H[0:3] = -g^T R [p]x = p x (R^T g), H[3:6] = g (:247-252), weights R_inv = 1000 / (1 + (|g|-1)^2) * 0.4 /
+// (0.4 + sdf^2) (:255-259, float64), and the ONLY things update_iterated (:299-305) needs from the N x 18 H:
+// S = H^T R_inv H (non-zero 6 x 6 block) and H^T R_inv z, accumulated in float64.
+struct TrackParams {
+  float R[9];
+  float t[3];
+  float scale;
+  float min_grad_norm, max_grad_norm;
+  int min_nn;
+};
+
+__global__ void __launch_bounds__(CLID_BLOCK)
+k_track_model(clid_map_view mv, const float* W1, const float* b1, const float* W2, const float* b2, TrackParams tp,
+              const float* __restrict__ pc_imu, int N, float* __restrict__ sdf_out, float* __restrict__ grad_out,
+              float* __restrict__ pmap_out, int* __restrict__ valid_out, double* __restrict__ normal_eq /* 28 */) {
+  __shared__ MlpLds mlp;
+  __shared__ DeltaLds dl;
+  __shared__ double red[CLID_QPB][28];
+  stage_mlp_and_delta(mlp, dl, mv, W1, b1, W2, b2);
+  const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48, grp_in_block = threadIdx.x >> 4;
+  const int q_raw = blockIdx.x * CLID_QPB + grp_in_block;
+  const bool live = q_raw < N;
+  const int q = live ? q_raw : (N - 1);
+  const float ix = pc_imu[q * 3 + 0], iy = pc_imu[q * 3 + 1], iz = pc_imu[q * 3 + 2];
+  const float px = tp.R[0] * ix + tp.R[1] * iy + tp.R[2] * iz + tp.t[0];
+  const float py = tp.R[3] * ix + tp.R[4] * iy + tp.R[5] * iz + tp.t[1];
+  const float pz = tp.R[6] * ix + tp.R[7] * iy + tp.R[8] * iz + tp.t[2];
+  const PointEval r = eval_point(mv, mlp, dl, tp.scale, px, py, pz, lane16, gbase);
+  const float gn = sqrtf(r.gx * r.gx + r.gy * r.gy + r.gz * r.gz);
+  const bool valid = live && r.nn >= tp.min_nn && gn < tp.max_grad_norm && gn > tp.min_grad_norm;
+  if (live && lane16 == 0) {
+    if (sdf_out) sdf_out[q] = r.sdf;
+    if (grad_out) { grad_out[q * 3 + 0] = r.gx; grad_out[q * 3 + 1] = r.gy; grad_out[q * 3 + 2] = r.gz; }
+    if (pmap_out) { pmap_out[q * 3 + 0] = px; pmap_out[q * 3 + 1] = py; pmap_out[q * 3 + 2] = pz; }
+    if (valid_out) valid_out[q] = valid ? 1 : 0;
+  }
+  if (!normal_eq) return;
+  // h = [p_imu x (R^T g), g] in fp32 (the reference builds it with fp32 bmm's), then float64 accumulation
+  const float qx = tp.R[0] * r.gx + tp.R[3] * r.gy + tp.R[6] * r.gz;
+  const float qy = tp.R[1] * r.gx + tp.R[4] * r.gy + tp.R[7] * r.gz;
+  const float qz = tp.R[2] * r.gx + tp.R[5] * r.gy + tp.R[8] * r.gz;
+  double h[6] = {(double)(iy * qz - iz * qy), (double)(iz * qx - ix * qz), (double)(ix * qy - iy * qx),
+                 (double)r.gx, (double)r.gy, (double)r.gz};
+  const double z = (double)r.sdf, ga = (double)gn - 1.0;
+  const double wgt = valid ? (1.0 / (1.0 + ga * ga)) * (0.4 / (0.4 + z * z)) * 1000.0 : 0.0;
+  if (lane16 == 0) {
+    int n = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b2i = a; b2i < 6; ++b2i) red[grp_in_block][n++] = wgt * h[a] * h[b2i];  // 21 upper-triangle entries
+#pragma unroll
+    for (int a = 0; a < 6; ++a) red[grp_in_block][n++] = wgt * h[a] * z;               // H^T R_inv z
+    red[grp_in_block][27] = valid ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  if (threadIdx.x < 28) {
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < CLID_QPB; ++g) s += red[g][threadIdx.x];
+    if (s != 0.0) atomicAdd(&normal_eq[threadIdx.x], s);
   }
 }
 
@@ -353,6 +434,31 @@ extern "C" int clid_sdf_grad_x(const clid_map_view* mv, const float* W1, const f
   hipLaunchKernelGGL(clid::k_sdf_grad_x, dim3((N + CLID_QPB - 1) / CLID_QPB), dim3(CLID_BLOCK), 0,
                      (hipStream_t)stream, *mv, W1, b1, W2, b2, sdf_scale, x, N, sdf_out, grad_out, nn_out,
                      cert_out);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+extern "C" int clid_track_model(const clid_map_view* mv, const float* W1, const float* b1, const float* W2,
+                                const float* b2, float sdf_scale, const float* rot_host, const float* pos_host,
+                                int32_t min_nn, float min_grad_norm, float max_grad_norm, const float* pc_imu,
+                                int32_t N, float* sdf_out, float* grad_out, float* pmap_out, int32_t* valid_out,
+                                double* normal_eq, void* stream) {
+  if (int e = check_view(mv, "clid_track_model")) return e;
+  if (!rot_host || !pos_host || !pc_imu || N < 0) {
+    clid_set_error("clid_track_model: bad argument");
+    return CLID_E_ARG;
+  }
+  if (N == 0) return CLID_OK;
+  clid::TrackParams tp;
+  for (int i = 0; i < 9; ++i) tp.R[i] = rot_host[i];
+  for (int i = 0; i < 3; ++i) tp.t[i] = pos_host[i];
+  tp.scale = sdf_scale;
+  tp.min_grad_norm = min_grad_norm;
+  tp.max_grad_norm = max_grad_norm;
+  tp.min_nn = min_nn;
+  hipLaunchKernelGGL(clid::k_track_model, dim3((N + CLID_QPB - 1) / CLID_QPB), dim3(CLID_BLOCK), 0,
+                     (hipStream_t)stream, *mv, W1, b1, W2, b2, tp, pc_imu, N, sdf_out, grad_out, pmap_out, valid_out,
+                     normal_eq);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

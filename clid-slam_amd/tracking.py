@@ -1,0 +1,80 @@
+"""Tracking measurement model ("next" row N1): the consumer of the analytic
+d SDF / d x inference path, `IEKFOM.h_model` (utils/error_state_iekf.py:176-264), as ONE fused HIP launch.
+
+    z, H, valid_points, R_inv = h_model(neural_points, geo_decoder, config, rot, pos, pc_imu)
+    S, HtRz, n_valid = normal_equations(neural_points, geo_decoder, config, rot, pos, pc_imu)
+
+`h_model` returns what the reference method returns (plus `R_inv`, which the reference stores on `self`).
+`normal_equations` returns the only quantities `update_iterated` (:299-305) derives from H:
+S = H^T R_inv H (18 x 18, float64, non-zero 6 x 6 block) and H^T R_inv z, reduced on the GPU without
+materialising H.  The 18-state filter itself (predict / boxplus / covariance) is host-side 18 x 18 math and
+stays with the reference (out of scope).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _launch(neural_points, geo_decoder, config, rot, pos, pc_imu, per_point: bool, reduce: bool):
+    if not config.weighted_first:
+        raise NotImplementedError("fused h_model serves weighted_first configs (all shipped ones); "
+                                  "use query_feature / Decoder.sdf / get_gradient otherwise")
+    lib = _lib.load()
+    x = _lib.require_cuda(pc_imu.detach().to(torch.float32).contiguous(), "pc_imu", torch.float32)
+    n = x.shape[0]
+    dev = x.device
+    view, keep = neural_points._map_view(True)
+    W1, b1, W2, b2 = geo_decoder.flat_params()
+    r = (C.c_float * 9)(*[float(v) for v in torch.as_tensor(rot).detach().cpu().to(torch.float32).reshape(-1)])
+    t = (C.c_float * 3)(*[float(v) for v in torch.as_tensor(pos).detach().cpu().to(torch.float32).reshape(-1)])
+    out = {}
+    if per_point:
+        out["sdf"] = torch.empty(n, device=dev, dtype=torch.float32)
+        out["grad"] = torch.empty((n, 3), device=dev, dtype=torch.float32)
+        out["pmap"] = torch.empty((n, 3), device=dev, dtype=torch.float32)
+        out["valid"] = torch.empty(n, device=dev, dtype=torch.int32)
+    ne = torch.zeros(28, device=dev, dtype=torch.float64) if reduce else None
+    _lib.check(
+        lib.clid_track_model(C.byref(view), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
+                             float(geo_decoder.sdf_scale), r, t, int(config.track_mask_query_nn_k),
+                             float(config.reg_min_grad_norm), float(config.reg_max_grad_norm), _lib.ptr(x), n,
+                             _lib.ptr(out.get("sdf")), _lib.ptr(out.get("grad")), _lib.ptr(out.get("pmap")),
+                             _lib.ptr(out.get("valid")), _lib.ptr(ne), _lib.stream()),
+        "clid_track_model",
+    )
+    return x, out, ne
+
+
+def h_model(neural_points, geo_decoder, config, rot, pos, pc_imu):
+    """(sdf_residual [Nv] f64, H [Nv,18] f64, valid_points [Nv,3], R_inv [Nv] f64) as
+    utils/error_state_iekf.py:176-264 computes them for the state (rot, pos)."""
+    x, out, _ = _launch(neural_points, geo_decoder, config, rot, pos, pc_imu, True, False)
+    tdt = getattr(config, "tran_dtype", torch.float64)
+    valid = out["valid"].bool()
+    g = out["grad"][valid]
+    p = x[valid]
+    rot32 = torch.as_tensor(rot).to(x.device, torch.float32)
+    q = g @ rot32  # rows: R^T g
+    H = torch.zeros((g.shape[0], 18), device=x.device, dtype=tdt)
+    H[:, 0:3] = torch.cross(p, q, dim=1)  # -g^T R [p]x
+    H[:, 3:6] = g
+    z = out["sdf"][valid].to(tdt)
+    ga = (g.norm(dim=-1) - 1.0).to(tdt)
+    r_inv = 1 / (1 + ga**2) * (0.4 / (0.4 + z**2)) * 1000
+    return z, H, out["pmap"][valid], r_inv
+
+
+def normal_equations(neural_points, geo_decoder, config, rot, pos, pc_imu):
+    """(S [18,18] f64 = H^T R_inv H, HtRz [18] f64 = H^T R_inv z, n_valid) in one launch."""
+    x, _, ne = _launch(neural_points, geo_decoder, config, rot, pos, pc_imu, False, True)
+    S = torch.zeros((18, 18), device=x.device, dtype=torch.float64)
+    iu = torch.triu_indices(6, 6, device=x.device)
+    S[iu[0], iu[1]] = ne[:21]
+    S[iu[1], iu[0]] = ne[:21]
+    b = torch.zeros(18, device=x.device, dtype=torch.float64)
+    b[:6] = ne[21:27]
+    return S, b, int(ne[27].item())

@@ -117,6 +117,19 @@ int clid_sdf_grad_x(const clid_map_view* mv, const float* W1, const float* b1, c
                     const float* b2, float sdf_scale, const float* x, int32_t N, float* sdf_out,
                     float* grad_out, int32_t* nn_out, float* cert_out, void* stream);
 
+/* Tracking measurement model, IEKFOM.h_model (utils/error_state_iekf.py:176-264), weighted_first configs:
+ * p_map = R p_imu + t, sdf + analytic gradient at p_map, validity mask (nn >= min_nn, min < |g| < max),
+ * and -- when normal_eq != NULL -- the float64 sums update_iterated (:299-305) needs instead of the N x 18 H:
+ *   normal_eq[0..20]  upper triangle (row-major) of the 6x6 block of S = H^T R_inv H   (+=, zero it first)
+ *   normal_eq[21..26] H^T R_inv z,   normal_eq[27] number of valid points
+ * rot_host [9] row-major / pos_host [3]: HOST floats (the filter state lives on the host).
+ * Per-point outputs (any may be NULL): sdf [N], grad [N][3], pmap [N][3], valid [N] int32. */
+int clid_track_model(const clid_map_view* mv, const float* W1, const float* b1, const float* W2,
+                     const float* b2, float sdf_scale, const float* rot_host, const float* pos_host,
+                     int32_t min_nn, float min_grad_norm, float max_grad_norm, const float* pc_imu,
+                     int32_t N, float* sdf_out, float* grad_out, float* pmap_out, int32_t* valid_out,
+                     double* normal_eq, void* stream);
+
 /* utils/loss.py:44-62 sdf_bce_loss (weighted, mean) + eikonal term (utils/mapper.py:779-798):
  * loss_out[0..2] = total, bce, eikonal (+=, zero it first); d_pred_out [N]; d_g_out [Ng][3]. */
 int clid_loss_fwd_bwd(const float* pred, const float* label, const float* weight, int32_t N,

@@ -427,3 +427,43 @@ def assign_local_to_global(st: MapState, local_mask: torch.Tensor, point_ts_upda
     st.geo_features[local_mask] = st.local_geo_features.detach()
     st.point_certainties[local_mask[:-1]] = st.local_point_certainties
     point_ts_update[local_mask[:-1]] = st.local_point_ts_update
+
+
+# --------------------------------------------------------------------------------------------------
+# N1: tracking measurement model
+# --------------------------------------------------------------------------------------------------
+def h_model(st: MapState, dec: DecoderParams, rot: torch.Tensor, pos: torch.Tensor, pc_imu: torch.Tensor,
+            min_nn: int = 6, min_grad_norm: float = 0.5, max_grad_norm: float = 1.5, max_sdf_std: float = 0.25):
+    """utils/error_state_iekf.py:176-264.  Returns (z [Nv] f64, H [Nv,18] f64, valid_points [Nv,3],
+    R_inv [Nv] f64, valid mask [N])."""
+    T = torch.eye(4)
+    T[:3, :3] = rot
+    T[:3, 3] = pos
+    homo = torch.cat([pc_imu, torch.ones(pc_imu.shape[0], 1)], dim=1)
+    pc_map = (homo @ T.T)[:, :3]  # utils/tools.py:590-609
+    x = pc_map.clone().requires_grad_(True)
+    f, w, nn, cert, _ = query_feature(st, x, training_mode=False)
+    sdf = mlp_sdf(dec, f)
+    sdf_std = torch.zeros(pc_map.shape[0])
+    if not st.weighted_first:
+        mean = (sdf * w).sum(dim=1)
+        sdf_std = torch.sqrt((w * (sdf - mean.unsqueeze(-1)) ** 2).sum(dim=1)).squeeze(1).detach()
+        sdf = mean.squeeze(1)
+    g = autograd_gradient(x, sdf).detach()
+    sdf = sdf.detach()
+    gn = g.norm(dim=-1)
+    valid = (nn >= min_nn) & (gn < max_grad_norm) & (gn > min_grad_norm) & (sdf_std < max_sdf_std)
+    g, gn, sdf, p = g[valid], gn[valid], sdf[valid], pc_imu[valid]
+    n = g.shape[0]
+    skew = torch.zeros((n, 3, 3))  # utils/so3_math.py:23-33
+    skew[:, 0, 1], skew[:, 0, 2] = -p[:, 2], p[:, 1]
+    skew[:, 1, 0], skew[:, 1, 2] = p[:, 2], -p[:, 0]
+    skew[:, 2, 0], skew[:, 2, 1] = -p[:, 1], p[:, 0]
+    A = rot.to(torch.float32).unsqueeze(0).repeat(n, 1, 1) @ skew
+    H = torch.zeros((n, 18), dtype=torch.float64)
+    H[:, 0:3] = -(g.unsqueeze(1) @ A).squeeze(1)
+    H[:, 3:6] = g
+    z = sdf.to(torch.float64)
+    ga = (gn - 1.0).to(torch.float64)
+    r_inv = 1 / (1 + ga**2) * (0.4 / (0.4 + z**2)) * 1000
+    return z, H, pc_map[valid], r_inv, valid

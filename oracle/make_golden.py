@@ -450,8 +450,69 @@ def map_build_fixture():
     print("G7 map build:", nm.count(), nm.local_count())
 
 
+GRAD_WINDOW = (0.004, 0.03)
+
+
+def tracking_fixture():
+    """G8: the reference's own IEKFOM.h_model (utils/error_state_iekf.py:176-264) on the golden map of
+    state.npz, for both layer_norm settings (weighted_first configs)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    ref = import_reference()
+    import golden_io as gio
+    from utils.error_state_iekf import IEKFOM
+    from clid_slam_amd.synth import box_room_scan
+
+    z = gio.load("state.npz")
+    out = {}
+    for ln in (False, True):
+        cfg = ref_config(ref)
+        cfg.layer_norm_on = ln
+        nm = ref.NeuralPoints(cfg)
+        tab = torch.full((cfg.buffer_size,), -1, dtype=torch.int64)
+        tab[gio.T(z["table_slot"])] = gio.T(z["table_idx"])
+        nm.buffer_pt_index = tab
+        nm.neural_points = gio.T(z["neural_points"])
+        nm.point_orientations = torch.zeros((nm.neural_points.shape[0], 4))
+        nm.point_ts_create = gio.T(z["point_ts_create"])
+        nm.point_ts_update = gio.T(z["point_ts_update"])
+        nm.travel_dist = gio.T(z["travel_dist"])
+        nm.cur_ts = int(gio.S(z["cur_ts"]))
+        nm.global2local = gio.T(z["global2local"])
+        nm.local_mask = gio.T(z["local_mask"])
+        nm.local_neural_points = gio.T(z["local_neural_points"])
+        nm.local_point_orientations = torch.zeros((nm.local_neural_points.shape[0], 4))
+        nm.local_geo_features = torch.nn.Parameter(gio.T(z["local_geo_features"]).clone())
+        nm.local_point_certainties = gio.T(z["local_point_certainties"]).clone()
+        nm.local_point_ts_update = gio.T(z["local_point_ts_update"]).clone()
+        dec = ref.Decoder(cfg, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, 1)
+        with torch.no_grad():
+            dec.layers[0].weight.copy_(gio.T(z["W1"])); dec.layers[0].bias.copy_(gio.T(z["b1"]))
+            dec.lout.weight.copy_(gio.T(z["W2"])); dec.lout.bias.copy_(gio.T(z["b2"]))
+        ekf = IEKFOM(cfg, nm, dec)
+        ang = 0.03
+        rot = torch.tensor([[np.cos(ang), -np.sin(ang), 0.0], [np.sin(ang), np.cos(ang), 0.0], [0.0, 0.0, 1.0]],
+                           dtype=torch.float64)
+        ekf.x.rot = rot
+        ekf.x.pos = torch.tensor([9.05, 2.95, 1.62], dtype=torch.float64)
+        scan = box_room_scan(n_elev=32, n_azim=256, seed=99, sensor=(9.0, 3.0, 1.6), vox_down_m=0.6)
+        # the fixture map is untrained (|grad| ~ 1e-2), so the gradient-norm window is moved there to make the
+        # mask non-trivial; the thresholds are plain parameters of the model
+        cfg.reg_min_grad_norm, cfg.reg_max_grad_norm = GRAD_WINDOW
+        zz, H, vp = ekf.h_model(scan.clone())
+        if not ln:
+            out.update(rot=rot.numpy(), pos=ekf.x.pos.numpy(), pc_imu=scan.numpy(), grad_window=np.array(GRAD_WINDOW))
+        tag = f"ln{int(ln)}"
+        out[f"z_{tag}"] = zz.numpy(); out[f"H6_{tag}"] = H[:, :6].numpy(); out[f"valid_points_{tag}"] = vp.detach().numpy()
+        out[f"R_inv_{tag}"] = ekf.R_inv.numpy()
+        assert H.shape[0] > 100 and float(H[:, 6:].abs().max()) == 0.0
+        print("G8", tag, "valid", H.shape[0], "of", scan.shape[0])
+    np.savez_compressed(os.path.join(OUT, "g8_tracking.npz"), **out)
+
+
 if __name__ == "__main__":
-    if "--only-g7" in sys.argv:
+    if "--only-g8" in sys.argv:
+        tracking_fixture()
+    elif "--only-g7" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
         map_build_fixture()
     else:

@@ -468,3 +468,31 @@ def test_sharded_gradients_at_65536(env):
         loss += lo
     assert float((acc - full).abs().max()) <= 5e-5 * float(full.abs().max())
     assert float((loss - loss_full).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("ln", [0, 1])
+def test_tracking_measurement_model_g8(env, ln):
+    """Row N1: fused h_model kernel (per-point outputs and the float64 normal equations) against the
+    reference's IEKFOM.h_model fixture."""
+    from clid_slam_amd import tracking
+
+    g = gio.load("g8_tracking.npz")
+    cfg = env.config(layer_norm_on=bool(ln))
+    cfg.reg_min_grad_norm, cfg.reg_max_grad_norm = float(g["grad_window"][0]), float(g["grad_window"][1])
+    nm = env.neural_points(cfg)
+    dec = env.decoder(cfg)
+    rot, pos, pc = gio.T(g["rot"]), gio.T(g["pos"]), gio.T(g["pc_imu"]).cuda()
+    z, H, vp, r_inv = tracking.h_model(nm, dec, cfg, rot, pos, pc)
+    Hr, zr, rr = g[f"H6_ln{ln}"], g[f"z_ln{ln}"], g[f"R_inv_ln{ln}"]
+    assert H.dtype == torch.float64 and H.shape == (Hr.shape[0], 18)
+    assert maxerr(z, zr) <= 2e-6
+    assert maxerr(H[:, :6], Hr) <= 5e-5 and float(H[:, 6:].abs().max()) == 0.0
+    assert maxerr(vp, g[f"valid_points_ln{ln}"]) <= 1e-5
+    assert maxerr(r_inv, rr) <= 2e-2
+    S, b, n = tracking.normal_equations(nm, dec, cfg, rot, pos, pc)
+    assert n == Hr.shape[0]
+    S_ref = (Hr.T * rr) @ Hr
+    b_ref = (Hr.T * rr) @ zr
+    assert np.abs(S[:6, :6].cpu().numpy() - S_ref).max() <= 2e-4 * np.abs(S_ref).max()
+    assert np.abs(b[:6].cpu().numpy() - b_ref).max() <= 2e-4 * max(np.abs(b_ref).max(), 1e-9)
+    assert float(S[6:, :].abs().max()) == 0.0 and float(S[:, 6:].abs().max()) == 0.0

@@ -161,3 +161,20 @@ def test_g6_mapping_loop(mode, frozen, ln):
     close(st.geo_features, base, 1e-4, "final geo features")
     close(st.point_certainties, g["final_point_certainties"], 1e-3)
     assert np.array_equal(tsu.numpy(), g["final_point_ts_update"])
+
+
+@pytest.mark.parametrize("ln", [0, 1])
+def test_g8_tracking_measurement_model(ln):
+    """Row N1: the oracle's h_model against the reference's own IEKFOM.h_model output."""
+    g = gio.load("g8_tracking.npz")
+    st = gio.map_state(layer_norm_on=bool(ln))
+    dec = gio.decoder()
+    lo, hi = g["grad_window"]
+    z, H, vp, r_inv, valid = O.h_model(st, dec, gio.T(g["rot"]), gio.T(g["pos"]), gio.T(g["pc_imu"]),
+                                       min_grad_norm=float(lo), max_grad_norm=float(hi))
+    assert H.shape[0] == g[f"H6_ln{ln}"].shape[0] > 100
+    close(z, g[f"z_ln{ln}"], 1e-6, "residual")
+    close(H[:, :6], g[f"H6_ln{ln}"], 2e-5, "Jacobian")
+    assert float(H[:, 6:].abs().max()) == 0.0
+    close(vp, g[f"valid_points_ln{ln}"], 1e-5, "valid points")
+    close(r_inv, g[f"R_inv_ln{ln}"], 1e-2, "R_inv")  # values ~1e3
