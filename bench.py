@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--bs", type=int, default=16384, help="samples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for single-GPU dry runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,14 +116,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    local_dev = local_rank % torch.cuda.device_count()  # dry runs may put several ranks on one GPU
+    torch.cuda.set_device(local_dev)
+    device = f"cuda:{local_dev}"
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(args.backend)
 
     import clid_slam_amd  # noqa: F401
     from clid_slam_amd import HotPathConfig, _lib
@@ -153,10 +158,11 @@ def main():
 
     # ---- roofline leg: per-kernel hipEvent timing on the launch stream (separate pass)
     roof = None
+    prof_steps = min(args.steps, 100)
     if rank == 0:
-        prof_steps = min(args.steps, 100)
         lib.clid_profile_enable(1)
-        mp.mapping(prof_steps)
+    mp.mapping(prof_steps)  # every rank takes part (the loop contains collectives when world > 1)
+    if rank == 0:
         out = (C.c_double * 5)()
         n = C.c_int(0)
         _lib.check(lib.clid_profile_read(out, C.byref(n), _lib.stream()), "clid_profile_read")
