@@ -65,6 +65,7 @@ _SIGS = {
     "clid_mlp_sdf_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _vp]),
     "clid_mlp_sdf_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "clid_sdf_grad_x": (C.c_int, [C.POINTER(MapView), _vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "clid_sdf_query": (C.c_int, [C.POINTER(MapView), _vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _vp, _vp]),
     "clid_track_model": (C.c_int, [C.POINTER(MapView), _vp, _vp, _vp, _vp, _f32, C.POINTER(_f32), C.POINTER(_f32), _i32,
                          _f32, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clid_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _f32, _i32, _vp, _i32, _f32, _vp, _vp, _vp, _vp]),

@@ -304,6 +304,70 @@ k_sdf_grad_x(clid_map_view mv, const float* W1, const float* b1, const float* W2
   }
 }
 
+// ---- dense inference for meshing ------------------------------------------------
+// Mesher.query_points (utils/mesher.py:38-163), SDF part: query_feature(training_mode=False) -> sdf where at
+// least one neighbour exists (else 0, :122-128), plus the neighbour count for the marching-cubes mask (:156-161).
+__global__ void __launch_bounds__(CLID_BLOCK)
+k_sdf_query(clid_map_view mv, const float* W1, const float* b1, const float* W2, const float* b2, float scale,
+            const float* __restrict__ x, int N, float* __restrict__ sdf_out, int* __restrict__ nn_out) {
+  __shared__ MlpLds mlp;
+  __shared__ DeltaLds dl;
+  stage_mlp_and_delta(mlp, dl, mv, W1, b1, W2, b2);
+  const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48;
+  const int my_k = lane16 >> 1;
+  const bool odd = lane16 & 1;
+  const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
+  const int n_groups = (N + CLID_QPB - 1) / CLID_QPB * CLID_QPB;
+  for (int g0 = blockIdx.x * CLID_QPB; g0 < n_groups; g0 += gridDim.x * CLID_QPB) {
+    const int q_raw = g0 + (threadIdx.x >> 4);
+    const bool live = q_raw < N;
+    const int q = live ? q_raw : (N - 1);
+    const float px = x[(size_t)q * 3 + 0], py = x[(size_t)q * 3 + 1], pz = x[(size_t)q * 3 + 2];
+    TopK t;
+    search_topk(mv, dl, px, py, pz, lane16, gbase, t);
+    float w[CLID_K], omega[CLID_K];
+    idw_weights(t, w, omega);
+    int my_j = -1;
+    float my_w = 0.f;
+#pragma unroll
+    for (int k = 0; k < CLID_K; ++k) {
+      my_j = (my_k == k) ? t.j[k] : my_j;
+      my_w = (my_k == k) ? w[k] : my_w;
+    }
+    const int jc = my_j >= 0 ? my_j : 0;
+    float4 v = reinterpret_cast<const float4*>(mv.feat)[(size_t)jc * 2 + (odd ? 1 : 0)];
+    const float4 pj = pos4[jc];
+    if (mv.layer_norm) {
+      float s1 = (v.x + v.y) + (v.z + v.w);
+      s1 += dpp_mov<0xB1>(s1);
+      const float mu = s1 * (1.0f / CLID_F);
+      v.x -= mu; v.y -= mu; v.z -= mu; v.w -= mu;
+      float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      s2 += dpp_mov<0xB1>(s2);
+      const float rstd = 1.0f / sqrtf(s2 * (1.0f / CLID_F) + 1e-5f);
+      v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
+    }
+    float f[CLID_D];
+    {
+      float a0 = v.x * my_w, a1 = v.y * my_w, a2 = v.z * my_w, a3 = v.w * my_w;
+      float r0 = fsub(px, pj.x) * my_w, r1 = fsub(py, pj.y) * my_w, r2 = fsub(pz, pj.z) * my_w;
+#define CLID_BFLY(x) x += dpp_mov<0x128>(x); x += dpp_mov<0x124>(x); x += dpp_mov<0x122>(x);
+      CLID_BFLY(a0) CLID_BFLY(a1) CLID_BFLY(a2) CLID_BFLY(a3) CLID_BFLY(r0) CLID_BFLY(r1) CLID_BFLY(r2)
+#undef CLID_BFLY
+      const float b0 = dpp_mov<0xB1>(a0), b1v = dpp_mov<0xB1>(a1), b2v = dpp_mov<0xB1>(a2), b3 = dpp_mov<0xB1>(a3);
+      f[0] = odd ? b0 : a0; f[1] = odd ? b1v : a1; f[2] = odd ? b2v : a2; f[3] = odd ? b3 : a3;
+      f[4] = odd ? a0 : b0; f[5] = odd ? a1 : b1v; f[6] = odd ? a2 : b2v; f[7] = odd ? a3 : b3;
+      f[8] = r0; f[9] = r1; f[10] = r2;
+    }
+    float pre[CLID_HPL];
+    const float sdf = mlp_forward(mlp, f, lane16, scale, pre);
+    if (live && lane16 == 0) {
+      sdf_out[q] = t.nn >= 1 ? sdf : 0.f;
+      nn_out[q] = t.nn;
+    }
+  }
+}
+
 // ---- tracking measurement model -----------------------------------------------
 // IEKFOM.h_model (utils/error_state_iekf.py:176-264) in one launch: p_map = R p + t (fp32, as transform_torch
 // with the fp32 T of :182-186), sdf + analytic gradient at p_map, validity mask (:233-241), Jacobian rows
@@ -459,6 +523,23 @@ extern "C" int clid_track_model(const clid_map_view* mv, const float* W1, const 
   hipLaunchKernelGGL(clid::k_track_model, dim3((N + CLID_QPB - 1) / CLID_QPB), dim3(CLID_BLOCK), 0,
                      (hipStream_t)stream, *mv, W1, b1, W2, b2, tp, pc_imu, N, sdf_out, grad_out, pmap_out, valid_out,
                      normal_eq);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+extern "C" int clid_sdf_query(const clid_map_view* mv, const float* W1, const float* b1, const float* W2,
+                              const float* b2, float sdf_scale, const float* x, int32_t N, float* sdf_out,
+                              int32_t* nn_out, void* stream) {
+  if (int e = check_view(mv, "clid_sdf_query")) return e;
+  if (!x || !sdf_out || !nn_out || N < 0) {
+    clid_set_error("clid_sdf_query: bad argument");
+    return CLID_E_ARG;
+  }
+  if (N == 0) return CLID_OK;
+  int nb = (N + CLID_QPB - 1) / CLID_QPB;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(clid::k_sdf_query, dim3(nb), dim3(CLID_BLOCK), 0, (hipStream_t)stream, *mv, W1, b1, W2, b2,
+                     sdf_scale, x, N, sdf_out, nn_out);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

@@ -117,6 +117,12 @@ int clid_sdf_grad_x(const clid_map_view* mv, const float* W1, const float* b1, c
                     const float* b2, float sdf_scale, const float* x, int32_t N, float* sdf_out,
                     float* grad_out, int32_t* nn_out, float* cert_out, void* stream);
 
+/* Dense inference for meshing, the SDF part of Mesher.query_points (utils/mesher.py:38-163): sdf_out [N]
+ * (0 where no neighbour exists, :122-128) and nn_out [N] for the marching-cubes mask (:156-161). */
+int clid_sdf_query(const clid_map_view* mv, const float* W1, const float* b1, const float* W2,
+                   const float* b2, float sdf_scale, const float* x, int32_t N, float* sdf_out,
+                   int32_t* nn_out, void* stream);
+
 /* Tracking measurement model, IEKFOM.h_model (utils/error_state_iekf.py:176-264), weighted_first configs:
  * p_map = R p_imu + t, sdf + analytic gradient at p_map, validity mask (nn >= min_nn, min < |g| < max),
  * and -- when normal_eq != NULL -- the float64 sums update_iterated (:299-305) needs instead of the N x 18 H:

@@ -496,3 +496,24 @@ def test_tracking_measurement_model_g8(env, ln):
     assert np.abs(S[:6, :6].cpu().numpy() - S_ref).max() <= 2e-4 * np.abs(S_ref).max()
     assert np.abs(b[:6].cpu().numpy() - b_ref).max() <= 2e-4 * max(np.abs(b_ref).max(), 1e-9)
     assert float(S[6:, :].abs().max()) == 0.0 and float(S[:, 6:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("ln,loc", [(0, 0), (1, 0), (0, 1)])
+def test_dense_sdf_query_vs_oracle(env, ln, loc):
+    """Row N3: the fused dense query (global map, no time filter) against the oracle's
+    query_feature -> decoder composition (both pinned on G2/G3), incl. the nn >= 1 / nn >= 4 masks."""
+    from clid_slam_amd import mesher
+
+    g = gio.load("g2_query.npz")
+    cfg = env.config(layer_norm_on=bool(ln))
+    nm = env.neural_points(cfg)
+    dec = env.decoder(cfg)
+    gen = torch.Generator().manual_seed(1)
+    x = torch.cat([gio.T(g["x"]), gio.T(g["x"]) + 0.3 * torch.randn(g["x"].shape, generator=gen)])
+    sdf, _, _, mask = mesher.query_points(nm, dec, cfg, x.cuda(), bs=700, query_locally=bool(loc), mask_min_nn_count=4)
+    st = gio.map_state(layer_norm_on=bool(ln))
+    f, _, nn, _, _ = O.query_feature(st, x, training_mode=False, query_locally=bool(loc))
+    ref = torch.where(nn >= 1, O.mlp_sdf(gio.decoder(), f), torch.zeros(()))
+    assert maxerr(sdf, ref) <= 2e-6
+    assert torch.equal(mask.cpu().bool(), nn >= 4)
+    assert (nn == 0).any() and (nn >= 4).any()
