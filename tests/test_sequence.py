@@ -1,0 +1,85 @@
+"""GPU: a short multi-frame run the way slam.py drives the objects (per frame: new `travel_dist` tensor,
+`NeuralPoints.update` -> new local map / new nn.Parameter, pool append, `Mapper.mapping`), checked against the
+CPU oracle on a copy of the state before every mapping call.  Guards the device-mirror cache: the compact probe
+table must be rebuilt whenever the map, the local window, cur_ts or travel_dist change."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_state(nm, cfg):
+    cpu = lambda t: t.detach().cpu().clone()
+    dx, mvd = O.search_neighborhood(cfg.num_nei_cells, cfg.search_alpha, cfg.voxel_size_m)
+    return O.MapState(
+        buffer_pt_index=cpu(nm.buffer_pt_index), neural_points=cpu(nm.neural_points),
+        point_ts_create=cpu(nm.point_ts_create), travel_dist=cpu(nm.travel_dist), cur_ts=int(nm.cur_ts),
+        global2local=cpu(nm.global2local), local_neural_points=cpu(nm.local_neural_points),
+        local_geo_features=cpu(nm.local_geo_features.data), local_point_certainties=cpu(nm.local_point_certainties),
+        local_point_ts_update=cpu(nm.local_point_ts_update), resolution=cfg.voxel_size_m, buffer_size=cfg.buffer_size,
+        diff_travel_dist_local=nm.diff_travel_dist_local, neighbor_dx=dx, max_valid_dist2=mvd,
+        layer_norm_on=cfg.layer_norm_on)
+
+
+@pytest.mark.parametrize("layer_norm", [False, True])
+def test_multi_frame_mapping_tracks_the_oracle(layer_norm):
+    from clid_slam_amd import Decoder, HotPathConfig, Mapper, NeuralPoints
+    from clid_slam_amd.synth import box_room_pool
+
+    class DS:
+        lose_track = False
+        stop_status = False
+        processed_frame = 0
+        gt_pose_provided = False
+
+    dev = "cuda:0"
+    cfg = HotPathConfig()
+    cfg.device, cfg.bs, cfg.bs_new_sample, cfg.layer_norm_on = dev, 4096, 500, layer_norm
+    cfg.buffer_size = 2_000_003  # collisions happen, the int64 table stays small for the CPU copies
+    cfg.feature_std = 0.05       # non-degenerate features for new points (the shipped value 0 gives all-zero rows)
+    torch.manual_seed(3)
+    nm = NeuralPoints(cfg)
+    nm.local_map_radius = 14.0   # so that old points leave the local window as the sensor moves
+    dec = Decoder(cfg, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, 1)
+    mp = Mapper(cfg, DS(), nm, None, dec)
+    gen = torch.Generator().manual_seed(8)
+    travel = [0.0]
+    pool = {k: torch.empty((0, 3) if k == "coord" else (0,)) for k in ("coord", "sdf_label", "weight")}
+    pool_time = torch.empty((0,), dtype=torch.int32)
+    sizes = []
+    for fid in range(5):
+        sensor = (-8.0 + 4.0 * fid, 1.0 * fid, 1.5)
+        if fid:
+            travel.append(travel[-1] + (200.0 if fid == 3 else 4.1))  # frame 3 jumps past the 310 m window later
+        nm.travel_dist = torch.tensor(travel + [travel[-1]] * 3, device=dev)  # re-assigned every frame (slam.py:159-162)
+        d = box_room_pool(cfg, n_elev=24, n_azim=192, seed=100 + fid, sensor=sensor)
+        near = d["sdf_label"].abs() < cfg.surface_sample_range_m * 0.5
+        nm.update(d["coord"][near].to(dev), d["sensor"].to(dev), torch.eye(3, device=dev), fid)
+        n_old = pool["coord"].shape[0]
+        for k in pool:
+            pool[k] = torch.cat((pool[k], d[k]))
+        pool_time = torch.cat((pool_time, torch.full((d["coord"].shape[0],), fid, dtype=torch.int32)))
+        new_idx = n_old + torch.randperm(d["coord"].shape[0], generator=gen)[:3000]
+        mp.set_pool(pool["coord"], pool["sdf_label"], pool["weight"], pool_time, new_idx)
+        iters = 2
+        idx = mp._draw_index(iters, cfg.bs)
+        # oracle on a snapshot of the state
+        st = _oracle_state(nm, cfg)
+        od = O.DecoderParams(*[p.detach().cpu().clone() for p in dec.flat_params()], sdf_scale=dec.sdf_scale)
+        opool = O.SamplePool(pool["coord"].clone(), pool["sdf_label"].clone(), pool_time.clone(), pool["weight"].clone())
+        recs = O.mapping_iters(st, od, opool, idx.cpu(), O.LoopConfig(sigma=mp.sdf_scale), record=True)
+        mp.mapping(iters, index_seq=idx)
+        got = mp.last_losses.cpu()
+        for it, r in enumerate(recs):
+            assert abs(float(got[it, 0]) - float(r["loss"])) <= 2e-5, (fid, it, got[it], r["loss"])
+        assert float((nm.local_geo_features.detach().cpu() - recs[-1]["theta"]).abs().max()) <= 1e-4, fid
+        for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
+            assert float((t.detach().cpu() - o).abs().max()) <= 1e-4
+        assert float((nm.local_point_certainties.cpu() - recs[-1]["certainties"]).abs().max()) <= 2e-3
+        assert torch.equal(nm.local_point_ts_update.cpu(), recs[-1]["ts_update"])
+        sizes.append((nm.count(), nm.local_count()))
+    # the scenario really moved the window and grew the map
+    assert sizes[-1][0] > sizes[0][0] and any(l < g for g, l in sizes[1:])
