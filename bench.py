@@ -168,14 +168,23 @@ def main():
         _lib.check(lib.clid_profile_read(out, C.byref(n), _lib.stream()), "clid_profile_read")
         lib.clid_profile_enable(0)
         ov = out[4]
-        names = ("k_train_fused8", "-", "k_reduce_partials", "k_adam_all")
+        pipelined = out[1] > 0.0  # the loop ran as search(t+1) || decode(t) + Adam(t)  (clid_mapping_run)
+        names = ("k_train_fused8<2> (decode)" if pipelined else "k_train_fused8", "k_train_fused8<1> (search)",
+                 "k_reduce_partials", "k_adam_all")
         ms = [max(out[i] / max(n.value, 1) - ov, 0.0) for i in range(4)]
         decim = cfg.gradient_decimation
         Q = args.bs + 6 * ((args.bs + decim - 1) // decim)
-        # algorithmic bytes per launch: fused fwd+bwd kernel = Q query points x
-        # (1004 + 436) B + the 24 B pool gather per batch sample; Adam = 256 B per feature row + decoder
-        alg = [Q * (BYTES_FWD_PER_QUERY + BYTES_BWD_PER_QUERY) + args.bs * BYTES_POOL_GATHER, 0.0, 0.0,
-               BYTES_ADAM_PER_ROW * (M + 1) + 833 * 28.0]
+        # algorithmic bytes per launch: search = 688 B per query point (position, 81 bucket
+        # probes, the valid probes' positions) + the 24 B pool gather per batch sample; decode fwd+bwd = 316 +
+        # 436 B per query point; when the two run as separate kernels the 96 B/query record of winners is
+        # written by one and read by the other.  Adam = 256 B per feature row + decoder
+        search_b = Q * 688.0 + args.bs * BYTES_POOL_GATHER
+        decode_b = Q * (BYTES_FWD_PER_QUERY - 688.0 + BYTES_BWD_PER_QUERY)
+        adam_b = BYTES_ADAM_PER_ROW * (M + 1) + 833 * 28.0
+        if pipelined:
+            alg = [decode_b + Q * 96.0, search_b + Q * 96.0, 0.0, adam_b]
+        else:
+            alg = [search_b + decode_b, 0.0, 0.0, adam_b]
         dom = max(range(4), key=lambda i: ms[i])
         achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9
         traffic = None  # HBM bytes per launch from the committed PMC passes (same workload only)
@@ -189,7 +198,8 @@ def main():
             "bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg[dom], "avg_launch_us": ms[dom] * 1e3,
-            "per_kernel_us": {nme: round(m * 1e3, 2) for nme, m in zip(names, ms) if nme != "-"},
+            "per_kernel_us": {nme: round(m * 1e3, 2) for nme, m in zip(names, ms) if m > 0.0},
+            "pipelined": pipelined,
             "event_pair_overhead_us": round(ov * 1e3, 2),
             "step_bytes": sum(alg), "step_frac_of_peak": sum(alg) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
             "note": "hipEvent-bracketed launches on the launch stream in a separate pass of the same loop, minus the "

@@ -75,6 +75,10 @@ _SIGS = {
     "clid_train_adam": (C.c_int, [C.POINTER(AdamArgs), C.POINTER(TrainArgs), _vp]),
     "clid_mapping_run": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), C.POINTER(AdamArgs), _i32, _vp, _i64, _vp, _vp]),
     "clid_debug_task_cover": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "clid_mapping_pipeline": (C.c_int, [C.c_int]),
+    "clid_train_search_floats": (_i64, [_i32, _i64, _i32, _i32, _i32]),
+    "clid_train_search": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), _i32, _vp, _i64, _vp, _vp]),
+    "clid_train_decode": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), _vp, _vp]),
     "clid_profile_enable": (C.c_int, [C.c_int]),
     "clid_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int), _vp]),
 }

@@ -116,10 +116,12 @@ __device__ __forceinline__ int group8_sum_i(int v) {
   return v;
 }
 
-struct WaveLds {
+struct WaveHead {       // what the search phase produces (one record of kRecFloat4 float4 per task)
   float4 qinfo[8];      // per query slot: x, y, z, pool sample index (int bits, -1 = padding)
   float4 qdesc[8];      // per query slot: batch position (int bits, -1 = padding), axis (int bits), sign, -
   float2 win[8][8];     // per slot: up to K winners (d2, local id bits), ascending; (9e3, -1) = none
+};
+struct WaveLds : WaveHead {
   float4 st[2][64][2];  // per decode round, per lane: {f[lane16], w_k, j_k bits, sdf}, {pre[0..3]}
   float cacc[CLID_K][CLID_F];  // bundle tasks: gradient rows of the decimated sample's neighbours, summed in-wave
   float ccert[8];              // ... and their certainty increments
@@ -201,19 +203,36 @@ __device__ __forceinline__ void search8(const clid_map_view& mv, const DeltaLds&
 }
 
 constexpr int kFusedBlock = 512;  // 8 waves share one partial row: half as many rows for k_adam_all to reduce
+// MODE 0: search + decode in one launch.  MODE 1 / 2: the same two phases as separate kernels with the
+// searches' winners (kRecFloat4 float4 per task: qinfo | qdesc | win, the head of WaveLds) parked in HBM, so
+// the host can run search(t+1) on a second stream underneath decode(t) + Adam(t): the search does not read
+// anything training writes (positions only), and both phases are latency- not throughput-bound.
+constexpr int kRecFloat4 = 48;
+template <int MODE>
 __global__ void __launch_bounds__(kFusedBlock, CLID_FUSED_WAVES)
-k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap) {
+k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap,
+               float4* __restrict__ rec, int n_iter, long long index_stride) {
   __shared__ MlpLds mlp;
   __shared__ DeltaLds dl;
-  __shared__ WaveLds wlds[kFusedBlock / 64];
+  __shared__ WaveLds wlds[MODE == 1 ? 1 : kFusedBlock / 64];
+  __shared__ WaveHead heads[MODE == 1 ? kFusedBlock / 64 : 1];  // the search-only kernel keeps just the record
   __shared__ float red[(kFusedBlock / 64) * kRedFloats];
-  stage_mlp_and_delta(mlp, dl, mv, ta.W1, ta.b1, ta.W2, ta.b2);
+  static_assert(sizeof(WaveHead) == kRecFloat4 * sizeof(float4), "record layout");
+  if constexpr (MODE == 1) {
+    stage_delta(dl, mv);
+    __syncthreads();
+  } else if constexpr (MODE == 2) {
+    stage_mlp(mlp, ta.W1, ta.b1, ta.W2, ta.b2);
+  } else {
+    stage_mlp_and_delta(mlp, dl, mv, ta.W1, ta.b1, ta.W2, ta.b2);
+  }
   const int lane = threadIdx.x & 63, lane16 = lane & 15, grp = lane >> 4;
   const int lane8 = lane & 7, slot8 = lane >> 3;
   const int wave = threadIdx.x >> 6, waves_per_block = kFusedBlock / 64;
   const int my_k = lane16 >> 1;
   const bool odd = lane16 & 1;
-  WaveLds& wl = wlds[wave];
+  WaveLds& wl = wlds[MODE == 1 ? 0 : wave];
+  WaveHead& hd = MODE == 1 ? heads[wave] : static_cast<WaveHead&>(wl);
   MlpAcc acc;
   acc.zero();
   float bce_acc = 0.f, eik_acc = 0.f;
@@ -223,28 +242,45 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
   const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
   const float sc = ta.sdf_scale;
 
-  for (int task = blockIdx.x * waves_per_block + wave; task < tmap.n_tasks; task += gridDim.x * waves_per_block) {
+  // MODE 1 searches n_iter iterations' batches in one launch (iteration `it` draws from ta.index + it*index_stride)
+  const int total = MODE == 1 ? tmap.n_tasks * n_iter : tmap.n_tasks;
+  for (int gtask = blockIdx.x * waves_per_block + wave; gtask < total; gtask += gridDim.x * waves_per_block) {
+    int task = gtask;
+    const long long* index = reinterpret_cast<const long long*>(ta.index);
+    if constexpr (MODE == 1) {
+      const int it = gtask / tmap.n_tasks;
+      task = gtask - it * tmap.n_tasks;
+      index += (long long)it * index_stride;
+    }
     const bool bundle = task < tmap.n_fd;
     CLID_STAMP(0);
     // ================= search: 8 slots x 8 lanes
-    {
+    if constexpr (MODE == 2) {
+      if (lane < kRecFloat4) reinterpret_cast<float4*>(&hd)[lane] = rec[(size_t)task * kRecFloat4 + lane];
+    } else {
       const QDesc qd = task_query(tmap, task, slot8 >> 2, slot8 & 3);
       const bool live = qd.p >= 0;
-      const long long s = ta.index[live ? qd.p : 0];
+      const long long s = index[live ? qd.p : 0];
       float px = ta.pool_coord[s * 3 + 0], py = ta.pool_coord[s * 3 + 1], pz = ta.pool_coord[s * 3 + 2];
       if (qd.axis == 0) px = fadd(px, qd.sign * ta.fd_eps);  // x + [eps,0,0] in fp32 (mapper.py:988-999)
       if (qd.axis == 1) py = fadd(py, qd.sign * ta.fd_eps);
       if (qd.axis == 2) pz = fadd(pz, qd.sign * ta.fd_eps);
       if (lane8 == 0) {
-        wl.qinfo[slot8] = make_float4(px, py, pz, __int_as_float(live ? (int)s : -1));
-        wl.qdesc[slot8] = make_float4(__int_as_float(qd.p), __int_as_float(qd.axis), qd.sign, 0.f);
+        hd.qinfo[slot8] = make_float4(px, py, pz, __int_as_float(live ? (int)s : -1));
+        hd.qdesc[slot8] = make_float4(__int_as_float(qd.p), __int_as_float(qd.axis), qd.sign, 0.f);
       }
-      if (lane8 < CLID_K) wl.win[slot8][lane8] = make_float2(9e3f, __int_as_float(-1));  // np.py:606
+      if (lane8 < CLID_K) hd.win[slot8][lane8] = make_float2(9e3f, __int_as_float(-1));  // np.py:606
       asm volatile("" ::"v"(px), "v"(py), "v"(pz));
       CLID_STAMP(1);
-      search8(mv, dl, px, py, pz, lane8, lane & 56, wl.win[slot8]);
+      search8(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
     }
     CLID_STAMP(3);
+    if constexpr (MODE == 1) {
+      wave_lds_fence();
+      if (lane < kRecFloat4) rec[(size_t)gtask * kRecFloat4 + lane] = reinterpret_cast<const float4*>(&hd)[lane];
+      wave_lds_fence();
+      continue;
+    }
     if (bundle) {
       if (lane < CLID_K * CLID_F) (&wl.cacc[0][0])[lane] = 0.f;
       if (lane < 8) wl.ccert[lane] = 0.f;
@@ -458,7 +494,7 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
     CLID_STAMP(10);
   }
   CLID_STAMP(24);
-  flush_mlp_acc(acc, bce_acc, eik_acc, red, partial + (size_t)blockIdx.x * kPartialStride);
+  if constexpr (MODE != 1) flush_mlp_acc(acc, bce_acc, eik_acc, red, partial + (size_t)blockIdx.x * kPartialStride);
   CLID_STAMP(25);
 }
 
@@ -615,16 +651,27 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
 using namespace clid;
 
 // ---- optional per-kernel timing (bench.py roofline leg): hipEvents on the launch stream ------------
+#include <cstdlib>
 #include <vector>
 namespace {
 bool g_prof = false;
-std::vector<hipEvent_t> g_ev;  // groups of 6: before fwd, after fwd, after bwd, after reduce, before adam, after adam
-hipEvent_t prof_mark(hipStream_t s) {
-  hipEvent_t e;
-  hipEventCreate(&e);
-  hipEventRecord(e, s);
-  g_ev.push_back(e);
-  return e;
+struct ProfSpan {
+  int tag;  // 0 fused / decode kernel, 1 search kernel (pipelined loop), 2 partial reduce, 3 adam
+  hipEvent_t a, b;
+};
+std::vector<ProfSpan> g_spans;
+int prof_begin(int tag, hipStream_t s) {
+  if (!g_prof) return -1;
+  ProfSpan sp;
+  sp.tag = tag;
+  hipEventCreate(&sp.a);
+  hipEventCreate(&sp.b);
+  hipEventRecord(sp.a, s);
+  g_spans.push_back(sp);
+  return (int)g_spans.size() - 1;
+}
+void prof_end(int h, hipStream_t s) {
+  if (h >= 0) hipEventRecord(g_spans[h].b, s);
 }
 }  // namespace
 
@@ -635,28 +682,30 @@ extern "C" int clid_debug_read_stamps(long long* out_host) {
 #endif
 
 extern "C" int clid_profile_enable(int on) {
-  for (hipEvent_t e : g_ev) hipEventDestroy(e);
-  g_ev.clear();
+  for (ProfSpan& sp : g_spans) {
+    hipEventDestroy(sp.a);
+    hipEventDestroy(sp.b);
+  }
+  g_spans.clear();
   g_prof = on != 0;
   return CLID_OK;
 }
 
-// sums of elapsed ms per kernel over all recorded iterations: out[0..3] = fwd, bwd, reduce, adam;
-// out[4] = back-to-back event-pair overhead (ms, mean) measured now; *iters = iterations recorded
+// sums of elapsed ms per kernel over all recorded iterations: out[0] = fused (or decode) kernel, out[1] =
+// search kernel of the pipelined loop, out[2] = partial reduce, out[3] = adam; out[4] = back-to-back
+// event-pair overhead (ms, mean) measured now; *iters = iterations recorded
 extern "C" int clid_profile_read(double* out, int* iters, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (hipStreamSynchronize(s) != hipSuccess) return CLID_E_HIP;
+  if (hipDeviceSynchronize() != hipSuccess) return CLID_E_HIP;
   for (int i = 0; i < 5; ++i) out[i] = 0.0;
-  const size_t n = g_ev.size() / 6;
-  for (size_t i = 0; i < n; ++i) {
-    float ms;
-    const hipEvent_t* e = &g_ev[i * 6];
-    hipEventElapsedTime(&ms, e[0], e[1]); out[0] += ms;
-    hipEventElapsedTime(&ms, e[1], e[2]); out[1] += ms;
-    hipEventElapsedTime(&ms, e[2], e[3]); out[2] += ms;
-    hipEventElapsedTime(&ms, e[4], e[5]); out[3] += ms;
+  int n = 0;
+  for (const ProfSpan& sp : g_spans) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) continue;
+    out[sp.tag] += ms;
+    n += sp.tag == 0;
   }
-  *iters = (int)n;
+  *iters = n;
   // marginal cost of an (event, event) bracket in a BUSY stream: 64 consecutive records, one sync
   {
     hipEvent_t ev[64];
@@ -681,6 +730,8 @@ static int n_queries(const clid_train_args* a, int* n_fd, int* first) {
   return a->bs + 6 * (*n_fd);
 }
 
+constexpr int kSearchBlocks = 2048;  // grid of the hoisted search launch (grid-stride over chunk x tasks)
+
 static int fused_blocks(int n_tasks, int block = kFusedBlock) {
   int nb = (n_tasks + block / 64 - 1) / (block / 64);
   return nb > kMaxBwdBlocks ? kMaxBwdBlocks : (nb < 1 ? 1 : nb);
@@ -690,7 +741,7 @@ extern "C" int64_t clid_train_workspace_floats(int32_t bs, int32_t decimation, i
   if (bs <= 0 || decimation <= 0) return -1;
   const long long nfd = eikonal_mode == 1 ? (bs + decimation - 1) / decimation : 0;
   const long long Q = bs + 6 * nfd;
-  return (Q + 4) + (Q * 12 + 4) + 2 * (Q * CLID_K + 4) + (long long)kMaxBwdBlocks * kPartialStride + 64;
+  return (long long)kMaxBwdBlocks * kPartialStride + (long long)rec_buffer_floats((int)Q) + 64;
 }
 
 extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args* a, void* stream) {
@@ -712,22 +763,23 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
   TrainWs ws = carve(a->ws, Q);
   const TaskMap tmap = make_task_map(a->bs, n_fd, first, a->decimation);
   const int nb = a->eikonal_mode == 2 ? clid_train_analytic_blocks(a->bs) : fused_blocks(tmap.n_tasks);
-  if (g_prof) prof_mark(s);
+  int h = prof_begin(0, s);
   if (a->eikonal_mode == 2) {  // loss.numerical_grad_on: False (utils/mapper.py:57-69, 660-661, 695-696)
     if (int e = clid_launch_train_analytic(mv, a, ws.partial, s)) return e;
   } else {
-    hipLaunchKernelGGL(k_train_fused8, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap);
+    hipLaunchKernelGGL(k_train_fused8<0>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap,
+                       (float4*)nullptr, 1, 0LL);
     CLID_CHECK_LAUNCH();
   }
-  if (g_prof) prof_mark(s);
-  if (g_prof) prof_mark(s);
+  prof_end(h, s);
   if (!a->defer_reduce) {
+    h = prof_begin(2, s);
     hipLaunchKernelGGL(k_reduce_partials, dim3((CLID_MLP_PARAMS + 2 + 15) / 16), dim3(256), 0, s, ws.partial,
                        nb, a->grad, a->loss_out, a->inv_n_main, a->inv_n_eik,
                        (a->eikonal_mode == 2 || (a->eikonal_mode == 1 && n_fd > 0)) ? a->weight_e : 0.f, a->train_decoder);
     CLID_CHECK_LAUNCH();
+    prof_end(h, s);
   }
-  if (g_prof) prof_mark(s);
   return CLID_OK;
 }
 
@@ -790,15 +842,151 @@ extern "C" int clid_train_adam(const clid_adam_args* a, const clid_train_args* t
   L.train_decoder = a->train_decoder;
   L.n_feat_blocks = (int)(((a->n_feat + 3) / 4 + 255) / 256);
   L.k = adam_scalars(a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->step);
-  if (g_prof) prof_mark(s);
+  const int h = prof_begin(3, s);
   hipLaunchKernelGGL(k_adam_all, dim3(L.n_feat_blocks + (CLID_MLP_PARAMS + 2 + 15) / 16), dim3(256), 0, s, L);
   CLID_CHECK_LAUNCH();
-  if (g_prof) prof_mark(s);
+  prof_end(h, s);
+  return CLID_OK;
+}
+
+// ---- the hoisted-search loop ----------------------------------------------------------------------------
+// Within one Mapper.mapping call the map's positions, the voxel table and the drawn sample indices are all
+// fixed (training moves features and decoder weights only), so the neighbour searches of ALL iterations are
+// independent of the training state.  They are hoisted out of the dependent chain: one large search launch
+// per chunk of iterations (a grid that fills the chip and runs at the memory system's gather rate, unlike a
+// single iteration's 3.3 k latency-bound waves) parks the winners in HBM, then the chunk's decode/backward +
+// Adam launches run back to back.
+namespace {
+int g_pipeline = -1;  // -1: read CLID_PIPELINE on first use; 0 fused per-iteration kernel, 1 hoisted searches
+}
+
+extern "C" int clid_mapping_pipeline(int mode) {
+  const int prev = g_pipeline;
+  g_pipeline = mode < 0 ? -1 : (mode != 0);
+  return prev;
+}
+
+static int pipeline_mode() {
+  if (g_pipeline < 0) {
+    const char* e = getenv("CLID_PIPELINE");
+    g_pipeline = (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : 1;
+  }
+  return g_pipeline;
+}
+
+static int check_train_args(const clid_map_view* mv, const clid_train_args* a, const char* who) {
+  if (!mv || !a || !mv->tab || !mv->tab_pos || !mv->delta) {
+    clid_set_error("%s: null argument", who);
+    return CLID_E_ARG;
+  }
+  if (mv->P > kMaxProbes) {
+    clid_set_error("%s: neighbourhood of %d cells exceeds the supported %d", who, mv->P, kMaxProbes);
+    return CLID_E_SHAPE;
+  }
+  if (a->bs <= 0 || a->decimation <= 0 || a->eikonal_mode == 2) {
+    clid_set_error("%s: bs=%d decimation=%d eikonal_mode=%d", who, a->bs, a->decimation, a->eikonal_mode);
+    return CLID_E_ARG;
+  }
+  return CLID_OK;
+}
+
+extern "C" int64_t clid_train_search_floats(int32_t bs, int64_t batch_offset, int32_t decimation,
+                                            int32_t eikonal_mode, int32_t n_iter) {
+  if (bs <= 0 || decimation <= 0 || n_iter < 0 || eikonal_mode == 2) return -1;
+  const int first = fd_first(batch_offset, decimation);
+  const int n_fd = eikonal_mode == 1 ? fd_count(bs, batch_offset, decimation) : 0;
+  return (int64_t)make_task_map(bs, n_fd, first, decimation).n_tasks * kRecFloatsPerTask * n_iter;
+}
+
+extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args* a, int32_t n_iter,
+                                 const int64_t* index_base, int64_t index_stride, float* rec_out, void* stream) {
+  if (int e = check_train_args(mv, a, "clid_train_search")) return e;
+  if (n_iter <= 0 || !index_base || !rec_out || !a->pool_coord) {
+    clid_set_error("clid_train_search: bad argument");
+    return CLID_E_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int n_fd, first;
+  n_queries(a, &n_fd, &first);
+  const TaskMap tmap = make_task_map(a->bs, n_fd, first, a->decimation);
+  if ((long long)tmap.n_tasks * n_iter > 0x7fffffffLL) {
+    clid_set_error("clid_train_search: %d tasks x %d iterations overflow", tmap.n_tasks, n_iter);
+    return CLID_E_SHAPE;
+  }
+  clid_train_args t2 = *a;
+  t2.index = index_base;
+  long long sb = ((long long)tmap.n_tasks * n_iter + kFusedBlock / 64 - 1) / (kFusedBlock / 64);
+  if (sb > kSearchBlocks) sb = kSearchBlocks;
+  const int h = prof_begin(1, s);
+  hipLaunchKernelGGL(k_train_fused8<1>, dim3((unsigned)sb), dim3(kFusedBlock), 0, s, *mv, t2, (float*)nullptr, tmap,
+                     reinterpret_cast<float4*>(rec_out), n_iter, (long long)index_stride);
+  CLID_CHECK_LAUNCH();
+  prof_end(h, s);
+  return CLID_OK;
+}
+
+extern "C" int clid_train_decode(const clid_map_view* mv, const clid_train_args* a, const float* rec,
+                                 void* stream) {
+  if (int e = check_train_args(mv, a, "clid_train_decode")) return e;
+  if (!mv->feat || !mv->cert || !a->grad || !a->ws || !a->loss_out || !rec) {
+    clid_set_error("clid_train_decode: null argument");
+    return CLID_E_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int n_fd, first;
+  const int Q = n_queries(a, &n_fd, &first);
+  TrainWs ws = carve(a->ws, Q);
+  const TaskMap tmap = make_task_map(a->bs, n_fd, first, a->decimation);
+  const int nb = fused_blocks(tmap.n_tasks);
+  int h = prof_begin(0, s);
+  hipLaunchKernelGGL(k_train_fused8<2>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap,
+                     reinterpret_cast<float4*>(const_cast<float*>(rec)), 1, 0LL);
+  CLID_CHECK_LAUNCH();
+  prof_end(h, s);
+  if (!a->defer_reduce) {
+    h = prof_begin(2, s);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((CLID_MLP_PARAMS + 2 + 15) / 16), dim3(256), 0, s, ws.partial,
+                       nb, a->grad, a->loss_out, a->inv_n_main, a->inv_n_eik,
+                       (a->eikonal_mode == 1 && n_fd > 0) ? a->weight_e : 0.f, a->train_decoder);
+    CLID_CHECK_LAUNCH();
+    prof_end(h, s);
+  }
+  return CLID_OK;
+}
+
+static int mapping_run_hoisted(const clid_map_view* mv, clid_train_args& ta, clid_adam_args& aa, int iters,
+                               const int64_t* index_base, int64_t index_stride, float* loss_base, void* stream) {
+  int n_fd, first;
+  const int Q = n_queries(&ta, &n_fd, &first);
+  TrainWs ws = carve(ta.ws, Q);
+  const size_t per_iter = (size_t)clid_train_search_floats(ta.bs, ta.batch_offset, ta.decimation, ta.eikonal_mode, 1);
+  long long chunk = (long long)(rec_buffer_floats(Q) / per_iter);
+  if (chunk < 1) {
+    clid_set_error("clid_mapping_run: the task records exceed the workspace bound");
+    return CLID_E_SHAPE;
+  }
+  if (chunk > kMaxChunkIters) chunk = kMaxChunkIters;
+  for (int it0 = 0; it0 < iters; it0 += (int)chunk) {
+    const int n_it = (iters - it0) < chunk ? (iters - it0) : (int)chunk;
+    if (int e = clid_train_search(mv, &ta, n_it, index_base + (int64_t)it0 * index_stride, index_stride, ws.rec,
+                                  stream))
+      return e;
+    for (int it = it0; it < it0 + n_it; ++it) {
+      ta.index = index_base + (int64_t)it * index_stride;
+      ta.loss_out = loss_base + (size_t)it * 4;
+      if (int e = clid_train_decode(mv, &ta, ws.rec + (size_t)(it - it0) * per_iter, stream)) return e;
+      aa.step = it + 1;
+      if (int e = clid_train_adam(&aa, &ta, stream)) return e;
+    }
+  }
   return CLID_OK;
 }
 
 // The whole single-GPU loop of Mapper.mapping (utils/mapper.py:642-860) enqueued by ONE host call:
-// per iteration the fused forward/backward kernel and the reduce+Adam kernel, back to back on `stream`.
+// mode 1 (default) = the neighbour searches hoisted into one launch per chunk of iterations, then per
+// iteration the decode/backward kernel and the reduce+Adam kernel; mode 0 = per iteration the fused
+// search+decode kernel and the reduce+Adam kernel (CLID_PIPELINE / clid_mapping_pipeline select; the results
+// are identical up to the order of the atomic accumulations).
 extern "C" int clid_mapping_run(const clid_map_view* mv, const clid_train_args* t, const clid_adam_args* a,
                                 int32_t iters, const int64_t* index_base, int64_t index_stride,
                                 float* loss_base, void* stream) {
@@ -809,6 +997,8 @@ extern "C" int clid_mapping_run(const clid_map_view* mv, const clid_train_args* 
   clid_train_args ta = *t;
   clid_adam_args aa = *a;
   ta.defer_reduce = 1;
+  if (ta.eikonal_mode != 2 && pipeline_mode() == 1 && iters > 0)
+    return mapping_run_hoisted(mv, ta, aa, iters, index_base, index_stride, loss_base, stream);
   for (int it = 0; it < iters; ++it) {
     ta.index = index_base + (int64_t)it * index_stride;
     ta.loss_out = loss_base + (size_t)it * 4;

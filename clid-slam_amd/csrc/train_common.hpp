@@ -9,13 +9,26 @@ namespace clid {
 constexpr int kPartialStride = 840;  // 833 decoder grads | bce sum | eik sum | pad
 constexpr int kMaxBwdBlocks = 1024;
 
+constexpr int kRecFloatsPerTask = 192;  // qinfo[8] | qdesc[8] | win[8][8]: what the search phase hands the decode phase
+
 struct TrainWs {
-  float* sdf;      // [Q]
-  float* fvec;     // [Q][12]
-  float* w;        // [Q][K]
-  int* idx;        // [Q][K]
   float* partial;  // [kMaxBwdBlocks][kPartialStride]
+  float* rec;      // [chunk iterations][tasks][kRecFloatsPerTask]: the hoisted searches of clid_mapping_run
 };
+
+// upper bound on wave tasks for Q queries (bundles carry 7-8 queries, plain tasks up to 8; the sparsest case is
+// decimation 3: one bundle + one single-sample task per 3 samples = 2Q/9 tasks)
+__host__ inline size_t max_tasks(int Q) { return (size_t)Q / 4 + 16; }
+// one record buffer holds the searches of a chunk of iterations: 16 iterations at the task bound (typically
+// ~32 at the actual task count), capped at 1 GiB for very large batches, never less than one iteration
+constexpr int kMaxChunkIters = 32;
+__host__ inline size_t rec_buffer_floats(int Q) {
+  const size_t one = max_tasks(Q) * kRecFloatsPerTask;
+  size_t it = (size_t(1) << 28) / one;
+  if (it > 16) it = 16;
+  if (it < 1) it = 1;
+  return one * it;
+}
 
 __host__ __device__ inline int fd_first(long long batch_offset, int decim) {
   const int r = (int)(batch_offset % decim);
@@ -34,11 +47,8 @@ __host__ inline TrainWs carve(float* ws, int Q) {
     o += (n + 3) & ~size_t(3);
     return p;
   };
-  t.sdf = take(Q);
-  t.fvec = take((size_t)Q * 12);
-  t.w = take((size_t)Q * CLID_K);
-  t.idx = reinterpret_cast<int*>(take((size_t)Q * CLID_K));
   t.partial = take((size_t)kMaxBwdBlocks * kPartialStride);
+  t.rec = take(rec_buffer_floats(Q));
   return t;
 }
 

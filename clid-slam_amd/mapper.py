@@ -205,15 +205,32 @@ class Mapper:
         idx_base, row_bytes = index_seq.data_ptr(), bs_global * 8
         loss_base = losses.data_ptr()
         if not dist:
-            # single GPU: the whole loop is enqueued by one C call (2 kernel launches per iteration)
+            # single GPU: the whole loop is enqueued by one C call (hoisted searches + 2 launches per iteration)
             ta.index, ta.loss_out = idx_base, loss_base
             _lib.check(lib.clid_mapping_run(C.byref(view), C.byref(ta), C.byref(aa), iter_count, idx_base, bs_global,
                                             loss_base, stream), "clid_mapping_run")
         else:
+            # the neighbour searches do not depend on the training state: one launch per chunk of iterations
+            # resolves this rank's shard of every batch, then decode/backward -> all-reduce -> Adam per iteration
+            hoist = eik_mode != 2 and os.environ.get("CLID_PIPELINE", "1") != "0"
+            chunk = min(iter_count, 32)
+            if hoist:
+                per_iter = int(lib.clid_train_search_floats(bs_local, batch_offset, decim, eik_mode, 1))
+                if getattr(self, "_rec", None) is None or self._rec.numel() < per_iter * chunk or self._rec.device != dev:
+                    self._rec = torch.empty(per_iter * chunk, device=dev, dtype=torch.float32)
             for it in range(iter_count):
                 ta.index = idx_base + it * row_bytes + batch_offset * 8
                 ta.loss_out = loss_base + it * 16
-                _lib.check(lib.clid_train_fwd_bwd(C.byref(view), C.byref(ta), stream), "clid_train_fwd_bwd")
+                if hoist:
+                    if it % chunk == 0:
+                        _lib.check(lib.clid_train_search(C.byref(view), C.byref(ta), min(chunk, iter_count - it),
+                                                         ta.index, bs_global, self._rec.data_ptr(), stream),
+                                   "clid_train_search")
+                    _lib.check(lib.clid_train_decode(C.byref(view), C.byref(ta),
+                                                     self._rec.data_ptr() + (it % chunk) * per_iter * 4, stream),
+                               "clid_train_decode")
+                else:
+                    _lib.check(lib.clid_train_fwd_bwd(C.byref(view), C.byref(ta), stream), "clid_train_fwd_bwd")
                 dist.all_reduce(grad)
                 aa.step = it + 1
                 _lib.check(lib.clid_train_adam(C.byref(aa), C.byref(ta), stream), "clid_train_adam")

@@ -205,10 +205,29 @@ int clid_mapping_run(const clid_map_view* mv, const clid_train_args* t, const cl
                      int32_t iters, const int64_t* index_base, int64_t index_stride, float* loss_base,
                      void* stream);
 
+/* The two halves of clid_train_fwd_bwd as separate calls (numerical-eikonal / no-eikonal modes).  Within one
+ * Mapper.mapping call the positions, the voxel table and the drawn indices are fixed, so the neighbour searches
+ * of all iterations do not depend on the training state: clid_train_search resolves n_iter iterations' batches
+ * in ONE launch (iteration i draws from index_base + i*index_stride, int64 elements; t->index is ignored) and
+ * parks each iteration's winners in rec_out (clid_train_search_floats(.., 1) floats per iteration);
+ * clid_train_decode is clid_train_fwd_bwd for one iteration starting from its records. */
+int64_t clid_train_search_floats(int32_t bs, int64_t batch_offset, int32_t decimation, int32_t eikonal_mode,
+                                 int32_t n_iter);
+int clid_train_search(const clid_map_view* mv, const clid_train_args* t, int32_t n_iter,
+                      const int64_t* index_base, int64_t index_stride, float* rec_out, void* stream);
+int clid_train_decode(const clid_map_view* mv, const clid_train_args* t, const float* rec, void* stream);
+
+/* How clid_mapping_run schedules the loop (numerical-eikonal / no-eikonal modes):
+ *   1  (default) clid_train_search over a chunk of iterations, then per iteration clid_train_decode + Adam;
+ *   0  per iteration the fused search+decode kernel of clid_train_fwd_bwd + Adam.
+ * mode < 0 re-reads the environment variable CLID_PIPELINE; returns the previous setting. */
+int clid_mapping_pipeline(int mode);
+
 /* ---- measurement aid (bench.py roofline leg; not part of the reference's interface) -----------
  * When enabled, clid_train_fwd_bwd / clid_train_adam bracket each kernel with hipEvents on the
  * launch stream.  clid_profile_read synchronises and returns summed elapsed ms per kernel:
- * out[0..3] = forward, backward, partial-reduce, adam; out[4] = empty event-pair overhead (ms). */
+ * out[0] = fused (or decode) kernel, out[1] = search kernel of the pipelined loop, out[2] = partial reduce,
+ * out[3] = adam; out[4] = empty event-pair overhead (ms). */
 int clid_profile_enable(int on);
 int clid_profile_read(double* out_host, int* iters_host, void* stream);
 

@@ -221,8 +221,9 @@ def test_mapping_loop_g6(env, mode, frozen, ln):
     assert np.array_equal(nm.point_ts_update.cpu().numpy(), g["final_point_ts_update"])
 
 
-def _fused_grads(env, cfg, p, g, index, batch_offset=0, n_main=None, n_eik=None, frozen=False):
-    """Run clid_train_fwd_bwd once (no Adam) and return (grad buffer, loss[4], certainties, ts)."""
+def _fused_grads(env, cfg, p, g, index, batch_offset=0, n_main=None, n_eik=None, frozen=False, split=False):
+    """Run clid_train_fwd_bwd (or, split=True, clid_train_search + clid_train_decode) once (no Adam) and
+    return (grad buffer, loss[4], certainties, ts)."""
     import ctypes as C
     from clid_slam_amd import _lib
 
@@ -250,9 +251,44 @@ def _fused_grads(env, cfg, p, g, index, batch_offset=0, n_main=None, n_eik=None,
     ta.W1, ta.b1, ta.W2, ta.b2 = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr()
     ta.sdf_scale, ta.defer_reduce = float(dec.sdf_scale), 0
     ta.grad, ta.ws, ta.loss_out = grad.data_ptr(), ws.data_ptr(), loss.data_ptr()
-    _lib.check(lib.clid_train_fwd_bwd(C.byref(view), C.byref(ta), _lib.stream()), "clid_train_fwd_bwd")
+    if split:
+        rec = torch.empty(int(lib.clid_train_search_floats(bs, batch_offset, decim, 1, 1)), device="cuda")
+        _lib.check(lib.clid_train_search(C.byref(view), C.byref(ta), 1, idx.data_ptr(), bs, rec.data_ptr(),
+                                         _lib.stream()), "clid_train_search")
+        _lib.check(lib.clid_train_decode(C.byref(view), C.byref(ta), rec.data_ptr(), _lib.stream()), "clid_train_decode")
+    else:
+        _lib.check(lib.clid_train_fwd_bwd(C.byref(view), C.byref(ta), _lib.stream()), "clid_train_fwd_bwd")
     torch.cuda.synchronize()
     return grad.cpu(), loss.cpu(), nm.local_point_certainties.cpu(), nm.local_point_ts_update.cpu()
+
+
+@pytest.mark.parametrize("batch_offset", [0, 7])
+def test_search_plus_decode_equals_the_fused_kernel(env, batch_offset):
+    """clid_train_search + clid_train_decode (the hoisted-search form clid_mapping_run uses by default) and the
+    single fused kernel of clid_train_fwd_bwd are the same computation: identical up to the order of the
+    atomic accumulations."""
+    g = gio.load("g6_loop_numerical_train_ln0.npz")
+    p = gio.load("pool.npz")
+    cfg = env.config(layer_norm_on=False)
+    index = gio.T(g["index_seq"])[0]
+    a = _fused_grads(env, cfg, p, g, index, batch_offset=batch_offset)
+    b = _fused_grads(env, cfg, p, g, index, batch_offset=batch_offset, split=True)
+    assert maxerr(a[0], b[0]) <= 2e-7 * max(1.0, float(a[0].abs().max()))
+    assert maxerr(a[1], b[1]) <= 1e-6
+    assert maxerr(a[2], b[2]) <= 1e-5
+    assert torch.equal(a[3], b[3])
+
+
+def test_mapping_loop_fused_schedule_matches_hoisted(env):
+    """CLID_PIPELINE=0 schedule of clid_mapping_run (fused kernel per iteration) against the golden loop too."""
+    from clid_slam_amd import _lib
+
+    lib = _lib.load()
+    prev = lib.clid_mapping_pipeline(0)
+    try:
+        test_mapping_loop_g6(env, "numerical", False, 0)
+    finally:
+        lib.clid_mapping_pipeline(prev)
 
 
 def test_fused_iteration_gradients_vs_reference(env):
