@@ -1,0 +1,149 @@
+"""Measurement of the two built "next" rows of SURVEY.md section 8(f) on one MI355X (bench.py keeps the
+headline metric; this prints one JSON line per row):
+
+  N1  tracking measurement model   IEKFOM.h_model / normal equations  (utils/error_state_iekf.py:176-305)
+  N3  dense SDF inference          Mesher.query_points                (utils/mesher.py:38-163)
+
+Both run on the same synthetic box-room map as bench.py after a short training run, with inputs resident in
+HBM, timed with events on the launch stream.  `roofline.achieved` = algorithmic bytes per launch / average
+launch time (bytes per query point: 688 B search + 216 B feature gather + outputs).
+The CPU leg times the oracle on a bounded sample (test infrastructure used only as the reported baseline).
+
+    python bench_next.py [--points 4194304] [--track-points 8192] [--no-cpu-baseline]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0
+BYTES_SEARCH = 688.0
+BYTES_FEAT = 216.0
+
+
+def timed(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=4194304, help="dense query points (N3)")
+    ap.add_argument("--track-points", type=int, default=8192, help="scan points per h_model call (N1)")
+    ap.add_argument("--train-iters", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import bench
+    from clid_slam_amd import HotPathConfig, _lib
+    from clid_slam_amd import mesher, tracking
+
+    _lib.load()
+    cfg = HotPathConfig()
+    cfg.device = "cuda:0"
+    torch.cuda.set_device(0)
+    nm, dec, mp, scene = bench.build_scene(cfg, "cuda:0")
+    mp.mapping(args.train_iters)
+    torch.cuda.synchronize()
+    dev = "cuda:0"
+    gen = torch.Generator().manual_seed(7)
+
+    # ---- N3: dense inference over points scattered through the mapped volume
+    pool = scene["coord"]
+    pick = torch.randint(0, pool.shape[0], (args.points,), generator=gen)
+    x = (pool[pick] + 0.05 * torch.randn((args.points, 3), generator=gen)).to(dev).contiguous()
+    run3 = lambda: mesher.query_points(nm, dec, cfg, x, query_locally=False)
+    t3 = timed(run3, 5, warm=2)
+    sdf3, _, _, mask3 = run3()
+    alg3 = args.points * (12.0 + BYTES_SEARCH + BYTES_FEAT + 8.0)
+    line3 = {
+        "row": "N3", "metric": "dense SDF query points/sec (Mesher.query_points)", "value": args.points / t3,
+        "unit": "points/s", "n_gpus": 1, "ms_per_call": 1e3 * t3, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "box-room map of bench.py, global map view, infer_bs = %d" % cfg.infer_bs,
+                   "points": args.points, "neural_points": int(nm.neural_points.shape[0]),
+                   "mask_fraction": float(mask3.mean().item())},
+        "roofline": {"bound": "hbm", "kernel": "k_sdf_query", "achieved": alg3 / t3 / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": alg3 / t3 / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg3 * min(cfg.infer_bs, args.points) / args.points},
+    }
+
+    # ---- N1: one evaluation of the measurement model on a scan around the sensor
+    near = scene["sdf_label"].abs() < 0.02
+    surf = scene["coord"][near]
+    sel = torch.randperm(surf.shape[0], generator=gen)[: args.track_points]
+    sensor = scene["sensor"].to(torch.float32)
+    pc_imu = (surf[sel] - sensor).to(dev).contiguous()
+    rot = torch.eye(3)
+    n1 = pc_imu.shape[0]
+    t1a = timed(lambda: tracking._launch(nm, dec, cfg, rot, sensor, pc_imu, False, True), 200, warm=10)
+    t1b = timed(lambda: tracking._launch(nm, dec, cfg, rot, sensor, pc_imu, True, False), 200, warm=10)
+    S, b, n_valid = tracking.normal_equations(nm, dec, cfg, rot, sensor, pc_imu)
+    alg1 = n1 * (12.0 + BYTES_SEARCH + BYTES_FEAT + 4.0)
+    line1 = {
+        "row": "N1", "metric": "tracking measurement-model points/sec (IEKFOM.h_model, fused normal equations)",
+        "value": n1 / t1a, "unit": "points/s", "n_gpus": 1, "us_per_call_normal_equations": 1e6 * t1a,
+        "us_per_call_per_point_outputs": 1e6 * t1b, "dtype": "f32 (f64 reduction)", "data": "synthetic",
+        "config": {"workload": "box-room map of bench.py, local map view, one IEKF iteration", "points": n1,
+                   "valid_points": n_valid},
+        "roofline": {"bound": "hbm", "kernel": "k_track_model", "achieved": alg1 / t1a / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": alg1 / t1a / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "note": "a few-thousand-point launch is latency-bound (one wave-latency long); host time per "
+                             "call includes the 9+3 float pose upload by value"},
+    }
+
+    if not args.no_cpu_baseline:
+        from oracle import cpu_ref as O
+
+        threads = min(16, os.cpu_count() or 1)
+        torch.set_num_threads(threads)
+        cpu = lambda t: t.detach().cpu().clone()
+        dx, mvd = O.search_neighborhood(cfg.num_nei_cells, cfg.search_alpha, cfg.voxel_size_m)
+        st = O.MapState(
+            buffer_pt_index=cpu(nm.buffer_pt_index), neural_points=cpu(nm.neural_points),
+            point_ts_create=cpu(nm.point_ts_create), travel_dist=cpu(nm.travel_dist), cur_ts=int(nm.cur_ts),
+            global2local=cpu(nm.global2local), local_neural_points=cpu(nm.local_neural_points),
+            local_geo_features=cpu(nm.local_geo_features.data), local_point_certainties=cpu(nm.local_point_certainties),
+            local_point_ts_update=cpu(nm.local_point_ts_update), resolution=cfg.voxel_size_m,
+            buffer_size=cfg.buffer_size, diff_travel_dist_local=nm.diff_travel_dist_local, neighbor_dx=dx,
+            max_valid_dist2=mvd, layer_norm_on=cfg.layer_norm_on, weighted_first=cfg.weighted_first,
+        )
+        od = O.DecoderParams(*[cpu(p) for p in dec.flat_params()], sdf_scale=dec.sdf_scale)
+        xs = x[:262144].cpu()
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 8.0:
+            O.sdf_at(st, od, xs)
+            reps += 1
+        dt = time.perf_counter() - t0
+        line3["cpu_baseline"] = {"value": xs.shape[0] * reps / dt, "unit": "points/s", "cores": threads, "kind": "port",
+                                 "sample": f"{reps} x {xs.shape[0]} points through the CPU oracle's query+decode, {dt:.1f} s"}
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 8.0:
+            O.h_model(st, od, rot, sensor, pc_imu.cpu(), cfg.track_mask_query_nn_k, cfg.reg_min_grad_norm,
+                      cfg.reg_max_grad_norm)
+            reps += 1
+        dt = time.perf_counter() - t0
+        line1["cpu_baseline"] = {"value": n1 * reps / dt, "unit": "points/s", "cores": threads, "kind": "port",
+                                 "sample": f"{reps} h_model evaluations of the CPU oracle on the same {n1} points, {dt:.1f} s"}
+    print(json.dumps(line1))
+    print(json.dumps(line3))
+
+
+if __name__ == "__main__":
+    main()
