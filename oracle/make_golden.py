@@ -509,8 +509,127 @@ def tracking_fixture():
     np.savez_compressed(os.path.join(OUT, "g8_tracking.npz"), **out)
 
 
+SAMPLER_FRAMES = [  # (sensor position, yaw [rad]) of the three synthetic frames of G9 / G10
+    ((0.0, 0.0, 1.5), 0.0), ((1.5, 0.4, 1.5), 0.05), ((3.1, 0.9, 1.55), 0.11),
+]
+
+
+def sampler_frames(n_elev=8, n_azim=256):
+    """Sensor-frame scans + float64 poses of the G9 / G10 frames."""
+    from clid_slam_amd.synth import box_room_scan
+
+    out = []
+    for fid, (s, yaw) in enumerate(SAMPLER_FRAMES):
+        world = box_room_scan(n_elev=n_elev, n_azim=n_azim, seed=300 + fid, sensor=s, vox_down_m=0.1) + torch.tensor(s)
+        pose = torch.eye(4, dtype=torch.float64)
+        pose[:3, :3] = torch.tensor([[np.cos(yaw), -np.sin(yaw), 0.0], [np.sin(yaw), np.cos(yaw), 0.0], [0.0, 0.0, 1.0]],
+                                    dtype=torch.float64)
+        pose[:3, 3] = torch.tensor(s, dtype=torch.float64)
+        local = ((world.double() - pose[:3, 3]) @ pose[:3, :3]).float().contiguous()  # R^T (p - t)
+        out.append((local, pose))
+    return out
+
+
+def sampler_fixture():
+    """G9: the reference's own LocalPointCloudMap (update_map, region_specific_sdf_estimation) and
+    DataSampler (sample, sample_pin) on three synthetic frames; G10: Mapper.process_frame over the same
+    frames (pool append / window filter / new-sample selection / adaptive iteration offset).  Random draws
+    are pinned by seeding torch's global generator right before each call (the seeds are stored)."""
+    torch.set_num_threads(1)
+    ref = import_reference()
+    from model.local_point_cloud_map import LocalPointCloudMap
+    from utils.data_sampler import DataSampler
+    from utils.tools import transform_torch
+
+    def cfg_for():
+        cfg = ref_config(ref)
+        cfg.local_buffer_size = 20011   # small table => real slot collisions in the fixture
+        cfg.local_map_size = 14.0       # the keep-radius of update_map cuts into the room
+        cfg.silence = True
+        return cfg
+
+    frames = sampler_frames()
+    cfg = cfg_for()
+    lpm, sampler = LocalPointCloudMap(cfg), DataSampler(cfg)
+    out = {"local_buffer_size": np.int64(cfg.local_buffer_size), "local_map_size": np.float64(cfg.local_map_size),
+           "n_frames": np.int64(len(frames))}
+    for fid, (pts, pose) in enumerate(frames):
+        lpm.update_map(pose[:3, 3], transform_torch(pts, pose))
+        occ = torch.nonzero(lpm.buffer_pt_index >= 0).flatten()
+        seed = 1000 + fid
+        torch.manual_seed(seed)
+        coord, label, weight = sampler.sample(pts, lpm, pose)
+        q = transform_torch(coord[::3], pose)           # a direct call as well (mixed surface / free samples)
+        d, ok = lpm.region_specific_sdf_estimation(q)
+        out.update({
+            f"f{fid}_points": pts.numpy(), f"f{fid}_pose": pose.numpy(), f"f{fid}_seed": np.int64(seed),
+            f"f{fid}_cloud": lpm.local_point_cloud_map.numpy(), f"f{fid}_slot": occ.numpy(),
+            f"f{fid}_slot_idx": lpm.buffer_pt_index[occ].numpy(),
+            f"f{fid}_coord": coord.numpy(), f"f{fid}_label": label.numpy(), f"f{fid}_weight": weight.numpy(),
+            f"f{fid}_q": q.numpy(), f"f{fid}_q_sdf": d.numpy(), f"f{fid}_q_ok": ok.numpy(),
+        })
+        print(f"G9 frame {fid}: rays {pts.shape[0]} cloud {lpm.local_point_cloud_map.shape[0]} samples {coord.shape[0]} "
+              f"of {pts.shape[0] * 8}; plane labels differ from nearest in {(d != d).sum().item()} (nan check)")
+    torch.manual_seed(2000)
+    c2, l2, _, _, _, w2 = sampler.sample_pin(frames[0][0], None, None, None)
+    out.update(pin_seed=np.int64(2000), pin_coord=c2.numpy(), pin_label=l2.numpy(), pin_weight=w2.numpy())
+    np.savez_compressed(os.path.join(OUT, "g9_sampler.npz"), **out)
+
+    # ---- G10: Mapper.process_frame
+    class _DS:
+        lose_track = False
+        stop_status = False
+        processed_frame = 0
+        gt_pose_provided = True
+        gt_poses = None
+        static_mask = None
+
+    cfg = cfg_for()
+    cfg.track_on, cfg.pgo_on = False, False
+    cfg.window_radius = 13.0            # the pool window filter drops part of the older frames
+    cfg.local_map_radius = 12.0
+    torch.manual_seed(42)
+    nm = ref.NeuralPoints(cfg)
+    nm.travel_dist = torch.tensor([0.0, 1.6, 3.3], dtype=torch.float32)
+    dec = ref.Decoder(cfg, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, 1)
+    ds = _DS()
+    ds.gt_poses = np.stack([p.numpy() for _, p in frames])
+    lpm = LocalPointCloudMap(cfg)
+    mp = ref.Mapper(cfg, ds, nm, lpm, dec)
+    out = {"window_radius": np.float64(cfg.window_radius), "local_map_radius": np.float64(cfg.local_map_radius),
+           "travel_dist": nm.travel_dist.numpy(),
+           "local_buffer_size": np.int64(cfg.local_buffer_size), "local_map_size": np.float64(cfg.local_map_size),
+           "buffer_size": np.int64(cfg.buffer_size)}
+    for fid, (pts, pose) in enumerate(frames):
+        ds.processed_frame = fid
+        if fid > 0:  # some certainty on part of the map so that the new-sample selection is not "everything"
+            nm.point_certainties[nm.neural_points[:, 0] < 1.0] = 2.0
+        seed = 3000 + fid
+        torch.manual_seed(seed)
+        mp.process_frame(pts.clone(), None, pose.clone(), fid)
+        out.update({
+            f"f{fid}_seed": np.int64(seed), f"f{fid}_pool_count": np.int64(mp.pool_sample_count),
+            f"f{fid}_cur_count": np.int64(mp.cur_sample_count), f"f{fid}_new_idx": mp.new_idx.numpy(),
+            f"f{fid}_iter_offset": np.int64(mp.adaptive_iter_offset), f"f{fid}_n_points": np.int64(nm.count()),
+            f"f{fid}_n_local": np.int64(nm.local_count()), f"f{fid}_new_ratio": np.float64(mp.cur_new_point_ratio),
+            f"f{fid}_time_hist": torch.bincount(mp.time_pool.long(), minlength=len(frames)).numpy(),
+            f"f{fid}_label_sum": np.float64(mp.sdf_label_pool.double().sum()),
+            f"f{fid}_gcoord_sum": mp.global_coord_pool.double().sum(0).numpy(),
+        })
+        print(f"G10 frame {fid}: pool {mp.pool_sample_count} cur {mp.cur_sample_count} new {mp.new_idx.shape[0]} "
+              f"offset {mp.adaptive_iter_offset} points {nm.count()} local {nm.local_count()}")
+    out.update(final_global_coord=mp.global_coord_pool.numpy(), final_coord=mp.coord_pool.numpy(),
+               final_label=mp.sdf_label_pool.numpy(), final_weight=mp.weight_pool.numpy(),
+               final_time=mp.time_pool.numpy(), final_neural_points=nm.neural_points.numpy())
+    np.savez_compressed(os.path.join(OUT, "g10_process_frame.npz"), **out)
+    for fn in ("g9_sampler.npz", "g10_process_frame.npz"):
+        print(f"{fn:40s} {os.path.getsize(os.path.join(OUT, fn)) / 1e6:.2f} MB")
+
+
 if __name__ == "__main__":
-    if "--only-g8" in sys.argv:
+    if "--only-g9" in sys.argv:
+        sampler_fixture()
+    elif "--only-g8" in sys.argv:
         tracking_fixture()
     elif "--only-g7" in sys.argv:
         os.makedirs(OUT, exist_ok=True)

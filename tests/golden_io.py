@@ -62,3 +62,13 @@ def decoder(z=None, prefix=""):
 def sample_pool():
     p = load("pool.npz")
     return O.SamplePool(T(p["coord"]), T(p["sdf_label"]), T(p["time"]), T(p["weight"])), p
+
+
+def sampler_noise(seed, n_rays, n_surface=4, n_front=2, n_behind=1):
+    """The random draws of DataSampler.sample / sample_pin for one frame, in the reference's order from
+    torch's CPU generator seeded with `seed` (utils/data_sampler.py:47, :72, :93)."""
+    g = torch.Generator().manual_seed(int(seed))
+    z_s = torch.randn(n_rays * n_surface, 1, generator=g)
+    u_f = torch.rand(n_rays * n_front, 1, generator=g)
+    u_b = torch.rand(n_rays * n_behind, 1, generator=g)
+    return z_s, u_f, u_b
