@@ -2,14 +2,17 @@
 inner loop behind the reference's own Python call signatures.
 
     from clid_slam_amd import NeuralPoints, Decoder, Mapper        # drop-ins for model/*.py, utils/mapper.py
+    from clid_slam_amd import LocalPointCloudMap, DataSampler     # ... model/local_point_cloud_map.py, utils/data_sampler.py
     from clid_slam_amd.loss import sdf_bce_loss
     from clid_slam_amd.tools import get_gradient, setup_optimizer
 
 The compute lives in libclid_native.so (include/clid_native.h); see DESIGN.md / INTEGRATION.md.
 """
 from .config import HotPathConfig  # noqa: F401
+from .data_sampler import DataSampler  # noqa: F401
 from .decoder import Decoder  # noqa: F401
+from .local_point_cloud_map import LocalPointCloudMap  # noqa: F401
 from .mapper import Mapper  # noqa: F401
 from .neural_points import NeuralPoints  # noqa: F401
 
-__all__ = ["NeuralPoints", "Decoder", "Mapper", "HotPathConfig"]
+__all__ = ["NeuralPoints", "Decoder", "Mapper", "LocalPointCloudMap", "DataSampler", "HotPathConfig"]

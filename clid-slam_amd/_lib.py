@@ -55,6 +55,24 @@ class AdamArgs(C.Structure):
     ]
 
 
+class CloudView(C.Structure):
+    _fields_ = [
+        ("buffer_pt_index", _vp), ("points", _vp), ("neighbor_idx", _vp), ("buffer_size", _i64),
+        ("n_points", _i32), ("P", _i32),
+        ("resolution", _f32), ("max_valid_range", _f32), ("eta_threshold", _f32), ("dist_threshold", _f32),
+    ]
+
+
+class SamplerParams(C.Structure):
+    _fields_ = [
+        ("surface_sample_range_m", _f32), ("free_sample_begin_ratio", _f32), ("free_sample_end_dist_m", _f32),
+        ("dist_weight_scale", _f32), ("max_range", _f32),
+        ("surface_sample_n", _i32), ("free_front_n", _i32), ("free_behind_n", _i32), ("dist_weight_on", _i32),
+        ("behind_dropoff_on", _i32),
+        ("pose", _f32 * 12), ("reserved", _i32 * 2),
+    ]
+
+
 _SIGS = {
     "clid_abi_version": (C.c_int, []),
     "clid_last_error": (C.c_char_p, []),
@@ -75,6 +93,9 @@ _SIGS = {
     "clid_train_adam": (C.c_int, [C.POINTER(AdamArgs), C.POINTER(TrainArgs), _vp]),
     "clid_mapping_run": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), C.POINTER(AdamArgs), _i32, _vp, _i64, _vp, _vp]),
     "clid_debug_task_cover": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "clid_region_sdf": (C.c_int, [C.POINTER(CloudView), _vp, _i32, _vp, _vp, _vp]),
+    "clid_sample_frame": (C.c_int, [C.POINTER(CloudView), C.POINTER(SamplerParams), _vp, _i32, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _vp]),
     "clid_mapping_pipeline": (C.c_int, [C.c_int]),
     "clid_train_search_floats": (_i64, [_i32, _i64, _i32, _i32, _i32]),
     "clid_train_search": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), _i32, _vp, _i64, _vp, _vp]),

@@ -36,6 +36,29 @@ class HotPathConfig:
         self.free_sample_end_dist_m = 1.2
         self.free_front_n = 2
         self.free_behind_n = 1
+        # raw-point map of the region-specific SDF labels (`utils/config.py:111,124,148,518-521`)
+        self.use_pin_mapper = False
+        self.local_voxel_size_m = 0.2
+        self.local_buffer_size = int(5e6)
+        self.local_map_size = 100.0
+        # per-frame glue of Mapper.process_frame (`utils/config.py:105-107,132-144,162-165,238-241`)
+        self.from_sample_points = True
+        self.from_all_samples = False
+        self.map_surface_ratio = 0.5
+        self.prune_map_on = False
+        self.prune_freq_frame = 100
+        self.max_prune_certainty = 3.0
+        self.pool_filter_freq = 1
+        self.new_certainty_thre = 1.0
+        self.new_sample_ratio_less = 0.02
+        self.new_sample_ratio_more = 0.15
+        self.new_sample_ratio_restart = 0.3
+        self.dynamic_filter_on = False
+        self.dynamic_certainty_thre = 0.5
+        self.dynamic_sdf_ratio_thre = 1.5
+        self.dynamic_min_grad_norm_thre = 0.3
+        self.track_on = False
+        self.pgo_on = False
         # neural points (`utils/config.py:542-600`)
         self.voxel_size_m = 0.4
         self.buffer_size = int(5e7)
@@ -112,11 +135,13 @@ class HotPathConfig:
         self.name = s.get("name", self.name)
         self.device = s.get("device", self.device)
         self.seed = s.get("random_seed", self.seed)
+        self.use_pin_mapper = s.get("use_pin_mapper", self.use_pin_mapper)
         p = g("process", {})
         self.min_range = p.get("min_range_m", self.min_range)
         self.max_range = p.get("max_range_m", self.max_range)
         self.vox_down_m = p.get("vox_down_m", self.vox_down_m)
         sa = g("sampler", {})
+        self.local_voxel_size_m = sa.get("local_voxel_size_m", self.vox_down_m)  # `utils/config.py:519-521`
         self.surface_sample_range_m = sa.get("surface_sample_range_m", self.surface_sample_range_m)
         self.surface_sample_n = sa.get("surface_sample_n", self.surface_sample_n)
         self.free_sample_begin_ratio = sa.get("free_sample_begin_ratio", self.free_sample_begin_ratio)
@@ -154,7 +179,16 @@ class HotPathConfig:
         else:
             self.gradient_decimation = lo.get("grad_decimation", self.gradient_decimation)
             self.num_grad_step_ratio = lo.get("num_grad_step_ratio", self.num_grad_step_ratio)
+        self.from_sample_points = n.get("from_sample_points", self.from_sample_points)
+        self.map_surface_ratio = n.get("map_surface_ratio", self.map_surface_ratio)
+        self.prune_map_on = n.get("prune_map_on", self.prune_map_on)
+        self.max_prune_certainty = n.get("max_prune_certainty", self.max_prune_certainty)
+        self.dynamic_filter_on = p.get("dynamic_filter_on", self.dynamic_filter_on)
+        self.dynamic_sdf_ratio_thre = p.get("dynamic_sdf_ratio_thre", self.dynamic_sdf_ratio_thre)
+        self.dynamic_certainty_thre = p.get("dynamic_certainty_thre", self.dynamic_certainty_thre)
         c = g("continual", {})
+        self.new_certainty_thre = float(c.get("new_certainty_thre", self.new_certainty_thre))
+        self.pool_filter_freq = c.get("pool_filter_freq", self.pool_filter_freq)
         self.bs_new_sample = int(c.get("batch_size_new_sample", self.bs_new_sample))
         self.pool_capacity = int(float(c.get("pool_capacity", self.pool_capacity)))
         o = g("optimizer", {})
@@ -162,5 +196,7 @@ class HotPathConfig:
         self.bs = o.get("batch_size", self.bs)
         self.lr = float(o.get("learning_rate", self.lr))
         self.adaptive_iters = o.get("adaptive_iters", self.adaptive_iters)
+        self.new_sample_ratio_less = o.get("new_sample_ratio_less", self.new_sample_ratio_less)
+        self.new_sample_ratio_more = o.get("new_sample_ratio_more", self.new_sample_ratio_more)
         self._derive()
         return self

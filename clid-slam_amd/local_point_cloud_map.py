@@ -1,0 +1,105 @@
+"""Raw-point voxel map used for the region-specific SDF labels ("next" row N2).
+
+Drop-in for `LocalPointCloudMap` (model/local_point_cloud_map.py:11-153): same constructor, attributes
+(`buffer_pt_index`, `local_point_cloud_map`, `neighbor_idx`, `max_valid_range`, `map_size`, ...) and methods.
+Map maintenance (`insert_points`, `update_map`) is a handful of torch ops on the device, once per frame;
+`region_specific_sdf_estimation` -- the 7-probe / top-4 / plane-fit estimate evaluated for every near-surface
+sample -- is the HIP kernel `k_region_sdf` (csrc/sampler.hip) behind `clid_region_sdf`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .tools import voxel_down_sample_torch
+
+
+class LocalPointCloudMap:
+    def __init__(self, config) -> None:
+        self.config = config
+        self.idx_dtype = torch.int64
+        self.dtype = config.dtype
+        self.device = config.device
+        self.resolution = config.local_voxel_size_m
+        self.buffer_size = int(config.local_buffer_size)
+        self.buffer_pt_index = torch.full((self.buffer_size,), -1, dtype=self.idx_dtype, device=self.device)
+        self.local_point_cloud_map = torch.empty((0, 3), dtype=torch.float32, device=self.device)
+        # NOT the neural-point primes: the middle one differs (model/local_point_cloud_map.py:27-29)
+        self.primes = torch.tensor([73856093, 19349663, 83492791], dtype=self.idx_dtype, device=self.device)
+        self.neighbor_idx = None
+        self.max_valid_range = None
+        self._neighbor_i32 = None
+        self.set_search_neighborhood()
+        self.map_size = config.local_map_size
+
+    # ------------------------------------------------------------------ table
+    def voxel_hash(self, points: torch.Tensor) -> torch.Tensor:
+        """model/local_point_cloud_map.py:38-41 (fmod keeps the sign; negative values index from the end)."""
+        cells = torch.floor(points / self.resolution).to(self.primes)
+        return torch.fmod((cells * self.primes).sum(-1), self.buffer_size)
+
+    def _write_slots(self, table: torch.Tensor, slots: torch.Tensor, first_index: int) -> None:
+        """table[slots] = arange + first_index where several entries may name one slot: the reference's plain
+        indexed assignment keeps the LAST one when run sequentially; amax is the same choice, deterministic
+        on the GPU."""
+        slots = torch.where(slots < 0, slots + self.buffer_size, slots)
+        vals = torch.arange(slots.shape[0], dtype=self.idx_dtype, device=table.device) + first_index
+        table.scatter_reduce_(0, slots, vals, reduce="amax", include_self=True)
+
+    def insert_points(self, points: torch.Tensor) -> None:
+        """:43-61: one point per voxel of this scan, appended where the voxel's slot is still empty."""
+        sample_points = points[voxel_down_sample_torch(points, self.resolution)]
+        slots = self.voxel_hash(sample_points)
+        empty = self.buffer_pt_index[slots] == -1
+        fresh = sample_points[empty]
+        self._write_slots(self.buffer_pt_index, slots[empty], self.local_point_cloud_map.shape[0])
+        self.local_point_cloud_map = torch.cat((self.local_point_cloud_map, fresh), 0)
+
+    def update_map(self, sensor_position: torch.Tensor, points: torch.Tensor) -> None:
+        """:63-72: insert, keep what is within `map_size` of the sensor, rebuild the slot table."""
+        self.insert_points(points)
+        near = torch.norm(self.local_point_cloud_map - sensor_position, dim=-1) < self.map_size
+        self.local_point_cloud_map = self.local_point_cloud_map[near].contiguous()
+        table = torch.full((self.buffer_size,), -1, dtype=self.idx_dtype, device=self.device)
+        self._write_slots(table, self.voxel_hash(self.local_point_cloud_map), 0)
+        self.buffer_pt_index = table
+
+    def set_search_neighborhood(self, num_nei_cells: int = 1, search_alpha: float = 0.2) -> None:
+        """:74-96: the cells within (num_nei_cells + search_alpha) of the centre cell (7 by default)."""
+        r = torch.arange(-num_nei_cells, num_nei_cells + 1, device=self.primes.device, dtype=self.primes.dtype)
+        dx = torch.stack(torch.meshgrid(r, r, r, indexing="ij"), dim=-1).reshape(-1, 3)
+        self.neighbor_idx = dx[torch.sum(dx**2, dim=-1) < (num_nei_cells + search_alpha) ** 2]
+        self.max_valid_range = 1.732 * (num_nei_cells + 1) * self.resolution
+        self._neighbor_i32 = self.neighbor_idx.to(torch.int32).contiguous()
+
+    # ------------------------------------------------------------------ kernel-side view
+    def _cloud_view(self):
+        """(CloudView, tensors to keep alive) for the HIP entry points."""
+        _lib.require_cuda(self.buffer_pt_index, "buffer_pt_index", torch.int64)
+        pts = _lib.require_cuda(self.local_point_cloud_map.contiguous(), "local_point_cloud_map", torch.float32)
+        nb = self._neighbor_i32
+        if nb.device != pts.device:
+            nb = self._neighbor_i32 = nb.to(pts.device)
+        v = _lib.CloudView()
+        v.buffer_pt_index, v.points, v.neighbor_idx = self.buffer_pt_index.data_ptr(), pts.data_ptr(), nb.data_ptr()
+        v.buffer_size, v.n_points, v.P = self.buffer_size, pts.shape[0], nb.shape[0]
+        v.resolution, v.max_valid_range = float(self.resolution), float(self.max_valid_range)
+        v.eta_threshold, v.dist_threshold = 0.2, 0.1  # estimate_plane's defaults (:156-158)
+        return v, (pts, nb, self.buffer_pt_index)
+
+    def region_specific_sdf_estimation(self, points: torch.Tensor):
+        """:98-153: (|SDF| estimate [N], surface mask [N] bool) for world-frame sample points."""
+        lib = _lib.load()
+        x = _lib.require_cuda(points.detach().to(torch.float32).contiguous(), "points", torch.float32)
+        n = x.shape[0]
+        sdf_abs = torch.empty(n, device=x.device, dtype=torch.float32)
+        mask = torch.empty(n, device=x.device, dtype=torch.uint8)
+        view, keep = self._cloud_view()
+        _lib.check(lib.clid_region_sdf(C.byref(view), x.data_ptr(), n, sdf_abs.data_ptr(), mask.data_ptr(),
+                                       _lib.stream()), "clid_region_sdf")
+        surface_mask = mask.bool()
+        if not self.config.silence:
+            print(surface_mask.sum().item() / max(surface_mask.numel(), 1))
+        return sdf_abs, surface_mask

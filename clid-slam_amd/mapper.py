@@ -337,9 +337,154 @@ class Mapper:
         self.sdf_label_pool = self.color_pool = self.sem_label_pool = self.normal_label_pool = None
         self.time_pool = None
 
-    def process_frame(self, *a, **k):
-        raise NotImplementedError("process_frame (sampling + pool maintenance, utils/mapper.py:159-470) is a 'next' row "
-                                  "(SURVEY.md section 8f N2); fill the pool with set_pool()")
+    # ------------------------------------------------------------------ N2: per-frame glue in front of the loop
+    def determine_used_pose(self):
+        """utils/mapper.py:138-157."""
+        cur = self.dataset.processed_frame
+        cfg = self.config
+        if getattr(cfg, "pgo_on", False):
+            poses = self.dataset.pgo_poses
+        elif getattr(cfg, "track_on", False):
+            poses = self.dataset.odom_poses
+        elif getattr(self.dataset, "gt_pose_provided", False):
+            poses = self.dataset.gt_poses
+        else:
+            return
+        self.used_poses = torch.as_tensor(poses[: cur + 1], device=self.device, dtype=torch.float64)
+
+    def dynamic_filter(self, points_torch, type_2_on: bool = True):
+        """utils/mapper.py:99-136: static = not (certainly free space), and the SDF gradient looks sane."""
+        cfg = self.config
+        sdf_pred, grad, _, certainty = self.neural_points.query_sdf_and_gradient(self.geo_mlp, points_torch)
+        static = (certainty < cfg.dynamic_certainty_thre) | (sdf_pred < cfg.dynamic_sdf_ratio_thre * cfg.voxel_size_m)
+        if type_2_on:
+            static = static & ((grad.norm(dim=-1) > getattr(cfg, "dynamic_min_grad_norm_thre", 0.3)) | (certainty < cfg.dynamic_certainty_thre))
+        return static
+
+    def process_frame(self, point_cloud_torch, frame_label_torch, cur_pose_torch, frame_id: int,
+                      filter_dynamic: bool = False):
+        """utils/mapper.py:159-470: raw-point map update -> sample + label this scan -> grow the neural-point
+        map -> append to / filter the training pool -> pick the newly observed samples and the adaptive
+        iteration offset.  Sampling is one HIP launch (data_sampler.py); the rest is per-frame bookkeeping."""
+        from .data_sampler import DataSampler
+        from .tools import transform_torch
+
+        cfg, nm = self.config, self.neural_points
+        if getattr(self, "sampler", None) is None:
+            self.sampler = DataSampler(cfg)
+        origin = cur_pose_torch[:3, 3]
+        orientation = cur_pose_torch[:3, :3]
+        pts = point_cloud_torch[:, :3]
+        use_pin = bool(getattr(cfg, "use_pin_mapper", False))
+        if not use_pin:  # :178-183
+            self.local_point_cloud_map.update_map(origin, transform_torch(pts, cur_pose_torch))
+        self.static_mask = torch.ones(pts.shape[0], dtype=torch.bool, device=pts.device)
+        if filter_dynamic:  # :189-204
+            nm.reset_local_map(origin, orientation, frame_id)
+            self.static_mask = self.dynamic_filter(transform_torch(pts, cur_pose_torch))
+            pts = pts[self.static_mask]
+            if frame_label_torch is not None:
+                frame_label_torch = frame_label_torch[self.static_mask]
+        self.dataset.static_mask = self.static_mask
+        color = None
+        if getattr(cfg, "color_on", False):
+            color = point_cloud_torch[:, 3:]
+            color = color[self.static_mask] if filter_dynamic else color
+
+        normal_label = sem_label = color_label = None
+        if use_pin:  # :224-239
+            coord, sdf_label, normal_label, sem_label, color_label, weight = self.sampler.sample_pin(
+                pts, None, frame_label_torch, color)
+        else:  # :240-245, the region-specific SDF estimation
+            coord, sdf_label, weight = self.sampler.sample(pts, self.local_point_cloud_map, cur_pose_torch)
+        n_cur = coord.shape[0]
+        stamp = torch.full((n_cur,), frame_id, dtype=torch.int, device=coord.device)
+        self.cur_sample_count = n_cur
+        self.pool_sample_count = self.sdf_label_pool.shape[0]
+
+        # grow the neural-point map from the samples closest to the surface (:257-283)
+        if getattr(cfg, "from_sample_points", True):
+            if getattr(cfg, "from_all_samples", False):
+                update_points = coord  # (sensor frame, as the reference passes it)
+            else:
+                near = torch.abs(sdf_label) < cfg.surface_sample_range_m * getattr(cfg, "map_surface_ratio", 0.5)
+                update_points = transform_torch(coord[near, :], cur_pose_torch)
+        else:
+            update_points = transform_torch(pts, cur_pose_torch)
+        if getattr(cfg, "prune_map_on", False) and (frame_id + 1) % cfg.prune_freq_frame == 0:
+            if nm.prune_map(cfg.max_prune_certainty):
+                nm.recreate_hash(None, None, True, True, frame_id)
+        self.cur_new_point_ratio = nm.update(update_points, origin, orientation, frame_id)
+
+        # pool append (:297-333)
+        self.coord_pool = torch.cat((self.coord_pool, coord), 0)
+        self.weight_pool = torch.cat((self.weight_pool, weight), 0)
+        self.sdf_label_pool = torch.cat((self.sdf_label_pool, sdf_label), 0)
+        self.time_pool = torch.cat((self.time_pool, stamp), 0)
+        self.sem_label_pool = None if sem_label is None else (
+            sem_label if self.sem_label_pool is None else torch.cat((self.sem_label_pool, sem_label), 0))
+        self.color_pool = None if color_label is None else (
+            color_label if self.color_pool is None else torch.cat((self.color_pool, color_label), 0))
+        self.normal_label_pool = None if normal_label is None else (
+            normal_label if self.normal_label_pool is None else torch.cat((self.normal_label_pool, normal_label), 0))
+        self.determine_used_pose()
+        if self.ba_done_flag:  # poses of old frames moved: re-project the whole pool (:322-327)
+            from .tools import transform_batch_torch
+
+            self.global_coord_pool = transform_batch_torch(self.coord_pool, self.used_poses[self.time_pool.long()])
+            self.ba_done_flag = False
+        else:
+            self.global_coord_pool = torch.cat((self.global_coord_pool, transform_torch(coord, cur_pose_torch)), 0)
+
+        # window / capacity filter (:337-392)
+        if (frame_id + 1) % getattr(cfg, "pool_filter_freq", 1) == 0:
+            rel = self.global_coord_pool - origin  # float64 when the pose is (type promotion, as in the reference)
+            keep = torch.sum(rel**2, dim=-1) < cfg.window_radius**2
+            kept = torch.nonzero(keep).squeeze(1)
+            if kept.shape[0] > cfg.pool_capacity:
+                drop = torch.randint(0, kept.shape[0], (kept.shape[0] - cfg.pool_capacity,), device=keep.device)
+                keep[kept[drop]] = False
+            self.coord_pool = self.coord_pool[keep]
+            self.global_coord_pool = self.global_coord_pool[keep].contiguous()
+            self.sdf_label_pool = self.sdf_label_pool[keep].contiguous()
+            self.weight_pool = self.weight_pool[keep].contiguous()
+            self.time_pool = self.time_pool[keep].contiguous()
+            if self.normal_label_pool is not None:
+                self.normal_label_pool = self.normal_label_pool[keep]
+            if self.sem_label_pool is not None:
+                self.sem_label_pool = self.sem_label_pool[keep]
+            if self.color_pool is not None:
+                self.color_pool = self.color_pool[keep]
+            self.cur_sample_count = int(keep[-n_cur:].sum().item()) if n_cur > 0 else 0
+            self.pool_sample_count = int(keep.sum().item())
+        else:
+            self.cur_sample_count = n_cur
+            self.pool_sample_count = self.coord_pool.shape[0]
+
+        # newly observed region: samples of this frame whose neighbourhood is still uncertain (:400-462)
+        if cfg.bs_new_sample > 0:
+            cur = self.global_coord_pool[self.global_coord_pool.shape[0] - self.cur_sample_count:]
+            cur_label = self.sdf_label_pool[self.sdf_label_pool.shape[0] - self.cur_sample_count:]
+            certainty = torch.zeros(cur.shape[0], device=cur.device)
+            nm.set_search_neighborhood(num_nei_cells=1, search_alpha=0.0)
+            try:
+                for head in range(0, cur.shape[0], cfg.infer_bs):
+                    certainty[head:head + cfg.infer_bs] = nm.query_certainty(cur[head:head + cfg.infer_bs, :])
+            finally:
+                nm.set_search_neighborhood(num_nei_cells=cfg.num_nei_cells, search_alpha=cfg.search_alpha)
+            self.new_idx = torch.where(
+                (certainty < getattr(cfg, "new_certainty_thre", 1.0)) & (torch.abs(cur_label) < cfg.surface_sample_range_m * 3.0)
+            )[0]
+            self.new_idx += self.pool_sample_count - self.cur_sample_count
+            self.adaptive_iter_offset = 0
+            ratio = self.new_idx.shape[0] / max(self.cur_sample_count, 1)
+            if cfg.adaptive_iters:
+                if ratio < getattr(cfg, "new_sample_ratio_less", 0.02):
+                    self.adaptive_iter_offset = -5
+                elif ratio > getattr(cfg, "new_sample_ratio_more", 0.15):
+                    self.adaptive_iter_offset = 5
+                    if frame_id > cfg.freeze_after_frame and ratio > getattr(cfg, "new_sample_ratio_restart", 0.3):
+                        self.adaptive_iter_offset = 10
 
     def bundle_adjustment(self, *a, **k):
         raise NotImplementedError("bundle_adjustment is disabled in all shipped configs (ba_freq_frame=0) and out of scope")

@@ -89,3 +89,16 @@ def voxel_down_sample_torch(points: torch.Tensor, voxel_size: float):
     first = torch.ones_like(fs, dtype=torch.bool)
     first[1:] = fs[1:] != fs[:-1]
     return order[first]
+
+
+def transform_torch(points: torch.Tensor, transformation: torch.Tensor):
+    """Rigid transform of [N,3] points by a 4x4 matrix, evaluated in the points' dtype
+    (utils/tools.py:590-609)."""
+    T = transformation.to(points)
+    return points @ T[:3, :3].T + T[:3, 3]
+
+
+def transform_batch_torch(points: torch.Tensor, transformation: torch.Tensor):
+    """Per-point rigid transform: points [N,3], transformation [N,4,4] (utils/tools.py:612-636)."""
+    T = transformation.to(points)
+    return torch.bmm(T[:, :3, :3], points.unsqueeze(-1)).squeeze(-1) + T[:, :3, 3]

@@ -223,6 +223,46 @@ int clid_train_decode(const clid_map_view* mv, const clid_train_args* t, const f
  * mode < 0 re-reads the environment variable CLID_PIPELINE; returns the previous setting. */
 int clid_mapping_pipeline(int mode);
 
+/* ---- sample + label generation in front of the path ("next" row N2) ---------------------------------
+ * What the kernels read of `LocalPointCloudMap` (model/local_point_cloud_map.py:11-36): the reference's own
+ * direct-mapped voxel table over the raw scan points, probed as is. */
+typedef struct clid_cloud_view {
+  const int64_t* buffer_pt_index; /* [buffer_size] raw-point index per voxel-hash slot, -1 = empty */
+  const float* points;            /* [n_points][3] local_point_cloud_map (world frame) */
+  const int32_t* neighbor_idx;    /* [P][3] cell offsets of set_search_neighborhood (:74-96), 7 by default */
+  int64_t buffer_size;            /* config.local_buffer_size */
+  int32_t n_points;
+  int32_t P;
+  float resolution;               /* config.local_voxel_size_m */
+  float max_valid_range;          /* 1.732 * (num_nei_cells + 1) * resolution */
+  float eta_threshold;            /* 0.2  (estimate_plane default, :157) */
+  float dist_threshold;           /* 0.1 */
+} clid_cloud_view;
+
+/* The sampler's keys of utils/config.py + the sensor pose of the frame. */
+typedef struct clid_sampler_params {
+  float surface_sample_range_m, free_sample_begin_ratio, free_sample_end_dist_m, dist_weight_scale, max_range;
+  int32_t surface_sample_n, free_front_n, free_behind_n, dist_weight_on, behind_dropoff_on;
+  float pose[12];                 /* rows 0..2 of the sensor->world transform, row-major, cast to f32 */
+  int32_t reserved[2];
+} clid_sampler_params;
+
+/* LocalPointCloudMap.region_specific_sdf_estimation (model/local_point_cloud_map.py:98-153) with
+ * estimate_plane (:156-201): points [n][3] world frame -> |SDF| estimate [n], surface mask [n] (0/1). */
+int clid_region_sdf(const clid_cloud_view* cloud, const float* points, int32_t n, float* sdf_abs_out,
+                    uint8_t* surface_mask_out, void* stream);
+
+/* DataSampler.sample (cloud != NULL, utils/data_sampler.py:260-402) / DataSampler.sample_pin geometry
+ * (cloud == NULL, :16-258) in one launch.  points [n_rays][3] sensor frame; the random draws are inputs in
+ * the reference's own layout and order (z_surface = randn [surface_sample_n * n_rays], u_front = rand
+ * [free_front_n * n_rays], u_behind = rand [free_behind_n * n_rays], sample-major).  Outputs are DENSE and
+ * ray-major, n_rays * (1 + surface_n + front_n + behind_n) rows: coord (sensor frame), sdf label, weight
+ * (negative = free-space sample) and keep (0 = near-surface sample without a raw point around it; the
+ * reference returns coord[keep], label[keep], weight[keep]). */
+int clid_sample_frame(const clid_cloud_view* cloud, const clid_sampler_params* p, const float* points,
+                      int32_t n_rays, const float* z_surface, const float* u_front, const float* u_behind,
+                      float* coord_out, float* label_out, float* weight_out, uint8_t* keep_out, void* stream);
+
 /* ---- measurement aid (bench.py roofline leg; not part of the reference's interface) -----------
  * When enabled, clid_train_fwd_bwd / clid_train_adam bracket each kernel with hipEvents on the
  * launch stream.  clid_profile_read synchronises and returns summed elapsed ms per kernel:
