@@ -3,6 +3,8 @@ headline metric; this prints one JSON line per row):
 
   N1  tracking measurement model   IEKFOM.h_model / normal equations  (utils/error_state_iekf.py:176-305)
   N3  dense SDF inference          Mesher.query_points                (utils/mesher.py:38-163)
+  N2  sample + label generation    DataSampler.sample / process_frame (utils/data_sampler.py:260-402,
+                                   model/local_point_cloud_map.py:98-201, utils/mapper.py:159-470)
 
 Both run on the same synthetic box-room map as bench.py after a short training run, with inputs resident in
 HBM, timed with events on the launch stream.  `roofline.achieved` = algorithmic bytes per launch / average
@@ -39,6 +41,80 @@ def timed(fn, reps, warm=3):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def sampler_row(cfg, args):
+    """N2: one Ouster-128-like scan (box room) through the raw-point map update, the fused sampler launch and
+    the whole Mapper.process_frame."""
+    from clid_slam_amd import DataSampler, Decoder, LocalPointCloudMap, Mapper, NeuralPoints
+    from clid_slam_amd.synth import box_room_scan
+    from clid_slam_amd.tools import transform_torch
+
+    dev = "cuda:0"
+    sensor = (0.0, 0.0, 1.5)
+    scan = box_room_scan(sensor=sensor).to(dev)  # sensor frame, ~1e5 rays after the 0.1 m voxel filter
+    pose = torch.eye(4, dtype=torch.float64, device=dev)
+    pose[:3, 3] = torch.tensor(sensor, dtype=torch.float64)
+    lpm = LocalPointCloudMap(cfg)
+    lpm.update_map(pose[:3, 3], transform_torch(scan, pose))
+    smp = DataSampler(cfg)
+    R = scan.shape[0]
+    n_all = 1 + cfg.surface_sample_n + cfg.free_front_n + cfg.free_behind_n
+    noise = (torch.randn(R * cfg.surface_sample_n, 1, device=dev), torch.rand(R * cfg.free_front_n, 1, device=dev),
+             torch.rand(R * cfg.free_behind_n, 1, device=dev))
+    t_kernel = timed(lambda: smp._run(scan, lpm, pose, noise), 50, warm=5)
+    t_sample = timed(lambda: smp.sample(scan, lpm, pose), 20, warm=3)
+    t_update = timed(lambda: lpm.update_map(pose[:3, 3], transform_torch(scan, pose)), 10, warm=2)
+
+    class _DS:
+        lose_track = False
+        stop_status = False
+        processed_frame = 0
+        gt_pose_provided = False
+
+    def one_frame():
+        nm = NeuralPoints(cfg)
+        nm.travel_dist = torch.zeros(4, device=dev)
+        mp = Mapper(cfg, _DS(), nm, LocalPointCloudMap(cfg), Decoder(cfg, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, 1))
+        mp.process_frame(scan, None, pose, 0)
+        return mp
+
+    t_frame = timed(one_frame, 5, warm=1)
+    mp = one_frame()
+    # per ray: 12 B in + 28 B noise + 8 x 21 B out + 4 near-surface samples x 7 probes x (8 B slot + 12 B point)
+    alg = R * (12.0 + 4.0 * (n_all - 1) + n_all * 21.0 + cfg.surface_sample_n * lpm.neighbor_idx.shape[0] * 20.0)
+    line = {
+        "row": "N2", "metric": "training samples/sec generated + labelled (DataSampler.sample, region-specific SDF)",
+        "value": R * n_all / t_kernel, "unit": "samples/s", "n_gpus": 1, "dtype": "f32", "data": "synthetic",
+        "us_fused_launch": 1e6 * t_kernel, "us_sample_with_compaction": 1e6 * t_sample,
+        "us_raw_point_map_update": 1e6 * t_update, "ms_process_frame_first_frame": 1e3 * t_frame,
+        "config": {"workload": "one box-room Ouster-128 scan, run_ncd128 sampler settings", "rays": R,
+                   "samples_per_ray": n_all, "raw_map_points": int(lpm.local_point_cloud_map.shape[0]),
+                   "pool_after_frame": int(mp.pool_sample_count), "neural_points": int(mp.neural_points.count())},
+        "roofline": {"bound": "hbm", "kernel": "k_sample_frame", "achieved": alg / t_kernel / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": alg / t_kernel / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import sampler_ref as SR
+
+        threads = min(16, os.cpu_count() or 1)
+        torch.set_num_threads(threads)
+        lc = SR.LocalCloud.empty(resolution=cfg.local_voxel_size_m, buffer_size=cfg.local_buffer_size,
+                                 map_size=cfg.local_map_size)
+        lc.buffer_pt_index, lc.points = lpm.buffer_pt_index.cpu(), lpm.local_point_cloud_map.cpu()
+        sc = SR.SamplerConfig(surface_sample_range_m=cfg.surface_sample_range_m, surface_sample_n=cfg.surface_sample_n,
+                              free_behind_n=cfg.free_behind_n, free_front_n=cfg.free_front_n, max_range=cfg.max_range)
+        pts_c, pose_c, noise_c = scan.cpu(), pose.cpu(), tuple(t.cpu() for t in noise)
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 8.0:
+            SR.sample_region_specific(sc, pts_c, lc, pose_c, noise_c)
+            reps += 1
+        dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": R * n_all * reps / dt, "unit": "samples/s", "cores": threads, "kind": "port",
+                                "sample": f"{reps} scans through the CPU oracle's sampler, {dt:.1f} s"}
+    return line
 
 
 def main():
@@ -141,7 +217,9 @@ def main():
         dt = time.perf_counter() - t0
         line1["cpu_baseline"] = {"value": n1 * reps / dt, "unit": "points/s", "cores": threads, "kind": "port",
                                  "sample": f"{reps} h_model evaluations of the CPU oracle on the same {n1} points, {dt:.1f} s"}
+    line2 = sampler_row(cfg, args)
     print(json.dumps(line1))
+    print(json.dumps(line2))
     print(json.dumps(line3))
 
 

@@ -65,8 +65,8 @@ class DataSampler:
         """utils/data_sampler.py:260-402: (coord [S,3] sensor frame, sdf_label [S], weight [S]); near-surface
         samples carry sign x region-specific |SDF| and are dropped where no raw map point is around them."""
         coord, label, weight, keep, _ = self._run(points_torch, local_point_cloud_map, cur_pose_torch, noise)
-        m = keep.bool()
-        return coord[m], label[m], weight[m]
+        kept = torch.nonzero(keep).flatten()  # one host round trip for the three outputs
+        return coord.index_select(0, kept), label.index_select(0, kept), weight.index_select(0, kept)
 
     def sample_pin(self, points_torch, normal_torch=None, sem_label_torch=None, color_torch=None, noise=None):
         """utils/data_sampler.py:16-258: 6-tuple (coord, sdf_label, normal_label, sem_label, color_label, weight)

@@ -52,9 +52,10 @@ class LocalPointCloudMap:
         """:43-61: one point per voxel of this scan, appended where the voxel's slot is still empty."""
         sample_points = points[voxel_down_sample_torch(points, self.resolution)]
         slots = self.voxel_hash(sample_points)
-        empty = self.buffer_pt_index[slots] == -1
-        fresh = sample_points[empty]
-        self._write_slots(self.buffer_pt_index, slots[empty], self.local_point_cloud_map.shape[0])
+        pos = torch.where(slots < 0, slots + self.buffer_size, slots)
+        empty = torch.nonzero(self.buffer_pt_index[pos] == -1).flatten()
+        fresh = sample_points.index_select(0, empty)
+        self._write_slots(self.buffer_pt_index, slots.index_select(0, empty), self.local_point_cloud_map.shape[0])
         self.local_point_cloud_map = torch.cat((self.local_point_cloud_map, fresh), 0)
 
     def update_map(self, sensor_position: torch.Tensor, points: torch.Tensor) -> None:

@@ -444,19 +444,21 @@ class Mapper:
             if kept.shape[0] > cfg.pool_capacity:
                 drop = torch.randint(0, kept.shape[0], (kept.shape[0] - cfg.pool_capacity,), device=keep.device)
                 keep[kept[drop]] = False
-            self.coord_pool = self.coord_pool[keep]
-            self.global_coord_pool = self.global_coord_pool[keep].contiguous()
-            self.sdf_label_pool = self.sdf_label_pool[keep].contiguous()
-            self.weight_pool = self.weight_pool[keep].contiguous()
-            self.time_pool = self.time_pool[keep].contiguous()
+                kept = torch.nonzero(keep).squeeze(1)
+            total = keep.shape[0]  # `kept` (one host round trip) sizes all pools
+            self.coord_pool = self.coord_pool.index_select(0, kept)
+            self.global_coord_pool = self.global_coord_pool.index_select(0, kept)
+            self.sdf_label_pool = self.sdf_label_pool.index_select(0, kept)
+            self.weight_pool = self.weight_pool.index_select(0, kept)
+            self.time_pool = self.time_pool.index_select(0, kept)
             if self.normal_label_pool is not None:
-                self.normal_label_pool = self.normal_label_pool[keep]
+                self.normal_label_pool = self.normal_label_pool.index_select(0, kept)
             if self.sem_label_pool is not None:
-                self.sem_label_pool = self.sem_label_pool[keep]
+                self.sem_label_pool = self.sem_label_pool.index_select(0, kept)
             if self.color_pool is not None:
-                self.color_pool = self.color_pool[keep]
-            self.cur_sample_count = int(keep[-n_cur:].sum().item()) if n_cur > 0 else 0
-            self.pool_sample_count = int(keep.sum().item())
+                self.color_pool = self.color_pool.index_select(0, kept)
+            self.cur_sample_count = int((kept >= total - n_cur).sum().item()) if n_cur > 0 else 0
+            self.pool_sample_count = kept.shape[0]
         else:
             self.cur_sample_count = n_cur
             self.pool_sample_count = self.coord_pool.shape[0]

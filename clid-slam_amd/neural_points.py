@@ -196,13 +196,13 @@ class NeuralPoints(nn.Module):
                 take = take | (gap > self.diff_travel_dist_local)
         else:
             take = torch.ones(held.shape, dtype=torch.bool, device=self.device)
-        added = sample_points[take]
+        taken = torch.nonzero(take).flatten()  # the one host round trip of the insert (sizes the appends)
+        added = sample_points.index_select(0, taken)
         n_new = added.shape[0]
         ratio = n_new / sample_points.shape[0]
         base = self.neural_points.shape[0]
-        held = held.clone()
-        held[take] = torch.arange(n_new, dtype=self.idx_dtype, device=self.device) + base
-        self.buffer_pt_index[slot] = held
+        rank = torch.cumsum(take, 0) - 1 + base  # index the i-th taken sample receives
+        self.buffer_pt_index[slot] = torch.where(take, rank, held)
         self.neural_points = torch.cat((self.neural_points, added), 0)
         quat = torch.zeros((n_new, 4), dtype=self.dtype, device=self.device)
         quat[:, 0] = 1.0
@@ -248,30 +248,36 @@ class NeuralPoints(nn.Module):
         local_ids = cand[d2 < self.local_map_radius**2]
         local_mask = torch.zeros(self.count() + 1, dtype=torch.bool, device=self.device)
         local_mask[local_ids] = True
-        self.local_neural_points = self.neural_points[local_mask[:-1]]
-        self.local_point_orientations = self.point_orientations[local_mask[:-1]]
-        self.local_point_certainties = self.point_certainties[local_mask[:-1]]
-        self.local_point_ts_update = self.point_ts_update[local_mask[:-1]]
+        # local_ids is ascending, so gathering by it == boolean-mask selection (without its host round trip)
+        self.local_neural_points = self.neural_points.index_select(0, local_ids)
+        self.local_point_orientations = self.point_orientations.index_select(0, local_ids)
+        self.local_point_certainties = self.point_certainties.index_select(0, local_ids)
+        self.local_point_ts_update = self.point_ts_update.index_select(0, local_ids)
         local_mask[-1] = True  # padding slot
         self.local_mask = local_mask
         g2l = torch.full((self.count() + 1,), -1, dtype=torch.long, device=self.device)
         g2l[local_ids] = torch.arange(local_ids.shape[0], device=self.device)
         self.global2local = g2l
-        self.local_geo_features = nn.Parameter(self.geo_features[local_mask])
+        with_pad = torch.cat((local_ids, torch.full((1,), self.count(), dtype=local_ids.dtype, device=local_ids.device)))
+        self.local_geo_features = nn.Parameter(self.geo_features.index_select(0, with_pad))
         if self.color_features is not None:
-            self.local_color_features = nn.Parameter(self.color_features[local_mask])
+            self.local_color_features = nn.Parameter(self.color_features.index_select(0, with_pad))
+        self._local_ids_pad = with_pad
         self.local_orientation = sensor_orientation
         self._local_ids = local_ids.contiguous()
         self._map_version += 1
 
     def assign_local_to_global(self):
         """model/neural_points.py:538-549."""
-        m = self.local_mask
-        self.geo_features[m] = self.local_geo_features.data
+        ids = getattr(self, "_local_ids", None)
+        if ids is None or ids.shape[0] != self.local_point_certainties.shape[0]:  # state installed from outside
+            ids = torch.nonzero(self.local_mask[:-1]).flatten()
+        pad = torch.cat((ids, torch.full((1,), self.count(), dtype=ids.dtype, device=ids.device)))
+        self.geo_features.index_copy_(0, pad, self.local_geo_features.data)
         if self.color_features is not None:
-            self.color_features[m] = self.local_color_features.data
-        self.point_certainties[m[:-1]] = self.local_point_certainties
-        self.point_ts_update[m[:-1]] = self.local_point_ts_update
+            self.color_features.index_copy_(0, pad, self.local_color_features.data)
+        self.point_certainties.index_copy_(0, ids, self.local_point_certainties)
+        self.point_ts_update.index_copy_(0, ids, self.local_point_ts_update)
 
     def recreate_hash(self, sensor_position=None, sensor_orientation=None, kept_points: bool = True,
                       with_ts: bool = True, cur_ts=0):
@@ -418,8 +424,8 @@ class NeuralPoints(nn.Module):
     def query_certainty(self, query_points: torch.Tensor):
         """model/neural_points.py:1032-1051."""
         _, idx = self.radius_neighborhood_search(query_points)
-        c = self.point_certainties[idx]
-        c[idx < 0] = 0.0
+        c = torch.where(idx < 0, torch.zeros((), dtype=self.point_certainties.dtype, device=idx.device),
+                        self.point_certainties[idx.clamp_min(0)])
         return torch.max(c, dim=-1)[0]
 
     def query_sdf_and_gradient(self, decoder, query_points: torch.Tensor):
