@@ -17,6 +17,7 @@ from __future__ import annotations
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -168,10 +169,12 @@ def main():
         _lib.check(lib.clid_profile_read(out, C.byref(n), _lib.stream()), "clid_profile_read")
         lib.clid_profile_enable(0)
         ov = out[4]
-        pipelined = out[1] > 0.0  # the loop ran as search(t+1) || decode(t) + Adam(t)  (clid_mapping_run)
+        pipelined = out[1] > 0.0  # hoisted searches: one search launch per chunk, then decode + Adam per iteration
         names = ("k_train_fused8<2> (decode)" if pipelined else "k_train_fused8", "k_train_fused8<1> (search)",
                  "k_reduce_partials", "k_adam_all")
         ms = [max(out[i] / max(n.value, 1) - ov, 0.0) for i in range(4)]
+        if pipelined:  # the search is bracketed once per chunk of <= 32 iterations, reported per iteration
+            ms[1] = max(out[1] - ov * math.ceil(n.value / 32), 0.0) / max(n.value, 1)
         decim = cfg.gradient_decimation
         Q = args.bs + 6 * ((args.bs + decim - 1) // decim)
         # algorithmic bytes per launch: search = 688 B per query point (position, 81 bucket
@@ -199,14 +202,14 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg[dom], "avg_launch_us": ms[dom] * 1e3,
             "per_kernel_us": {nme: round(m * 1e3, 2) for nme, m in zip(names, ms) if m > 0.0},
-            "pipelined": pipelined,
+            "hoisted_search": pipelined,
             "event_pair_overhead_us": round(ov * 1e3, 2),
             "step_bytes": sum(alg), "step_frac_of_peak": sum(alg) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
             "note": "hipEvent-bracketed launches on the launch stream in a separate pass of the same loop, minus the "
                     "measured cost of an empty event pair (rocprofv3 --kernel-trace average for the same kernel: "
-                    "profiles/r01_bench_v4_kernel_stats.csv, ~3 us higher because it spans dispatch to completion); "
+                    "profiles/r01_bench_v5_kernel_stats.csv, ~3 us higher because it spans dispatch to completion); "
                     "traffic = offline PMC passes (profiles/r01_hbm_traffic.json); the kernel is bound by dependent-load "
-                    "latency and instruction issue (profiles/r01_pmc_v4_summary.txt), not by HBM bandwidth",
+                    "latency and instruction issue (profiles/r01_pmc_v5_summary.txt), not by HBM bandwidth",
         }
     sync()
 
