@@ -117,8 +117,10 @@ __device__ __forceinline__ int group8_sum_i(int v) {
 }
 
 struct WaveHead {       // what the search phase produces (one record of kRecFloat4 float4 per task)
-  float4 qinfo[8];      // per query slot: x, y, z, pool sample index (int bits, -1 = padding)
-  float4 qdesc[8];      // per query slot: batch position (int bits, -1 = padding), axis (int bits), sign, -
+  float4 qinfo[8];      // per query slot: x, y, z, time stamp of the sample (int bits; -1 = padding slot, 0 for shifted copies)
+  float4 qdesc[8];      // per query slot: batch position (int bits, -1 = padding), axis/sign code (int bits: -1 = the
+                        // sample itself, else 2*axis + (sign > 0)), SDF label, loss weight -- everything the decode
+                        // phase needs of the pool, gathered while the search's own loads are in flight
   float2 win[8][8];     // per slot: up to K winners (d2, local id bits), ascending; (9e3, -1) = none
 };
 struct WaveLds : WaveHead {
@@ -266,8 +268,16 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
       if (qd.axis == 1) py = fadd(py, qd.sign * ta.fd_eps);
       if (qd.axis == 2) pz = fadd(pz, qd.sign * ta.fd_eps);
       if (lane8 == 0) {
-        hd.qinfo[slot8] = make_float4(px, py, pz, __int_as_float(live ? (int)s : -1));
-        hd.qdesc[slot8] = make_float4(__int_as_float(qd.p), __int_as_float(qd.axis), qd.sign, 0.f);
+        float label = 0.f, wt = 1.f;
+        int ts = live ? 0 : -1;
+        if (live && qd.axis < 0) {  // the sample itself: its label, weight (mapper.py:747-749) and time stamp
+          label = ta.pool_label[s];
+          if (ta.loss_weight_on) wt = fabsf(ta.pool_weight[s]);
+          if (ta.pool_ts) ts = ta.pool_ts[s];
+        }
+        const int code = qd.axis < 0 ? -1 : 2 * qd.axis + (qd.sign > 0.f ? 1 : 0);
+        hd.qinfo[slot8] = make_float4(px, py, pz, __int_as_float(ts));
+        hd.qdesc[slot8] = make_float4(__int_as_float(qd.p), __int_as_float(code), label, wt);
       }
       if (lane8 < CLID_K) hd.win[slot8][lane8] = make_float2(9e3f, __int_as_float(-1));  // np.py:606
       asm volatile("" ::"v"(px), "v"(py), "v"(pz));
@@ -328,7 +338,7 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
       float pre[CLID_HPL];
       const float sdf = mlp_forward(mlp, f, lane16, sc, pre);
       if (valid && !odd && !(ta.debug_flags & 1)) {  // training_mode side effects (np.py:708-733)
-        const int q_axis = __float_as_int(wl.qdesc[s16].y);
+        const int q_axis = __float_as_int(wl.qdesc[s16].y);  // -1 = the sample itself
         const bool shares = bundle && !(round == 1 && grp == 3);  // every slot but the unrelated 8th sample
         const int m = shares ? match_base(wl, my_j) : -1;
         if (m >= 0) atomicAdd(&wl.ccert[m], my_w);
@@ -336,7 +346,7 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
         if (q_axis < 0 && mv.ts_update) {
           // amax is idempotent: only the first touch of a point by a newer stamp needs the atomic (a scattered
           // atomic costs ~10x a scattered load: tools/ubench_gather.hip)
-          const int ts = ta.pool_ts[sidx];
+          const int ts = sidx;  // qinfo.w carries the sample's time stamp
           if (mv.ts_update[my_j] < ts) atomicMax(&mv.ts_update[my_j], ts);
         }
       }
@@ -364,9 +374,12 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
 #pragma unroll 1
     for (int round = 0; round < 2; ++round) {
       QDesc qd;
+      float q_label, q_wt;
       {
         const float4 qq = wl.qdesc[round * 4 + grp];
-        qd.p = __float_as_int(qq.x); qd.axis = __float_as_int(qq.y); qd.sign = qq.z;
+        const int code = __float_as_int(qq.y);
+        qd.p = __float_as_int(qq.x); qd.axis = code < 0 ? -1 : (code >> 1); qd.sign = (code & 1) ? 1.0f : -1.0f;
+        q_label = qq.z; q_wt = qq.w;
       }
       const float4 s0 = wl.st[round][lane][0], s1 = wl.st[round][lane][1];
       const float fb = s0.x, my_w = s0.y, sdf = s0.w;
@@ -374,9 +387,7 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
       float delta = 0.f;
       if (qd.p >= 0) {
         if (qd.axis < 0) {
-          const int sidx = __float_as_int(wl.qinfo[round * 4 + grp].w);
-          const float label = ta.pool_label[sidx];
-          const float wt = ta.loss_weight_on ? fabsf(ta.pool_weight[sidx]) : 1.0f;  // mapper.py:747-749
+          const float label = q_label, wt = q_wt;
           const float z = sdf * inv_sigma;
           const float tgt = __frcp_rn(1.0f + __expf(-label * inv_sigma));           // loss.py:60
           const float ez = __expf(-fabsf(z));
