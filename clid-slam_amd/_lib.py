@@ -27,8 +27,9 @@ _f32 = C.c_float
 class MapView(C.Structure):
     _fields_ = [
         ("tab", _vp), ("tab_pos", _vp), ("pos4", _vp), ("feat", _vp), ("cert", _vp), ("ts_update", _vp), ("delta", _vp),
+        ("filter", _vp),
         ("log2cap", _i32), ("M", _i32), ("P", _i32), ("buffer_size", _i32),
-        ("resolution", _f32), ("max_valid_dist2", _f32), ("layer_norm", _i32), ("reserved", _i32),
+        ("resolution", _f32), ("max_valid_dist2", _f32), ("layer_norm", _i32), ("log2filter", _i32),
     ]
 
 
@@ -76,7 +77,8 @@ class SamplerParams(C.Structure):
 _SIGS = {
     "clid_abi_version": (C.c_int, []),
     "clid_last_error": (C.c_char_p, []),
-    "clid_table_build": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _f32, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _i32, _vp, _vp]),
+    "clid_table_build": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _f32, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _i32, _vp, _vp, _i32,
+                                   _vp]),
     "clid_radius_search": (C.c_int, [C.POINTER(MapView), _vp, _i32, _vp, _vp, _vp]),
     "clid_query_fwd": (C.c_int, [C.POINTER(MapView), _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clid_query_bwd": (C.c_int, [C.POINTER(MapView), _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

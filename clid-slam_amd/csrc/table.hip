@@ -16,7 +16,7 @@ __global__ void k_table_build(const int64_t* __restrict__ ids, int n, const floa
                               const int64_t* __restrict__ big, int B, float res,
                               const int* __restrict__ ts_create, const float* __restrict__ travel,
                               int cur_ts, int time_filtering, float diff_travel, int4* tab,
-                              float4* tab_pos, int log2cap, float4* pos4) {
+                              float4* tab_pos, int log2cap, float4* pos4, unsigned* filter, int log2filter) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const long long gi = ids ? ids[j] : (long long)j;
@@ -27,6 +27,10 @@ __global__ void k_table_build(const int64_t* __restrict__ ids, int n, const floa
   if (time_filtering) {         // np.py:1003-1009
     const float gap = fabsf(fsub(travel[cur_ts], travel[ts_create[gi]]));
     if (!(gap < diff_travel)) return;
+  }
+  if (filter) {  // probe prefilter: one bit per key (csrc/train.hip, search-only kernel)
+    const unsigned b = filter_bit(slot, log2filter);
+    atomicOr(&filter[b >> 5], 1u << (b & 31));
   }
   // 4-key buckets, keys claimed in order (so "key3 taken" == bucket full); overflow walks to the next bucket
   const unsigned mask = (1u << log2cap) - 1u;
@@ -51,7 +55,7 @@ extern "C" int clid_table_build(const int64_t* ids, int32_t n, const float* neur
                                 const int32_t* point_ts_create, const float* travel_dist,
                                 int32_t cur_ts, int32_t time_filtering, float diff_travel,
                                 int32_t* tab_out, float* tab_pos_out, int32_t log2cap, float* pos4_out,
-                                void* stream) {
+                                uint32_t* filter_out, int32_t log2filter, void* stream) {
   if (n < 0 || log2cap < 5 || log2cap > 30 || buffer_size <= 0 || buffer_size >= (1LL << 30)) {
     clid_set_error("clid_table_build: bad argument (n=%d log2cap=%d buffer_size=%lld)", n, log2cap,
                    (long long)buffer_size);
@@ -61,8 +65,13 @@ extern "C" int clid_table_build(const int64_t* ids, int32_t n, const float* neur
     clid_set_error("clid_table_build: table capacity 4*2^%d < 2*n (n=%d) or null output", log2cap, n);
     return CLID_E_ARG;
   }
+  if (filter_out && (log2filter < 10 || log2filter > 30)) {
+    clid_set_error("clid_table_build: log2filter=%d out of range", log2filter);
+    return CLID_E_ARG;
+  }
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(tab_out, 0xFF, sizeof(int32_t) * 4 * ((size_t)1 << log2cap), s) != hipSuccess) {
+  if (hipMemsetAsync(tab_out, 0xFF, sizeof(int32_t) * 4 * ((size_t)1 << log2cap), s) != hipSuccess ||
+      (filter_out && hipMemsetAsync(filter_out, 0, sizeof(uint32_t) * (((size_t)1 << log2filter) / 32), s) != hipSuccess)) {
     clid_set_error("clid_table_build: memset failed");
     return CLID_E_HIP;
   }
@@ -70,7 +79,7 @@ extern "C" int clid_table_build(const int64_t* ids, int32_t n, const float* neur
   hipLaunchKernelGGL(clid::k_table_build, dim3((n + 255) / 256), dim3(256), 0, s, ids, n, neural_points,
                      buffer_pt_index, (int)buffer_size, resolution, point_ts_create, travel_dist, cur_ts,
                      time_filtering, diff_travel, reinterpret_cast<int4*>(tab_out), reinterpret_cast<float4*>(tab_pos_out), log2cap,
-                     reinterpret_cast<float4*>(pos4_out));
+                     reinterpret_cast<float4*>(pos4_out), filter_out, log2filter);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

@@ -144,8 +144,11 @@ __device__ __forceinline__ int match_base(const WaveLds& wl, int j) {
 constexpr int kProbeRows8 = 6;  // probes per lane per chunk; chunk = 48 slots
 
 // 81-cell search of one query by the 8 lanes of a group; winners -> win[0..K)
+// `filt` (optional, LDS): bit per stored slot; a probe whose bit is clear cannot match and is not loaded
+template <bool FILTER>
 __device__ __forceinline__ void search8(const clid_map_view& mv, const DeltaLds& dl, float x, float y, float z,
-                                        int lane8, int gshift, float2* __restrict__ win) {
+                                        int lane8, int gshift, float2* __restrict__ win,
+                                        const unsigned* __restrict__ filt = nullptr) {
   const int4* __restrict__ tab = reinterpret_cast<const int4*>(mv.tab);
   const float4* __restrict__ tpos = reinterpret_cast<const float4*>(mv.tab_pos);
   const int B = mv.buffer_size;
@@ -161,10 +164,17 @@ __device__ __forceinline__ void search8(const clid_map_view& mv, const DeltaLds&
       const int o = o0 + 8 * t + lane8;
       int sl = r0 + dl.d[o];
       if (sl >= B) sl -= B;
-      const bool in = o < mv.P;
+      bool in = o < mv.P;
       slot[t] = in ? sl : -2;
       home[t] = tab_home(sl, mv.log2cap);
-      bk[t] = tab[in ? home[t] : 0];
+      if constexpr (FILTER) {
+        const unsigned b = filter_bit(sl, mv.log2filter);
+        in = in && ((filt[b >> 5] >> (b & 31)) & 1u);
+        bk[t] = make_int4(-1, -1, -1, -1);  // "empty bucket": no match, no walk
+        if (in) bk[t] = tab[home[t]];
+      } else {
+        bk[t] = tab[in ? home[t] : 0];
+      }
     }
     int cell[kProbeRows8];
     bool walk = false;
@@ -213,15 +223,18 @@ constexpr int kRecFloat4 = 48;
 template <int MODE>
 __global__ void __launch_bounds__(kFusedBlock, CLID_FUSED_WAVES)
 k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap,
-               float4* __restrict__ rec, int n_iter, long long index_stride) {
+               float4* __restrict__ rec, int n_iter, long long index_stride, int use_filter) {
   __shared__ MlpLds mlp;
   __shared__ DeltaLds dl;
   __shared__ WaveLds wlds[MODE == 1 ? 1 : kFusedBlock / 64];
   __shared__ WaveHead heads[MODE == 1 ? kFusedBlock / 64 : 1];  // the search-only kernel keeps just the record
   __shared__ float red[(kFusedBlock / 64) * kRedFloats];
+  extern __shared__ unsigned filt_lds[];  // MODE 1 with a prefilter: 2^log2filter bits (dynamic LDS)
   static_assert(sizeof(WaveHead) == kRecFloat4 * sizeof(float4), "record layout");
   if constexpr (MODE == 1) {
     stage_delta(dl, mv);
+    if (use_filter)
+      for (int i = threadIdx.x; i < (1 << mv.log2filter) / 32; i += kFusedBlock) filt_lds[i] = mv.filter[i];
     __syncthreads();
   } else if constexpr (MODE == 2) {
     stage_mlp(mlp, ta.W1, ta.b1, ta.W2, ta.b2);
@@ -282,7 +295,8 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
       if (lane8 < CLID_K) hd.win[slot8][lane8] = make_float2(9e3f, __int_as_float(-1));  // np.py:606
       asm volatile("" ::"v"(px), "v"(py), "v"(pz));
       CLID_STAMP(1);
-      search8(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
+      if (MODE == 1 && use_filter) search8<true>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], filt_lds);
+      else search8<false>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
     }
     CLID_STAMP(3);
     if constexpr (MODE == 1) {
@@ -779,7 +793,7 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
     if (int e = clid_launch_train_analytic(mv, a, ws.partial, s)) return e;
   } else {
     hipLaunchKernelGGL(k_train_fused8<0>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap,
-                       (float4*)nullptr, 1, 0LL);
+                       (float4*)nullptr, 1, 0LL, 0);
     CLID_CHECK_LAUNCH();
   }
   prof_end(h, s);
@@ -885,6 +899,15 @@ static int pipeline_mode() {
   return g_pipeline;
 }
 
+static bool filter_enabled() {  // CLID_FILTER=0 turns the probe prefilter off (measurement aid)
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("CLID_FILTER");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return on != 0;
+}
+
 static int check_train_args(const clid_map_view* mv, const clid_train_args* a, const char* who) {
   if (!mv || !a || !mv->tab || !mv->tab_pos || !mv->delta) {
     clid_set_error("%s: null argument", who);
@@ -929,8 +952,13 @@ extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args*
   long long sb = ((long long)tmap.n_tasks * n_iter + kFusedBlock / 64 - 1) / (kFusedBlock / 64);
   if (sb > kSearchBlocks) sb = kSearchBlocks;
   const int h = prof_begin(1, s);
-  hipLaunchKernelGGL(k_train_fused8<1>, dim3((unsigned)sb), dim3(kFusedBlock), 0, s, *mv, t2, (float*)nullptr, tmap,
-                     reinterpret_cast<float4*>(rec_out), n_iter, (long long)index_stride);
+  // probe prefilter in LDS when the map provides one that fits (<= 32 KB) and the launch is large enough to
+  // amortise staging it per block
+  const bool use_filter = mv->filter && mv->log2filter >= 10 && mv->log2filter <= 18 && filter_enabled() &&
+                          (long long)tmap.n_tasks * n_iter >= 4 * sb * (kFusedBlock / 64);
+  const size_t dyn = use_filter ? ((size_t)1 << mv->log2filter) / 8 : 0;
+  hipLaunchKernelGGL(k_train_fused8<1>, dim3((unsigned)sb), dim3(kFusedBlock), dyn, s, *mv, t2, (float*)nullptr, tmap,
+                     reinterpret_cast<float4*>(rec_out), n_iter, (long long)index_stride, use_filter ? 1 : 0);
   CLID_CHECK_LAUNCH();
   prof_end(h, s);
   return CLID_OK;
@@ -951,7 +979,7 @@ extern "C" int clid_train_decode(const clid_map_view* mv, const clid_train_args*
   const int nb = fused_blocks(tmap.n_tasks);
   int h = prof_begin(0, s);
   hipLaunchKernelGGL(k_train_fused8<2>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap,
-                     reinterpret_cast<float4*>(const_cast<float*>(rec)), 1, 0LL);
+                     reinterpret_cast<float4*>(const_cast<float*>(rec)), 1, 0LL, 0);
   CLID_CHECK_LAUNCH();
   prof_end(h, s);
   if (!a->defer_reduce) {

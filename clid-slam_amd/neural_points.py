@@ -351,6 +351,11 @@ class NeuralPoints(nn.Module):
         tab = torch.empty((1 << log2cap, 4), device=pts.device, dtype=torch.int32)
         tab_pos = torch.zeros((1 << log2cap, 4, 4), device=pts.device, dtype=torch.float32)
         pos4 = torch.empty((max(n, 1), 4), device=pts.device, dtype=torch.float32)
+        # probe prefilter (one-hash Bloom filter over the stored slots): 8 bits per key where possible, at most
+        # 32 KB so the chunked search kernel can keep it in LDS next to its other state; very large local maps
+        # (> 128 k points, < 2 bits per key) go without
+        log2filter = min(18, max(13, int(math.ceil(math.log2(max(8 * n, 32))))))
+        filt = torch.empty(((1 << log2filter) // 32,), device=pts.device, dtype=torch.int32) if n <= (1 << 17) else None
         tsc = self.point_ts_create if time_filtering else None
         trv = self.travel_dist.to(torch.float32).contiguous() if time_filtering else None
         _lib.check(
@@ -358,17 +363,17 @@ class NeuralPoints(nn.Module):
                                  float(self.resolution), _lib.ptr(tsc), _lib.ptr(trv), int(self.cur_ts),
                                  int(time_filtering), float(self.diff_travel_dist_local), _lib.ptr(tab), _lib.ptr(tab_pos),
                                  log2cap,
-                                 _lib.ptr(pos4), _lib.stream()),
+                                 _lib.ptr(pos4), _lib.ptr(filt), log2filter, _lib.stream()),
             "clid_table_build",
         )
-        self._tables[slot] = (key, (tab, tab_pos), pos4, log2cap)
-        return (tab, tab_pos), pos4, log2cap
+        self._tables[slot] = (key, (tab, tab_pos, filt, log2filter), pos4, log2cap)
+        return (tab, tab_pos, filt, log2filter), pos4, log2cap
 
     def _map_view(self, query_locally: bool, time_filtering=None):
         """Fill a clid_map_view for the current tensors.  Returns (view, keep_alive)."""
         if time_filtering is None:
             time_filtering = bool(self.temporal_local_map_on and query_locally)
-        (tab, tab_pos), pos4, log2cap = self._table(query_locally, time_filtering)
+        (tab, tab_pos, filt, log2filter), pos4, log2cap = self._table(query_locally, time_filtering)
         if query_locally:
             feat, cert, tsu = self.local_geo_features.data, self.local_point_certainties, self.local_point_ts_update
         else:
@@ -382,12 +387,13 @@ class NeuralPoints(nn.Module):
         v.feat, v.cert = feat.data_ptr(), cert.data_ptr()
         v.ts_update = tsu.data_ptr() if tsu is not None else None
         v.delta = self._delta.data_ptr()
+        v.filter, v.log2filter = (None, 0) if filt is None else (filt.data_ptr(), log2filter)
         v.log2cap, v.M, v.P = log2cap, cert.shape[0], int(self.neighbor_K)
         v.buffer_size = int(self.buffer_size)
         v.resolution = float(self.resolution)
         v.max_valid_dist2 = float(self.max_valid_dist2)
         v.layer_norm = int(bool(self.config.layer_norm_on))
-        return v, (tab, tab_pos, pos4, feat, cert, tsu, self._delta)
+        return v, (tab, tab_pos, filt, pos4, feat, cert, tsu, self._delta)
 
     # ------------------------------------------------------------------ hot methods
     def query_feature(self, query_points: torch.Tensor, query_ts: torch.Tensor = None, training_mode: bool = True,

@@ -55,6 +55,7 @@ typedef struct clid_map_view {
   float* cert;             /* [M] point certainties (read; +atomicAdd when training_mode) */
   int32_t* ts_update;      /* [M] last-update stamps (atomicMax when query_ts given), may be NULL */
   const int32_t* delta;    /* [P] (sum_c dx_c * prime_c) mod buffer_size, non-negative */
+  const uint32_t* filter;  /* [2^log2filter / 32] probe prefilter: bit set for every key of `tab` (may be NULL) */
   int32_t log2cap;
   int32_t M;
   int32_t P;               /* neighbor_K, 81 for num_nei_cells=2, search_alpha=0.5 (np.py:931-969) */
@@ -62,7 +63,7 @@ typedef struct clid_map_view {
   float resolution;        /* voxel_size_m */
   float max_valid_dist2;   /* 3*((num_nei_cells+1)*res)^2 */
   int32_t layer_norm;      /* config.layer_norm_on */
-  int32_t reserved;
+  int32_t log2filter;      /* bits of `filter`, >= 8 per key recommended (false-positive rate <= 12 %) */
 } clid_map_view;
 
 /* Builds the compact probe table for one (map, window, time-filter) state.
@@ -73,12 +74,15 @@ typedef struct clid_map_view {
  *   ids            [n] int64 global point index of local point j, or NULL for identity (global map)
  *   neural_points  [Mg][3], buffer_pt_index [buffer_size] int64, point_ts_create [Mg] int32
  *   tab_out        [2^log2cap][4] int32 keys (4-key buckets, 2^log2cap >= n/2 ... load <= 0.5 keys/bucket
- *                  recommended), tab_pos_out [2^log2cap][4][4] f32, pos4_out [n][4] */
+ *                  recommended), tab_pos_out [2^log2cap][4][4] f32, pos4_out [n][4]
+ *   filter_out     [2^log2filter / 32] u32 or NULL: one-hash Bloom filter over the stored slot numbers; the
+ *                  chunked search kernel keeps it in LDS and skips the probes it rules out (never a false
+ *                  negative, so results are unchanged) */
 int clid_table_build(const int64_t* ids, int32_t n, const float* neural_points,
                      const int64_t* buffer_pt_index, int64_t buffer_size, float resolution,
                      const int32_t* point_ts_create, const float* travel_dist, int32_t cur_ts,
                      int32_t time_filtering, float diff_travel, int32_t* tab_out, float* tab_pos_out,
-                     int32_t log2cap, float* pos4_out, void* stream);
+                     int32_t log2cap, float* pos4_out, uint32_t* filter_out, int32_t log2filter, void* stream);
 
 /* NeuralPoints.radius_neighborhood_search (model/neural_points.py:971-1030).
  * dist2_out [N][P] f32, idx_out [N][P] int32 (ids of the view, -1 invalid). */
