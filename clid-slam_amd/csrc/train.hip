@@ -143,18 +143,61 @@ __device__ __forceinline__ int match_base(const WaveLds& wl, int j) {
 
 constexpr int kProbeRows8 = 6;  // probes per lane per chunk; chunk = 48 slots
 
-// 81-cell search of one query by the 8 lanes of a group; winners -> win[0..K)
+// Per-lane sorted candidate list of DEPTH entries.  The 81 probes of a query are spread over 8 lanes, so a lane
+// almost never owns more than 3 of the 6 winners: the throughput (search-only) kernel runs with DEPTH = 3 -- half
+// the compare/select work of the insert, which is 40 % of the search's instructions -- and remembers the best
+// distance it ever pushed out; if that could have been a winner the wave repeats the search at full depth.
+template <int DEPTH>
+struct CandN {
+  float d[DEPTH];
+  int j[DEPTH];
+  float dropped;
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) {
+      d[s] = __builtin_inff();
+      j[s] = -1;
+    }
+    dropped = __builtin_inff();
+  }
+  __device__ __forceinline__ void insert(float nd, int nj) {
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) {
+      const bool lt = nd < d[s];
+      const float td = lt ? d[s] : nd;
+      const int tj = lt ? j[s] : nj;
+      d[s] = lt ? nd : d[s];
+      j[s] = lt ? nj : j[s];
+      nd = td;
+      nj = tj;
+    }
+    if (DEPTH < CLID_K) dropped = fminf(dropped, nd);
+  }
+  __device__ __forceinline__ void pop() {
+#pragma unroll
+    for (int s = 0; s < DEPTH - 1; ++s) {
+      d[s] = d[s + 1];
+      j[s] = j[s + 1];
+    }
+    d[DEPTH - 1] = __builtin_inff();
+    j[DEPTH - 1] = -1;
+  }
+};
+
+// 81-cell search of one query by the 8 lanes of a group; winners -> win[0..K).  Returns true when a DEPTH < K
+// list may have lost a winner (the caller then repeats with DEPTH = K).
 // `filt` (optional, LDS): bit per stored slot; a probe whose bit is clear cannot match and is not loaded
-template <bool FILTER>
-__device__ __forceinline__ void search8(const clid_map_view& mv, const DeltaLds& dl, float x, float y, float z,
+template <bool FILTER, int DEPTH>
+__device__ __forceinline__ bool search8(const clid_map_view& mv, const DeltaLds& dl, float x, float y, float z,
                                         int lane8, int gshift, float2* __restrict__ win,
                                         const unsigned* __restrict__ filt = nullptr) {
   const int4* __restrict__ tab = reinterpret_cast<const int4*>(mv.tab);
   const float4* __restrict__ tpos = reinterpret_cast<const float4*>(mv.tab_pos);
   const int B = mv.buffer_size;
   const int r0 = base_slot(x, y, z, mv.resolution, B);
-  Cand c;
+  CandN<DEPTH> c;
   c.init();
+  if (lane8 < CLID_K) win[lane8] = make_float2(9e3f, __int_as_float(-1));  // np.py:606
   for (int o0 = 0; o0 < mv.P; o0 += 8 * kProbeRows8) {
     int slot[kProbeRows8];
     unsigned home[kProbeRows8];
@@ -200,10 +243,11 @@ __device__ __forceinline__ void search8(const clid_map_view& mv, const DeltaLds&
     }
   }
   CLID_STAMP(2);
+  float m = 0.f;
 #pragma unroll
   for (int k = 0; k < CLID_K; ++k) {
     const float head = c.d[0];
-    const float m = group8_min(head);
+    m = group8_min(head);
     const bool mine = (head == m) && (c.j[0] >= 0);
     const unsigned long long b = __ballot(mine);
     const unsigned gb = (unsigned)(b >> gshift) & 0xFFu;
@@ -212,6 +256,8 @@ __device__ __forceinline__ void search8(const clid_map_view& mv, const DeltaLds&
       c.pop();
     }
   }
+  // m = distance of the 6th winner (inf when fewer were found): anything pushed out at or below it is suspect
+  return DEPTH < CLID_K && c.dropped <= m && c.dropped < __builtin_inff();
 }
 
 constexpr int kFusedBlock = 512;  // 8 waves share one partial row: half as many rows for k_adam_all to reduce
@@ -292,11 +338,17 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
         hd.qinfo[slot8] = make_float4(px, py, pz, __int_as_float(ts));
         hd.qdesc[slot8] = make_float4(__int_as_float(qd.p), __int_as_float(code), label, wt);
       }
-      if (lane8 < CLID_K) hd.win[slot8][lane8] = make_float2(9e3f, __int_as_float(-1));  // np.py:606
       asm volatile("" ::"v"(px), "v"(py), "v"(pz));
       CLID_STAMP(1);
-      if (MODE == 1 && use_filter) search8<true>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], filt_lds);
-      else search8<false>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
+      if constexpr (MODE == 1) {
+        bool redo;
+        if (use_filter) redo = search8<true, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], filt_lds);
+        else redo = search8<false, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
+        if (__any(redo) || (ta.debug_flags & 4))  // rare (debug bit 2 forces it: tests compare the two paths)
+          search8<false, CLID_K>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
+      } else {
+        search8<false, CLID_K>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
+      }
     }
     CLID_STAMP(3);
     if constexpr (MODE == 1) {

@@ -182,7 +182,8 @@ typedef struct clid_train_args {
   /* workspace, sized by clid_train_workspace_floats() */
   float* ws;
   float* loss_out;           /* [4] total,bce,eik,unused (+=) */
-  int32_t debug_flags;       /* 0 in production; bit 0 / bit 1 suppress the certainty / gradient atomics (timing ablation) */
+  int32_t debug_flags;       /* 0 in production; bit 0 / bit 1 suppress the certainty / gradient atomics (timing ablation);
+                                bit 2 makes clid_train_search take its full-depth path for every wave (tests) */
   int32_t pad1;
 } clid_train_args;
 

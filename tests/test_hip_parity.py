@@ -553,3 +553,40 @@ def test_dense_sdf_query_vs_oracle(env, ln, loc):
     assert maxerr(sdf, ref) <= 2e-6
     assert torch.equal(mask.cpu().bool(), nn >= 4)
     assert (nn == 0).any() and (nn >= 4).any()
+
+
+def test_search_records_short_lists_equal_full_depth():
+    """The chunked search keeps 3 candidates per lane and repeats a wave at full depth when one it pushed out
+    could have been a winner; forcing the full-depth path for every wave (debug bit 2) must give bit-identical
+    records, at the full batch size and over several iterations, with and without the probe prefilter."""
+    import ctypes as C
+    import bench
+    from clid_slam_amd import HotPathConfig, _lib
+
+    lib = _lib.load()
+    cfg = HotPathConfig()
+    cfg.device = "cuda:0"
+    nm, dec, mp, scene = bench.build_scene(cfg, "cuda:0")
+    bs, iters, decim = 16384, 3, cfg.gradient_decimation
+    idx = torch.randint(0, mp.pool_sample_count, (iters, bs), device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+    view, keep = nm._map_view(True)
+    ta = _lib.TrainArgs()
+    ta.pool_coord, ta.pool_label = mp.global_coord_pool.data_ptr(), mp.sdf_label_pool.data_ptr()
+    ta.pool_ts, ta.pool_weight = mp.time_pool.data_ptr(), mp.weight_pool.data_ptr()
+    ta.bs, ta.decimation, ta.batch_offset, ta.eikonal_mode, ta.loss_weight_on = bs, decim, 0, 1, 1
+    ta.fd_eps = float(cfg.voxel_size_m * cfg.num_grad_step_ratio)
+    n = int(lib.clid_train_search_floats(bs, 0, decim, 1, iters))
+    recs = []
+    for flags in (0, 4):
+        ta.debug_flags = flags
+        rec = torch.zeros(n, device="cuda")
+        _lib.check(lib.clid_train_search(C.byref(view), C.byref(ta), iters, idx.data_ptr(), bs, rec.data_ptr(),
+                                         _lib.stream()), "clid_train_search")
+        torch.cuda.synchronize()
+        recs.append(rec.view(-1, 48, 4).cpu())
+    a, b = recs
+    assert torch.equal(a[:, :16].contiguous().view(torch.int32), b[:, :16].contiguous().view(torch.int32))  # positions, descriptors, labels (bit patterns)
+    wa, wb = a[:, 16:].reshape(-1, 8, 8, 2)[:, :, :6], b[:, 16:].reshape(-1, 8, 8, 2)[:, :, :6]
+    assert torch.equal(wa.contiguous().view(torch.int32), wb.contiguous().view(torch.int32))
+    found = (wa[..., 1].contiguous().view(torch.int32) >= 0).float().mean()
+    assert found > 0.5  # the comparison is not vacuous
