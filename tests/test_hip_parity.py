@@ -590,3 +590,50 @@ def test_search_records_short_lists_equal_full_depth():
     assert torch.equal(wa.contiguous().view(torch.int32), wb.contiguous().view(torch.int32))
     found = (wa[..., 1].contiguous().view(torch.int32) >= 0).float().mean()
     assert found > 0.5  # the comparison is not vacuous
+
+
+SWEEP = [
+    # (bs, decimation, num_nei_cells, search_alpha, layer_norm, loss_weight_on, eikonal)
+    (37, 10, 2, 0.5, 0, True, True),      # tiny ragged batch: one partial lattice block + tail task
+    (1000, 3, 2, 0.5, 0, True, True),     # sparsest task packing (2 tasks per 3 samples)
+    (1001, 2, 2, 0.5, 1, True, True),     # every second sample on the lattice, odd batch, layer norm
+    (513, 7, 1, 1.0, 0, False, True),     # 27-cell neighbourhood (P = 27), unweighted loss
+    (640, 10, 3, 0.2, 0, True, True),     # 147-cell neighbourhood (P > 96: two probe chunks of the 16-lane search too)
+    (777, 10, 2, 0.5, 0, True, False),    # eikonal term off: plain tasks only
+    (256, 1, 2, 0.5, 0, True, True),      # numerical eikonal on EVERY sample (bundles only)
+]
+
+
+@pytest.mark.parametrize("bs,decim,nnc,alpha,ln,lw,eik", SWEEP)
+def test_mapping_loop_configuration_sweep_vs_oracle(env, bs, decim, nnc, alpha, ln, lw, eik):
+    """The fused loop against the pinned CPU oracle across batch shapes, decimations and search neighbourhoods
+    the golden fixtures do not cover (2 iterations, fresh random batches)."""
+    p = gio.load("pool.npz")
+    g = gio.load("g6_loop_numerical_train_ln0.npz")
+    iters = 2
+    cfg = env.config(layer_norm_on=bool(ln), bs=bs, gradient_decimation=decim, num_nei_cells=nnc, search_alpha=alpha,
+                     loss_weight_on=lw, ekional_loss_on=eik)
+    gen = torch.Generator().manual_seed(1000 + bs)
+    idx = torch.randint(0, p["coord"].shape[0], (iters, bs), generator=gen)
+    nm = env.neural_points(cfg, base=p)
+    nm.set_search_neighborhood(num_nei_cells=nnc, search_alpha=alpha)
+    dec = env.decoder(cfg, g, "init_")
+    mp, _ = env.mapper(cfg, nm, dec)
+    mp.mapping(iters, index_seq=idx.cuda())
+    st = gio.map_state(layer_norm_on=bool(ln))
+    st.neighbor_dx, st.max_valid_dist2 = O.search_neighborhood(nnc, alpha, cfg.voxel_size_m)
+    st.local_geo_features = gio.T(p["base_geo_features"])[gio.T(g["local_mask"])].clone()
+    st.local_point_certainties = gio.T(p["base_point_certainties"])[gio.T(g["local_mask"])[:-1]].clone()
+    st.local_point_ts_update = gio.T(p["base_point_ts_update"])[gio.T(g["local_mask"])[:-1]].clone()
+    pool, _ = gio.sample_pool()
+    od = gio.decoder(g, "init_")
+    lc = O.LoopConfig(numerical_grad=True, gradient_decimation=decim, loss_weight_on=lw, ekional_loss_on=eik)
+    recs = O.mapping_iters(st, od, pool, idx, lc, record=True)
+    got = mp.last_losses.cpu()
+    for it, r in enumerate(recs):
+        assert abs(float(got[it, 0]) - float(r["loss"])) <= 2e-5, (it, got[it], r["loss"])
+    assert maxerr(nm.local_geo_features, recs[-1]["theta"]) <= 1e-4
+    for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
+        assert maxerr(t, o) <= 1e-4
+    assert maxerr(nm.local_point_certainties, recs[-1]["certainties"]) <= 2e-3
+    assert torch.equal(nm.local_point_ts_update.cpu(), recs[-1]["ts_update"])
