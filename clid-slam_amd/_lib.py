@@ -98,6 +98,8 @@ _SIGS = {
     "clid_region_sdf": (C.c_int, [C.POINTER(CloudView), _vp, _i32, _vp, _vp, _vp]),
     "clid_sample_frame": (C.c_int, [C.POINTER(CloudView), C.POINTER(SamplerParams), _vp, _i32, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp]),
+    "clid_voxel_workspace_bytes": (_i64, [_i32]),
+    "clid_voxel_down_sample": (C.c_int, [_vp, _i32, _f32, _vp, _vp, _vp]),
     "clid_mapping_pipeline": (C.c_int, [C.c_int]),
     "clid_train_search_floats": (_i64, [_i32, _i64, _i32, _i32, _i32]),
     "clid_train_search": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), _i32, _vp, _i64, _vp, _vp]),

@@ -1,0 +1,224 @@
+// Map maintenance on the device ("next" row N4 of SURVEY.md section 8f): the per-frame steps around the hot path
+// that the reference runs as long chains of small torch ops.
+//
+//   clid_voxel_down_sample   voxel_down_sample_torch (utils/tools.py:639-682): one point per voxel, the one closest
+//                            to the voxel centre (distance quantised to 1000 levels, lowest index among equals),
+//                            voxels in ascending order of the reference's linear voxel id.  The reference does it
+//                            with unique + scatter_reduce(amin) (non-deterministic on the GPU by its own comment);
+//                            here: bounding box reduction -> hash-table insert with a 64-bit atomicMin of
+//                            (quantised distance, index) per voxel -> compaction -> radix sort of the surviving
+//                            voxels only.  Deterministic.
+//
+// HBM-bound integer work: no LDS tiling, no MFMA; atomics are the scattered kind (one per point).
+#include <hipcub/hipcub.hpp>
+
+#include "common.hpp"
+
+namespace clid {
+
+struct VoxStats {
+  int lo[3];         // min coordinate per axis, order-preserving int encoding of the float
+  int hi[3];         // max coordinate per axis
+  unsigned dmax;     // max distance to the voxel centre (non-negative float bits order like unsigned ints)
+  unsigned count;    // number of occupied voxels (filled by the compaction)
+  long long stride;  // v = max over axes of (cell - offset), the reference's linearisation stride
+};
+
+__device__ __forceinline__ int ordered(float f) {
+  const int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__host__ __device__ __forceinline__ float unordered(int i) {
+  const int b = i >= 0 ? i : i ^ 0x7fffffff;
+#ifdef __HIP_DEVICE_COMPILE__
+  return __int_as_float(b);
+#else
+  float f;
+  memcpy(&f, &b, 4);
+  return f;
+#endif
+}
+
+__device__ __forceinline__ float centre_dist(float x, float y, float z, float v, float* cx, float* cy, float* cz) {
+  *cx = floorf(fdiv(x, v)); *cy = floorf(fdiv(y, v)); *cz = floorf(fdiv(z, v));  // tools.py:654
+  const float dx = fsub(x, fmul(fadd(*cx, 0.5f), v)), dy = fsub(y, fmul(fadd(*cy, 0.5f), v)),
+              dz = fsub(z, fmul(fadd(*cz, 0.5f), v));                               // :655-656
+  return sqrtf(fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz)));
+}
+
+__global__ void __launch_bounds__(256) k_vox_stats(const float* __restrict__ pts, int n, float v, VoxStats* st) {
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  unsigned dm = 0u;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+    float cx, cy, cz;
+    const float d = centre_dist(x, y, z, v, &cx, &cy, &cz);
+    const int ox = ordered(x), oy = ordered(y), oz = ordered(z);
+    lo[0] = min(lo[0], ox); lo[1] = min(lo[1], oy); lo[2] = min(lo[2], oz);
+    hi[0] = max(hi[0], ox); hi[1] = max(hi[1], oy); hi[2] = max(hi[2], oz);
+    dm = max(dm, (unsigned)__float_as_int(d));
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      lo[a] = min(lo[a], __shfl_xor(lo[a], o, 64));
+      hi[a] = max(hi[a], __shfl_xor(hi[a], o, 64));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) dm = max(dm, (unsigned)__shfl_xor((int)dm, o, 64));
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      atomicMin(&st->lo[a], lo[a]);
+      atomicMax(&st->hi[a], hi[a]);
+    }
+    atomicMax(&st->dmax, dm);
+  }
+}
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33;
+  return k;
+}
+
+__global__ void __launch_bounds__(256) k_vox_insert(const float* __restrict__ pts, int n, float v, VoxStats* st,
+                                                    long long* keys, unsigned long long* vals, int log2cap) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // tools.py:653, :661-663: offset = floor(min / v); stride = max(cell - offset) over ALL axes (not max + 1: voxels
+  // whose coordinate equals the stride alias another voxel, reproduced on purpose -- it decides which points exist)
+  long long off[3], stride = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    off[a] = (long long)floorf(fdiv(unordered(st->lo[a]), v));
+    const long long top = (long long)floorf(fdiv(unordered(st->hi[a]), v)) - off[a];
+    stride = top > stride ? top : stride;
+  }
+  if (i == 0) st->stride = stride;
+  const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+  float cx, cy, cz;
+  const float d = centre_dist(x, y, z, v, &cx, &cy, &cz);
+  const float dmax = __int_as_float((int)st->dmax);
+  const long long q = dmax > 0.f ? (long long)fmul(fdiv(d, dmax), 999.0f) : 0;  // :657-659
+  const long long gx = (long long)cx - off[0], gy = (long long)cy - off[1], gz = (long long)cz - off[2];
+  const long long flat = gx + gy * stride + gz * stride * stride;
+  const unsigned long long pack = ((unsigned long long)q << 32) | (unsigned)i;  // min == (smallest q, then smallest index)
+  const unsigned long long mask = (1ULL << log2cap) - 1ULL;
+  unsigned long long h = mix64((unsigned long long)flat) & mask;
+  for (;;) {
+    const long long prev = (long long)atomicCAS(reinterpret_cast<unsigned long long*>(&keys[h]), ~0ULL, (unsigned long long)flat);
+    if (prev == -1LL || prev == flat) {
+      atomicMin(&vals[h], pack);
+      return;
+    }
+    h = (h + 1) & mask;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_vox_compact(const long long* __restrict__ keys,
+                                                     const unsigned long long* __restrict__ vals, int log2cap,
+                                                     VoxStats* st, long long* flat_out, long long* idx_out) {
+  const long long h = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= (1LL << log2cap)) return;
+  const long long k = keys[h];
+  if (k == -1LL) return;
+  const unsigned pos = atomicAdd(&st->count, 1u);
+  flat_out[pos] = k;
+  idx_out[pos] = (long long)(vals[h] & 0xffffffffULL);
+}
+
+static int vox_log2cap(int n) {
+  int l = 10;
+  while ((1LL << l) < 2LL * n) ++l;
+  return l;
+}
+
+}  // namespace clid
+
+using namespace clid;
+
+static size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
+
+struct VoxLayout {
+  size_t stats, keys, vals, flat_a, idx_a, flat_b, cub, total, cub_bytes;
+};
+
+static VoxLayout vox_layout(int n) {
+  VoxLayout L;
+  const size_t cap = (size_t)1 << vox_log2cap(n);
+  size_t o = 0;
+  L.stats = o; o += align256(sizeof(VoxStats));
+  L.keys = o; o += align256(cap * 8);
+  L.vals = o; o += align256(cap * 8);
+  L.flat_a = o; o += align256((size_t)n * 8);
+  L.idx_a = o; o += align256((size_t)n * 8);
+  L.flat_b = o; o += align256((size_t)n * 8);
+  size_t tmp = 0;
+  hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const long long*)nullptr, (long long*)nullptr, (const long long*)nullptr,
+                                     (long long*)nullptr, n);
+  L.cub_bytes = tmp;
+  L.cub = o; o += align256(tmp);
+  L.total = o;
+  return L;
+}
+
+extern "C" int64_t clid_voxel_workspace_bytes(int32_t n) {
+  if (n <= 0) return 256;
+  return (int64_t)vox_layout(n).total;
+}
+
+extern "C" int clid_voxel_down_sample(const float* points, int32_t n, float voxel_size, void* workspace,
+                                      int64_t* idx_out, void* stream) {
+  if (n < 0 || !(voxel_size > 0.f) || (n > 0 && (!points || !workspace || !idx_out))) {
+    clid_set_error("clid_voxel_down_sample: bad argument");
+    return CLID_E_ARG;
+  }
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const VoxLayout L = vox_layout(n);
+  char* ws = static_cast<char*>(workspace);
+  VoxStats* st = reinterpret_cast<VoxStats*>(ws + L.stats);
+  long long* keys = reinterpret_cast<long long*>(ws + L.keys);
+  unsigned long long* vals = reinterpret_cast<unsigned long long*>(ws + L.vals);
+  long long* flat_a = reinterpret_cast<long long*>(ws + L.flat_a);
+  long long* idx_a = reinterpret_cast<long long*>(ws + L.idx_a);
+  long long* flat_b = reinterpret_cast<long long*>(ws + L.flat_b);
+  const int log2cap = vox_log2cap(n);
+  VoxStats init;
+  for (int a = 0; a < 3; ++a) { init.lo[a] = 0x7fffffff; init.hi[a] = (int)0x80000000; }
+  init.dmax = 0u; init.count = 0u; init.stride = 0;
+  if (hipMemcpyAsync(st, &init, sizeof(init), hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemsetAsync(keys, 0xFF, ((size_t)1 << log2cap) * 16, s) != hipSuccess) {  // keys and vals are adjacent
+    clid_set_error("clid_voxel_down_sample: workspace init failed");
+    return CLID_E_HIP;
+  }
+  int sb = (n + 255) / 256;
+  if (sb > 1024) sb = 1024;
+  hipLaunchKernelGGL(k_vox_stats, dim3(sb), dim3(256), 0, s, points, n, voxel_size, st);
+  hipLaunchKernelGGL(k_vox_insert, dim3((n + 255) / 256), dim3(256), 0, s, points, n, voxel_size, st, keys, vals, log2cap);
+  hipLaunchKernelGGL(k_vox_compact, dim3((unsigned)((((size_t)1 << log2cap) + 255) / 256)), dim3(256), 0, s, keys, vals,
+                     log2cap, st, flat_a, idx_a);
+  CLID_CHECK_LAUNCH();
+  VoxStats got;  // the output size is data dependent: ONE host round trip (the caller sizes its tensors with it)
+  if (hipMemcpyAsync(&got, st, sizeof(got), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess) {
+    clid_set_error("clid_voxel_down_sample: read-back failed");
+    return CLID_E_HIP;
+  }
+  const int m = (int)got.count;
+  int bits = 1;
+  {
+    const unsigned long long top = (unsigned long long)got.stride * (1ULL + (unsigned long long)got.stride +
+                                                                     (unsigned long long)got.stride * got.stride);
+    while (bits < 63 && (top >> bits)) ++bits;
+  }
+  size_t tmp = L.cub_bytes;
+  if (hipcub::DeviceRadixSort::SortPairs(ws + L.cub, tmp, flat_a, flat_b, idx_a, reinterpret_cast<long long*>(idx_out), m,
+                                         0, bits, s) != hipSuccess) {
+    clid_set_error("clid_voxel_down_sample: sort failed");
+    return CLID_E_HIP;
+  }
+  return m;
+}

@@ -268,6 +268,17 @@ int clid_sample_frame(const clid_cloud_view* cloud, const clid_sampler_params* p
                       int32_t n_rays, const float* z_surface, const float* u_front, const float* u_behind,
                       float* coord_out, float* label_out, float* weight_out, uint8_t* keep_out, void* stream);
 
+/* ---- map maintenance on the device ("next" row N4) ----------------------------------------------------
+ * voxel_down_sample_torch (utils/tools.py:639-682): indices of one point per voxel -- the one closest to the
+ * voxel centre, distance quantised to 1000 levels, lowest index among equals -- in ascending order of the
+ * reference's linear voxel id (stride = max cell coordinate, aliasing included).  points [n][3];
+ * workspace of clid_voxel_workspace_bytes(n) bytes; idx_out [n] int64 (capacity).  Returns the number of
+ * voxels m >= 0 (idx_out[0..m) valid) or a negative error.  The output size is data dependent, so this call
+ * synchronises `stream` once (the caller needs m to size its tensors). */
+int64_t clid_voxel_workspace_bytes(int32_t n);
+int clid_voxel_down_sample(const float* points, int32_t n, float voxel_size, void* workspace, int64_t* idx_out,
+                           void* stream);
+
 /* ---- measurement aid (bench.py roofline leg; not part of the reference's interface) -----------
  * When enabled, clid_train_fwd_bwd / clid_train_adam bracket each kernel with hipEvents on the
  * launch stream.  clid_profile_read synchronises and returns summed elapsed ms per kernel:

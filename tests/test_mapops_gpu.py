@@ -1,0 +1,38 @@
+"""GPU: map-maintenance kernels ("next" row N4) against the torch / oracle restatements of the same rules."""
+import numpy as np
+import pytest
+import torch
+
+import golden_io as gio
+from oracle import sampler_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,voxel,seed", [(1, 0.2, 0), (7, 0.4, 1), (5000, 0.2, 2), (200000, 0.4, 3), (450000, 0.1, 4)])
+def test_voxel_down_sample_kernel_matches_the_reference_rule(n, voxel, seed):
+    """clid_voxel_down_sample == the oracle's restatement of utils/tools.py:639-682 (scatter-amin on the CPU) on
+    identical points: same indices in the same order, including the stride-aliasing quirk."""
+    from clid_slam_amd.tools import voxel_down_sample_torch
+
+    g = torch.Generator().manual_seed(seed)
+    pts = (torch.rand((n, 3), generator=g) - 0.3) * torch.tensor([40.0, 25.0, 6.0])
+    if n > 10:
+        pts[n // 2] = pts[n // 3]  # exact duplicates: the lower index wins
+    want = R.voxel_down_sample(pts, voxel)
+    got = voxel_down_sample_torch(pts.cuda(), voxel)
+    assert got.dtype == torch.int64 and got.is_cuda
+    assert torch.equal(got.cpu(), want)
+
+
+def test_voxel_down_sample_kernel_on_a_scan():
+    from clid_slam_amd.synth import box_room_scan
+    from clid_slam_amd.tools import voxel_down_sample_torch
+
+    scan = box_room_scan(n_elev=64, n_azim=1024, seed=5, vox_down_m=0.0) + torch.tensor([3.0, -2.0, 1.5])
+    for voxel in (0.1, 0.2, 0.4):
+        want = R.voxel_down_sample(scan, voxel)
+        got = voxel_down_sample_torch(scan.cuda(), voxel).cpu()
+        assert torch.equal(got, want)
+        # one point per occupied voxel of the reference's own linearisation
+        assert got.unique().numel() == got.numel()
