@@ -98,6 +98,7 @@ _SIGS = {
     "clid_region_sdf": (C.c_int, [C.POINTER(CloudView), _vp, _i32, _vp, _vp, _vp]),
     "clid_sample_frame": (C.c_int, [C.POINTER(CloudView), C.POINTER(SamplerParams), _vp, _i32, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp]),
+    "clid_transform_points": (C.c_int, [_vp, _i32, C.POINTER(_f32), _vp, _vp]),
     "clid_voxel_workspace_bytes": (_i64, [_i32]),
     "clid_voxel_down_sample": (C.c_int, [_vp, _i32, _f32, _vp, _vp, _vp]),
     "clid_mapping_pipeline": (C.c_int, [C.c_int]),

@@ -68,13 +68,40 @@ __global__ void __launch_bounds__(256) k_vox_stats(const float* __restrict__ pts
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) dm = max(dm, (unsigned)__shfl_xor((int)dm, o, 64));
+  // one set of (contended, same-address) atomics per BLOCK: combine the block's waves through LDS first
+  __shared__ int part[4][7];
+  const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      atomicMin(&st->lo[a], lo[a]);
-      atomicMax(&st->hi[a], hi[a]);
+      part[wave][a] = lo[a];
+      part[wave][3 + a] = hi[a];
     }
-    atomicMax(&st->dmax, dm);
+    part[wave][6] = (int)dm;
+  }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int c = threadIdx.x;
+    int v0 = part[0][c];
+    for (int w = 1; w < 4; ++w) {
+      const int o = part[w][c];
+      v0 = c < 3 ? min(v0, o) : (c < 6 ? max(v0, o) : (int)max((unsigned)v0, (unsigned)o));
+    }
+    if (c < 3) atomicMin(&st->lo[c], v0);
+    else if (c < 6) atomicMax(&st->hi[c - 3], v0);
+    else atomicMax(&st->dmax, (unsigned)v0);
+  }
+}
+
+__global__ void k_vox_init(VoxStats* st) {
+  if (threadIdx.x == 0) {
+    for (int a = 0; a < 3; ++a) {
+      st->lo[a] = 0x7fffffff;
+      st->hi[a] = (int)0x80000000;
+    }
+    st->dmax = 0u;
+    st->count = 0u;
+    st->stride = 0;
   }
 }
 
@@ -121,12 +148,31 @@ __global__ void __launch_bounds__(256) k_vox_compact(const long long* __restrict
                                                      const unsigned long long* __restrict__ vals, int log2cap,
                                                      VoxStats* st, long long* flat_out, long long* idx_out) {
   const long long h = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= (1LL << log2cap)) return;
-  const long long k = keys[h];
-  if (k == -1LL) return;
-  const unsigned pos = atomicAdd(&st->count, 1u);
+  const long long k = h < (1LL << log2cap) ? keys[h] : -1LL;
+  const bool live = k != -1LL;
+  // one counter bump per wave (the counter is a single address): ballot, prefix popcount, broadcast the base
+  const unsigned long long m = __ballot(live);
+  const int lane = threadIdx.x & 63;
+  unsigned base = 0;
+  if (lane == 0 && m) base = atomicAdd(&st->count, (unsigned)__popcll(m));
+  base = __shfl(base, 0, 64);
+  if (!live) return;
+  const unsigned pos = base + (unsigned)__popcll(m & ((1ULL << lane) - 1ULL));
   flat_out[pos] = k;
   idx_out[pos] = (long long)(vals[h] & 0xffffffffULL);
+}
+
+struct Pose12 {
+  float T[12];
+};
+// transform_torch (utils/tools.py:590-609): y = R x + t in fp32
+__global__ void __launch_bounds__(256) k_transform(const float* __restrict__ pts, int n, Pose12 p, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+  out[i * 3 + 0] = fmaf(z, p.T[2], fmaf(y, p.T[1], fmaf(x, p.T[0], p.T[3])));
+  out[i * 3 + 1] = fmaf(z, p.T[6], fmaf(y, p.T[5], fmaf(x, p.T[4], p.T[7])));
+  out[i * 3 + 2] = fmaf(z, p.T[10], fmaf(y, p.T[9], fmaf(x, p.T[8], p.T[11])));
 }
 
 static int vox_log2cap(int n) {
@@ -186,27 +232,31 @@ extern "C" int clid_voxel_down_sample(const float* points, int32_t n, float voxe
   long long* idx_a = reinterpret_cast<long long*>(ws + L.idx_a);
   long long* flat_b = reinterpret_cast<long long*>(ws + L.flat_b);
   const int log2cap = vox_log2cap(n);
-  VoxStats init;
-  for (int a = 0; a < 3; ++a) { init.lo[a] = 0x7fffffff; init.hi[a] = (int)0x80000000; }
-  init.dmax = 0u; init.count = 0u; init.stride = 0;
-  if (hipMemcpyAsync(st, &init, sizeof(init), hipMemcpyHostToDevice, s) != hipSuccess ||
-      hipMemsetAsync(keys, 0xFF, ((size_t)1 << log2cap) * 16, s) != hipSuccess) {  // keys and vals are adjacent
+  if (hipMemsetAsync(keys, 0xFF, ((size_t)1 << log2cap) * 16, s) != hipSuccess) {  // keys and vals are adjacent
     clid_set_error("clid_voxel_down_sample: workspace init failed");
     return CLID_E_HIP;
   }
+  hipLaunchKernelGGL(k_vox_init, dim3(1), dim3(64), 0, s, st);
   int sb = (n + 255) / 256;
-  if (sb > 1024) sb = 1024;
+  if (sb > 512) sb = 512;
   hipLaunchKernelGGL(k_vox_stats, dim3(sb), dim3(256), 0, s, points, n, voxel_size, st);
   hipLaunchKernelGGL(k_vox_insert, dim3((n + 255) / 256), dim3(256), 0, s, points, n, voxel_size, st, keys, vals, log2cap);
   hipLaunchKernelGGL(k_vox_compact, dim3((unsigned)((((size_t)1 << log2cap) + 255) / 256)), dim3(256), 0, s, keys, vals,
                      log2cap, st, flat_a, idx_a);
   CLID_CHECK_LAUNCH();
-  VoxStats got;  // the output size is data dependent: ONE host round trip (the caller sizes its tensors with it)
-  if (hipMemcpyAsync(&got, st, sizeof(got), hipMemcpyDeviceToHost, s) != hipSuccess ||
+  // the output size is data dependent: ONE host round trip (the caller sizes its tensors with it), through a
+  // pinned landing buffer (a pageable destination makes hipMemcpyAsync stage and block for ~150 us)
+  static thread_local VoxStats* pinned = nullptr;
+  if (!pinned && hipHostMalloc(reinterpret_cast<void**>(&pinned), sizeof(VoxStats), hipHostMallocDefault) != hipSuccess) {
+    clid_set_error("clid_voxel_down_sample: cannot allocate the pinned read-back buffer");
+    return CLID_E_HIP;
+  }
+  if (hipMemcpyAsync(pinned, st, sizeof(VoxStats), hipMemcpyDeviceToHost, s) != hipSuccess ||
       hipStreamSynchronize(s) != hipSuccess) {
     clid_set_error("clid_voxel_down_sample: read-back failed");
     return CLID_E_HIP;
   }
+  const VoxStats got = *pinned;
   const int m = (int)got.count;
   int bits = 1;
   {
@@ -221,4 +271,17 @@ extern "C" int clid_voxel_down_sample(const float* points, int32_t n, float voxe
     return CLID_E_HIP;
   }
   return m;
+}
+
+extern "C" int clid_transform_points(const float* points, int32_t n, const float* pose12_host, float* out, void* stream) {
+  if (n < 0 || !pose12_host || (n > 0 && (!points || !out))) {
+    clid_set_error("clid_transform_points: bad argument");
+    return CLID_E_ARG;
+  }
+  if (n == 0) return CLID_OK;
+  Pose12 p;
+  for (int i = 0; i < 12; ++i) p.T[i] = pose12_host[i];
+  hipLaunchKernelGGL(k_transform, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, points, n, p, out);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
 }

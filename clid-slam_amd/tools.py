@@ -123,6 +123,19 @@ def voxel_down_sample_torch(points: torch.Tensor, voxel_size: float):
 def transform_torch(points: torch.Tensor, transformation: torch.Tensor):
     """Rigid transform of [N,3] points by a 4x4 matrix, evaluated in the points' dtype
     (utils/tools.py:590-609)."""
+    if points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.shape[1] == 3 and points.shape[0] > 0:
+        import ctypes as C
+
+        from . import _lib
+
+        lib = _lib.load()
+        x = points.detach().contiguous()
+        out = torch.empty_like(x)
+        T = transformation.detach().to("cpu", torch.float32)  # 16 numbers; `.to(points)` in the reference
+        pose = (C.c_float * 12)(*[float(v) for v in T[:3, :].reshape(-1)])
+        _lib.check(lib.clid_transform_points(x.data_ptr(), x.shape[0], pose, out.data_ptr(), _lib.stream()),
+                   "clid_transform_points")
+        return out
     T = transformation.to(points)
     return points @ T[:3, :3].T + T[:3, 3]
 

@@ -275,6 +275,9 @@ int clid_sample_frame(const clid_cloud_view* cloud, const clid_sampler_params* p
  * workspace of clid_voxel_workspace_bytes(n) bytes; idx_out [n] int64 (capacity).  Returns the number of
  * voxels m >= 0 (idx_out[0..m) valid) or a negative error.  The output size is data dependent, so this call
  * synchronises `stream` once (the caller needs m to size its tensors). */
+/* transform_torch (utils/tools.py:590-609): out[i] = R points[i] + t; pose12_host = rows 0..2 of the 4x4
+ * transform, row-major, HOST memory (passed by value to the kernel). */
+int clid_transform_points(const float* points, int32_t n, const float* pose12_host, float* out, void* stream);
 int64_t clid_voxel_workspace_bytes(int32_t n);
 int clid_voxel_down_sample(const float* points, int32_t n, float voxel_size, void* workspace, int64_t* idx_out,
                            void* stream);

@@ -75,7 +75,16 @@ def test_multi_frame_mapping_tracks_the_oracle(layer_norm):
         got = mp.last_losses.cpu()
         for it, r in enumerate(recs):
             assert abs(float(got[it, 0]) - float(r["loss"])) <= 2e-5, (fid, it, got[it], r["loss"])
-        assert float((nm.local_geo_features.detach().cpu() - recs[-1]["theta"]).abs().max()) <= 1e-4, fid
+        # Adam with eps = 1e-15 turns ANY non-zero gradient into a +-lr step: an entry whose gradient is pure
+        # cancellation residue (|g| < 1e-10, e.g. +a - a' = 1e-16 in one summation order and 0 in another) is
+        # chaotic in the reference itself; such entries are only bounded by lr * iters, all others must agree
+        noise = torch.zeros_like(recs[-1]["theta"], dtype=torch.bool)
+        for r in recs:  # entries of a TOUCHED row (some component got a gradient) that are themselves at noise level
+            ga = r["grad_theta"].abs()
+            noise |= (ga < 1e-10) & (ga.max(dim=1, keepdim=True).values > 0)
+        err = (nm.local_geo_features.detach().cpu() - recs[-1]["theta"]).abs()
+        assert float(err[~noise].max()) <= 1e-4, fid
+        assert float(err.max()) <= cfg.lr * iters * 1.01 and int((err > 1e-4).sum()) <= 8, (fid, int((err > 1e-4).sum()))
         for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
             assert float((t.detach().cpu() - o).abs().max()) <= 1e-4
         assert float((nm.local_point_certainties.cpu() - recs[-1]["certainties"]).abs().max()) <= 2e-3
