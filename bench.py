@@ -207,9 +207,9 @@ def main():
             "step_bytes": sum(alg), "step_frac_of_peak": sum(alg) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
             "note": "hipEvent-bracketed launches on the launch stream in a separate pass of the same loop, minus the "
                     "measured cost of an empty event pair (rocprofv3 --kernel-trace average for the same kernel: "
-                    "profiles/r01_bench_v5_kernel_stats.csv, ~3 us higher because it spans dispatch to completion); "
+                    "profiles/r01_bench_v6_kernel_stats.csv, ~3 us higher because it spans dispatch to completion); "
                     "traffic = offline PMC passes (profiles/r01_hbm_traffic.json); the kernel is bound by dependent-load "
-                    "latency and instruction issue (profiles/r01_pmc_v5_summary.txt), not by HBM bandwidth",
+                    "latency and instruction issue (profiles/r01_pmc_v6_summary.txt), not by HBM bandwidth",
         }
     sync()
 
