@@ -1,0 +1,22 @@
+"""Developer tool: build a variant of the library with extra -D flags into /tmp on the GPU box and run bench.py
+against it (the committed library is untouched).   usage: python tools/variant_bench.py "-DCLID_DECODE_WAVES=5" [bench args...]"""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+flags = sys.argv[1].split()
+csrc = os.path.join(ROOT, "clid-slam_amd", "csrc")
+out = "/tmp/libclid_variant.so"
+srcs = [os.path.join(csrc, f) for f in ("api.hip", "table.hip", "query.hip", "train.hip", "train_analytic.hip", "mlp.hip", "sampler.hip", "mapops.hip")]
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=on",
+                       "-Wno-unused-value", "-Wno-unused-result", "-w", *flags, "-shared", *srcs, "-o", out])
+import clid_slam_amd  # noqa
+from clid_slam_amd import _lib
+_lib.LIB_PATH = out
+sys.argv = ["bench.py", "--no-cpu-baseline"] + sys.argv[2:]
+import io, contextlib
+buf = io.StringIO()
+import bench
+with contextlib.redirect_stdout(buf):
+    bench.main()
+d = json.loads(buf.getvalue().strip().splitlines()[-1])
+print(sys.argv[1:], flags, os.environ.get("CLID_PIPELINE"), round(d["ms_per_step"] * 1e3, 2), d["roofline"]["per_kernel_us"])
