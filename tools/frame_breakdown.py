@@ -54,6 +54,8 @@ if os.environ.get("CLID_TORCHPROF"):
         mp.process_frame(scan, None, pose, fid)
         torch.cuda.synchronize()
     print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=14, max_name_column_width=50))
+    ops = sorted(((e.count, e.key) for e in prof.key_averages() if e.key.startswith("aten::")), reverse=True)[:28]
+    print("aten op counts:", ", ".join(f"{k[6:]}x{c}" for c, k in ops))
     print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=14, max_name_column_width=50))
 
 if os.environ.get("CLID_CPROFILE"):
