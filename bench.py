@@ -169,11 +169,11 @@ def main():
         _lib.check(lib.clid_profile_read(out, C.byref(n), _lib.stream()), "clid_profile_read")
         lib.clid_profile_enable(0)
         ov = out[4]
-        pipelined = out[1] > 0.0  # hoisted searches: one search launch per chunk, then decode + Adam per iteration
-        names = ("k_train_fused8<2> (decode)" if pipelined else "k_train_fused8", "k_train_fused8<1> (search)",
+        hoisted = out[1] > 0.0  # hoisted searches: one search launch per chunk, then decode + Adam per iteration
+        names = ("k_train_fused8<2> (decode)" if hoisted else "k_train_fused8", "k_train_fused8<1> (search)",
                  "k_reduce_partials", "k_adam_all")
         ms = [max(out[i] / max(n.value, 1) - ov, 0.0) for i in range(4)]
-        if pipelined:  # the search is bracketed once per chunk of <= 32 iterations, reported per iteration
+        if hoisted:  # the search is bracketed once per chunk of <= 32 iterations, reported per iteration
             ms[1] = max(out[1] - ov * math.ceil(n.value / 32), 0.0) / max(n.value, 1)
         decim = cfg.gradient_decimation
         Q = args.bs + 6 * ((args.bs + decim - 1) // decim)
@@ -184,7 +184,7 @@ def main():
         search_b = Q * 688.0 + args.bs * BYTES_POOL_GATHER
         decode_b = Q * (BYTES_FWD_PER_QUERY - 688.0 + BYTES_BWD_PER_QUERY)
         adam_b = BYTES_ADAM_PER_ROW * (M + 1) + 833 * 28.0
-        if pipelined:
+        if hoisted:
             alg = [decode_b + Q * 96.0, search_b + Q * 96.0, 0.0, adam_b]
         else:
             alg = [search_b + decode_b, 0.0, 0.0, adam_b]
@@ -202,7 +202,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg[dom], "avg_launch_us": ms[dom] * 1e3,
             "per_kernel_us": {nme: round(m * 1e3, 2) for nme, m in zip(names, ms) if m > 0.0},
-            "hoisted_search": pipelined,
+            "hoisted_search": hoisted,
             "event_pair_overhead_us": round(ov * 1e3, 2),
             "step_bytes": sum(alg), "step_frac_of_peak": sum(alg) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
             "note": "hipEvent-bracketed launches on the launch stream in a separate pass of the same loop, minus the "

@@ -262,9 +262,9 @@ __device__ __forceinline__ bool search8(const clid_map_view& mv, const DeltaLds&
 
 constexpr int kFusedBlock = 512;  // 8 waves share one partial row: half as many rows for k_adam_all to reduce
 // MODE 0: search + decode in one launch.  MODE 1 / 2: the same two phases as separate kernels with the
-// searches' winners (kRecFloat4 float4 per task: qinfo | qdesc | win, the head of WaveLds) parked in HBM, so
-// the host can run search(t+1) on a second stream underneath decode(t) + Adam(t): the search does not read
-// anything training writes (positions only), and both phases are latency- not throughput-bound.
+// searches' winners (kRecFloat4 float4 per task: qinfo | qdesc | win, the head of WaveLds) parked in HBM: the
+// search reads nothing that training writes (positions, table and sample indices only), so one MODE 1 launch
+// resolves a whole chunk of iterations ahead of the dependent decode -> Adam chain (clid_train_search).
 constexpr int kRecFloat4 = 48;
 template <int MODE>
 __global__ void __launch_bounds__(kFusedBlock, CLID_FUSED_WAVES)
@@ -733,7 +733,7 @@ using namespace clid;
 namespace {
 bool g_prof = false;
 struct ProfSpan {
-  int tag;  // 0 fused / decode kernel, 1 search kernel (pipelined loop), 2 partial reduce, 3 adam
+  int tag;  // 0 fused / decode kernel, 1 search kernel (hoisted-search loop), 2 partial reduce, 3 adam
   hipEvent_t a, b;
 };
 std::vector<ProfSpan> g_spans;
@@ -769,7 +769,7 @@ extern "C" int clid_profile_enable(int on) {
 }
 
 // sums of elapsed ms per kernel over all recorded iterations: out[0] = fused (or decode) kernel, out[1] =
-// search kernel of the pipelined loop, out[2] = partial reduce, out[3] = adam; out[4] = back-to-back
+// search kernel of the hoisted-search loop, out[2] = partial reduce, out[3] = adam; out[4] = back-to-back
 // event-pair overhead (ms, mean) measured now; *iters = iterations recorded
 extern "C" int clid_profile_read(double* out, int* iters, void* stream) {
   hipStream_t s = (hipStream_t)stream;

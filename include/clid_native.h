@@ -285,7 +285,7 @@ int clid_voxel_down_sample(const float* points, int32_t n, float voxel_size, voi
 /* ---- measurement aid (bench.py roofline leg; not part of the reference's interface) -----------
  * When enabled, clid_train_fwd_bwd / clid_train_adam bracket each kernel with hipEvents on the
  * launch stream.  clid_profile_read synchronises and returns summed elapsed ms per kernel:
- * out[0] = fused (or decode) kernel, out[1] = search kernel of the pipelined loop, out[2] = partial reduce,
+ * out[0] = fused (or decode) kernel, out[1] = search kernel of the hoisted-search loop, out[2] = partial reduce,
  * out[3] = adam; out[4] = empty event-pair overhead (ms). */
 int clid_profile_enable(int on);
 int clid_profile_read(double* out_host, int* iters_host, void* stream);
