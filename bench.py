@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--bs", type=int, default=16384, help="samples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--freeze-decoder", action="store_true",
+                    help="steady-state variant: decoder frozen (freeze_model, slam.py:193-196); not the headline config")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for single-GPU dry runs)")
     args = ap.parse_args()
 
@@ -145,6 +147,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.freeze_decoder:
+        from clid_slam_amd.tools import freeze_model
+
+        freeze_model(dec)
     mp.mapping(args.warmup)
     sync()
     t0 = time.perf_counter()
@@ -227,7 +233,7 @@ def main():
             "config": {
                 "workload": "run_ncd128.yaml defaults, single-scan mapping loop: fp32, numerical eikonal "
                             f"(decimation {cfg.gradient_decimation}), Adam; synthetic box-room Ouster-128 scan",
-                "bs_per_gpu": args.bs, "global_batch": args.bs * world, "query_points_per_step_per_gpu":
+                "bs_per_gpu": args.bs, "decoder_frozen": bool(args.freeze_decoder), "global_batch": args.bs * world, "query_points_per_step_per_gpu":
                     args.bs + 6 * ((args.bs + cfg.gradient_decimation - 1) // cfg.gradient_decimation),
                 "neural_points_local": M, "pool_samples": int(mp.pool_sample_count), "buffer_size": cfg.buffer_size,
                 "parallelism": f"dp{world} (batch sharded, RCCL all-reduce of [decoder|feature] grads)" if world > 1 else "single GPU",

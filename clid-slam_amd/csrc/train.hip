@@ -571,7 +571,8 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
     CLID_STAMP(10);
   }
   CLID_STAMP(24);
-  if constexpr (MODE != 1) flush_mlp_acc(acc, bce_acc, eik_acc, red, partial + (size_t)blockIdx.x * kPartialStride);
+  if constexpr (MODE != 1)
+    flush_mlp_acc(acc, bce_acc, eik_acc, red, partial + (size_t)blockIdx.x * kPartialStride, ta.train_decoder != 0);
   CLID_STAMP(25);
 }
 
@@ -644,6 +645,7 @@ k_reduce_partials(const float* __restrict__ partial, int nb, float* __restrict__
                   int train_decoder) {
   __shared__ float sm[256];
   const int col0 = blockIdx.x * 16;
+  if (!train_decoder && col0 + 15 < CLID_MLP_PARAMS) return;  // frozen decoder: only the loss columns carry data
   const float tot = column_sum16(partial, nb, col0, sm);
   const int p = col0 + (threadIdx.x & 15);
   if ((threadIdx.x >> 4) != 0 || p >= CLID_MLP_PARAMS + 2) return;
@@ -692,6 +694,7 @@ __global__ void __launch_bounds__(256) k_adam_all(AdamLaunch a) {
   }
   const int col0 = ((int)blockIdx.x - a.n_feat_blocks) * 16;
   const int p = col0 + (threadIdx.x & 15);
+  if (!a.train_decoder && col0 + 15 < CLID_MLP_PARAMS) return;  // frozen decoder: no decoder gradients were produced
   float gsum;
   if (a.partial) {
     gsum = column_sum16(a.partial, a.nb, col0, sm);

@@ -193,7 +193,7 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
       }
     }
   }
-  flush_mlp_acc(acc, bce_acc, eik_acc, red, partial + (size_t)blockIdx.x * kPartialStride);
+  flush_mlp_acc(acc, bce_acc, eik_acc, red, partial + (size_t)blockIdx.x * kPartialStride, ta.train_decoder != 0);
 }
 
 #undef CLID_BFLY

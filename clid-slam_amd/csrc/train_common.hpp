@@ -80,10 +80,26 @@ constexpr int kRedFloats = CLID_MLP_PARAMS + 3;  // 833 grads | bce | eik | pad
 // Block reduction of the waves' accumulators: plain LDS stores into per-wave rows, one barrier, then
 // a 4-way sum and one coalesced global store.  (LDS float atomics -- ds_add_f32 -- retire at ~1-2
 // lanes/clk on gfx950: measured 20 us for this flush, so they are avoided.)
+// With a frozen decoder (freeze_model after `freeze_after_frame`, the steady state of a run) only the two loss
+// sums leave the block.
 __device__ __forceinline__ void flush_mlp_acc(const MlpAcc& acc, float bce, float eik, float* red /*LDS [4][kRedFloats]*/,
-                                              float* __restrict__ out /* [kPartialStride] */) {
+                                              float* __restrict__ out /* [kPartialStride] */, bool train_decoder = true) {
   const int lane = threadIdx.x & 63, lane16 = lane & 15, grp = lane >> 4, wave = threadIdx.x >> 6;
   float* mine = red + wave * kRedFloats;
+  if (!train_decoder) {
+    const float v1 = cross_group_sum(bce), v2 = cross_group_sum(eik);
+    if (lane == 0) {
+      mine[CLID_MLP_PARAMS] = v1;
+      mine[CLID_MLP_PARAMS + 1] = v2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      float s = 0.f;
+      for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) s += red[wv * kRedFloats + CLID_MLP_PARAMS + threadIdx.x];
+      out[CLID_MLP_PARAMS + threadIdx.x] = s;
+    }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < CLID_HPL; ++u) {
 #pragma unroll
