@@ -485,11 +485,12 @@ def test_default_buffer_size_scene_vs_oracle(env):
     assert maxerr(nm.local_point_certainties, recs[-1]["certainties"]) <= 5e-3
 
 
-def test_sharded_gradients_at_65536(env):
-    """BASELINE config 3/4 batch size: 65536 samples, 4 shards through the C ABI sum to the full batch."""
+@pytest.mark.parametrize("bs", [65536, 262144])
+def test_sharded_gradients_at_large_batches(env, bs):
+    """BASELINE configs 2 and 3 batch sizes (65 536 and 262 144 samples per iteration, the latter "sharded 4x"):
+    4 shards through the C ABI -- fused kernel and the search + decode pair -- sum to the full batch."""
     p = gio.load("pool.npz")
     g = gio.load("g6_loop_numerical_train_ln0.npz")
-    bs = 65536
     cfg = env.config(bs=bs)
     gen = torch.Generator().manual_seed(4)
     index = torch.randint(0, p["coord"].shape[0], (bs,), generator=gen)
@@ -499,7 +500,7 @@ def test_sharded_gradients_at_65536(env):
     per = bs // 4
     for r in range(4):
         gr, lo, _, _ = _fused_grads(env, cfg, p, g, index[r * per : (r + 1) * per], batch_offset=r * per, n_main=bs,
-                                    n_eik=(bs + 9) // 10)
+                                    n_eik=(bs + 9) // 10, split=(r % 2 == 1))
         acc += gr
         loss += lo
     assert float((acc - full).abs().max()) <= 5e-5 * float(full.abs().max())
