@@ -202,7 +202,7 @@ class NeuralPoints(nn.Module):
         ratio = n_new / sample_points.shape[0]
         base = self.neural_points.shape[0]
         rank = torch.cumsum(take, 0) - 1 + base  # index the i-th taken sample receives
-        self.buffer_pt_index[slot] = torch.where(take, rank, held)
+        self._assign_slots(slot, torch.where(take, rank, held))
         self.neural_points = torch.cat((self.neural_points, added), 0)
         quat = torch.zeros((n_new, 4), dtype=self.dtype, device=self.device)
         quat[:, 0] = 1.0
@@ -220,6 +220,17 @@ class NeuralPoints(nn.Module):
         self._map_version += 1
         self.reset_local_map(sensor_position, sensor_orientation, cur_ts, reboot_map=True)
         return ratio
+
+    def _assign_slots(self, slot: torch.Tensor, value: torch.Tensor) -> None:
+        """`buffer_pt_index[slot] = value` where several entries may name one slot: the reference's sequential CPU
+        semantics keep the LAST one; an indexed assignment with duplicates is arbitrary on the GPU (and could differ
+        between the ranks of a multi-GPU run).  Keep exactly the last writer per slot."""
+        phys = torch.where(slot < 0, slot + int(self.buffer_size), slot)  # fmod keeps the sign; -k indexes slot B-k
+        order = torch.argsort(phys, stable=True)
+        s_sorted = phys[order]
+        last = torch.ones_like(s_sorted, dtype=torch.bool)
+        last[:-1] = s_sorted[:-1] != s_sorted[1:]
+        self.buffer_pt_index[s_sorted[last]] = value[order][last]
 
     def reset_local_map(self, sensor_position, sensor_orientation, cur_ts: int, use_travel_dist: bool = True,
                         diff_ts_local: int = 50, reboot_map: bool = False):
@@ -288,7 +299,7 @@ class NeuralPoints(nn.Module):
         cells = torch.floor(self.neural_points / self.resolution).to(self.primes)
         slot = torch.fmod((cells * self.primes).sum(-1), int(self.buffer_size))
         self.buffer_pt_index = torch.full((self.buffer_size,), -1, dtype=self.idx_dtype, device=self.device)
-        self.buffer_pt_index[slot] = torch.arange(self.count(), dtype=self.idx_dtype, device=self.device)
+        self._assign_slots(slot, torch.arange(self.count(), dtype=self.idx_dtype, device=self.device))
         self._map_version += 1
         if with_ts and sensor_position is not None:
             self.reset_local_map(sensor_position, sensor_orientation, cur_ts)

@@ -36,3 +36,34 @@ def test_voxel_down_sample_kernel_on_a_scan():
         assert torch.equal(got, want)
         # one point per occupied voxel of the reference's own linearisation
         assert got.unique().numel() == got.numel()
+
+
+def test_map_growth_on_the_gpu_rebuilds_the_reference_map():
+    """NeuralPoints.update / reset_local_map on the device (voxel kernel + deterministic last-writer slot updates)
+    against G7, the map the reference builds single-threaded from the same three frames: identical points, stamps,
+    slot table and local window."""
+    from clid_slam_amd import HotPathConfig, NeuralPoints
+    from clid_slam_amd.synth import box_room_pool
+
+    z = gio.load("g7_mapbuild.npz")
+    cfg = HotPathConfig()
+    cfg.device = "cuda"
+    cfg.buffer_size = int(gio.S(z["buffer_size"]))
+    torch.manual_seed(42)
+    nm = NeuralPoints(cfg)
+    nm.travel_dist = torch.tensor([0.0, 400.0, 403.5], device="cuda")
+    sensors = [(0.0, 0.0, 1.5), (6.0, 2.0, 1.5), (9.0, 3.0, 1.6)]
+    for fid, s in enumerate(sensors):
+        d = box_room_pool(cfg, n_elev=32, n_azim=256, seed=42 + fid, sensor=s)
+        near = d["sdf_label"].abs() < cfg.surface_sample_range_m * 0.5
+        nm.update(d["coord"][near].cuda(), d["sensor"].cuda(), torch.eye(3, device="cuda"), fid)
+    assert nm.count() == z["neural_points"].shape[0]
+    assert np.array_equal(nm.neural_points.cpu().numpy(), z["neural_points"])
+    assert np.array_equal(nm.point_ts_create.cpu().numpy(), z["point_ts_create"])
+    occ = torch.nonzero(nm.buffer_pt_index >= 0).flatten()
+    assert np.array_equal(occ.cpu().numpy(), z["table_slot"])
+    assert np.array_equal(nm.buffer_pt_index[occ].cpu().numpy(), z["table_idx"])
+    nm.local_map_radius = 12.0
+    nm.reset_local_map(torch.tensor(sensors[-1], device="cuda"), torch.eye(3, device="cuda"), 2, reboot_map=True)
+    assert np.array_equal(nm.global2local.cpu().numpy(), z["global2local"])
+    assert np.array_equal(nm.local_neural_points.cpu().numpy(), z["local_neural_points"])
