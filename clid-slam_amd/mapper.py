@@ -51,6 +51,9 @@ class Mapper:
             self.require_gradient = False
         self.total_iter: int = 0
         self.sdf_scale = config.logistic_gaussian_ratio * config.sigma_sigmoid_m
+        from .data_sampler import DataSampler
+
+        self.sampler = DataSampler(config)  # utils/mapper.py:74
         self.ray_sample_count = 1 + config.surface_sample_n + config.free_behind_n + config.free_front_n
         self.new_idx = None
         self.ba_done_flag = False
@@ -366,11 +369,12 @@ class Mapper:
         """utils/mapper.py:159-470: raw-point map update -> sample + label this scan -> grow the neural-point
         map -> append to / filter the training pool -> pick the newly observed samples and the adaptive
         iteration offset.  Sampling is one HIP launch (data_sampler.py); the rest is per-frame bookkeeping."""
-        from .data_sampler import DataSampler
         from .tools import transform_torch
 
         cfg, nm = self.config, self.neural_points
-        if getattr(self, "sampler", None) is None:
+        if getattr(self, "sampler", None) is None:  # e.g. the reference's Mapper subclassed over this method
+            from .data_sampler import DataSampler
+
             self.sampler = DataSampler(cfg)
         origin = cur_pose_torch[:3, 3]
         orientation = cur_pose_torch[:3, :3]
