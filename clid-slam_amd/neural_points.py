@@ -292,16 +292,34 @@ class NeuralPoints(nn.Module):
 
     def recreate_hash(self, sensor_position=None, sensor_orientation=None, kept_points: bool = True,
                       with_ts: bool = True, cur_ts=0):
-        """Rebuild `buffer_pt_index` from the point positions (model/neural_points.py:878-929,
-        re-hash part only; the optional pruning of `kept_points=False` is out of scope)."""
-        if not kept_points:
-            raise NotImplementedError("recreate_hash(kept_points=False) (map merging) is outside the hot-path scope")
-        cells = torch.floor(self.neural_points / self.resolution).to(self.primes)
-        slot = torch.fmod((cells * self.primes).sum(-1), int(self.buffer_size))
+        """Rebuild `buffer_pt_index` (model/neural_points.py:840-929): every voxel points at ONE of its neural points
+        -- the one closest in time to `cur_ts` (`with_ts`) or the most certain one; `kept_points=False` also drops
+        the others (map merging, as vis_pin_map.py:121-123 does after loading a map)."""
+        from .tools import voxel_down_sample_min_value_torch
+
         self.buffer_pt_index = torch.full((self.buffer_size,), -1, dtype=self.idx_dtype, device=self.device)
-        self._assign_slots(slot, torch.arange(self.count(), dtype=self.idx_dtype, device=self.device))
+        if with_ts:
+            ts_used = ((self.point_ts_create + self.point_ts_update) / 2).int() if self.config.use_mid_ts else self.point_ts_create
+            score = torch.abs(ts_used - cur_ts).float()
+        else:
+            score = self.point_certainties.max() - self.point_certainties
+        keep = voxel_down_sample_min_value_torch(self.neural_points, self.resolution, score)
+        if not kept_points:
+            self.neural_points = self.neural_points[keep]
+            self.point_orientations = self.point_orientations[keep]
+            self.point_ts_create = self.point_ts_create[keep]
+            self.point_ts_update = self.point_ts_update[keep]
+            self.point_certainties = self.point_certainties[keep]
+            pad = torch.cat((keep, torch.full((1,), -1, dtype=keep.dtype, device=keep.device)))
+            self.geo_features = self.geo_features[pad]
+            if self.color_features is not None:
+                self.color_features = self.color_features[pad]
+            keep = torch.arange(self.count(), dtype=self.idx_dtype, device=self.device)
+        cells = torch.floor(self.neural_points[keep] / self.resolution).to(self.primes)
+        slot = torch.fmod((cells * self.primes).sum(-1), int(self.buffer_size))
+        self._assign_slots(slot, keep.to(self.idx_dtype))
         self._map_version += 1
-        if with_ts and sensor_position is not None:
+        if sensor_position is not None:
             self.reset_local_map(sensor_position, sensor_orientation, cur_ts)
 
     def clear_temp(self, clean_more: bool = False):
@@ -322,8 +340,29 @@ class NeuralPoints(nn.Module):
             self.point_ts_update = None
             self.point_certainties = None
 
-    def prune_map(self, *a, **k):
-        raise NotImplementedError("prune_map (model/neural_points.py:771-876) is map maintenance outside the hot-path scope")
+    def prune_map(self, prune_certainty_thre, min_prune_count=500, global_prune=False):
+        """model/neural_points.py:771-812: drop uncertain points that have left the travel-distance window (or all
+        uncertain ones); returns True when something was pruned (the caller then recreates the hash)."""
+        uncertain = self.point_certainties < prune_certainty_thre
+        if global_prune:
+            prune = uncertain
+        else:
+            gap = torch.abs(self.travel_dist[self.cur_ts] - self.travel_dist[self.point_ts_update])
+            prune = (gap > self.diff_travel_dist_local) & uncertain
+        if int(torch.sum(prune).item()) <= min_prune_count:
+            return False
+        keep = torch.nonzero(~prune).flatten()
+        self.neural_points = self.neural_points.index_select(0, keep)
+        self.point_orientations = self.point_orientations.index_select(0, keep)
+        self.point_ts_create = self.point_ts_create.index_select(0, keep)
+        self.point_ts_update = self.point_ts_update.index_select(0, keep)
+        self.point_certainties = self.point_certainties.index_select(0, keep)
+        pad = torch.cat((keep, torch.full((1,), self.geo_features.shape[0] - 1, dtype=keep.dtype, device=keep.device)))
+        self.geo_features = self.geo_features.index_select(0, pad)
+        if self.color_features is not None:
+            self.color_features = self.color_features.index_select(0, pad)
+        self._map_version += 1
+        return True
 
     def adjust_map(self, *a, **k):
         raise NotImplementedError("adjust_map (PGO map deformation) is outside the hot-path scope")

@@ -120,6 +120,24 @@ def voxel_down_sample_torch(points: torch.Tensor, voxel_size: float):
     return order[first]
 
 
+def voxel_down_sample_min_value_torch(points: torch.Tensor, voxel_size: float, value: torch.Tensor):
+    """Indices of one point per voxel: the one with the smallest `value` (quantised to 1000 levels of value.max()),
+    lowest index among equals; voxels in ascending order of the reference's linear voxel id (stride = max cell
+    coordinate, as above).  Selection rule of utils/tools.py:685-724, written with sorts (deterministic)."""
+    cell = torch.floor(points / voxel_size).long() - torch.floor(points.min(dim=0)[0] / voxel_size).long()
+    v = cell.max()
+    flat = cell[:, 0] + cell[:, 1] * v + cell[:, 2] * v * v
+    q = (value / value.max() * 999).long()
+    n = points.shape[0]
+    key = q * n + torch.arange(n, device=points.device)
+    order = torch.argsort(key)
+    order = order[torch.argsort(flat[order], stable=True)]
+    fs = flat[order]
+    first = torch.ones_like(fs, dtype=torch.bool)
+    first[1:] = fs[1:] != fs[:-1]
+    return order[first]
+
+
 def transform_torch(points: torch.Tensor, transformation: torch.Tensor):
     """Rigid transform of [N,3] points by a 4x4 matrix, evaluated in the points' dtype
     (utils/tools.py:590-609)."""

@@ -626,8 +626,46 @@ def sampler_fixture():
         print(f"{fn:40s} {os.path.getsize(os.path.join(OUT, fn)) / 1e6:.2f} MB")
 
 
+def map_maintenance_fixture():
+    """G11: the reference's own prune_map / recreate_hash (both branches) on the three-frame map of G7 with a
+    deterministic certainty pattern.  Single-threaded (indexed assignments with duplicate slots)."""
+    torch.set_num_threads(1)
+    ref = import_reference()
+    from clid_slam_amd.synth import box_room_pool
+
+    cfg = ref_config(ref)
+    torch.manual_seed(42)
+    nm = ref.NeuralPoints(cfg)
+    nm.travel_dist = torch.tensor([0.0, 400.0, 403.5], dtype=torch.float32)
+    sensors = [(0.0, 0.0, 1.5), (6.0, 2.0, 1.5), (9.0, 3.0, 1.6)]
+    for fid, s in enumerate(sensors):
+        d = box_room_pool(cfg, n_elev=32, n_azim=256, seed=42 + fid, sensor=s)
+        near = d["sdf_label"].abs() < cfg.surface_sample_range_m * 0.5
+        nm.update(d["coord"][near], d["sensor"], torch.eye(3), fid)
+    n0 = nm.count()
+    nm.point_certainties = ((torch.arange(n0) * 7919) % 1000).float() / 250.0
+    nm.geo_features = torch.cat((torch.arange(n0, dtype=torch.float32)[:, None].repeat(1, 8) * 1e-3, torch.zeros(1, 8)), 0)
+    out = {"n0": np.int64(n0), "buffer_size": np.int64(cfg.buffer_size)}
+    pruned = nm.prune_map(1.0, min_prune_count=50)
+    out.update(pruned=np.int64(int(pruned)), p_points=nm.neural_points.numpy(), p_ts_create=nm.point_ts_create.numpy(),
+               p_cert=nm.point_certainties.numpy(), p_feat0=nm.geo_features[:, 0].numpy())
+    nm.recreate_hash(None, None, True, True, 2)
+    occ = torch.nonzero(nm.buffer_pt_index >= 0).flatten()
+    out.update(k_slot=occ.numpy(), k_idx=nm.buffer_pt_index[occ].numpy())
+    nm.local_map_radius = 12.0
+    nm.recreate_hash(torch.tensor(sensors[-1]), torch.eye(3), False, False, 2)
+    occ = torch.nonzero(nm.buffer_pt_index >= 0).flatten()
+    out.update(m_points=nm.neural_points.numpy(), m_cert=nm.point_certainties.numpy(), m_feat0=nm.geo_features[:, 0].numpy(),
+               m_slot=occ.numpy(), m_idx=nm.buffer_pt_index[occ].numpy(), m_local=nm.local_neural_points.numpy())
+    np.savez_compressed(os.path.join(OUT, "g11_map_maintenance.npz"), **out)
+    print("G11: points", n0, "-> pruned", nm_count_after := out["p_points"].shape[0], "-> merged", out["m_points"].shape[0],
+          "| kept-hash slots", out["k_slot"].shape[0], "local", out["m_local"].shape[0])
+
+
 if __name__ == "__main__":
-    if "--only-g9" in sys.argv:
+    if "--only-g11" in sys.argv:
+        map_maintenance_fixture()
+    elif "--only-g9" in sys.argv:
         sampler_fixture()
     elif "--only-g8" in sys.argv:
         tracking_fixture()

@@ -128,3 +128,45 @@ def test_pickles_like_the_reference_module(tmp_path):
                  "point_certainties", "local_neural_points", "local_geo_features", "local_point_certainties",
                  "local_point_ts_update", "local_mask", "global2local", "buffer_pt_index"):
         assert hasattr(nm2, name)
+
+
+def _g11_run(device):
+    z = gio.load("g11_map_maintenance.npz")
+    cfg = HotPathConfig()
+    cfg.device = device
+    cfg.buffer_size = int(gio.S(z["buffer_size"]))
+    torch.manual_seed(42)
+    nm = NeuralPoints(cfg)
+    nm.travel_dist = torch.tensor([0.0, 400.0, 403.5], device=device)
+    sensors = [(0.0, 0.0, 1.5), (6.0, 2.0, 1.5), (9.0, 3.0, 1.6)]
+    for fid, s in enumerate(sensors):
+        d = box_room_pool(cfg, n_elev=32, n_azim=256, seed=42 + fid, sensor=s)
+        near = d["sdf_label"].abs() < cfg.surface_sample_range_m * 0.5
+        nm.update(d["coord"][near].to(device), d["sensor"].to(device), torch.eye(3, device=device), fid)
+    n0 = nm.count()
+    assert n0 == int(gio.S(z["n0"]))
+    nm.point_certainties = (((torch.arange(n0) * 7919) % 1000).float() / 250.0).to(device)
+    nm.geo_features = torch.cat((torch.arange(n0, dtype=torch.float32)[:, None].repeat(1, 8) * 1e-3, torch.zeros(1, 8)), 0).to(device)
+    cpu = lambda t: t.detach().cpu().numpy()
+    # prune_map (model/neural_points.py:771-812)
+    assert nm.prune_map(1.0, min_prune_count=50) == bool(gio.S(z["pruned"]))
+    assert np.array_equal(cpu(nm.neural_points), z["p_points"]) and np.array_equal(cpu(nm.point_ts_create), z["p_ts_create"])
+    assert np.array_equal(cpu(nm.point_certainties), z["p_cert"]) and np.array_equal(cpu(nm.geo_features[:, 0]), z["p_feat0"])
+    # recreate_hash keeping every point: one representative per voxel, the closest in time (:840-890)
+    nm.recreate_hash(None, None, True, True, 2)
+    occ = torch.nonzero(nm.buffer_pt_index >= 0).flatten()
+    assert np.array_equal(cpu(occ), z["k_slot"]) and np.array_equal(cpu(nm.buffer_pt_index[occ]), z["k_idx"])
+    # recreate_hash merging by certainty, then the local map around the sensor (:891-929, vis_pin_map.py:121-123)
+    nm.local_map_radius = 12.0
+    nm.recreate_hash(torch.tensor(sensors[-1], device=device), torch.eye(3, device=device), False, False, 2)
+    assert np.array_equal(cpu(nm.neural_points), z["m_points"]) and np.array_equal(cpu(nm.point_certainties), z["m_cert"])
+    assert np.array_equal(cpu(nm.geo_features[:, 0]), z["m_feat0"])
+    occ = torch.nonzero(nm.buffer_pt_index >= 0).flatten()
+    assert np.array_equal(cpu(occ), z["m_slot"]) and np.array_equal(cpu(nm.buffer_pt_index[occ]), z["m_idx"])
+    assert np.array_equal(cpu(nm.local_neural_points), z["m_local"])
+
+
+def test_prune_and_recreate_hash_match_the_reference():
+    """G11: the reference's own prune_map / recreate_hash (keeping and merging) on the three-frame map."""
+    torch.set_num_threads(1)
+    _g11_run("cpu")

@@ -67,3 +67,9 @@ def test_map_growth_on_the_gpu_rebuilds_the_reference_map():
     nm.reset_local_map(torch.tensor(sensors[-1], device="cuda"), torch.eye(3, device="cuda"), 2, reboot_map=True)
     assert np.array_equal(nm.global2local.cpu().numpy(), z["global2local"])
     assert np.array_equal(nm.local_neural_points.cpu().numpy(), z["local_neural_points"])
+
+
+def test_prune_and_recreate_hash_on_the_gpu_match_the_reference():
+    from test_host_logic import _g11_run
+
+    _g11_run("cuda")
