@@ -47,7 +47,7 @@ class DataSampler:
         p.dist_weight_on, p.behind_dropoff_on = int(bool(cfg.dist_weight_on)), int(bool(cfg.behind_dropoff_on))
         T = torch.eye(4) if pose is None else torch.as_tensor(pose).detach().cpu()
         T = T.to(torch.float32)  # transform_torch casts the pose to the points' dtype (utils/tools.py:604)
-        p.pose = (C.c_float * 12)(*[float(v) for v in T[:3, :].reshape(-1)])
+        p.pose = (C.c_float * 12)(*T[:3, :].reshape(-1).tolist())
         coord = torch.empty((R * n_all, 3), device=dev, dtype=torch.float32)
         label = torch.empty(R * n_all, device=dev, dtype=torch.float32)
         weight = torch.empty(R * n_all, device=dev, dtype=torch.float32)

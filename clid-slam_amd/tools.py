@@ -150,7 +150,7 @@ def transform_torch(points: torch.Tensor, transformation: torch.Tensor):
         x = points.detach().contiguous()
         out = torch.empty_like(x)
         T = transformation.detach().to("cpu", torch.float32)  # 16 numbers; `.to(points)` in the reference
-        pose = (C.c_float * 12)(*[float(v) for v in T[:3, :].reshape(-1)])
+        pose = (C.c_float * 12)(*T[:3, :].reshape(-1).tolist())
         _lib.check(lib.clid_transform_points(x.data_ptr(), x.shape[0], pose, out.data_ptr(), _lib.stream()),
                    "clid_transform_points")
         return out

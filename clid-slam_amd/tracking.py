@@ -29,8 +29,8 @@ def _launch(neural_points, geo_decoder, config, rot, pos, pc_imu, per_point: boo
     dev = x.device
     view, keep = neural_points._map_view(True)
     W1, b1, W2, b2 = geo_decoder.flat_params()
-    r = (C.c_float * 9)(*[float(v) for v in torch.as_tensor(rot).detach().cpu().to(torch.float32).reshape(-1)])
-    t = (C.c_float * 3)(*[float(v) for v in torch.as_tensor(pos).detach().cpu().to(torch.float32).reshape(-1)])
+    r = (C.c_float * 9)(*torch.as_tensor(rot).detach().to("cpu", torch.float32).reshape(-1).tolist())
+    t = (C.c_float * 3)(*torch.as_tensor(pos).detach().to("cpu", torch.float32).reshape(-1).tolist())
     out = {}
     if per_point:
         out["sdf"] = torch.empty(n, device=dev, dtype=torch.float32)
