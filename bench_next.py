@@ -139,6 +139,30 @@ def main():
     dev = "cuda:0"
     gen = torch.Generator().manual_seed(7)
 
+    # ---- N1: one evaluation of the measurement model on a scan around the sensor
+    near = scene["sdf_label"].abs() < 0.02
+    surf = scene["coord"][near]
+    sel = torch.randperm(surf.shape[0], generator=gen)[: args.track_points]
+    sensor = scene["sensor"].to(torch.float32)
+    pc_imu = (surf[sel] - sensor).to(dev).contiguous()
+    rot = torch.eye(3)
+    n1 = pc_imu.shape[0]
+    t1a = timed(lambda: tracking._launch(nm, dec, cfg, rot, sensor, pc_imu, False, True), 200, warm=50)
+    t1b = timed(lambda: tracking._launch(nm, dec, cfg, rot, sensor, pc_imu, True, False), 200, warm=10)
+    S, b, n_valid = tracking.normal_equations(nm, dec, cfg, rot, sensor, pc_imu)
+    alg1 = n1 * (12.0 + BYTES_SEARCH + BYTES_FEAT + 4.0)
+    line1 = {
+        "row": "N1", "metric": "tracking measurement-model points/sec (IEKFOM.h_model, fused normal equations)",
+        "value": n1 / t1a, "unit": "points/s", "n_gpus": 1, "us_per_call_normal_equations": 1e6 * t1a,
+        "us_per_call_per_point_outputs": 1e6 * t1b, "dtype": "f32 (f64 reduction)", "data": "synthetic",
+        "config": {"workload": "box-room map of bench.py, local map view, one IEKF iteration", "points": n1,
+                   "valid_points": n_valid},
+        "roofline": {"bound": "hbm", "kernel": "k_track_model", "achieved": alg1 / t1a / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": alg1 / t1a / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "note": "a few-thousand-point launch is latency-bound (one wave-latency long); host time per "
+                             "call includes the 9+3 float pose upload by value"},
+    }
+
     # ---- N3: dense inference over points scattered through the mapped volume
     pool = scene["coord"]
     pick = torch.randint(0, pool.shape[0], (args.points,), generator=gen)
@@ -156,30 +180,6 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_sdf_query", "achieved": alg3 / t3 / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": alg3 / t3 / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg3 * min(cfg.infer_bs, args.points) / args.points},
-    }
-
-    # ---- N1: one evaluation of the measurement model on a scan around the sensor
-    near = scene["sdf_label"].abs() < 0.02
-    surf = scene["coord"][near]
-    sel = torch.randperm(surf.shape[0], generator=gen)[: args.track_points]
-    sensor = scene["sensor"].to(torch.float32)
-    pc_imu = (surf[sel] - sensor).to(dev).contiguous()
-    rot = torch.eye(3)
-    n1 = pc_imu.shape[0]
-    t1a = timed(lambda: tracking._launch(nm, dec, cfg, rot, sensor, pc_imu, False, True), 200, warm=10)
-    t1b = timed(lambda: tracking._launch(nm, dec, cfg, rot, sensor, pc_imu, True, False), 200, warm=10)
-    S, b, n_valid = tracking.normal_equations(nm, dec, cfg, rot, sensor, pc_imu)
-    alg1 = n1 * (12.0 + BYTES_SEARCH + BYTES_FEAT + 4.0)
-    line1 = {
-        "row": "N1", "metric": "tracking measurement-model points/sec (IEKFOM.h_model, fused normal equations)",
-        "value": n1 / t1a, "unit": "points/s", "n_gpus": 1, "us_per_call_normal_equations": 1e6 * t1a,
-        "us_per_call_per_point_outputs": 1e6 * t1b, "dtype": "f32 (f64 reduction)", "data": "synthetic",
-        "config": {"workload": "box-room map of bench.py, local map view, one IEKF iteration", "points": n1,
-                   "valid_points": n_valid},
-        "roofline": {"bound": "hbm", "kernel": "k_track_model", "achieved": alg1 / t1a / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": alg1 / t1a / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "note": "a few-thousand-point launch is latency-bound (one wave-latency long); host time per "
-                             "call includes the 9+3 float pose upload by value"},
     }
 
     if not args.no_cpu_baseline:
