@@ -638,3 +638,46 @@ def test_mapping_loop_configuration_sweep_vs_oracle(env, bs, decim, nnc, alpha, 
         assert maxerr(t, o) <= 1e-4
     assert maxerr(nm.local_point_certainties, recs[-1]["certainties"]) <= 2e-3
     assert torch.equal(nm.local_point_ts_update.cpu(), recs[-1]["ts_update"])
+
+
+def test_tiny_map_and_empty_inputs(env):
+    """Edge cases: a local map with fewer points than K, queries with no neighbour at all, zero-length inputs."""
+    from clid_slam_amd import Decoder, HotPathConfig, Mapper, NeuralPoints
+
+    cfg = HotPathConfig()
+    cfg.device, cfg.bs, cfg.bs_new_sample, cfg.buffer_size = "cuda", 16, 0, 100003
+    torch.manual_seed(1)
+    nm = NeuralPoints(cfg)
+    nm.travel_dist = torch.zeros(2, device="cuda")
+    pts = torch.tensor([[0.1, 0.1, 0.1], [0.5, 0.1, 0.1], [0.1, 0.9, 0.1]], device="cuda")
+    nm.update(pts, torch.zeros(3, device="cuda"), torch.eye(3, device="cuda"), 0)
+    assert nm.count() == 3 and nm.local_count() == 3
+    nm.geo_features = torch.cat((0.1 * torch.randn(3, 8), torch.zeros(1, 8))).cuda()
+    nm.reset_local_map(torch.zeros(3, device="cuda"), torch.eye(3, device="cuda"), 0, reboot_map=True)
+    # queries: near the points, and far away (no neighbour in the 81 cells)
+    x = torch.tensor([[0.2, 0.2, 0.2], [30.0, 30.0, 30.0], [0.4, 0.5, 0.0]], device="cuda")
+    feat, _, w, nn_cnt, cert = nm.query_feature(x, training_mode=False)
+    assert nn_cnt.tolist()[0] == 3 and nn_cnt.tolist()[1] == 0
+    assert torch.isfinite(feat).all() and float(w[1].abs().sum()) == 0.0
+    assert abs(float(w[0].sum()) - 1.0) <= 1e-5
+    # zero-length query
+    f0, _, w0, n0, _ = nm.query_feature(torch.empty((0, 3), device="cuda"), training_mode=False)
+    assert f0.shape[0] == 0 and w0.shape[0] == 0 and n0.shape[0] == 0
+    # a short training run on a 40-sample pool (every batch index repeats samples)
+    dec = Decoder(cfg, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, 1)
+
+    class DS:
+        lose_track = False
+        stop_status = False
+        processed_frame = 0
+        gt_pose_provided = False
+
+    mp = Mapper(cfg, DS(), nm, None, dec)
+    g = torch.Generator().manual_seed(2)
+    coord = torch.rand((40, 3), generator=g) * torch.tensor([1.0, 1.2, 0.4])
+    coord[::7] += 25.0  # some samples far from the map
+    mp.set_pool(coord, 0.1 * torch.randn(40, generator=g), torch.ones(40), torch.zeros(40, dtype=torch.int32))
+    before = nm.local_geo_features.detach().clone()
+    mp.mapping(3)
+    assert torch.isfinite(mp.last_losses).all() and torch.isfinite(nm.local_geo_features).all()
+    assert not torch.equal(before, nm.local_geo_features.detach())
