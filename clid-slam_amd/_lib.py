@@ -16,7 +16,13 @@ LIB_PATH = os.path.join(_HERE, "lib", "libclid_native.so")
 
 F, D, H, K = 8, 11, 64, 6
 MLP_PARAMS = H * D + H + H + 1  # 833
-GRAD_FEAT_OFFSET = 836
+GRAD_FEAT_OFFSET = 836     # compact layout: [836 | (M+1) x 8]
+GRAD_ROW16 = 16            # 16-float accumulation rows: 8 gradients | certainty increment | 7 unused
+GRAD_FEAT_OFFSET16 = 848   # [848 | (M+1) x 16], rows 64-byte aligned (include/clid_native.h)
+
+
+def grad_offset(stride: int) -> int:
+    return GRAD_FEAT_OFFSET16 if stride == GRAD_ROW16 else GRAD_FEAT_OFFSET
 
 _vp = C.c_void_p
 _i32 = C.c_int32
@@ -42,7 +48,7 @@ class TrainArgs(C.Structure):
         ("W1", _vp), ("b1", _vp), ("W2", _vp), ("b2", _vp),
         ("sdf_scale", _f32), ("defer_reduce", _i32),
         ("grad", _vp), ("ws", _vp), ("loss_out", _vp),
-        ("debug_flags", _i32), ("pad1", _i32),
+        ("debug_flags", _i32), ("grad_stride", _i32),
     ]
 
 
@@ -52,7 +58,8 @@ class AdamArgs(C.Structure):
         ("W1", _vp), ("b1", _vp), ("W2", _vp), ("b2", _vp), ("m_mlp", _vp), ("v_mlp", _vp),
         ("n_feat", _i64),
         ("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32),
-        ("step", _i32), ("train_decoder", _i32), ("pad0", _i32),
+        ("step", _i32), ("train_decoder", _i32), ("grad_stride", _i32),
+        ("cert", _vp), ("n_cert", _i32), ("pad0", _i32),
     ]
 
 
@@ -102,6 +109,9 @@ _SIGS = {
     "clid_voxel_workspace_bytes": (_i64, [_i32]),
     "clid_voxel_down_sample": (C.c_int, [_vp, _i32, _f32, _vp, _vp, _vp]),
     "clid_mapping_pipeline": (C.c_int, [C.c_int]),
+    "clid_decode_variant": (C.c_int, [C.c_int]),
+    "clid_debug_decode_sdf_out": (C.c_int, [_vp]),
+    "clid_train_decode_kernel": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs)]),
     "clid_train_search_floats": (_i64, [_i32, _i64, _i32, _i32, _i32]),
     "clid_train_search": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), _i32, _vp, _i64, _vp, _vp]),
     "clid_train_decode": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), _vp, _vp]),
@@ -128,7 +138,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.clid_abi_version() != 1:
+    if lib.clid_abi_version() != 2:
         raise RuntimeError("libclid_native.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

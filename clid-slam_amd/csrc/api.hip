@@ -14,4 +14,4 @@ extern "C" void clid_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* clid_last_error(void) { return g_err; }
-extern "C" int clid_abi_version(void) { return 1; }
+extern "C" int clid_abi_version(void) { return 2; }

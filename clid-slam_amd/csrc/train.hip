@@ -21,75 +21,10 @@ namespace clid {
 // All six finite-difference SDFs of a bundle therefore live in one wave, so the eikonal term, its
 // backward, the BCE term and the decoder / feature gradients are produced without a grid-wide hand-off
 // and without writing per-query state to HBM.
-struct QDesc {
-  int p;      // position in this rank's batch, -1 = padding
-  int axis;   // -1 batch sample, 0..2 shifted copy
-  float sign;
-};
-
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Task -> query mapping (no integer division on the common path).  The local batch is cut into lattice
-// blocks of `decim` positions starting at a decimated sample pj = first + j*decim:
-//   bundle task j        : the 6 shifted copies of pj, pj itself, and pj - 1 (the sample in front of it)
-//   plain task (b, c)    : positions pj_b + 1 + 8c .. pj_b + 8 + 8c of block b (offsets <= decim - 2),
-//                          b = -1 covers the samples in front of the first decimated one
-//   tail task            : the last position of the last block (nobody's "pj - 1")
-// n_fd == 0 (no eikonal term): task t simply covers positions 8t .. 8t+7.
-struct TaskMap {
-  int bs, n_fd, first, decim;
-  int chunks;   // plain tasks per lattice block = ceil((decim - 2) / 8)
-  int n_plain;  // (n_fd + 1) * chunks
-  int n_tasks;
-};
-__host__ __device__ inline TaskMap make_task_map(int bs, int n_fd, int first, int decim) {
-  TaskMap m;
-  m.bs = bs; m.n_fd = n_fd; m.first = first; m.decim = decim;
-  if (n_fd == 0) {
-    m.chunks = 1; m.n_plain = (bs + 7) / 8; m.n_tasks = m.n_plain;
-  } else {
-    m.chunks = decim > 2 ? (decim - 2 + 7) / 8 : 0;
-    m.n_plain = (n_fd + 1) * m.chunks;
-    m.n_tasks = n_fd + m.n_plain + 1;  // + tail task
-  }
-  return m;
-}
-__host__ __device__ __forceinline__ QDesc task_query(const TaskMap& tm, int task, int round, int grp) {
-  QDesc q;
-  q.axis = -1;
-  q.sign = 0.f;
-  q.p = -1;
-  const int slot = round * 4 + grp;
-  if (tm.n_fd == 0) {
-    const int p = task * 8 + slot;
-    q.p = p < tm.bs ? p : -1;
-  } else if (task < tm.n_fd) {  // bundle: A = x+,x-,y+,y- ; B = z+, z-, sample, the sample in front of it
-    const int pj = tm.first + task * tm.decim;
-    if (round == 0) {
-      q.p = pj; q.axis = grp >> 1; q.sign = (grp & 1) ? -1.f : 1.f;
-    } else if (grp < 2) {
-      q.p = pj; q.axis = 2; q.sign = grp ? -1.f : 1.f;
-    } else if (grp == 2) {
-      q.p = pj;
-    } else {
-      q.p = tm.decim >= 2 ? pj - 1 : -1;  // -1 for the very first sample: padding
-    }
-  } else if (task < tm.n_fd + tm.n_plain) {
-    const int t = task - tm.n_fd;
-    const int b = (tm.chunks == 1) ? t : t / tm.chunks;
-    const int c = t - b * tm.chunks;
-    const int off = 1 + c * 8 + slot;
-    const int p = tm.first + (b - 1) * tm.decim + off;
-    q.p = (off <= tm.decim - 2 && p >= 0 && p < tm.bs) ? p : -1;
-  } else {
-    const int p = tm.first + tm.n_fd * tm.decim - 1;
-    q.p = (slot == 0 && p < tm.bs && tm.decim >= 2) ? p : -1;
-  }
-  return q;
 }
 
 #ifndef CLID_FUSED_WAVES
@@ -116,12 +51,22 @@ __device__ __forceinline__ int group8_sum_i(int v) {
   return v;
 }
 
+__device__ __forceinline__ float group8_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  return v;
+}
+
 struct WaveHead {       // what the search phase produces (one record of kRecFloat4 float4 per task)
   float4 qinfo[8];      // per query slot: x, y, z, time stamp of the sample (int bits; -1 = padding slot, 0 for shifted copies)
   float4 qdesc[8];      // per query slot: batch position (int bits, -1 = padding), axis/sign code (int bits: -1 = the
                         // sample itself, else 2*axis + (sign > 0)), SDF label, loss weight -- everything the decode
                         // phase needs of the pool, gathered while the search's own loads are in flight
-  float2 win[8][8];     // per slot: up to K winners (d2, local id bits), ascending; (9e3, -1) = none
+  float2 win[8][8];     // per slot: the K nearest neighbours, ascending distance: (IDW weight w_k, local id bits; -1 = none);
+                        // [6] = (fx, fy), [7] = (fz, -): the blended offset sum_k w_k (x - p_k) = decoder inputs 8..10.
+                        // Weights and offsets depend on positions only, never on the training state, so the hoisted
+                        // search resolves them once (np.py:653-706) and the decode kernels gather features only.
 };
 struct WaveLds : WaveHead {
   float4 st[2][64][2];  // per decode round, per lane: {f[lane16], w_k, j_k bits, sdf}, {pre[0..3]}
@@ -297,7 +242,8 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
   MlpAcc acc;
   acc.zero();
   float bce_acc = 0.f, eik_acc = 0.f;
-  float* g_theta = ta.grad + CLID_GRAD_FEAT_OFFSET;
+  const int gstride = ta.grad_stride == CLID_GRAD_ROW16 ? CLID_GRAD_ROW16 : CLID_F;  // floats per accumulation row
+  float* g_theta = ta.grad + CLID_GRAD_OFFSET(gstride);
   const float inv_sigma = fdiv(1.0f, ta.sigma);
   const float inv_two_eps = fdiv(1.0f, 2.0f * ta.fd_eps);
   const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
@@ -349,6 +295,22 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
       } else {
         search8<false, CLID_K>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
       }
+      // (d2, id) -> (IDW weight, id) + blended offset (np.py:653-706), lane8 = k
+      wave_lds_fence();
+      {
+        const float2 wn = hd.win[slot8][lane8 < CLID_K ? lane8 : 0];
+        const int id = __float_as_int(wn.y);
+        const bool valid = lane8 < CLID_K && id >= 0;
+        const float om = valid ? fdiv(1.0f, fadd(wn.x, 1e-15f)) : 0.f;   // np.py:688-693
+        const float osum = group8_sum(om);
+        const float w = valid ? fmul(om, fdiv(1.0f, osum)) : 0.f;        // np.py:699-706
+        const float4 pk = pos4[valid ? id : 0];
+        const float rx = group8_sum(fsub(px, pk.x) * w), ry = group8_sum(fsub(py, pk.y) * w),
+                    rz = group8_sum(fsub(pz, pk.z) * w);
+        wave_lds_fence();
+        hd.win[slot8][lane8] = lane8 < CLID_K ? make_float2(w, wn.y)
+                                              : (lane8 == CLID_K ? make_float2(rx, ry) : make_float2(rz, 0.f));
+      }
     }
     CLID_STAMP(3);
     if constexpr (MODE == 1) {
@@ -372,10 +334,7 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
       const float2 wn = wl.win[s16][my_k];  // my_k < 8 always in range; k = 6,7 hold stale/none -> masked
       int my_j = (lane16 < 2 * CLID_K && sidx >= 0) ? __float_as_int(wn.y) : -1;
       const bool valid = my_j >= 0;
-      float om = valid ? fdiv(1.0f, fadd(wn.x, 1e-15f)) : 0.f;  // np.py:688-693
-      float osum = om;
-      osum += dpp_mov<0x128>(osum); osum += dpp_mov<0x124>(osum); osum += dpp_mov<0x122>(osum);
-      const float my_w = valid ? fmul(om, fdiv(1.0f, osum)) : 0.f;  // np.py:699-706
+      const float my_w = valid ? wn.x : 0.f;  // IDW weight from the search record (np.py:688-706)
       const int jc = valid ? my_j : 0;
       float4 v = reinterpret_cast<const float4*>(mv.feat)[(size_t)jc * 2 + (odd ? 1 : 0)];
       const float4 pj = pos4[jc];
@@ -507,7 +466,7 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
             if (jk >= 0 && delta != 0.f) {
               const int m = (bundle && !(round == 1 && grp == 3)) ? match_base(wl, jk) : -1;
               if (m >= 0) atomicAdd(&wl.cacc[m][lane16 & 7], wk * dfc);
-              else atomicAdd(&g_theta[(size_t)jk * CLID_F + (lane16 & 7)], wk * dfc);
+              else atomicAdd(&g_theta[(size_t)jk * gstride + (lane16 & 7)], wk * dfc);
             }
           }
         } else {
@@ -549,7 +508,7 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
             if (jk >= 0 && delta != 0.f) {
               const int m = (bundle && !(round == 1 && grp == 3)) ? match_base(wl, jk) : -1;
               if (m >= 0) atomicAdd(&wl.cacc[m][c], val);
-              else atomicAdd(&g_theta[(size_t)jk * CLID_F + c], val);
+              else atomicAdd(&g_theta[(size_t)jk * gstride + c], val);
             }
           }
         }
@@ -562,7 +521,7 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
         const int m = lane >> 3, c = lane & 7;
         const int j = __float_as_int(wl.win[6][m].y);
         if (j >= 0) {
-          if (!(ta.debug_flags & 2)) atomicAdd(&g_theta[(size_t)j * CLID_F + c], wl.cacc[m][c]);
+          if (!(ta.debug_flags & 2)) atomicAdd(&g_theta[(size_t)j * gstride + c], wl.cacc[m][c]);
           if (c == 0 && !(ta.debug_flags & 1) && wl.ccert[m] != 0.f) atomicAdd(&mv.cert[j], wl.ccert[m]);
         }
       }
@@ -662,6 +621,8 @@ struct AdamLaunch {
   const float* partial; int nb;           // non-null: decoder grads / loss sums come from the partial rows
   float* loss_out; float inv_n_main, inv_n_eik, weight_e;
   int train_decoder; int n_feat_blocks;
+  int gstride;             // floats per accumulation row of `grad`: CLID_F, or CLID_GRAD_ROW16 (column 8 = certainty increment)
+  float* cert; int n_cert;
   AdamK k;
 };
 
@@ -671,7 +632,30 @@ __global__ void __launch_bounds__(256) k_adam_all(AdamLaunch a) {
   __shared__ float sm[256];
   if ((int)blockIdx.x < a.n_feat_blocks) {
     const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    float* g = a.grad + CLID_GRAD_FEAT_OFFSET;
+    float* g = a.grad + CLID_GRAD_OFFSET(a.gstride);
+    if (a.gstride == CLID_GRAD_ROW16) {  // 16-float accumulation rows: gradients in columns 0..7, certainty increment in 8
+      if (i4 >= a.n_feat) return;
+      const long long row = i4 >> 3;
+      float* gr = g + row * CLID_GRAD_ROW16 + (i4 & 7);
+      float4 P = *reinterpret_cast<float4*>(a.feat + i4), G = *reinterpret_cast<float4*>(gr);
+      float4 M = *reinterpret_cast<float4*>(a.m + i4), V = *reinterpret_cast<float4*>(a.v + i4);
+      adam_update(P.x, G.x, M.x, V.x, a.k, a.k.wd);
+      adam_update(P.y, G.y, M.y, V.y, a.k, a.k.wd);
+      adam_update(P.z, G.z, M.z, V.z, a.k, a.k.wd);
+      adam_update(P.w, G.w, M.w, V.w, a.k, a.k.wd);
+      *reinterpret_cast<float4*>(a.feat + i4) = P;
+      *reinterpret_cast<float4*>(a.m + i4) = M;
+      *reinterpret_cast<float4*>(a.v + i4) = V;
+      *reinterpret_cast<float4*>(gr) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((i4 & 7) == 4 && a.cert && row < a.n_cert) {  // the thread next to column 8 merges the certainty increment (np.py:714)
+        const float inc = gr[4];
+        if (inc != 0.f) {
+          a.cert[row] += inc;
+          gr[4] = 0.f;
+        }
+      }
+      return;
+    }
     if (i4 + 3 < a.n_feat) {
       float4 P = *reinterpret_cast<float4*>(a.feat + i4), G = *reinterpret_cast<float4*>(g + i4);
       float4 M = *reinterpret_cast<float4*>(a.m + i4), V = *reinterpret_cast<float4*>(a.v + i4);
@@ -734,6 +718,9 @@ using namespace clid;
 #include <cstdlib>
 #include <vector>
 namespace {
+// rows of per-block partials the most recent clid_train_fwd_bwd / clid_train_decode launch of this host thread left in
+// the workspace (with defer_reduce the following clid_train_adam folds their reduction into its launch)
+thread_local int g_last_partial_rows = 0;
 bool g_prof = false;
 struct ProfSpan {
   int tag;  // 0 fused / decode kernel, 1 search kernel (hoisted-search loop), 2 partial reduce, 3 adam
@@ -843,6 +830,7 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
   TrainWs ws = carve(a->ws, Q);
   const TaskMap tmap = make_task_map(a->bs, n_fd, first, a->decimation);
   const int nb = a->eikonal_mode == 2 ? clid_train_analytic_blocks(a->bs) : fused_blocks(tmap.n_tasks);
+  g_last_partial_rows = nb;
   int h = prof_begin(0, s);
   if (a->eikonal_mode == 2) {  // loss.numerical_grad_on: False (utils/mapper.py:57-69, 660-661, 695-696)
     if (int e = clid_launch_train_analytic(mv, a, ws.partial, s)) return e;
@@ -912,14 +900,20 @@ extern "C" int clid_train_adam(const clid_adam_args* a, const clid_train_args* t
     const int Q = n_queries(t, &n_fd, &first);
     TrainWs ws = carve(t->ws, Q);
     L.partial = ws.partial;
-    L.nb = t->eikonal_mode == 2 ? clid_train_analytic_blocks(t->bs)
-                                : fused_blocks(make_task_map(t->bs, n_fd, first, t->decimation).n_tasks);
+    L.nb = g_last_partial_rows;
     L.loss_out = t->loss_out;
     L.inv_n_main = t->inv_n_main;
     L.inv_n_eik = t->inv_n_eik;
     L.weight_e = (t->eikonal_mode == 2 || (t->eikonal_mode == 1 && n_fd > 0)) ? t->weight_e : 0.f;
   }
   L.train_decoder = a->train_decoder;
+  L.gstride = a->grad_stride == CLID_GRAD_ROW16 ? CLID_GRAD_ROW16 : CLID_F;
+  L.cert = a->cert;
+  L.n_cert = a->cert ? a->n_cert : 0;
+  if (L.gstride == CLID_GRAD_ROW16 && (a->n_feat % CLID_F) != 0) {
+    clid_set_error("clid_train_adam: n_feat=%lld is not a whole number of rows", (long long)a->n_feat);
+    return CLID_E_ARG;
+  }
   L.n_feat_blocks = (int)(((a->n_feat + 3) / 4 + 255) / 256);
   L.k = adam_scalars(a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->step);
   const int h = prof_begin(3, s);
@@ -952,6 +946,36 @@ static int pipeline_mode() {
     g_pipeline = (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : 1;
   }
   return g_pipeline;
+}
+
+namespace {
+int g_decode = -2;  // -2: read CLID_DECODE on first use; 0 VALU kernel, 1 tile kernel fp32 MFMA, 2 tile kernel bf16 MFMA
+}
+static int decode_variant() {
+  if (g_decode == -2) {
+    const char* e = getenv("CLID_DECODE");
+    g_decode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+  }
+  return g_decode;
+}
+extern "C" int clid_decode_variant(int mode) {
+  const int prev = decode_variant();
+  g_decode = mode < 0 ? -2 : (mode > 2 ? 2 : mode);
+  return prev;
+}
+// the tile kernels cover the numerical / no-eikonal modes on 16-float accumulation rows;
+// everything else runs on the 16-lanes-per-query kernel
+static int decode_variant_for(const clid_map_view* mv, const clid_train_args* a) {
+  const int v = decode_variant();
+  if (v == 0 || a->eikonal_mode == 2 || a->grad_stride != CLID_GRAD_ROW16) return 0;
+  return v;
+}
+extern "C" int clid_train_decode_kernel(const clid_map_view* mv, const clid_train_args* a) {
+  return (mv && a) ? decode_variant_for(mv, a) : CLID_E_ARG;
+}
+// partial rows the decode launch of this iteration leaves in the workspace
+static int decode_blocks(const clid_map_view* mv, const clid_train_args* a, const TaskMap& tmap) {
+  return decode_variant_for(mv, a) ? clid_decode_tile_blocks(tmap.n_tasks) : fused_blocks(tmap.n_tasks);
 }
 
 static bool filter_enabled() {  // CLID_FILTER=0 turns the probe prefilter off (measurement aid)
@@ -1031,11 +1055,17 @@ extern "C" int clid_train_decode(const clid_map_view* mv, const clid_train_args*
   const int Q = n_queries(a, &n_fd, &first);
   TrainWs ws = carve(a->ws, Q);
   const TaskMap tmap = make_task_map(a->bs, n_fd, first, a->decimation);
-  const int nb = fused_blocks(tmap.n_tasks);
+  const int variant = decode_variant_for(mv, a);
+  const int nb = decode_blocks(mv, a, tmap);
+  g_last_partial_rows = nb;
   int h = prof_begin(0, s);
-  hipLaunchKernelGGL(k_train_fused8<2>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap,
-                     reinterpret_cast<float4*>(const_cast<float*>(rec)), 1, 0LL, 0);
-  CLID_CHECK_LAUNCH();
+  if (variant) {
+    if (int e = clid_launch_decode_tile(mv, a, ws.partial, tmap, rec, variant == 2 ? 1 : 0, s)) return e;
+  } else {
+    hipLaunchKernelGGL(k_train_fused8<2>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap,
+                       reinterpret_cast<float4*>(const_cast<float*>(rec)), 1, 0LL, 0);
+    CLID_CHECK_LAUNCH();
+  }
   prof_end(h, s);
   if (!a->defer_reduce) {
     h = prof_begin(2, s);

@@ -29,7 +29,8 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
   MlpAcc acc;
   acc.zero();
   float bce_acc = 0.f, eik_acc = 0.f;
-  float* g_theta = ta.grad + CLID_GRAD_FEAT_OFFSET;
+  const int gstride = ta.grad_stride == CLID_GRAD_ROW16 ? CLID_GRAD_ROW16 : CLID_F;
+  float* g_theta = ta.grad + CLID_GRAD_OFFSET(gstride);
   const float inv_sigma = fdiv(1.0f, ta.sigma);
   const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
   const float sc = ta.sdf_scale;
@@ -188,7 +189,7 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
         d2 = rstd * (d2 - m1 - v.z * m2); d3 = rstd * (d3 - m1 - v.w * m2);
       }
       if (valid && lane16 < 2 * CLID_K && ck != 0.f) {
-        float* dst = g_theta + (size_t)my_j * CLID_F + (odd ? 4 : 0);
+        float* dst = g_theta + (size_t)my_j * gstride + (odd ? 4 : 0);
         atomicAdd(dst + 0, d0); atomicAdd(dst + 1, d1); atomicAdd(dst + 2, d2); atomicAdd(dst + 3, d3);
       }
     }

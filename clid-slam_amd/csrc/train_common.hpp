@@ -52,6 +52,73 @@ __host__ inline TrainWs carve(float* ws, int Q) {
   return t;
 }
 
+// ---- wave tasks of the training kernels (search records are laid out per task) -------------------------
+struct QDesc {
+  int p;      // position in this rank's batch, -1 = padding
+  int axis;   // -1 batch sample, 0..2 shifted copy
+  float sign;
+};
+
+// Task -> query mapping (no integer division on the common path).  The local batch is cut into lattice
+// blocks of `decim` positions starting at a decimated sample pj = first + j*decim:
+//   bundle task j        : the 6 shifted copies of pj, pj itself, and pj - 1 (the sample in front of it)
+//   plain task (b, c)    : positions pj_b + 1 + 8c .. pj_b + 8 + 8c of block b (offsets <= decim - 2),
+//                          b = -1 covers the samples in front of the first decimated one
+//   tail task            : the last position of the last block (nobody's "pj - 1")
+// n_fd == 0 (no eikonal term): task t simply covers positions 8t .. 8t+7.
+struct TaskMap {
+  int bs, n_fd, first, decim;
+  int chunks;   // plain tasks per lattice block = ceil((decim - 2) / 8)
+  int n_plain;  // (n_fd + 1) * chunks
+  int n_tasks;
+};
+__host__ __device__ inline TaskMap make_task_map(int bs, int n_fd, int first, int decim) {
+  TaskMap m;
+  m.bs = bs; m.n_fd = n_fd; m.first = first; m.decim = decim;
+  if (n_fd == 0) {
+    m.chunks = 1; m.n_plain = (bs + 7) / 8; m.n_tasks = m.n_plain;
+  } else {
+    m.chunks = decim > 2 ? (decim - 2 + 7) / 8 : 0;
+    m.n_plain = (n_fd + 1) * m.chunks;
+    m.n_tasks = n_fd + m.n_plain + 1;  // + tail task
+  }
+  return m;
+}
+__host__ __device__ __forceinline__ QDesc task_query(const TaskMap& tm, int task, int round, int grp) {
+  QDesc q;
+  q.axis = -1;
+  q.sign = 0.f;
+  q.p = -1;
+  const int slot = round * 4 + grp;
+  if (tm.n_fd == 0) {
+    const int p = task * 8 + slot;
+    q.p = p < tm.bs ? p : -1;
+  } else if (task < tm.n_fd) {  // bundle: A = x+,x-,y+,y- ; B = z+, z-, sample, the sample in front of it
+    const int pj = tm.first + task * tm.decim;
+    if (round == 0) {
+      q.p = pj; q.axis = grp >> 1; q.sign = (grp & 1) ? -1.f : 1.f;
+    } else if (grp < 2) {
+      q.p = pj; q.axis = 2; q.sign = grp ? -1.f : 1.f;
+    } else if (grp == 2) {
+      q.p = pj;
+    } else {
+      q.p = tm.decim >= 2 ? pj - 1 : -1;  // -1 for the very first sample: padding
+    }
+  } else if (task < tm.n_fd + tm.n_plain) {
+    const int t = task - tm.n_fd;
+    const int b = (tm.chunks == 1) ? t : t / tm.chunks;
+    const int c = t - b * tm.chunks;
+    const int off = 1 + c * 8 + slot;
+    const int p = tm.first + (b - 1) * tm.decim + off;
+    q.p = (off <= tm.decim - 2 && p >= 0 && p < tm.bs) ? p : -1;
+  } else {
+    const int p = tm.first + tm.n_fd * tm.decim - 1;
+    q.p = (slot == 0 && p < tm.bs && tm.decim >= 2) ? p : -1;
+  }
+  return q;
+}
+
+
 // ---- decoder-gradient accumulation -------------------------------------------------------------------
 // dW1 [64 x 11] = sum_q dh_q (x) f_q is a GEMM whose reduction runs over the QUERIES, so it goes on the
 // matrix cores: v_mfma_f32_16x16x4_f32 (exact fp32, == an fmaf chain) with
@@ -161,6 +228,10 @@ __device__ __forceinline__ void mlp_backward(const MlpLds& s, const float (&f)[C
 
 }  // namespace clid
 
+// host-side launchers of the tile (matrix-core) decode kernels (train_tile.hip); prec 0 = fp32, 1 = bf16 operands
+int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, float* partial, const clid::TaskMap& tmap,
+                            const float* rec, int prec, hipStream_t s);
+int clid_decode_tile_blocks(int n_tasks);
 // host-side launchers of the analytic-eikonal iteration (train_analytic.hip)
 int clid_launch_train_analytic(const clid_map_view* mv, const clid_train_args* a, float* partial, hipStream_t s);
 int clid_train_analytic_blocks(int bs);

@@ -1,0 +1,518 @@
+// Decode / backward of one mapping iteration on the matrix cores: one wave per TILE of 16 query points.
+//
+// Replaces, for the numerical-eikonal / no-eikonal modes, the same reference code as k_train_fused8<2>
+// (csrc/train.hip): label/weight gathers of Mapper.get_batch (utils/mapper.py:501-507), the blend of
+// NeuralPoints.query_feature (model/neural_points.py:618-754) from the hoisted search records, Decoder.sdf
+// (model/decoder.py:58-82), the finite-difference eikonal term (mapper.py:697-704, 985-1034), BCE + eikonal
+// loss (utils/loss.py:44-62, mapper.py:746-798) and the backward of all of it.
+//
+// Geometry.  lane = (q = lane & 15, g = lane >> 4): 16 query slots x 4 lanes.  A tile is two consecutive wave
+// tasks of the search kernel (8 query slots each, records of kRecFloat4 float4), so the six shifted copies of a
+// decimated sample and the sample itself sit in lanes q0 .. q0+6 of one DPP row.
+//   gather   lane g = 0 / 1 loads feature columns 0-3 / 4-7 of the query's 6 neighbours (one 16-byte load each),
+//            g = 2 their positions, g = 3 the update stamps; every lane blends ITS 4 columns of the decoder input
+//            f = [sum_k w_k feat_k | sum_k w_k (x - p_k) | 1] in registers -- no cross-lane traffic at all.
+//   layer 1  pre[h][q] = sum_c W1e[h][c] f[c][q] as D = A.B on v_mfma_f32_16x16x4_f32: A[i = h][k] = W1e (the
+//            bias is column 11, f[11] = 1), B[k = g][j = q] = the lane's own blended column 4g + s for K-step s.
+//            The accumulator D_u[r] of lane (q, g) is hidden unit 16u + 4g + r of query q.
+//   layer 2  16 in-lane FMAs + two permlane swaps (lane ^ 16, lane ^ 32).
+//   backward d f[q][c] = sum_h dh[q][h] W1[h][c] with the operands SWAPPED (A = dh straight from the accumulator
+//            registers, B = W1 rows): the result has the feature column on lane & 15 and the query on
+//            (lane >> 4, register).
+//   scatter  The fp32 atomic units at the memory side retire ~17 G REQUESTS/s whatever their width up to 64 bytes
+//            (tools/ubench_atomic.hip) and this launch is bound by them, so the tile first merges its 96 (query,
+//            neighbour) pairs per map row: the distinct rows are numbered through a small LDS hash (integer CAS),
+//            the pair weights form a matrix Wm[row][query], and G[row][c] = sum_q Wm[row][q] d f[q][c] is one more
+//            MFMA with B = the d f registers as they are (column 8 of B is 1, so column 8 of G is the row's
+//            certainty increment, np.py:714).  9 consecutive lanes then add one row = ONE request per distinct row
+//            of the tile (the 7 queries around a decimated sample share nearly all their neighbours).  With layer
+//            norm the row's backward operator is linear and depends on the row only, so it is applied once to the
+//            merged gradient.
+//   dW1      = sum_q dh_q (x) f_q contracts over the queries, which sit on lane & 15: dh and f take one trip
+//            through LDS to put them on the K axis (skipped when the decoder is frozen).
+// PREC = 1 runs the three contractions on v_mfma_f32_16x16x32_bf16 (bf16 operands, fp32 accumulation,
+// BASELINE.json configs[2]); everything outside the MFMAs is unchanged fp32.
+#include "train_common.hpp"
+
+namespace clid {
+
+constexpr int kTileBlock = 256;
+constexpr int kTileWaves = kTileBlock / 64;
+constexpr int kRecF4 = 48;       // float4 per search record (== kRecFloat4 of train.hip)
+constexpr int kDhStride = 84;    // floats per query row of the dh transposition buffer (conflict-free b128 stores)
+constexpr int kFStride = 20;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHash = 128;      // LDS hash slots for the <= 96 distinct map rows of a tile
+constexpr int kMaxRows = 96;
+struct alignas(16) TileLds {
+  float dh[16 * kDhStride];  // [q][h]
+  float f[16 * kFStride];    // [q][c], c = 0..15 (11 = the bias input 1, 12..15 = 0)
+  float wm[kMaxRows * 16];   // [row][q]: weight of query q on the tile's distinct map row `row`
+  int hkey[kHash];           // hash slot -> map row id, -1 empty
+  int hrow[kHash];           // hash slot -> row number inside the tile
+  int rowid[kMaxRows];       // row number -> map row id
+  int count;                 // distinct rows of the tile
+};
+
+__device__ __forceinline__ float xsum16(float v) {  // v[lane] + v[lane ^ 16]
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xsum32(float v) {  // v[lane] + v[lane ^ 32]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// two floats -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32); `lo` lands in bits 0..15
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{lo, hi}), bf16x2));
+}
+__device__ __forceinline__ float bf16_round(float x) { return __uint_as_float(pack_bf16(x, 0.f) << 16); }
+__device__ __forceinline__ bf16x8 bf16_frag(unsigned a, unsigned b, unsigned c, unsigned d) {
+  return __builtin_bit_cast(bf16x8, (u32x4{a, b, c, d}));
+}
+
+__device__ __forceinline__ void tile_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int PREC, bool LN>
+__global__ void __launch_bounds__(kTileBlock)
+k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap,
+              const float4* __restrict__ rec, int n_tiles, float* __restrict__ sdf_dbg) {
+  __shared__ TileLds tls[kTileWaves];
+  static_assert(sizeof(TileLds) % 16 == 0 && sizeof(TileLds) * kTileWaves >= kTileWaves * kRedFloats * sizeof(float), "LDS plan");
+  float* red = reinterpret_cast<float*>(tls);  // the block flush reuses the tile buffers (after a barrier)
+  const int lane = threadIdx.x & 63, q = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+  TileLds& tl = tls[wave];
+  const bool train = ta.train_decoder != 0;
+  const float sc = ta.sdf_scale;
+  const float inv_sigma = fdiv(1.0f, ta.sigma);
+  const float inv_two_eps = fdiv(1.0f, 2.0f * ta.fd_eps);
+  float* __restrict__ rows = ta.grad + CLID_GRAD_FEAT_OFFSET16;
+  const float4* __restrict__ feat4 = reinterpret_cast<const float4*>(mv.feat);
+  const float4* __restrict__ pos4 = reinterpret_cast<const float4*>(mv.pos4);
+
+  // ---- constant MFMA operands (decoder weights, 3.3 KB, L2-resident)
+  //   A1[u][s] = W1e[16u + q][4g + s]     (W1e = [W1 | b1 | 0 0 0 0])            layer 1, A[i = lane & 15][k = lane >> 4]
+  //   W2r[u][r] = W2[16u + 4g + r]                                                 layer 2 / dh, accumulator layout
+  //   A2[u][r] = W1[16u + 4g + r][q], q < 8                                        d f, B[k = lane >> 4][j = lane & 15]
+  float A1[4][4], W2r[4][4], A2[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int h = 16 * u + q, c = 4 * g + s;
+      float a = 0.f;
+      if (c < CLID_D) a = ta.W1[h * CLID_D + c];
+      else if (c == CLID_D) a = ta.b1[h];
+      const int h2 = 16 * u + 4 * g + s;
+      float w2 = ta.W2[h2];
+      float a2 = q < CLID_F ? ta.W1[h2 * CLID_D + q] : 0.f;
+      if (PREC == 1) {  // bf16 operands; the bias column stays exact (it is added as hi + lo, see below)
+        if (c != CLID_D) a = bf16_round(a);
+        a2 = bf16_round(a2);
+      }
+      A1[u][s] = a;
+      W2r[u][s] = w2;
+      A2[u][s] = a2;
+    }
+  const float b2 = ta.b2[0];
+  CLID_STAMP(0);
+  asm volatile("" ::"v"(A1[3][3]), "v"(W2r[3][3]), "v"(A2[3][3]));
+  CLID_STAMP(1);
+
+  f32x4 dW1a[4];
+  float dW2a[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    dW1a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dW2a[u][r] = 0.f;
+  }
+  float db2a = 0.f, bce_acc = 0.f, eik_acc = 0.f;
+
+  for (int tile = blockIdx.x * kTileWaves + wave; tile < n_tiles; tile += gridDim.x * kTileWaves) {
+    // ================= record of this lane's query slot
+    const int task = 2 * tile + (q >> 3), slot = q & 7;
+    const bool tlive = task < tmap.n_tasks;
+    const float4* r = rec + (size_t)(tlive ? task : 0) * kRecF4;
+    const float4 qi = r[slot];
+    const float4 qq = r[8 + slot];
+    const float4 w01 = r[16 + slot * 4], w23 = r[16 + slot * 4 + 1], w45 = r[16 + slot * 4 + 2];
+    const float4 wf = r[16 + slot * 4 + 3];              // (fx, fy | fz, -): blended offset, decoder inputs 8..10
+    const int sidx = tlive ? __float_as_int(qi.w) : -1;  // time stamp of the sample, -1 = padding slot
+    const bool bundle = tlive && task < tmap.n_fd;
+    // IDW weights and neighbour ids come from the search record (np.py:688-706)
+    float w[CLID_K] = {w01.x, w01.z, w23.x, w23.z, w45.x, w45.z};
+    int j[CLID_K] = {__float_as_int(w01.y), __float_as_int(w01.w), __float_as_int(w23.y),
+                     __float_as_int(w23.w), __float_as_int(w45.y), __float_as_int(w45.w)};
+#pragma unroll
+    for (int k = 0; k < CLID_K; ++k) {
+      if (sidx < 0) j[k] = -1;
+      if (j[k] < 0) w[k] = 0.f;
+    }
+    CLID_STAMP(2);
+    // ================= gather + blend of this lane's 4 decoder-input columns
+    float4 v[CLID_K];
+    int ts_old[CLID_K];
+#pragma unroll
+    for (int k = 0; k < CLID_K; ++k) {
+      const int jc = j[k] >= 0 ? j[k] : 0;
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      ts_old[k] = 0x7fffffff;
+      if (g < 2) v[k] = feat4[(size_t)jc * 2 + g];
+      else if (g == 3 && mv.ts_update && j[k] >= 0) ts_old[k] = mv.ts_update[jc];
+    }
+    if (LN) {  // F.layer_norm over the 8 features of every neighbour row (np.py:632-633); lanes g = 0,1 hold the halves
+#pragma unroll
+      for (int k = 0; k < CLID_K; ++k) {
+        const float mu = xsum16((v[k].x + v[k].y) + (v[k].z + v[k].w)) * (1.0f / CLID_F);
+        const float4 c = make_float4(v[k].x - mu, v[k].y - mu, v[k].z - mu, v[k].w - mu);
+        const float var = xsum16((c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w)) * (1.0f / CLID_F);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        v[k] = make_float4(c.x * rstd, c.y * rstd, c.z * rstd, c.w * rstd);
+      }
+    }
+    CLID_STAMP(3);
+    float pc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CLID_K; ++k) {
+      pc[0] = fmaf(v[k].x, w[k], pc[0]);
+      pc[1] = fmaf(v[k].y, w[k], pc[1]);
+      pc[2] = fmaf(v[k].z, w[k], pc[2]);
+      pc[3] = fmaf(v[k].w, w[k], pc[3]);
+    }
+    if (g == 2) {  // x - neighbour position, blended by the search (np.py:653-674), and the bias input
+      pc[0] = wf.x; pc[1] = wf.y; pc[2] = wf.z; pc[3] = 1.0f;
+    } else if (g == 3) {
+      pc[0] = pc[1] = pc[2] = pc[3] = 0.f;
+    }
+    CLID_STAMP(4);
+    // ================= layer 1 on the matrix cores
+    f32x4 D[4];
+    if (PREC == 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        D[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) D[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[u][s], pc[s], D[u], 0, 0, 0);
+      }
+    } else {
+      // K = 32: lane (q, g) owns K slots 8g .. 8g+7 = its 4 columns (bf16) | 4 spare slots; the spare slots of the
+      // g = 2 lanes carry the bias a second time: b1 = hi + lo with the input 1.0 in slots 3 and 4
+      const bf16x8 bq = bf16_frag(pack_bf16(pc[0], pc[1]), pack_bf16(pc[2], pc[3]), g == 2 ? pack_bf16(1.0f, 0.f) : 0u, 0u);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float blo = A1[u][3] - bf16_round(A1[u][3]);  // g == 2: the bias' low part
+        const bf16x8 aq = bf16_frag(pack_bf16(A1[u][0], A1[u][1]), pack_bf16(A1[u][2], A1[u][3]),
+                                    g == 2 ? pack_bf16(blo, 0.f) : 0u, 0u);
+        D[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bq, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      }
+    }
+    // ================= layer 2 (decoder.py:76-82)
+    float part = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) part = fmaf(W2r[u][rr], fmaxf(D[u][rr], 0.f), part);
+    const float sdf = sc * (xsum32(xsum16(part)) + b2);
+    if (sdf_dbg && g == 0 && tlive) sdf_dbg[(size_t)task * 8 + slot] = sdf;  // tests: SDF per record slot
+    CLID_STAMP(5);
+    // ================= losses
+    const int p = tlive ? __float_as_int(qq.x) : -1;
+    const int code = __float_as_int(qq.y);  // -1 = a batch sample, else 2*axis + (sign > 0)
+    float delta = 0.f;
+    {
+      const int b8 = lane & ~7;
+      const float s0 = __shfl(sdf, b8 + 0, 64), s1 = __shfl(sdf, b8 + 1, 64), s2 = __shfl(sdf, b8 + 2, 64);
+      const float s3 = __shfl(sdf, b8 + 3, 64), s4 = __shfl(sdf, b8 + 4, 64), s5 = __shfl(sdf, b8 + 5, 64);
+      float gx = 0.f, gy = 0.f, gz = 0.f, ecoef = 0.f;
+      if (bundle) {
+        gx = (s0 - s1) * inv_two_eps;  // mapper.py:1011-1013
+        gy = (s2 - s3) * inv_two_eps;
+        gz = (s4 - s5) * inv_two_eps;
+        const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
+        if (slot == 6 && g == 0) eik_acc += (nrm - 1.f) * (nrm - 1.f);
+        ecoef = nrm > 0.f ? ta.weight_e * 2.f * (nrm - 1.f) * ta.inv_n_eik * inv_two_eps / nrm : 0.f;
+      }
+      if (p >= 0) {
+        if (code < 0) {
+          const float label = qq.z, wt = qq.w;
+          const float z = sdf * inv_sigma;
+          const float tgt = __frcp_rn(1.0f + __expf(-label * inv_sigma));  // loss.py:60
+          const float ez = __expf(-fabsf(z));
+          const float sg = (z >= 0.f ? 1.0f : ez) * __frcp_rn(1.0f + ez);
+          const float li = fmaxf(z, 0.f) - z * tgt + __logf(1.0f + ez);    // BCEWithLogits
+          if (g == 0) bce_acc += wt * li;
+          delta = wt * (sg - tgt) * inv_sigma * ta.inv_n_main;
+        } else {
+          const int axis = code >> 1;
+          const float ga = axis == 0 ? gx : (axis == 1 ? gy : gz);
+          delta = ((code & 1) ? 1.0f : -1.0f) * ecoef * ga;
+        }
+      }
+    }
+    CLID_STAMP(6);
+    // ================= backward through the decoder
+    const float dz = sc * delta;
+    float dh[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const bool on = D[u][rr] > 0.f;
+        dh[u][rr] = on ? dz * W2r[u][rr] : 0.f;
+        if (train) dW2a[u][rr] += on ? dz * D[u][rr] : 0.f;
+      }
+    if (train && g == 0) db2a += dz;
+    // d f, operands swapped: Df[rr] of lane (c = lane & 15, G = lane >> 4) = d f[c] of query slot 4G + rr
+    f32x4 Df = {0.f, 0.f, 0.f, 0.f};
+    if (PREC == 0) {
+      f32x4 Df2 = {0.f, 0.f, 0.f, 0.f};  // two independent chains (40-cycle dependent latency vs 32-cycle issue)
+#pragma unroll
+      for (int u = 0; u < 4; u += 2)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          Df = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[u][rr], A2[u][rr], Df, 0, 0, 0);
+          Df2 = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[u + 1][rr], A2[u + 1][rr], Df2, 0, 0, 0);
+        }
+      Df += Df2;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {  // K slot 8g + e <-> hidden 16(2t + e/4) + 4g + e%4
+        const bf16x8 aq = bf16_frag(pack_bf16(dh[2 * t][0], dh[2 * t][1]), pack_bf16(dh[2 * t][2], dh[2 * t][3]),
+                                    pack_bf16(dh[2 * t + 1][0], dh[2 * t + 1][1]), pack_bf16(dh[2 * t + 1][2], dh[2 * t + 1][3]));
+        const bf16x8 bq = bf16_frag(pack_bf16(A2[2 * t][0], A2[2 * t][1]), pack_bf16(A2[2 * t][2], A2[2 * t][3]),
+                                    pack_bf16(A2[2 * t + 1][0], A2[2 * t + 1][1]), pack_bf16(A2[2 * t + 1][2], A2[2 * t + 1][3]));
+        Df = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bq, Df, 0, 0, 0);
+      }
+    }
+    CLID_STAMP(7);
+    // ================= scatter: merge the tile's (query, neighbour) pairs per map row, one request per row
+    // a query's own list may name a row twice (two colliding cells returning the same point): fold the weights
+#pragma unroll
+    for (int k = 1; k < CLID_K; ++k)
+#pragma unroll
+      for (int k2 = 0; k2 < k; ++k2)
+        if (j[k] >= 0 && j[k] == j[k2]) {
+          w[k2] += w[k];
+          j[k] = -1;
+        }
+    tl.hkey[lane] = -1;
+    tl.hkey[lane + 64] = -1;
+    if (lane == 0) tl.count = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxRows * 16 / (64 * 4); ++i)
+      *reinterpret_cast<float4*>(&tl.wm[(i * 64 + lane) * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (train) {  // stage dh and f for the dW1 contraction (same fences)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        *reinterpret_cast<float4*>(&tl.dh[q * kDhStride + 16 * u + 4 * g]) = make_float4(dh[u][0], dh[u][1], dh[u][2], dh[u][3]);
+      *reinterpret_cast<float4*>(&tl.f[q * kFStride + 4 * g]) = make_float4(pc[0], pc[1], pc[2], pc[3]);
+    }
+    tile_lds_fence();
+    // lane (q, g) numbers neighbours k = g and (g < 2) k = g + 4 of its query
+    int hs[2] = {-1, -1};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int k = g + 4 * t;
+      int jk = -1;
+#pragma unroll
+      for (int kk = 0; kk < CLID_K; ++kk) jk = (kk == k) ? j[kk] : jk;
+      if (k < CLID_K && jk >= 0) {
+        unsigned h = ((unsigned)jk * 2654435761u) >> 25;  // 7 bits
+        for (;;) {
+          const int old = atomicCAS(&tl.hkey[h], -1, jk);
+          if (old == -1) {  // first pair of this row in the tile: take the next row number
+            const int d = atomicAdd(&tl.count, 1);
+            tl.hrow[h] = d;
+            tl.rowid[d] = jk;
+            break;
+          }
+          if (old == jk) break;
+          h = (h + 1) & (kHash - 1);
+        }
+        hs[t] = (int)h;
+      }
+    }
+    tile_lds_fence();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int k = g + 4 * t;
+      float wk = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < CLID_K; ++kk) wk = (kk == k) ? w[kk] : wk;
+      if (hs[t] >= 0) tl.wm[tl.hrow[hs[t]] * 16 + q] = wk;
+    }
+    tile_lds_fence();
+    CLID_STAMP(8);
+    {
+      const bool do_cert = !(ta.debug_flags & 1), do_grad = !(ta.debug_flags & 2);
+      const bool act = q < CLID_F ? do_grad : (q == CLID_F && do_cert);
+      const int n_rows = tl.count;
+      // B[k = G][j = c] of K-step rr = d f[c] of query 4G + rr (the registers as they are); column 8 = 1
+      float Bx[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) Bx[rr] = q < CLID_F ? Df[rr] : (q == CLID_F ? 1.0f : 0.f);
+      for (int t0 = 0; t0 < n_rows; t0 += 16) {
+        const float4 a = *reinterpret_cast<const float4*>(&tl.wm[(t0 + q) * 16 + 4 * g]);  // Wm[row t0 + q][4G .. 4G+3]
+        f32x4 G = {0.f, 0.f, 0.f, 0.f};
+        G = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, Bx[0], G, 0, 0, 0);
+        G = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, Bx[1], G, 0, 0, 0);
+        G = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, Bx[2], G, 0, 0, 0);
+        G = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, Bx[3], G, 0, 0, 0);
+        const int4 ids = *reinterpret_cast<const int4*>(&tl.rowid[t0 + 4 * g]);
+        const int id4[4] = {ids.x, ids.y, ids.z, ids.w};
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {  // G[rr] of lane (c, G) = merged gradient column c of row t0 + 4G + rr
+          const bool live_row = t0 + 4 * g + rr < n_rows;
+          float val = G[rr];
+          if (LN) {  // layer-norm backward of the row, once (linear in the incoming gradient; np.py:632-633)
+            const int idc = live_row ? id4[rr] : 0;
+            const float th = q < CLID_F ? mv.feat[(size_t)idc * CLID_F + q] : 0.f;
+            float s1 = th, gsum = q < CLID_F ? val : 0.f;
+            s1 += dpp_mov<0xB1>(s1); s1 += dpp_mov<0x4E>(s1); s1 += dpp_mov<0x141>(s1);
+            const float mu = s1 * (1.0f / CLID_F);
+            const float xc = th - mu;
+            float s2 = xc * xc;
+            s2 += dpp_mov<0xB1>(s2); s2 += dpp_mov<0x4E>(s2); s2 += dpp_mov<0x141>(s2);
+            const float rstd = 1.0f / sqrtf(s2 * (1.0f / CLID_F) + 1e-5f);
+            const float xh = xc * rstd;
+            float gx = gsum * xh;
+            gsum += dpp_mov<0xB1>(gsum); gsum += dpp_mov<0x4E>(gsum); gsum += dpp_mov<0x141>(gsum);
+            gx += dpp_mov<0xB1>(gx); gx += dpp_mov<0x4E>(gx); gx += dpp_mov<0x141>(gx);
+            if (q < CLID_F) val = rstd * (val - gsum * (1.0f / CLID_F) - xh * gx * (1.0f / CLID_F));
+          }
+          if (act && live_row) atomicAdd(&rows[(size_t)id4[rr] * CLID_GRAD_ROW16 + q], val);
+        }
+      }
+    }
+    CLID_STAMP(9);
+    // time stamps (np.py:719-728): amax is idempotent, only a newer stamp needs the atomic
+    if (g == 3 && code < 0 && p >= 0 && mv.ts_update && !(ta.debug_flags & 1)) {
+#pragma unroll
+      for (int k = 0; k < CLID_K; ++k)
+        if (j[k] >= 0 && ts_old[k] < sidx) atomicMax(&mv.ts_update[j[k]], sidx);
+    }
+    CLID_STAMP(10);
+    // ================= dW1 (+ db1 through the bias column) on the matrix cores
+    if (train) {
+      if (PREC == 0) {
+        float bt[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bt[s] = tl.f[(4 * s + g) * kFStride + q];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            dW1a[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(tl.dh[(4 * s + g) * kDhStride + 16 * u + q], bt[s], dW1a[u], 0, 0, 0);
+      } else {  // K slot 8g + e <-> query 8g + e (g < 2), zero above
+        float fq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fq[e] = g < 2 ? tl.f[(8 * g + e) * kFStride + q] : 0.f;
+        const bf16x8 bq = bf16_frag(pack_bf16(fq[0], fq[1]), pack_bf16(fq[2], fq[3]), pack_bf16(fq[4], fq[5]), pack_bf16(fq[6], fq[7]));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float dq[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dq[e] = g < 2 ? tl.dh[(8 * g + e) * kDhStride + 16 * u + q] : 0.f;
+          const bf16x8 aq = bf16_frag(pack_bf16(dq[0], dq[1]), pack_bf16(dq[2], dq[3]), pack_bf16(dq[4], dq[5]), pack_bf16(dq[6], dq[7]));
+          dW1a[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bq, dW1a[u], 0, 0, 0);
+        }
+      }
+    }
+    tile_lds_fence();
+    CLID_STAMP(11);
+  }
+
+  CLID_STAMP(12);
+  __syncthreads();
+  // ---- block flush: one partial row [833 decoder gradients | bce | eik] per block
+  float* mine = red + wave * kRedFloats;
+  const float bce_w = wave_sum(bce_acc), eik_w = wave_sum(eik_acc);
+  if (train) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int h = 16 * u + 4 * g + rr;
+        if (q < CLID_D) mine[h * CLID_D + q] = dW1a[u][rr];
+        else if (q == CLID_D) mine[CLID_H * CLID_D + h] = dW1a[u][rr];
+        const float s2 = group_sum(dW2a[u][rr]);
+        if (q == 0) mine[CLID_H * CLID_D + CLID_H + h] = s2;
+      }
+    const float db2_w = wave_sum(db2a);
+    if (lane == 0) mine[CLID_MLP_PARAMS - 1] = db2_w;
+  }
+  if (lane == 0) {
+    mine[CLID_MLP_PARAMS] = bce_w;
+    mine[CLID_MLP_PARAMS + 1] = eik_w;
+  }
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * kPartialStride;
+  for (int i = train ? threadIdx.x : CLID_MLP_PARAMS + threadIdx.x; i < CLID_MLP_PARAMS + 2; i += kTileBlock) {
+    float s = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < kTileWaves; ++wv) s += red[wv * kRedFloats + i];
+    out[i] = s;
+  }
+  CLID_STAMP(13);
+}
+
+}  // namespace clid
+
+using namespace clid;
+
+namespace {
+float* g_sdf_dbg = nullptr;
+}
+#ifdef CLID_TIMING
+extern "C" int clid_debug_read_stamps_tile(long long* out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(clid::clid_stamps), sizeof(long long) * 256 * 32) == hipSuccess ? 0 : -3;
+}
+#endif
+// test aid: the tile kernels also store the predicted SDF of every record slot ([n_tasks][8] floats, device memory)
+extern "C" int clid_debug_decode_sdf_out(float* sdf_out) {
+  g_sdf_dbg = sdf_out;
+  return CLID_OK;
+}
+
+int clid_decode_tile_blocks(int n_tasks) {
+  const int tiles = (n_tasks + 1) / 2;
+  int nb = (tiles + kTileWaves - 1) / kTileWaves;
+  return nb > kMaxBwdBlocks ? kMaxBwdBlocks : (nb < 1 ? 1 : nb);
+}
+
+int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, float* partial, const TaskMap& tmap,
+                            const float* rec, int prec, hipStream_t s) {
+  if (a->grad_stride != CLID_GRAD_ROW16) {
+    clid_set_error("clid_train_decode: the tile kernels need grad_stride == %d (got %d)", CLID_GRAD_ROW16, a->grad_stride);
+    return CLID_E_ARG;
+  }
+  if (((uintptr_t)a->grad & 63) != 0) {
+    clid_set_error("clid_train_decode: grad must be 64-byte aligned for the 16-float accumulation rows");
+    return CLID_E_ARG;
+  }
+  const int n_tiles = (tmap.n_tasks + 1) / 2;
+  const int nb = clid_decode_tile_blocks(tmap.n_tasks);
+  const float4* r4 = reinterpret_cast<const float4*>(rec);
+#define CLID_TILE_LAUNCH(P, L) \
+  hipLaunchKernelGGL((k_decode_tile<P, L>), dim3(nb), dim3(kTileBlock), 0, s, *mv, *a, partial, tmap, r4, n_tiles, g_sdf_dbg)
+  if (prec == 1) {
+    if (mv->layer_norm) CLID_TILE_LAUNCH(1, true);
+    else CLID_TILE_LAUNCH(1, false);
+  } else {
+    if (mv->layer_norm) CLID_TILE_LAUNCH(0, true);
+    else CLID_TILE_LAUNCH(0, false);
+  }
+#undef CLID_TILE_LAUNCH
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}

@@ -164,7 +164,10 @@ class Mapper:
         n_eik_global = (bs_global + decim - 1) // decim
 
         n_feat = theta.numel()
-        grad = torch.zeros(_lib.GRAD_FEAT_OFFSET + n_feat, device=dev, dtype=torch.float32)
+        # fused gradient buffer [decoder 833 | pad | (M+1) accumulation rows of 16 floats: 8 gradients, certainty
+        # increment, 7 unused] (include/clid_native.h CLID_GRAD_ROW16)
+        gstride = _lib.GRAD_ROW16
+        grad = torch.zeros(_lib.GRAD_FEAT_OFFSET16 + (n_feat // _lib.F) * gstride, device=dev, dtype=torch.float32)
         m = torch.zeros(n_feat, device=dev, dtype=torch.float32)
         v = torch.zeros(n_feat, device=dev, dtype=torch.float32)
         m_mlp = torch.zeros(_lib.MLP_PARAMS, device=dev, dtype=torch.float32)
@@ -194,6 +197,7 @@ class Mapper:
         ta.grad, ta.ws = grad.data_ptr(), self._ws.data_ptr()
         ta.defer_reduce = 0 if dist else 1
         ta.debug_flags = int(os.environ.get('CLID_DEBUG_FLAGS', '0'))
+        ta.grad_stride = gstride
 
         aa = _lib.AdamArgs()
         aa.feat, aa.grad, aa.m, aa.v = theta.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr()
@@ -203,6 +207,8 @@ class Mapper:
         aa.lr, aa.beta1, aa.beta2, aa.eps = float(cfg.lr), 0.9, 0.99, float(cfg.adam_eps)
         aa.weight_decay = float(cfg.weight_decay)
         aa.train_decoder = int(train_decoder)
+        aa.grad_stride = gstride
+        aa.cert, aa.n_cert = nm.local_point_certainties.data_ptr(), int(nm.local_point_certainties.shape[0])
 
         stream = _lib.stream()
         idx_base, row_bytes = index_seq.data_ptr(), bs_global * 8
@@ -216,6 +222,9 @@ class Mapper:
             # the neighbour searches do not depend on the training state: one launch per chunk of iterations
             # resolves this rank's shard of every batch, then decode/backward -> all-reduce -> Adam per iteration
             hoist = eik_mode != 2 and os.environ.get("CLID_PIPELINE", "1") != "0"
+            # with the tile kernels the certainty increments ride in the all-reduced accumulation rows (every rank's
+            # Adam launch applies the global sum); the 16-lane kernel adds this rank's share to the array directly
+            cert_in_rows = hoist and lib.clid_train_decode_kernel(C.byref(view), C.byref(ta)) > 0
             chunk = min(iter_count, 32)
             if hoist:
                 per_iter = int(lib.clid_train_search_floats(bs_local, batch_offset, decim, eik_mode, 1))
@@ -240,9 +249,10 @@ class Mapper:
         self.total_iter += iter_count
         if dist:
             # merge the replicas' side effects once per call (not read inside the loop's loss)
-            inc = nm.local_point_certainties - cert0
-            dist.all_reduce(inc)
-            nm.local_point_certainties.copy_(cert0 + inc)
+            if not cert_in_rows:
+                inc = nm.local_point_certainties - cert0
+                dist.all_reduce(inc)
+                nm.local_point_certainties.copy_(cert0 + inc)
             dist.all_reduce(nm.local_point_ts_update, op=dist.ReduceOp.MAX)
             dist.all_reduce(losses)
         self.last_losses = losses

@@ -34,6 +34,16 @@ extern "C" {
 #define CLID_K 6   /* config.query_nn_k             (utils/config.py:546) */
 #define CLID_MLP_PARAMS (CLID_H * CLID_D + CLID_H + CLID_H + 1) /* 833: W1|b1|W2|b2 */
 #define CLID_GRAD_FEAT_OFFSET 836 /* feature gradients start here in the fused gradient buffer (16 B aligned) */
+/* Accumulation-row layout of the fused gradient buffer (clid_train_args.grad_stride):
+ *   8  (or 0): [836 | (M+1) rows of F = 8 floats]                      -- the layout of round 1
+ *   16       : [848 | (M+1) rows of 16 floats = 8 gradients | certainty increment | 7 unused]
+ * With 16-float rows (64-byte aligned) the scatter of one (query, neighbour) pair -- 8 gradient adds and the
+ * certainty add of np.py:714 -- is ONE memory-side atomic request instead of two (the atomic units retire
+ * ~17 G requests/s whatever their width up to 64 bytes: tools/ubench_atomic.hip); clid_train_adam folds the
+ * certainty column into `cert` and zeroes it. */
+#define CLID_GRAD_FEAT_OFFSET16 848
+#define CLID_GRAD_ROW16 16
+#define CLID_GRAD_OFFSET(stride) ((stride) == CLID_GRAD_ROW16 ? CLID_GRAD_FEAT_OFFSET16 : CLID_GRAD_FEAT_OFFSET)
 
 #define CLID_OK 0
 #define CLID_E_ARG (-1)
@@ -184,7 +194,7 @@ typedef struct clid_train_args {
   float* loss_out;           /* [4] total,bce,eik,unused (+=) */
   int32_t debug_flags;       /* 0 in production; bit 0 / bit 1 suppress the certainty / gradient atomics (timing ablation);
                                 bit 2 makes clid_train_search take its full-depth path for every wave (tests) */
-  int32_t pad1;
+  int32_t grad_stride;       /* floats per feature row of `grad`: 0 or 8 (compact), 16 (see CLID_GRAD_ROW16) */
 } clid_train_args;
 
 int64_t clid_train_workspace_floats(int32_t bs, int32_t decimation, int32_t eikonal_mode);
@@ -199,6 +209,9 @@ typedef struct clid_adam_args {
   float lr, beta1, beta2, eps, weight_decay;
   int32_t step;                                        /* 1-based, restarts every mapping() call */
   int32_t train_decoder;
+  int32_t grad_stride;                                 /* as clid_train_args.grad_stride */
+  float* cert;                                         /* [n_cert] local_point_certainties: += column 8 of the 16-float rows */
+  int32_t n_cert;                                      /* M (0 / NULL with 8-float rows) */
   int32_t pad0;
 } clid_adam_args;
 /* `t` = the args of the clid_train_fwd_bwd call this step belongs to (NULL unless t->defer_reduce) */
@@ -227,6 +240,20 @@ int clid_train_decode(const clid_map_view* mv, const clid_train_args* t, const f
  *   0  per iteration the fused search+decode kernel of clid_train_fwd_bwd + Adam.
  * mode < 0 re-reads the environment variable CLID_PIPELINE; returns the previous setting. */
 int clid_mapping_pipeline(int mode);
+
+/* Which kernel clid_train_decode launches (numerical-eikonal / no-eikonal modes):
+ *   0  k_train_fused8<2>: 16 lanes per query, decoder on the VALU, dW1 on fp32 MFMA (round 1);
+ *   1  k_decode_tile<f32>: one wave per 16-query tile, all three decoder contractions of model/decoder.py:58-82
+ *      and their transposes on v_mfma_f32_16x16x4_f32 (exact fp32) -- needs grad_stride == 16;
+ *   2  k_decode_tile<bf16>: the same with bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulation
+ *      (BASELINE.json configs[2]; NOT within the 1e-4 parity bar, reports its own error).
+ * mode < 0 re-reads the environment variable CLID_DECODE; returns the previous setting. */
+int clid_decode_variant(int mode);
+/* the kernel (0 / 1 / 2 as above) clid_train_decode would launch for these arguments: the tile kernels cover the
+ * numerical / no-eikonal modes on 16-float accumulation rows, the rest runs on kernel 0.  With
+ * kernels 1 / 2 the certainty increments travel in column 8 of the accumulation rows (merged by clid_train_adam,
+ * and all-reduced with the gradients when world > 1); kernel 0 adds them to `cert` directly. */
+int clid_train_decode_kernel(const clid_map_view* mv, const clid_train_args* t);
 
 /* ---- sample + label generation in front of the path ("next" row N2) ---------------------------------
  * What the kernels read of `LocalPointCloudMap` (model/local_point_cloud_map.py:11-36): the reference's own
@@ -289,6 +316,10 @@ int clid_voxel_down_sample(const float* points, int32_t n, float voxel_size, voi
  * out[3] = adam; out[4] = empty event-pair overhead (ms). */
 int clid_profile_enable(int on);
 int clid_profile_read(double* out_host, int* iters_host, void* stream);
+
+/* Test aid: while a non-NULL device buffer is registered, the tile decode kernels (clid_decode_variant 1 / 2) also
+ * store the SDF they predict for every record slot, [n_tasks][8] floats in the order of the search records. */
+int clid_debug_decode_sdf_out(float* sdf_out);
 
 /* CPU-only test aid: enumerate the fused kernel's task -> query mapping (see csrc/train.hip). */
 int clid_debug_task_cover(int32_t bs, int64_t batch_offset, int32_t decimation, int32_t eikonal_mode,

@@ -221,9 +221,13 @@ def test_mapping_loop_g6(env, mode, frozen, ln):
     assert np.array_equal(nm.point_ts_update.cpu().numpy(), g["final_point_ts_update"])
 
 
-def _fused_grads(env, cfg, p, g, index, batch_offset=0, n_main=None, n_eik=None, frozen=False, split=False):
+def _fused_grads(env, cfg, p, g, index, batch_offset=0, n_main=None, n_eik=None, frozen=False, split=False,
+                 variant=0, sdf_out=None):
     """Run clid_train_fwd_bwd (or, split=True, clid_train_search + clid_train_decode) once (no Adam) and
-    return (grad buffer, loss[4], certainties, ts)."""
+    return (grad buffer, loss[4], certainties, ts).  `variant` selects the decode kernel of the split form
+    (include/clid_native.h clid_decode_variant): the tile kernels accumulate into 16-float rows whose column 8
+    carries the certainty increments; the result is converted back to the compact layout here.  `sdf_out`
+    (tile kernels): list that receives (records, sdf per record slot)."""
     import ctypes as C
     from clid_slam_amd import _lib
 
@@ -234,7 +238,12 @@ def _fused_grads(env, cfg, p, g, index, batch_offset=0, n_main=None, n_eik=None,
     bs = index.shape[0]
     decim = cfg.gradient_decimation
     view, keep = nm._map_view(True)
-    grad = torch.zeros(_lib.GRAD_FEAT_OFFSET + nm.local_geo_features.numel(), device="cuda")
+    tile = split and variant > 0
+    n_rows = nm.local_geo_features.shape[0]
+    if tile:
+        grad = torch.zeros(_lib.GRAD_FEAT_OFFSET16 + n_rows * _lib.GRAD_ROW16, device="cuda")
+    else:
+        grad = torch.zeros(_lib.GRAD_FEAT_OFFSET + nm.local_geo_features.numel(), device="cuda")
     loss = torch.zeros(4, device="cuda")
     ws = torch.empty(int(lib.clid_train_workspace_floats(bs, decim, 1)), device="cuda")
     idx = index.to(torch.int64).cuda().contiguous()
@@ -251,15 +260,36 @@ def _fused_grads(env, cfg, p, g, index, batch_offset=0, n_main=None, n_eik=None,
     ta.W1, ta.b1, ta.W2, ta.b2 = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr()
     ta.sdf_scale, ta.defer_reduce = float(dec.sdf_scale), 0
     ta.grad, ta.ws, ta.loss_out = grad.data_ptr(), ws.data_ptr(), loss.data_ptr()
+    ta.grad_stride = _lib.GRAD_ROW16 if tile else 0
     if split:
         rec = torch.empty(int(lib.clid_train_search_floats(bs, batch_offset, decim, 1, 1)), device="cuda")
         _lib.check(lib.clid_train_search(C.byref(view), C.byref(ta), 1, idx.data_ptr(), bs, rec.data_ptr(),
                                          _lib.stream()), "clid_train_search")
-        _lib.check(lib.clid_train_decode(C.byref(view), C.byref(ta), rec.data_ptr(), _lib.stream()), "clid_train_decode")
+        prev = lib.clid_decode_variant(variant)
+        sdf = None
+        if sdf_out is not None and tile:
+            sdf = torch.zeros(rec.numel() // 192 * 8, device="cuda")
+            lib.clid_debug_decode_sdf_out(sdf.data_ptr())
+        try:
+            assert lib.clid_train_decode_kernel(C.byref(view), C.byref(ta)) == variant
+            _lib.check(lib.clid_train_decode(C.byref(view), C.byref(ta), rec.data_ptr(), _lib.stream()), "clid_train_decode")
+            torch.cuda.synchronize()
+        finally:
+            lib.clid_decode_variant(prev)
+            lib.clid_debug_decode_sdf_out(None)
+        if sdf is not None:
+            sdf_out.append((rec.view(-1, 48, 4).cpu(), sdf.view(-1, 8).cpu()))
     else:
         _lib.check(lib.clid_train_fwd_bwd(C.byref(view), C.byref(ta), _lib.stream()), "clid_train_fwd_bwd")
     torch.cuda.synchronize()
-    return grad.cpu(), loss.cpu(), nm.local_point_certainties.cpu(), nm.local_point_ts_update.cpu()
+    cert = nm.local_point_certainties.cpu()
+    grad = grad.cpu()
+    if tile:  # back to the compact layout: [836 | rows x 8], certainty increments out of column 8
+        rows = grad[_lib.GRAD_FEAT_OFFSET16:].view(n_rows, _lib.GRAD_ROW16)
+        cert = cert + rows[: cert.shape[0], 8]
+        assert not rows[:, 9:].any()
+        grad = torch.cat((grad[: _lib.GRAD_FEAT_OFFSET], rows[:, :8].reshape(-1)))
+    return grad, loss.cpu(), cert, nm.local_point_ts_update.cpu()
 
 
 @pytest.mark.parametrize("batch_offset", [0, 7])

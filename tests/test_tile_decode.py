@@ -1,0 +1,179 @@
+"""GPU parity of the matrix-core decode kernels (csrc/train_tile.hip, clid_decode_variant 1 = fp32 MFMA, 2 = bf16 MFMA)
+against the 16-lanes-per-query kernel, the reference fixtures (G6) and the CPU oracle.
+
+fp32 variant: same bar as everything else (1e-4, in practice ~1e-6: an MFMA fp32 product chain is an fmaf chain).
+bf16 variant (BASELINE.json configs[2]): bf16 operands / fp32 accumulation is NOT inside the 1e-4 bar; the test
+prints the measured SDF error and bounds it by what bf16 rounding of an 11-term / 64-term dot product allows."""
+import numpy as np
+import pytest
+import torch
+
+import golden_io as gio
+from oracle import cpu_ref as O
+import test_hip_parity as T
+from test_hip_parity import _fused_grads, maxerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import shim_io
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return shim_io
+
+
+def _inputs(env, bs, seed=3, ln=False):
+    p = gio.load("pool.npz")
+    g = gio.load("g6_loop_numerical_train_ln0.npz")
+    cfg = env.config(bs=bs, layer_norm_on=ln)
+    if bs == int(g["index_seq"].shape[1]):
+        index = gio.T(g["index_seq"])[0]
+    else:
+        gen = torch.Generator().manual_seed(seed)
+        index = torch.randint(0, p["coord"].shape[0], (bs,), generator=gen)
+    return p, g, cfg, index
+
+
+@pytest.mark.parametrize("bs,batch_offset,frozen,ln", [(4096, 0, False, 0), (4096, 7, False, 1), (16384, 0, False, 0),
+                                                       (16384, 3, True, 0), (16384, 0, False, 1), (1000, 0, False, 0),
+                                                       (1000, 5, True, 1), (65536, 0, False, 0)])
+def test_tile_fp32_equals_the_valu_decode_kernel(env, bs, batch_offset, frozen, ln):
+    """Same search records, the two decode kernels: gradients / losses / certainties equal up to summation order,
+    time stamps bit-equal.  Covers ragged task counts (bs = 1000: the last tile is half empty) and the grid-stride
+    path (bs = 65536: more tiles than blocks)."""
+    p, g, cfg, index = _inputs(env, bs, ln=bool(ln))
+    a = _fused_grads(env, cfg, p, g, index, batch_offset=batch_offset, frozen=frozen, split=True, variant=0)
+    b = _fused_grads(env, cfg, p, g, index, batch_offset=batch_offset, frozen=frozen, split=True, variant=1)
+    scale = max(1.0, float(a[0].abs().max()))
+    assert maxerr(a[0], b[0]) <= 5e-6 * scale
+    if frozen:
+        assert not b[0][:833].any()
+    assert maxerr(a[1], b[1]) <= 2e-6
+    assert maxerr(a[2], b[2]) <= 1e-5 * max(1.0, float(a[2].abs().max()))  # certainties grow with the batch size
+    assert torch.equal(a[3], b[3])
+    # exact zeros stay exact: rows no query touched
+    ga, gb = a[0][836:].view(-1, 8), b[0][836:].view(-1, 8)
+    assert torch.equal((ga == 0).all(1), (gb == 0).all(1))
+
+
+def test_tile_fp32_gradients_vs_reference(env):
+    """One iteration of the tile kernel against the REFERENCE's own gradients (G6 it0)."""
+    from clid_slam_amd import _lib
+
+    bs = int(gio.load("g6_loop_numerical_train_ln0.npz")["index_seq"].shape[1])
+    p, g, cfg, index = _inputs(env, bs)
+    grad, loss, cert, ts = _fused_grads(env, cfg, p, g, index, split=True, variant=1)
+    assert abs(float(loss[1]) - float(g["loss_bce"][0])) <= 5e-6
+    assert abs(float(loss[0]) - float(g["loss_total"][0])) <= 5e-6
+    H, D = _lib.H, _lib.D
+    parts = {"W1": grad[: H * D].view(H, D), "b1": grad[H * D: H * D + H],
+             "W2": grad[H * D + H: H * D + 2 * H].view(1, H), "b2": grad[H * D + 2 * H: H * D + 2 * H + 1]}
+    for n, t in parts.items():
+        ref = g[f"it0_grad_{n}"]
+        assert np.abs(t.numpy() - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-12), n
+    gt = grad[_lib.GRAD_FEAT_OFFSET:].view(-1, 8).numpy()
+    rows = g["it0_grad_theta_rows"].astype(np.int64)
+    dense = np.zeros_like(gt)
+    dense[rows] = g["it0_grad_theta_vals"]
+    assert np.abs(gt - dense).max() <= 1e-4 * np.abs(dense).max()
+    untouched = np.ones(gt.shape[0], bool)
+    untouched[rows] = False
+    assert not gt[untouched].any()
+    assert maxerr(cert, g["it0_certainties"]) <= 1e-3
+    assert np.array_equal(ts.numpy(), g["it0_ts_update"])
+
+
+def _oracle_sdf(rec, g):
+    """SDF of the oracle at the query position of every live record slot."""
+    qi = rec[:, 0:8, :]  # [tasks, 8, (x, y, z, stamp bits)]
+    live = qi[..., 3].contiguous().view(torch.int32) >= 0
+    x = qi[..., :3][live].contiguous()
+    st = gio.map_state()
+    st.local_geo_features = gio.T(gio.load("pool.npz")["base_geo_features"])[gio.T(gio.load("state.npz")["local_mask"])].clone()
+    dec = gio.decoder(g, "init_")
+    with torch.no_grad():
+        s = O.sdf_at(st, dec, x)
+    return live, s
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_tile_sdf_vs_oracle(env, variant):
+    """max |SDF_hip - SDF_oracle| over every query point of one iteration (batch + finite-difference copies)."""
+    p, g, cfg, index = _inputs(env, 4096)
+    out = []
+    _fused_grads(env, cfg, p, g, index, split=True, variant=variant, sdf_out=out)
+    rec, sdf = out[0]
+    live, ref = _oracle_sdf(rec, g)
+    err = float((sdf[live] - ref).abs().max())
+    rng = float(ref.abs().max())
+    print(f"\n[tile decode variant {variant}] max|dSDF| vs oracle = {err:.3e} over {int(live.sum())} query points "
+          f"(|SDF| up to {rng:.3f} m)")
+    if variant == 1:
+        assert err <= 1e-5          # north-star bar is 1e-4
+    else:
+        assert 1e-7 < err <= 3e-3   # bf16 operands: ~2^-9 relative per product, sdf_scale 0.055
+
+
+def test_mapping_loop_g6_on_the_valu_kernel(env):
+    """The tile kernel is the default decode kernel; the 16-lane kernel must stay green on the reference loop too."""
+    from clid_slam_amd import _lib
+
+    lib = _lib.load()
+    prev = lib.clid_decode_variant(0)
+    try:
+        T.test_mapping_loop_g6(env, "numerical", False, 0)
+        T.test_mapping_loop_g6(env, "numerical", False, 1)
+        T.test_mapping_loop_g6(env, "numerical", True, 0)
+    finally:
+        lib.clid_decode_variant(prev)
+
+
+def test_default_decode_kernel_is_the_tile_kernel(env):
+    import ctypes as C
+
+    from clid_slam_amd import _lib
+
+    lib = _lib.load()
+    p, g, cfg, _ = _inputs(env, 4096)
+    nm = env.neural_points(cfg, base=p)
+    view, keep = nm._map_view(True)
+    ta = _lib.TrainArgs()
+    ta.eikonal_mode, ta.grad_stride = 1, _lib.GRAD_ROW16
+    assert lib.clid_train_decode_kernel(C.byref(view), C.byref(ta)) == 1
+    ta.eikonal_mode = 2  # analytic eikonal: 16-lane kernel family
+    assert lib.clid_train_decode_kernel(C.byref(view), C.byref(ta)) == 0
+
+
+def test_bf16_mapping_tracks_fp32(env):
+    """BASELINE.json configs[2] (bf16 decoder contractions, fp32 master weights / accumulation): 10 iterations from
+    the same state as the fp32 run.  The loss trajectory must track the fp32 one closely; parameters are compared
+    statistically (Adam with eps = 1e-15 turns sign differences of tiny gradients into +-lr steps)."""
+    from clid_slam_amd import _lib
+
+    lib = _lib.load()
+    p, g, cfg, _ = _inputs(env, 16384)
+    gen = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, p["coord"].shape[0], (10, 16384), generator=gen).cuda()
+    res = {}
+    for variant in (1, 2):
+        nm = env.neural_points(cfg, base=p)
+        dec = env.decoder(cfg, g, "init_")
+        mp, _ = env.mapper(cfg, nm, dec)
+        prev = lib.clid_decode_variant(variant)
+        try:
+            mp.mapping(10, index_seq=idx)
+            torch.cuda.synchronize()
+        finally:
+            lib.clid_decode_variant(prev)
+        res[variant] = (mp.last_losses.cpu(), nm.local_geo_features.detach().cpu().clone(),
+                        [t.detach().cpu().clone() for t in dec.flat_params()])
+    l32, l16 = res[1][0], res[2][0]
+    dl = float((l32[:, 0] - l16[:, 0]).abs().max())
+    dtheta = (res[1][1] - res[2][1]).abs()
+    print(f"\n[bf16 vs fp32, 10 iterations bs 16384] max|dloss| {dl:.2e} (loss {float(l32[-1, 0]):.4f}); "
+          f"theta: mean|d| {float(dtheta.mean()):.2e}, max|d| {float(dtheta.max()):.2e}")
+    assert dl <= 5e-3 * max(1.0, float(l32[:, 0].abs().max()))
+    assert float(l16[-1, 0]) < float(l16[0, 0])  # it trains
+    assert float(dtheta.mean()) <= 2e-3

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "clid-slam_amd", "csrc")
 out = "/tmp/libclid_timing.so"
-srcs = [os.path.join(csrc, f) for f in ("api.hip", "table.hip", "query.hip", "train.hip", "train_analytic.hip", "mlp.hip", "sampler.hip", "mapops.hip")]
+srcs = [os.path.join(csrc, f) for f in ("api.hip", "table.hip", "query.hip", "train.hip", "train_analytic.hip", "train_tile.hip", "mlp.hip", "sampler.hip", "mapops.hip")]
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
                        "-ffp-contract=on", "-DCLID_TIMING", "-Wno-unused-value", "-shared", *srcs, "-o", out])
 import clid_slam_amd
@@ -30,6 +30,11 @@ names = {0: "A start", 1: "A buckets", 2: "A pos4", 3: "A inserted", 4: "A selec
          16: "stashed", 17: "bwdA start", 18: "bwdA end", 20: "bwdB start", 21: "bwdB end", 24: "loop end", 25: "flushed"}
 import os
 names = names8
+if os.environ.get("CLID_DECODE", "1") != "0":  # the tile (matrix-core) decode kernel has its own stamps
+    assert lib.clid_debug_read_stamps_tile(buf) == 0
+    a = np.array(buf, dtype=np.int64).reshape(256, 32)
+    names = {0: "start", 1: "weights", 2: "record", 3: "gathered", 4: "blended", 5: "mlp fwd", 6: "loss", 7: "dh+df", 8: "lds fence",
+             9: "atomics", 10: "stamps", 11: "dW1", 12: "loop end", 13: "flushed"}
 keys = sorted(names)
 print("phase deltas (median / p90 cycles at 100 MHz s_memtime? raw units), relative to previous stamp:")
 prev = None
@@ -38,4 +43,4 @@ for k in keys:
         d = a[:, k] - a[:, prev]
         print(f"{names[prev]:>12s} -> {names[k]:<12s} median {np.median(d):9.0f}  p90 {np.percentile(d, 90):9.0f}")
     prev = k
-print("total", np.median(a[:, 25] - a[:, 0]))
+print("total", np.median(a[:, max(keys)] - a[:, 0]))
