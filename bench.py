@@ -1,24 +1,29 @@
 #!/usr/bin/env python3
-"""Headline benchmark: sampled points / second through one mapping iteration of CLID-SLAM's
-SDF training loop (BASELINE.json `metric`), config `run_ncd128.yaml` defaults (configs[1]): fp32,
-bs = 16384 per GPU, numerical eikonal term on every 10th sample, Adam step included.
+"""Headline benchmark: sampled points / second through one mapping iteration of CLID-SLAM's SDF training loop
+(BASELINE.json `metric`).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--config cfg2|cfg3|cfg4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one iteration of `Mapper.mapping` (get_batch gathers, query of bs + 6*ceil(bs/10)
-points, decode, loss, backward, Adam).  N > 1: weak scaling -- every rank trains on its own 16384-
-sample slice of a global batch of N*16384, gradients all-reduced over RCCL each iteration.
-Prints ONE JSON line on rank 0.  Inputs are synthetic (box-room scan, seeds fixed) and resident in
-HBM before the timed region.
+One "step" = one iteration of `Mapper.mapping` (utils/mapper.py:642-836): get_batch gathers, query of bs + 6*ceil(bs/10)
+points, decode, BCE + numerical eikonal loss, backward, Adam.  Workloads (BASELINE.json `configs`):
+  cfg2 (default)  run_ncd128.yaml defaults: fp32, 16384 samples per GPU per step (weak scaling for N > 1)
+  cfg3            65536 samples per step, decoder contractions on bf16 MFMA (fp32 accumulation / master weights)
+  cfg4            262144 samples per step GLOBAL, sharded over the N ranks (strong scaling), fp32
+(cfg5, the SubT_MRS sequence, is a multi-frame run: tools/sequence_bench.py.)
+The timed region is EXACTLY `--steps` iterations of one `mapping()` call between two barrier+synchronize pairs, all
+inputs resident in HBM.  Also reported: the reference's per-frame regime (`mapping(10)` calls, slam.py:187-200, median
+of 100), the per-kernel durations / roofline fractions of a profiled pass (hipExtLaunchKernelGGL start/stop events =
+the dispatch time stamps rocprofv3 --kernel-trace reads), and the CPU oracle on a bounded sample of the same workload.
+Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
 import json
-import math
 import os
+import statistics
 import sys
 import time
 
@@ -28,11 +33,21 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
-# algorithmic bytes per query point (restated in DESIGN.md)
-BYTES_FWD_PER_QUERY = 1004.0
-BYTES_BWD_PER_QUERY = 436.0
-BYTES_POOL_GATHER = 24.0
-BYTES_ADAM_PER_ROW = 256.0
+# Algorithmic bytes per unit (restated in DESIGN.md section 4): per QUERY POINT the forward is
+# 1004 B = 688 B of search (position 12, 81 slot probes 324, valid probes' xyz/stamp/index 352) + 316 B of decode
+# (6 feature rows + certainties 216, side-effect RMWs 96, sdf 4); the backward is 436 B; a batch sample adds a 24 B
+# pool gather; dense Adam moves 256 B per feature row + 28 B per decoder parameter.
+B_SEARCH_Q, B_DECODE_FWD_Q, B_BWD_Q = 688.0, 316.0, 436.0
+B_POOL_SAMPLE, B_ADAM_ROW, B_ADAM_PARAM = 24.0, 256.0, 28.0
+
+CONFIGS = {
+    "cfg2": dict(bs=16384, scaling="weak", decode=1, dtype="f32",
+                 what="run_ncd128.yaml defaults, single-scan mapping loop: fp32"),
+    "cfg3": dict(bs=65536, scaling="weak", decode=2, dtype="bf16",
+                 what="run_ncd128.yaml, 65 536 samples/iter, decoder contractions on bf16 MFMA (fp32 accumulate)"),
+    "cfg4": dict(bs=262144, scaling="strong", decode=1, dtype="f32",
+                 what="run_ncd128.yaml, 262 144 samples/iter sharded over the ranks, RCCL gradient all-reduce, fp32"),
+}
 
 
 def build_scene(cfg, device):
@@ -62,13 +77,13 @@ def build_scene(cfg, device):
     return nm, dec, mp, d
 
 
-def cpu_baseline(cfg, nm, dec, mp, budget_s=15.0, max_iters=400):
+def cpu_baseline(cfg, nm, dec, mp, bs, budget_s=15.0, max_iters=400):
     """The CPU oracle (port of the reference's PyTorch path) on the same map/pool, host cores."""
     from oracle import cpu_ref as O
 
     threads = min(16, os.cpu_count() or 1)  # slam.py:44 uses 16
     torch.set_num_threads(threads)
-    cpu = lambda t: t.detach().cpu().clone()
+    cpu = lambda t: t.detach().cpu().clone()  # noqa: E731
     dx, mv = O.search_neighborhood(cfg.num_nei_cells, cfg.search_alpha, cfg.voxel_size_m)
     st = O.MapState(
         buffer_pt_index=cpu(nm.buffer_pt_index), neural_points=cpu(nm.neural_points),
@@ -85,7 +100,6 @@ def cpu_baseline(cfg, nm, dec, mp, budget_s=15.0, max_iters=400):
                       fd_eps=cfg.voxel_size_m * cfg.num_grad_step_ratio, lr=cfg.lr, adam_eps=cfg.adam_eps)
     gen = torch.Generator().manual_seed(1)
     S = pool.global_coord.shape[0]
-    bs = 16384
     O.mapping_iters(st, od, pool, [torch.randint(0, S, (bs,), generator=gen)], lc)  # warm-up
     done, t0 = 0, time.perf_counter()
     while done < max_iters and time.perf_counter() - t0 < budget_s:
@@ -100,17 +114,63 @@ def cpu_baseline(cfg, nm, dec, mp, budget_s=15.0, max_iters=400):
     }
 
 
+def kernel_report(lib, mp, steps, bs_local, decim, M, decode_variant):
+    """Profiled pass: average dispatch duration per kernel + roofline fraction on the section-8(d) bytes."""
+    from clid_slam_amd import _lib
+
+    lib.clid_profile_enable(1)
+    mp.mapping(steps)
+    out = (C.c_double * 5)()
+    n = C.c_int(0)
+    _lib.check(lib.clid_profile_read(out, C.byref(n), _lib.stream()), "clid_profile_read")
+    lib.clid_profile_enable(0)
+    iters = max(n.value, 1)
+    Q = bs_local + 6 * ((bs_local + decim - 1) // decim)
+    hoisted = out[1] > 0.0
+    dname = {0: "k_train_fused8<2> (decode, 16 lanes/query)", 1: "k_decode_tile<fp32 MFMA>", 2: "k_decode_tile<bf16 MFMA>"}[decode_variant]
+    rows = [
+        (dname if hoisted else "k_train_fused8<0> (search+decode)", out[0] / iters,
+         Q * (B_DECODE_FWD_Q + B_BWD_Q) if hoisted else Q * (B_SEARCH_Q + B_DECODE_FWD_Q + B_BWD_Q) + bs_local * B_POOL_SAMPLE,
+         "752 B/query (316 fwd after the search + 436 bwd) x %d query points" % Q if hoisted else "1440 B/query + 24 B/sample"),
+        ("k_train_fused8<1> (search, per iteration of a <=32-iteration launch)", out[1] / iters,
+         Q * B_SEARCH_Q + bs_local * B_POOL_SAMPLE, "688 B/query x %d + 24 B x %d samples" % (Q, bs_local)),
+        ("k_reduce_partials", out[2] / iters, 0.0, ""),
+        ("k_adam_all", out[3] / iters, B_ADAM_ROW * (M + 1) + 833 * B_ADAM_PARAM, "256 B/row x %d rows + 28 B x 833" % (M + 1)),
+    ]
+    kernels = []
+    for name, ms, alg, how in rows:
+        if ms <= 0.0:
+            continue
+        gbs = alg / (ms * 1e-3) / 1e9 if alg else None
+        kernels.append({"kernel": name, "avg_us": round(ms * 1e3, 3), "algorithmic_bytes": alg, "bytes_rule": how,
+                        "achieved_GBs": gbs and round(gbs, 1), "frac_of_hbm_peak": gbs and round(gbs / HBM_PEAK_GBS, 4)})
+    return kernels, iters
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--bs", type=int, default=16384, help="samples per GPU per step")
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--bs", type=int, default=None, help="override the samples per step (per GPU for weak scaling)")
+    ap.add_argument("--scaling", default=None, choices=("weak", "strong"))
+    ap.add_argument("--decode", type=int, default=None, choices=(0, 1, 2), help="override the decode kernel (clid_decode_variant)")
+    ap.add_argument("--frame-calls", type=int, default=100, help="repetitions of mapping(10) for the per-frame regime (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--freeze-decoder", action="store_true",
                     help="steady-state variant: decoder frozen (freeze_model, slam.py:193-196); not the headline config")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for single-GPU dry runs)")
     args = ap.parse_args()
+    wl = dict(CONFIGS[args.config])
+    if args.bs:
+        wl["bs"] = args.bs
+    if args.scaling:
+        wl["scaling"] = args.scaling
+    if args.decode is not None:
+        wl["decode"] = args.decode
+    elif "CLID_DECODE" in os.environ and args.config == "cfg2":
+        wl["decode"] = int(os.environ["CLID_DECODE"])
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -137,10 +197,18 @@ def main():
 
     cfg = HotPathConfig()  # == config/run_ncd128.yaml resolved values (SURVEY.md section 8 header)
     cfg.device = device
-    cfg.bs = args.bs * world  # global batch; each rank trains on its 16384-sample slice
+    if wl["scaling"] == "strong":
+        if wl["bs"] % world:
+            raise SystemExit(f"global batch {wl['bs']} is not divisible by {world} ranks")
+        bs_global, bs_local = wl["bs"], wl["bs"] // world
+    else:
+        bs_global, bs_local = wl["bs"] * world, wl["bs"]
+    cfg.bs = bs_global
     nm, dec, mp, scene = build_scene(cfg, device)
     lib = _lib.load()
+    lib.clid_decode_variant(wl["decode"])
     M = nm.local_count()
+    decim = cfg.gradient_decimation
 
     def sync():
         if dist:
@@ -151,6 +219,7 @@ def main():
         from clid_slam_amd.tools import freeze_model
 
         freeze_model(dec)
+    mp.reserve(max(args.steps, args.warmup, 10))  # workspaces sized once: nothing is allocated inside a timed region
     mp.mapping(args.warmup)
     sync()
     t0 = time.perf_counter()
@@ -163,83 +232,79 @@ def main():
         dt = float(t.item())
     losses = mp.last_losses[-1].tolist()
 
-    # ---- roofline leg: per-kernel hipEvent timing on the launch stream (separate pass)
-    roof = None
+    # ---- the reference's per-frame regime: mapping(10) per scan (slam.py:187-200), each call timed on its own
+    frame = None
+    if args.frame_calls > 0:
+        per_call = []
+        for _ in range(args.frame_calls):
+            sync()
+            t1 = time.perf_counter()
+            mp.mapping(10)
+            torch.cuda.synchronize()
+            per_call.append(time.perf_counter() - t1)
+        med = statistics.median(per_call)
+        if dist:
+            t = torch.tensor([med], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            med = float(t.item())
+        frame = {"iters_per_call": 10, "calls": args.frame_calls, "median_ms_per_call": 1e3 * med,
+                 "ms_per_step": 1e2 * med, "value": bs_global * 10 / med, "p10_ms_per_call": 1e3 * sorted(per_call)[len(per_call) // 10],
+                 "note": "one Mapper.mapping(10) call per repetition incl. index draw, workspace reset, hoisted search of the "
+                         "10 batches, 10 x (decode, Adam), write-back to the global map; host-synchronised around each call"}
+
+    # ---- roofline leg: dispatch time stamps of every kernel in a separate pass of the same loop
+    kernels, roof = None, None
     prof_steps = min(args.steps, 100)
     if rank == 0:
-        lib.clid_profile_enable(1)
-    mp.mapping(prof_steps)  # every rank takes part (the loop contains collectives when world > 1)
+        kernels, n_prof = kernel_report(lib, mp, prof_steps, bs_local, decim, M, wl["decode"])
+    else:
+        mp.mapping(prof_steps)  # every rank takes part (the loop contains collectives when world > 1)
     if rank == 0:
-        out = (C.c_double * 5)()
-        n = C.c_int(0)
-        _lib.check(lib.clid_profile_read(out, C.byref(n), _lib.stream()), "clid_profile_read")
-        lib.clid_profile_enable(0)
-        ov = out[4]
-        hoisted = out[1] > 0.0  # hoisted searches: one search launch per chunk, then decode + Adam per iteration
-        names = ("k_train_fused8<2> (decode)" if hoisted else "k_train_fused8", "k_train_fused8<1> (search)",
-                 "k_reduce_partials", "k_adam_all")
-        ms = [max(out[i] / max(n.value, 1) - ov, 0.0) for i in range(4)]
-        if hoisted:  # the search is bracketed once per chunk of <= 32 iterations, reported per iteration
-            ms[1] = max(out[1] - ov * math.ceil(n.value / 32), 0.0) / max(n.value, 1)
-        decim = cfg.gradient_decimation
-        Q = args.bs + 6 * ((args.bs + decim - 1) // decim)
-        # algorithmic bytes per launch: search = 688 B per query point (position, 81 bucket
-        # probes, the valid probes' positions) + the 24 B pool gather per batch sample; decode fwd+bwd = 316 +
-        # 436 B per query point; when the two run as separate kernels the 96 B/query record of winners is
-        # written by one and read by the other.  Adam = 256 B per feature row + decoder
-        search_b = Q * 688.0 + args.bs * BYTES_POOL_GATHER
-        decode_b = Q * (BYTES_FWD_PER_QUERY - 688.0 + BYTES_BWD_PER_QUERY)
-        adam_b = BYTES_ADAM_PER_ROW * (M + 1) + 833 * 28.0
-        if hoisted:
-            alg = [decode_b + Q * 96.0, search_b + Q * 96.0, 0.0, adam_b]
-        else:
-            alg = [search_b + decode_b, 0.0, 0.0, adam_b]
-        dom = max(range(4), key=lambda i: ms[i])
-        achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch from the committed PMC passes (same workload only)
+        dom = max(kernels, key=lambda k: k["avg_us"])
+        traffic = None  # HBM bytes per launch from the committed PMC passes (same workload and kernel only)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-            if tj["workload"]["bs_per_gpu"] == args.bs and tj["workload"]["decimation"] == decim and names[dom] in tj:
-                traffic = tj[names[dom]]["traffic_bytes"]
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
+            wk = tj["workload"]
+            if wk["bs_per_gpu"] == bs_local and wk["decimation"] == decim and dom["kernel"] in tj:
+                traffic = tj[dom["kernel"]]["traffic_bytes"]
         except (OSError, KeyError, ValueError):
             pass
+        step_bytes = sum(k["algorithmic_bytes"] for k in kernels)
         roof = {
-            "bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes_per_launch": alg[dom], "avg_launch_us": ms[dom] * 1e3,
-            "per_kernel_us": {nme: round(m * 1e3, 2) for nme, m in zip(names, ms) if m > 0.0},
-            "hoisted_search": hoisted,
-            "event_pair_overhead_us": round(ov * 1e3, 2),
-            "step_bytes": sum(alg), "step_frac_of_peak": sum(alg) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-            "note": "hipEvent-bracketed launches on the launch stream in a separate pass of the same loop, minus the "
-                    "measured cost of an empty event pair (rocprofv3 --kernel-trace average for the same kernel: "
-                    "profiles/r01_bench_v6_kernel_stats.csv, ~3 us higher because it spans dispatch to completion); "
-                    "traffic = offline PMC passes (profiles/r01_hbm_traffic.json); the kernel is bound by dependent-load "
-                    "latency and instruction issue (profiles/r01_pmc_v6_summary.txt), not by HBM bandwidth",
+            "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": dom["frac_of_hbm_peak"], "traffic": traffic,
+            "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "bytes_rule": dom["bytes_rule"],
+            "avg_launch_us": dom["avg_us"], "kernels": kernels, "profiled_steps": n_prof,
+            "step_bytes": step_bytes, "step_frac_of_peak": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+            "note": "avg_launch_us = mean dispatch begin->end of the kernel (hipExtLaunchKernelGGL start/stop events on the "
+                    "launch stream, the clock rocprofv3 --kernel-trace reports; committed trace: profiles/r02_*_kernel_stats.csv); "
+                    "achieved = SURVEY section 8(d) algorithmic bytes of the launch / that duration; traffic = offline PMC passes "
+                    "(profiles/r02_hbm_traffic.json, 2 x FETCH_SIZE + WRITE_SIZE); the loop is bound by dependent-launch latency "
+                    "and the memory-side atomic rate at this batch size, not by HBM bandwidth (DESIGN.md section 6)",
         }
     sync()
 
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base = cpu_baseline(cfg, nm, dec, mp)
+        base = cpu_baseline(cfg, nm, dec, mp, min(bs_local, 16384))
 
     if rank == 0:
-        value = args.bs * world * args.steps / dt
+        value = bs_global * args.steps / dt
         line = {
             "metric": "sampled-points/sec through SDF-MLP fwd+bwd per mapping iter",
             "value": value, "unit": "sampled-points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": wl["scaling"], "vs_baseline": None,
+            "dtype": wl["dtype"], "data": "synthetic",
             "config": {
-                "workload": "run_ncd128.yaml defaults, single-scan mapping loop: fp32, numerical eikonal "
-                            f"(decimation {cfg.gradient_decimation}), Adam; synthetic box-room Ouster-128 scan",
-                "bs_per_gpu": args.bs, "decoder_frozen": bool(args.freeze_decoder), "global_batch": args.bs * world, "query_points_per_step_per_gpu":
-                    args.bs + 6 * ((args.bs + cfg.gradient_decimation - 1) // cfg.gradient_decimation),
+                "workload": f"{args.config}: {wl['what']}; numerical eikonal (decimation {decim}), Adam; synthetic box-room "
+                            "Ouster-128 scan",
+                "bs_per_gpu": bs_local, "global_batch": bs_global, "decoder_frozen": bool(args.freeze_decoder),
+                "decode_kernel": wl["decode"], "query_points_per_step_per_gpu": bs_local + 6 * ((bs_local + decim - 1) // decim),
                 "neural_points_local": M, "pool_samples": int(mp.pool_sample_count), "buffer_size": cfg.buffer_size,
                 "parallelism": f"dp{world} (batch sharded, RCCL all-reduce of [decoder|feature] grads)" if world > 1 else "single GPU",
             },
             "final_loss": {"total": losses[0], "bce": losses[1], "eikonal": losses[2]},
-            "roofline": roof, "cpu_baseline": base,
+            "per_frame_regime": frame, "roofline": roof, "cpu_baseline": base,
         }
         if base:
             line["speedup_vs_cpu_baseline"] = value / base["value"]

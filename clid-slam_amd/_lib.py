@@ -108,6 +108,7 @@ _SIGS = {
     "clid_transform_points": (C.c_int, [_vp, _i32, C.POINTER(_f32), _vp, _vp]),
     "clid_voxel_workspace_bytes": (_i64, [_i32]),
     "clid_voxel_down_sample": (C.c_int, [_vp, _i32, _f32, _vp, _vp, _vp]),
+    "clid_local_to_global": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clid_mapping_pipeline": (C.c_int, [C.c_int]),
     "clid_decode_variant": (C.c_int, [C.c_int]),
     "clid_debug_decode_sdf_out": (C.c_int, [_vp]),

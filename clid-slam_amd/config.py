@@ -140,16 +140,18 @@ class HotPathConfig:
         self.min_range = p.get("min_range_m", self.min_range)
         self.max_range = p.get("max_range_m", self.max_range)
         self.vox_down_m = p.get("vox_down_m", self.vox_down_m)
-        sa = g("sampler", {})
-        self.local_voxel_size_m = sa.get("local_voxel_size_m", self.vox_down_m)  # `utils/config.py:519-521`
-        self.surface_sample_range_m = sa.get("surface_sample_range_m", self.surface_sample_range_m)
-        self.surface_sample_n = sa.get("surface_sample_n", self.surface_sample_n)
-        self.free_sample_begin_ratio = sa.get("free_sample_begin_ratio", self.free_sample_begin_ratio)
-        self.free_sample_end_dist_m = sa.get("free_sample_end_dist_m", self.free_sample_end_dist_m)
-        self.free_front_n = sa.get("free_front_sample_n", self.free_front_n)
-        self.free_behind_n = sa.get("free_behind_sample_n", self.free_behind_n)
-        n = g("neuralpoints", {})
-        self.voxel_size_m = n.get("voxel_size_m", self.voxel_size_m)
+        if "sampler" in args:  # `utils/config.py:518-540`: absent keys fall back to values DERIVED from vox_down_m
+            sa = args["sampler"] or {}
+            self.local_voxel_size_m = sa.get("local_voxel_size_m", self.vox_down_m)
+            self.surface_sample_range_m = sa.get("surface_sample_range_m", self.vox_down_m * 3.0)
+            self.free_sample_begin_ratio = sa.get("free_sample_begin_ratio", self.free_sample_begin_ratio)
+            self.free_sample_end_dist_m = sa.get("free_sample_end_dist_m", self.surface_sample_range_m * 4.0)
+            self.surface_sample_n = sa.get("surface_sample_n", self.surface_sample_n)
+            self.free_front_n = sa.get("free_front_sample_n", self.free_front_n)
+            self.free_behind_n = sa.get("free_behind_sample_n", self.free_behind_n)
+        n = g("neuralpoints", {}) or {}
+        if "neuralpoints" in args:  # `utils/config.py:542-545`
+            self.voxel_size_m = n.get("voxel_size_m", self.vox_down_m * 5.0)
         self.query_nn_k = n.get("query_nn_k", self.query_nn_k)
         self.buffer_size = int(float(n.get("buffer_size", self.buffer_size)))
         self.num_nei_cells = n.get("num_nei_cells", self.num_nei_cells)
@@ -166,11 +168,14 @@ class HotPathConfig:
         self.geo_mlp_level = d.get("mlp_level", self.geo_mlp_level)
         self.geo_mlp_hidden_dim = d.get("mlp_hidden_dim", self.geo_mlp_hidden_dim)
         self.freeze_after_frame = d.get("freeze_after_frame", self.freeze_after_frame)
-        lo = g("loss", {})
+        lo = g("loss", {}) or {}
         self.main_loss_type = lo.get("main_loss_type", self.main_loss_type)
-        self.sigma_sigmoid_m = lo.get("sigma_sigmoid_m", self.sigma_sigmoid_m)
+        if "loss" in args:  # `utils/config.py:624-626`
+            self.sigma_sigmoid_m = lo.get("sigma_sigmoid_m", self.vox_down_m)
         self.loss_weight_on = lo.get("loss_weight_on", self.loss_weight_on)
-        self.dist_weight_scale = lo.get("dist_weight_scale", self.dist_weight_scale)
+        if self.loss_weight_on:  # `utils/config.py:630-637`
+            self.dist_weight_scale = lo.get("dist_weight_scale", self.dist_weight_scale)
+            self.behind_dropoff_on = lo.get("behind_dropoff_on", self.behind_dropoff_on)
         self.ekional_loss_on = lo.get("ekional_loss_on", self.ekional_loss_on)
         self.weight_e = float(lo.get("weight_e", self.weight_e))
         self.numerical_grad = lo.get("numerical_grad_on", self.numerical_grad)
@@ -191,6 +196,16 @@ class HotPathConfig:
         self.pool_filter_freq = c.get("pool_filter_freq", self.pool_filter_freq)
         self.bs_new_sample = int(c.get("batch_size_new_sample", self.bs_new_sample))
         self.pool_capacity = int(float(c.get("pool_capacity", self.pool_capacity)))
+        # `utils/config.py:676, 742-743`: tracking is on only when the YAML has a `tracker` section, PGO only with
+        # tracking and a `pgo` section -- determine_used_pose picks odom / pgo / gt poses from these
+        self.track_on = bool(g("tracker", False))
+        self.pgo_on = bool(g("pgo", False)) if self.track_on else False
+        if self.track_on:  # the measurement model's keys (`utils/config.py:718-727`)
+            tr = args["tracker"]
+            self.reg_iter_n = tr.get("iter_n", self.reg_iter_n)
+            self.track_mask_query_nn_k = tr.get("valid_nn_k", self.track_mask_query_nn_k)
+            self.reg_min_grad_norm = tr.get("min_grad_norm", self.reg_min_grad_norm)
+            self.reg_max_grad_norm = tr.get("max_grad_norm", self.reg_max_grad_norm)
         o = g("optimizer", {})
         self.iters = o.get("iters", self.iters)
         self.bs = o.get("batch_size", self.bs)

@@ -188,6 +188,24 @@ __global__ void __launch_bounds__(256) k_transform(const float* __restrict__ pts
   out[i * 3 + 2] = fmaf(z, p.T[10], fmaf(y, p.T[9], fmaf(x, p.T[8], p.T[11])));
 }
 
+// NeuralPoints.assign_local_to_global (model/neural_points.py:538-549): the three masked assignments in one launch.
+// ids [n] = global index of local point i (ascending, == nonzero(local_mask[:-1])); the padding row n of the local
+// feature table goes to global row `pad_row` (the reference's mask includes the last, padding, element).
+__global__ void __launch_bounds__(256)
+k_local_to_global(const long long* __restrict__ ids, int n, long long pad_row, const float4* __restrict__ lfeat,
+                  const float* __restrict__ lcert, const int* __restrict__ lts, float4* __restrict__ gfeat,
+                  float* __restrict__ gcert, int* __restrict__ gts) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = t >> 1, half = t & 1;
+  if (row > n) return;
+  const long long dst = row < n ? ids[row] : pad_row;
+  gfeat[dst * 2 + half] = lfeat[(size_t)row * 2 + half];
+  if (half == 0 && row < n) {
+    gcert[dst] = lcert[row];
+    gts[dst] = lts[row];
+  }
+}
+
 static int vox_log2cap(int n) {
   int l = 10;
   while ((1LL << l) < 2LL * n) ++l;
@@ -295,6 +313,22 @@ extern "C" int clid_transform_points(const float* points, int32_t n, const float
   Pose12 p;
   for (int i = 0; i < 12; ++i) p.T[i] = pose12_host[i];
   hipLaunchKernelGGL(k_transform, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, points, n, p, out);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+extern "C" int clid_local_to_global(const int64_t* ids, int32_t n, int64_t pad_row, const float* local_feat,
+                                    const float* local_cert, const int32_t* local_ts, float* global_feat,
+                                    float* global_cert, int32_t* global_ts, void* stream) {
+  if (n < 0 || !ids || !local_feat || !local_cert || !local_ts || !global_feat || !global_cert || !global_ts) {
+    clid_set_error("clid_local_to_global: bad argument");
+    return CLID_E_ARG;
+  }
+  const int threads = 2 * (n + 1);
+  hipLaunchKernelGGL(k_local_to_global, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(ids), n, (long long)pad_row,
+                     reinterpret_cast<const float4*>(local_feat), local_cert, local_ts,
+                     reinterpret_cast<float4*>(global_feat), global_cert, global_ts);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

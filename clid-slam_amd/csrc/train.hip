@@ -557,32 +557,25 @@ __device__ __forceinline__ float* mlp_param_ptr(float* W1, float* b1, float* W2,
   return b2;
 }
 
-// sum of column p over the nb partial rows; 16 x 16 thread tile: threadIdx = (py, px), 16 columns / block
-__device__ __forceinline__ float column_sum16(const float* __restrict__ partial, int nb, int col0, float* sm) {
-  const int px = threadIdx.x & 15, py = threadIdx.x >> 4;
-  const int p = col0 + px;
-  float s0 = 0.f, s1 = 0.f;
+// sum of column p over the nb partial rows by ONE WAVE: lane l takes rows l, l + 64, ... with all of its loads in
+// flight at once (7 at nb = 410), then a wave reduction -- one memory round trip instead of a chain of them
+__device__ __forceinline__ float column_sum_wave(const float* __restrict__ partial, int nb, int p) {
+  const int lane = threadIdx.x & 63;
+  float a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = 0.f;
+  float s1 = 0.f;
   if (p < CLID_MLP_PARAMS + 2) {
-    float a[8];
+    int b = lane;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = 0.f;
-    int b = py;
-    for (; b + 16 * 7 < nb; b += 16 * 8) {  // 8 independent loads in flight per thread
-#pragma unroll
-      for (int i = 0; i < 8; ++i) a[i] += partial[(size_t)(b + 16 * i) * kPartialStride + p];
-    }
-    for (; b < nb; b += 16) s1 += partial[(size_t)b * kPartialStride + p];
-    s0 = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    for (int i = 0; i < 8; ++i, b += 64)
+      if (b < nb) a[i] = partial[(size_t)b * kPartialStride + p];
+    for (; b < nb; b += 64) s1 += partial[(size_t)b * kPartialStride + p];
   }
-  sm[threadIdx.x] = s0 + s1;
-  __syncthreads();
-  float tot = 0.f;
-  if (py == 0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tot += sm[r * 16 + px];
-  }
-  return tot;  // valid for py == 0
+  return wave_sum((((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + s1);
 }
+constexpr int kColsPerBlock = 4;  // 256 threads = 4 waves = 4 columns of the partial rows
+constexpr int kColBlocks = (CLID_MLP_PARAMS + 2 + kColsPerBlock - 1) / kColsPerBlock;
 
 __device__ __forceinline__ void finish_loss(int p, float tot, float* loss_out, float inv_n_main, float inv_n_eik,
                                             float weight_e) {
@@ -602,17 +595,13 @@ __global__ void __launch_bounds__(256)
 k_reduce_partials(const float* __restrict__ partial, int nb, float* __restrict__ grad,
                   float* __restrict__ loss_out, float inv_n_main, float inv_n_eik, float weight_e,
                   int train_decoder) {
-  __shared__ float sm[256];
-  const int col0 = blockIdx.x * 16;
-  if (!train_decoder && col0 + 15 < CLID_MLP_PARAMS) return;  // frozen decoder: only the loss columns carry data
-  const float tot = column_sum16(partial, nb, col0, sm);
-  const int p = col0 + (threadIdx.x & 15);
-  if ((threadIdx.x >> 4) != 0 || p >= CLID_MLP_PARAMS + 2) return;
-  if (p < CLID_MLP_PARAMS) {
-    if (train_decoder) grad[p] = tot;
-  } else {
-    finish_loss(p, tot, loss_out, inv_n_main, inv_n_eik, weight_e);
-  }
+  const int p = blockIdx.x * kColsPerBlock + (threadIdx.x >> 6);
+  if (p >= CLID_MLP_PARAMS + 2) return;
+  if (!train_decoder && p < CLID_MLP_PARAMS) return;  // frozen decoder: only the loss columns carry data
+  const float tot = column_sum_wave(partial, nb, p);
+  if ((threadIdx.x & 63) != 0) return;
+  if (p < CLID_MLP_PARAMS) grad[p] = tot;
+  else finish_loss(p, tot, loss_out, inv_n_main, inv_n_eik, weight_e);
 }
 
 struct AdamLaunch {
@@ -629,7 +618,6 @@ struct AdamLaunch {
 // blocks [0, n_feat_blocks): dense Adam over the feature table (float4), gradient zeroed in the same pass
 // blocks [n_feat_blocks, +53):  16 decoder parameters each (reduce partial rows or read grad), Adam
 __global__ void __launch_bounds__(256) k_adam_all(AdamLaunch a) {
-  __shared__ float sm[256];
   if ((int)blockIdx.x < a.n_feat_blocks) {
     const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     float* g = a.grad + CLID_GRAD_OFFSET(a.gstride);
@@ -676,16 +664,13 @@ __global__ void __launch_bounds__(256) k_adam_all(AdamLaunch a) {
     }
     return;
   }
-  const int col0 = ((int)blockIdx.x - a.n_feat_blocks) * 16;
-  const int p = col0 + (threadIdx.x & 15);
-  if (!a.train_decoder && col0 + 15 < CLID_MLP_PARAMS) return;  // frozen decoder: no decoder gradients were produced
+  const int p = ((int)blockIdx.x - a.n_feat_blocks) * kColsPerBlock + (threadIdx.x >> 6);
+  if (p >= CLID_MLP_PARAMS + 2) return;
+  if (!a.train_decoder && p < CLID_MLP_PARAMS) return;  // frozen decoder: no decoder gradients were produced
   float gsum;
-  if (a.partial) {
-    gsum = column_sum16(a.partial, a.nb, col0, sm);
-  } else {
-    gsum = (p < CLID_MLP_PARAMS) ? a.grad[p] : 0.f;
-  }
-  if ((threadIdx.x >> 4) != 0 || p >= CLID_MLP_PARAMS + 2) return;
+  if (a.partial) gsum = column_sum_wave(a.partial, a.nb, p);
+  else gsum = (p < CLID_MLP_PARAMS) ? a.grad[p] : 0.f;
+  if ((threadIdx.x & 63) != 0) return;
   if (p < CLID_MLP_PARAMS) {
     if (a.train_decoder) {
       float* dst = mlp_param_ptr(a.W1, a.b1, a.W2, a.b2, p);
@@ -727,20 +712,35 @@ struct ProfSpan {
   hipEvent_t a, b;
 };
 std::vector<ProfSpan> g_spans;
-int prof_begin(int tag, hipStream_t s) {
+thread_local hipEvent_t g_pend_a = nullptr, g_pend_b = nullptr;  // events of the bracket opened by prof_begin
+// opens a bracket: the next CLID_KLAUNCH on this host thread is issued through hipExtLaunchKernelGGL with the
+// bracket's start / stop events, i.e. they carry the dispatch's own begin / end time stamps (what rocprofv3
+// --kernel-trace reports), not the stream time around an event pair
+int prof_begin(int tag, hipStream_t) {
   if (!g_prof) return -1;
   ProfSpan sp;
   sp.tag = tag;
   hipEventCreate(&sp.a);
   hipEventCreate(&sp.b);
-  hipEventRecord(sp.a, s);
   g_spans.push_back(sp);
+  g_pend_a = sp.a;
+  g_pend_b = sp.b;
   return (int)g_spans.size() - 1;
 }
 void prof_end(int h, hipStream_t s) {
-  if (h >= 0) hipEventRecord(g_spans[h].b, s);
+  if (h >= 0 && g_pend_a) {  // no CLID_KLAUNCH consumed the bracket: plain event pair around whatever was enqueued
+    hipEventRecord(g_spans[h].b, s);
+  }
+  g_pend_a = g_pend_b = nullptr;
 }
 }  // namespace
+
+bool clid_prof_take(hipEvent_t* a, hipEvent_t* b) {
+  *a = g_pend_a;
+  *b = g_pend_b;
+  g_pend_a = g_pend_b = nullptr;
+  return *a != nullptr;
+}
 
 #ifdef CLID_TIMING
 extern "C" int clid_debug_read_stamps(long long* out_host) {
@@ -835,14 +835,14 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
   if (a->eikonal_mode == 2) {  // loss.numerical_grad_on: False (utils/mapper.py:57-69, 660-661, 695-696)
     if (int e = clid_launch_train_analytic(mv, a, ws.partial, s)) return e;
   } else {
-    hipLaunchKernelGGL(k_train_fused8<0>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap,
+    CLID_KLAUNCH(k_train_fused8<0>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap,
                        (float4*)nullptr, 1, 0LL, 0);
     CLID_CHECK_LAUNCH();
   }
   prof_end(h, s);
   if (!a->defer_reduce) {
     h = prof_begin(2, s);
-    hipLaunchKernelGGL(k_reduce_partials, dim3((CLID_MLP_PARAMS + 2 + 15) / 16), dim3(256), 0, s, ws.partial,
+    CLID_KLAUNCH(k_reduce_partials, dim3(kColBlocks), dim3(256), 0, s, ws.partial,
                        nb, a->grad, a->loss_out, a->inv_n_main, a->inv_n_eik,
                        (a->eikonal_mode == 2 || (a->eikonal_mode == 1 && n_fd > 0)) ? a->weight_e : 0.f, a->train_decoder);
     CLID_CHECK_LAUNCH();
@@ -917,7 +917,7 @@ extern "C" int clid_train_adam(const clid_adam_args* a, const clid_train_args* t
   L.n_feat_blocks = (int)(((a->n_feat + 3) / 4 + 255) / 256);
   L.k = adam_scalars(a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->step);
   const int h = prof_begin(3, s);
-  hipLaunchKernelGGL(k_adam_all, dim3(L.n_feat_blocks + (CLID_MLP_PARAMS + 2 + 15) / 16), dim3(256), 0, s, L);
+  CLID_KLAUNCH(k_adam_all, dim3(L.n_feat_blocks + kColBlocks), dim3(256), 0, s, L);
   CLID_CHECK_LAUNCH();
   prof_end(h, s);
   return CLID_OK;
@@ -1036,7 +1036,7 @@ extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args*
   const bool use_filter = mv->filter && mv->log2filter >= 10 && mv->log2filter <= 18 && filter_enabled() &&
                           (long long)tmap.n_tasks * n_iter >= 4 * sb * (kFusedBlock / 64);
   const size_t dyn = use_filter ? ((size_t)1 << mv->log2filter) / 8 : 0;
-  hipLaunchKernelGGL(k_train_fused8<1>, dim3((unsigned)sb), dim3(kFusedBlock), dyn, s, *mv, t2, (float*)nullptr, tmap,
+  CLID_KLAUNCH(k_train_fused8<1>, dim3((unsigned)sb), dim3(kFusedBlock), dyn, s, *mv, t2, (float*)nullptr, tmap,
                      reinterpret_cast<float4*>(rec_out), n_iter, (long long)index_stride, use_filter ? 1 : 0);
   CLID_CHECK_LAUNCH();
   prof_end(h, s);
@@ -1062,14 +1062,14 @@ extern "C" int clid_train_decode(const clid_map_view* mv, const clid_train_args*
   if (variant) {
     if (int e = clid_launch_decode_tile(mv, a, ws.partial, tmap, rec, variant == 2 ? 1 : 0, s)) return e;
   } else {
-    hipLaunchKernelGGL(k_train_fused8<2>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap,
+    CLID_KLAUNCH(k_train_fused8<2>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap,
                        reinterpret_cast<float4*>(const_cast<float*>(rec)), 1, 0LL, 0);
     CLID_CHECK_LAUNCH();
   }
   prof_end(h, s);
   if (!a->defer_reduce) {
     h = prof_begin(2, s);
-    hipLaunchKernelGGL(k_reduce_partials, dim3((CLID_MLP_PARAMS + 2 + 15) / 16), dim3(256), 0, s, ws.partial,
+    CLID_KLAUNCH(k_reduce_partials, dim3(kColBlocks), dim3(256), 0, s, ws.partial,
                        nb, a->grad, a->loss_out, a->inv_n_main, a->inv_n_eik,
                        (a->eikonal_mode == 1 && n_fd > 0) ? a->weight_e : 0.f, a->train_decoder);
     CLID_CHECK_LAUNCH();

@@ -228,6 +228,20 @@ __device__ __forceinline__ void mlp_backward(const MlpLds& s, const float (&f)[C
 
 }  // namespace clid
 
+// ---- launches under the optional per-kernel timing of clid_profile_enable (train.hip) -------------------------
+// Inside a prof_begin / prof_end bracket the kernel goes out through hipExtLaunchKernelGGL with the bracket's start and
+// stop events, which then hold the DISPATCH's begin / end time stamps (the same clock rocprofv3 --kernel-trace reads).
+#include <hip/hip_ext.h>
+bool clid_prof_take(hipEvent_t* a, hipEvent_t* b);
+#define CLID_KLAUNCH(kernel, grid, block, shmem, stream, ...)                                        \
+  do {                                                                                               \
+    hipEvent_t ea__, eb__;                                                                           \
+    if (clid_prof_take(&ea__, &eb__))                                                                \
+      hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, ea__, eb__, 0, __VA_ARGS__);         \
+    else                                                                                             \
+      hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                           \
+  } while (0)
+
 // host-side launchers of the tile (matrix-core) decode kernels (train_tile.hip); prec 0 = fp32, 1 = bf16 operands
 int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, float* partial, const clid::TaskMap& tmap,
                             const float* rec, int prec, hipStream_t s);

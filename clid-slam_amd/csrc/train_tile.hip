@@ -99,31 +99,47 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
   const float4* __restrict__ feat4 = reinterpret_cast<const float4*>(mv.feat);
   const float4* __restrict__ pos4 = reinterpret_cast<const float4*>(mv.pos4);
 
-  // ---- constant MFMA operands (decoder weights, 3.3 KB, L2-resident)
+  // ---- constant MFMA operands: the decoder weights (3.3 KB) are staged through LDS with one coalesced load per
+  // thread (48 strided global loads per lane cost ~1.5 us of address-unit time at the start of every wave)
   //   A1[u][s] = W1e[16u + q][4g + s]     (W1e = [W1 | b1 | 0 0 0 0])            layer 1, A[i = lane & 15][k = lane >> 4]
   //   W2r[u][r] = W2[16u + 4g + r]                                                 layer 2 / dh, accumulator layout
   //   A2[u][r] = W1[16u + 4g + r][q], q < 8                                        d f, B[k = lane >> 4][j = lane & 15]
-  float A1[4][4], W2r[4][4], A2[4][4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int h = 16 * u + q, c = 4 * g + s;
-      float a = 0.f;
-      if (c < CLID_D) a = ta.W1[h * CLID_D + c];
-      else if (c == CLID_D) a = ta.b1[h];
-      const int h2 = 16 * u + 4 * g + s;
-      float w2 = ta.W2[h2];
-      float a2 = q < CLID_F ? ta.W1[h2 * CLID_D + q] : 0.f;
-      if (PREC == 1) {  // bf16 operands; the bias column stays exact (it is added as hi + lo, see below)
-        if (c != CLID_D) a = bf16_round(a);
-        a2 = bf16_round(a2);
-      }
-      A1[u][s] = a;
-      W2r[u][s] = w2;
-      A2[u][s] = a2;
+  {
+    float* wl = reinterpret_cast<float*>(tls);  // [W1 704 | b1 64 | W2 64 | b2 1]; overwritten by the first tile's fences later
+    for (int i = threadIdx.x; i < CLID_H * CLID_D; i += kTileBlock) wl[i] = ta.W1[i];
+    if (threadIdx.x < CLID_H) {
+      wl[CLID_H * CLID_D + threadIdx.x] = ta.b1[threadIdx.x];
+      wl[CLID_H * CLID_D + CLID_H + threadIdx.x] = ta.W2[threadIdx.x];
     }
-  const float b2 = ta.b2[0];
+    if (threadIdx.x == 0) wl[CLID_MLP_PARAMS - 1] = ta.b2[0];
+  }
+  __syncthreads();
+  float A1[4][4], W2r[4][4], A2[4][4];
+  float b2;
+  {
+    const float* wl = reinterpret_cast<const float*>(tls);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int h = 16 * u + q, c = 4 * g + s;
+        float a = 0.f;
+        if (c < CLID_D) a = wl[h * CLID_D + c];
+        else if (c == CLID_D) a = wl[CLID_H * CLID_D + h];
+        const int h2 = 16 * u + 4 * g + s;
+        const float w2 = wl[CLID_H * CLID_D + CLID_H + h2];
+        float a2 = q < CLID_F ? wl[h2 * CLID_D + q] : 0.f;
+        if (PREC == 1) {  // bf16 operands; the bias column stays exact (it is added as hi + lo, see below)
+          if (c != CLID_D) a = bf16_round(a);
+          a2 = bf16_round(a2);
+        }
+        A1[u][s] = a;
+        W2r[u][s] = w2;
+        A2[u][s] = a2;
+      }
+    b2 = wl[CLID_MLP_PARAMS - 1];
+  }
+  __syncthreads();  // the tile buffers may be written from here on
   CLID_STAMP(0);
   asm volatile("" ::"v"(A1[3][3]), "v"(W2r[3][3]), "v"(A2[3][3]));
   CLID_STAMP(1);
@@ -504,7 +520,7 @@ int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, f
   const int nb = clid_decode_tile_blocks(tmap.n_tasks);
   const float4* r4 = reinterpret_cast<const float4*>(rec);
 #define CLID_TILE_LAUNCH(P, L) \
-  hipLaunchKernelGGL((k_decode_tile<P, L>), dim3(nb), dim3(kTileBlock), 0, s, *mv, *a, partial, tmap, r4, n_tiles, g_sdf_dbg)
+  CLID_KLAUNCH((k_decode_tile<P, L>), dim3(nb), dim3(kTileBlock), 0, s, *mv, *a, partial, tmap, r4, n_tiles, g_sdf_dbg)
   if (prec == 1) {
     if (mv->layer_norm) CLID_TILE_LAUNCH(1, true);
     else CLID_TILE_LAUNCH(1, false);

@@ -76,6 +76,43 @@ class Mapper:
         self._gen = None
         self._seed = int(getattr(config, "seed", 42))
 
+    def reserve(self, iter_count: int):
+        """Size the cached workspaces of `mapping()` for calls of up to `iter_count` iterations on the current local
+        map and batch size (optional: `mapping()` grows them on demand; a caller that wants allocation-free calls --
+        e.g. a timed region -- reserves once)."""
+        lib = _lib.load()
+        cfg, nm = self.config, self.neural_points
+        dev = nm.local_geo_features.device
+        dist = _dist()
+        bs_local = int(cfg.bs) // (dist.get_world_size() if dist else 1)
+        self._loop_buffers(nm.local_geo_features.shape[0], iter_count, dev)
+        need = int(lib.clid_train_workspace_floats(bs_local, max(int(cfg.gradient_decimation), 1), 1))
+        if getattr(self, "_ws", None) is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, device=dev, dtype=torch.float32)
+        n_idx = iter_count * int(cfg.bs)
+        if getattr(self, "_idx_buf", None) is None or self._idx_buf.numel() < n_idx or self._idx_buf.device != dev:
+            self._idx_buf = torch.empty(n_idx, device=dev, dtype=torch.int64)
+
+    def _loop_buffers(self, n_rows: int, iters: int, dev):
+        """Views [grad | m | v | m_mlp | v_mlp | losses] of one flat fp32 buffer, zeroed.  The buffer is cached and
+        only re-allocated when it has to grow, so a steady-state `mapping()` call allocates nothing;
+        `last_losses` therefore stays valid until the next call."""
+        n_feat = n_rows * _lib.F
+        sizes = (_lib.GRAD_FEAT_OFFSET16 + n_rows * _lib.GRAD_ROW16, n_feat, n_feat, 848, 848, iters * 4)
+        total = sum(sizes)
+        flat = getattr(self, "_flat", None)
+        if flat is None or flat.numel() < total or flat.device != torch.device(dev):
+            flat = torch.empty(int(total * 1.25) + 4096, device=dev, dtype=torch.float32)
+            self._flat = flat
+        flat[:total].zero_()
+        out, off = [], 0
+        for n in sizes:
+            out.append(flat[off:off + n])
+            off += n
+        out[3], out[4] = out[3][:_lib.MLP_PARAMS], out[4][:_lib.MLP_PARAMS]
+        out[5] = out[5].view(iters, 4)
+        return out
+
     # ------------------------------------------------------------------ a1
     def _draw_index(self, iters: int, bs: int) -> torch.Tensor:
         """[iters, bs] int64 batch indices composed as utils/mapper.py:473-500 (device RNG)."""
@@ -93,6 +130,10 @@ class Mapper:
             hist = torch.randint(0, self.pool_sample_count, (iters, bs - bs_new), device=dev, generator=self._gen)
             pick = torch.randint(0, self.new_idx.shape[0], (iters, bs_new), device=dev, generator=self._gen)
             return torch.cat((hist, self.new_idx[pick]), dim=1).contiguous()
+        buf = getattr(self, "_idx_buf", None)  # cached by reserve(): no allocation in steady state
+        if buf is not None and buf.numel() >= iters * bs and buf.device == torch.device(dev):
+            out = buf[: iters * bs].view(iters, bs)
+            return torch.randint(0, self.pool_sample_count, (iters, bs), device=dev, generator=self._gen, out=out)
         return torch.randint(0, self.pool_sample_count, (iters, bs), device=dev, generator=self._gen)
 
     def get_batch(self, global_coord=False):
@@ -165,14 +206,10 @@ class Mapper:
 
         n_feat = theta.numel()
         # fused gradient buffer [decoder 833 | pad | (M+1) accumulation rows of 16 floats: 8 gradients, certainty
-        # increment, 7 unused] (include/clid_native.h CLID_GRAD_ROW16)
+        # increment, 7 unused] (include/clid_native.h CLID_GRAD_ROW16) + Adam state + per-iteration losses: ONE cached
+        # allocation, zeroed by one fill per call (the optimiser state restarts every call, utils/mapper.py:634)
         gstride = _lib.GRAD_ROW16
-        grad = torch.zeros(_lib.GRAD_FEAT_OFFSET16 + (n_feat // _lib.F) * gstride, device=dev, dtype=torch.float32)
-        m = torch.zeros(n_feat, device=dev, dtype=torch.float32)
-        v = torch.zeros(n_feat, device=dev, dtype=torch.float32)
-        m_mlp = torch.zeros(_lib.MLP_PARAMS, device=dev, dtype=torch.float32)
-        v_mlp = torch.zeros(_lib.MLP_PARAMS, device=dev, dtype=torch.float32)
-        losses = torch.zeros((iter_count, 4), device=dev, dtype=torch.float32)
+        grad, m, v, m_mlp, v_mlp, losses = self._loop_buffers(n_feat // _lib.F, iter_count, dev)
         need = int(lib.clid_train_workspace_floats(bs_local, decim, eik_mode))
         if getattr(self, "_ws", None) is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(need, device=dev, dtype=torch.float32)

@@ -42,3 +42,31 @@ def query_points(neural_points, sdf_mlp, config, coord, bs=None, query_sdf=True,
         sdf_pred = None if sdf_pred is None else sdf_pred.cpu().numpy().astype("float64")
         mc_mask = None if mc_mask is None else mc_mask.cpu().numpy().astype("float64")
     return sdf_pred, None, None, mc_mask
+
+
+class Mesher:
+    """`Mesher` with the reference's constructor and `query_points` signature (utils/mesher.py:20-47) for the part that is
+    on the hot path: the dense SDF / mask query.  Marching cubes and mesh export need skimage / open3d and stay with the
+    reference (out of scope): those methods raise."""
+
+    def __init__(self, config, neural_points, decoders: dict):
+        self.config = config
+        self.silence = getattr(config, "silence", True)
+        self.neural_points = neural_points
+        self.sdf_mlp = decoders["sdf"]
+        self.sem_mlp = decoders.get("semantic")
+        self.color_mlp = decoders.get("color")
+        self.device = config.device
+        self.cur_device = self.device
+        self.dtype = config.dtype
+
+    def query_points(self, coord, bs, query_sdf=True, query_sem=False, query_color=False, query_mask=True,
+                     query_locally=False, mask_min_nn_count: int = 4, out_torch: bool = False):
+        """utils/mesher.py:38-163: (sdf_pred, sem_pred, color_pred, mc_mask)."""
+        return query_points(self.neural_points, self.sdf_mlp, self.config, coord, bs, query_sdf, query_sem, query_color,
+                            query_mask, query_locally, mask_min_nn_count, out_torch)
+
+    def recon_aabb_mesh(self, *args, **kwargs):
+        raise NotImplementedError("marching cubes / mesh export (utils/mesher.py:371-667) need skimage + open3d: out of scope")
+
+    mc_mesh = recon_aabb_mesh

@@ -283,6 +283,19 @@ class NeuralPoints(nn.Module):
         ids = getattr(self, "_local_ids", None)
         if ids is None or ids.shape[0] != self.local_point_certainties.shape[0]:  # state installed from outside
             ids = torch.nonzero(self.local_mask[:-1]).flatten()
+        theta = self.local_geo_features.data
+        if (theta.is_cuda and self.color_features is None and theta.dtype == torch.float32 and theta.shape[1] == _lib.F
+                and ids.dtype == torch.int64 and self.point_ts_update.dtype == torch.int32
+                and all(t.is_contiguous() for t in (theta, self.geo_features, self.point_certainties, self.point_ts_update,
+                                                    self.local_point_certainties, self.local_point_ts_update))):
+            # one launch for the three masked assignments (csrc/mapops.hip k_local_to_global)
+            ids = ids.contiguous()
+            _lib.check(_lib.load().clid_local_to_global(
+                ids.data_ptr(), int(ids.shape[0]), int(self.count()), theta.data_ptr(),
+                self.local_point_certainties.data_ptr(), self.local_point_ts_update.data_ptr(),
+                self.geo_features.data_ptr(), self.point_certainties.data_ptr(), self.point_ts_update.data_ptr(),
+                _lib.stream()), "clid_local_to_global")
+            return
         pad = torch.cat((ids, torch.full((1,), self.count(), dtype=ids.dtype, device=ids.device)))
         self.geo_features.index_copy_(0, pad, self.local_geo_features.data)
         if self.color_features is not None:

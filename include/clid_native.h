@@ -309,6 +309,13 @@ int64_t clid_voxel_workspace_bytes(int32_t n);
 int clid_voxel_down_sample(const float* points, int32_t n, float voxel_size, void* workspace, int64_t* idx_out,
                            void* stream);
 
+/* NeuralPoints.assign_local_to_global (model/neural_points.py:538-549) in one launch: local features (n + 1 rows of
+ * F, the last one the padding row -> global row pad_row), certainties and update stamps back to the global arrays
+ * at ids [n] int64 (= nonzero(local_mask[:-1]), ascending). */
+int clid_local_to_global(const int64_t* ids, int32_t n, int64_t pad_row, const float* local_feat,
+                         const float* local_cert, const int32_t* local_ts, float* global_feat, float* global_cert,
+                         int32_t* global_ts, void* stream);
+
 /* ---- measurement aid (bench.py roofline leg; not part of the reference's interface) -----------
  * When enabled, clid_train_fwd_bwd / clid_train_adam bracket each kernel with hipEvents on the
  * launch stream.  clid_profile_read synchronises and returns summed elapsed ms per kernel:

@@ -5,7 +5,8 @@ modules are imported unmodified with empty stub modules for the three absent thi
 none of the hot-path functions touch (open3d, wandb, roma).
 What is committed are the resulting input/output tensors (small .npz files), not reference code.
 
-    python oracle/make_golden.py            # rewrites tests/golden/*.npz
+    python oracle/make_golden.py            # rewrites EVERY fixture under tests/golden/ (G1-G13), single-threaded
+    python oracle/make_golden.py --check    # regenerates into a scratch directory and diffs against tests/golden/
 
 Fixtures: G1 search, G2 query, G3 mlp, G4 analytic gradient, G5 loss,
 G6 mapping loop (teacher-forced batch indices recorded from the reference's own `get_batch`).
@@ -662,16 +663,125 @@ def map_maintenance_fixture():
           "| kept-hash slots", out["k_slot"].shape[0], "local", out["m_local"].shape[0])
 
 
+def config_fixture():
+    """G13: what the reference's own `Config.load` resolves for every shipped YAML (the hot path's keys), next to the
+    parsed YAML itself, so `HotPathConfig.load` can be checked against it without the reference tree."""
+    import json
+    import yaml
+
+    ref = import_reference()
+    import clid_slam_amd  # noqa: F401
+    from clid_slam_amd import HotPathConfig
+
+    keys = sorted(k for k, v in vars(HotPathConfig()).items()
+                  if isinstance(v, (bool, int, float, str)) and k not in ("device", "name", "silence"))
+    out = {}
+    for name in ("run_ncd128.yaml", "run_SubT_MRS.yaml", "run_quad.yaml"):
+        path = os.path.join(REF, "config", name)
+        cfg = ref.Config()
+        cfg.load(path)
+        resolved = {}
+        for k in keys:
+            if hasattr(cfg, k):
+                v = getattr(cfg, k)
+                if isinstance(v, dict):  # `track_on` holds the tracker section itself when present
+                    v = True
+                if isinstance(v, (bool, int, float, str)):
+                    resolved[k] = v
+        with open(path) as fh:
+            out[name] = {"yaml": yaml.safe_load(fh), "resolved": resolved}
+    with open(os.path.join(OUT, "g13_config_resolved.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print("G13: resolved", {k: len(v["resolved"]) for k, v in out.items()}, "keys")
+
+
+def mesher_fixture():
+    """G12: the reference's own `Mesher.query_points` (utils/mesher.py:38-163) on the map / decoder of state.npz:
+    global and local queries, both masks.  skimage (marching cubes only) is stubbed like open3d."""
+    ref = import_reference()
+    for n in ("skimage", "skimage.measure"):
+        sys.modules.setdefault(n, _Stub(n))
+    from utils.mesher import Mesher
+
+    cfg = ref_config(ref)
+    nm, pool = build_scene(ref, cfg)
+    torch.manual_seed(42)
+    dec = ref.Decoder(cfg, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, 1)
+    x, _ = query_points(pool, 1536, 12)
+    gen = torch.Generator().manual_seed(13)
+    x = torch.cat((x, x[:1024] + 0.4 * torch.randn((1024, 3), generator=gen)))  # incl. points away from the surface
+    out = {"x": x.numpy()}
+    for ln in (False, True):
+        cfg.layer_norm_on = ln
+        mesher = Mesher(cfg, nm, {"sdf": dec, "semantic": None, "color": None})
+        for loc in (False, True):
+            sdf, _, _, mask = mesher.query_points(x, 700, query_locally=loc, mask_min_nn_count=4, out_torch=True)
+            out[f"sdf_ln{int(ln)}_loc{int(loc)}"] = sdf.numpy().astype(np.float32)
+            out[f"mask_ln{int(ln)}_loc{int(loc)}"] = mask.numpy().astype(np.uint8)
+    cfg.layer_norm_on = False
+    np.savez_compressed(os.path.join(OUT, "g12_mesher.npz"), **out)
+    print("G12: mesher query on", x.shape[0], "points; masked-in", int(out["mask_ln0_loc0"].sum()), "global /",
+          int(out["mask_ln0_loc1"].sum()), "local")
+
+
+def generate_all(out_dir):
+    """Every fixture, one process, ONE thread: the reference's voxel down-sampling uses `scatter_reduce` and indexed
+    assignments with duplicate indices (utils/tools.py:677-679), whose result depends on the thread schedule; single-
+    threaded the whole set is bit-reproducible."""
+    global OUT
+    OUT = out_dir
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)
+    main()
+    map_build_fixture()
+    tracking_fixture()
+    sampler_fixture()
+    map_maintenance_fixture()
+    mesher_fixture()
+    config_fixture()
+
+
+def check():
+    """Regenerate into a scratch directory and compare with the committed fixtures, array by array, bit for bit."""
+    import filecmp
+    import json
+    import tempfile
+
+    committed = OUT
+    bad = []
+    with tempfile.TemporaryDirectory() as tmp:
+        generate_all(tmp)
+        names = sorted(set(os.listdir(tmp)) | {n for n in os.listdir(committed) if n.endswith((".npz", ".json"))})
+        for n in names:
+            a, b = os.path.join(tmp, n), os.path.join(committed, n)
+            if not (os.path.exists(a) and os.path.exists(b)):
+                bad.append(f"{n}: only in {'fresh run' if os.path.exists(a) else 'tests/golden'}")
+                continue
+            if n.endswith(".json"):
+                if json.load(open(a)) != json.load(open(b)):
+                    bad.append(f"{n}: differs")
+                continue
+            fa, fb = np.load(a), np.load(b)
+            if sorted(fa.files) != sorted(fb.files):
+                bad.append(f"{n}: array names differ")
+                continue
+            for k in fa.files:
+                if fa[k].shape != fb[k].shape or fa[k].dtype != fb[k].dtype or not np.array_equal(fa[k], fb[k], equal_nan=True):
+                    bad.append(f"{n}[{k}]: differs")
+    print("\n".join(bad) if bad else "tests/golden matches a fresh run of the reference bit for bit")
+    return 1 if bad else 0
+
+
 if __name__ == "__main__":
-    if "--only-g11" in sys.argv:
-        map_maintenance_fixture()
-    elif "--only-g9" in sys.argv:
-        sampler_fixture()
-    elif "--only-g8" in sys.argv:
-        tracking_fixture()
-    elif "--only-g7" in sys.argv:
+    only = {"--only-g11": map_maintenance_fixture, "--only-g9": sampler_fixture, "--only-g8": tracking_fixture,
+            "--only-g7": map_build_fixture, "--only-g12": mesher_fixture, "--only-g13": config_fixture}
+    picked = [f for flag, f in only.items() if flag in sys.argv]
+    if "--check" in sys.argv:
+        sys.exit(check())
+    elif picked:
         os.makedirs(OUT, exist_ok=True)
-        map_build_fixture()
+        torch.set_num_threads(1)
+        for f in picked:
+            f()
     else:
-        main()
-        map_build_fixture()
+        generate_all(OUT)

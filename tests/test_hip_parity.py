@@ -586,6 +586,24 @@ def test_dense_sdf_query_vs_oracle(env, ln, loc):
     assert (nn == 0).any() and (nn >= 4).any()
 
 
+@pytest.mark.parametrize("ln,loc", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_mesher_query_points_vs_reference_g12(env, ln, loc):
+    """Row N3 against the reference's own `Mesher.query_points` output (fixture G12), through the `Mesher` drop-in."""
+    from clid_slam_amd.mesher import Mesher
+
+    g = gio.load("g12_mesher.npz")
+    cfg = env.config(layer_norm_on=bool(ln))
+    nm = env.neural_points(cfg)
+    dec = env.decoder(cfg)
+    mesher = Mesher(cfg, nm, {"sdf": dec, "semantic": None, "color": None})
+    sdf, sem, col, mask = mesher.query_points(gio.T(g["x"]).cuda(), 700, query_locally=bool(loc), mask_min_nn_count=4, out_torch=True)
+    assert sem is None and col is None
+    assert maxerr(sdf, g[f"sdf_ln{ln}_loc{loc}"]) <= 2e-6
+    assert np.array_equal(mask.cpu().numpy().astype(np.uint8), g[f"mask_ln{ln}_loc{loc}"])
+    sdf_np, _, _, mask_np = mesher.query_points(gio.T(g["x"]).cuda(), 10_000, query_locally=bool(loc), out_torch=False)
+    assert isinstance(sdf_np, np.ndarray) and maxerr(sdf_np, g[f"sdf_ln{ln}_loc{loc}"]) <= 2e-6
+
+
 def test_search_records_short_lists_equal_full_depth():
     """The chunked search keeps 3 candidates per lane and repeats a wave at full depth when one it pushed out
     could have been a winner; forcing the full-depth path for every wave (debug bit 2) must give bit-identical

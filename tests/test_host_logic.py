@@ -170,3 +170,34 @@ def test_prune_and_recreate_hash_match_the_reference():
     """G11: the reference's own prune_map / recreate_hash (keeping and merging) on the three-frame map."""
     torch.set_num_threads(1)
     _g11_run("cpu")
+
+
+def test_config_loader_resolves_every_shipped_yaml_like_the_reference(tmp_path):
+    """HotPathConfig.load against the reference's own Config.load (fixture G13 = parsed YAML + the values the reference
+    resolves for it), incl. the defaults derived from vox_down_m and the tracker / pgo switches."""
+    import json
+    import os
+
+    import yaml
+    from clid_slam_amd import HotPathConfig
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g13_config_resolved.json")
+    fx = json.load(open(path))
+    assert sorted(fx) == ["run_SubT_MRS.yaml", "run_ncd128.yaml", "run_quad.yaml"]
+    for name, rec in fx.items():
+        y = tmp_path / name
+        y.write_text(yaml.safe_dump(rec["yaml"]))
+        cfg = HotPathConfig().load(str(y))
+        bad = {}
+        for k, want in rec["resolved"].items():
+            got = getattr(cfg, k)
+            ok = (abs(float(got) - float(want)) <= 1e-12 * max(1.0, abs(float(want)))) if isinstance(want, float) else (got == want)
+            if not ok:
+                bad[k] = (got, want)
+        assert not bad, (name, bad)
+    # a sampler section without the range keys falls back to the vox_down_m-derived defaults (utils/config.py:518-545)
+    y = tmp_path / "sparse.yaml"
+    y.write_text(yaml.safe_dump({"process": {"vox_down_m": 0.08}, "sampler": {}, "neuralpoints": {}, "loss": {}}))
+    cfg = HotPathConfig().load(str(y))
+    assert abs(cfg.surface_sample_range_m - 0.24) < 1e-12 and abs(cfg.free_sample_end_dist_m - 0.96) < 1e-12
+    assert abs(cfg.voxel_size_m - 0.4) < 1e-12 and abs(cfg.sigma_sigmoid_m - 0.08) < 1e-12 and cfg.track_on is False

@@ -178,3 +178,17 @@ def test_g8_tracking_measurement_model(ln):
     assert float(H[:, 6:].abs().max()) == 0.0
     close(vp, g[f"valid_points_ln{ln}"], 1e-5, "valid points")
     close(r_inv, g[f"R_inv_ln{ln}"], 1e-2, "R_inv")  # values ~1e3
+
+
+def test_oracle_query_composition_vs_reference_mesher_g12():
+    """Row N3: the oracle's query_feature -> decoder composition against the REFERENCE's own Mesher.query_points
+    (fixture G12: global + local map, with and without layer norm, nn >= 1 / nn >= 4 masks)."""
+    g = gio.load("g12_mesher.npz")
+    x = gio.T(g["x"])
+    for ln in (0, 1):
+        for loc in (0, 1):
+            st = gio.map_state(layer_norm_on=bool(ln))
+            f, _, nn, _, _ = O.query_feature(st, x, training_mode=False, query_locally=bool(loc))
+            sdf = torch.where(nn >= 1, O.mlp_sdf(gio.decoder(), f), torch.zeros(()))
+            assert float((sdf - gio.T(g[f"sdf_ln{ln}_loc{loc}"])).abs().max()) <= 1e-6, (ln, loc)
+            assert torch.equal((nn >= 4), gio.T(g[f"mask_ln{ln}_loc{loc}"]).bool()), (ln, loc)

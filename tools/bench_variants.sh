@@ -4,7 +4,7 @@ out=${1:-gpurun_out/variants}
 mkdir -p "$out"
 for v in ${VARIANTS:-0 1 2}; do
   for st in ${STEPS:-200 20}; do
-    CLID_DECODE=$v python bench.py --steps "$st" --warmup 5 --no-cpu-baseline ${BENCH_ARGS:-} > "$out/v${v}_s${st}.json" 2> "$out/err.log" || tail -5 "$out/err.log"
+    python bench.py --decode $v --steps "$st" --warmup 5 --no-cpu-baseline ${BENCH_ARGS:-} > "$out/v${v}_s${st}.json" 2> "$out/err.log" || tail -5 "$out/err.log"
   done
 done
 python - "$out" <<'EOF'
@@ -15,5 +15,7 @@ for f in sorted(glob.glob(os.path.join(sys.argv[1], "v*_s*.json"))):
     except Exception as e:
         print(f, "unreadable", e); continue
     r = d["roofline"]
-    print(os.path.basename(f), round(d["ms_per_step"] * 1e3, 2), "us/step", r["per_kernel_us"], "loss", round(d["final_loss"]["total"], 5))
+    pf = d.get("per_frame_regime") or {}
+    print(os.path.basename(f), round(d["ms_per_step"] * 1e3, 2), "us/step |", "mapping(10):", round(pf.get("ms_per_step", 0) * 1e3, 2), "us/step |",
+          {k["kernel"].split(" ")[0]: k["avg_us"] for k in r["kernels"]}, "frac", r["frac"], "loss", round(d["final_loss"]["total"], 5))
 EOF
