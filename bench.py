@@ -207,6 +207,10 @@ def main():
     nm, dec, mp, scene = build_scene(cfg, device)
     lib = _lib.load()
     lib.clid_decode_variant(wl["decode"])
+    rccl_ranks = 0
+    if dist:  # RCCL communicator behind the C ABI (csrc/comm.hip): the sharded loop then needs no Python per iteration
+        comm = _lib.rccl_comm(dist)
+        rccl_ranks = int(lib.clid_comm_size(comm)) if comm is not None else 0
     M = nm.local_count()
     decim = cfg.gradient_decimation
 
@@ -302,6 +306,7 @@ def main():
                 "decode_kernel": wl["decode"], "query_points_per_step_per_gpu": bs_local + 6 * ((bs_local + decim - 1) // decim),
                 "neural_points_local": M, "pool_samples": int(mp.pool_sample_count), "buffer_size": cfg.buffer_size,
                 "parallelism": f"dp{world} (batch sharded, RCCL all-reduce of [decoder|feature] grads)" if world > 1 else "single GPU",
+                "rccl_ranks_in_c_abi": rccl_ranks,
             },
             "final_loss": {"total": losses[0], "bce": losses[1], "eikonal": losses[2]},
             "per_frame_regime": frame, "roofline": roof, "cpu_baseline": base,

@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4]: the run_SubT_MRS.yaml sequence workload -- online mapping at scan rate with the eikonal
+term -- on a synthetic 200-frame sweep (the datasets are not shipped; SURVEY.md section 8d "Sequence").
+
+    python bench_sequence.py [--frames 200] [--check-frames 0]
+
+Per frame, exactly as slam.py:135-200 drives the objects (tracking is out of scope: the known poses play the role of
+`gt_poses`): new `travel_dist` tensor -> `Mapper.process_frame` (raw-point map, `DataSampler.sample` with the
+region-specific SDF labels, `NeuralPoints.update`, pool append / window filter, new-sample detection, adaptive
+iteration offset) -> iterations = iters * init_iter_ratio on frame 0, else iters (+ offset) -> `freeze_model` at
+frame `freeze_after_frame` -> `Mapper.mapping`.  Config values = what the reference's Config.load resolves for
+config/run_SubT_MRS.yaml (tests/golden/g13_config_resolved.json: layer_norm_on True, free_sample_begin_ratio 0.8).
+Prints one JSON line: scans/s and sampled-points/s over frames 1..N-1 (frame 0 with its 400 iterations separately),
+per-frame time split, and the growth of the local map.  `--check-frames K` also replays the mapping() calls of the
+first K frames on the CPU oracle from a snapshot of the state (slow; tests/test_sequence.py does this under -m gpu).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+
+def subt_config(device):
+    """HotPathConfig loaded from the SubT YAML content (fixture G13), checked against the reference-resolved values."""
+    from clid_slam_amd import HotPathConfig
+
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "g13_config_resolved.json")))["run_SubT_MRS.yaml"]
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as fh:
+        yaml.safe_dump(fx["yaml"], fh)
+    cfg = HotPathConfig().load(fh.name)
+    os.unlink(fh.name)
+    for k in ("layer_norm_on", "free_sample_begin_ratio", "bs", "iters", "voxel_size_m", "surface_sample_range_m"):
+        assert getattr(cfg, k) == fx["resolved"][k], k
+    cfg.device = device
+    cfg.track_on = False  # tracking (IEKF) is out of scope: the synthetic poses are used like `gt_poses`
+    return cfg
+
+
+class Dataset:  # the attributes Mapper reads of SLAMDataset (utils/slam_dataset.py)
+    lose_track = False
+    stop_status = False
+    processed_frame = 0
+    gt_pose_provided = True
+    gt_poses = None
+    static_mask = None
+
+
+def run(frames, device, check_frames=0, seed=42, quiet=False):
+    from clid_slam_amd import Decoder, LocalPointCloudMap, Mapper, NeuralPoints
+    from clid_slam_amd.synth import hall_scan, sweep_poses
+    from clid_slam_amd.tools import freeze_model
+
+    cfg = subt_config(device)
+    torch.manual_seed(seed)
+    nm = NeuralPoints(cfg)
+    dec = Decoder(cfg, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, 1)
+    ds = Dataset()
+    mp = Mapper(cfg, ds, nm, LocalPointCloudMap(cfg), dec)
+    poses = sweep_poses(frames)
+    ds.gt_poses = poses.numpy()
+    travel = np.concatenate(([0.0], np.cumsum(np.linalg.norm(np.diff(ds.gt_poses[:, :3, 3], axis=0), axis=1))))
+    rows, checks = [], []
+    sync = torch.cuda.synchronize
+    for fid in range(frames):
+        pts = hall_scan(poses[fid], seed=1000 + fid, device=device, min_range=cfg.min_range, max_range=cfg.max_range,
+                        vox_down_m=cfg.vox_down_m)
+        pose = poses[fid].to(device)
+        ds.processed_frame = fid
+        sync()
+        t0 = time.perf_counter()
+        nm.travel_dist = torch.tensor(travel[: fid + 1], device=device, dtype=cfg.dtype)  # slam.py:159-162
+        mp.process_frame(pts, None, pose, fid, False)
+        sync()
+        t1 = time.perf_counter()
+        iters = cfg.iters * cfg.init_iter_ratio if fid == 0 else cfg.iters  # slam.py:187-191
+        if fid == cfg.freeze_after_frame:  # slam.py:193-196
+            freeze_model(dec)
+        snap = None
+        if fid < check_frames:
+            snap = _snapshot(nm, dec, mp, cfg)
+            idx = mp._draw_index(max(1, iters + mp.adaptive_iter_offset), cfg.bs)
+            mp.mapping(iters, index_seq=idx)
+        else:
+            mp.mapping(iters)
+        sync()
+        t2 = time.perf_counter()
+        n_it = int(mp.last_losses.shape[0])
+        rows.append(dict(frame=fid, rays=int(pts.shape[0]), t_process_ms=1e3 * (t1 - t0), t_mapping_ms=1e3 * (t2 - t1), iters=n_it,
+                         pool=int(mp.pool_sample_count), new=int(0 if mp.new_idx is None else mp.new_idx.shape[0]),
+                         M_global=int(nm.count()), M_local=int(nm.local_count()), loss=float(mp.last_losses[-1, 0])))
+        if snap is not None:
+            checks.append(_check_against_oracle(snap, idx, nm, dec, mp, cfg, fid))
+        if not quiet and (fid < 3 or fid % 25 == 0 or fid == frames - 1):
+            r = rows[-1]
+            print(f"frame {fid:3d}: rays {r['rays']:6d} pool {r['pool']:8d} M_local {r['M_local']:6d} iters {r['iters']:3d} "
+                  f"process {r['t_process_ms']:6.2f} ms mapping {r['t_mapping_ms']:6.2f} ms loss {r['loss']:.4f}", file=sys.stderr)
+    return cfg, rows, checks, (nm, dec, mp)
+
+
+def _snapshot(nm, dec, mp, cfg):
+    from oracle import cpu_ref as O
+
+    cpu = lambda t: t.detach().cpu().clone()  # noqa: E731
+    dx, mvd = O.search_neighborhood(cfg.num_nei_cells, cfg.search_alpha, cfg.voxel_size_m)
+    st = O.MapState(
+        buffer_pt_index=cpu(nm.buffer_pt_index), neural_points=cpu(nm.neural_points), point_ts_create=cpu(nm.point_ts_create),
+        travel_dist=cpu(nm.travel_dist), cur_ts=int(nm.cur_ts), global2local=cpu(nm.global2local),
+        local_neural_points=cpu(nm.local_neural_points), local_geo_features=cpu(nm.local_geo_features.data),
+        local_point_certainties=cpu(nm.local_point_certainties), local_point_ts_update=cpu(nm.local_point_ts_update),
+        resolution=cfg.voxel_size_m, buffer_size=cfg.buffer_size, diff_travel_dist_local=nm.diff_travel_dist_local,
+        neighbor_dx=dx, max_valid_dist2=mvd, layer_norm_on=cfg.layer_norm_on)
+    od = O.DecoderParams(*[cpu(p) for p in dec.flat_params()], sdf_scale=dec.sdf_scale)
+    pool = O.SamplePool(cpu(mp.global_coord_pool), cpu(mp.sdf_label_pool), cpu(mp.time_pool), cpu(mp.weight_pool))
+    frozen = not all(p.requires_grad for p in dec.flat_params())
+    return st, od, pool, frozen
+
+
+def _check_against_oracle(snap, idx, nm, dec, mp, cfg, fid):
+    from oracle import cpu_ref as O
+
+    st, od, pool, frozen = snap
+    lc = O.LoopConfig(sigma=mp.sdf_scale, gradient_decimation=cfg.gradient_decimation,
+                      fd_eps=cfg.voxel_size_m * cfg.num_grad_step_ratio, lr=cfg.lr, adam_eps=cfg.adam_eps)
+    if frozen:
+        lc.train_decoder = False
+    n_all = idx.shape[0]
+    n_rep = min(n_all, 16)  # the 400-iteration call of frame 0 is replayed for its first iterations only (losses)
+    recs = O.mapping_iters(st, od, pool, idx.cpu()[:n_rep], lc, record=True)
+    got = mp.last_losses.cpu()
+    out = dict(frame=fid, iters=n_all, replayed=n_rep,
+               max_dloss=max(abs(float(got[i, 0]) - float(r["loss"])) for i, r in enumerate(recs)))
+    if n_rep == n_all:  # same number of Adam steps: parameters are comparable
+        dth = (nm.local_geo_features.detach().cpu() - recs[-1]["theta"]).abs()
+        out.update(max_dtheta=float(dth.max()), n_dtheta_gt_1e4=int((dth > 1e-4).sum()),
+                   max_ddecoder=max(float((t.detach().cpu() - o).abs().max()) for t, o in zip(dec.flat_params(), recs[-1]["dec"])),
+                   max_dcert=float((nm.local_point_certainties.cpu() - recs[-1]["certainties"]).abs().max()))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--check-frames", type=int, default=0)
+    ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--profile-last", action="store_true",
+                    help="per-kernel dispatch durations of 10 more iterations on the final state (large local map, full pool)")
+    args = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_sequence.py needs a GPU (the HIP path has no CPU fallback)")
+    device = "cuda:0"
+    import clid_slam_amd  # noqa: F401
+
+    t_all = time.perf_counter()
+    cfg, rows, checks, objs = run(args.frames, device, args.check_frames, quiet=args.quiet)
+    large = None
+    if args.profile_last:
+        import bench
+        from clid_slam_amd import _lib
+
+        nm, dec, mp = objs
+        kernels, _ = bench.kernel_report(_lib.load(), mp, 10, cfg.bs, cfg.gradient_decimation, nm.local_count(), 1)
+        large = {"M_local": nm.local_count(), "pool": int(mp.pool_sample_count), "layer_norm_on": cfg.layer_norm_on,
+                 "decoder_frozen": not all(p.requires_grad for p in dec.flat_params()), "kernels": kernels}
+    steady = rows[1:] if len(rows) > 1 else rows
+    t_frames = sum(r["t_process_ms"] + r["t_mapping_ms"] for r in steady) * 1e-3
+    t_map = sum(r["t_mapping_ms"] for r in steady) * 1e-3
+    n_iters = sum(r["iters"] for r in steady)
+    line = {
+        "metric": "online mapping rate on the run_SubT_MRS.yaml sequence workload (synthetic 1 m/frame sweep)",
+        "value": len(steady) / t_frames, "unit": "scans/s", "frames": len(rows), "data": "synthetic", "dtype": "f32", "n_gpus": 1,
+        "scan_rate_required_hz": 10.0, "realtime_factor": len(steady) / t_frames / 10.0,
+        "sampled_points_per_s_in_mapping": cfg.bs * n_iters / t_map, "sampled_points_per_s_end_to_end": cfg.bs * n_iters / t_frames,
+        "ms_per_frame": {"process_frame": 1e3 * (t_frames - t_map) / len(steady), "mapping": 1e3 * t_map / len(steady),
+                         "iters_per_frame": n_iters / len(steady)},
+        "frame0": {"iters": rows[0]["iters"], "t_process_ms": rows[0]["t_process_ms"], "t_mapping_ms": rows[0]["t_mapping_ms"]},
+        "map_growth": {"M_local_first": rows[0]["M_local"], "M_local_max": max(r["M_local"] for r in rows),
+                       "M_global_last": rows[-1]["M_global"], "pool_last": rows[-1]["pool"]},
+        "config": {"workload": "cfg5: run_SubT_MRS.yaml values (layer_norm_on, free_sample_begin_ratio 0.8, bs 16384, iters 10, "
+                               "numerical eikonal), per-frame process_frame -> mapping as slam.py:135-200, decoder frozen at frame "
+                               f"{cfg.freeze_after_frame}; synthetic hall sweep, {rows[1]['rays'] if len(rows) > 1 else rows[0]['rays']} rays/scan",
+                   "bs": cfg.bs, "layer_norm_on": cfg.layer_norm_on, "free_sample_begin_ratio": cfg.free_sample_begin_ratio},
+        "final_loss": rows[-1]["loss"], "oracle_checks": checks or None, "large_map_kernels": large, "wall_s": time.perf_counter() - t_all,
+        "every_25th_frame": [rows[i] for i in range(0, len(rows), 25)],
+    }
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

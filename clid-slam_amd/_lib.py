@@ -109,6 +109,13 @@ _SIGS = {
     "clid_voxel_workspace_bytes": (_i64, [_i32]),
     "clid_voxel_down_sample": (C.c_int, [_vp, _i32, _f32, _vp, _vp, _vp]),
     "clid_local_to_global": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clid_comm_unique_id": (C.c_int, [_vp]),
+    "clid_comm_init": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
+    "clid_comm_size": (C.c_int, [_vp]),
+    "clid_comm_allreduce": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "clid_comm_destroy": (C.c_int, [_vp]),
+    "clid_mapping_run_dist": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), C.POINTER(AdamArgs), _i32, _vp, _i64, _vp,
+                                        _vp, _i64, _vp]),
     "clid_mapping_pipeline": (C.c_int, [C.c_int]),
     "clid_decode_variant": (C.c_int, [C.c_int]),
     "clid_debug_decode_sdf_out": (C.c_int, [_vp]),
@@ -143,6 +150,64 @@ def load():
         raise RuntimeError("libclid_native.so ABI version mismatch; rebuild")
     _lib = lib
     return lib
+
+
+def replica_generator(owner, config, device, salt: int):
+    """Random draws that must be IDENTICAL on every rank of a data-parallel group (new neural-point features, the
+    sampler's noise, the pool-capacity filter): under torch.distributed with world > 1 they come from a generator owned
+    by `owner` and seeded from config.seed (+ salt), independent of the ranks' global RNG state.  Single process: None,
+    i.e. torch's global generator exactly like the reference."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return None
+    gens = owner.__dict__.setdefault("_replica_gens", {})
+    key = (str(device), salt)
+    if key not in gens:
+        g = torch.Generator(device=device)
+        g.manual_seed(int(getattr(config, "seed", 42)) * 1000003 + salt)
+        gens[key] = g
+    return gens[key]
+
+
+_comm = None  # RCCL communicator of this process: None = not tried, False = unavailable, else a C pointer
+
+
+def rccl_comm(dist):
+    """The process-wide RCCL communicator behind the C ABI (clid_comm_*), created collectively on first use from the
+    torch.distributed group: rank 0's unique id is broadcast, every rank runs ncclCommInitRank on its current device.
+    Returns None (callers keep the torch.distributed path) when the backend is not RCCL ("nccl") or RCCL cannot be
+    initialised on EVERY rank."""
+    global _comm
+    if _comm is not None:
+        return _comm or None
+    _comm = False
+    if dist.get_backend() != "nccl" or os.environ.get("CLID_RCCL", "1") == "0":
+        return None
+    lib = load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ident = torch.zeros(129, dtype=torch.uint8, device=dev)  # [128] id | ok flag
+    if rank == 0:
+        buf = (C.c_uint8 * 128)()
+        if lib.clid_comm_unique_id(buf) == 0:
+            ident[:128] = torch.tensor(list(buf), dtype=torch.uint8)
+            ident[128] = 1
+    dist.broadcast(ident, 0)
+    host = ident.cpu()
+    ok = torch.zeros(1, dtype=torch.int32, device=dev)
+    ptr_out = _vp()
+    if int(host[128]) == 1:
+        idb = (C.c_uint8 * 128)(*host[:128].tolist())
+        if lib.clid_comm_init(idb, rank, world, C.byref(ptr_out)) == 0 and lib.clid_comm_size(ptr_out) == world:
+            ok[0] = 1
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        _comm = ptr_out
+        return _comm
+    if ptr_out:
+        lib.clid_comm_destroy(ptr_out)
+    return None
 
 
 def check(rc: int, what: str) -> None:

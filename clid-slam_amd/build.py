@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libclid_native.so")
-SOURCES = ["api.hip", "table.hip", "query.hip", "train.hip", "train_analytic.hip", "train_tile.hip", "mlp.hip", "sampler.hip", "mapops.hip"]
+SOURCES = ["api.hip", "comm.hip", "table.hip", "query.hip", "train.hip", "train_analytic.hip", "train_tile.hip", "mlp.hip", "sampler.hip", "mapops.hip"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "train_common.hpp"), os.path.join(HERE, "..", "include", "clid_native.h")]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -64,7 +64,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", LIB]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -1133,6 +1133,63 @@ extern "C" int clid_mapping_run(const clid_map_view* mv, const clid_train_args* 
   return CLID_OK;
 }
 
+// The sharded loop of one rank, stream-resident: hoisted searches of this rank's slice of every
+// batch, then per iteration decode/backward -> partial reduction -> RCCL all-reduce of the fused gradient buffer
+// [decoder | accumulation rows] ON THE LAUNCH STREAM -> the identical Adam step on every replica.  `index_base` points at
+// this rank's slice of iteration 0 (row stride index_stride); t->batch_offset / inv_n_* carry the global lattice phase
+// and normalisers.  After the loop the per-iteration losses (SUM) and the update stamps (MAX) are merged once.
+struct clid_comm;
+extern "C" int clid_comm_allreduce(clid_comm* comm, void* buf, int64_t count, int32_t is_int32, int32_t op_max, void* stream);
+
+extern "C" int clid_mapping_run_dist(const clid_map_view* mv, const clid_train_args* t, const clid_adam_args* a,
+                                     int32_t iters, const int64_t* index_base, int64_t index_stride, float* loss_base,
+                                     clid_comm* comm, int64_t grad_floats, void* stream) {
+  if (!mv || !t || !a || iters < 0 || !index_base || !loss_base || !comm || grad_floats <= 0) {
+    clid_set_error("clid_mapping_run_dist: bad argument");
+    return CLID_E_ARG;
+  }
+  clid_train_args ta = *t;
+  clid_adam_args aa = *a;
+  ta.defer_reduce = 0;  // the decoder gradients must sit in `grad` before the all-reduce
+  const bool hoist = ta.eikonal_mode != 2 && pipeline_mode() == 1;
+  int n_fd, first;
+  const int Q = n_queries(&ta, &n_fd, &first);
+  TrainWs ws = carve(ta.ws, Q);
+  size_t per_iter = 0;
+  long long chunk = 1;
+  if (hoist) {
+    per_iter = (size_t)clid_train_search_floats(ta.bs, ta.batch_offset, ta.decimation, ta.eikonal_mode, 1);
+    chunk = (long long)(rec_buffer_floats(Q) / per_iter);
+    if (chunk < 1) {
+      clid_set_error("clid_mapping_run_dist: the task records exceed the workspace bound");
+      return CLID_E_SHAPE;
+    }
+    if (chunk > kMaxChunkIters) chunk = kMaxChunkIters;
+  }
+  for (int it = 0; it < iters; ++it) {
+    ta.index = index_base + (int64_t)it * index_stride;
+    ta.loss_out = loss_base + (size_t)it * 4;
+    if (hoist) {
+      if (it % chunk == 0) {
+        const int n_it = (iters - it) < chunk ? (iters - it) : (int)chunk;
+        if (int e = clid_train_search(mv, &ta, n_it, ta.index, index_stride, ws.rec, stream)) return e;
+      }
+      if (int e = clid_train_decode(mv, &ta, ws.rec + (size_t)(it % chunk) * per_iter, stream)) return e;
+    } else {
+      if (int e = clid_train_fwd_bwd(mv, &ta, stream)) return e;
+    }
+    if (int e = clid_comm_allreduce(comm, ta.grad, grad_floats, 0, 0, stream)) return e;
+    aa.step = it + 1;
+    if (int e = clid_train_adam(&aa, &ta, stream)) return e;
+  }
+  if (iters > 0) {
+    if (int e = clid_comm_allreduce(comm, loss_base, (int64_t)iters * 4, 0, 0, stream)) return e;
+    if (mv->ts_update && mv->M > 0)
+      if (int e = clid_comm_allreduce(comm, mv->ts_update, mv->M, 1, 1, stream)) return e;
+  }
+  return CLID_OK;
+}
+
 // Host-side enumeration of the task -> query mapping the fused kernel uses (same code, compiled for the
 // host): counts how often each local batch position is trained as a batch sample (must be exactly 1)
 // and how many shifted copies it gets (6 on the decimation lattice, else 0).  CPU-only; used by tests.

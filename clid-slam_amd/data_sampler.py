@@ -33,9 +33,10 @@ class DataSampler:
         ns, nf, nb = int(cfg.surface_sample_n), int(cfg.free_front_n), int(cfg.free_behind_n)
         n_all = 1 + ns + nf + nb
         if noise is None:  # utils/data_sampler.py:47, :72, :93 (this order)
-            z_s = torch.randn(R * ns, 1, device=dev)
-            u_f = torch.rand(R * nf, 1, device=dev)
-            u_b = torch.rand(R * nb, 1, device=dev)
+            gen = _lib.replica_generator(self, cfg, dev, 1)  # None (global RNG, as the reference) unless data-parallel
+            z_s = torch.randn(R * ns, 1, device=dev, generator=gen)
+            u_f = torch.rand(R * nf, 1, device=dev, generator=gen)
+            u_b = torch.rand(R * nb, 1, device=dev, generator=gen)
         else:
             z_s, u_f, u_b = (t.to(dev, torch.float32).contiguous() for t in noise)
         p = _lib.SamplerParams()

@@ -25,7 +25,8 @@ from . import _lib
 def _dist():
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size() > 1 or os.environ.get("CLID_DIST_SINGLE") == "1"):  # (debug aid: sharded path with one rank)
         return dist
     return None
 
@@ -262,27 +263,19 @@ class Mapper:
             # with the tile kernels the certainty increments ride in the all-reduced accumulation rows (every rank's
             # Adam launch applies the global sum); the 16-lane kernel adds this rank's share to the array directly
             cert_in_rows = hoist and lib.clid_train_decode_kernel(C.byref(view), C.byref(ta)) > 0
-            chunk = min(iter_count, 32)
-            if hoist:
-                per_iter = int(lib.clid_train_search_floats(bs_local, batch_offset, decim, eik_mode, 1))
-                if getattr(self, "_rec", None) is None or self._rec.numel() < per_iter * chunk or self._rec.device != dev:
-                    self._rec = torch.empty(per_iter * chunk, device=dev, dtype=torch.float32)
-            for it in range(iter_count):
-                ta.index = idx_base + it * row_bytes + batch_offset * 8
-                ta.loss_out = loss_base + it * 16
-                if hoist:
-                    if it % chunk == 0:
-                        _lib.check(lib.clid_train_search(C.byref(view), C.byref(ta), min(chunk, iter_count - it),
-                                                         ta.index, bs_global, self._rec.data_ptr(), stream),
-                                   "clid_train_search")
-                    _lib.check(lib.clid_train_decode(C.byref(view), C.byref(ta),
-                                                     self._rec.data_ptr() + (it % chunk) * per_iter * 4, stream),
-                               "clid_train_decode")
-                else:
-                    _lib.check(lib.clid_train_fwd_bwd(C.byref(view), C.byref(ta), stream), "clid_train_fwd_bwd")
-                dist.all_reduce(grad)
-                aa.step = it + 1
-                _lib.check(lib.clid_train_adam(C.byref(aa), C.byref(ta), stream), "clid_train_adam")
+            comm = _lib.rccl_comm(dist)
+            shard_base = idx_base + batch_offset * 8
+            if comm is not None:
+                # RCCL behind the C ABI: the whole sharded loop is ONE host call, the all-reduce sits on the launch
+                # stream between the partial reduction and Adam (csrc/train.hip clid_mapping_run_dist)
+                ta.index, ta.loss_out = shard_base, loss_base
+                _lib.check(lib.clid_mapping_run_dist(C.byref(view), C.byref(ta), C.byref(aa), iter_count, shard_base, bs_global,
+                                                     loss_base, comm, grad.numel(), stream), "clid_mapping_run_dist")
+                merged = True  # losses (SUM) and update stamps (MAX) were merged by the call
+            else:
+                merged = False
+                self._mapping_loop_torch_dist(lib, dist, view, ta, aa, grad, iter_count, shard_base, row_bytes, loss_base,
+                                              hoist, bs_local, batch_offset, decim, eik_mode, dev, stream)
         self.total_iter += iter_count
         if dist:
             # merge the replicas' side effects once per call (not read inside the loop's loss)
@@ -290,11 +283,60 @@ class Mapper:
                 inc = nm.local_point_certainties - cert0
                 dist.all_reduce(inc)
                 nm.local_point_certainties.copy_(cert0 + inc)
-            dist.all_reduce(nm.local_point_ts_update, op=dist.ReduceOp.MAX)
-            dist.all_reduce(losses)
+            if not merged:
+                dist.all_reduce(nm.local_point_ts_update, op=dist.ReduceOp.MAX)
+                dist.all_reduce(losses)
+            self._check_replicas(dist)
         self.last_losses = losses
         self._keep = (keep, index_seq, grad, m, v, m_mlp, v_mlp)
         nm.assign_local_to_global()
+
+    def _mapping_loop_torch_dist(self, lib, dist, view, ta, aa, grad, iter_count, shard_base, row_bytes, loss_base, hoist,
+                                 bs_local, batch_offset, decim, eik_mode, dev, stream):
+        """The sharded loop with torch.distributed's all-reduce between two C calls per iteration: the path for
+        non-RCCL backends (gloo dry runs / tests with several ranks on one GPU)."""
+        chunk = min(iter_count, 32)
+        if hoist:
+            per_iter = int(lib.clid_train_search_floats(bs_local, batch_offset, decim, eik_mode, 1))
+            if getattr(self, "_rec", None) is None or self._rec.numel() < per_iter * chunk or self._rec.device != dev:
+                self._rec = torch.empty(per_iter * chunk, device=dev, dtype=torch.float32)
+        for it in range(iter_count):
+            ta.index = shard_base + it * row_bytes
+            ta.loss_out = loss_base + it * 16
+            if hoist:
+                if it % chunk == 0:
+                    _lib.check(lib.clid_train_search(C.byref(view), C.byref(ta), min(chunk, iter_count - it),
+                                                     ta.index, row_bytes // 8, self._rec.data_ptr(), stream),
+                               "clid_train_search")
+                _lib.check(lib.clid_train_decode(C.byref(view), C.byref(ta),
+                                                 self._rec.data_ptr() + (it % chunk) * per_iter * 4, stream),
+                           "clid_train_decode")
+            else:
+                _lib.check(lib.clid_train_fwd_bwd(C.byref(view), C.byref(ta), stream), "clid_train_fwd_bwd")
+            dist.all_reduce(grad)
+            aa.step = it + 1
+            _lib.check(lib.clid_train_adam(C.byref(aa), C.byref(ta), stream), "clid_train_adam")
+
+    def _check_replicas(self, dist):
+        """Data parallelism here relies on every rank holding a bit-identical replica of the map and the pool (same
+        seeds, same frames).  A cheap consistency check once per `mapping()` call: pool size, local map size and a
+        checksum of the drawn batch must agree on all ranks (MIN == MAX), else the gradients that were just averaged
+        belong to different samples / rows."""
+        nm = self.neural_points
+        dev = nm.local_geo_features.device
+        sig = torch.stack((
+            torch.tensor([float(self.pool_sample_count), float(nm.local_count()), float(nm.count()),
+                          float(0 if self.new_idx is None else self.new_idx.shape[0])], device=dev, dtype=torch.float64).sum(),
+            self.sdf_label_pool.sum(dtype=torch.float64),                 # pool CONTENT (the samplers' draws)
+            nm.local_geo_features.data.sum(dtype=torch.float64)))         # features after the identical Adam steps
+        both = torch.cat((sig, -sig))
+        dist.all_reduce(both, op=dist.ReduceOp.MIN)  # one collective: min(x) and -max(x)
+        lo, hi = both[:3], -both[3:]
+        if not torch.equal(lo, hi):
+            raise RuntimeError(
+                f"data-parallel replicas diverged ([counts, pool label sum, feature sum] min {lo.tolist()} max {hi.tolist()}): "
+                "every rank must process the same frames with the same seeds (clid_slam_amd seeds its own generators from "
+                "config.seed; see INTEGRATION.md)")
 
     def _mapping_unfused(self, iter_count, index_seq=None):
         """`weighted_first: False` (decode every neighbour, blend the SDFs; utils/mapper.py:679-680): the
@@ -494,7 +536,8 @@ class Mapper:
             keep = torch.sum(rel**2, dim=-1) < cfg.window_radius**2
             kept = torch.nonzero(keep).squeeze(1)
             if kept.shape[0] > cfg.pool_capacity:
-                drop = torch.randint(0, kept.shape[0], (kept.shape[0] - cfg.pool_capacity,), device=keep.device)
+                drop = torch.randint(0, kept.shape[0], (kept.shape[0] - cfg.pool_capacity,), device=keep.device,
+                                     generator=_lib.replica_generator(self, cfg, keep.device, 3))
                 keep[kept[drop]] = False
                 kept = torch.nonzero(keep).squeeze(1)
             total = keep.shape[0]  # `kept` (one host round trip) sizes all pools

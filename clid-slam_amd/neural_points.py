@@ -210,10 +210,13 @@ class NeuralPoints(nn.Module):
         stamp = torch.full((n_new,), cur_ts, device=self.device, dtype=torch.int)
         self.point_ts_create = torch.cat((self.point_ts_create, stamp), 0)
         self.point_ts_update = torch.cat((self.point_ts_update, stamp), 0)
-        fresh = self.geo_feature_std * torch.randn(n_new + 1, self.geo_feature_dim, device=self.device, dtype=self.dtype)
+        gen = _lib.replica_generator(self, self.config, self.device, 2)  # None = global RNG unless data-parallel
+        fresh = self.geo_feature_std * torch.randn(n_new + 1, self.geo_feature_dim, device=self.device, dtype=self.dtype,
+                                                   generator=gen)
         self.geo_features = torch.cat((self.geo_features[:-1], fresh), 0)
         if self.color_features is not None:
-            fresh = self.color_feature_std * torch.randn(n_new + 1, self.color_feature_dim, device=self.device, dtype=self.dtype)
+            fresh = self.color_feature_std * torch.randn(n_new + 1, self.color_feature_dim, device=self.device, dtype=self.dtype,
+                                                         generator=gen)
             self.color_features = torch.cat((self.color_features[:-1], fresh), 0)
         self.point_certainties = torch.cat(
             (self.point_certainties, torch.zeros(n_new, device=self.device, dtype=self.dtype)), 0)

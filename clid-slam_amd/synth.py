@@ -108,3 +108,62 @@ def box_room_pool(cfg, n_elev: int = 128, n_azim: int = 1024, seed: int = 42, se
         "weight": weight,
         "sensor": off,
     }
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Sequence of BASELINE.json configs[4] / SURVEY.md section 8(d): the datasets are not shipped, so the "full
+# sequence" is a synthetic sweep through a large hall -- 1 m per frame, a straight leg, one 90 degree turn, a
+# second leg -- seen by the same Ouster-128 pattern.  Input synthesis only; never timed.
+HALL_MIN = (-45.0, -45.0, 0.0)
+HALL_MAX = (170.0, 130.0, 8.0)
+
+
+def sweep_poses(n_frames: int = 200, step_m: float = 1.0, turn_at: int = 120, height: float = 1.5) -> torch.Tensor:
+    """[n_frames, 4, 4] float64 sensor->world poses: +x for `turn_at` frames, then yaw 90 degrees and +y."""
+    poses = torch.eye(4, dtype=torch.float64).repeat(n_frames, 1, 1)
+    x = y = 0.0
+    for i in range(n_frames):
+        yaw = 0.0 if i < turn_at else math.pi / 2
+        if i > 0:
+            if i <= turn_at:
+                x += step_m
+            else:
+                y += step_m
+        c, s = math.cos(yaw), math.sin(yaw)
+        poses[i, :3, :3] = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float64)
+        poses[i, :3, 3] = torch.tensor([x, y, height], dtype=torch.float64)
+    return poses
+
+
+def hall_scan(pose: torch.Tensor, seed: int, device="cpu", n_elev: int = 128, n_azim: int = 1024, noise_std: float = 0.01,
+              min_range: float = 1.0, max_range: float = 60.0, vox_down_m: float = 0.1,
+              box_min=HALL_MIN, box_max=HALL_MAX) -> torch.Tensor:
+    """Scan points [R, 3] fp32 in the SENSOR frame of `pose` (4x4 sensor->world) inside the axis-aligned hall."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    elev = torch.linspace(-22.5, 22.5, n_elev, dtype=torch.float64, device=device) * math.pi / 180.0
+    azim = torch.arange(n_azim, dtype=torch.float64, device=device) * (2.0 * math.pi / n_azim)
+    ce, se = torch.cos(elev)[:, None], torch.sin(elev)[:, None]
+    d_s = torch.stack((ce * torch.cos(azim)[None], ce * torch.sin(azim)[None], se.expand(-1, n_azim)), dim=-1).reshape(-1, 3)
+    pose = pose.to(device=device, dtype=torch.float64)
+    d = d_s @ pose[:3, :3].T  # world-frame ray directions
+    o = pose[:3, 3]
+    lo = torch.tensor(box_min, dtype=torch.float64, device=device)
+    hi = torch.tensor(box_max, dtype=torch.float64, device=device)
+    t_axis = torch.where(d > 0, (hi - o) / d, (lo - o) / d)
+    t_axis = torch.where(d == 0, torch.full_like(t_axis, float("inf")), t_axis)
+    t = t_axis.min(dim=1).values
+    t = t + noise_std * torch.randn(t.shape, generator=gen, dtype=torch.float64, device=device)
+    pts = (d_s * t[:, None]).to(torch.float32)
+    r = pts.norm(dim=1)
+    pts = pts[(r > min_range) & (r < max_range)]
+    if vox_down_m > 0:
+        key = torch.floor(pts / vox_down_m).to(torch.int64)
+        key = key - key.min(dim=0).values
+        ext = key.max(dim=0).values + 1
+        flat = (key[:, 0] * ext[1] + key[:, 1]) * ext[2] + key[:, 2]
+        order = torch.argsort(flat, stable=True)
+        sf = flat[order]
+        first = torch.ones_like(sf, dtype=torch.bool)
+        first[1:] = sf[1:] != sf[:-1]
+        pts = pts[order[first].sort().values]
+    return pts.contiguous()

@@ -235,6 +235,28 @@ int clid_train_search(const clid_map_view* mv, const clid_train_args* t, int32_t
                       const int64_t* index_base, int64_t index_stride, float* rec_out, void* stream);
 int clid_train_decode(const clid_map_view* mv, const clid_train_args* t, const float* rec, void* stream);
 
+/* ---- multi-GPU: RCCL inside the C ABI (new; the reference is single-GPU, slam.py:11) ---------------------------
+ * One process per GPU.  Rank 0 creates a 128-byte id (clid_comm_unique_id), the host distributes it (e.g.
+ * torch.distributed.broadcast), every rank calls clid_comm_init (collective: ncclCommInitRank on the current HIP
+ * device).  clid_comm_allreduce is ncclAllReduce in place on `stream` (float32 SUM, or int32 / MAX).  RCCL is
+ * resolved with dlopen at first use: the library loads without it, these calls then return an error. */
+typedef struct clid_comm clid_comm;
+int clid_comm_unique_id(uint8_t* id_out_host /* [128] */);
+int clid_comm_init(const uint8_t* id_host /* [128] */, int32_t rank, int32_t world, clid_comm** comm_out);
+int clid_comm_size(const clid_comm* comm); /* number of ranks (ncclCommCount), < 0 on error */
+int clid_comm_allreduce(clid_comm* comm, void* buf, int64_t count, int32_t is_int32, int32_t op_max, void* stream);
+int clid_comm_destroy(clid_comm* comm);
+
+/* Mapper.mapping on one rank of a data-parallel group in ONE host call: this rank's slice of
+ * every batch (index_base = its first element of iteration 0, row stride index_stride; t->batch_offset, t->inv_n_main,
+ * t->inv_n_eik carry the global lattice phase and normalisers), per iteration decode/backward -> RCCL all-reduce (SUM)
+ * of the fused gradient buffer `t->grad` [grad_floats] on `stream` -> the identical Adam step; afterwards the losses
+ * [iters][4] (SUM) and mv->ts_update [M] (MAX) are merged.  With the tile decode kernels the certainty increments travel
+ * inside the all-reduced accumulation rows; with kernel 0 the caller merges its certainty deltas itself. */
+int clid_mapping_run_dist(const clid_map_view* mv, const clid_train_args* t, const clid_adam_args* a, int32_t iters,
+                          const int64_t* index_base, int64_t index_stride, float* loss_base, clid_comm* comm,
+                          int64_t grad_floats, void* stream);
+
 /* How clid_mapping_run schedules the loop (numerical-eikonal / no-eikonal modes):
  *   1  (default) clid_train_search over a chunk of iterations, then per iteration clid_train_decode + Adam;
  *   0  per iteration the fused search+decode kernel of clid_train_fwd_bwd + Adam.
