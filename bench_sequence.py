@@ -56,7 +56,28 @@ class Dataset:  # the attributes Mapper reads of SLAMDataset (utils/slam_dataset
     static_mask = None
 
 
-def run(frames, device, check_frames=0, seed=42, quiet=False):
+def _wrap_stages(mp, nm, lpm, acc):
+    """Synchronised wall-clock timers around the stages of process_frame (changes the totals: --breakdown runs only)."""
+    def wrap(obj, name, label):
+        fn = getattr(obj, name)
+
+        def w(*a, **k):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = fn(*a, **k)
+            torch.cuda.synchronize()
+            acc.setdefault(label, []).append(time.perf_counter() - t0)
+            return r
+        setattr(obj, name, w)
+    wrap(lpm, "update_map", "raw-point map update")
+    wrap(mp.sampler, "sample", "sampler (launch + compaction)")
+    wrap(nm, "update", "NeuralPoints.update (incl. reset_local_map)")
+    wrap(nm, "reset_local_map", "reset_local_map")
+    wrap(nm, "query_certainty", "query_certainty (new-sample detection)")
+    wrap(nm, "assign_local_to_global", "assign_local_to_global")
+
+
+def run(frames, device, check_frames=0, seed=42, quiet=False, breakdown=None):
     from clid_slam_amd import Decoder, LocalPointCloudMap, Mapper, NeuralPoints
     from clid_slam_amd.synth import hall_scan, sweep_poses
     from clid_slam_amd.tools import freeze_model
@@ -67,6 +88,8 @@ def run(frames, device, check_frames=0, seed=42, quiet=False):
     dec = Decoder(cfg, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, 1)
     ds = Dataset()
     mp = Mapper(cfg, ds, nm, LocalPointCloudMap(cfg), dec)
+    if breakdown is not None:
+        _wrap_stages(mp, nm, mp.local_point_cloud_map, breakdown)
     poses = sweep_poses(frames)
     ds.gt_poses = poses.numpy()
     travel = np.concatenate(([0.0], np.cumsum(np.linalg.norm(np.diff(ds.gt_poses[:, :3, 3], axis=0), axis=1))))
@@ -153,6 +176,7 @@ def main():
     ap.add_argument("--frames", type=int, default=200)
     ap.add_argument("--check-frames", type=int, default=0)
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="synchronised per-stage timers inside process_frame (perturbs the totals)")
     ap.add_argument("--profile-last", action="store_true",
                     help="per-kernel dispatch durations of 10 more iterations on the final state (large local map, full pool)")
     args = ap.parse_args()
@@ -162,7 +186,8 @@ def main():
     import clid_slam_amd  # noqa: F401
 
     t_all = time.perf_counter()
-    cfg, rows, checks, objs = run(args.frames, device, args.check_frames, quiet=args.quiet)
+    acc = {} if args.breakdown else None
+    cfg, rows, checks, objs = run(args.frames, device, args.check_frames, quiet=args.quiet, breakdown=acc)
     large = None
     if args.profile_last:
         import bench
@@ -190,7 +215,8 @@ def main():
                                "numerical eikonal), per-frame process_frame -> mapping as slam.py:135-200, decoder frozen at frame "
                                f"{cfg.freeze_after_frame}; synthetic hall sweep, {rows[1]['rays'] if len(rows) > 1 else rows[0]['rays']} rays/scan",
                    "bs": cfg.bs, "layer_norm_on": cfg.layer_norm_on, "free_sample_begin_ratio": cfg.free_sample_begin_ratio},
-        "final_loss": rows[-1]["loss"], "oracle_checks": checks or None, "large_map_kernels": large, "wall_s": time.perf_counter() - t_all,
+        "final_loss": rows[-1]["loss"], "oracle_checks": checks or None, "large_map_kernels": large,
+        "process_frame_stage_ms": None if acc is None else {k: 1e3 * sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in acc.items()}, "wall_s": time.perf_counter() - t_all,
         "every_25th_frame": [rows[i] for i in range(0, len(rows), 25)],
     }
     print(json.dumps(line))

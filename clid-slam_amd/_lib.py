@@ -87,6 +87,7 @@ _SIGS = {
     "clid_table_build": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _f32, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _i32, _vp, _vp, _i32,
                                    _vp]),
     "clid_radius_search": (C.c_int, [C.POINTER(MapView), _vp, _i32, _vp, _vp, _vp]),
+    "clid_query_certainty": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _i32, _vp, _vp]),
     "clid_query_fwd": (C.c_int, [C.POINTER(MapView), _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clid_query_bwd": (C.c_int, [C.POINTER(MapView), _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "clid_mlp_sdf_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _vp]),

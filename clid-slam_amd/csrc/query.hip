@@ -31,6 +31,32 @@ __global__ void k_radius_search(clid_map_view mv, const float* __restrict__ x, i
   idx_out[t] = j;
 }
 
+// ---- query_certainty on the GLOBAL map straight from the reference's own table (model/neural_points.py:1032-1051) ----
+// buffer_pt_index[hash] -> point -> collision test -> certainty, max over the P probe cells.  Used once per frame on the
+// new samples with a 1-cell neighbourhood (utils/mapper.py:409-423): one 8-byte probe per sample instead of building a
+// compact mirror of the whole global map for a single pass.
+__global__ void __launch_bounds__(256)
+k_query_certainty_direct(const long long* __restrict__ table, int buffer_size, const float* __restrict__ points,
+                         const float* __restrict__ cert, const int* __restrict__ delta, int P, float resolution,
+                         float max_valid_dist2, const float* __restrict__ x, int N, float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float px = x[n * 3 + 0], py = x[n * 3 + 1], pz = x[n * 3 + 2];
+  const int r0 = base_slot(px, py, pz, resolution, buffer_size);
+  float best = 0.f;  // certainties are >= 0; cells without a valid point contribute 0 (np.py:1043-1049)
+  for (int o = 0; o < P; ++o) {
+    int slot = r0 + delta[o];
+    if (slot >= buffer_size) slot -= buffer_size;
+    const long long j = table[slot];
+    if (j < 0) continue;
+    const float ax = fsub(points[j * 3 + 0], px), ay = fsub(points[j * 3 + 1], py), az = fsub(points[j * 3 + 2], pz);
+    const float d2 = fadd(fadd(fmul(ax, ax), fmul(ay, ay)), fmul(az, az));
+    if (d2 > max_valid_dist2) continue;  // hash collision: a foreign point (np.py:1016-1020)
+    best = fmaxf(best, cert[j]);
+  }
+  out[n] = best;
+}
+
 // ---- a3: query_feature forward ------------------------------------------------------------------------
 // One 16-lane group per query.  Writes f (weighted) or v_k (per neighbour), w, idx, nn, certainty.
 __global__ void __launch_bounds__(CLID_BLOCK)
@@ -453,6 +479,22 @@ extern "C" int clid_radius_search(const clid_map_view* mv, const float* x, int32
   const long long total = (long long)N * mv->P;
   hipLaunchKernelGGL(clid::k_radius_search, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, *mv, x, N, dist2_out, idx_out);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+extern "C" int clid_query_certainty(const int64_t* buffer_pt_index, int64_t buffer_size, const float* neural_points,
+                                    const float* point_certainties, const int32_t* delta, int32_t P, float resolution,
+                                    float max_valid_dist2, const float* x, int32_t N, float* cert_out, void* stream) {
+  if (!buffer_pt_index || !neural_points || !point_certainties || !delta || !x || !cert_out || P <= 0 ||
+      buffer_size <= 0 || buffer_size >= (1LL << 30)) {
+    clid_set_error("clid_query_certainty: bad argument");
+    return CLID_E_ARG;
+  }
+  if (N <= 0) return CLID_OK;
+  hipLaunchKernelGGL(clid::k_query_certainty_direct, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(buffer_pt_index), (int)buffer_size, neural_points, point_certainties,
+                     delta, P, resolution, max_valid_dist2, x, N, cert_out);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

@@ -583,5 +583,27 @@ class Mapper:
                     if frame_id > cfg.freeze_after_frame and ratio > getattr(cfg, "new_sample_ratio_restart", 0.3):
                         self.adaptive_iter_offset = 10
 
-    def bundle_adjustment(self, *a, **k):
+    def bundle_adjustment(self, iter_count, window_size: int = 50, use_lie_group: bool = False):
+        """utils/mapper.py:866-965 (needs pypose; ba_freq_frame = 0 in every shipped config)."""
         raise NotImplementedError("bundle_adjustment is disabled in all shipped configs (ba_freq_frame=0) and out of scope")
+
+    def get_data_pool_o3d(self, down_rate=1, only_cur_data=False):
+        """utils/mapper.py:553-600: the training pool as a point cloud for the GUI, coloured by the SDF label (red
+        behind / blue in front of the surface).  open3d PointCloud when installed, else tools.PointCloudArrays."""
+        import numpy as np
+
+        from .tools import point_cloud_o3d
+
+        if only_cur_data:
+            sl = slice(self.global_coord_pool.shape[0] - self.cur_sample_count, None, 3)
+        else:
+            sl = slice(None, None, max(int(down_rate), 1))
+        pts = self.global_coord_pool[sl].detach().cpu().numpy().astype(np.float64)
+        colors = None
+        if self.sdf_label_pool is not None:
+            lab = self.sdf_label_pool[sl].detach().cpu().numpy().astype(np.float64)
+            t = np.clip(np.abs(lab) / max(float(self.config.free_sample_end_dist_m), 1e-6), 0.0, 1.0)
+            colors = np.zeros((lab.shape[0], 3))
+            colors[lab < 0, 0] = 1.0 - 0.5 * t[lab < 0]   # behind the surface: red
+            colors[lab >= 0, 2] = 1.0 - 0.5 * t[lab >= 0]  # in front: blue
+        return point_cloud_o3d(pts, colors)

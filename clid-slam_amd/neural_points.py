@@ -167,6 +167,7 @@ class NeuralPoints(nn.Module):
         st = super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__.copy()
         st = dict(st)
         st["_tables"] = {}
+        st.pop("_replica_gens", None)  # torch.Generator objects do not pickle
         return st
 
     # ------------------------------------------------------------------ search region
@@ -380,8 +381,44 @@ class NeuralPoints(nn.Module):
         self._map_version += 1
         return True
 
-    def adjust_map(self, *a, **k):
-        raise NotImplementedError("adjust_map (PGO map deformation) is outside the hot-path scope")
+    def adjust_map(self, pose_diff_torch):
+        """model/neural_points.py:814-838 (map deformation after a pose-graph optimisation)."""
+        raise NotImplementedError("adjust_map (PGO map deformation; pgo is off in every shipped config) is outside the hot-path scope")
+
+    def compute_feature_principle_components(self, down_rate: int = 1):
+        """model/neural_points.py:176-188: principal directions of the local latent features (GUI colouring,
+        vis_pin_map.py:124)."""
+        from .tools import feature_pca_torch
+
+        _, self.geo_feature_pca = feature_pca_torch(self.local_geo_features.detach()[:-1], down_rate=down_rate, project_data=False)
+        if self.color_features is not None:
+            _, self.color_feature_pca = feature_pca_torch(self.local_color_features.detach()[:-1], down_rate=down_rate,
+                                                          project_data=False)
+
+    def get_neural_points_o3d(self, query_global: bool = True, color_mode: int = -1, random_down_ratio: int = 1):
+        """model/neural_points.py:190-322: the neural points as a point cloud for the GUI; colour modes 0 (geometry-feature
+        PCA), 2 (update stamp), 3 (certainty) as in the reference.  Returns an open3d PointCloud when open3d is
+        installed, else `tools.PointCloudArrays` (numpy `.points` / `.colors`)."""
+        import numpy as np
+
+        from .tools import feature_pca_torch, point_cloud_o3d
+
+        r = max(int(random_down_ratio), 1)
+        pts = (self.neural_points if query_global else self.local_neural_points)[::r]
+        colors = None
+        if color_mode == 0 and self.geo_feature_pca is not None:
+            feats = self.geo_features[:-1:r] if query_global else self.local_geo_features[:-1:r].detach()
+            colors, _ = feature_pca_torch(feats, principal_components=self.geo_feature_pca)
+        elif color_mode == 2:  # time stamp of the last update, normalised
+            ts = (self.point_ts_update if query_global else self.local_point_ts_update)[::r].float()
+            t = ts / ts.max().clamp_min(1.0)
+            colors = torch.stack((t, 1.0 - (2.0 * t - 1.0).abs(), 1.0 - t), dim=1)
+        elif color_mode == 3:  # certainty, saturating
+            c = (self.point_certainties if query_global else self.local_point_certainties)[::r]
+            t = (c / 100.0).clamp(0.0, 1.0)
+            colors = torch.stack((t, 1.0 - (2.0 * t - 1.0).abs(), 1.0 - t), dim=1)
+        return point_cloud_o3d(pts.detach().cpu().numpy().astype(np.float64),
+                               None if colors is None else colors.detach().cpu().numpy().astype(np.float64))
 
     # ------------------------------------------------------------------ device mirror
     def _table(self, locally: bool, time_filtering: bool):
@@ -494,7 +531,20 @@ class NeuralPoints(nn.Module):
         return d2, idx.to(torch.int64)
 
     def query_certainty(self, query_points: torch.Tensor):
-        """model/neural_points.py:1032-1051."""
+        """model/neural_points.py:1032-1051: max certainty of the neural points in the probe cells (global map, no time
+        filter).  On the GPU the reference's own table is probed directly (one launch, no mirror of the global map)."""
+        big = self.buffer_pt_index
+        if (query_points.is_cuda and big is not None and big.is_cuda and big.dtype == torch.int64
+                and int(self.buffer_size) < (1 << 30) and self.point_certainties.dtype == torch.float32):
+            x = query_points.detach().to(torch.float32).contiguous()
+            out = torch.empty((x.shape[0],), device=x.device, dtype=torch.float32)
+            if self._delta.device != x.device:
+                self._delta = self._delta.to(x.device)
+            _lib.check(_lib.load().clid_query_certainty(
+                big.data_ptr(), int(self.buffer_size), _lib.require_cuda(self.neural_points, "neural_points", torch.float32).data_ptr(),
+                self.point_certainties.contiguous().data_ptr(), self._delta.data_ptr(), int(self.neighbor_K), float(self.resolution),
+                float(self.max_valid_dist2), x.data_ptr(), int(x.shape[0]), out.data_ptr(), _lib.stream()), "clid_query_certainty")
+            return out
         _, idx = self.radius_neighborhood_search(query_points)
         c = torch.where(idx < 0, torch.zeros((), dtype=self.point_certainties.dtype, device=idx.device),
                         self.point_certainties[idx.clamp_min(0)])
@@ -504,6 +554,11 @@ class NeuralPoints(nn.Module):
         """Fused inference used by tracking-style callers: query (training_mode=False, local map)
         -> Decoder.sdf -> analytic d sdf / d x, i.e. utils/error_state_iekf.py:209-227 in ONE kernel.
         Returns (sdf [N], grad [N,3], nn_counts [N] int64, certainty [N])."""
+        if not self.config.weighted_first:
+            # the fused kernel blends the neighbours' features, then decodes once (weighted_first semantics); decoding
+            # every neighbour and blending the SDFs (utils/mapper.py:107-112) would give a different value
+            raise NotImplementedError("query_sdf_and_gradient serves weighted_first configs (all shipped ones); use "
+                                      "query_feature + Decoder.sdf + get_gradient for weighted_first=False")
         lib = _lib.load()
         x = _lib.require_cuda(query_points.detach().contiguous(), "query_points", torch.float32)
         view, keep = self._map_view(True)

@@ -162,3 +162,83 @@ def transform_batch_torch(points: torch.Tensor, transformation: torch.Tensor):
     """Per-point rigid transform: points [N,3], transformation [N,4,4] (utils/tools.py:612-636)."""
     T = transformation.to(points)
     return torch.bmm(T[:, :3, :3], points.unsqueeze(-1)).squeeze(-1) + T[:, :3, 3]
+
+
+def feature_pca_torch(data, principal_components=None, principal_dim: int = 3, down_rate: int = 1,
+                      project_data: bool = True, normalize: bool = True):
+    """utils/tools.py:858-916: PCA of an [N, D] tensor -> (projected [N, principal_dim] or None, components [D, k]).
+    The covariance is symmetric, so `eigh` replaces the reference's general `eig` (same subspace, eigenvector signs are
+    arbitrary in both); projections are min-max normalised to [0, 1] per component like the reference."""
+    n = data.shape[0]
+    centered = data - data.mean(dim=0)
+    if principal_components is None:
+        used = centered[::down_rate]
+        if used.shape[0] <= principal_dim:
+            raise ValueError("not enough data for the PCA (down_rate too large or too few points)")
+        cov = used.T @ used / max(n - 1, 1)
+        evals, evecs = torch.linalg.eigh(cov.double())
+        order = torch.argsort(evals, descending=True)[:principal_dim]
+        principal_components = evecs[:, order].to(data.dtype)
+    projected = None
+    if project_data:
+        projected = centered @ principal_components
+        if normalize:
+            lo, hi = projected.min(dim=0).values, projected.max(dim=0).values
+            projected = (projected - lo) / (hi - lo).clamp_min(1e-12)
+    return projected, principal_components
+
+
+class PointCloudArrays:
+    """What the GUI packets need of an Open3D point cloud (gui/gui_utils.py:52-130 reads `.points` / `.colors` and converts
+    them to numpy): returned by the `*_o3d` helpers when open3d is not installed."""
+
+    def __init__(self, points, colors=None):
+        import numpy as np
+
+        self.points = np.asarray(points, dtype=np.float64)
+        self.colors = None if colors is None else np.asarray(colors, dtype=np.float64)
+
+    def __len__(self):
+        return self.points.shape[0]
+
+
+def point_cloud_o3d(points_np, colors_np=None):
+    """An open3d.geometry.PointCloud when open3d is importable, else a PointCloudArrays with the same two fields."""
+    try:
+        import open3d as o3d
+
+        pc = o3d.geometry.PointCloud()
+        pc.points = o3d.utility.Vector3dVector(points_np)
+        if colors_np is not None:
+            pc.colors = o3d.utility.Vector3dVector(colors_np)
+        return pc
+    except Exception:  # open3d absent (this image) or stubbed
+        return PointCloudArrays(points_np, colors_np)
+
+
+def save_implicit_map(run_path, neural_points, mlp_dict, with_footprint: bool = True):
+    """utils/tools.py:347-367: `<run_path>/model/pin_map.pth` = {"neural_points": the whole NeuralPoints module, one
+    state_dict (or None) per decoder key} -- the object contract vis_pin_map.py:118-127 loads (it then re-hashes the map
+    with recreate_hash and calls compute_feature_principle_components) -- plus memory_footprint.npy."""
+    import os
+
+    import numpy as np
+
+    map_model = {"neural_points": neural_points}
+    for key in list(mlp_dict.keys()):
+        map_model[key] = None if mlp_dict[key] is None else mlp_dict[key].state_dict()
+    os.makedirs(os.path.join(run_path, "model"), exist_ok=True)
+    model_save_path = os.path.join(run_path, "model", "pin_map.pth")
+    torch.save(map_model, model_save_path)
+    if with_footprint:
+        np.save(os.path.join(run_path, "memory_footprint.npy"), np.array(neural_points.memory_footprint))
+    return model_save_path
+
+
+def load_decoders(loaded_model, mlp_dict, freeze_decoders: bool = True):
+    """utils/tools.py:370-382: restore the decoders saved by save_implicit_map."""
+    for key in list(loaded_model.keys()):
+        if key != "neural_points" and loaded_model[key] is not None and mlp_dict.get(key) is not None:
+            mlp_dict[key].load_state_dict(loaded_model[key])
+            if freeze_decoders:
+                freeze_model(mlp_dict[key])

@@ -99,6 +99,13 @@ int clid_table_build(const int64_t* ids, int32_t n, const float* neural_points,
 int clid_radius_search(const clid_map_view* mv, const float* x, int32_t N, float* dist2_out,
                        int32_t* idx_out, void* stream);
 
+/* NeuralPoints.query_certainty (model/neural_points.py:1032-1051) on the GLOBAL map, probing the reference's own
+ * buffer_pt_index [buffer_size] int64 directly (no mirror): cert_out[n] = max over the P cells of the certainty of the
+ * point stored there (0 where the cell is empty or holds a colliding foreign point).  delta [P] as in clid_map_view. */
+int clid_query_certainty(const int64_t* buffer_pt_index, int64_t buffer_size, const float* neural_points,
+                         const float* point_certainties, const int32_t* delta, int32_t P, float resolution,
+                         float max_valid_dist2, const float* x, int32_t N, float* cert_out, void* stream);
+
 /* NeuralPoints.query_feature (model/neural_points.py:553-769), geometry features.
  *   query_ts  [N] int32 or NULL;  training_mode: certainty/ts side effects (np.py:708-733)
  *   weighted_first: feat_out [N][D] else [N][K][D]

@@ -604,6 +604,24 @@ def test_mesher_query_points_vs_reference_g12(env, ln, loc):
     assert isinstance(sdf_np, np.ndarray) and maxerr(sdf_np, g[f"sdf_ln{ln}_loc{loc}"]) <= 2e-6
 
 
+@pytest.mark.parametrize("cells,alpha", [(1, 0.0), (2, 0.5)])
+def test_query_certainty_direct_probe_vs_oracle(env, cells, alpha):
+    """NeuralPoints.query_certainty (global map, model/neural_points.py:1032-1051): the direct probe of buffer_pt_index
+    against the oracle, for the 1-cell neighbourhood process_frame uses (utils/mapper.py:409-423) and the default one."""
+    g = gio.load("g2_query.npz")
+    cfg = env.config()
+    nm = env.neural_points(cfg)
+    gen = torch.Generator().manual_seed(4)
+    x = torch.cat([gio.T(g["x"]), gio.T(g["x"]) + 0.5 * torch.randn(g["x"].shape, generator=gen)])
+    nm.set_search_neighborhood(num_nei_cells=cells, search_alpha=alpha)
+    got = nm.query_certainty(x.cuda())
+    st = gio.map_state()
+    st.neighbor_dx, st.max_valid_dist2 = O.search_neighborhood(cells, alpha, st.resolution)
+    ref = O.query_certainty(st, x)
+    assert maxerr(got, ref) == 0.0
+    assert (ref > 0).any() and (ref == 0).any()
+
+
 def test_search_records_short_lists_equal_full_depth():
     """The chunked search keeps 3 candidates per lane and repeats a wave at full depth when one it pushed out
     could have been a winner; forcing the full-depth path for every wave (debug bit 2) must give bit-identical

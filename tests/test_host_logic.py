@@ -201,3 +201,58 @@ def test_config_loader_resolves_every_shipped_yaml_like_the_reference(tmp_path):
     cfg = HotPathConfig().load(str(y))
     assert abs(cfg.surface_sample_range_m - 0.24) < 1e-12 and abs(cfg.free_sample_end_dist_m - 0.96) < 1e-12
     assert abs(cfg.voxel_size_m - 0.4) < 1e-12 and abs(cfg.sigma_sigmoid_m - 0.08) < 1e-12 and cfg.track_on is False
+
+
+def test_save_implicit_map_object_contract(tmp_path):
+    """utils/tools.py:347-367 / vis_pin_map.py:118-127: pin_map.pth holds the whole NeuralPoints module + decoder
+    state_dicts; a loader finds the attribute set it reads, can re-hash the map and compute the feature PCA."""
+    import shim_io
+    from clid_slam_amd.tools import load_decoders, save_implicit_map
+
+    cfg = shim_io.config(device="cpu")
+    nm = shim_io.neural_points(cfg)
+    nm.memory_footprint = [1.0, 2.0]
+    dec = shim_io.decoder(cfg)
+    path = save_implicit_map(str(tmp_path), nm, {"sdf": dec, "semantic": None, "color": None})
+    assert path.endswith("model/pin_map.pth") and (tmp_path / "memory_footprint.npy").exists()
+    loaded = torch.load(path, weights_only=False)
+    assert sorted(loaded) == ["color", "neural_points", "sdf", "semantic"] and loaded["semantic"] is None
+    nm2 = loaded["neural_points"]
+    for name in ("neural_points", "point_orientations", "geo_features", "color_features", "point_ts_create", "point_ts_update",
+                 "point_certainties", "local_neural_points", "local_geo_features", "local_mask", "buffer_pt_index",
+                 "temporal_local_map_on", "resolution", "memory_footprint"):
+        assert hasattr(nm2, name), name
+    assert torch.equal(nm2.geo_features, nm.geo_features)
+    dec2 = shim_io.decoder(cfg)
+    with torch.no_grad():
+        dec2.lout.weight.zero_()
+    load_decoders(loaded, {"sdf": dec2, "semantic": None, "color": None})
+    assert torch.equal(dec2.lout.weight, dec.lout.weight) and not any(p.requires_grad for p in dec2.parameters())
+    nm2.temporal_local_map_on = False  # what vis_pin_map.py does after loading
+    nm2.compute_feature_principle_components(down_rate=3)
+    assert nm2.geo_feature_pca.shape == (cfg.feature_dim, 3)
+    pc = nm2.get_neural_points_o3d(query_global=True, color_mode=0, random_down_ratio=2)
+    assert np.asarray(pc.points).shape == ((nm2.neural_points.shape[0] + 1) // 2, 3)
+    assert np.asarray(pc.colors).min() >= 0.0 and np.asarray(pc.colors).max() <= 1.0
+
+
+def test_surface_audit_methods_exist_with_the_reference_signatures():
+    """The names slam.py / gui touch on the three classes (SURVEY.md section 8b surface audit)."""
+    import inspect
+
+    import shim_io
+    from clid_slam_amd import Mapper, NeuralPoints
+
+    assert list(inspect.signature(NeuralPoints.adjust_map).parameters) == ["self", "pose_diff_torch"]
+    assert list(inspect.signature(Mapper.bundle_adjustment).parameters) == ["self", "iter_count", "window_size", "use_lie_group"]
+    assert list(inspect.signature(NeuralPoints.get_neural_points_o3d).parameters) == ["self", "query_global", "color_mode", "random_down_ratio"]
+    assert list(inspect.signature(Mapper.get_data_pool_o3d).parameters) == ["self", "down_rate", "only_cur_data"]
+    cfg = shim_io.config(device="cpu")
+    nm = shim_io.neural_points(cfg)
+    mp, _ = shim_io.mapper(cfg, nm, shim_io.decoder(cfg))
+    mp.cur_sample_count = 300
+    pc = mp.get_data_pool_o3d(down_rate=7)
+    assert np.asarray(pc.points).shape[1] == 3 and np.asarray(pc.colors).shape == np.asarray(pc.points).shape
+    assert len(np.asarray(mp.get_data_pool_o3d(only_cur_data=True).points)) == 100
+    with pytest.raises(NotImplementedError):
+        nm.adjust_map(torch.eye(4)[None])

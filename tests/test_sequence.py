@@ -92,3 +92,23 @@ def test_multi_frame_mapping_tracks_the_oracle(layer_norm):
         sizes.append((nm.count(), nm.local_count()))
     # the scenario really moved the window and grew the map
     assert sizes[-1][0] > sizes[0][0] and any(l < g for g, l in sizes[1:])
+
+
+def test_subt_sequence_harness_first_frames_vs_oracle():
+    """BASELINE configs[4] workload: the run_SubT_MRS.yaml values (fixture G13: layer norm, free_sample_begin_ratio 0.8)
+    driving process_frame -> mapping per frame as slam.py:135-200 (bench_sequence.py); the mapping() calls of the first
+    frames are replayed on the CPU oracle from a snapshot of the state before each call."""
+    import bench_sequence as BS
+
+    cfg, rows, checks, _ = BS.run(3, "cuda:0", check_frames=3, quiet=True)
+    assert cfg.layer_norm_on and cfg.free_sample_begin_ratio == 0.8 and cfg.bs == 16384
+    assert rows[0]["iters"] >= cfg.iters * cfg.init_iter_ratio - 10 and rows[1]["iters"] <= cfg.iters + 10
+    assert rows[2]["M_local"] > rows[0]["M_local"] and rows[2]["pool"] > rows[0]["pool"]
+    for c in checks:
+        assert c["max_dloss"] <= 2e-5, c
+        if "max_dtheta" in c:
+            # Adam with eps = 1e-15: entries whose gradient is cancellation residue move by up to lr * iters in either
+            # implementation (see test_multi_frame_mapping_tracks_the_oracle); everything else must agree to 1e-4
+            assert c["max_dtheta"] <= cfg.lr * c["iters"] * 1.01, c
+            assert c["n_dtheta_gt_1e4"] <= 2e-3 * rows[c["frame"]]["M_local"] * 8, c
+            assert c["max_ddecoder"] <= 1e-4 and c["max_dcert"] <= 2e-2, c
