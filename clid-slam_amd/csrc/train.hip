@@ -224,7 +224,7 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
   static_assert(sizeof(WaveHead) == kRecFloat4 * sizeof(float4), "record layout");
   if constexpr (MODE == 1) {
     stage_delta(dl, mv);
-    if (use_filter)
+    if (use_filter == 1)
       for (int i = threadIdx.x; i < (1 << mv.log2filter) / 32; i += kFusedBlock) filt_lds[i] = mv.filter[i];
     __syncthreads();
   } else if constexpr (MODE == 2) {
@@ -288,7 +288,8 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
       CLID_STAMP(1);
       if constexpr (MODE == 1) {
         bool redo;
-        if (use_filter) redo = search8<true, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], filt_lds);
+        if (use_filter == 1) redo = search8<true, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], filt_lds);
+        else if (use_filter == 2) redo = search8<true, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], mv.filter);
         else redo = search8<false, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
         if (__any(redo) || (ta.debug_flags & 4))  // rare (debug bit 2 forces it: tests compare the two paths)
           search8<false, CLID_K>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
@@ -625,8 +626,24 @@ __global__ void __launch_bounds__(256) k_adam_all(AdamLaunch a) {
       if (i4 >= a.n_feat) return;
       const long long row = i4 >> 3;
       float* gr = g + row * CLID_GRAD_ROW16 + (i4 & 7);
-      float4 P = *reinterpret_cast<float4*>(a.feat + i4), G = *reinterpret_cast<float4*>(gr);
+      float4 G = *reinterpret_cast<float4*>(gr);
       float4 M = *reinterpret_cast<float4*>(a.m + i4), V = *reinterpret_cast<float4*>(a.v + i4);
+      const bool idle = a.k.wd == 0.f && G.x == 0.f && G.y == 0.f && G.z == 0.f && G.w == 0.f && M.x == 0.f && M.y == 0.f &&
+                        M.z == 0.f && M.w == 0.f && V.x == 0.f && V.y == 0.f && V.z == 0.f && V.w == 0.f;
+      if (idle) {
+        // never touched since this mapping() call started (the optimiser state restarts per call): the update is exactly
+        // zero, nothing to read of the parameters and nothing to write -- 48 instead of 144 bytes per float4 on the
+        // (majority of) rows of a large local map that the call's batches do not reach
+        if ((i4 & 7) == 4 && a.cert && row < a.n_cert) {
+          const float inc = gr[4];
+          if (inc != 0.f) {
+            a.cert[row] += inc;
+            gr[4] = 0.f;
+          }
+        }
+        return;
+      }
+      float4 P = *reinterpret_cast<float4*>(a.feat + i4);
       adam_update(P.x, G.x, M.x, V.x, a.k, a.k.wd);
       adam_update(P.y, G.y, M.y, V.y, a.k, a.k.wd);
       adam_update(P.z, G.z, M.z, V.z, a.k, a.k.wd);
@@ -1031,13 +1048,18 @@ extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args*
   long long sb = ((long long)tmap.n_tasks * n_iter + kFusedBlock / 64 - 1) / (kFusedBlock / 64);
   if (sb > kSearchBlocks) sb = kSearchBlocks;
   const int h = prof_begin(1, s);
-  // probe prefilter in LDS when the map provides one that fits (<= 32 KB) and the launch is large enough to
-  // amortise staging it per block
-  const bool use_filter = mv->filter && mv->log2filter >= 10 && mv->log2filter <= 18 && filter_enabled() &&
-                          (long long)tmap.n_tasks * n_iter >= 4 * sb * (kFusedBlock / 64);
-  const size_t dyn = use_filter ? ((size_t)1 << mv->log2filter) / 8 : 0;
+  // probe prefilter (a one-hash Bloom filter over the stored slots; 59 of the 81 probes of a typical query hit nothing):
+  // staged in LDS when it fits (<= 32 KB) and the launch is large enough to amortise staging it per block; for large
+  // local maps (> 2^17 points: the filter is up to 2 MB, the key table 8+ MB) it is read from global memory, where it
+  // stays L2-resident while the bucket loads it saves would each touch a line of the far larger table
+  int use_filter = 0;
+  if (mv->filter && mv->log2filter >= 10 && filter_enabled()) {
+    if (mv->log2filter <= 18) use_filter = ((long long)tmap.n_tasks * n_iter >= 4 * sb * (kFusedBlock / 64)) ? 1 : 0;
+    else use_filter = 2;
+  }
+  const size_t dyn = use_filter == 1 ? ((size_t)1 << mv->log2filter) / 8 : 0;
   CLID_KLAUNCH(k_train_fused8<1>, dim3((unsigned)sb), dim3(kFusedBlock), dyn, s, *mv, t2, (float*)nullptr, tmap,
-                     reinterpret_cast<float4*>(rec_out), n_iter, (long long)index_stride, use_filter ? 1 : 0);
+                     reinterpret_cast<float4*>(rec_out), n_iter, (long long)index_stride, use_filter);
   CLID_CHECK_LAUNCH();
   prof_end(h, s);
   return CLID_OK;

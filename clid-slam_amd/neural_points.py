@@ -454,11 +454,12 @@ class NeuralPoints(nn.Module):
         tab = torch.empty((1 << log2cap, 4), device=pts.device, dtype=torch.int32)
         tab_pos = torch.zeros((1 << log2cap, 4, 4), device=pts.device, dtype=torch.float32)
         pos4 = torch.empty((max(n, 1), 4), device=pts.device, dtype=torch.float32)
-        # probe prefilter (one-hash Bloom filter over the stored slots): 8 bits per key where possible, at most
-        # 32 KB so the chunked search kernel can keep it in LDS next to its other state; very large local maps
-        # (> 128 k points, < 2 bits per key) go without
-        log2filter = min(18, max(13, int(math.ceil(math.log2(max(8 * n, 32))))))
-        filt = torch.empty(((1 << log2filter) // 32,), device=pts.device, dtype=torch.int32) if n <= (1 << 17) else None
+        # probe prefilter (one-hash Bloom filter over the stored slots), 8 bits per key: up to 2^18 bits (32 KB) the chunked
+        # search kernel keeps it in LDS next to its other state; larger local maps get a filter of up to 2^24 bits (2 MB)
+        # that the kernel reads from global memory (it stays L2-resident, unlike the key table it guards)
+        log2filter = max(13, int(math.ceil(math.log2(max(8 * n, 32)))))
+        log2filter = min(18, log2filter) if n <= (1 << 17) else min(24, log2filter)
+        filt = torch.empty(((1 << log2filter) // 32,), device=pts.device, dtype=torch.int32)
         tsc = self.point_ts_create if time_filtering else None
         trv = self.travel_dist.to(torch.float32).contiguous() if time_filtering else None
         _lib.check(

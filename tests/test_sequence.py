@@ -111,4 +111,5 @@ def test_subt_sequence_harness_first_frames_vs_oracle():
             # implementation (see test_multi_frame_mapping_tracks_the_oracle); everything else must agree to 1e-4
             assert c["max_dtheta"] <= cfg.lr * c["iters"] * 1.01, c
             assert c["n_dtheta_gt_1e4"] <= 2e-3 * rows[c["frame"]]["M_local"] * 8, c
-            assert c["max_ddecoder"] <= 1e-4 and c["max_dcert"] <= 2e-2, c
+            # (the decoder sees the chaotic feature entries through the next iterations' forward passes)
+            assert c["max_ddecoder"] <= (1e-4 if c["n_dtheta_gt_1e4"] == 0 else 1e-3) and c["max_dcert"] <= 2e-2, c
