@@ -206,6 +206,153 @@ k_local_to_global(const long long* __restrict__ ids, int n, long long pad_row, c
   }
 }
 
+// ---- training-pool maintenance (utils/mapper.py:297-392) ---------------------------------------------------------
+// The reference concatenates the frame's samples onto five pool arrays, masks the pool by distance to the sensor
+// (fp64 under type promotion with the float64 pose), drops random picks above `pool_capacity` and compacts every array
+// with a boolean mask: ~25 torch ops and 3 host round trips over 1e7 samples per frame.  Here: flags -> exclusive scan
+// -> (capacity drop -> scan) -> one scatter that moves all five arrays, sizes kept in device memory until the caller
+// reads the two counts it needs.  The order of the samples is preserved (stable compaction) like the boolean mask does.
+struct PoolSrc {
+  const float* coord; const float* gcoord; const float* label; const float* weight; const int* time;
+  long long n;
+};
+__device__ __forceinline__ const float* pool_gcoord(const PoolSrc& a, const PoolSrc& b, long long i) {
+  return i < a.n ? a.gcoord + i * 3 : b.gcoord + (i - a.n) * 3;
+}
+__global__ void __launch_bounds__(256)
+k_pool_flags(PoolSrc a, PoolSrc b, double ox, double oy, double oz, double r2, int* __restrict__ flag) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n + b.n) return;
+  const float* g = pool_gcoord(a, b, i);
+  const double dx = (double)g[0] - ox, dy = (double)g[1] - oy, dz = (double)g[2] - oz;  // mapper.py:346-349, float64
+  flag[i] = ((dx * dx + dy * dy) + dz * dz) < r2 ? 1 : 0;
+}
+// kept_list[rank] = index for the samples that passed the window test; counts[2] = kept (before the capacity drop)
+__global__ void __launch_bounds__(256)
+k_pool_list(const int* __restrict__ flag, const int* __restrict__ pos, long long n, int* __restrict__ kept_list,
+            long long* __restrict__ counts) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (flag[i]) kept_list[pos[i]] = (int)i;
+  if (i == n - 1) counts[2] = pos[i] + flag[i];
+}
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ULL;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+  return x ^ (x >> 31);
+}
+// mapper.py:352-361: `kept - capacity` uniform picks WITH replacement among the kept samples are dropped
+__global__ void __launch_bounds__(256)
+k_pool_drop(int* __restrict__ flag, const int* __restrict__ kept_list, const long long* __restrict__ counts, long long capacity,
+            unsigned long long seed) {
+  const long long kept = counts[2];
+  const long long excess = kept - capacity;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < excess; t += (long long)gridDim.x * blockDim.x) {
+    const unsigned long long r = splitmix64(seed + (unsigned long long)t);
+    flag[kept_list[(long long)(r % (unsigned long long)kept)]] = 0;
+  }
+}
+struct PoolDst {
+  float* coord; float* gcoord; float* label; float* weight; int* time;
+};
+__global__ void __launch_bounds__(256)
+k_pool_scatter(PoolSrc a, PoolSrc b, const int* __restrict__ flag, const int* __restrict__ pos, PoolDst d,
+               long long* __restrict__ counts) {
+  const long long n = a.n + b.n;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i == n - 1) {
+    counts[0] = pos[i] + flag[i];                               // samples kept in total
+    counts[1] = counts[0] - (a.n > 0 ? pos[a.n - 1] + flag[a.n - 1] : 0);  // ... of which from this frame (the tail)
+  }
+  if (!flag[i]) return;
+  const long long j = pos[i];
+  const bool old = i < a.n;
+  const PoolSrc& s = old ? a : b;
+  const long long k = old ? i : i - a.n;
+  d.coord[j * 3 + 0] = s.coord[k * 3 + 0]; d.coord[j * 3 + 1] = s.coord[k * 3 + 1]; d.coord[j * 3 + 2] = s.coord[k * 3 + 2];
+  d.gcoord[j * 3 + 0] = s.gcoord[k * 3 + 0]; d.gcoord[j * 3 + 1] = s.gcoord[k * 3 + 1]; d.gcoord[j * 3 + 2] = s.gcoord[k * 3 + 2];
+  d.label[j] = s.label[k];
+  d.weight[j] = s.weight[k];
+  d.time[j] = s.time[k];
+}
+
+// ---- local-window selection (model/neural_points.py:439-536) -------------------------------------------------------
+// reset_local_map: travel-distance (or frame-count) window AND distance to the sensor select the trainable local map;
+// the reference then builds global2local / local_mask and gathers six local arrays with ~40 torch ops and two host round
+// trips.  Here: flags (+ count of the time window) -> scan -> one gather pass; the caller reads ONE count.
+struct WindowArgs {
+  const float* points; const int* ts_create; const int* ts_update; const float* travel; long long n;
+  int cur_ts, use_mid_ts, temporal, use_travel, diff_ts_local, reboot_ts, reboot_map;
+  float diff_travel;
+  double sx, sy, sz, r2;
+  int pos_f64;  // the sensor position is float64 (pose dtype): the distance test then runs in float64 by type promotion
+};
+__global__ void __launch_bounds__(256) k_window_flags(WindowArgs a, unsigned char* __restrict__ bits, long long* __restrict__ counts) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool t_ok = true;
+  bool d_ok = false;
+  if (i < a.n) {
+    if (a.temporal) {
+      int ts = a.ts_create[i];
+      if (a.use_mid_ts) ts = (int)(((float)a.ts_create[i] + (float)a.ts_update[i]) / 2.0f);  // ((a + b) / 2).int(), :449
+      if (a.use_travel) t_ok = fabsf(fsub(a.travel[a.cur_ts], a.travel[ts])) < a.diff_travel;  // :452-455
+      else t_ok = abs(a.cur_ts - ts) < a.diff_ts_local;
+      if (a.reboot_map) t_ok = t_ok && ts >= a.reboot_ts;
+    }
+    if (a.pos_f64) {
+      const double dx = (double)a.points[i * 3 + 0] - a.sx, dy = (double)a.points[i * 3 + 1] - a.sy, dz = (double)a.points[i * 3 + 2] - a.sz;
+      d_ok = ((dx * dx + dy * dy) + dz * dz) < a.r2;  // :474-478
+    } else {
+      const float dx = fsub(a.points[i * 3 + 0], (float)a.sx), dy = fsub(a.points[i * 3 + 1], (float)a.sy),
+                  dz = fsub(a.points[i * 3 + 2], (float)a.sz);
+      d_ok = fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz)) < (float)a.r2;
+    }
+    bits[i] = (unsigned char)((t_ok ? 1 : 0) | (d_ok ? 2 : 0));
+  }
+  const unsigned long long b = __ballot(i < a.n && t_ok);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[0]), (unsigned long long)__popcll(b));
+}
+// fewer than 100 points inside the time window -> the window is dropped (:462-466)
+__global__ void __launch_bounds__(256) k_window_combine(const unsigned char* __restrict__ bits, long long n, int temporal,
+                                                        const long long* __restrict__ counts, int* __restrict__ flag) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool use_time = temporal && counts[0] >= 100;
+  flag[i] = ((bits[i] & 2) && (!use_time || (bits[i] & 1))) ? 1 : 0;
+}
+struct WindowOut {
+  long long* local_ids; long long* g2l; unsigned char* local_mask;
+  float* l_points; float* l_orient; float* l_cert; int* l_ts; float* l_feat;
+  const float* g_orient; const float* g_cert; const float* g_feat;
+};
+__global__ void __launch_bounds__(256) k_window_gather(WindowArgs a, const int* __restrict__ flag, const int* __restrict__ pos,
+                                                       WindowOut o, long long* __restrict__ counts) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > a.n) return;
+  if (i == a.n) {  // the padding element: always part of the mask, never of the map (:518-530)
+    const long long m = a.n > 0 ? pos[a.n - 1] + flag[a.n - 1] : 0;
+    counts[1] = m;
+    o.g2l[i] = -1;
+    o.local_mask[i] = 1;
+    for (int c = 0; c < CLID_F; ++c) o.l_feat[m * CLID_F + c] = o.g_feat[a.n * CLID_F + c];
+    return;
+  }
+  const bool in = flag[i] != 0;
+  o.local_mask[i] = in ? 1 : 0;
+  o.g2l[i] = in ? (long long)pos[i] : -1;
+  if (!in) return;
+  const long long j = pos[i];
+  o.local_ids[j] = i;
+  o.l_points[j * 3 + 0] = a.points[i * 3 + 0]; o.l_points[j * 3 + 1] = a.points[i * 3 + 1]; o.l_points[j * 3 + 2] = a.points[i * 3 + 2];
+  reinterpret_cast<float4*>(o.l_orient)[j] = reinterpret_cast<const float4*>(o.g_orient)[i];
+  o.l_cert[j] = o.g_cert[i];
+  o.l_ts[j] = a.ts_update[i];
+  reinterpret_cast<float4*>(o.l_feat)[j * 2] = reinterpret_cast<const float4*>(o.g_feat)[i * 2];
+  reinterpret_cast<float4*>(o.l_feat)[j * 2 + 1] = reinterpret_cast<const float4*>(o.g_feat)[i * 2 + 1];
+}
+
 static int vox_log2cap(int n) {
   int l = 10;
   while ((1LL << l) < 2LL * n) ++l;
@@ -329,6 +476,114 @@ extern "C" int clid_local_to_global(const int64_t* ids, int32_t n, int64_t pad_r
                      reinterpret_cast<const long long*>(ids), n, (long long)pad_row,
                      reinterpret_cast<const float4*>(local_feat), local_cert, local_ts,
                      reinterpret_cast<float4*>(global_feat), global_cert, global_ts);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+// ---- pool maintenance --------------------------------------------------------------------------------------------
+static size_t pool_scan_bytes(long long n) {
+  size_t tmp = 0;
+  hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, (const int*)nullptr, (int*)nullptr, (int)n);
+  return tmp;
+}
+extern "C" int64_t clid_pool_workspace_bytes(int64_t n_total) {
+  if (n_total <= 0) return 256;
+  return (int64_t)(3 * align256((size_t)n_total * 4) + align256(pool_scan_bytes(n_total)) + 256);
+}
+
+extern "C" int clid_pool_filter(const float* coord_a, const float* gcoord_a, const float* label_a, const float* weight_a,
+                                const int32_t* time_a, int64_t n_a, const float* coord_b, const float* gcoord_b,
+                                const float* label_b, const float* weight_b, const int32_t* time_b, int64_t n_b,
+                                const double* origin_host, double radius2, int64_t capacity, uint64_t seed, float* coord_out,
+                                float* gcoord_out, float* label_out, float* weight_out, int32_t* time_out,
+                                int64_t* counts_out, void* workspace, void* stream) {
+  const long long n = n_a + n_b;
+  if (n_a < 0 || n_b < 0 || n >= (1LL << 31) || !origin_host || !counts_out || !workspace || capacity < 0 ||
+      (n_a > 0 && (!coord_a || !gcoord_a || !label_a || !weight_a || !time_a)) ||
+      (n_b > 0 && (!coord_b || !gcoord_b || !label_b || !weight_b || !time_b)) ||
+      (n > 0 && (!coord_out || !gcoord_out || !label_out || !weight_out || !time_out))) {
+    clid_set_error("clid_pool_filter: bad argument");
+    return CLID_E_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  long long* counts = reinterpret_cast<long long*>(counts_out);
+  if (n == 0) return hipMemsetAsync(counts, 0, 3 * sizeof(long long), s) == hipSuccess ? CLID_OK : CLID_E_HIP;
+  char* ws = static_cast<char*>(workspace);
+  int* flag = reinterpret_cast<int*>(ws);
+  int* pos = reinterpret_cast<int*>(ws + align256((size_t)n * 4));
+  int* kept_list = reinterpret_cast<int*>(ws + 2 * align256((size_t)n * 4));
+  void* cub = ws + 3 * align256((size_t)n * 4);
+  size_t cub_bytes = pool_scan_bytes(n);
+  const PoolSrc a{coord_a, gcoord_a, label_a, weight_a, time_a, n_a}, b{coord_b, gcoord_b, label_b, weight_b, time_b, n_b};
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_pool_flags, dim3(blocks), dim3(256), 0, s, a, b, origin_host[0], origin_host[1], origin_host[2], radius2, flag);
+  if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)n, s) != hipSuccess) {
+    clid_set_error("clid_pool_filter: scan failed");
+    return CLID_E_HIP;
+  }
+  if (n > capacity) {  // only then can more than `capacity` samples survive the window test
+    hipLaunchKernelGGL(k_pool_list, dim3(blocks), dim3(256), 0, s, flag, pos, n, kept_list, counts);
+    hipLaunchKernelGGL(k_pool_drop, dim3(1024), dim3(256), 0, s, flag, kept_list, counts, (long long)capacity,
+                       (unsigned long long)seed);
+    if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)n, s) != hipSuccess) {
+      clid_set_error("clid_pool_filter: scan failed");
+      return CLID_E_HIP;
+    }
+  }
+  const PoolDst d{coord_out, gcoord_out, label_out, weight_out, time_out};
+  hipLaunchKernelGGL(k_pool_scatter, dim3(blocks), dim3(256), 0, s, a, b, flag, pos, d, counts);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+// ---- local window ------------------------------------------------------------------------------------------------
+extern "C" int64_t clid_local_window_workspace_bytes(int64_t n) {
+  if (n <= 0) return 1024;
+  return (int64_t)(align256((size_t)n) + 2 * align256((size_t)n * 4) + align256(pool_scan_bytes(n)) + 256);
+}
+
+extern "C" int clid_local_window(const float* neural_points, const int32_t* ts_create, const int32_t* ts_update,
+                                 const float* travel_dist, int64_t n, int32_t cur_ts, int32_t use_mid_ts, int32_t temporal,
+                                 int32_t use_travel_dist, float diff_travel, int32_t diff_ts_local, int32_t reboot_ts,
+                                 int32_t reboot_map, const double* sensor_pos_host, double radius2, int32_t pos_is_f64,
+                                 const float* point_orientations,
+                                 const float* point_certainties, const float* geo_features, int64_t* local_ids_out,
+                                 int64_t* global2local_out, uint8_t* local_mask_out, float* local_points_out,
+                                 float* local_orient_out, float* local_cert_out, int32_t* local_ts_out, float* local_feat_out,
+                                 int64_t* counts_out, void* workspace, void* stream) {
+  if (n < 0 || n >= (1LL << 31) || !sensor_pos_host || !counts_out || !workspace || !global2local_out || !local_mask_out ||
+      !geo_features || !local_feat_out ||
+      (n > 0 && (!neural_points || !ts_create || !ts_update || !point_orientations || !point_certainties || !local_ids_out ||
+                 !local_points_out || !local_orient_out || !local_cert_out || !local_ts_out)) ||
+      (temporal && use_travel_dist && !travel_dist)) {
+    clid_set_error("clid_local_window: bad argument");
+    return CLID_E_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  long long* counts = reinterpret_cast<long long*>(counts_out);
+  if (hipMemsetAsync(counts, 0, 2 * sizeof(long long), s) != hipSuccess) return CLID_E_HIP;
+  char* ws = static_cast<char*>(workspace);
+  unsigned char* bits = reinterpret_cast<unsigned char*>(ws);
+  int* flag = reinterpret_cast<int*>(ws + align256((size_t)n));
+  int* pos = reinterpret_cast<int*>(ws + align256((size_t)n) + align256((size_t)n * 4));
+  void* cub = ws + align256((size_t)n) + 2 * align256((size_t)n * 4);
+  size_t cub_bytes = n > 0 ? pool_scan_bytes(n) : 0;
+  WindowArgs a{neural_points, ts_create, ts_update, travel_dist, n, cur_ts, use_mid_ts, temporal, use_travel_dist,
+               diff_ts_local, reboot_ts, reboot_map, diff_travel, sensor_pos_host[0], sensor_pos_host[1], sensor_pos_host[2],
+               radius2, pos_is_f64};
+  if (n > 0) {
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_window_flags, dim3(blocks), dim3(256), 0, s, a, bits, counts);
+    hipLaunchKernelGGL(k_window_combine, dim3(blocks), dim3(256), 0, s, bits, n, temporal, counts, flag);
+    if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)n, s) != hipSuccess) {
+      clid_set_error("clid_local_window: scan failed");
+      return CLID_E_HIP;
+    }
+  }
+  WindowOut o{reinterpret_cast<long long*>(local_ids_out), reinterpret_cast<long long*>(global2local_out), local_mask_out,
+              local_points_out, local_orient_out, local_cert_out, local_ts_out, local_feat_out, point_orientations,
+              point_certainties, geo_features};
+  hipLaunchKernelGGL(k_window_gather, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s, a, flag, pos, o, counts);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

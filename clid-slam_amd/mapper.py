@@ -508,8 +508,54 @@ class Mapper:
         if getattr(cfg, "prune_map_on", False) and (frame_id + 1) % cfg.prune_freq_frame == 0:
             if nm.prune_map(cfg.max_prune_certainty):
                 nm.recreate_hash(None, None, True, True, frame_id)
+        nm._sensor_pos_host = (origin, tuple(float(v) for v in cur_pose_torch[:3, 3].tolist()))  # spares reset_local_map a read-back
         self.cur_new_point_ratio = nm.update(update_points, origin, orientation, frame_id)
 
+        self.determine_used_pose()
+        fused_pool = (coord.is_cuda and sem_label is None and color_label is None and normal_label is None
+                      and self.sem_label_pool is None and self.color_pool is None and self.normal_label_pool is None
+                      and not self.ba_done_flag and (frame_id + 1) % getattr(cfg, "pool_filter_freq", 1) == 0
+                      and cur_pose_torch.dtype == torch.float64  # the window test is float64 by type promotion (:346-349)
+                      and self.coord_pool.shape[0] + n_cur < (1 << 31) and os.environ.get("CLID_FUSED_POOL", "1") != "0")
+        if fused_pool:
+            self._pool_append_filter_fused(coord, transform_torch(coord, cur_pose_torch), sdf_label, weight, stamp,
+                                           cur_pose_torch, frame_id)
+        else:
+            self._pool_append_filter_torch(coord, sdf_label, weight, stamp, sem_label, color_label, normal_label,
+                                           cur_pose_torch, origin, frame_id, n_cur)
+
+        # newly observed region: samples of this frame whose neighbourhood is still uncertain (:400-462)
+        if cfg.bs_new_sample > 0:
+            cur = self.global_coord_pool[self.global_coord_pool.shape[0] - self.cur_sample_count:]
+            cur_label = self.sdf_label_pool[self.sdf_label_pool.shape[0] - self.cur_sample_count:]
+            certainty = torch.zeros(cur.shape[0], device=cur.device)
+            nm.set_search_neighborhood(num_nei_cells=1, search_alpha=0.0)
+            try:
+                for head in range(0, cur.shape[0], cfg.infer_bs):
+                    certainty[head:head + cfg.infer_bs] = nm.query_certainty(cur[head:head + cfg.infer_bs, :])
+            finally:
+                nm.set_search_neighborhood(num_nei_cells=cfg.num_nei_cells, search_alpha=cfg.search_alpha)
+            self.new_idx = torch.where(
+                (certainty < getattr(cfg, "new_certainty_thre", 1.0)) & (torch.abs(cur_label) < cfg.surface_sample_range_m * 3.0)
+            )[0]
+            self.new_idx += self.pool_sample_count - self.cur_sample_count
+            self.adaptive_iter_offset = 0
+            ratio = self.new_idx.shape[0] / max(self.cur_sample_count, 1)
+            if cfg.adaptive_iters:
+                if ratio < getattr(cfg, "new_sample_ratio_less", 0.02):
+                    self.adaptive_iter_offset = -5
+                elif ratio > getattr(cfg, "new_sample_ratio_more", 0.15):
+                    self.adaptive_iter_offset = 5
+                    if frame_id > cfg.freeze_after_frame and ratio > getattr(cfg, "new_sample_ratio_restart", 0.3):
+                        self.adaptive_iter_offset = 10
+
+    def _pool_append_filter_torch(self, coord, sdf_label, weight, stamp, sem_label, color_label, normal_label,
+                                  cur_pose_torch, origin, frame_id, n_cur):
+        """utils/mapper.py:297-392 as torch ops (configs with semantic / colour / normal pools, a pending pose-graph
+        re-projection, pool_filter_freq > 1, or CPU tensors)."""
+        from .tools import transform_torch
+
+        cfg = self.config
         # pool append (:297-333)
         self.coord_pool = torch.cat((self.coord_pool, coord), 0)
         self.weight_pool = torch.cat((self.weight_pool, weight), 0)
@@ -521,7 +567,6 @@ class Mapper:
             color_label if self.color_pool is None else torch.cat((self.color_pool, color_label), 0))
         self.normal_label_pool = None if normal_label is None else (
             normal_label if self.normal_label_pool is None else torch.cat((self.normal_label_pool, normal_label), 0))
-        self.determine_used_pose()
         if self.ba_done_flag:  # poses of old frames moved: re-project the whole pool (:322-327)
             from .tools import transform_batch_torch
 
@@ -558,30 +603,51 @@ class Mapper:
             self.cur_sample_count = n_cur
             self.pool_sample_count = self.coord_pool.shape[0]
 
-        # newly observed region: samples of this frame whose neighbourhood is still uncertain (:400-462)
-        if cfg.bs_new_sample > 0:
-            cur = self.global_coord_pool[self.global_coord_pool.shape[0] - self.cur_sample_count:]
-            cur_label = self.sdf_label_pool[self.sdf_label_pool.shape[0] - self.cur_sample_count:]
-            certainty = torch.zeros(cur.shape[0], device=cur.device)
-            nm.set_search_neighborhood(num_nei_cells=1, search_alpha=0.0)
-            try:
-                for head in range(0, cur.shape[0], cfg.infer_bs):
-                    certainty[head:head + cfg.infer_bs] = nm.query_certainty(cur[head:head + cfg.infer_bs, :])
-            finally:
-                nm.set_search_neighborhood(num_nei_cells=cfg.num_nei_cells, search_alpha=cfg.search_alpha)
-            self.new_idx = torch.where(
-                (certainty < getattr(cfg, "new_certainty_thre", 1.0)) & (torch.abs(cur_label) < cfg.surface_sample_range_m * 3.0)
-            )[0]
-            self.new_idx += self.pool_sample_count - self.cur_sample_count
-            self.adaptive_iter_offset = 0
-            ratio = self.new_idx.shape[0] / max(self.cur_sample_count, 1)
-            if cfg.adaptive_iters:
-                if ratio < getattr(cfg, "new_sample_ratio_less", 0.02):
-                    self.adaptive_iter_offset = -5
-                elif ratio > getattr(cfg, "new_sample_ratio_more", 0.15):
-                    self.adaptive_iter_offset = 5
-                    if frame_id > cfg.freeze_after_frame and ratio > getattr(cfg, "new_sample_ratio_restart", 0.3):
-                        self.adaptive_iter_offset = 10
+
+    def _pool_append_filter_fused(self, coord, gcoord, sdf_label, weight, stamp, cur_pose_torch, frame_id):
+        """utils/mapper.py:297-392 in one enqueue (csrc/mapops.hip clid_pool_filter): append this frame's samples, window
+        test in float64, random drop above `pool_capacity`, stable compaction of the five arrays into the other half of a
+        ping-pong buffer; ONE small read-back for the two counts the host needs (pool size for the batch draws, number
+        of this frame's samples that stayed)."""
+        lib = _lib.load()
+        cfg = self.config
+        dev = coord.device
+        n_a, n_b = int(self.coord_pool.shape[0]), int(coord.shape[0])
+        n = n_a + n_b
+        bufs = getattr(self, "_pool_bufs", None)
+        if bufs is None or any(bf is not None and bf["coord"].device != dev for bf in bufs):
+            bufs = self._pool_bufs = [None, None]
+            self._pool_side = 0
+        side = 1 - self._pool_side
+        cap_rows = max(n, min(int(cfg.pool_capacity) + 2 * n_b, 2 * n) + 1024)
+        if bufs[side] is None or bufs[side]["coord"].shape[0] < n:
+            bufs[side] = {"coord": torch.empty((cap_rows, 3), device=dev), "gcoord": torch.empty((cap_rows, 3), device=dev),
+                          "label": torch.empty(cap_rows, device=dev), "weight": torch.empty(cap_rows, device=dev),
+                          "time": torch.empty(cap_rows, device=dev, dtype=torch.int32)}
+        out = bufs[side]
+        need = int(lib.clid_pool_workspace_bytes(n))
+        if getattr(self, "_pool_ws", None) is None or self._pool_ws.numel() < need or self._pool_ws.device != dev:
+            self._pool_ws = torch.empty(int(need * 1.2) + 256, device=dev, dtype=torch.uint8)
+            self._pool_counts = torch.zeros(3, device=dev, dtype=torch.int64)
+        a = [_lib.require_cuda(t, nme, dt) for t, nme, dt in (
+            (self.coord_pool, "coord_pool", torch.float32), (self.global_coord_pool, "global_coord_pool", torch.float32),
+            (self.sdf_label_pool, "sdf_label_pool", torch.float32), (self.weight_pool, "weight_pool", torch.float32),
+            (self.time_pool, "time_pool", torch.int32))]
+        b = [t.contiguous() for t in (coord.float(), gcoord.float(), sdf_label.float(), weight.float(), stamp.to(torch.int32))]
+        origin = (C.c_double * 3)(*[float(v) for v in cur_pose_torch[:3, 3].tolist()])  # the pose is already on the host
+        self._pool_drop_seed = (getattr(self, "_pool_drop_seed", int(getattr(cfg, "seed", 42)) * 7919) * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        _lib.check(lib.clid_pool_filter(
+            a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), a[4].data_ptr(), n_a,
+            b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), b[3].data_ptr(), b[4].data_ptr(), n_b,
+            origin, float(cfg.window_radius) ** 2, int(cfg.pool_capacity), self._pool_drop_seed,
+            out["coord"].data_ptr(), out["gcoord"].data_ptr(), out["label"].data_ptr(), out["weight"].data_ptr(),
+            out["time"].data_ptr(), self._pool_counts.data_ptr(), self._pool_ws.data_ptr(), _lib.stream()), "clid_pool_filter")
+        kept, kept_cur = self._pool_counts[:2].tolist()  # the one host round trip of the pool maintenance
+        self._pool_side = side
+        self.coord_pool, self.global_coord_pool = out["coord"][:kept], out["gcoord"][:kept]
+        self.sdf_label_pool, self.weight_pool, self.time_pool = out["label"][:kept], out["weight"][:kept], out["time"][:kept]
+        self.cur_sample_count = int(kept_cur)
+        self.pool_sample_count = int(kept)
 
     def bundle_adjustment(self, iter_count, window_size: int = 50, use_lie_group: bool = False):
         """utils/mapper.py:866-965 (needs pypose; ba_freq_frame = 0 in every shipped config)."""

@@ -168,6 +168,8 @@ class NeuralPoints(nn.Module):
         st = dict(st)
         st["_tables"] = {}
         st.pop("_replica_gens", None)  # torch.Generator objects do not pickle
+        for k in ("_sensor_pos_host", "_win_ws", "_win_counts"):
+            st.pop(k, None)
         return st
 
     # ------------------------------------------------------------------ search region
@@ -242,6 +244,8 @@ class NeuralPoints(nn.Module):
         (model/neural_points.py:439-536)."""
         self.cur_ts = cur_ts
         self.max_ts = max(self.max_ts, cur_ts)
+        if self._reset_local_map_fused(sensor_position, sensor_orientation, cur_ts, use_travel_dist, diff_ts_local, reboot_map):
+            return
         if self.temporal_local_map_on:
             if self.config.use_mid_ts:
                 ts_used = ((self.point_ts_create + self.point_ts_update) / 2).int()
@@ -281,6 +285,55 @@ class NeuralPoints(nn.Module):
         self.local_orientation = sensor_orientation
         self._local_ids = local_ids.contiguous()
         self._map_version += 1
+
+    def _reset_local_map_fused(self, sensor_position, sensor_orientation, cur_ts, use_travel_dist, diff_ts_local, reboot_map):
+        """The window selection and the gathers of reset_local_map in one enqueue (csrc/mapops.hip clid_local_window) with
+        ONE count read back; False = not applicable here (CPU tensors, colour features), the torch path runs."""
+        pts = self.neural_points
+        if not (pts.is_cuda and self.color_features is None and pts.dtype == torch.float32 and self.count() > 0
+                and self.geo_features.shape[1] == _lib.F and self.point_ts_create.dtype == torch.int32):
+            return False
+        lib = _lib.load()
+        dev, n = pts.device, int(self.count())
+        hint = getattr(self, "_sensor_pos_host", None)  # (tensor, host tuple) left by Mapper.process_frame: no read-back
+        if hint is not None and hint[0] is sensor_position:
+            sp = hint[1]
+        else:
+            sp = [float(v) for v in sensor_position.detach().reshape(-1)[:3].tolist()]
+        f64 = int(sensor_position.dtype == torch.float64)
+        temporal = int(bool(self.temporal_local_map_on))
+        travel = self.travel_dist.to(torch.float32).contiguous() if (temporal and use_travel_dist) else None
+        need = int(lib.clid_local_window_workspace_bytes(n))
+        if getattr(self, "_win_ws", None) is None or self._win_ws.numel() < need or self._win_ws.device != dev:
+            self._win_ws = torch.empty(int(need * 1.3) + 1024, device=dev, dtype=torch.uint8)
+            self._win_counts = torch.zeros(2, device=dev, dtype=torch.int64)
+        ids = torch.empty(n, device=dev, dtype=torch.int64)
+        g2l = torch.empty(n + 1, device=dev, dtype=torch.int64)
+        mask = torch.empty(n + 1, device=dev, dtype=torch.bool)
+        l_pts = torch.empty((n, 3), device=dev, dtype=torch.float32)
+        l_ori = torch.empty((n, 4), device=dev, dtype=torch.float32)
+        l_cert = torch.empty(n, device=dev, dtype=torch.float32)
+        l_ts = torch.empty(n, device=dev, dtype=torch.int32)
+        l_feat = torch.empty((n + 1, _lib.F), device=dev, dtype=torch.float32)
+        for name in ("point_orientations", "point_certainties", "geo_features", "point_ts_update", "point_ts_create"):
+            _lib.require_cuda(getattr(self, name), name)
+        _lib.check(lib.clid_local_window(
+            pts.contiguous().data_ptr(), self.point_ts_create.data_ptr(), self.point_ts_update.data_ptr(), _lib.ptr(travel), n,
+            int(cur_ts), int(bool(self.config.use_mid_ts)), temporal, int(bool(use_travel_dist)), float(self.diff_travel_dist_local),
+            int(diff_ts_local), int(self.reboot_ts), int(bool(reboot_map)), (C.c_double * 3)(*sp), float(self.local_map_radius) ** 2, f64,
+            self.point_orientations.data_ptr(), self.point_certainties.data_ptr(), self.geo_features.data_ptr(),
+            ids.data_ptr(), g2l.data_ptr(), mask.data_ptr(), l_pts.data_ptr(), l_ori.data_ptr(), l_cert.data_ptr(),
+            l_ts.data_ptr(), l_feat.data_ptr(), self._win_counts.data_ptr(), self._win_ws.data_ptr(), _lib.stream()), "clid_local_window")
+        m = int(self._win_counts[1].item())  # the one host round trip: sizes the local arrays
+        self.local_neural_points, self.local_point_orientations = l_pts[:m], l_ori[:m]
+        self.local_point_certainties, self.local_point_ts_update = l_cert[:m], l_ts[:m]
+        self.local_mask, self.global2local = mask, g2l
+        self.local_geo_features = nn.Parameter(l_feat[:m + 1])
+        self._local_ids = ids[:m]
+        self._local_ids_pad = None
+        self.local_orientation = sensor_orientation
+        self._map_version += 1
+        return True
 
     def assign_local_to_global(self):
         """model/neural_points.py:538-549."""

@@ -338,6 +338,38 @@ int64_t clid_voxel_workspace_bytes(int32_t n);
 int clid_voxel_down_sample(const float* points, int32_t n, float voxel_size, void* workspace, int64_t* idx_out,
                            void* stream);
 
+/* Training-pool maintenance of Mapper.process_frame (utils/mapper.py:297-392) in one enqueue: the pool `a` (n_a samples)
+ * followed by this frame's samples `b` (n_b) -- coord / global_coord [.,3] f32, sdf label, weight f32, time i32 -- are
+ * filtered by ||global_coord - origin||^2 < radius2 (float64, like the reference under type promotion), when more than
+ * `capacity` survive `kept - capacity` uniform picks with replacement are dropped (:352-361; generator = splitmix64 of
+ * `seed`), and the survivors are compacted IN ORDER into the *_out arrays (capacity n_a + n_b rows; must not alias the
+ * inputs).  counts_out [3] int64 (device): samples kept, how many of them come from `b`, scratch.  Nothing synchronises:
+ * the caller reads counts_out when it needs the sizes.  workspace: clid_pool_workspace_bytes(n_a + n_b). */
+int64_t clid_pool_workspace_bytes(int64_t n_total);
+int clid_pool_filter(const float* coord_a, const float* gcoord_a, const float* label_a, const float* weight_a,
+                     const int32_t* time_a, int64_t n_a, const float* coord_b, const float* gcoord_b, const float* label_b,
+                     const float* weight_b, const int32_t* time_b, int64_t n_b, const double* origin_host, double radius2,
+                     int64_t capacity, uint64_t seed, float* coord_out, float* gcoord_out, float* label_out,
+                     float* weight_out, int32_t* time_out, int64_t* counts_out, void* workspace, void* stream);
+
+/* NeuralPoints.reset_local_map (model/neural_points.py:439-536): the local window = points whose creation (or mid)
+ * stamp lies within `diff_travel` of travelled distance (or `diff_ts_local` frames) of cur_ts -- dropped when it holds
+ * fewer than 100 points, restricted to stamps >= reboot_ts when reboot_map -- AND within sqrt(radius2) of the sensor
+ * (pos_is_f64: the caller's sensor position tensor is float64, so the reference's test runs in float64).
+ * Outputs (capacity n rows, n + 1 where noted): local_ids [n] int64 ascending global indices, global2local [n + 1] int64
+ * (-1 outside, the padding element -1), local_mask [n + 1] bool (padding element true), and the gathered local arrays
+ * (points [.,3], orientations [.,4], certainties, update stamps, features [(m + 1), F] with the global padding row last).
+ * counts_out [2] int64 (device): points inside the time window, m = local points.  Nothing synchronises. */
+int64_t clid_local_window_workspace_bytes(int64_t n);
+int clid_local_window(const float* neural_points, const int32_t* ts_create, const int32_t* ts_update, const float* travel_dist,
+                      int64_t n, int32_t cur_ts, int32_t use_mid_ts, int32_t temporal, int32_t use_travel_dist,
+                      float diff_travel, int32_t diff_ts_local, int32_t reboot_ts, int32_t reboot_map,
+                      const double* sensor_pos_host, double radius2, int32_t pos_is_f64, const float* point_orientations,
+                      const float* point_certainties, const float* geo_features, int64_t* local_ids_out,
+                      int64_t* global2local_out, uint8_t* local_mask_out, float* local_points_out, float* local_orient_out,
+                      float* local_cert_out, int32_t* local_ts_out, float* local_feat_out, int64_t* counts_out,
+                      void* workspace, void* stream);
+
 /* NeuralPoints.assign_local_to_global (model/neural_points.py:538-549) in one launch: local features (n + 1 rows of
  * F, the last one the padding row -> global row pad_row), certainties and update stamps back to the global arrays
  * at ids [n] int64 (= nonzero(local_mask[:-1]), ascending). */
