@@ -78,3 +78,19 @@ def normal_equations(neural_points, geo_decoder, config, rot, pos, pc_imu):
     b = torch.zeros(18, device=x.device, dtype=torch.float64)
     b[:6] = ne[21:27]
     return S, b, int(ne[27].item())
+
+
+class IEKFOMMeasurement:
+    """`IEKFOM.h_model` with the reference's METHOD signature (utils/error_state_iekf.py:176): a mixin / patch for the
+    reference's filter class, which keeps everything else (predict, boxplus, covariance algebra: host-side 18 x 18 math,
+    out of scope).  It reads what the reference method reads of `self` -- `neural_points`, `geo_decoder`, `config`,
+    `x.rot`, `x.pos` -- stores `self.R_inv` and returns `(sdf_residual, H, valid_points)`:
+
+        from utils.error_state_iekf import IEKFOM
+        IEKFOM.h_model = clid_slam_amd.tracking.IEKFOMMeasurement.h_model          # update_iterated() stays unchanged
+    """
+
+    def h_model(self, pc_imu: torch.Tensor):
+        z, H, valid_points, r_inv = h_model(self.neural_points, self.geo_decoder, self.config, self.x.rot, self.x.pos, pc_imu)
+        self.R_inv = r_inv
+        return z, H, valid_points

@@ -565,6 +565,29 @@ def test_tracking_measurement_model_g8(env, ln):
     assert float(S[6:, :].abs().max()) == 0.0 and float(S[:, 6:].abs().max()) == 0.0
 
 
+def test_iekfom_h_model_method_form_g8(env):
+    """Row N1 through the METHOD form a maintainer patches onto the reference's IEKFOM (same attributes read of `self`,
+    `self.R_inv` stored, 3-tuple returned) against the reference's own h_model output (G8)."""
+    from clid_slam_amd.tracking import IEKFOMMeasurement
+
+    g = gio.load("g8_tracking.npz")
+    cfg = env.config(layer_norm_on=False)
+    cfg.reg_min_grad_norm, cfg.reg_max_grad_norm = float(g["grad_window"][0]), float(g["grad_window"][1])
+
+    class State:
+        rot, pos = gio.T(g["rot"]), gio.T(g["pos"])
+
+    class Filter(IEKFOMMeasurement):
+        pass
+
+    f = Filter()
+    f.config, f.neural_points, f.geo_decoder, f.x, f.R_inv = cfg, env.neural_points(cfg), env.decoder(cfg), State(), None
+    z, H, pts = f.h_model(gio.T(g["pc_imu"]).cuda())
+    assert H.shape[1] == 18 and pts.shape[1] == 3 and f.R_inv is not None and f.R_inv.shape == z.shape
+    assert z.shape[0] == g["z_ln0"].shape[0]
+    assert maxerr(z, g["z_ln0"]) <= 2e-6 and maxerr(f.R_inv, g["R_inv_ln0"]) <= 2e-2 and maxerr(H[:, :6], g["H6_ln0"]) <= 5e-5
+
+
 @pytest.mark.parametrize("ln,loc", [(0, 0), (1, 0), (0, 1)])
 def test_dense_sdf_query_vs_oracle(env, ln, loc):
     """Row N3: the fused dense query (global map, no time filter) against the oracle's
