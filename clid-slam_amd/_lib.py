@@ -123,10 +123,6 @@ _SIGS = {
     "clid_comm_destroy": (C.c_int, [_vp]),
     "clid_mapping_run_dist": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), C.POINTER(AdamArgs), _i32, _vp, _i64, _vp,
                                         _vp, _i64, _vp]),
-    "clid_mapping_fused_floats": (_i64, [_i64]),
-    "clid_mapping_fused_supported": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs)]),
-    "clid_mapping_run_fused": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), C.POINTER(AdamArgs), _i32, _vp, _i64, _vp, _vp, _i64,
-                                         _vp, _vp]),
     "clid_mapping_pipeline": (C.c_int, [C.c_int]),
     "clid_decode_variant": (C.c_int, [C.c_int]),
     "clid_debug_decode_sdf_out": (C.c_int, [_vp]),

@@ -540,6 +540,17 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
 // torch.optim.Adam._single_tensor_adam, op order as ATen's:
 //   m.lerp_(g, 1-b1); v.mul_(b2).addcmul_(g, g, 1-b2); denom = sqrt(v)/sqrt(bc2) + eps;
 //   p.addcdiv_(m, denom, -lr/bc1)
+struct AdamK {
+  float one_m_b1, b2, one_m_b2, bc2_sqrt, eps, neg_step, wd;
+};
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, const AdamK& k, float wd) {
+  if (wd != 0.f) g = fmaf(wd, p, g);
+  m = fadd(m, fmul(k.one_m_b1, fsub(g, m)));
+  v = fadd(fmul(v, k.b2), fmul(fmul(k.one_m_b2, g), g));
+  const float denom = fadd(fdiv(sqrtf(v), k.bc2_sqrt), k.eps);
+  p = fadd(p, fdiv(fmul(k.neg_step, m), denom));
+}
+
 __device__ __forceinline__ float* mlp_param_ptr(float* W1, float* b1, float* W2, float* b2, int i) {
   if (i < CLID_H * CLID_D) return W1 + i;
   if (i < CLID_H * CLID_D + CLID_H) return b1 + (i - CLID_H * CLID_D);
@@ -857,6 +868,20 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
   return CLID_OK;
 }
 
+static AdamK adam_scalars(float lr, float b1, float b2, float eps, float wd, int step) {
+  const double bc1 = 1.0 - pow((double)b1, (double)step);
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  AdamK k;
+  k.one_m_b1 = (float)(1.0 - (double)b1);
+  k.b2 = b2;
+  k.one_m_b2 = (float)(1.0 - (double)b2);
+  k.bc2_sqrt = (float)sqrt(bc2);
+  k.eps = eps;
+  k.neg_step = (float)(-((double)lr / bc1));
+  k.wd = wd;
+  return k;
+}
+
 extern "C" int clid_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1,
                               float beta2, float eps, float weight_decay, int32_t step, int32_t zero_grad,
                               void* stream) {
@@ -1103,150 +1128,11 @@ static int mapping_run_hoisted(const clid_map_view* mv, clid_train_args& ta, cli
   return CLID_OK;
 }
 
-struct clid_comm;
-extern "C" int clid_comm_allreduce(clid_comm* comm, void* buf, int64_t count, int32_t is_int32, int32_t op_max, void* stream);
-
-// ---- the one-launch-per-iteration loop (Adam on read, train_common.hpp) --------------------------------------------
-static size_t pad16(size_t n) { return (n + 15) & ~size_t(15); }
-extern "C" int64_t clid_mapping_fused_floats(int64_t n_feat) {
-  if (n_feat <= 0 || (n_feat % CLID_F) != 0) return -1;
-  const size_t rows = (size_t)n_feat / CLID_F;
-  return (int64_t)(3 * pad16(kGHead + rows * CLID_GRAD_ROW16) + 5 * pad16((size_t)n_feat) + 6 * pad16(kGHeadStride));
-}
-static bool fused_enabled() {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("CLID_FUSED_ADAM");
-    on = (e && e[0] == '0') ? 0 : 1;
-  }
-  return on != 0;
-}
-// the redundant Adam-on-read work grows with the batch (6 rows per query) while the launch it replaces does not: the
-// one-launch form is used where the loop is latency-bound (<= 4096 tiles, i.e. batches up to ~40 k samples)
-static bool fused_applicable(const clid_map_view* mv, const clid_train_args* a) {
-  if (!fused_enabled() || decode_variant_for(mv, a) == 0 || pipeline_mode() != 1) return false;
-  int n_fd, first;
-  n_queries(a, &n_fd, &first);
-  return (make_task_map(a->bs, n_fd, first, a->decimation).n_tasks + 1) / 2 <= 4096;
-}
-extern "C" int clid_mapping_fused_supported(const clid_map_view* mv, const clid_train_args* t) {
-  return (mv && t) ? (fused_applicable(mv, t) ? 1 : 0) : CLID_E_ARG;
-}
-
-static int mapping_run_fused(const clid_map_view* mv, clid_train_args& ta, const clid_adam_args& aa, int iters,
-                             const int64_t* index_base, int64_t index_stride, float* loss_base, float* fws, clid_comm* comm,
-                             void* stream) {
-  hipStream_t s = (hipStream_t)stream;
-  const size_t n_feat = (size_t)aa.n_feat, rows = n_feat / CLID_F;
-  const size_t gsz = pad16(kGHead + rows * CLID_GRAD_ROW16), fsz = pad16(n_feat), wsz = pad16(kGHeadStride);
-  float* G[3] = {fws, fws + gsz, fws + 2 * gsz};
-  float* th_alt = fws + 3 * gsz;
-  float* M[2] = {th_alt + fsz, th_alt + 2 * fsz};
-  float* V[2] = {th_alt + 3 * fsz, th_alt + 4 * fsz};
-  float* wbase = th_alt + 5 * fsz;
-  float* Wd[2] = {wbase, wbase + wsz};
-  float* MW[2] = {wbase + 2 * wsz, wbase + 3 * wsz};
-  float* VW[2] = {wbase + 4 * wsz, wbase + 5 * wsz};
-  const bool train = aa.train_decoder != 0;
-  // the caller zeroed `fws`; the second halves of the ping-pong pairs start as copies of the parameters
-  bool ok = hipMemcpyAsync(th_alt, aa.feat, n_feat * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess;
-  if (train) {
-    ok = ok && hipMemcpyAsync(Wd[0], aa.W1, CLID_H * CLID_D * 4, hipMemcpyDeviceToDevice, s) == hipSuccess;
-    ok = ok && hipMemcpyAsync(Wd[0] + CLID_H * CLID_D, aa.b1, CLID_H * 4, hipMemcpyDeviceToDevice, s) == hipSuccess;
-    ok = ok && hipMemcpyAsync(Wd[0] + CLID_H * CLID_D + CLID_H, aa.W2, CLID_H * 4, hipMemcpyDeviceToDevice, s) == hipSuccess;
-    ok = ok && hipMemcpyAsync(Wd[0] + CLID_MLP_PARAMS - 1, aa.b2, 4, hipMemcpyDeviceToDevice, s) == hipSuccess;
-  }
-  if (!ok) {
-    clid_set_error("clid_mapping_run: fused-loop set-up copies failed");
-    return CLID_E_HIP;
-  }
-  int n_fd, first;
-  const int Q = n_queries(&ta, &n_fd, &first);
-  TrainWs ws = carve(ta.ws, Q);
-  const TaskMap tmap = make_task_map(ta.bs, n_fd, first, ta.decimation);
-  const size_t per_iter = (size_t)clid_train_search_floats(ta.bs, ta.batch_offset, ta.decimation, ta.eikonal_mode, 1);
-  long long chunk = (long long)(rec_buffer_floats(Q) / per_iter);
-  if (chunk < 1) {
-    clid_set_error("clid_mapping_run: the task records exceed the workspace bound");
-    return CLID_E_SHAPE;
-  }
-  if (chunk > kMaxChunkIters) chunk = kMaxChunkIters;
-  const int variant = decode_variant_for(mv, &ta);
-  const float weight_e = (ta.eikonal_mode == 1 && n_fd > 0) ? ta.weight_e : 0.f;
-  auto make_iter = [&](int it) {
-    FusedIter fi{};
-    const int p = it & 1;
-    fi.th_old = p ? th_alt : aa.feat;
-    fi.th_new = p ? aa.feat : th_alt;
-    fi.m_old = M[p]; fi.m_new = M[1 - p];
-    fi.v_old = V[p]; fi.v_new = V[1 - p];
-    fi.g_prev = G[(it + 2) % 3]; fi.g_cur = G[it % 3]; fi.g_next = G[(it + 1) % 3];
-    fi.wd_old = Wd[p]; fi.wd_new = Wd[1 - p];
-    fi.mw_old = MW[p]; fi.mw_new = MW[1 - p];
-    fi.vw_old = VW[p]; fi.vw_new = VW[1 - p];
-    fi.cert = aa.cert; fi.n_cert = aa.cert ? aa.n_cert : 0;
-    fi.n_feat = (long long)n_feat;
-    fi.loss_prev = it > 0 ? loss_base + (size_t)(it - 1) * 4 : nullptr;
-    fi.inv_n_main = ta.inv_n_main; fi.inv_n_eik = ta.inv_n_eik; fi.weight_e = weight_e;
-    fi.step = it;
-    fi.k = adam_scalars(aa.lr, aa.beta1, aa.beta2, aa.eps, aa.weight_decay, it);
-    return fi;
-  };
-  for (int it = 0; it < iters; ++it) {
-    ta.index = index_base + (int64_t)it * index_stride;
-    if (it % chunk == 0) {
-      const int n_it = (iters - it) < chunk ? (iters - it) : (int)chunk;
-      if (int e = clid_train_search(mv, &ta, n_it, ta.index, index_stride, ws.rec, stream)) return e;
-    }
-    const FusedIter fi = make_iter(it);
-    const int h = prof_begin(0, s);
-    if (int e = clid_launch_decode_tile(mv, &ta, nullptr, tmap, ws.rec + (size_t)(it % chunk) * per_iter, variant == 2 ? 1 : 0, s, &fi))
-      return e;
-    prof_end(h, s);
-    if (comm)
-      if (int e = clid_comm_allreduce(comm, fi.g_cur, (int64_t)(kGHead + rows * CLID_GRAD_ROW16), 0, 0, stream)) return e;
-  }
-  if (iters > 0) {
-    FusedIter fi = make_iter(iters);
-    fi.th_new = aa.feat;  // the final update lands in the caller's array (in place when it is already the current half)
-    fi.g_next = nullptr;
-    const int h = prof_begin(3, s);
-    if (int e = clid_launch_fused_final(&fi, aa.W1, aa.b1, aa.W2, aa.b2, train ? 1 : 0, s)) return e;
-    prof_end(h, s);
-  }
-  return CLID_OK;
-}
-
 // The whole single-GPU loop of Mapper.mapping (utils/mapper.py:642-860) enqueued by ONE host call:
 // mode 1 (default) = the neighbour searches hoisted into one launch per chunk of iterations, then per
 // iteration the decode/backward kernel and the reduce+Adam kernel; mode 0 = per iteration the fused
 // search+decode kernel and the reduce+Adam kernel (CLID_PIPELINE / clid_mapping_pipeline select; the results
 // are identical up to the order of the atomic accumulations).
-extern "C" int clid_mapping_run_fused(const clid_map_view* mv, const clid_train_args* t, const clid_adam_args* a, int32_t iters,
-                                      const int64_t* index_base, int64_t index_stride, float* loss_base, float* fused_ws,
-                                      int64_t fused_ws_floats, clid_comm* comm, void* stream) {
-  if (!mv || !t || !a || iters < 0 || !index_base || !loss_base || !fused_ws) {
-    clid_set_error("clid_mapping_run_fused: bad argument");
-    return CLID_E_ARG;
-  }
-  if (!fused_applicable(mv, t)) {
-    clid_set_error("clid_mapping_run_fused: not applicable to these arguments (see clid_mapping_fused_supported)");
-    return CLID_E_ARG;
-  }
-  if (fused_ws_floats < clid_mapping_fused_floats(a->n_feat) || ((uintptr_t)fused_ws & 63) != 0) {
-    clid_set_error("clid_mapping_run_fused: workspace too small or not 64-byte aligned");
-    return CLID_E_ARG;
-  }
-  clid_train_args ta = *t;
-  ta.defer_reduce = 1;
-  int e = mapping_run_fused(mv, ta, *a, iters, index_base, index_stride, loss_base, fused_ws, comm, stream);
-  if (!e && comm && iters > 0) {
-    e = clid_comm_allreduce(comm, loss_base, (int64_t)iters * 4, 0, 0, stream);
-    if (!e && mv->ts_update && mv->M > 0) e = clid_comm_allreduce(comm, mv->ts_update, mv->M, 1, 1, stream);
-  }
-  return e;
-}
-
 extern "C" int clid_mapping_run(const clid_map_view* mv, const clid_train_args* t, const clid_adam_args* a,
                                 int32_t iters, const int64_t* index_base, int64_t index_stride,
                                 float* loss_base, void* stream) {
@@ -1274,6 +1160,9 @@ extern "C" int clid_mapping_run(const clid_map_view* mv, const clid_train_args* 
 // [decoder | accumulation rows] ON THE LAUNCH STREAM -> the identical Adam step on every replica.  `index_base` points at
 // this rank's slice of iteration 0 (row stride index_stride); t->batch_offset / inv_n_* carry the global lattice phase
 // and normalisers.  After the loop the per-iteration losses (SUM) and the update stamps (MAX) are merged once.
+struct clid_comm;
+extern "C" int clid_comm_allreduce(clid_comm* comm, void* buf, int64_t count, int32_t is_int32, int32_t op_max, void* stream);
+
 extern "C" int clid_mapping_run_dist(const clid_map_view* mv, const clid_train_args* t, const clid_adam_args* a,
                                      int32_t iters, const int64_t* index_base, int64_t index_stride, float* loss_base,
                                      clid_comm* comm, int64_t grad_floats, void* stream) {

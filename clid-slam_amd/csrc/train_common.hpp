@@ -228,162 +228,6 @@ __device__ __forceinline__ void mlp_backward(const MlpLds& s, const float (&f)[C
 
 }  // namespace clid
 
-// ---- Adam (torch.optim.Adam._single_tensor_adam; ATen's op order) ----------------------------------
-//   m.lerp_(g, 1-b1); v.mul_(b2).addcmul_(g, g, 1-b2); denom = sqrt(v)/sqrt(bc2) + eps; p.addcdiv_(m, denom, -lr/bc1)
-namespace clid {
-struct AdamK {
-  float one_m_b1, b2, one_m_b2, bc2_sqrt, eps, neg_step, wd;
-};
-__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, const AdamK& k, float wd) {
-  if (wd != 0.f) g = fmaf(wd, p, g);
-  m = fadd(m, fmul(k.one_m_b1, fsub(g, m)));
-  v = fadd(fmul(v, k.b2), fmul(fmul(k.one_m_b2, g), g));
-  const float denom = fadd(fdiv(sqrtf(v), k.bc2_sqrt), k.eps);
-  p = fadd(p, fdiv(fmul(k.neg_step, m), denom));
-}
-__host__ inline AdamK adam_scalars(float lr, float b1, float b2, float eps, float wd, int step) {
-  AdamK k;
-  k.one_m_b1 = (float)(1.0 - (double)b1);
-  k.b2 = b2;
-  k.one_m_b2 = (float)(1.0 - (double)b2);
-  k.eps = eps;
-  k.wd = wd;
-  if (step < 1) {  // "step 0": nothing to apply yet (the fused loop's first launch)
-    k.bc2_sqrt = 1.f;
-    k.neg_step = 0.f;
-    return k;
-  }
-  const double bc1 = 1.0 - pow((double)b1, (double)step);
-  const double bc2 = 1.0 - pow((double)b2, (double)step);
-  k.bc2_sqrt = (float)sqrt(bc2);
-  k.neg_step = (float)(-((double)lr / bc1));
-  return k;
-}
-
-// ---- the one-launch iteration (k_decode_tile<.., FUSED>): Adam applied ON READ ------------------------------------
-// Iteration t's launch needs theta_t = Adam(theta_{t-1}, g_{t-1}).  Instead of a separate Adam launch between two
-// decode launches (a 5 us kernel + a 3.4 us boundary at the ncd128 batch size), the tile waves apply the pending update to
-// the few rows they gather, from read-only copies of (theta, m, v, g) of the previous iteration, while extra blocks of the
-// SAME launch sweep all rows and write (theta, m, v) of this iteration into the other half of a ping-pong pair.  Nothing
-// inside the launch depends on anything written by it, so no grid-wide synchronisation is needed; the kernel boundary to
-// the next iteration is the only barrier.  Gradients rotate over three accumulation buffers: read g_{t-1}, accumulate
-// g_t, zero the buffer of g_{t+1}.  Decoder gradients and the two loss sums are added by atomics into 8 copies of an
-// 848-float head of the accumulation buffer (same-line contention: tools/ubench_atomic.hip), summed by the reader.
-constexpr int kGHeadCopies = 8;
-constexpr int kGHeadStride = 848;                       // 833 decoder gradients | bce | eik | pad, 64-byte aligned
-constexpr int kGHead = kGHeadCopies * kGHeadStride;     // floats in front of the accumulation rows
-struct FusedIter {
-  const float* th_old; float* th_new;                   // features [(M+1)*F]
-  const float* m_old; float* m_new;
-  const float* v_old; float* v_new;
-  const float* g_prev; float* g_cur; float* g_next;     // accumulation buffers [kGHead + (M+1)*16]
-  const float* wd_old; float* wd_new;                   // decoder W1|b1|W2|b2 flat [848] (trainable decoder only)
-  const float* mw_old; float* mw_new;
-  const float* vw_old; float* vw_new;
-  float* cert; int n_cert;                              // local_point_certainties: += column 8 of g_prev
-  long long n_feat;
-  float* loss_prev;                                     // [4] loss row of the previous iteration (NULL at the first)
-  float inv_n_main, inv_n_eik, weight_e;
-  int step;                                             // Adam step applied on read (0 = none)
-  int n_tile_blocks;                                    // blocks [0, n_tile_blocks) run tiles, the rest sweep rows
-  AdamK k;
-};
-
-// theta_t of one float4 of a feature row from the previous iteration's state (identical arithmetic for the readers and
-// for the sweep, so what a tile wave uses is bit for bit what the sweep stores)
-__device__ __forceinline__ float4 adam_on_read4(const FusedIter& fi, long long i4, float4* m_out = nullptr, float4* v_out = nullptr,
-                                                bool* idle_out = nullptr) {
-  float4 P = *reinterpret_cast<const float4*>(fi.th_old + i4);
-  bool idle = true;
-  if (fi.step > 0) {
-    const long long row = i4 >> 3;
-    const float4 G = *reinterpret_cast<const float4*>(fi.g_prev + kGHead + row * CLID_GRAD_ROW16 + (i4 & 7));
-    float4 M = *reinterpret_cast<const float4*>(fi.m_old + i4), V = *reinterpret_cast<const float4*>(fi.v_old + i4);
-    idle = fi.k.wd == 0.f && G.x == 0.f && G.y == 0.f && G.z == 0.f && G.w == 0.f && M.x == 0.f && M.y == 0.f && M.z == 0.f &&
-           M.w == 0.f && V.x == 0.f && V.y == 0.f && V.z == 0.f && V.w == 0.f;
-    if (!idle) {
-      adam_update(P.x, G.x, M.x, V.x, fi.k, fi.k.wd);
-      adam_update(P.y, G.y, M.y, V.y, fi.k, fi.k.wd);
-      adam_update(P.z, G.z, M.z, V.z, fi.k, fi.k.wd);
-      adam_update(P.w, G.w, M.w, V.w, fi.k, fi.k.wd);
-    }
-    if (m_out) *m_out = M;
-    if (v_out) *v_out = V;
-  }
-  if (idle_out) *idle_out = idle;
-  return P;
-}
-__device__ __forceinline__ float adam_on_read1(const FusedIter& fi, long long i) {
-  float P = fi.th_old[i];
-  if (fi.step > 0) {
-    const float G = fi.g_prev[kGHead + (i >> 3) * CLID_GRAD_ROW16 + (i & 7)];
-    float M = fi.m_old[i], V = fi.v_old[i];
-    if (!(fi.k.wd == 0.f && G == 0.f && M == 0.f && V == 0.f)) adam_update(P, G, M, V, fi.k, fi.k.wd);
-  }
-  return P;
-}
-// the sweep over the feature rows: thread t owns float4 number t.  Writes theta / m / v of this iteration (rows idle since
-// the call began are identical in both halves of the ping-pong pair and are left alone), merges the certainty column of
-// g_prev (np.py:714) and zeroes the row of g_next.
-__device__ __forceinline__ void adam_sweep_thread(const FusedIter& fi, long long t4, bool write_state, bool zero_next) {
-  const long long i4 = t4 * 4;
-  if (i4 >= fi.n_feat) return;
-  const long long row = i4 >> 3;
-  const bool second = (i4 & 7) == 4;
-  if (zero_next && fi.g_next) {
-    float* z = fi.g_next + kGHead + row * CLID_GRAD_ROW16 + (i4 & 7);
-    *reinterpret_cast<float4*>(z) = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (second) {
-      *reinterpret_cast<float4*>(z + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(z + 8) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  if (fi.step <= 0) return;
-  float4 M, V;
-  bool idle;
-  const float4 P = adam_on_read4(fi, i4, &M, &V, &idle);
-  if (!idle) {
-    *reinterpret_cast<float4*>(fi.th_new + i4) = P;
-    if (write_state) {
-      *reinterpret_cast<float4*>(fi.m_new + i4) = M;
-      *reinterpret_cast<float4*>(fi.v_new + i4) = V;
-    }
-  }  // (a row idle since the call began holds the same value in both halves of the ping-pong pair: nothing to copy)
-  if (second && fi.cert && row < fi.n_cert) {
-    const float inc = fi.g_prev[kGHead + row * CLID_GRAD_ROW16 + CLID_F];
-    if (inc != 0.f) fi.cert[row] += inc;
-  }
-}
-// decoder parameter i (flat layout) of this iteration from the previous state + the 8 head copies of g_prev
-__device__ __forceinline__ float decoder_on_read(const FusedIter& fi, int i, float* m_out = nullptr, float* v_out = nullptr) {
-  float P = fi.wd_old[i];
-  if (fi.step > 0) {
-    float gsum = 0.f;
-#pragma unroll
-    for (int c = 0; c < kGHeadCopies; ++c) gsum += fi.g_prev[c * kGHeadStride + i];
-    float M = fi.mw_old[i], V = fi.vw_old[i];
-    adam_update(P, gsum, M, V, fi.k, 0.f);
-    if (m_out) *m_out = M;
-    if (v_out) *v_out = V;
-  }
-  return P;
-}
-// total / bce / eikonal of the previous iteration from the head copies of g_prev (one thread)
-__device__ __forceinline__ void finish_loss_prev(const FusedIter& fi) {
-  if (!fi.loss_prev) return;
-  float bce = 0.f, eik = 0.f;
-  for (int c = 0; c < kGHeadCopies; ++c) {
-    bce += fi.g_prev[c * kGHeadStride + CLID_MLP_PARAMS];
-    eik += fi.g_prev[c * kGHeadStride + CLID_MLP_PARAMS + 1];
-  }
-  bce *= fi.inv_n_main;
-  eik *= fi.inv_n_eik;
-  fi.loss_prev[0] += bce + fi.weight_e * eik;
-  fi.loss_prev[1] += bce;
-  fi.loss_prev[2] += eik;
-}
-}  // namespace clid
-
 // ---- launches under the optional per-kernel timing of clid_profile_enable (train.hip) -------------------------
 // Inside a prof_begin / prof_end bracket the kernel goes out through hipExtLaunchKernelGGL with the bracket's start and
 // stop events, which then hold the DISPATCH's begin / end time stamps (the same clock rocprofv3 --kernel-trace reads).
@@ -400,8 +244,7 @@ bool clid_prof_take(hipEvent_t* a, hipEvent_t* b);
 
 // host-side launchers of the tile (matrix-core) decode kernels (train_tile.hip); prec 0 = fp32, 1 = bf16 operands
 int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, float* partial, const clid::TaskMap& tmap,
-                            const float* rec, int prec, hipStream_t s, const clid::FusedIter* fused = nullptr);
-int clid_launch_fused_final(const clid::FusedIter* fi, float* W1, float* b1, float* W2, float* b2, int train_decoder, hipStream_t s);
+                            const float* rec, int prec, hipStream_t s);
 int clid_decode_tile_blocks(int n_tasks);
 // host-side launchers of the analytic-eikonal iteration (train_analytic.hip)
 int clid_launch_train_analytic(const clid_map_view* mv, const clid_train_args* a, float* partial, hipStream_t s);

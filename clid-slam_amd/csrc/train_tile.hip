@@ -82,10 +82,10 @@ __device__ __forceinline__ void tile_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int PREC, bool LN, bool FUSED>
-__global__ void __launch_bounds__(kTileBlock, 2)  // 2 waves per SIMD: VGPRs + AGPRs <= 256
+template <int PREC, bool LN>
+__global__ void __launch_bounds__(kTileBlock)
 k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap,
-              const float4* __restrict__ rec, int n_tiles, float* __restrict__ sdf_dbg, FusedIter fi) {
+              const float4* __restrict__ rec, int n_tiles, float* __restrict__ sdf_dbg) {
   __shared__ TileLds tls[kTileWaves];
   static_assert(sizeof(TileLds) % 16 == 0 && sizeof(TileLds) * kTileWaves >= kTileWaves * kRedFloats * sizeof(float), "LDS plan");
   float* red = reinterpret_cast<float*>(tls);  // the block flush reuses the tile buffers (after a barrier)
@@ -95,14 +95,7 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
   const float sc = ta.sdf_scale;
   const float inv_sigma = fdiv(1.0f, ta.sigma);
   const float inv_two_eps = fdiv(1.0f, 2.0f * ta.fd_eps);
-  if (FUSED && (int)blockIdx.x >= fi.n_tile_blocks) {  // the sweep blocks of the one-launch iteration (train_common.hpp)
-    const long long t4 = ((long long)blockIdx.x - fi.n_tile_blocks) * kTileBlock + threadIdx.x;
-    adam_sweep_thread(fi, t4, true, true);
-    if ((int)blockIdx.x == fi.n_tile_blocks && fi.g_next)  // ... and the head of the buffer the NEXT iteration accumulates into
-      for (int i = threadIdx.x; i < kGHead; i += kTileBlock) fi.g_next[i] = 0.f;
-    return;
-  }
-  float* __restrict__ rows = FUSED ? fi.g_cur + kGHead : ta.grad + CLID_GRAD_FEAT_OFFSET16;
+  float* __restrict__ rows = ta.grad + CLID_GRAD_FEAT_OFFSET16;
   const float4* __restrict__ feat4 = reinterpret_cast<const float4*>(mv.feat);
   const float4* __restrict__ pos4 = reinterpret_cast<const float4*>(mv.pos4);
 
@@ -113,26 +106,12 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
   //   A2[u][r] = W1[16u + 4g + r][q], q < 8                                        d f, B[k = lane >> 4][j = lane & 15]
   {
     float* wl = reinterpret_cast<float*>(tls);  // [W1 704 | b1 64 | W2 64 | b2 1]; overwritten by the first tile's fences later
-    if (FUSED && train) {  // the decoder of THIS iteration = Adam on read of the previous state; block 0 stores it
-      for (int i = threadIdx.x; i < CLID_MLP_PARAMS; i += kTileBlock) {
-        float M = 0.f, V = 0.f;
-        const float P = decoder_on_read(fi, i, &M, &V);
-        wl[i] = P;
-        if (blockIdx.x == 0) {  // (also at step 0: the other half of the ping-pong pair must hold valid values)
-          fi.wd_new[i] = P;
-          fi.mw_new[i] = M;
-          fi.vw_new[i] = V;
-        }
-      }
-    } else {
-      for (int i = threadIdx.x; i < CLID_H * CLID_D; i += kTileBlock) wl[i] = ta.W1[i];
-      if (threadIdx.x < CLID_H) {
-        wl[CLID_H * CLID_D + threadIdx.x] = ta.b1[threadIdx.x];
-        wl[CLID_H * CLID_D + CLID_H + threadIdx.x] = ta.W2[threadIdx.x];
-      }
-      if (threadIdx.x == 0) wl[CLID_MLP_PARAMS - 1] = ta.b2[0];
+    for (int i = threadIdx.x; i < CLID_H * CLID_D; i += kTileBlock) wl[i] = ta.W1[i];
+    if (threadIdx.x < CLID_H) {
+      wl[CLID_H * CLID_D + threadIdx.x] = ta.b1[threadIdx.x];
+      wl[CLID_H * CLID_D + CLID_H + threadIdx.x] = ta.W2[threadIdx.x];
     }
-    if (FUSED && blockIdx.x == 0 && threadIdx.x == 64) finish_loss_prev(fi);
+    if (threadIdx.x == 0) wl[CLID_MLP_PARAMS - 1] = ta.b2[0];
   }
   __syncthreads();
   float A1[4][4], W2r[4][4], A2[4][4];
@@ -197,53 +176,34 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
     }
     CLID_STAMP(2);
     // ================= gather + blend of this lane's 4 decoder-input columns
+    float4 v[CLID_K];
     int ts_old[CLID_K];
 #pragma unroll
     for (int k = 0; k < CLID_K; ++k) {
+      const int jc = j[k] >= 0 ? j[k] : 0;
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       ts_old[k] = 0x7fffffff;
-      if (g == 3 && mv.ts_update && j[k] >= 0) ts_old[k] = mv.ts_update[j[k]];
+      if (g < 2) v[k] = feat4[(size_t)jc * 2 + g];
+      else if (g == 3 && mv.ts_update && j[k] >= 0) ts_old[k] = mv.ts_update[jc];
     }
-    float pc[4] = {0.f, 0.f, 0.f, 0.f};
-    auto blend = [&](float4 vk, float wk) {
-      if (LN) {  // F.layer_norm over the 8 features of the neighbour row (np.py:632-633); lanes g = 0,1 hold the halves
-        const float mu = xsum16((vk.x + vk.y) + (vk.z + vk.w)) * (1.0f / CLID_F);
-        const float4 c = make_float4(vk.x - mu, vk.y - mu, vk.z - mu, vk.w - mu);
-        const float var = xsum16((c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w)) * (1.0f / CLID_F);
-        const float rstd = 1.0f / sqrtf(var + 1e-5f);
-        vk = make_float4(c.x * rstd, c.y * rstd, c.z * rstd, c.w * rstd);
-      }
-      pc[0] = fmaf(vk.x, wk, pc[0]);
-      pc[1] = fmaf(vk.y, wk, pc[1]);
-      pc[2] = fmaf(vk.z, wk, pc[2]);
-      pc[3] = fmaf(vk.w, wk, pc[3]);
-    };
-    if (FUSED) {
-      // theta of THIS iteration = Adam on read (4 sixteen-byte loads per half row): two batches of three neighbours, so
-      // that 12 loads are in flight at a time and the kernel stays inside 256 registers (2 waves per SIMD)
-#pragma unroll
-      for (int b3 = 0; b3 < CLID_K; b3 += 3) {
-        float4 vk[3];
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-          const int jc = j[b3 + kk] >= 0 ? j[b3 + kk] : 0;
-          vk[kk] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (g < 2) vk[kk] = adam_on_read4(fi, ((long long)jc * 2 + g) * 4);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) blend(vk[kk], w[b3 + kk]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-      float4 v[CLID_K];
+    if (LN) {  // F.layer_norm over the 8 features of every neighbour row (np.py:632-633); lanes g = 0,1 hold the halves
 #pragma unroll
       for (int k = 0; k < CLID_K; ++k) {
-        const int jc = j[k] >= 0 ? j[k] : 0;
-        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g < 2) v[k] = feat4[(size_t)jc * 2 + g];
+        const float mu = xsum16((v[k].x + v[k].y) + (v[k].z + v[k].w)) * (1.0f / CLID_F);
+        const float4 c = make_float4(v[k].x - mu, v[k].y - mu, v[k].z - mu, v[k].w - mu);
+        const float var = xsum16((c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w)) * (1.0f / CLID_F);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        v[k] = make_float4(c.x * rstd, c.y * rstd, c.z * rstd, c.w * rstd);
       }
-      CLID_STAMP(3);
+    }
+    CLID_STAMP(3);
+    float pc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < CLID_K; ++k) blend(v[k], w[k]);
+    for (int k = 0; k < CLID_K; ++k) {
+      pc[0] = fmaf(v[k].x, w[k], pc[0]);
+      pc[1] = fmaf(v[k].y, w[k], pc[1]);
+      pc[2] = fmaf(v[k].z, w[k], pc[2]);
+      pc[3] = fmaf(v[k].w, w[k], pc[3]);
     }
     if (g == 2) {  // x - neighbour position, blended by the search (np.py:653-674), and the bias input
       pc[0] = wf.x; pc[1] = wf.y; pc[2] = wf.z; pc[3] = 1.0f;
@@ -432,8 +392,7 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
           float val = G[rr];
           if (LN) {  // layer-norm backward of the row, once (linear in the incoming gradient; np.py:632-633)
             const int idc = live_row ? id4[rr] : 0;
-            float th = 0.f;
-            if (q < CLID_F) th = FUSED ? adam_on_read1(fi, (long long)idc * CLID_F + q) : mv.feat[(size_t)idc * CLID_F + q];
+            const float th = q < CLID_F ? mv.feat[(size_t)idc * CLID_F + q] : 0.f;
             float s1 = th, gsum = q < CLID_F ? val : 0.f;
             s1 += dpp_mov<0xB1>(s1); s1 += dpp_mov<0x4E>(s1); s1 += dpp_mov<0x141>(s1);
             const float mu = s1 * (1.0f / CLID_F);
@@ -513,13 +472,12 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
     mine[CLID_MLP_PARAMS + 1] = eik_w;
   }
   __syncthreads();
-  float* out = FUSED ? fi.g_cur + (blockIdx.x % kGHeadCopies) * kGHeadStride : partial + (size_t)blockIdx.x * kPartialStride;
+  float* out = partial + (size_t)blockIdx.x * kPartialStride;
   for (int i = train ? threadIdx.x : CLID_MLP_PARAMS + threadIdx.x; i < CLID_MLP_PARAMS + 2; i += kTileBlock) {
     float s = 0.f;
 #pragma unroll
     for (int wv = 0; wv < kTileWaves; ++wv) s += red[wv * kRedFloats + i];
-    if (FUSED) atomicAdd(&out[i], s);  // 8 head copies of the accumulation buffer: summed by the next launch
-    else out[i] = s;
+    out[i] = s;
   }
   CLID_STAMP(13);
 }
@@ -549,70 +507,28 @@ int clid_decode_tile_blocks(int n_tasks) {
 }
 
 int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, float* partial, const TaskMap& tmap,
-                            const float* rec, int prec, hipStream_t s, const FusedIter* fused) {
+                            const float* rec, int prec, hipStream_t s) {
   if (a->grad_stride != CLID_GRAD_ROW16) {
     clid_set_error("clid_train_decode: the tile kernels need grad_stride == %d (got %d)", CLID_GRAD_ROW16, a->grad_stride);
     return CLID_E_ARG;
   }
-  if (!fused && ((uintptr_t)a->grad & 63) != 0) {
+  if (((uintptr_t)a->grad & 63) != 0) {
     clid_set_error("clid_train_decode: grad must be 64-byte aligned for the 16-float accumulation rows");
     return CLID_E_ARG;
   }
   const int n_tiles = (tmap.n_tasks + 1) / 2;
   const int nb = clid_decode_tile_blocks(tmap.n_tasks);
   const float4* r4 = reinterpret_cast<const float4*>(rec);
-  FusedIter fi{};
-  int grid = nb;
-  if (fused) {
-    fi = *fused;
-    fi.n_tile_blocks = nb;
-    grid = nb + (int)((fi.n_feat / 4 + kTileBlock - 1) / kTileBlock);
+#define CLID_TILE_LAUNCH(P, L) \
+  CLID_KLAUNCH((k_decode_tile<P, L>), dim3(nb), dim3(kTileBlock), 0, s, *mv, *a, partial, tmap, r4, n_tiles, g_sdf_dbg)
+  if (prec == 1) {
+    if (mv->layer_norm) CLID_TILE_LAUNCH(1, true);
+    else CLID_TILE_LAUNCH(1, false);
+  } else {
+    if (mv->layer_norm) CLID_TILE_LAUNCH(0, true);
+    else CLID_TILE_LAUNCH(0, false);
   }
-#define CLID_TILE_LAUNCH(P, L, F) \
-  CLID_KLAUNCH((k_decode_tile<P, L, F>), dim3(grid), dim3(kTileBlock), 0, s, *mv, *a, partial, tmap, r4, n_tiles, g_sdf_dbg, fi)
-#define CLID_TILE_PICK(F)                               \
-  do {                                                  \
-    if (prec == 1) {                                    \
-      if (mv->layer_norm) CLID_TILE_LAUNCH(1, true, F); \
-      else CLID_TILE_LAUNCH(1, false, F);               \
-    } else {                                            \
-      if (mv->layer_norm) CLID_TILE_LAUNCH(0, true, F); \
-      else CLID_TILE_LAUNCH(0, false, F);               \
-    }                                                   \
-  } while (0)
-  if (fused) CLID_TILE_PICK(true);
-  else CLID_TILE_PICK(false);
-#undef CLID_TILE_PICK
 #undef CLID_TILE_LAUNCH
-  CLID_CHECK_LAUNCH();
-  return CLID_OK;
-}
-
-// the last step of the one-launch iteration scheme: apply the pending Adam update of the final iteration into the caller's
-// arrays (features in place or from the ping-pong half, decoder parameters into W1 | b1 | W2 | b2), merge the certainty
-// column, finish the last loss row
-namespace clid {
-__global__ void __launch_bounds__(256) k_fused_final(FusedIter fi, float* W1, float* b1, float* W2, float* b2, int train_decoder,
-                                                     int n_sweep_blocks) {
-  if ((int)blockIdx.x < n_sweep_blocks) {
-    adam_sweep_thread(fi, (long long)blockIdx.x * 256 + threadIdx.x, false, false);
-    return;
-  }
-  const int i = ((int)blockIdx.x - n_sweep_blocks) * 256 + threadIdx.x;
-  if (train_decoder && i < CLID_MLP_PARAMS) {
-    const float P = decoder_on_read(fi, i);
-    float* dst = i < CLID_H * CLID_D ? W1 + i
-                 : (i < CLID_H * CLID_D + CLID_H ? b1 + (i - CLID_H * CLID_D)
-                    : (i < CLID_H * CLID_D + 2 * CLID_H ? W2 + (i - CLID_H * CLID_D - CLID_H) : b2));
-    *dst = P;
-  }
-  if (i == CLID_MLP_PARAMS) finish_loss_prev(fi);
-}
-}  // namespace clid
-
-int clid_launch_fused_final(const FusedIter* fi, float* W1, float* b1, float* W2, float* b2, int train_decoder, hipStream_t s) {
-  const int sweep = (int)((fi->n_feat / 4 + 255) / 256);
-  CLID_KLAUNCH(clid::k_fused_final, dim3(sweep + 4), dim3(256), 0, s, *fi, W1, b1, W2, b2, train_decoder, sweep);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

@@ -86,8 +86,7 @@ class Mapper:
         dev = nm.local_geo_features.device
         dist = _dist()
         bs_local = int(cfg.bs) // (dist.get_world_size() if dist else 1)
-        self._loop_buffers(nm.local_geo_features.shape[0], iter_count, dev, True)   # the larger of the two layouts
-
+        self._loop_buffers(nm.local_geo_features.shape[0], iter_count, dev)
         need = int(lib.clid_train_workspace_floats(bs_local, max(int(cfg.gradient_decimation), 1), 1))
         if getattr(self, "_ws", None) is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(need, device=dev, dtype=torch.float32)
@@ -95,17 +94,12 @@ class Mapper:
         if getattr(self, "_idx_buf", None) is None or self._idx_buf.numel() < n_idx or self._idx_buf.device != dev:
             self._idx_buf = torch.empty(n_idx, device=dev, dtype=torch.int64)
 
-    def _loop_buffers(self, n_rows: int, iters: int, dev, fused: bool = False):
-        """Views [grad | m | v | m_mlp | v_mlp | losses | fused workspace] of one flat fp32 buffer, zeroed.  The buffer is
-        cached and only re-allocated when it has to grow, so a steady-state `mapping()` call allocates nothing;
-        `last_losses` therefore stays valid until the next call.  `fused`: the one-launch-per-iteration loop keeps its own
-        ping-pong / rotating state (clid_mapping_fused_floats) and the two-launch buffers shrink to stubs."""
+    def _loop_buffers(self, n_rows: int, iters: int, dev):
+        """Views [grad | m | v | m_mlp | v_mlp | losses] of one flat fp32 buffer, zeroed.  The buffer is cached and
+        only re-allocated when it has to grow, so a steady-state `mapping()` call allocates nothing;
+        `last_losses` therefore stays valid until the next call."""
         n_feat = n_rows * _lib.F
-        if fused:
-            fws_n = int(_lib.load().clid_mapping_fused_floats(n_feat))
-            sizes = (_lib.GRAD_FEAT_OFFSET16, 16, 16, 848, 848, ((iters * 4 + 15) // 16) * 16, fws_n)
-        else:
-            sizes = (_lib.GRAD_FEAT_OFFSET16 + n_rows * _lib.GRAD_ROW16, n_feat, n_feat, 848, 848, ((iters * 4 + 15) // 16) * 16, 0)
+        sizes = (_lib.GRAD_FEAT_OFFSET16 + n_rows * _lib.GRAD_ROW16, n_feat, n_feat, 848, 848, iters * 4)
         total = sum(sizes)
         flat = getattr(self, "_flat", None)
         if flat is None or flat.numel() < total or flat.device != torch.device(dev):
@@ -117,7 +111,7 @@ class Mapper:
             out.append(flat[off:off + n])
             off += n
         out[3], out[4] = out[3][:_lib.MLP_PARAMS], out[4][:_lib.MLP_PARAMS]
-        out[5] = out[5][:iters * 4].view(iters, 4)
+        out[5] = out[5].view(iters, 4)
         return out
 
     # ------------------------------------------------------------------ a1
@@ -216,6 +210,7 @@ class Mapper:
         # increment, 7 unused] (include/clid_native.h CLID_GRAD_ROW16) + Adam state + per-iteration losses: ONE cached
         # allocation, zeroed by one fill per call (the optimiser state restarts every call, utils/mapper.py:634)
         gstride = _lib.GRAD_ROW16
+        grad, m, v, m_mlp, v_mlp, losses = self._loop_buffers(n_feat // _lib.F, iter_count, dev)
         need = int(lib.clid_train_workspace_floats(bs_local, decim, eik_mode))
         if getattr(self, "_ws", None) is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(need, device=dev, dtype=torch.float32)
@@ -237,15 +232,10 @@ class Mapper:
         ta.loss_weight_on, ta.eikonal_mode, ta.train_decoder = int(bool(cfg.loss_weight_on)), eik_mode, int(train_decoder)
         ta.W1, ta.b1, ta.W2, ta.b2 = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr()
         ta.sdf_scale = float(self.geo_mlp.sdf_scale)
-        ta.ws = self._ws.data_ptr()
+        ta.grad, ta.ws = grad.data_ptr(), self._ws.data_ptr()
         ta.defer_reduce = 0 if dist else 1
         ta.debug_flags = int(os.environ.get('CLID_DEBUG_FLAGS', '0'))
         ta.grad_stride = gstride
-        # one launch per iteration with Adam applied on read (csrc/train_common.hpp FusedIter) where the loop is latency-bound
-        comm = _lib.rccl_comm(dist) if dist else None
-        fused = lib.clid_mapping_fused_supported(C.byref(view), C.byref(ta)) == 1 and (not dist or comm is not None)
-        grad, m, v, m_mlp, v_mlp, losses, fws = self._loop_buffers(n_feat // _lib.F, iter_count, dev, fused)
-        ta.grad = grad.data_ptr()
 
         aa = _lib.AdamArgs()
         aa.feat, aa.grad, aa.m, aa.v = theta.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr()
@@ -262,14 +252,10 @@ class Mapper:
         idx_base, row_bytes = index_seq.data_ptr(), bs_global * 8
         loss_base = losses.data_ptr()
         if not dist:
-            # single GPU: the whole loop is enqueued by one C call
+            # single GPU: the whole loop is enqueued by one C call (hoisted searches + 2 launches per iteration)
             ta.index, ta.loss_out = idx_base, loss_base
-            if fused:  # hoisted searches + ONE launch per iteration
-                _lib.check(lib.clid_mapping_run_fused(C.byref(view), C.byref(ta), C.byref(aa), iter_count, idx_base, bs_global,
-                                                      loss_base, fws.data_ptr(), fws.numel(), None, stream), "clid_mapping_run_fused")
-            else:      # hoisted searches + decode and Adam launches per iteration
-                _lib.check(lib.clid_mapping_run(C.byref(view), C.byref(ta), C.byref(aa), iter_count, idx_base, bs_global,
-                                                loss_base, stream), "clid_mapping_run")
+            _lib.check(lib.clid_mapping_run(C.byref(view), C.byref(ta), C.byref(aa), iter_count, idx_base, bs_global,
+                                            loss_base, stream), "clid_mapping_run")
         else:
             # the neighbour searches do not depend on the training state: one launch per chunk of iterations
             # resolves this rank's shard of every batch, then decode/backward -> all-reduce -> Adam per iteration
@@ -277,18 +263,14 @@ class Mapper:
             # with the tile kernels the certainty increments ride in the all-reduced accumulation rows (every rank's
             # Adam launch applies the global sum); the 16-lane kernel adds this rank's share to the array directly
             cert_in_rows = hoist and lib.clid_train_decode_kernel(C.byref(view), C.byref(ta)) > 0
+            comm = _lib.rccl_comm(dist)
             shard_base = idx_base + batch_offset * 8
             if comm is not None:
                 # RCCL behind the C ABI: the whole sharded loop is ONE host call, the all-reduce sits on the launch
-                # stream (csrc/train.hip clid_mapping_run_fused / clid_mapping_run_dist)
+                # stream between the partial reduction and Adam (csrc/train.hip clid_mapping_run_dist)
                 ta.index, ta.loss_out = shard_base, loss_base
-                if fused:
-                    _lib.check(lib.clid_mapping_run_fused(C.byref(view), C.byref(ta), C.byref(aa), iter_count, shard_base,
-                                                          bs_global, loss_base, fws.data_ptr(), fws.numel(), comm, stream),
-                               "clid_mapping_run_fused")
-                else:
-                    _lib.check(lib.clid_mapping_run_dist(C.byref(view), C.byref(ta), C.byref(aa), iter_count, shard_base,
-                                                         bs_global, loss_base, comm, grad.numel(), stream), "clid_mapping_run_dist")
+                _lib.check(lib.clid_mapping_run_dist(C.byref(view), C.byref(ta), C.byref(aa), iter_count, shard_base, bs_global,
+                                                     loss_base, comm, grad.numel(), stream), "clid_mapping_run_dist")
                 merged = True  # losses (SUM) and update stamps (MAX) were merged by the call
             else:
                 merged = False

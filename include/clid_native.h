@@ -264,19 +264,6 @@ int clid_mapping_run_dist(const clid_map_view* mv, const clid_train_args* t, con
                           const int64_t* index_base, int64_t index_stride, float* loss_base, clid_comm* comm,
                           int64_t grad_floats, void* stream);
 
-/* The loop with ONE launch per iteration (single GPU: comm == NULL; sharded: the RCCL all-reduce of the accumulation buffer
- * follows each launch).  Adam is applied ON READ: iteration t's launch gathers theta_t = Adam(theta_{t-1}, g_{t-1}) for the
- * rows it touches from read-only state while extra blocks of the same launch sweep all rows into the other half of a
- * ping-pong pair; gradients rotate over three accumulation buffers; a last small launch applies the final update into
- * a->feat / a->W1..b2 and a->cert.  Same results as clid_mapping_run up to summation order.  Only for the tile decode
- * kernels at latency-bound batch sizes: ask clid_mapping_fused_supported().  fused_ws: clid_mapping_fused_floats(a->n_feat)
- * floats, 64-byte aligned, ZEROED by the caller.  t->grad, a->m, a->v, a->m_mlp, a->v_mlp are not used. */
-int64_t clid_mapping_fused_floats(int64_t n_feat);
-int clid_mapping_fused_supported(const clid_map_view* mv, const clid_train_args* t);
-int clid_mapping_run_fused(const clid_map_view* mv, const clid_train_args* t, const clid_adam_args* a, int32_t iters,
-                           const int64_t* index_base, int64_t index_stride, float* loss_base, float* fused_ws,
-                           int64_t fused_ws_floats, clid_comm* comm, void* stream);
-
 /* How clid_mapping_run schedules the loop (numerical-eikonal / no-eikonal modes):
  *   1  (default) clid_train_search over a chunk of iterations, then per iteration clid_train_decode + Adam;
  *   0  per iteration the fused search+decode kernel of clid_train_fwd_bwd + Adam.
