@@ -131,6 +131,33 @@ static void lds_bench() {
     }
 }
 
+// every block adds a [n_lines x 16]-float vector into the SAME n_lines 64-byte lines (a decoder-gradient reduction by
+// atomics): `copies` > 1 spreads the blocks over that many private copies (blockIdx %% copies)
+__global__ void __launch_bounds__(256) k_same_lines(float* g, int n_lines, int copies) {
+  float* base = g + (size_t)(blockIdx.x % copies) * n_lines * 16;
+  for (int i = threadIdx.x; i < n_lines * 16; i += 256) atomicAdd(&base[i], 1.0f);
+}
+static void same_line_bench(float* g) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  for (int copies : {1, 8, 32})
+    for (int blocks : {410, 1640}) {
+      float best = 1e9;
+      for (int rep = 0; rep < 4; ++rep) {
+        CK(hipMemset(g, 0, 64 * 53 * 16 * sizeof(float)));
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL(k_same_lines, dim3(blocks), dim3(256), 0, 0, g, 53, copies);
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float ms;
+        CK(hipEventElapsedTime(&ms, a, b));
+        best = ms < best ? ms : best;
+      }
+      printf("same-line atomics: %4d blocks x 53 lines (64 B requests), %2d copies: %6.1f us\n", blocks, copies, best * 1e3);
+    }
+}
+
 __global__ void k_xcc(int* out) {
   if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
 }
@@ -158,6 +185,7 @@ int main() {
   run<0, 3>("agent rows16 (9 of 16 lanes)", g, rows, 0);
   run<0, 4>("agent rows16 (16 lanes, 64 B)", g, rows, 0);
   lds_bench();
+  same_line_bench(g);
   run<1, 2>("workgroup scatter", g, rows, 1);
   return 0;
 }
