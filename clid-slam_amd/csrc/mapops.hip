@@ -353,6 +353,66 @@ __global__ void __launch_bounds__(256) k_window_gather(WindowArgs a, const int* 
   reinterpret_cast<float4*>(o.l_feat)[j * 2 + 1] = reinterpret_cast<const float4*>(o.g_feat)[i * 2 + 1];
 }
 
+// ---- neural-point insertion (model/neural_points.py:324-437) --------------------------------------------------------
+// NeuralPoints.update after the voxel down-sampling: per sample, the slot of its voxel in the reference's own table, the
+// point held there, the take test (empty slot | held point farther than sqrt(3) voxels | held point stale by travelled
+// distance), ranks of the taken samples, the table update with the reference's sequential semantics (among several samples
+// naming one slot the LAST one wins, whether it was taken or not) and the append of positions / orientations / stamps /
+// certainties -- ~45 torch ops incl. an argsort in the reference-style chain, four launches + a scan here.
+struct InsertArgs {
+  const float* samples; int n;            // voxel-down-sampled points [n][3]
+  long long* table; int buffer_size;      // buffer_pt_index
+  float* points; float* orient; int* ts_create; int* ts_update; float* cert;  // global arrays with room for n more rows
+  const float* travel;                    // travel_dist or NULL
+  long long base;                         // points in the map before the insert
+  int test_on;                            // 0: empty map / reboot frame -> every sample is taken (:370-371)
+  int temporal;
+  int cur_ts;
+  float res, far2, diff_travel;
+};
+constexpr long long kClaimBase = 1LL << 40;  // above any point index: marks a slot as claimed by sample (value - base)
+__global__ void __launch_bounds__(256) k_insert_probe(InsertArgs a, int* __restrict__ phys, long long* __restrict__ held,
+                                                      int* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const float x = a.samples[i * 3 + 0], y = a.samples[i * 3 + 1], z = a.samples[i * 3 + 2];
+  const int slot = base_slot(x, y, z, a.res, a.buffer_size);  // == fmod(sum cell*prime, B) taken non-negative (:355-361)
+  const long long h = a.table[slot];
+  bool take = true;
+  if (a.test_on) {
+    take = h == -1;
+    if (!take) {
+      const float dx = fsub(a.points[h * 3 + 0], x), dy = fsub(a.points[h * 3 + 1], y), dz = fsub(a.points[h * 3 + 2], z);
+      take = fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz)) > a.far2;                       // :373-377
+      if (!take && a.temporal) take = fsub(a.travel[a.cur_ts], a.travel[a.ts_update[h]]) > a.diff_travel;  // :379-385
+    }
+  }
+  phys[i] = slot;
+  held[i] = h;
+  flag[i] = take ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_insert_claim(InsertArgs a, const int* __restrict__ phys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  atomicMax(reinterpret_cast<long long*>(&a.table[phys[i]]), kClaimBase + i);
+}
+__global__ void __launch_bounds__(256) k_insert_commit(InsertArgs a, const int* __restrict__ phys, const long long* __restrict__ held,
+                                                       const int* __restrict__ flag, const int* __restrict__ pos,
+                                                       long long* __restrict__ counts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  if (i == a.n - 1) counts[0] = pos[i] + flag[i];
+  const bool take = flag[i] != 0;
+  const long long dst = a.base + pos[i];
+  if (a.table[phys[i]] == kClaimBase + i) a.table[phys[i]] = take ? dst : held[i];  // the last sample naming this slot decides it
+  if (!take) return;
+  a.points[dst * 3 + 0] = a.samples[i * 3 + 0]; a.points[dst * 3 + 1] = a.samples[i * 3 + 1]; a.points[dst * 3 + 2] = a.samples[i * 3 + 2];
+  reinterpret_cast<float4*>(a.orient)[dst] = make_float4(1.f, 0.f, 0.f, 0.f);
+  a.ts_create[dst] = a.cur_ts;
+  a.ts_update[dst] = a.cur_ts;
+  a.cert[dst] = 0.f;
+}
+
 static int vox_log2cap(int n) {
   int l = 10;
   while ((1LL << l) < 2LL * n) ++l;
@@ -584,6 +644,48 @@ extern "C" int clid_local_window(const float* neural_points, const int32_t* ts_c
               local_points_out, local_orient_out, local_cert_out, local_ts_out, local_feat_out, point_orientations,
               point_certainties, geo_features};
   hipLaunchKernelGGL(k_window_gather, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s, a, flag, pos, o, counts);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+// ---- neural-point insertion -----------------------------------------------------------------------------------------
+extern "C" int64_t clid_map_insert_workspace_bytes(int32_t n) {
+  if (n <= 0) return 1024;
+  return (int64_t)(3 * align256((size_t)n * 4) + align256((size_t)n * 8) + align256(pool_scan_bytes(n)) + 256);
+}
+
+extern "C" int clid_map_insert(const float* samples, int32_t n, int64_t* buffer_pt_index, int64_t buffer_size, float resolution,
+                               float* neural_points, float* point_orientations, int32_t* ts_create, int32_t* ts_update,
+                               float* certainties, int64_t base, const float* travel_dist, int32_t cur_ts, int32_t test_on,
+                               int32_t temporal, float far_dist2, float diff_travel, int64_t* count_out, void* workspace,
+                               void* stream) {
+  if (n < 0 || !buffer_pt_index || buffer_size <= 0 || buffer_size >= (1LL << 30) || !count_out || !workspace || base < 0 ||
+      (n > 0 && (!samples || !neural_points || !point_orientations || !ts_create || !ts_update || !certainties)) ||
+      (test_on && temporal && !travel_dist)) {
+    clid_set_error("clid_map_insert: bad argument");
+    return CLID_E_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  long long* counts = reinterpret_cast<long long*>(count_out);
+  if (n == 0) return hipMemsetAsync(counts, 0, sizeof(long long), s) == hipSuccess ? CLID_OK : CLID_E_HIP;
+  char* ws = static_cast<char*>(workspace);
+  int* phys = reinterpret_cast<int*>(ws);
+  int* flag = reinterpret_cast<int*>(ws + align256((size_t)n * 4));
+  int* pos = reinterpret_cast<int*>(ws + 2 * align256((size_t)n * 4));
+  long long* held = reinterpret_cast<long long*>(ws + 3 * align256((size_t)n * 4));
+  void* cub = ws + 3 * align256((size_t)n * 4) + align256((size_t)n * 8);
+  size_t cub_bytes = pool_scan_bytes(n);
+  InsertArgs a{samples, n, reinterpret_cast<long long*>(buffer_pt_index), (int)buffer_size, neural_points, point_orientations,
+               ts_create, ts_update, certainties, travel_dist, (long long)base, test_on, temporal, cur_ts, resolution, far_dist2,
+               diff_travel};
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_insert_probe, dim3(blocks), dim3(256), 0, s, a, phys, held, flag);
+  if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, n, s) != hipSuccess) {
+    clid_set_error("clid_map_insert: scan failed");
+    return CLID_E_HIP;
+  }
+  hipLaunchKernelGGL(k_insert_claim, dim3(blocks), dim3(256), 0, s, a, phys);
+  hipLaunchKernelGGL(k_insert_commit, dim3(blocks), dim3(256), 0, s, a, phys, held, flag, pos, counts);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

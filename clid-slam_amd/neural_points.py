@@ -168,8 +168,12 @@ class NeuralPoints(nn.Module):
         st = dict(st)
         st["_tables"] = {}
         st.pop("_replica_gens", None)  # torch.Generator objects do not pickle
-        for k in ("_sensor_pos_host", "_win_ws", "_win_counts"):
+        for k in ("_sensor_pos_host", "_win_ws", "_win_counts", "_ins_ws", "_ins_count", "_gbuf"):
             st.pop(k, None)
+        for k in self._GLOBAL_ARRAYS:  # views of the capacity buffers would drag the whole buffers into the pickle
+            t = st.get(k)
+            if isinstance(t, torch.Tensor) and t.numel() and t.untyped_storage().nbytes() > t.numel() * t.element_size():
+                st[k] = t.clone()
         return st
 
     # ------------------------------------------------------------------ search region
@@ -188,6 +192,10 @@ class NeuralPoints(nn.Module):
         """Insert new neural points for `points` [N,3] (model/neural_points.py:324-437)."""
         res = self.resolution
         sample_points = points[voxel_down_sample_torch(points, res)]
+        if (sample_points.is_cuda and self.color_features is None and sample_points.dtype == torch.float32
+                and self.buffer_pt_index is not None and self.buffer_pt_index.is_cuda and int(self.buffer_size) < (1 << 30)
+                and self.geo_features.shape[1] == _lib.F and self.point_ts_create.dtype == torch.int32):
+            return self._update_fused(sample_points.contiguous(), sensor_position, sensor_orientation, cur_ts)
         cells = torch.floor(sample_points / res).to(self.primes)
         slot = torch.fmod((cells * self.primes).sum(-1), int(self.buffer_size))
         held = self.buffer_pt_index[slot]
@@ -226,6 +234,77 @@ class NeuralPoints(nn.Module):
         self._map_version += 1
         self.reset_local_map(sensor_position, sensor_orientation, cur_ts, reboot_map=True)
         return ratio
+
+    _GLOBAL_ARRAYS = ("neural_points", "point_orientations", "point_ts_create", "point_ts_update", "point_certainties",
+                      "geo_features")
+
+    def _ensure_global_capacity(self, extra: int):
+        """The six global arrays as views of capacity buffers with room for `extra` more points, so that an insert appends
+        in place instead of re-allocating and copying the whole map every frame.  Arrays replaced from outside (prune_map,
+        a loaded map, a test installing its own state) are simply re-attached by one copy."""
+        n = int(self.count())
+        need = n + int(extra)
+        buf = getattr(self, "_gbuf", None)
+        attached = buf is not None and buf["cap"] >= need and all(
+            getattr(self, k).data_ptr() == buf[k].data_ptr() and getattr(self, k).shape[0] == (n + 1 if k == "geo_features" else n)
+            for k in self._GLOBAL_ARRAYS)
+        if attached:
+            return buf
+        cap = max(2 * need, 1 << 16)
+        dev = self.neural_points.device
+        buf = {"cap": cap,
+               "neural_points": torch.empty((cap, 3), device=dev, dtype=torch.float32),
+               "point_orientations": torch.empty((cap, 4), device=dev, dtype=torch.float32),
+               "point_ts_create": torch.empty(cap, device=dev, dtype=torch.int32),
+               "point_ts_update": torch.empty(cap, device=dev, dtype=torch.int32),
+               "point_certainties": torch.empty(cap, device=dev, dtype=torch.float32),
+               "geo_features": torch.empty((cap + 1, self.geo_features.shape[1]), device=dev, dtype=torch.float32)}
+        for k in self._GLOBAL_ARRAYS:
+            cur = getattr(self, k)
+            rows = n + 1 if k == "geo_features" else n
+            if cur.shape[0] != rows:
+                raise RuntimeError(f"NeuralPoints.{k} has {cur.shape[0]} rows, expected {rows}")
+            buf[k][:rows].copy_(cur)
+            setattr(self, k, buf[k][:rows])
+        self._gbuf = buf
+        return buf
+
+    def _update_fused(self, sample_points, sensor_position, sensor_orientation, cur_ts: int):
+        """The insert of `update` in one enqueue (csrc/mapops.hip clid_map_insert) + ONE count read-back, appending in
+        place into the capacity buffers."""
+        lib = _lib.load()
+        n, base = int(sample_points.shape[0]), int(self.count())
+        dev = sample_points.device
+        buf = self._ensure_global_capacity(n)
+        test_on = int((not self.is_empty()) and (cur_ts != self.reboot_ts))
+        temporal = int(bool(self.temporal_local_map_on))
+        travel = self.travel_dist.to(torch.float32).contiguous() if (test_on and temporal) else None
+        need = int(lib.clid_map_insert_workspace_bytes(n))
+        if getattr(self, "_ins_ws", None) is None or self._ins_ws.numel() < need or self._ins_ws.device != dev:
+            self._ins_ws = torch.empty(int(need * 1.5) + 1024, device=dev, dtype=torch.uint8)
+            self._ins_count = torch.zeros(1, device=dev, dtype=torch.int64)
+        res = float(self.resolution)
+        _lib.check(lib.clid_map_insert(
+            sample_points.data_ptr(), n, self.buffer_pt_index.data_ptr(), int(self.buffer_size), res,
+            buf["neural_points"].data_ptr(), buf["point_orientations"].data_ptr(), buf["point_ts_create"].data_ptr(),
+            buf["point_ts_update"].data_ptr(), buf["point_certainties"].data_ptr(), base, _lib.ptr(travel), int(cur_ts), test_on,
+            temporal, float(3 * res**2), float(self.diff_travel_dist_local), self._ins_count.data_ptr(), self._ins_ws.data_ptr(),
+            _lib.stream()), "clid_map_insert")
+        n_new = int(self._ins_count.item())  # the one host round trip of the insert (sizes the views)
+        total = base + n_new
+        feat = buf["geo_features"]
+        if self.geo_feature_std != 0:
+            gen = _lib.replica_generator(self, self.config, self.device, 2)  # None = global RNG unless data-parallel
+            feat[base:total + 1] = self.geo_feature_std * torch.randn(n_new + 1, feat.shape[1], device=dev, dtype=torch.float32,
+                                                                       generator=gen)
+        else:
+            feat[base:total + 1].zero_()
+        self.neural_points, self.point_orientations = buf["neural_points"][:total], buf["point_orientations"][:total]
+        self.point_ts_create, self.point_ts_update = buf["point_ts_create"][:total], buf["point_ts_update"][:total]
+        self.point_certainties, self.geo_features = buf["point_certainties"][:total], feat[:total + 1]
+        self._map_version += 1
+        self.reset_local_map(sensor_position, sensor_orientation, cur_ts, reboot_map=True)
+        return n_new / max(n, 1)
 
     def _assign_slots(self, slot: torch.Tensor, value: torch.Tensor) -> None:
         """`buffer_pt_index[slot] = value` where several entries may name one slot: the reference's sequential CPU

@@ -352,6 +352,18 @@ int clid_pool_filter(const float* coord_a, const float* gcoord_a, const float* l
                      int64_t capacity, uint64_t seed, float* coord_out, float* gcoord_out, float* label_out,
                      float* weight_out, int32_t* time_out, int64_t* counts_out, void* workspace, void* stream);
 
+/* The insert of NeuralPoints.update (model/neural_points.py:346-437) for the voxel-down-sampled `samples` [n][3]: slot of
+ * each sample's voxel in buffer_pt_index, take test (empty | held point farther than sqrt(far_dist2) | held point stale
+ * by `diff_travel` of travelled distance; test_on = 0 takes every sample: empty map / reboot frame), table update with the
+ * reference's sequential semantics (the LAST sample naming a slot decides it), and the append of position, identity
+ * orientation, stamps = cur_ts, certainty 0 at rows base + rank of the global arrays (which must have room for n more
+ * rows).  count_out [1] int64 (device) = points added.  Features are the caller's (feature_std * randn). */
+int64_t clid_map_insert_workspace_bytes(int32_t n);
+int clid_map_insert(const float* samples, int32_t n, int64_t* buffer_pt_index, int64_t buffer_size, float resolution,
+                    float* neural_points, float* point_orientations, int32_t* ts_create, int32_t* ts_update, float* certainties,
+                    int64_t base, const float* travel_dist, int32_t cur_ts, int32_t test_on, int32_t temporal, float far_dist2,
+                    float diff_travel, int64_t* count_out, void* workspace, void* stream);
+
 /* NeuralPoints.reset_local_map (model/neural_points.py:439-536): the local window = points whose creation (or mid)
  * stamp lies within `diff_travel` of travelled distance (or `diff_ts_local` frames) of cur_ts -- dropped when it holds
  * fewer than 100 points, restricted to stamps >= reboot_ts when reboot_map -- AND within sqrt(radius2) of the sensor
