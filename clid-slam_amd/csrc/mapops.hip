@@ -413,6 +413,67 @@ __global__ void __launch_bounds__(256) k_insert_commit(InsertArgs a, const int* 
   a.cert[dst] = 0.f;
 }
 
+// ---- raw-point map maintenance (model/local_point_cloud_map.py:43-72) -------------------------------------------------
+// LocalPointCloudMap.update_map: scan points whose voxel slot is still empty are appended, the map is cropped to
+// `map_size` around the sensor and the slot table is rebuilt from scratch (every frame).  Here: probe -> flags over
+// [existing | samples] -> scan -> compaction into the other half of a ping-pong buffer -> table fill + amax scatter.
+__device__ __forceinline__ int cloud_slot(float x, float y, float z, float res, int B) {  // :38-41, ITS OWN middle prime
+  const double cx = (double)floorf(fdiv(x, res)), cy = (double)floorf(fdiv(y, res)), cz = (double)floorf(fdiv(z, res));
+  const double h = fma(cx, 73856093.0, fma(cy, 19349663.0, cz * 83492791.0));
+  const double Bd = (double)B;
+  const double q = floor(h / Bd);
+  double r = fma(-q, Bd, h);
+  if (r < 0.0) r += Bd;
+  if (r >= Bd) r -= Bd;
+  return (int)r;
+}
+struct CloudArgs {
+  const float* old_pts; long long n_a;   // map before the update
+  const float* samples; long long n_s;   // voxel-down-sampled scan points (world frame)
+  const long long* table_old; long long* table_new; int buffer_size;
+  float res;
+  double sx, sy, sz, map_size;
+  int pos_f64;
+};
+__device__ __forceinline__ bool cloud_near(const CloudArgs& a, const float* p) {
+  if (a.pos_f64) {
+    const double dx = (double)p[0] - a.sx, dy = (double)p[1] - a.sy, dz = (double)p[2] - a.sz;
+    return sqrt((dx * dx + dy * dy) + dz * dz) < a.map_size;  // torch.norm(...) < map_size in float64 (:66)
+  }
+  const float dx = fsub(p[0], (float)a.sx), dy = fsub(p[1], (float)a.sy), dz = fsub(p[2], (float)a.sz);
+  return sqrtf(fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz))) < (float)a.map_size;
+}
+__global__ void __launch_bounds__(256) k_cloud_flags(CloudArgs a, int* __restrict__ flag, long long* __restrict__ counts) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = a.n_a + a.n_s;
+  bool fresh = false, keep = false;
+  if (i < n) {
+    if (i < a.n_a) {
+      keep = cloud_near(a, a.old_pts + i * 3);
+    } else {
+      const float* p = a.samples + (i - a.n_a) * 3;
+      fresh = a.table_old[cloud_slot(p[0], p[1], p[2], a.res, a.buffer_size)] == -1;  // :49-56: slot still empty
+      keep = fresh && cloud_near(a, p);
+    }
+    flag[i] = keep ? 1 : 0;
+  }
+  const unsigned long long b = __ballot(fresh);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[1]), (unsigned long long)__popcll(b));
+}
+__global__ void __launch_bounds__(256) k_cloud_scatter(CloudArgs a, const int* __restrict__ flag, const int* __restrict__ pos,
+                                                       float* __restrict__ out, long long* __restrict__ counts) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = a.n_a + a.n_s;
+  if (i >= n) return;
+  if (i == n - 1) counts[0] = pos[i] + flag[i];
+  if (!flag[i]) return;
+  const float* p = i < a.n_a ? a.old_pts + i * 3 : a.samples + (i - a.n_a) * 3;
+  const long long j = pos[i];
+  out[j * 3 + 0] = p[0]; out[j * 3 + 1] = p[1]; out[j * 3 + 2] = p[2];
+  // the rebuilt table: several points may share a slot, the largest index stays (:69-71, amax == last writer)
+  atomicMax(&a.table_new[cloud_slot(p[0], p[1], p[2], a.res, a.buffer_size)], j);
+}
+
 static int vox_log2cap(int n) {
   int l = 10;
   while ((1LL << l) < 2LL * n) ++l;
@@ -686,6 +747,50 @@ extern "C" int clid_map_insert(const float* samples, int32_t n, int64_t* buffer_
   }
   hipLaunchKernelGGL(k_insert_claim, dim3(blocks), dim3(256), 0, s, a, phys);
   hipLaunchKernelGGL(k_insert_commit, dim3(blocks), dim3(256), 0, s, a, phys, held, flag, pos, counts);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+// ---- raw-point map ----------------------------------------------------------------------------------------------------
+extern "C" int64_t clid_cloud_workspace_bytes(int64_t n_total) {
+  if (n_total <= 0) return 1024;
+  return (int64_t)(2 * align256((size_t)n_total * 4) + align256(pool_scan_bytes(n_total)) + 256);
+}
+
+extern "C" int clid_cloud_update(const float* map_points, int64_t n_map, const float* samples, int64_t n_samples,
+                                 const int64_t* table_old, int64_t* table_new, int64_t buffer_size, float resolution,
+                                 const double* sensor_pos_host, double map_size, int32_t pos_is_f64, float* points_out,
+                                 int64_t* counts_out, void* workspace, void* stream) {
+  const long long n = n_map + n_samples;
+  if (n_map < 0 || n_samples < 0 || n >= (1LL << 31) || !table_old || !table_new || table_old == table_new || buffer_size <= 0 ||
+      buffer_size >= (1LL << 30) || !sensor_pos_host || !counts_out || !workspace || (n_map > 0 && !map_points) ||
+      (n_samples > 0 && !samples) || (n > 0 && !points_out)) {
+    clid_set_error("clid_cloud_update: bad argument");
+    return CLID_E_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  long long* counts = reinterpret_cast<long long*>(counts_out);
+  if (hipMemsetAsync(counts, 0, 2 * sizeof(long long), s) != hipSuccess ||
+      hipMemsetAsync(table_new, 0xFF, (size_t)buffer_size * sizeof(int64_t), s) != hipSuccess) {
+    clid_set_error("clid_cloud_update: memset failed");
+    return CLID_E_HIP;
+  }
+  if (n == 0) return CLID_OK;
+  char* ws = static_cast<char*>(workspace);
+  int* flag = reinterpret_cast<int*>(ws);
+  int* pos = reinterpret_cast<int*>(ws + align256((size_t)n * 4));
+  void* cub = ws + 2 * align256((size_t)n * 4);
+  size_t cub_bytes = pool_scan_bytes(n);
+  CloudArgs a{map_points, n_map, samples, n_samples, reinterpret_cast<const long long*>(table_old),
+              reinterpret_cast<long long*>(table_new), (int)buffer_size, resolution, sensor_pos_host[0], sensor_pos_host[1],
+              sensor_pos_host[2], map_size, pos_is_f64};
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_cloud_flags, dim3(blocks), dim3(256), 0, s, a, flag, counts);
+  if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)n, s) != hipSuccess) {
+    clid_set_error("clid_cloud_update: scan failed");
+    return CLID_E_HIP;
+  }
+  hipLaunchKernelGGL(k_cloud_scatter, dim3(blocks), dim3(256), 0, s, a, flag, pos, points_out, counts);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

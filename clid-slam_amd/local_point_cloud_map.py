@@ -60,12 +60,54 @@ class LocalPointCloudMap:
 
     def update_map(self, sensor_position: torch.Tensor, points: torch.Tensor) -> None:
         """:63-72: insert, keep what is within `map_size` of the sensor, rebuild the slot table."""
+        if self._update_map_fused(sensor_position, points):
+            return
         self.insert_points(points)
         near = torch.norm(self.local_point_cloud_map - sensor_position, dim=-1) < self.map_size
         self.local_point_cloud_map = self.local_point_cloud_map[near].contiguous()
         table = torch.full((self.buffer_size,), -1, dtype=self.idx_dtype, device=self.device)
         self._write_slots(table, self.voxel_hash(self.local_point_cloud_map), 0)
         self.buffer_pt_index = table
+
+    def _update_map_fused(self, sensor_position: torch.Tensor, points: torch.Tensor) -> bool:
+        """update_map in one enqueue (csrc/mapops.hip clid_cloud_update) + ONE count read-back; the point array and the slot
+        table ping-pong between two buffers each.  False = not applicable (CPU tensors), the torch path runs."""
+        if not (points.is_cuda and self.buffer_pt_index.is_cuda and self.local_point_cloud_map.dtype == torch.float32
+                and points.dtype == torch.float32 and self.buffer_size < (1 << 30)):
+            return False
+        lib = _lib.load()
+        dev = points.device
+        samples = points[voxel_down_sample_torch(points, self.resolution)].contiguous()
+        old = self.local_point_cloud_map.contiguous()
+        n_a, n_s = int(old.shape[0]), int(samples.shape[0])
+        n = n_a + n_s
+        hint = getattr(self, "_sensor_pos_host", None)  # (tensor, host tuple) left by Mapper.process_frame: no read-back
+        if hint is not None and hint[0] is sensor_position:
+            sp = hint[1]
+        else:
+            sp = [float(v) for v in sensor_position.detach().reshape(-1)[:3].tolist()]
+        state = getattr(self, "_pp", None)
+        if state is None or state["dev"] != dev:
+            state = self._pp = {"dev": dev, "side": 0, "pts": [None, None], "tab": [None, None]}
+        side = 1 - state["side"]
+        if state["pts"][side] is None or state["pts"][side].shape[0] < n:
+            state["pts"][side] = torch.empty((max(int(n * 1.5), 1 << 16), 3), device=dev, dtype=torch.float32)
+        if state["tab"][side] is None or state["tab"][side].data_ptr() == self.buffer_pt_index.data_ptr():
+            state["tab"][side] = torch.empty((self.buffer_size,), device=dev, dtype=self.idx_dtype)
+        out_pts, out_tab = state["pts"][side], state["tab"][side]
+        need = int(lib.clid_cloud_workspace_bytes(n))
+        if getattr(self, "_cloud_ws", None) is None or self._cloud_ws.numel() < need or self._cloud_ws.device != dev:
+            self._cloud_ws = torch.empty(int(need * 1.5) + 1024, device=dev, dtype=torch.uint8)
+            self._cloud_counts = torch.zeros(2, device=dev, dtype=torch.int64)
+        _lib.check(lib.clid_cloud_update(
+            old.data_ptr(), n_a, samples.data_ptr(), n_s, self.buffer_pt_index.data_ptr(), out_tab.data_ptr(), self.buffer_size,
+            float(self.resolution), (C.c_double * 3)(*sp), float(self.map_size), int(sensor_position.dtype == torch.float64),
+            out_pts.data_ptr(), self._cloud_counts.data_ptr(), self._cloud_ws.data_ptr(), _lib.stream()), "clid_cloud_update")
+        kept = int(self._cloud_counts[0].item())  # the one host round trip (sizes the map)
+        state["side"] = side
+        self.local_point_cloud_map = out_pts[:kept]
+        self.buffer_pt_index = out_tab
+        return True
 
     def set_search_neighborhood(self, num_nei_cells: int = 1, search_alpha: float = 0.2) -> None:
         """:74-96: the cells within (num_nei_cells + search_alpha) of the centre cell (7 by default)."""

@@ -471,6 +471,7 @@ class Mapper:
         pts = point_cloud_torch[:, :3]
         use_pin = bool(getattr(cfg, "use_pin_mapper", False))
         if not use_pin:  # :178-183
+            self.local_point_cloud_map._sensor_pos_host = (origin, tuple(float(v) for v in cur_pose_torch[:3, 3].tolist()))
             self.local_point_cloud_map.update_map(origin, transform_torch(pts, cur_pose_torch))
         self.static_mask = torch.ones(pts.shape[0], dtype=torch.bool, device=pts.device)
         if filter_dynamic:  # :189-204

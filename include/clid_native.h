@@ -352,6 +352,16 @@ int clid_pool_filter(const float* coord_a, const float* gcoord_a, const float* l
                      int64_t capacity, uint64_t seed, float* coord_out, float* gcoord_out, float* label_out,
                      float* weight_out, int32_t* time_out, int64_t* counts_out, void* workspace, void* stream);
 
+/* LocalPointCloudMap.update_map (model/local_point_cloud_map.py:43-72) after the voxel down-sampling of the scan: the
+ * `samples` whose voxel slot in table_old is still empty are appended to the map, the map is cropped to `map_size` around
+ * the sensor (float64 when the caller's sensor position is) and table_new [buffer_size] int64 is rebuilt from scratch
+ * (-1 fill, largest index per slot).  points_out: capacity n_map + n_samples rows, must not alias map_points.
+ * counts_out [2] int64 (device): points in the new map, samples that found their slot empty.  Nothing synchronises. */
+int64_t clid_cloud_workspace_bytes(int64_t n_total);
+int clid_cloud_update(const float* map_points, int64_t n_map, const float* samples, int64_t n_samples, const int64_t* table_old,
+                      int64_t* table_new, int64_t buffer_size, float resolution, const double* sensor_pos_host, double map_size,
+                      int32_t pos_is_f64, float* points_out, int64_t* counts_out, void* workspace, void* stream);
+
 /* The insert of NeuralPoints.update (model/neural_points.py:346-437) for the voxel-down-sampled `samples` [n][3]: slot of
  * each sample's voxel in buffer_pt_index, take test (empty | held point farther than sqrt(far_dist2) | held point stale
  * by `diff_travel` of travelled distance; test_on = 0 takes every sample: empty map / reboot frame), table update with the
