@@ -30,6 +30,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 #ifndef CLID_FUSED_WAVES
 #define CLID_FUSED_WAVES 4
 #endif
+#ifndef CLID_SEARCH_WAVES
+#define CLID_SEARCH_WAVES 6  // waves per SIMD the search-only instantiation is compiled for (tools/variant_bench.py sweeps it)
+#endif
 
 // ---- the kernel: 8-lane search groups, 16-lane decode groups ----------------------------------
 // The probe/selection phase is replicated work per lane-slot, so it runs with 8 lanes per query: one pass
@@ -86,7 +89,10 @@ __device__ __forceinline__ int match_base(const WaveLds& wl, int j) {
   return j >= 0 ? m : -1;
 }
 
-constexpr int kProbeRows8 = 6;  // probes per lane per chunk; chunk = 48 slots
+#ifndef CLID_PROBE_ROWS
+#define CLID_PROBE_ROWS 6
+#endif
+constexpr int kProbeRows8 = CLID_PROBE_ROWS;  // probes per lane per chunk; chunk = 8 * rows slots
 
 // Per-lane sorted candidate list of DEPTH entries.  The 81 probes of a query are spread over 8 lanes, so a lane
 // almost never owns more than 3 of the 6 winners: the throughput (search-only) kernel runs with DEPTH = 3 -- half
@@ -212,7 +218,7 @@ constexpr int kFusedBlock = 512;  // 8 waves share one partial row: half as many
 // resolves a whole chunk of iterations ahead of the dependent decode -> Adam chain (clid_train_search).
 constexpr int kRecFloat4 = 48;
 template <int MODE>
-__global__ void __launch_bounds__(kFusedBlock, CLID_FUSED_WAVES)
+__global__ void __launch_bounds__(kFusedBlock, MODE == 1 ? CLID_SEARCH_WAVES : CLID_FUSED_WAVES)
 k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap,
                float4* __restrict__ rec, int n_iter, long long index_stride, int use_filter) {
   __shared__ MlpLds mlp;

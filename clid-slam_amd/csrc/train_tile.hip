@@ -82,8 +82,11 @@ __device__ __forceinline__ void tile_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef CLID_TILE_WAVES
+#define CLID_TILE_WAVES (LN ? 2 : 1)  // layer norm: pin 2 waves per SIMD (VGPRs + AGPRs <= 256; it lands on 1 otherwise)
+#endif
 template <int PREC, bool LN>
-__global__ void __launch_bounds__(kTileBlock, LN ? 2 : 1)  // layer norm: pin 2 waves per SIMD (VGPRs + AGPRs <= 256; it lands on 1 otherwise)
+__global__ void __launch_bounds__(kTileBlock, CLID_TILE_WAVES)
 k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap,
               const float4* __restrict__ rec, int n_tiles, float* __restrict__ sdf_dbg) {
   __shared__ TileLds tls[kTileWaves];

@@ -6,9 +6,9 @@ sys.path.insert(0, ROOT)
 flags = sys.argv[1].split()
 csrc = os.path.join(ROOT, "clid-slam_amd", "csrc")
 out = "/tmp/libclid_variant.so"
-srcs = [os.path.join(csrc, f) for f in ("api.hip", "table.hip", "query.hip", "train.hip", "train_analytic.hip", "train_tile.hip", "mlp.hip", "sampler.hip", "mapops.hip")]
+srcs = [os.path.join(csrc, f) for f in ("api.hip", "comm.hip", "table.hip", "query.hip", "train.hip", "train_analytic.hip", "train_tile.hip", "mlp.hip", "sampler.hip", "mapops.hip")]
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=on",
-                       "-Wno-unused-value", "-Wno-unused-result", "-w", *flags, "-shared", *srcs, "-o", out])
+                       "-Wno-unused-value", "-Wno-unused-result", "-w", *flags, "-shared", *srcs, "-ldl", "-o", out])
 import clid_slam_amd  # noqa
 from clid_slam_amd import _lib
 _lib.LIB_PATH = out
@@ -19,4 +19,4 @@ import bench
 with contextlib.redirect_stdout(buf):
     bench.main()
 d = json.loads(buf.getvalue().strip().splitlines()[-1])
-print(sys.argv[1:], flags, os.environ.get("CLID_PIPELINE"), round(d["ms_per_step"] * 1e3, 2), d["roofline"]["per_kernel_us"])
+print(sys.argv[1:], flags, os.environ.get("CLID_PIPELINE"), round(d["ms_per_step"] * 1e3, 2), [(k["kernel"][:16], k["avg_us"]) for k in d["roofline"]["kernels"]])
