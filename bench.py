@@ -224,7 +224,8 @@ def main():
 
         freeze_model(dec)
     mp.reserve(max(args.steps, args.warmup, 10))  # workspaces sized once: nothing is allocated inside a timed region
-    mp.mapping(args.warmup)
+    for _ in range(args.warmup):  # W untimed steps, one per call: the GPU's clocks ramp over several hundred us of work
+        mp.mapping(1)             # (a single 5-iteration call leaves the first timed call 14 % slow: tools/warm_clocks.py)
     sync()
     t0 = time.perf_counter()
     mp.mapping(args.steps)

@@ -19,4 +19,5 @@ import bench
 with contextlib.redirect_stdout(buf):
     bench.main()
 d = json.loads(buf.getvalue().strip().splitlines()[-1])
-print(sys.argv[1:], flags, os.environ.get("CLID_PIPELINE"), round(d["ms_per_step"] * 1e3, 2), [(k["kernel"][:16], k["avg_us"]) for k in d["roofline"]["kernels"]])
+print(sys.argv[1:], flags, os.environ.get("CLID_SEARCH_BLOCKS"), round(d["ms_per_step"] * 1e3, 2),
+      "frame-regime", round((d.get("per_frame_regime") or {}).get("ms_per_step", 0) * 1e3, 2), [(k["kernel"][:16], k["avg_us"]) for k in d["roofline"]["kernels"]])
