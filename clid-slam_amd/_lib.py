@@ -120,6 +120,8 @@ _SIGS = {
     "clid_local_window": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _i32, C.POINTER(C.c_double), C.c_double, _i32,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clid_local_to_global": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clid_mapping_prep": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i64, _vp, _i64, C.c_uint64, C.c_uint64, _vp]),
+    "clid_debug_prep_draw": (_i64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
     "clid_comm_unique_id": (C.c_int, [_vp]),
     "clid_comm_init": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
     "clid_comm_size": (C.c_int, [_vp]),
@@ -234,7 +236,14 @@ def ptr(t) -> int:
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream() -> int:
+    """hipStream_t of torch's current stream on the current device (the raw getter is ~10x cheaper than building a
+    torch.cuda.Stream object per call; this sits in front of every launch)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -601,6 +601,69 @@ extern "C" int clid_local_to_global(const int64_t* ids, int32_t n, int64_t pad_r
   return CLID_OK;
 }
 
+// ---- per-call preparation of Mapper.mapping: workspace reset + batch index draw in ONE launch ----------------------
+// Batch composition of utils/mapper.py:473-500 for every iteration of the call: bs - bs_new uniform draws from the pool
+// followed by bs_new uniform draws from the newest frame's samples (new_idx).  Counter-based generator: element e of
+// call `counter` is mix64(seed, counter, e) -> multiply-high into the range (bias < 2^-40), so the draw is a pure function
+// of (seed, counter, position): identical on every rank of a multi-GPU run and reproducible on the host (tests).
+__host__ __device__ inline unsigned long long clid_mix64(unsigned long long seed, unsigned long long counter,
+                                                           unsigned long long e) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (counter + 1) + 0xD1B54A32D192ED03ull * (e + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;  // splitmix64 finaliser, twice
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ void __launch_bounds__(256)
+k_mapping_prep(float4* __restrict__ zero4, long long n_zero4, long long* __restrict__ index_out, long long n_index, int bs,
+               int bs_new, unsigned long long pool_count, const long long* __restrict__ new_idx, unsigned long long n_new,
+               unsigned long long seed, unsigned long long counter) {
+  const long long stride = (long long)gridDim.x * 256;
+  const long long t0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (long long i = t0; i < n_zero4; i += stride) zero4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int n_hist = bs - bs_new;
+  for (long long e = t0; e < n_index; e += stride) {
+    const int col = (int)(e % bs);
+    const unsigned long long r = clid_mix64(seed, counter, (unsigned long long)e);
+    long long v;
+    if (col < n_hist) v = (long long)__umul64hi(r, pool_count);
+    else v = new_idx[__umul64hi(r, n_new)];
+    index_out[e] = v;
+  }
+}
+
+extern "C" int clid_mapping_prep(float* zero_base, int64_t zero_floats, int64_t* index_out, int32_t iters, int32_t bs,
+                                 int32_t bs_new, int64_t pool_count, const int64_t* new_idx, int64_t n_new, uint64_t seed,
+                                 uint64_t counter, void* stream) {
+  if (zero_floats < 0 || (zero_floats && (!zero_base || (zero_floats & 3) || ((uintptr_t)zero_base & 15))) || iters < 0 ||
+      bs < 0 || bs_new < 0 || bs_new > bs || (iters && bs && !index_out) || (index_out && iters && bs && pool_count <= 0) ||
+      (bs_new > 0 && (!new_idx || n_new <= 0))) {
+    clid_set_error("clid_mapping_prep: bad argument");
+    return CLID_E_ARG;
+  }
+  const long long n_index = index_out ? (long long)iters * bs : 0;
+  const long long work = (zero_floats / 4 > n_index ? zero_floats / 4 : n_index);
+  if (work == 0) return CLID_OK;
+  long long blocks = (work + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_mapping_prep, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<float4*>(zero_base), (long long)(zero_floats / 4),
+                     reinterpret_cast<long long*>(index_out), n_index, bs, bs_new, (unsigned long long)pool_count,
+                     reinterpret_cast<const long long*>(new_idx), (unsigned long long)n_new, (unsigned long long)seed,
+                     (unsigned long long)counter);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+// host restatement of one draw (tests): the value k_mapping_prep writes at flat position e for a uniform column
+extern "C" int64_t clid_debug_prep_draw(uint64_t seed, uint64_t counter, uint64_t e, uint64_t range) {
+  const unsigned long long r = clid_mix64(seed, counter, e);
+  return (int64_t)(unsigned long long)(((unsigned __int128)r * range) >> 64);
+}
+
 // ---- pool maintenance --------------------------------------------------------------------------------------------
 static size_t pool_scan_bytes(long long n) {
   size_t tmp = 0;

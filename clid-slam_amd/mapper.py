@@ -94,10 +94,11 @@ class Mapper:
         if getattr(self, "_idx_buf", None) is None or self._idx_buf.numel() < n_idx or self._idx_buf.device != dev:
             self._idx_buf = torch.empty(n_idx, device=dev, dtype=torch.int64)
 
-    def _loop_buffers(self, n_rows: int, iters: int, dev):
-        """Views [grad | m | v | m_mlp | v_mlp | losses] of one flat fp32 buffer, zeroed.  The buffer is cached and
-        only re-allocated when it has to grow, so a steady-state `mapping()` call allocates nothing;
-        `last_losses` therefore stays valid until the next call."""
+    def _loop_buffers(self, n_rows: int, iters: int, dev, zero: bool = True):
+        """Views [grad | m | v | m_mlp | v_mlp | losses] of one flat fp32 buffer, zeroed (zero=False: the caller resets
+        `self._flat[:self._flat_used]` itself, see `_prepare_call`).  The buffer is cached and only re-allocated when it
+        has to grow, so a steady-state `mapping()` call allocates nothing; `last_losses` therefore stays valid until the
+        next call."""
         n_feat = n_rows * _lib.F
         sizes = (_lib.GRAD_FEAT_OFFSET16 + n_rows * _lib.GRAD_ROW16, n_feat, n_feat, 848, 848, iters * 4)
         total = sum(sizes)
@@ -105,13 +106,20 @@ class Mapper:
         if flat is None or flat.numel() < total or flat.device != torch.device(dev):
             flat = torch.empty(int(total * 1.25) + 4096, device=dev, dtype=torch.float32)
             self._flat = flat
-        flat[:total].zero_()
+        self._flat_used = (total + 3) & ~3
+        if zero:
+            flat[:total].zero_()
+        key = (n_rows, iters, flat.data_ptr())
+        cached = getattr(self, "_flat_views", None)
+        if cached is not None and cached[0] == key:  # the six views of an unchanged layout (slicing costs ~2 us each)
+            return list(cached[1])
         out, off = [], 0
         for n in sizes:
             out.append(flat[off:off + n])
             off += n
         out[3], out[4] = out[3][:_lib.MLP_PARAMS], out[4][:_lib.MLP_PARAMS]
         out[5] = out[5].view(iters, 4)
+        self._flat_views = (key, tuple(out))
         return out
 
     # ------------------------------------------------------------------ a1
@@ -136,6 +144,30 @@ class Mapper:
             out = buf[: iters * bs].view(iters, bs)
             return torch.randint(0, self.pool_sample_count, (iters, bs), device=dev, generator=self._gen, out=out)
         return torch.randint(0, self.pool_sample_count, (iters, bs), device=dev, generator=self._gen)
+
+    def _prepare_call(self, iters: int, bs: int, n_rows: int, dev, lib):
+        """Workspace reset + batch draw of one `mapping()` call in ONE launch (`clid_mapping_prep`): the composition rule
+        of `_draw_index` (utils/mapper.py:473-500) with a counter-based generator keyed on (seed, call number), so every
+        rank of a multi-GPU run draws the same batches.  Returns (loop buffers, index_seq [iters, bs])."""
+        bufs = self._loop_buffers(n_rows, iters, dev, zero=False)
+        buf = getattr(self, "_idx_buf", None)
+        if buf is None or buf.numel() < iters * bs or buf.device != torch.device(dev):
+            buf = self._idx_buf = torch.empty(iters * bs, device=dev, dtype=torch.int64)
+        index_seq = buf[: iters * bs].view(iters, bs)
+        use_new = (
+            self.config.bs_new_sample > 0 and self.new_idx is not None and self.new_idx.shape[0] > 0
+            and not getattr(self.dataset, "lose_track", False) and not getattr(self.dataset, "stop_status", False)
+        )
+        bs_new, new_ptr, n_new = 0, None, 0
+        if use_new:
+            new_idx = _lib.require_cuda(self.new_idx, "new_idx", torch.int64)
+            bs_new, new_ptr, n_new = min(new_idx.shape[0], self.config.bs_new_sample, bs), new_idx.data_ptr(), new_idx.shape[0]
+        self._draw_calls = getattr(self, "_draw_calls", 0) + 1
+        seed = int(getattr(self, "_seed", getattr(self.config, "seed", 42))) & 0xFFFFFFFFFFFFFFFF
+        _lib.check(lib.clid_mapping_prep(self._flat.data_ptr(), self._flat_used, buf.data_ptr(), iters, bs, bs_new,
+                                         int(self.pool_sample_count), new_ptr, n_new, seed, self._draw_calls, _lib.stream()),
+                   "clid_mapping_prep")
+        return bufs, index_seq
 
     def get_batch(self, global_coord=False):
         """utils/mapper.py:473-523: 7-tuple (coord, sdf_label, ts, normal, sem, color, weight)."""
@@ -186,16 +218,20 @@ class Mapper:
         if bs_global % world != 0:
             raise ValueError(f"batch size {bs_global} must be divisible by the world size {world}")
         bs_local = bs_global // world
-        if index_seq is None:
-            index_seq = self._draw_index(iter_count, bs_global)
-        else:
-            iter_count = index_seq.shape[0]
-        index_seq = _lib.require_cuda(index_seq.to(torch.int64).contiguous(), "index_seq", torch.int64)
-        batch_offset = rank * bs_local
-
         theta = nm.local_geo_features
         _lib.require_cuda(theta.data, "local_geo_features", torch.float32)
         dev = theta.device
+        n_feat = theta.numel()
+        bufs = None
+        if index_seq is None:
+            if self.pool_sample_count <= 0:
+                raise RuntimeError("mapping(): the sample pool is empty")
+            bufs, index_seq = self._prepare_call(iter_count, bs_global, n_feat // _lib.F, dev, lib)
+        else:
+            iter_count = index_seq.shape[0]
+            index_seq = _lib.require_cuda(index_seq.to(torch.int64).contiguous(), "index_seq", torch.int64)
+        batch_offset = rank * bs_local
+
         W1, b1, W2, b2 = self.geo_mlp.flat_params()
         # freeze_model flips requires_grad on the decoder's children (utils/tools.py:314-317)
         train_decoder = all(p.requires_grad for p in (W1, b1, W2, b2))
@@ -205,12 +241,11 @@ class Mapper:
         decim = int(cfg.gradient_decimation) if eik_mode == 1 else 1
         n_eik_global = (bs_global + decim - 1) // decim
 
-        n_feat = theta.numel()
         # fused gradient buffer [decoder 833 | pad | (M+1) accumulation rows of 16 floats: 8 gradients, certainty
         # increment, 7 unused] (include/clid_native.h CLID_GRAD_ROW16) + Adam state + per-iteration losses: ONE cached
         # allocation, zeroed by one fill per call (the optimiser state restarts every call, utils/mapper.py:634)
         gstride = _lib.GRAD_ROW16
-        grad, m, v, m_mlp, v_mlp, losses = self._loop_buffers(n_feat // _lib.F, iter_count, dev)
+        grad, m, v, m_mlp, v_mlp, losses = bufs if bufs is not None else self._loop_buffers(n_feat // _lib.F, iter_count, dev)
         need = int(lib.clid_train_workspace_floats(bs_local, decim, eik_mode))
         if getattr(self, "_ws", None) is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(need, device=dev, dtype=torch.float32)

@@ -399,6 +399,17 @@ int clid_local_to_global(const int64_t* ids, int32_t n, int64_t pad_row, const f
                          const float* local_cert, const int32_t* local_ts, float* global_feat, float* global_cert,
                          int32_t* global_ts, void* stream);
 
+/* Per-call preparation of Mapper.mapping in one launch: zero `zero_floats` floats at `zero_base` (16-byte aligned,
+ * multiple of 4: the fused gradient buffer, the Adam state and the loss rows restart every call, utils/mapper.py:634) and
+ * draw the batches of all `iters` iterations, index_out [iters][bs] int64, composed as utils/mapper.py:473-500:
+ * bs - bs_new uniform rows of the pool [0, pool_count) followed by bs_new uniform picks from new_idx [n_new] (bs_new may
+ * be 0).  The generator is counter-based on (seed, counter, position): identical on every rank.  index_out may be NULL
+ * (reset only).  clid_debug_prep_draw is the host restatement of one uniform draw (tests). */
+int clid_mapping_prep(float* zero_base, int64_t zero_floats, int64_t* index_out, int32_t iters, int32_t bs, int32_t bs_new,
+                      int64_t pool_count, const int64_t* new_idx, int64_t n_new, uint64_t seed, uint64_t counter,
+                      void* stream);
+int64_t clid_debug_prep_draw(uint64_t seed, uint64_t counter, uint64_t e, uint64_t range);
+
 /* ---- measurement aid (bench.py roofline leg; not part of the reference's interface) -----------
  * When enabled, clid_train_fwd_bwd / clid_train_adam bracket each kernel with hipEvents on the
  * launch stream.  clid_profile_read synchronises and returns summed elapsed ms per kernel:

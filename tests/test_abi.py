@@ -104,3 +104,32 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("oracle/", "").lower() or f in ("neural_points.py",), f
+
+
+def _mix64(seed, counter, e):
+    M = (1 << 64) - 1
+    z = (seed + 0x9E3779B97F4A7C15 * (counter + 1) + 0xD1B54A32D192ED03 * (e + 1)) & M
+    for _ in range(2):
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        z ^= z >> 31
+    return z
+
+
+def test_batch_draw_generator_host_restatement():
+    """The counter-based generator of clid_mapping_prep (batch composition of utils/mapper.py:473-500): the host entry point
+    equals the published splitmix64 arithmetic restated here, stays in range and is uniform (chi-square, 16 bins)."""
+    lib = _lib.load()
+    for seed, counter, e, rng in ((42, 1, 0, 10), (42, 1, 1, 897000), (2**63 + 5, 77, 123456789, 10_000_000), (0, 0, 0, 1)):
+        assert lib.clid_debug_prep_draw(seed, counter, e, rng) == (_mix64(seed, counter, e) * rng) >> 64
+    draws = np.array([lib.clid_debug_prep_draw(42, 3, e, 16) for e in range(32000)])
+    assert draws.min() == 0 and draws.max() == 15
+    counts = np.bincount(draws, minlength=16)
+    chi2 = float(((counts - 2000.0) ** 2 / 2000.0).sum())
+    assert chi2 < 45.0  # 15 degrees of freedom: p(chi2 > 45) < 1e-4
+    # consecutive positions / consecutive calls are decorrelated
+    a = np.array([lib.clid_debug_prep_draw(42, 3, e, 1 << 20) for e in range(4000)], dtype=np.float64)
+    b = np.array([lib.clid_debug_prep_draw(42, 4, e, 1 << 20) for e in range(4000)], dtype=np.float64)
+    assert abs(np.corrcoef(a[:-1], a[1:])[0, 1]) < 0.06 and abs(np.corrcoef(a, b)[0, 1]) < 0.06
+    rc = lib.clid_mapping_prep(None, 8, None, 0, 0, 0, 0, None, 0, 0, 0, None)
+    assert rc == -1 and b"clid_mapping_prep" in lib.clid_last_error()

@@ -770,3 +770,55 @@ def test_tiny_map_and_empty_inputs(env):
     mp.mapping(3)
     assert torch.isfinite(mp.last_losses).all() and torch.isfinite(nm.local_geo_features).all()
     assert not torch.equal(before, nm.local_geo_features.detach())
+
+
+def test_mapping_prep_resets_and_draws_like_the_host_restatement():
+    """clid_mapping_prep: one launch zeroes the loop's workspace and draws [iters, bs] batch indices composed as
+    utils/mapper.py:473-500 (history part uniform over the pool, the last bs_new columns picked from new_idx); every
+    entry equals the host restatement of the generator; Mapper.mapping uses it and advances the call counter."""
+    import ctypes as C
+
+    from clid_slam_amd import _lib
+
+    lib = _lib.load()
+    dev = "cuda:0"
+    iters, bs, bs_new, pool = 7, 1000, 300, 897_123
+    new_idx = torch.arange(800_000, 800_000 + 5000, device=dev, dtype=torch.int64) * 1 + 17
+    flat = torch.full((4096 + 8,), 3.0, device=dev)
+    idx = torch.full((iters, bs), -5, device=dev, dtype=torch.int64)
+    seed, counter = 42, 9
+    _lib.check(lib.clid_mapping_prep(flat.data_ptr(), 4096, idx.data_ptr(), iters, bs, bs_new, pool, new_idx.data_ptr(),
+                                     new_idx.shape[0], seed, counter, _lib.stream()), "clid_mapping_prep")
+    torch.cuda.synchronize()
+    assert float(flat[:4096].abs().max()) == 0.0 and float(flat[4096:].min()) == 3.0
+    got = idx.cpu().numpy()
+    nid = new_idx.cpu().numpy()
+    for it, col in ((0, 0), (0, 699), (3, 17), (6, 699)):
+        assert got[it, col] == lib.clid_debug_prep_draw(seed, counter, it * bs + col, pool)
+    for it, col in ((0, 700), (2, 999), (6, 850)):
+        assert got[it, col] == nid[lib.clid_debug_prep_draw(seed, counter, it * bs + col, nid.shape[0])]
+    assert got[:, :700].min() >= 0 and got[:, :700].max() < pool and np.isin(got[:, 700:], nid).all()
+    assert abs(got[:, :700].mean() / pool - 0.5) < 0.02 and len(np.unique(got[:, :700])) > 0.99 * 4900
+    idx2 = torch.empty_like(idx)
+    _lib.check(lib.clid_mapping_prep(None, 0, idx2.data_ptr(), iters, bs, 0, pool, None, 0, seed, counter + 1,
+                                     _lib.stream()), "clid_mapping_prep")
+    g2 = idx2.cpu().numpy()
+    assert (g2 != got).mean() > 0.99 and g2.max() < pool
+    # through the Mapper: two calls draw different batches, a second Mapper with the same seed reproduces them
+    import bench
+    from clid_slam_amd import HotPathConfig
+
+    draws = []
+    for rep in range(2):
+        cfg = HotPathConfig()
+        cfg.device, cfg.bs = dev, 2048
+        torch.manual_seed(1)
+        nm, dec, mp, scene = bench.build_scene(cfg, dev)
+        mp.mapping(2)
+        a = mp._keep[1].clone()
+        mp.mapping(2)
+        b = mp._keep[1].clone()
+        assert a.shape == (2, 2048) and int(a.max()) < mp.pool_sample_count and not torch.equal(a, b)
+        assert torch.isfinite(mp.last_losses).all() and float(mp.last_losses[:, 0].min()) > 0
+        draws.append((a, b))
+    assert torch.equal(draws[0][0], draws[1][0]) and torch.equal(draws[0][1], draws[1][1])
