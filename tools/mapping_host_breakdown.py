@@ -1,3 +1,4 @@
+"""Developer tool: wall-clock breakdown of the host side of Mapper.mapping(10) (wrapped sub-calls, no cProfile)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
