@@ -36,8 +36,11 @@
 
 namespace clid {
 
-constexpr int kTileBlock = 256;
-constexpr int kTileWaves = kTileBlock / 64;
+// waves (= tiles in flight) per block: 4 while one round of blocks covers the batch (the reference's 16 384 samples: one
+// partial row per 4 tiles keeps k_adam_all's column sums short), 2 beyond that (finer tail; 45.1 -> 41.1 us at 65 536)
+constexpr int kTileWavesSmall = 4, kTileWavesLarge = 2;
+constexpr int kTileLargeFrom = 2048;  // tiles
+__host__ inline int tile_waves_for(int n_tiles) { return n_tiles > kTileLargeFrom ? kTileWavesLarge : kTileWavesSmall; }
 constexpr int kRecF4 = 48;       // float4 per search record (== kRecFloat4 of train.hip)
 constexpr int kDhStride = 84;    // floats per query row of the dh transposition buffer (conflict-free b128 stores)
 constexpr int kFStride = 20;
@@ -85,12 +88,12 @@ __device__ __forceinline__ void tile_lds_fence() {
 #ifndef CLID_TILE_WAVES
 #define CLID_TILE_WAVES (LN ? 2 : 1)  // layer norm: pin 2 waves per SIMD (VGPRs + AGPRs <= 256; it lands on 1 otherwise)
 #endif
-template <int PREC, bool LN>
-__global__ void __launch_bounds__(kTileBlock, CLID_TILE_WAVES)
+template <int PREC, bool LN, int TW>
+__global__ void __launch_bounds__(TW * 64, CLID_TILE_WAVES)
 k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap,
               const float4* __restrict__ rec, int n_tiles, float* __restrict__ sdf_dbg) {
-  __shared__ TileLds tls[kTileWaves];
-  static_assert(sizeof(TileLds) % 16 == 0 && sizeof(TileLds) * kTileWaves >= kTileWaves * kRedFloats * sizeof(float), "LDS plan");
+  __shared__ TileLds tls[TW];
+  static_assert(sizeof(TileLds) % 16 == 0 && sizeof(TileLds) * TW >= TW * kRedFloats * sizeof(float), "LDS plan");
   float* red = reinterpret_cast<float*>(tls);  // the block flush reuses the tile buffers (after a barrier)
   const int lane = threadIdx.x & 63, q = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
   TileLds& tl = tls[wave];
@@ -109,7 +112,7 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
   //   A2[u][r] = W1[16u + 4g + r][q], q < 8                                        d f, B[k = lane >> 4][j = lane & 15]
   {
     float* wl = reinterpret_cast<float*>(tls);  // [W1 704 | b1 64 | W2 64 | b2 1]; overwritten by the first tile's fences later
-    for (int i = threadIdx.x; i < CLID_H * CLID_D; i += kTileBlock) wl[i] = ta.W1[i];
+    for (int i = threadIdx.x; i < CLID_H * CLID_D; i += (TW * 64)) wl[i] = ta.W1[i];
     if (threadIdx.x < CLID_H) {
       wl[CLID_H * CLID_D + threadIdx.x] = ta.b1[threadIdx.x];
       wl[CLID_H * CLID_D + CLID_H + threadIdx.x] = ta.W2[threadIdx.x];
@@ -157,7 +160,7 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
   }
   float db2a = 0.f, bce_acc = 0.f, eik_acc = 0.f;
 
-  for (int tile = blockIdx.x * kTileWaves + wave; tile < n_tiles; tile += gridDim.x * kTileWaves) {
+  for (int tile = blockIdx.x * TW + wave; tile < n_tiles; tile += gridDim.x * TW) {
     // ================= record of this lane's query slot
     const int task = 2 * tile + (q >> 3), slot = q & 7;
     const bool tlive = task < tmap.n_tasks;
@@ -476,10 +479,10 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
   }
   __syncthreads();
   float* out = partial + (size_t)blockIdx.x * kPartialStride;
-  for (int i = train ? threadIdx.x : CLID_MLP_PARAMS + threadIdx.x; i < CLID_MLP_PARAMS + 2; i += kTileBlock) {
+  for (int i = train ? threadIdx.x : CLID_MLP_PARAMS + threadIdx.x; i < CLID_MLP_PARAMS + 2; i += (TW * 64)) {
     float s = 0.f;
 #pragma unroll
-    for (int wv = 0; wv < kTileWaves; ++wv) s += red[wv * kRedFloats + i];
+    for (int wv = 0; wv < TW; ++wv) s += red[wv * kRedFloats + i];
     out[i] = s;
   }
   CLID_STAMP(13);
@@ -505,7 +508,8 @@ extern "C" int clid_debug_decode_sdf_out(float* sdf_out) {
 
 int clid_decode_tile_blocks(int n_tasks) {
   const int tiles = (n_tasks + 1) / 2;
-  int nb = (tiles + kTileWaves - 1) / kTileWaves;
+  const int tw = tile_waves_for(tiles);
+  int nb = (tiles + tw - 1) / tw;
   return nb > kMaxBwdBlocks ? kMaxBwdBlocks : (nb < 1 ? 1 : nb);
 }
 
@@ -522,8 +526,15 @@ int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, f
   const int n_tiles = (tmap.n_tasks + 1) / 2;
   const int nb = clid_decode_tile_blocks(tmap.n_tasks);
   const float4* r4 = reinterpret_cast<const float4*>(rec);
-#define CLID_TILE_LAUNCH(P, L) \
-  CLID_KLAUNCH((k_decode_tile<P, L>), dim3(nb), dim3(kTileBlock), 0, s, *mv, *a, partial, tmap, r4, n_tiles, g_sdf_dbg)
+#define CLID_TILE_LAUNCH(P, L)                                                                                        \
+  do {                                                                                                                \
+    if (tile_waves_for(n_tiles) == kTileWavesSmall)                                                                   \
+      CLID_KLAUNCH((k_decode_tile<P, L, kTileWavesSmall>), dim3(nb), dim3(kTileWavesSmall * 64), 0, s, *mv, *a,       \
+                   partial, tmap, r4, n_tiles, g_sdf_dbg);                                                            \
+    else                                                                                                              \
+      CLID_KLAUNCH((k_decode_tile<P, L, kTileWavesLarge>), dim3(nb), dim3(kTileWavesLarge * 64), 0, s, *mv, *a,       \
+                   partial, tmap, r4, n_tiles, g_sdf_dbg);                                                            \
+  } while (0)
   if (prec == 1) {
     if (mv->layer_norm) CLID_TILE_LAUNCH(1, true);
     else CLID_TILE_LAUNCH(1, false);
