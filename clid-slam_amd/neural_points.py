@@ -168,7 +168,7 @@ class NeuralPoints(nn.Module):
         st = dict(st)
         st["_tables"] = {}
         st.pop("_replica_gens", None)  # torch.Generator objects do not pickle
-        for k in ("_sensor_pos_host", "_win_ws", "_win_counts", "_ins_ws", "_ins_count", "_gbuf"):
+        for k in ("_sensor_pos_host", "_win_ws", "_win_counts", "_ins_ws", "_ins_count", "_gbuf", "_stencils"):
             st.pop(k, None)
         for k in self._GLOBAL_ARRAYS:  # views of the capacity buffers would drag the whole buffers into the pickle
             t = st.get(k)
@@ -178,7 +178,15 @@ class NeuralPoints(nn.Module):
 
     # ------------------------------------------------------------------ search region
     def set_search_neighborhood(self, num_nei_cells: int = 1, search_alpha: float = 1.0):
-        """model/neural_points.py:931-969 (+ the per-offset slot deltas the kernels use)."""
+        """model/neural_points.py:931-969 (+ the per-offset slot deltas the kernels use).  The stencil of a
+        (num_nei_cells, search_alpha) pair is a constant: process_frame switches to the 1-cell stencil and back every
+        frame (utils/mapper.py:425-437), so the tensors are built once per pair (a dozen launches and a read-back each)."""
+        key = (int(num_nei_cells), float(search_alpha), int(self.buffer_size), float(self.resolution), str(self.primes.device))
+        cache = self.__dict__.setdefault("_stencils", {})
+        hit = cache.get(key)
+        if hit is not None:
+            self.neighbor_dx, self.neighbor_K, self.max_valid_dist2, self._delta = hit
+            return
         r = torch.arange(-num_nei_cells, num_nei_cells + 1, device=self.primes.device, dtype=self.primes.dtype)
         gx, gy, gz = torch.meshgrid(r, r, r, indexing="ij")
         cube = torch.stack((gx, gy, gz), dim=-1).reshape(-1, 3)
@@ -186,6 +194,7 @@ class NeuralPoints(nn.Module):
         self.neighbor_K = self.neighbor_dx.shape[0]
         self.max_valid_dist2 = 3 * ((num_nei_cells + 1) * self.resolution) ** 2
         self._delta = torch.remainder((self.neighbor_dx * self.primes).sum(-1), int(self.buffer_size)).to(torch.int32).contiguous()
+        cache[key] = (self.neighbor_dx, self.neighbor_K, self.max_valid_dist2, self._delta)
 
     # ------------------------------------------------------------------ map maintenance (host logic)
     def update(self, points: torch.Tensor, sensor_position: torch.Tensor, sensor_orientation: torch.Tensor, cur_ts: int):
