@@ -77,7 +77,7 @@ def _wrap_stages(mp, nm, lpm, acc):
     wrap(nm, "assign_local_to_global", "assign_local_to_global")
 
 
-def run(frames, device, check_frames=0, seed=42, quiet=False, breakdown=None):
+def run(frames, device, check_frames=0, seed=42, quiet=False, breakdown=None, after_process=None):
     from clid_slam_amd import Decoder, LocalPointCloudMap, Mapper, NeuralPoints
     from clid_slam_amd.synth import hall_scan, sweep_poses
     from clid_slam_amd.tools import freeze_model
@@ -106,6 +106,8 @@ def run(frames, device, check_frames=0, seed=42, quiet=False, breakdown=None):
         mp.process_frame(pts, None, pose, fid, False)
         sync()
         t1 = time.perf_counter()
+        if after_process is not None:  # tests: look at the state process_frame left
+            after_process(mp, nm)
         iters = cfg.iters * cfg.init_iter_ratio if fid == 0 else cfg.iters  # slam.py:187-191
         if fid == cfg.freeze_after_frame:  # slam.py:193-196
             freeze_model(dec)

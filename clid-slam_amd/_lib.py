@@ -120,6 +120,12 @@ _SIGS = {
     "clid_local_window": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _i32, C.POINTER(C.c_double), C.c_double, _i32,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clid_local_to_global": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clid_sample_compact_workspace_bytes": (_i64, [_i64]),
+    "clid_sample_compact": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, C.c_float, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clid_new_sample_workspace_bytes": (_i64, [_i64]),
+    "clid_new_sample_select": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, C.c_float, C.c_float, _vp, _vp, _i64, C.c_float,
+                                         C.c_float, _i64, _vp, _vp, _vp, _vp]),
+    "clid_read_back": (C.c_int, [_vp, _i32, _vp, _vp]),
     "clid_mapping_prep": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i64, _vp, _i64, C.c_uint64, C.c_uint64, _vp]),
     "clid_debug_prep_draw": (_i64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
     "clid_comm_unique_id": (C.c_int, [_vp]),
@@ -245,6 +251,16 @@ def stream() -> int:
     if _raw_stream is not None:
         return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+def read_counts(t: torch.Tensor, n: int):
+    """The first `n` int64 counts of device tensor `t` as Python ints: ONE synchronising read-back through the library's
+    pinned landing buffer (`.item()` / `.tolist()` copy into pageable memory, several times slower)."""
+    if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and t.numel() >= n and n <= 32):
+        return [int(v) for v in t[:n].tolist()]
+    host = (C.c_int64 * n)()
+    check(load().clid_read_back(t.data_ptr(), 8 * n, host, stream()), "clid_read_back")
+    return list(host)
 
 
 def require_cuda(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:

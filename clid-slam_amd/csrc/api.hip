@@ -1,6 +1,7 @@
 // Error plumbing and ABI version of libclid_native.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "common.hpp"
 
@@ -15,3 +16,27 @@ extern "C" void clid_set_error(const char* fmt, ...) {
 
 extern "C" const char* clid_last_error(void) { return g_err; }
 extern "C" int clid_abi_version(void) { return 2; }
+
+// Small device -> host read-back through a pinned landing buffer (a pageable destination makes the runtime stage the
+// copy and block for ~100 us): the data-dependent counts of the map-maintenance calls.  Synchronises `stream`.
+extern "C" int clid_read_back(const void* device_src, int32_t bytes, void* host_dst, void* stream) {
+  static thread_local void* pinned = nullptr;
+  if (bytes < 0 || bytes > 256 || (bytes && (!device_src || !host_dst))) {
+    clid_set_error("clid_read_back: bad argument (at most 256 bytes)");
+    return CLID_E_ARG;
+  }
+  if (bytes == 0) return CLID_OK;
+  if (!pinned && hipHostMalloc(&pinned, 256, hipHostMallocDefault) != hipSuccess) {
+    pinned = nullptr;
+    clid_set_error("clid_read_back: cannot allocate the pinned buffer");
+    return CLID_E_HIP;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemcpyAsync(pinned, device_src, (size_t)bytes, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess) {
+    clid_set_error("clid_read_back: copy failed: %s", hipGetErrorString(hipGetLastError()));
+    return CLID_E_HIP;
+  }
+  memcpy(host_dst, pinned, (size_t)bytes);
+  return CLID_OK;
+}

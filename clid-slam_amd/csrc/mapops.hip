@@ -720,6 +720,165 @@ extern "C" int clid_pool_filter(const float* coord_a, const float* gcoord_a, con
   return CLID_OK;
 }
 
+// ---- sampler output -> this frame's pool rows + the points that grow the map (utils/mapper.py:240-283, :297-310) -------
+// The sampler kernel leaves [rays x samples] rows with a keep mask; the reference then runs boolean-mask indexing on three
+// arrays, a second mask |sdf| < surface_range * ratio, another indexed copy and two rigid transforms.  One flag pass, ONE
+// scan over packed (kept, near) 64-bit counters and one scatter: compacted coord / label / weight, the frame stamp, the
+// world-frame coordinates (pool) and the world-frame near-surface subset (NeuralPoints.update), stable order.
+static size_t scan64_bytes(long long n) {
+  size_t tmp = 0;
+  hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (int)n);
+  return tmp;
+}
+
+__global__ void __launch_bounds__(256)
+k_compact_flags(const unsigned char* __restrict__ keep, const float* __restrict__ label, long long n, float near_range,
+                unsigned long long* __restrict__ flag) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const bool k = keep[i] != 0;
+  const bool nr = k && fabsf(label[i]) < near_range;
+  flag[i] = (k ? 1ULL : 0ULL) | (nr ? (1ULL << 32) : 0ULL);
+}
+
+__global__ void __launch_bounds__(256)
+k_compact_scatter(const float* __restrict__ coord, const float* __restrict__ label, const float* __restrict__ weight,
+                  const unsigned long long* __restrict__ flag, const unsigned long long* __restrict__ pos, long long n,
+                  Pose12 p, int stamp, float* __restrict__ coord_out, float* __restrict__ gcoord_out,
+                  float* __restrict__ label_out, float* __restrict__ weight_out, int* __restrict__ stamp_out,
+                  float* __restrict__ update_out, long long* __restrict__ counts) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long f = flag[i], q = pos[i];
+  if (i == n - 1) {
+    counts[0] = (long long)((q + f) & 0xffffffffULL);
+    counts[1] = (long long)((q + f) >> 32);
+  }
+  if (!(f & 1ULL)) return;
+  const long long o = (long long)(q & 0xffffffffULL);
+  const float x = coord[i * 3 + 0], y = coord[i * 3 + 1], z = coord[i * 3 + 2];
+  const float gx = fmaf(z, p.T[2], fmaf(y, p.T[1], fmaf(x, p.T[0], p.T[3])));  // transform_torch (utils/tools.py:590-609)
+  const float gy = fmaf(z, p.T[6], fmaf(y, p.T[5], fmaf(x, p.T[4], p.T[7])));
+  const float gz = fmaf(z, p.T[10], fmaf(y, p.T[9], fmaf(x, p.T[8], p.T[11])));
+  coord_out[o * 3 + 0] = x; coord_out[o * 3 + 1] = y; coord_out[o * 3 + 2] = z;
+  gcoord_out[o * 3 + 0] = gx; gcoord_out[o * 3 + 1] = gy; gcoord_out[o * 3 + 2] = gz;
+  label_out[o] = label[i];
+  weight_out[o] = weight[i];
+  stamp_out[o] = stamp;
+  if (f >> 32) {
+    const long long u = (long long)(q >> 32);
+    update_out[u * 3 + 0] = gx; update_out[u * 3 + 1] = gy; update_out[u * 3 + 2] = gz;
+  }
+}
+
+extern "C" int64_t clid_sample_compact_workspace_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  return (int64_t)(2 * align256((size_t)n * 8) + align256(scan64_bytes(n)) + 256);
+}
+
+extern "C" int clid_sample_compact(const float* coord, const float* label, const float* weight, const uint8_t* keep, int64_t n,
+                                   const float* pose12_host, float near_range, int32_t stamp, float* coord_out,
+                                   float* gcoord_out, float* label_out, float* weight_out, int32_t* stamp_out,
+                                   float* update_out, int64_t* counts_out, void* workspace, void* stream) {
+  if (n < 0 || n >= (1LL << 31) || !pose12_host || !counts_out || !workspace ||
+      (n > 0 && (!coord || !label || !weight || !keep || !coord_out || !gcoord_out || !label_out || !weight_out || !stamp_out ||
+                 !update_out))) {
+    clid_set_error("clid_sample_compact: bad argument");
+    return CLID_E_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  long long* counts = reinterpret_cast<long long*>(counts_out);
+  if (n == 0) return hipMemsetAsync(counts, 0, 2 * sizeof(long long), s) == hipSuccess ? CLID_OK : CLID_E_HIP;
+  char* ws = static_cast<char*>(workspace);
+  unsigned long long* flag = reinterpret_cast<unsigned long long*>(ws);
+  unsigned long long* pos = reinterpret_cast<unsigned long long*>(ws + align256((size_t)n * 8));
+  void* cub = ws + 2 * align256((size_t)n * 8);
+  size_t cub_bytes = scan64_bytes(n);
+  Pose12 p;
+  for (int i = 0; i < 12; ++i) p.T[i] = pose12_host[i];
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_compact_flags, dim3(blocks), dim3(256), 0, s, keep, label, (long long)n, near_range, flag);
+  if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)n, s) != hipSuccess) {
+    clid_set_error("clid_sample_compact: scan failed");
+    return CLID_E_HIP;
+  }
+  hipLaunchKernelGGL(k_compact_scatter, dim3(blocks), dim3(256), 0, s, coord, label, weight, flag, pos, (long long)n, p,
+                     (int)stamp, coord_out, gcoord_out, label_out, weight_out, stamp_out, update_out, counts);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+// ---- newly observed samples (utils/mapper.py:400-423): 1-stencil certainty probe of the GLOBAL map + the two tests +
+// the ascending index list, one flag pass and one scan
+__global__ void __launch_bounds__(256)
+k_new_sample_flags(const long long* __restrict__ table, int buffer_size, const float* __restrict__ points,
+                   const float* __restrict__ cert, const int* __restrict__ delta, int P, float resolution,
+                   float max_valid_dist2, const float* __restrict__ x, const float* __restrict__ label, int n,
+                   float cert_thre, float label_max, int* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float px = x[i * 3 + 0], py = x[i * 3 + 1], pz = x[i * 3 + 2];
+  const int r0 = base_slot(px, py, pz, resolution, buffer_size);
+  float best = 0.f;  // NeuralPoints.query_certainty (model/neural_points.py:1032-1051)
+  for (int o = 0; o < P; ++o) {
+    int slot = r0 + delta[o];
+    if (slot >= buffer_size) slot -= buffer_size;
+    const long long j = table[slot];
+    if (j < 0) continue;
+    const float ax = fsub(points[j * 3 + 0], px), ay = fsub(points[j * 3 + 1], py), az = fsub(points[j * 3 + 2], pz);
+    const float d2 = fadd(fadd(fmul(ax, ax), fmul(ay, ay)), fmul(az, az));
+    if (d2 > max_valid_dist2) continue;
+    best = fmaxf(best, cert[j]);
+  }
+  flag[i] = (best < cert_thre && fabsf(label[i]) < label_max) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+k_new_sample_list(const int* __restrict__ flag, const int* __restrict__ pos, int n, long long offset,
+                  long long* __restrict__ idx_out, long long* __restrict__ count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i == n - 1) count[0] = (long long)pos[i] + flag[i];
+  if (flag[i]) idx_out[pos[i]] = offset + i;
+}
+
+extern "C" int64_t clid_new_sample_workspace_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  return (int64_t)(2 * align256((size_t)n * 4) + align256(pool_scan_bytes(n)) + 256);
+}
+
+extern "C" int clid_new_sample_select(const int64_t* buffer_pt_index, int64_t buffer_size, const float* neural_points,
+                                      const float* point_certainties, const int32_t* delta, int32_t P, float resolution,
+                                      float max_valid_dist2, const float* x, const float* sdf_label, int64_t n,
+                                      float certainty_thre, float label_max, int64_t index_offset, int64_t* idx_out,
+                                      int64_t* count_out, void* workspace, void* stream) {
+  if (n < 0 || n >= (1LL << 31) || buffer_size <= 0 || buffer_size >= (1LL << 30) || P <= 0 || !count_out || !workspace ||
+      (n > 0 && (!buffer_pt_index || !neural_points || !point_certainties || !delta || !x || !sdf_label || !idx_out))) {
+    clid_set_error("clid_new_sample_select: bad argument");
+    return CLID_E_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  long long* count = reinterpret_cast<long long*>(count_out);
+  if (n == 0) return hipMemsetAsync(count, 0, sizeof(long long), s) == hipSuccess ? CLID_OK : CLID_E_HIP;
+  char* ws = static_cast<char*>(workspace);
+  int* flag = reinterpret_cast<int*>(ws);
+  int* pos = reinterpret_cast<int*>(ws + align256((size_t)n * 4));
+  void* cub = ws + 2 * align256((size_t)n * 4);
+  size_t cub_bytes = pool_scan_bytes(n);
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_new_sample_flags, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const long long*>(buffer_pt_index),
+                     (int)buffer_size, neural_points, point_certainties, delta, P, resolution, max_valid_dist2, x, sdf_label,
+                     (int)n, certainty_thre, label_max, flag);
+  if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)n, s) != hipSuccess) {
+    clid_set_error("clid_new_sample_select: scan failed");
+    return CLID_E_HIP;
+  }
+  hipLaunchKernelGGL(k_new_sample_list, dim3(blocks), dim3(256), 0, s, flag, pos, (int)n, (long long)index_offset,
+                     reinterpret_cast<long long*>(idx_out), count);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
 // ---- local window ------------------------------------------------------------------------------------------------
 extern "C" int64_t clid_local_window_workspace_bytes(int64_t n) {
   if (n <= 0) return 1024;

@@ -103,7 +103,7 @@ class LocalPointCloudMap:
             old.data_ptr(), n_a, samples.data_ptr(), n_s, self.buffer_pt_index.data_ptr(), out_tab.data_ptr(), self.buffer_size,
             float(self.resolution), (C.c_double * 3)(*sp), float(self.map_size), int(sensor_position.dtype == torch.float64),
             out_pts.data_ptr(), self._cloud_counts.data_ptr(), self._cloud_ws.data_ptr(), _lib.stream()), "clid_cloud_update")
-        kept = int(self._cloud_counts[0].item())  # the one host round trip (sizes the map)
+        kept = _lib.read_counts(self._cloud_counts, 1)[0]  # the one host round trip (sizes the map)
         state["side"] = side
         self.local_point_cloud_map = out_pts[:kept]
         self.buffer_pt_index = out_tab

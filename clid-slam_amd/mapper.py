@@ -522,18 +522,28 @@ class Mapper:
             color = color[self.static_mask] if filter_dynamic else color
 
         normal_label = sem_label = color_label = None
+        gcoord = None
+        fused_compact = (not use_pin and pts.is_cuda and hasattr(self.sampler, "_run") and getattr(cfg, "from_sample_points", True)
+                         and not getattr(cfg, "from_all_samples", False) and os.environ.get("CLID_FUSED_COMPACT", "1") != "0")
         if use_pin:  # :224-239
             coord, sdf_label, normal_label, sem_label, color_label, weight = self.sampler.sample_pin(
                 pts, None, frame_label_torch, color)
+        elif fused_compact:
+            # :240-283 + :297-310 in one enqueue: compaction of the sampler's rows, frame stamps, world-frame coordinates for
+            # the pool and the near-surface world-frame subset that grows the map; ONE read-back for the two counts
+            coord, gcoord, sdf_label, weight, stamp, update_points = self._sample_compact_fused(pts, cur_pose_torch, frame_id)
         else:  # :240-245, the region-specific SDF estimation
             coord, sdf_label, weight = self.sampler.sample(pts, self.local_point_cloud_map, cur_pose_torch)
         n_cur = coord.shape[0]
-        stamp = torch.full((n_cur,), frame_id, dtype=torch.int, device=coord.device)
+        if not fused_compact:
+            stamp = torch.full((n_cur,), frame_id, dtype=torch.int, device=coord.device)
         self.cur_sample_count = n_cur
         self.pool_sample_count = self.sdf_label_pool.shape[0]
 
         # grow the neural-point map from the samples closest to the surface (:257-283)
-        if getattr(cfg, "from_sample_points", True):
+        if fused_compact:
+            pass
+        elif getattr(cfg, "from_sample_points", True):
             if getattr(cfg, "from_all_samples", False):
                 update_points = coord  # (sensor frame, as the reference passes it)
             else:
@@ -554,8 +564,8 @@ class Mapper:
                       and cur_pose_torch.dtype == torch.float64  # the window test is float64 by type promotion (:346-349)
                       and self.coord_pool.shape[0] + n_cur < (1 << 31) and os.environ.get("CLID_FUSED_POOL", "1") != "0")
         if fused_pool:
-            self._pool_append_filter_fused(coord, transform_torch(coord, cur_pose_torch), sdf_label, weight, stamp,
-                                           cur_pose_torch, frame_id)
+            self._pool_append_filter_fused(coord, gcoord if gcoord is not None else transform_torch(coord, cur_pose_torch),
+                                           sdf_label, weight, stamp, cur_pose_torch, frame_id)
         else:
             self._pool_append_filter_torch(coord, sdf_label, weight, stamp, sem_label, color_label, normal_label,
                                            cur_pose_torch, origin, frame_id, n_cur)
@@ -564,17 +574,20 @@ class Mapper:
         if cfg.bs_new_sample > 0:
             cur = self.global_coord_pool[self.global_coord_pool.shape[0] - self.cur_sample_count:]
             cur_label = self.sdf_label_pool[self.sdf_label_pool.shape[0] - self.cur_sample_count:]
-            certainty = torch.zeros(cur.shape[0], device=cur.device)
             nm.set_search_neighborhood(num_nei_cells=1, search_alpha=0.0)
             try:
-                for head in range(0, cur.shape[0], cfg.infer_bs):
-                    certainty[head:head + cfg.infer_bs] = nm.query_certainty(cur[head:head + cfg.infer_bs, :])
+                if self._new_sample_fused_ok(cur, cur_label):
+                    self.new_idx = self._new_sample_select_fused(cur, cur_label)
+                else:
+                    certainty = torch.zeros(cur.shape[0], device=cur.device)
+                    for head in range(0, cur.shape[0], cfg.infer_bs):
+                        certainty[head:head + cfg.infer_bs] = nm.query_certainty(cur[head:head + cfg.infer_bs, :])
+                    self.new_idx = torch.where(
+                        (certainty < getattr(cfg, "new_certainty_thre", 1.0)) & (torch.abs(cur_label) < cfg.surface_sample_range_m * 3.0)
+                    )[0]
+                    self.new_idx += self.pool_sample_count - self.cur_sample_count
             finally:
                 nm.set_search_neighborhood(num_nei_cells=cfg.num_nei_cells, search_alpha=cfg.search_alpha)
-            self.new_idx = torch.where(
-                (certainty < getattr(cfg, "new_certainty_thre", 1.0)) & (torch.abs(cur_label) < cfg.surface_sample_range_m * 3.0)
-            )[0]
-            self.new_idx += self.pool_sample_count - self.cur_sample_count
             self.adaptive_iter_offset = 0
             ratio = self.new_idx.shape[0] / max(self.cur_sample_count, 1)
             if cfg.adaptive_iters:
@@ -584,6 +597,61 @@ class Mapper:
                     self.adaptive_iter_offset = 5
                     if frame_id > cfg.freeze_after_frame and ratio > getattr(cfg, "new_sample_ratio_restart", 0.3):
                         self.adaptive_iter_offset = 10
+
+    def _sample_compact_fused(self, pts, cur_pose_torch, frame_id):
+        """Sampler launch + `clid_sample_compact`: (coord, gcoord, sdf_label, weight, stamp, update_points) of this frame
+        as utils/mapper.py:240-283 / :297-310 produce them (kept rows in order; update_points = world-frame rows with
+        |sdf| < surface_sample_range_m * map_surface_ratio)."""
+        cfg = self.config
+        lib = _lib.load()
+        coord, label, weight, keep, _ = self.sampler._run(pts, self.local_point_cloud_map, cur_pose_torch, None)
+        n, dev = coord.shape[0], coord.device
+        need = int(lib.clid_sample_compact_workspace_bytes(n))
+        if getattr(self, "_cmp_ws", None) is None or self._cmp_ws.numel() < need or self._cmp_ws.device != dev:
+            self._cmp_ws = torch.empty(int(need * 1.3) + 256, device=dev, dtype=torch.uint8)
+            self._cmp_counts = torch.zeros(2, device=dev, dtype=torch.int64)
+        out3 = torch.empty((3, max(n, 1), 3), device=dev, dtype=torch.float32)   # coord | gcoord | update_points
+        out1 = torch.empty((2, max(n, 1)), device=dev, dtype=torch.float32)      # label | weight
+        stamp = torch.empty(max(n, 1), device=dev, dtype=torch.int32)
+        T = cur_pose_torch.detach().to("cpu", torch.float32)  # transform_torch casts the pose to the points' dtype
+        pose = (C.c_float * 12)(*T[:3, :].reshape(-1).tolist())
+        near = float(cfg.surface_sample_range_m * getattr(cfg, "map_surface_ratio", 0.5))
+        _lib.check(lib.clid_sample_compact(coord.data_ptr(), label.data_ptr(), weight.data_ptr(), keep.data_ptr(), n, pose, near,
+                                           int(frame_id), out3[0].data_ptr(), out3[1].data_ptr(), out1[0].data_ptr(),
+                                           out1[1].data_ptr(), stamp.data_ptr(), out3[2].data_ptr(),
+                                           self._cmp_counts.data_ptr(), self._cmp_ws.data_ptr(), _lib.stream()),
+                   "clid_sample_compact")
+        kept, n_near = _lib.read_counts(self._cmp_counts, 2)  # the one host round trip (sizes the views)
+        return out3[0][:kept], out3[1][:kept], out1[0][:kept], out1[1][:kept], stamp[:kept], out3[2][:n_near]
+
+    def _new_sample_fused_ok(self, cur, cur_label):
+        nm = self.neural_points
+        big = nm.buffer_pt_index
+        return (cur.is_cuda and cur.dtype == torch.float32 and cur_label.dtype == torch.float32 and big is not None and big.is_cuda
+                and big.dtype == torch.int64 and int(nm.buffer_size) < (1 << 30) and nm.point_certainties.dtype == torch.float32
+                and nm.neural_points.dtype == torch.float32 and os.environ.get("CLID_FUSED_NEWSEL", "1") != "0")
+
+    def _new_sample_select_fused(self, cur, cur_label):
+        """utils/mapper.py:409-423 in one enqueue (`clid_new_sample_select`): certainty probe of the global map with the
+        current stencil, the two tests, the ascending pool indices of the selected samples; ONE read-back (their count)."""
+        cfg, nm = self.config, self.neural_points
+        lib = _lib.load()
+        n, dev = int(cur.shape[0]), cur.device
+        need = int(lib.clid_new_sample_workspace_bytes(n))
+        if getattr(self, "_new_ws", None) is None or self._new_ws.numel() < need or self._new_ws.device != dev:
+            self._new_ws = torch.empty(int(need * 1.3) + 256, device=dev, dtype=torch.uint8)
+            self._new_count = torch.zeros(1, device=dev, dtype=torch.int64)
+        idx = torch.empty(max(n, 1), device=dev, dtype=torch.int64)
+        if nm._delta.device != dev:
+            nm._delta = nm._delta.to(dev)
+        x, lab = cur.contiguous(), cur_label.contiguous()
+        _lib.check(lib.clid_new_sample_select(
+            nm.buffer_pt_index.data_ptr(), int(nm.buffer_size), _lib.require_cuda(nm.neural_points, "neural_points", torch.float32).data_ptr(),
+            nm.point_certainties.contiguous().data_ptr(), nm._delta.data_ptr(), int(nm.neighbor_K), float(nm.resolution),
+            float(nm.max_valid_dist2), x.data_ptr(), lab.data_ptr(), n, float(getattr(cfg, "new_certainty_thre", 1.0)),
+            float(cfg.surface_sample_range_m * 3.0), int(self.pool_sample_count - self.cur_sample_count), idx.data_ptr(),
+            self._new_count.data_ptr(), self._new_ws.data_ptr(), _lib.stream()), "clid_new_sample_select")
+        return idx[: _lib.read_counts(self._new_count, 1)[0]]
 
     def _pool_append_filter_torch(self, coord, sdf_label, weight, stamp, sem_label, color_label, normal_label,
                                   cur_pose_torch, origin, frame_id, n_cur):
@@ -678,7 +746,7 @@ class Mapper:
             origin, float(cfg.window_radius) ** 2, int(cfg.pool_capacity), self._pool_drop_seed,
             out["coord"].data_ptr(), out["gcoord"].data_ptr(), out["label"].data_ptr(), out["weight"].data_ptr(),
             out["time"].data_ptr(), self._pool_counts.data_ptr(), self._pool_ws.data_ptr(), _lib.stream()), "clid_pool_filter")
-        kept, kept_cur = self._pool_counts[:2].tolist()  # the one host round trip of the pool maintenance
+        kept, kept_cur = _lib.read_counts(self._pool_counts, 2)  # the one host round trip of the pool maintenance
         self._pool_side = side
         self.coord_pool, self.global_coord_pool = out["coord"][:kept], out["gcoord"][:kept]
         self.sdf_label_pool, self.weight_pool, self.time_pool = out["label"][:kept], out["weight"][:kept], out["time"][:kept]

@@ -299,7 +299,7 @@ class NeuralPoints(nn.Module):
             buf["point_ts_update"].data_ptr(), buf["point_certainties"].data_ptr(), base, _lib.ptr(travel), int(cur_ts), test_on,
             temporal, float(3 * res**2), float(self.diff_travel_dist_local), self._ins_count.data_ptr(), self._ins_ws.data_ptr(),
             _lib.stream()), "clid_map_insert")
-        n_new = int(self._ins_count.item())  # the one host round trip of the insert (sizes the views)
+        n_new = _lib.read_counts(self._ins_count, 1)[0]  # the one host round trip of the insert (sizes the views)
         total = base + n_new
         feat = buf["geo_features"]
         if self.geo_feature_std != 0:
@@ -412,7 +412,7 @@ class NeuralPoints(nn.Module):
             self.point_orientations.data_ptr(), self.point_certainties.data_ptr(), self.geo_features.data_ptr(),
             ids.data_ptr(), g2l.data_ptr(), mask.data_ptr(), l_pts.data_ptr(), l_ori.data_ptr(), l_cert.data_ptr(),
             l_ts.data_ptr(), l_feat.data_ptr(), self._win_counts.data_ptr(), self._win_ws.data_ptr(), _lib.stream()), "clid_local_window")
-        m = int(self._win_counts[1].item())  # the one host round trip: sizes the local arrays
+        m = _lib.read_counts(self._win_counts, 2)[1]  # the one host round trip: sizes the local arrays
         self.local_neural_points, self.local_point_orientations = l_pts[:m], l_ori[:m]
         self.local_point_certainties, self.local_point_ts_update = l_cert[:m], l_ts[:m]
         self.local_mask, self.global2local = mask, g2l

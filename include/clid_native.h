@@ -52,6 +52,9 @@ extern "C" {
 
 const char* clid_last_error(void);
 int clid_abi_version(void);
+/* Copy at most 256 bytes from device memory to `host_dst` through a pinned landing buffer and synchronise `stream`: the
+ * one read-back of a map-maintenance call (data-dependent counts). */
+int clid_read_back(const void* device_src, int32_t bytes, void* host_dst, void* stream);
 
 /* ---- neural-point map view ------------------------------------------------------------------
  * What the kernels read of `NeuralPoints` (model/neural_points.py:79-133).  `tab`/`pos4` are a
@@ -398,6 +401,29 @@ int clid_local_window(const float* neural_points, const int32_t* ts_create, cons
 int clid_local_to_global(const int64_t* ids, int32_t n, int64_t pad_row, const float* local_feat,
                          const float* local_cert, const int32_t* local_ts, float* global_feat, float* global_cert,
                          int32_t* global_ts, void* stream);
+
+/* Sampler output -> this frame's pool rows and the points that grow the map (utils/mapper.py:240-283, :297-310) in one
+ * flag pass + one scan + one scatter.  Inputs: the [n] rows clid_sample_frame wrote (coord [n,3] sensor frame, label,
+ * weight, keep mask), the pose (12 floats, row-major 3x4, host), near_range = surface_sample_range_m * map_surface_ratio,
+ * the frame stamp.  Outputs (capacity n rows each, stable order): rows with keep != 0 -> coord_out, gcoord_out (= pose *
+ * coord, transform_torch arithmetic), label_out, weight_out, stamp_out; of those, rows with |label| < near_range ->
+ * update_out (world frame).  counts_out (device, 2 x int64) = {kept, near}. */
+int64_t clid_sample_compact_workspace_bytes(int64_t n);
+int clid_sample_compact(const float* coord, const float* label, const float* weight, const uint8_t* keep, int64_t n,
+                        const float* pose12_host, float near_range, int32_t stamp, float* coord_out, float* gcoord_out,
+                        float* label_out, float* weight_out, int32_t* stamp_out, float* update_out, int64_t* counts_out,
+                        void* workspace, void* stream);
+
+/* Newly observed samples of a frame (utils/mapper.py:400-423): certainty of the sample's probe cells in the GLOBAL map
+ * (NeuralPoints.query_certainty with the stencil `delta` [P], model/neural_points.py:1032-1051) < certainty_thre and
+ * |sdf_label| < label_max; idx_out = index_offset + position of the selected samples, ascending; count_out (device, 1 x
+ * int64). */
+int64_t clid_new_sample_workspace_bytes(int64_t n);
+int clid_new_sample_select(const int64_t* buffer_pt_index, int64_t buffer_size, const float* neural_points,
+                           const float* point_certainties, const int32_t* delta, int32_t P, float resolution,
+                           float max_valid_dist2, const float* x, const float* sdf_label, int64_t n, float certainty_thre,
+                           float label_max, int64_t index_offset, int64_t* idx_out, int64_t* count_out, void* workspace,
+                           void* stream);
 
 /* Per-call preparation of Mapper.mapping in one launch: zero `zero_floats` floats at `zero_base` (16-byte aligned,
  * multiple of 4: the fused gradient buffer, the Adam state and the loss rows restart every call, utils/mapper.py:634) and
