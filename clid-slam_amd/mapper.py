@@ -555,15 +555,30 @@ class Mapper:
             if nm.prune_map(cfg.max_prune_certainty):
                 nm.recreate_hash(None, None, True, True, frame_id)
         nm._sensor_pos_host = (origin, tuple(float(v) for v in cur_pose_torch[:3, 3].tolist()))  # spares reset_local_map a read-back
-        self.cur_new_point_ratio = nm.update(update_points, origin, orientation, frame_id)
-
-        self.determine_used_pose()
         fused_pool = (coord.is_cuda and sem_label is None and color_label is None and normal_label is None
                       and self.sem_label_pool is None and self.color_pool is None and self.normal_label_pool is None
                       and not self.ba_done_flag and (frame_id + 1) % getattr(cfg, "pool_filter_freq", 1) == 0
                       and cur_pose_torch.dtype == torch.float64  # the window test is float64 by type promotion (:346-349)
                       and self.coord_pool.shape[0] + n_cur < (1 << 31) and os.environ.get("CLID_FUSED_POOL", "1") != "0")
-        if fused_pool:
+        # The pool maintenance (:297-392) and the map growth (:257-283) touch disjoint state: the pool's launches (the
+        # frame's largest, bandwidth-bound at a full pool) go to a side stream and run under NeuralPoints.update, whose
+        # launches are small and separated by its read-backs; joined before anything reads the pool.
+        overlap = fused_pool and gcoord is not None and os.environ.get("CLID_POOL_OVERLAP", "1") != "0"
+        if overlap:
+            main = torch.cuda.current_stream(coord.device)
+            side = getattr(self, "_side_stream", None)
+            if side is None or side.device != coord.device:
+                side = self._side_stream = torch.cuda.Stream(device=coord.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._pool_append_filter_fused(coord, gcoord, sdf_label, weight, stamp, cur_pose_torch, frame_id, defer=True)
+        self.cur_new_point_ratio = nm.update(update_points, origin, orientation, frame_id)
+
+        self.determine_used_pose()
+        if overlap:
+            main.wait_stream(side)
+            self._pool_filter_finish()
+        elif fused_pool:
             self._pool_append_filter_fused(coord, gcoord if gcoord is not None else transform_torch(coord, cur_pose_torch),
                                            sdf_label, weight, stamp, cur_pose_torch, frame_id)
         else:
@@ -708,7 +723,7 @@ class Mapper:
             self.pool_sample_count = self.coord_pool.shape[0]
 
 
-    def _pool_append_filter_fused(self, coord, gcoord, sdf_label, weight, stamp, cur_pose_torch, frame_id):
+    def _pool_append_filter_fused(self, coord, gcoord, sdf_label, weight, stamp, cur_pose_torch, frame_id, defer=False):
         """utils/mapper.py:297-392 in one enqueue (csrc/mapops.hip clid_pool_filter): append this frame's samples, window
         test in float64, random drop above `pool_capacity`, stable compaction of the five arrays into the other half of a
         ping-pong buffer; ONE small read-back for the two counts the host needs (pool size for the batch draws, number
@@ -746,6 +761,13 @@ class Mapper:
             origin, float(cfg.window_radius) ** 2, int(cfg.pool_capacity), self._pool_drop_seed,
             out["coord"].data_ptr(), out["gcoord"].data_ptr(), out["label"].data_ptr(), out["weight"].data_ptr(),
             out["time"].data_ptr(), self._pool_counts.data_ptr(), self._pool_ws.data_ptr(), _lib.stream()), "clid_pool_filter")
+        self._pool_pending = (side, out, (a, b))  # (inputs stay referenced until the launches have been joined)
+        if not defer:
+            self._pool_filter_finish()
+
+    def _pool_filter_finish(self):
+        side, out, _ = self._pool_pending
+        self._pool_pending = None
         kept, kept_cur = _lib.read_counts(self._pool_counts, 2)  # the one host round trip of the pool maintenance
         self._pool_side = side
         self.coord_pool, self.global_coord_pool = out["coord"][:kept], out["gcoord"][:kept]
