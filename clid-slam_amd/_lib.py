@@ -263,6 +263,16 @@ def read_counts(t: torch.Tensor, n: int):
     return list(host)
 
 
+def small_to_host(t: torch.Tensor) -> torch.Tensor:
+    """`t.detach().cpu()` for a tensor of at most 256 bytes (a pose) through the pinned landing buffer."""
+    t = t.detach()
+    if not (t.is_cuda and t.is_contiguous() and 0 < t.numel() * t.element_size() <= 256):
+        return t.cpu()
+    out = torch.empty(t.shape, dtype=t.dtype)
+    check(load().clid_read_back(t.data_ptr(), t.numel() * t.element_size(), out.data_ptr(), stream()), "clid_read_back")
+    return out
+
+
 def require_cuda(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")

@@ -502,7 +502,7 @@ class Mapper:
             self.sampler = DataSampler(cfg)
         origin = cur_pose_torch[:3, 3]
         orientation = cur_pose_torch[:3, :3]
-        cur_pose_torch = cur_pose_torch.detach().cpu()  # one read-back: the kernels take the 12 pose numbers by value
+        cur_pose_torch = _lib.small_to_host(cur_pose_torch)  # one read-back: the kernels take the 12 pose numbers by value
         pts = point_cloud_torch[:, :3]
         use_pin = bool(getattr(cfg, "use_pin_mapper", False))
         if not use_pin:  # :178-183
