@@ -227,10 +227,15 @@ def main():
     for _ in range(args.warmup):  # W untimed steps, one per call: the GPU's clocks ramp over several hundred us of work
         mp.mapping(1)             # (a single 5-iteration call leaves the first timed call 14 % slow: tools/warm_clocks.py)
     sync()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     mp.mapping(args.steps)
+    ev1.record()
+    t_enq = time.perf_counter() - t0
     sync()
     dt = time.perf_counter() - t0
+    timed_split = {"host_enqueue_ms": 1e3 * t_enq, "gpu_ms": float(ev0.elapsed_time(ev1)), "wall_ms": 1e3 * dt}
     if dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -311,6 +316,7 @@ def main():
             },
             "final_loss": {"total": losses[0], "bce": losses[1], "eikonal": losses[2]},
             "per_frame_regime": frame, "roofline": roof, "cpu_baseline": base,
+            "timed_region_split": timed_split,  # host time to enqueue the K steps | GPU time between events | wall clock
         }
         if base:
             line["speedup_vs_cpu_baseline"] = value / base["value"]
