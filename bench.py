@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--decode", type=int, default=None, choices=(0, 1, 2), help="override the decode kernel (clid_decode_variant)")
     ap.add_argument("--frame-calls", type=int, default=100, help="repetitions of mapping(10) for the per-frame regime (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layer-norm", action="store_true", help="layer_norm_on: True (run_SubT_MRS.yaml:27) instead of the ncd128 default")
     ap.add_argument("--freeze-decoder", action="store_true",
                     help="steady-state variant: decoder frozen (freeze_model, slam.py:193-196); not the headline config")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for single-GPU dry runs)")
@@ -196,6 +197,7 @@ def main():
     from clid_slam_amd import HotPathConfig, _lib
 
     cfg = HotPathConfig()  # == config/run_ncd128.yaml resolved values (SURVEY.md section 8 header)
+    cfg.layer_norm_on = bool(args.layer_norm)
     cfg.device = device
     if wl["scaling"] == "strong":
         if wl["bs"] % world:
@@ -308,7 +310,7 @@ def main():
             "config": {
                 "workload": f"{args.config}: {wl['what']}; numerical eikonal (decimation {decim}), Adam; synthetic box-room "
                             "Ouster-128 scan",
-                "bs_per_gpu": bs_local, "global_batch": bs_global, "decoder_frozen": bool(args.freeze_decoder),
+                "bs_per_gpu": bs_local, "global_batch": bs_global, "decoder_frozen": bool(args.freeze_decoder), "layer_norm_on": bool(args.layer_norm),
                 "decode_kernel": wl["decode"], "query_points_per_step_per_gpu": bs_local + 6 * ((bs_local + decim - 1) // decim),
                 "neural_points_local": M, "pool_samples": int(mp.pool_sample_count), "buffer_size": cfg.buffer_size,
                 "parallelism": f"dp{world} (batch sharded, RCCL all-reduce of [decoder|feature] grads)" if world > 1 else "single GPU",

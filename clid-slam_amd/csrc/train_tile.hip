@@ -60,6 +60,13 @@ struct alignas(16) TileLds {
   int hrow[kHash];           // hash slot -> row number inside the tile
   int rowid[kMaxRows];       // row number -> map row id
   int count;                 // distinct rows of the tile
+  int pad_[3];
+};
+// layer-norm variants: what F.layer_norm's backward needs of every distinct row, saved by the forward pass
+struct alignas(16) TileLnLds {
+  float xh[kMaxRows * CLID_F];  // [row][c]: normalised features
+  float rs[kMaxRows];           // [row]: 1 / sqrt(var + eps)
+  int rown[16 * 8];             // [q][k]: row number of neighbour k of query q (-1: none)
 };
 
 __device__ __forceinline__ float xsum16(float v) {  // v[lane] + v[lane ^ 16]
@@ -93,10 +100,12 @@ __global__ void __launch_bounds__(TW * 64, CLID_TILE_WAVES)
 k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap,
               const float4* __restrict__ rec, int n_tiles, float* __restrict__ sdf_dbg) {
   __shared__ TileLds tls[TW];
+  __shared__ TileLnLds lns[LN ? TW : 1];
   static_assert(sizeof(TileLds) % 16 == 0 && sizeof(TileLds) * TW >= TW * kRedFloats * sizeof(float), "LDS plan");
   float* red = reinterpret_cast<float*>(tls);  // the block flush reuses the tile buffers (after a barrier)
   const int lane = threadIdx.x & 63, q = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
   TileLds& tl = tls[wave];
+  TileLnLds& ln = lns[LN ? wave : 0];
   const bool train = ta.train_decoder != 0;
   const float sc = ta.sdf_scale;
   const float inv_sigma = fdiv(1.0f, ta.sigma);
@@ -181,7 +190,7 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
       if (j[k] < 0) w[k] = 0.f;
     }
     CLID_STAMP(2);
-    // ================= gather + blend of this lane's 4 decoder-input columns
+    // ================= gather of this lane's 4 decoder-input columns: the loads are issued first ...
     float4 v[CLID_K];
     int ts_old[CLID_K];
 #pragma unroll
@@ -192,6 +201,62 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
       if (g < 2) v[k] = feat4[(size_t)jc * 2 + g];
       else if (g == 3 && mv.ts_update && j[k] >= 0) ts_old[k] = mv.ts_update[jc];
     }
+    // ================= ... and in their shadow the tile's (query, neighbour) pairs are numbered per distinct map row
+    // through the LDS hash (ids and weights come from the record, not from the gather), and Wm[row][query] is filled
+    tl.hkey[lane] = -1;
+    tl.hkey[lane + 64] = -1;
+    if (lane == 0) tl.count = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxRows * 16 / (64 * 4); ++i)
+      *reinterpret_cast<float4*>(&tl.wm[(i * 64 + lane) * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    tile_lds_fence();
+    // lane (q, g) numbers neighbours k = g and (g < 2) k = g + 4 of its query.  A query's own list may name a row twice
+    // (two colliding cells returning the same point): the first occurrence carries the sum of the weights
+    int hs[2] = {-1, -1};
+    float wsum[2] = {0.f, 0.f};
+    bool first[2] = {false, false};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int k = g + 4 * t;
+      int jk = -1;
+#pragma unroll
+      for (int kk = 0; kk < CLID_K; ++kk) jk = (kk == k) ? j[kk] : jk;
+      bool fst = true;
+      float tot = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < CLID_K; ++kk) {  // ascending, so the sum has the order of a sequential fold
+        const bool same = j[kk] == jk;
+        if (same && kk < k) fst = false;
+        if (same) tot += w[kk];
+      }
+      if (k < CLID_K && jk >= 0) {
+        unsigned h = ((unsigned)jk * 2654435761u) >> 25;  // 7 bits
+        for (;;) {
+          const int old = atomicCAS(&tl.hkey[h], -1, jk);
+          if (old == -1) {  // first pair of this row in the tile: take the next row number
+            const int d = atomicAdd(&tl.count, 1);
+            tl.hrow[h] = d;
+            tl.rowid[d] = jk;
+            break;
+          }
+          if (old == jk) break;
+          h = (h + 1) & (kHash - 1);
+        }
+        hs[t] = (int)h;
+        first[t] = fst;
+        wsum[t] = tot;
+      }
+    }
+    tile_lds_fence();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int k = g + 4 * t;
+      const int row = hs[t] >= 0 ? tl.hrow[hs[t]] : -1;
+      if (first[t]) tl.wm[row * 16 + q] = wsum[t];
+      if (LN && k < CLID_K) ln.rown[q * 8 + k] = row;
+    }
+    tile_lds_fence();
+    CLID_STAMP(8);
     if (LN) {  // F.layer_norm over the 8 features of every neighbour row (np.py:632-633); lanes g = 0,1 hold the halves
 #pragma unroll
       for (int k = 0; k < CLID_K; ++k) {
@@ -200,7 +265,15 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
         const float var = xsum16((c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w)) * (1.0f / CLID_F);
         const float rstd = 1.0f / sqrtf(var + 1e-5f);
         v[k] = make_float4(c.x * rstd, c.y * rstd, c.z * rstd, c.w * rstd);
+        // the backward of this row (applied once to the merged gradient below) reads what autograd would have saved;
+        // pairs that share the row store identical values
+        const int row = ln.rown[q * 8 + k];
+        if (g < 2 && row >= 0) {
+          *reinterpret_cast<float4*>(&ln.xh[row * CLID_F + 4 * g]) = v[k];
+          if (g == 0) ln.rs[row] = rstd;
+        }
       }
+      tile_lds_fence();
     }
     CLID_STAMP(3);
     float pc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -317,64 +390,14 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
       }
     }
     CLID_STAMP(7);
-    // ================= scatter: merge the tile's (query, neighbour) pairs per map row, one request per row
-    // a query's own list may name a row twice (two colliding cells returning the same point): fold the weights
-#pragma unroll
-    for (int k = 1; k < CLID_K; ++k)
-#pragma unroll
-      for (int k2 = 0; k2 < k; ++k2)
-        if (j[k] >= 0 && j[k] == j[k2]) {
-          w[k2] += w[k];
-          j[k] = -1;
-        }
-    tl.hkey[lane] = -1;
-    tl.hkey[lane + 64] = -1;
-    if (lane == 0) tl.count = 0;
-#pragma unroll
-    for (int i = 0; i < kMaxRows * 16 / (64 * 4); ++i)
-      *reinterpret_cast<float4*>(&tl.wm[(i * 64 + lane) * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (train) {  // stage dh and f for the dW1 contraction (same fences)
+    // ================= scatter: the tile's pairs were numbered per map row above; G = Wm x d f, one request per row
+    if (train) {  // stage dh and f for the dW1 contraction
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         *reinterpret_cast<float4*>(&tl.dh[q * kDhStride + 16 * u + 4 * g]) = make_float4(dh[u][0], dh[u][1], dh[u][2], dh[u][3]);
       *reinterpret_cast<float4*>(&tl.f[q * kFStride + 4 * g]) = make_float4(pc[0], pc[1], pc[2], pc[3]);
+      tile_lds_fence();
     }
-    tile_lds_fence();
-    // lane (q, g) numbers neighbours k = g and (g < 2) k = g + 4 of its query
-    int hs[2] = {-1, -1};
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int k = g + 4 * t;
-      int jk = -1;
-#pragma unroll
-      for (int kk = 0; kk < CLID_K; ++kk) jk = (kk == k) ? j[kk] : jk;
-      if (k < CLID_K && jk >= 0) {
-        unsigned h = ((unsigned)jk * 2654435761u) >> 25;  // 7 bits
-        for (;;) {
-          const int old = atomicCAS(&tl.hkey[h], -1, jk);
-          if (old == -1) {  // first pair of this row in the tile: take the next row number
-            const int d = atomicAdd(&tl.count, 1);
-            tl.hrow[h] = d;
-            tl.rowid[d] = jk;
-            break;
-          }
-          if (old == jk) break;
-          h = (h + 1) & (kHash - 1);
-        }
-        hs[t] = (int)h;
-      }
-    }
-    tile_lds_fence();
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int k = g + 4 * t;
-      float wk = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < CLID_K; ++kk) wk = (kk == k) ? w[kk] : wk;
-      if (hs[t] >= 0) tl.wm[tl.hrow[hs[t]] * 16 + q] = wk;
-    }
-    tile_lds_fence();
-    CLID_STAMP(8);
     {
       const bool do_cert = !(ta.debug_flags & 1), do_grad = !(ta.debug_flags & 2);
       const bool act = q < CLID_F ? do_grad : (q == CLID_F && do_cert);
@@ -397,16 +420,10 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
           const bool live_row = t0 + 4 * g + rr < n_rows;
           float val = G[rr];
           if (LN) {  // layer-norm backward of the row, once (linear in the incoming gradient; np.py:632-633)
-            const int idc = live_row ? id4[rr] : 0;
-            const float th = q < CLID_F ? mv.feat[(size_t)idc * CLID_F + q] : 0.f;
-            float s1 = th, gsum = q < CLID_F ? val : 0.f;
-            s1 += dpp_mov<0xB1>(s1); s1 += dpp_mov<0x4E>(s1); s1 += dpp_mov<0x141>(s1);
-            const float mu = s1 * (1.0f / CLID_F);
-            const float xc = th - mu;
-            float s2 = xc * xc;
-            s2 += dpp_mov<0xB1>(s2); s2 += dpp_mov<0x4E>(s2); s2 += dpp_mov<0x141>(s2);
-            const float rstd = 1.0f / sqrtf(s2 * (1.0f / CLID_F) + 1e-5f);
-            const float xh = xc * rstd;
+            const int rl = live_row ? t0 + 4 * g + rr : 0;
+            const float xh = q < CLID_F ? ln.xh[rl * CLID_F + q] : 0.f;
+            const float rstd = ln.rs[rl];
+            float gsum = q < CLID_F ? val : 0.f;
             float gx = gsum * xh;
             gsum += dpp_mov<0xB1>(gsum); gsum += dpp_mov<0x4E>(gsum); gsum += dpp_mov<0x141>(gsum);
             gx += dpp_mov<0xB1>(gx); gx += dpp_mov<0x4E>(gx); gx += dpp_mov<0x141>(gx);
