@@ -624,10 +624,23 @@ __host__ __device__ inline unsigned long long clid_mix64(unsigned long long seed
   return z ^ (z >> 31);
 }
 
+// 8 bits per axis of the sample's voxel coordinate, interleaved (x lowest): the order the sorted variant presents a batch in
+__device__ __forceinline__ unsigned morton24(int cx, int cy, int cz) {
+  auto spread = [](unsigned v) {
+    v &= 0xFFu;
+    v = (v | (v << 8)) & 0x00F00Fu;
+    v = (v | (v << 4)) & 0x0C30C3u;
+    v = (v | (v << 2)) & 0x249249u;
+    return v;
+  };
+  return spread((unsigned)cx) | (spread((unsigned)cy) << 1) | (spread((unsigned)cz) << 2);
+}
+
 __global__ void __launch_bounds__(256)
 k_mapping_prep(float4* __restrict__ zero4, long long n_zero4, long long* __restrict__ index_out, long long n_index, int bs,
                int bs_new, unsigned long long pool_count, const long long* __restrict__ new_idx, unsigned long long n_new,
-               unsigned long long seed, unsigned long long counter) {
+               unsigned long long seed, unsigned long long counter, const float* __restrict__ pool_coord, float resolution,
+               unsigned* __restrict__ key_out) {
   const long long stride = (long long)gridDim.x * 256;
   const long long t0 = (long long)blockIdx.x * 256 + threadIdx.x;
   for (long long i = t0; i < n_zero4; i += stride) zero4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -639,28 +652,169 @@ k_mapping_prep(float4* __restrict__ zero4, long long n_zero4, long long* __restr
     if (col < n_hist) v = (long long)__umul64hi(r, pool_count);
     else v = new_idx[__umul64hi(r, n_new)];
     index_out[e] = v;
+    if (key_out) {  // Morton code of the sample's voxel (8 bits per axis: wraps every 256 voxels): the sort key of k_batch_sort
+      struct F3 {
+        float x, y, z;
+      };
+      const F3 c = reinterpret_cast<const F3*>(pool_coord)[v];
+      key_out[e] = morton24((int)floorf(fdiv(c.x, resolution)), (int)floorf(fdiv(c.y, resolution)),
+                            (int)floorf(fdiv(c.z, resolution)));
+    }
   }
+}
+
+// Spatially ordered variant: one 1024-thread block per (iteration, 16 384-sample segment of the batch) redraws the
+// segment's samples (the draw is a pure function of the position), keys them by the Morton code of their voxel (8 bits per
+// axis: wraps every 256 voxels) and sorts (key, position) in LDS with a stable block radix sort, so the order is a function
+// of the draws alone: identical on every rank.  The zero fill is shared by all blocks.
+#ifndef CLID_SORT_SEG
+#define CLID_SORT_SEG 16384
+#endif
+constexpr int kSortSeg = CLID_SORT_SEG, kSortThreads = 1024, kSortItems = kSortSeg / kSortThreads, kSortBins = 256;
+constexpr int kSortWaves = kSortThreads / 64;
+using BinScan = hipcub::BlockScan<unsigned, kSortThreads>;
+
+// lanes of the wave that hold the same 8-bit digit as this lane (an OR-mask row in LDS per wave does the same with two LDS
+// operations, but the block is LDS-throughput-bound on its one CU: 60 vs 54 us)
+__device__ __forceinline__ unsigned long long match8(unsigned d) {
+  unsigned long long m = ~0ULL;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const unsigned long long s = __ballot((d >> b) & 1u);
+    m &= ((d >> b) & 1u) ? s : ~s;
+  }
+  return m;
+}
+
+// One stable counting-sort pass over a 16 384-element sequence held 16 per thread in WAVE-BLOCKED order: element
+// (wave, r, lane) is sequence position wave * 1024 + r * 64 + lane.  A wave walks its 1024 elements in order, so the rank
+// of an element among the equal digits of ITS wave is (running count of the digit in the wave's column of `tab`) + (equal
+// digits in lower lanes, from ballots); one exclusive scan over tab[digit][wave] then turns the columns into global
+// offsets.  No atomic decides an order: the permutation is a function of the digits alone.  Three barriers per pass.
+__device__ __forceinline__ void counting_pass(const unsigned (&digit)[kSortItems], unsigned (&dest)[kSortItems], unsigned* tab,
+                                              typename BinScan::TempStorage& scan_tmp) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < kSortBins * kSortWaves; i += kSortThreads) tab[i] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const unsigned d = digit[r];
+    const unsigned long long peers = match8(d);
+    const unsigned rk = (unsigned)__popcll(peers & ((1ULL << lane) - 1ULL));
+    const int leader = __ffsll((long long)peers) - 1;
+    unsigned old = 0;
+    if (rk == 0) {  // (lane == leader) only this wave touches its column, in program order
+      old = tab[d * kSortWaves + wave];
+      tab[d * kSortWaves + wave] = old + (unsigned)__popcll(peers);
+    }
+    dest[r] = (unsigned)__shfl((int)old, leader, 64) + rk;  // rank among the wave's equal digits so far
+  }
+  __syncthreads();
+  {  // exclusive scan over [digit][wave]: 4 consecutive entries per thread
+    constexpr int kPer = kSortBins * kSortWaves / kSortThreads;
+    const int b0 = threadIdx.x * kPer;
+    unsigned c[kPer], sum = 0;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      c[i] = tab[b0 + i];
+      sum += c[i];
+    }
+    unsigned off;
+    BinScan(scan_tmp).ExclusiveSum(sum, off);
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      tab[b0 + i] = off;
+      off += c[i];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) dest[r] += tab[digit[r] * kSortWaves + wave];
+  __syncthreads();
+}
+
+// Spatially ordered batches: one 1024-thread block per (iteration, 16 384-sample segment of the batch) orders the segment's
+// draws by (Morton code of the sample's voxel, draw position) -- a total order, so the result is a function of the draws
+// alone, identical on every rank -- through three stable 8-bit counting passes in LDS.  draws / keys come from
+// k_mapping_prep (computed by the whole chip: the 16 k random 12-byte gathers of a segment take 25 us through one CU's L1).
+__global__ void __launch_bounds__(kSortThreads)
+k_batch_sort(const long long* __restrict__ draws, const unsigned* __restrict__ keys, long long* __restrict__ index_out, int bs) {
+  __shared__ unsigned tab[kSortBins * kSortWaves];  // [digit][wave]
+  __shared__ unsigned seq[kSortSeg];                // the sequence between passes: (remaining code << 14) | draw position
+  __shared__ typename BinScan::TempStorage scan_tmp;
+  const int segs = (bs + kSortSeg - 1) / kSortSeg;
+  const int it = blockIdx.x / segs, seg = blockIdx.x - it * segs;
+  const int base = seg * kSortSeg;
+  const int n = bs - base < kSortSeg ? bs - base : kSortSeg;
+  const long long e0 = (long long)it * bs + base;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int p0 = wave * (kSortItems * 64) + lane;  // sequence position of item r: p0 + 64 r
+  unsigned key[kSortItems], digit[kSortItems], dest[kSortItems];
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const int p = p0 + 64 * r;
+    key[r] = p < n ? keys[e0 + p] : 0xFFFFFFu;  // padding of a short segment: behind every real element
+    digit[r] = key[r] & 0xFFu;
+  }
+  counting_pass(digit, dest, tab, scan_tmp);
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) seq[dest[r]] = ((key[r] >> 8) << 14) | (unsigned)(p0 + 64 * r);
+  __syncthreads();
+  unsigned s[kSortItems];
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    s[r] = seq[p0 + 64 * r];
+    digit[r] = (s[r] >> 14) & 0xFFu;
+  }
+  counting_pass(digit, dest, tab, scan_tmp);  // (its barriers also cover the reads of seq above)
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) seq[dest[r]] = ((s[r] >> 22) << 14) | (s[r] & 0x3FFFu);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    s[r] = seq[p0 + 64 * r];
+    digit[r] = (s[r] >> 14) & 0xFFu;
+  }
+  counting_pass(digit, dest, tab, scan_tmp);
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r)
+    if ((int)dest[r] < n) index_out[e0 + dest[r]] = draws[e0 + (s[r] & 0x3FFFu)];
+}
+
+extern "C" int64_t clid_mapping_prep_workspace_bytes(int32_t iters, int32_t bs) {
+  const long long n = (long long)iters * bs;
+  if (n <= 0) return 256;
+  return (int64_t)(align256((size_t)n * 8) + align256((size_t)n * 4) + 256);  // unsorted draws | keys
 }
 
 extern "C" int clid_mapping_prep(float* zero_base, int64_t zero_floats, int64_t* index_out, int32_t iters, int32_t bs,
                                  int32_t bs_new, int64_t pool_count, const int64_t* new_idx, int64_t n_new, uint64_t seed,
-                                 uint64_t counter, void* stream) {
+                                 uint64_t counter, const float* pool_coord, float resolution, void* sort_workspace,
+                                 void* stream) {
   if (zero_floats < 0 || (zero_floats && (!zero_base || (zero_floats & 3) || ((uintptr_t)zero_base & 15))) || iters < 0 ||
       bs < 0 || bs_new < 0 || bs_new > bs || (iters && bs && !index_out) || (index_out && iters && bs && pool_count <= 0) ||
-      (bs_new > 0 && (!new_idx || n_new <= 0))) {
+      (bs_new > 0 && (!new_idx || n_new <= 0)) || (sort_workspace && (!pool_coord || !(resolution > 0.f)))) {
     clid_set_error("clid_mapping_prep: bad argument");
     return CLID_E_ARG;
   }
+  hipStream_t s = (hipStream_t)stream;
   const long long n_index = index_out ? (long long)iters * bs : 0;
   const long long work = (zero_floats / 4 > n_index ? zero_floats / 4 : n_index);
   if (work == 0) return CLID_OK;
+  const long long sort_blocks = (long long)iters * ((bs + kSortSeg - 1) / kSortSeg);
+  const bool sorted = sort_workspace && n_index > 0 && sort_blocks <= 65535;
+  char* ws = static_cast<char*>(sort_workspace);
+  long long* draws = sorted ? reinterpret_cast<long long*>(ws) : reinterpret_cast<long long*>(index_out);
+  unsigned* keys = sorted ? reinterpret_cast<unsigned*>(ws + align256((size_t)n_index * 8)) : nullptr;
   long long blocks = (work + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_mapping_prep, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<float4*>(zero_base), (long long)(zero_floats / 4),
-                     reinterpret_cast<long long*>(index_out), n_index, bs, bs_new, (unsigned long long)pool_count,
+  hipLaunchKernelGGL(k_mapping_prep, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<float4*>(zero_base),
+                     (long long)(zero_floats / 4), draws, n_index, bs, bs_new, (unsigned long long)pool_count,
                      reinterpret_cast<const long long*>(new_idx), (unsigned long long)n_new, (unsigned long long)seed,
-                     (unsigned long long)counter);
+                     (unsigned long long)counter, pool_coord, resolution, keys);
+  if (sorted)
+    hipLaunchKernelGGL(k_batch_sort, dim3((unsigned)sort_blocks), dim3(kSortThreads), 0, s, draws, keys,
+                       reinterpret_cast<long long*>(index_out), bs);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

@@ -145,6 +145,8 @@ class Mapper:
             return torch.randint(0, self.pool_sample_count, (iters, bs), device=dev, generator=self._gen, out=out)
         return torch.randint(0, self.pool_sample_count, (iters, bs), device=dev, generator=self._gen)
 
+    SORT_BATCH_MIN_ITERS = 32
+
     def _prepare_call(self, iters: int, bs: int, n_rows: int, dev, lib):
         """Workspace reset + batch draw of one `mapping()` call in ONE launch (`clid_mapping_prep`): the composition rule
         of `_draw_index` (utils/mapper.py:473-500) with a counter-based generator keyed on (seed, call number), so every
@@ -164,8 +166,23 @@ class Mapper:
             bs_new, new_ptr, n_new = min(new_idx.shape[0], self.config.bs_new_sample, bs), new_idx.data_ptr(), new_idx.shape[0]
         self._draw_calls = getattr(self, "_draw_calls", 0) + 1
         seed = int(getattr(self, "_seed", getattr(self.config, "seed", 42))) & 0xFFFFFFFFFFFFFFFF
+        # spatially ordered batches (the same draws, each 16 384-sample segment written in Morton order of the samples'
+        # voxels by a second launch; both run while the host assembles the loop's arguments).  CLID_SORT_BATCH=0 keeps the
+        # draw order.
+        coord_ptr, sort_ptr = None, None
+        sort_mode = os.environ.get("CLID_SORT_BATCH", "auto")  # auto: calls long enough for the kernels' gain (3 us per
+        # iteration at 16 384 samples) to exceed the ordering launch (54 us); 1: always; 0: never
+        if ((sort_mode == "1" or (sort_mode != "0" and iters >= self.SORT_BATCH_MIN_ITERS))
+                and self.global_coord_pool.dtype == torch.float32):
+            need = int(lib.clid_mapping_prep_workspace_bytes(iters, bs))
+            ws = getattr(self, "_sort_ws", None)
+            if ws is None or ws.numel() < need or ws.device != torch.device(dev):
+                ws = self._sort_ws = torch.empty(int(need * 1.25) + 256, device=dev, dtype=torch.uint8)
+            coord_ptr = _lib.require_cuda(self.global_coord_pool, "global_coord_pool", torch.float32).data_ptr()
+            sort_ptr = ws.data_ptr()
         _lib.check(lib.clid_mapping_prep(self._flat.data_ptr(), self._flat_used, buf.data_ptr(), iters, bs, bs_new,
-                                         int(self.pool_sample_count), new_ptr, n_new, seed, self._draw_calls, _lib.stream()),
+                                         int(self.pool_sample_count), new_ptr, n_new, seed, self._draw_calls, coord_ptr,
+                                         float(self.neural_points.resolution), sort_ptr, _lib.stream()),
                    "clid_mapping_prep")
         return bufs, index_seq
 

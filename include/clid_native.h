@@ -430,10 +430,18 @@ int clid_new_sample_select(const int64_t* buffer_pt_index, int64_t buffer_size, 
  * draw the batches of all `iters` iterations, index_out [iters][bs] int64, composed as utils/mapper.py:473-500:
  * bs - bs_new uniform rows of the pool [0, pool_count) followed by bs_new uniform picks from new_idx [n_new] (bs_new may
  * be 0).  The generator is counter-based on (seed, counter, position): identical on every rank.  index_out may be NULL
- * (reset only).  clid_debug_prep_draw is the host restatement of one uniform draw (tests). */
+ * (reset only).
+ * sort_workspace != NULL (clid_mapping_prep_workspace_bytes; needs pool_coord [pool_count, 3] world frame and the voxel
+ * size `resolution`): every 16 384-sample segment of every iteration's batch -- the same draws -- is written in Morton
+ * order of the samples' voxels by a second launch (three stable 8-bit counting passes in LDS on (Morton code, draw
+ * position): a function of the draws alone, identical on every rank).  The loss and gradient sums do not depend on the
+ * order; neighbouring queries then share neural points, which is what the kernels' per-tile row merging and the caches
+ * feed on.  The `[::decimation]` eikonal subset becomes a systematic subsample of the ordered batch (each sample still has
+ * probability 1/decimation).  clid_debug_prep_draw is the host restatement of one uniform draw (tests). */
+int64_t clid_mapping_prep_workspace_bytes(int32_t iters, int32_t bs);
 int clid_mapping_prep(float* zero_base, int64_t zero_floats, int64_t* index_out, int32_t iters, int32_t bs, int32_t bs_new,
                       int64_t pool_count, const int64_t* new_idx, int64_t n_new, uint64_t seed, uint64_t counter,
-                      void* stream);
+                      const float* pool_coord, float resolution, void* sort_workspace, void* stream);
 int64_t clid_debug_prep_draw(uint64_t seed, uint64_t counter, uint64_t e, uint64_t range);
 
 /* ---- measurement aid (bench.py roofline leg; not part of the reference's interface) -----------

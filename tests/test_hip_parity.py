@@ -788,7 +788,7 @@ def test_mapping_prep_resets_and_draws_like_the_host_restatement():
     idx = torch.full((iters, bs), -5, device=dev, dtype=torch.int64)
     seed, counter = 42, 9
     _lib.check(lib.clid_mapping_prep(flat.data_ptr(), 4096, idx.data_ptr(), iters, bs, bs_new, pool, new_idx.data_ptr(),
-                                     new_idx.shape[0], seed, counter, _lib.stream()), "clid_mapping_prep")
+                                     new_idx.shape[0], seed, counter, None, 0.4, None, _lib.stream()), "clid_mapping_prep")
     torch.cuda.synchronize()
     assert float(flat[:4096].abs().max()) == 0.0 and float(flat[4096:].min()) == 3.0
     got = idx.cpu().numpy()
@@ -800,10 +800,34 @@ def test_mapping_prep_resets_and_draws_like_the_host_restatement():
     assert got[:, :700].min() >= 0 and got[:, :700].max() < pool and np.isin(got[:, 700:], nid).all()
     assert abs(got[:, :700].mean() / pool - 0.5) < 0.02 and len(np.unique(got[:, :700])) > 0.99 * 4900
     idx2 = torch.empty_like(idx)
-    _lib.check(lib.clid_mapping_prep(None, 0, idx2.data_ptr(), iters, bs, 0, pool, None, 0, seed, counter + 1,
+    _lib.check(lib.clid_mapping_prep(None, 0, idx2.data_ptr(), iters, bs, 0, pool, None, 0, seed, counter + 1, None, 0.4, None,
                                      _lib.stream()), "clid_mapping_prep")
     g2 = idx2.cpu().numpy()
     assert (g2 != got).mean() > 0.99 and g2.max() < pool
+    # spatially ordered variant: per iteration the SAME draws, in Morton order of the samples' voxels (stable)
+    coords = (torch.rand((pool, 3), device=dev) * 80.0 - 40.0).contiguous()
+    idx3 = torch.empty_like(idx)
+    ws = torch.empty(int(lib.clid_mapping_prep_workspace_bytes(iters, bs)), device=dev, dtype=torch.uint8)
+    _lib.check(lib.clid_mapping_prep(None, 0, idx3.data_ptr(), iters, bs, bs_new, pool, new_idx.data_ptr(), new_idx.shape[0], seed,
+                                     counter, coords.data_ptr(), 0.4, ws.data_ptr(), _lib.stream()), "clid_mapping_prep")
+    g3 = idx3.cpu().numpy()
+    assert np.array_equal(np.sort(g3, axis=1), np.sort(got, axis=1))  # a permutation of every iteration's draws
+
+    def morton(c):
+        out = np.zeros(c.shape[:-1], dtype=np.int64)
+        for b in range(8):
+            for a in range(3):
+                out |= ((c[..., a] >> b) & 1) << (3 * b + a)
+        return out
+
+    cells = np.floor(coords.cpu().numpy()[g3] / np.float32(0.4)).astype(np.int64) & 255
+    keys = morton(cells)
+    assert (np.diff(keys, axis=1) >= 0).all() and len(np.unique(keys[0])) > 500
+    # stable: equal keys keep their draw order
+    pos_in_draw = {int(v): i for i, v in reversed(list(enumerate(got[0])))}
+    same = np.nonzero(np.diff(keys[0]) == 0)[0]
+    assert all(pos_in_draw[int(g3[0, i])] <= pos_in_draw[int(g3[0, i + 1])] for i in same[:200])
+
     # through the Mapper: two calls draw different batches, a second Mapper with the same seed reproduces them
     import bench
     from clid_slam_amd import HotPathConfig
@@ -822,3 +846,43 @@ def test_mapping_prep_resets_and_draws_like_the_host_restatement():
         assert torch.isfinite(mp.last_losses).all() and float(mp.last_losses[:, 0].min()) > 0
         draws.append((a, b))
     assert torch.equal(draws[0][0], draws[1][0]) and torch.equal(draws[0][1], draws[1][1])
+
+
+@pytest.mark.parametrize("layer_norm", [False, True])
+def test_mapping_with_internal_draws_replays_on_the_oracle(layer_norm, monkeypatch):
+    """Mapper.mapping with its own (spatially ordered) batch draws: the batches it used are replayed on the CPU oracle
+    from a snapshot of the state -- losses, features, decoder and certainties agree as in the teacher-forced tests."""
+    import bench
+    from clid_slam_amd import HotPathConfig
+    from oracle import cpu_ref as O
+    from test_sequence import _oracle_state
+
+    monkeypatch.setenv("CLID_SORT_BATCH", "1")  # (auto orders only calls of >= 32 iterations)
+    dev = "cuda:0"
+    cfg = HotPathConfig()
+    cfg.device, cfg.bs, cfg.layer_norm_on = dev, 4096, layer_norm
+    cfg.buffer_size = 2_000_003
+    nm, dec, mp, scene = bench.build_scene(cfg, dev)
+    st = _oracle_state(nm, cfg)
+    od = O.DecoderParams(*[p.detach().cpu().clone() for p in dec.flat_params()], sdf_scale=dec.sdf_scale)
+    opool = O.SamplePool(mp.global_coord_pool.cpu().clone(), mp.sdf_label_pool.cpu().clone(), mp.time_pool.cpu().clone(),
+                         mp.weight_pool.cpu().clone())
+    mp.mapping(3)
+    idx = mp._keep[1].cpu()
+    assert idx.shape == (3, 4096)
+    keys = torch.floor(mp.global_coord_pool.cpu()[idx[0]] / cfg.voxel_size_m)
+    assert len(torch.unique(keys, dim=0)) > 100  # a real batch, and ordered: consecutive samples are neighbours
+    step = (keys[1:] - keys[:-1]).abs().max(dim=1).values.float().median()
+    assert float(step) <= 2.0
+    recs = O.mapping_iters(st, od, opool, idx, O.LoopConfig(sigma=mp.sdf_scale), record=True)
+    got = mp.last_losses.cpu()
+    for it, r in enumerate(recs):
+        assert abs(float(got[it, 0]) - float(r["loss"])) <= 2e-5, (it, got[it], r["loss"])
+    noise = torch.zeros_like(recs[-1]["theta"], dtype=torch.bool)
+    for r in recs:
+        ga = r["grad_theta"].abs()
+        noise |= (ga < 1e-10) & (ga.max(dim=1, keepdim=True).values > 0)
+    err = (nm.local_geo_features.detach().cpu() - recs[-1]["theta"]).abs()
+    assert float(err[~noise].max()) <= 1e-4 and int((err > 1e-4).sum()) <= 8
+    for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
+        assert float((t.detach().cpu() - o).abs().max()) <= 1e-4

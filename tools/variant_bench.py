@@ -1,5 +1,5 @@
 """Developer tool: build a variant of the library with extra -D flags into /tmp on the GPU box and run bench.py
-against it (the committed library is untouched).   usage: python tools/variant_bench.py "-DCLID_DECODE_WAVES=5" [bench args...]"""
+against it (the committed library is untouched).   usage: python tools/variant_bench.py "-DCLID_DECODE_WAVES=5" [bench args... | --sequence [frames]]"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,6 +12,15 @@ subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-
 import clid_slam_amd  # noqa
 from clid_slam_amd import _lib
 _lib.LIB_PATH = out
+if len(sys.argv) > 2 and sys.argv[2] == "--sequence":  # the large-map point of the sequence workload instead of bench.py
+    import bench, bench_sequence as BS
+    frames = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+    cfg, rows, checks, (nm, dec, mp) = BS.run(frames, "cuda:0", quiet=True)
+    kernels, _ = bench.kernel_report(_lib.load(), mp, 10, cfg.bs, cfg.gradient_decimation, nm.local_count(), 1)
+    tail = rows[frames // 2:]
+    print(flags, "M_local", nm.local_count(), "median mapping ms", round(sorted(r["t_mapping_ms"] for r in tail)[len(tail) // 2], 3),
+          [(k["kernel"][:16], k["avg_us"]) for k in kernels])
+    sys.exit(0)
 sys.argv = ["bench.py", "--no-cpu-baseline"] + sys.argv[2:]
 import io, contextlib
 buf = io.StringIO()
