@@ -667,15 +667,16 @@ k_mapping_prep(float4* __restrict__ zero4, long long n_zero4, long long* __restr
 // segment's samples (the draw is a pure function of the position), keys them by the Morton code of their voxel (8 bits per
 // axis: wraps every 256 voxels) and sorts (key, position) in LDS with a stable block radix sort, so the order is a function
 // of the draws alone: identical on every rank.  The zero fill is shared by all blocks.
-#ifndef CLID_SORT_SEG
-#define CLID_SORT_SEG 16384
+constexpr int kSortSeg = 16384, kSortThreads = 1024, kSortBins = 256, kSortWaves = kSortThreads / 64;
+#ifndef CLID_SORT_BUCKETS
+#define CLID_SORT_BUCKETS 8
 #endif
-constexpr int kSortSeg = CLID_SORT_SEG, kSortThreads = 1024, kSortItems = kSortSeg / kSortThreads, kSortBins = 256;
-constexpr int kSortWaves = kSortThreads / 64;
+constexpr int kSortBuckets = CLID_SORT_BUCKETS;        // blocks (= CUs) that share one full segment
+constexpr int kSortBucketItems = 32 / kSortBuckets;  // capacity of a bucket block = twice the mean
 using BinScan = hipcub::BlockScan<unsigned, kSortThreads>;
 
 // lanes of the wave that hold the same 8-bit digit as this lane (an OR-mask row in LDS per wave does the same with two LDS
-// operations, but the block is LDS-throughput-bound on its one CU: 60 vs 54 us)
+// operations, but a sorting block is LDS-throughput-bound on its one CU)
 __device__ __forceinline__ unsigned long long match8(unsigned d) {
   unsigned long long m = ~0ULL;
 #pragma unroll
@@ -686,18 +687,19 @@ __device__ __forceinline__ unsigned long long match8(unsigned d) {
   return m;
 }
 
-// One stable counting-sort pass over a 16 384-element sequence held 16 per thread in WAVE-BLOCKED order: element
-// (wave, r, lane) is sequence position wave * 1024 + r * 64 + lane.  A wave walks its 1024 elements in order, so the rank
-// of an element among the equal digits of ITS wave is (running count of the digit in the wave's column of `tab`) + (equal
-// digits in lower lanes, from ballots); one exclusive scan over tab[digit][wave] then turns the columns into global
-// offsets.  No atomic decides an order: the permutation is a function of the digits alone.  Three barriers per pass.
-__device__ __forceinline__ void counting_pass(const unsigned (&digit)[kSortItems], unsigned (&dest)[kSortItems], unsigned* tab,
+// One stable counting-sort pass over a sequence of ITEMS * 1024 elements held ITEMS per thread in WAVE-BLOCKED order:
+// element (wave, r, lane) is sequence position wave * 64 * ITEMS + r * 64 + lane.  A wave walks its elements in order, so
+// the rank of an element among the equal digits of ITS wave is (running count of the digit in the wave's column of `tab`)
+// + (equal digits in lower lanes, from ballots); one exclusive scan over tab[digit][wave] then turns the columns into
+// global offsets.  No atomic decides an order: the permutation is a function of the digits alone.
+template <int ITEMS>
+__device__ __forceinline__ void counting_pass(const unsigned (&digit)[ITEMS], unsigned (&dest)[ITEMS], unsigned* tab,
                                               typename BinScan::TempStorage& scan_tmp) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int i = threadIdx.x; i < kSortBins * kSortWaves; i += kSortThreads) tab[i] = 0;
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     const unsigned d = digit[r];
     const unsigned long long peers = match8(d);
     const unsigned rk = (unsigned)__popcll(peers & ((1ULL << lane) - 1ULL));
@@ -729,56 +731,164 @@ __device__ __forceinline__ void counting_pass(const unsigned (&digit)[kSortItems
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) dest[r] += tab[digit[r] * kSortWaves + wave];
+  for (int r = 0; r < ITEMS; ++r) dest[r] += tab[digit[r] * kSortWaves + wave];
   __syncthreads();
 }
 
-// Spatially ordered batches: one 1024-thread block per (iteration, 16 384-sample segment of the batch) orders the segment's
-// draws by (Morton code of the sample's voxel, draw position) -- a total order, so the result is a function of the draws
-// alone, identical on every rank -- through three stable 8-bit counting passes in LDS.  draws / keys come from
-// k_mapping_prep (computed by the whole chip: the 16 k random 12-byte gathers of a segment take 25 us through one CU's L1).
+// Three stable 8-bit passes over (key24, pos14) pairs held ITEMS per thread (wave-blocked): on return element r of the
+// thread is the one with draw position pos[r] and its place in the order by (key, sequence position) is dest[r].
+template <int ITEMS>
+__device__ __forceinline__ void sort_pairs(unsigned (&key)[ITEMS], unsigned (&pos)[ITEMS], unsigned (&dest)[ITEMS], unsigned* tab,
+                                           unsigned* seq, typename BinScan::TempStorage& scan_tmp) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i0 = wave * (ITEMS * 64) + lane;  // sequence position of item r: i0 + 64 r
+  unsigned digit[ITEMS], s[ITEMS];
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) digit[r] = key[r] & 0xFFu;
+  counting_pass<ITEMS>(digit, dest, tab, scan_tmp);
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) seq[dest[r]] = ((key[r] >> 8) << 14) | pos[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    s[r] = seq[i0 + 64 * r];
+    digit[r] = (s[r] >> 14) & 0xFFu;
+  }
+  counting_pass<ITEMS>(digit, dest, tab, scan_tmp);  // (its barriers also cover the reads of seq above)
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) seq[dest[r]] = ((s[r] >> 22) << 14) | (s[r] & 0x3FFFu);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    s[r] = seq[i0 + 64 * r];
+    digit[r] = (s[r] >> 14) & 0xFFu;
+    pos[r] = s[r] & 0x3FFFu;
+  }
+  counting_pass<ITEMS>(digit, dest, tab, scan_tmp);
+}
+
+// Spatially ordered batches.  A segment = 16 384 consecutive samples of one iteration's batch; its draws are ordered by
+// (Morton code of the sample's voxel, draw position) -- a total order, so the result is a function of the draws alone,
+// identical on every rank.  draws / keys come from k_mapping_prep (computed by the whole chip: the 16 k random 12-byte
+// gathers of a segment take 25 us through one CU's L1).
+//
+// k_batch_sort_tail: one block orders a whole (short) segment: the tail of a batch that is no multiple of 16 384.
 __global__ void __launch_bounds__(kSortThreads)
-k_batch_sort(const long long* __restrict__ draws, const unsigned* __restrict__ keys, long long* __restrict__ index_out, int bs) {
+k_batch_sort_tail(const long long* __restrict__ draws, const unsigned* __restrict__ keys, long long* __restrict__ index_out, int bs,
+                  int base) {
+  constexpr int ITEMS = kSortSeg / kSortThreads;
   __shared__ unsigned tab[kSortBins * kSortWaves];  // [digit][wave]
   __shared__ unsigned seq[kSortSeg];                // the sequence between passes: (remaining code << 14) | draw position
   __shared__ typename BinScan::TempStorage scan_tmp;
-  const int segs = (bs + kSortSeg - 1) / kSortSeg;
-  const int it = blockIdx.x / segs, seg = blockIdx.x - it * segs;
-  const int base = seg * kSortSeg;
-  const int n = bs - base < kSortSeg ? bs - base : kSortSeg;
-  const long long e0 = (long long)it * bs + base;
+  const int n = bs - base;
+  const long long e0 = (long long)blockIdx.x * bs + base;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int p0 = wave * (kSortItems * 64) + lane;  // sequence position of item r: p0 + 64 r
-  unsigned key[kSortItems], digit[kSortItems], dest[kSortItems];
+  unsigned key[ITEMS], pos[ITEMS], dest[ITEMS];
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
-    const int p = p0 + 64 * r;
-    key[r] = p < n ? keys[e0 + p] : 0xFFFFFFu;  // padding of a short segment: behind every real element
-    digit[r] = key[r] & 0xFFu;
+  for (int r = 0; r < ITEMS; ++r) {
+    const int p = wave * (ITEMS * 64) + r * 64 + lane;
+    pos[r] = (unsigned)p;
+    key[r] = p < n ? keys[e0 + p] : 0xFFFFFFu;  // padding: behind every real element (largest code, larger position)
   }
-  counting_pass(digit, dest, tab, scan_tmp);
+  sort_pairs<ITEMS>(key, pos, dest, tab, seq, scan_tmp);
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) seq[dest[r]] = ((key[r] >> 8) << 14) | (unsigned)(p0 + 64 * r);
+  for (int r = 0; r < ITEMS; ++r)
+    if ((int)dest[r] < n) index_out[e0 + dest[r]] = draws[e0 + pos[r]];
+}
+
+// k_batch_sort_bucket: a FULL segment is shared by kSortBuckets blocks (sorting in LDS is bound by one CU's LDS rate: 54 us
+// for 16 384 elements in one block).  Every block derives the same 7 splitters from the same 256 sample keys, scans the
+// segment's keys (64 KB, coalesced), keeps the elements of ITS key range in position order, sorts them and writes them
+// behind the smaller ranges.  No communication between the blocks.
+__global__ void __launch_bounds__(kSortThreads)
+k_batch_sort_bucket(const long long* __restrict__ draws, const unsigned* __restrict__ keys, long long* __restrict__ index_out,
+                    int bs, int full_segs) {
+  constexpr int ITEMS = kSortBucketItems, CAP = ITEMS * kSortThreads, SCAN = kSortSeg / kSortThreads;
+  __shared__ unsigned tab[kSortBins * kSortWaves];
+  __shared__ unsigned seq[CAP];
+  __shared__ unsigned sel_key[CAP], sel_pos[CAP];
+  __shared__ unsigned samp[256], sorted[256], wcnt[kSortWaves], wlow[kSortWaves];
+  __shared__ typename BinScan::TempStorage scan_tmp;
+  const int bk = blockIdx.x % kSortBuckets;
+  const int sg = blockIdx.x / kSortBuckets;
+  const int it = sg / full_segs, seg = sg - it * full_segs;
+  const long long e0 = (long long)it * bs + (long long)seg * kSortSeg;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // ---- splitters: the 256 keys at positions 0, 64, 128, ... ranked by (key, sample number)
+  if (threadIdx.x < 256) samp[threadIdx.x] = keys[e0 + 64 * threadIdx.x];
   __syncthreads();
-  unsigned s[kSortItems];
-#pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
-    s[r] = seq[p0 + 64 * r];
-    digit[r] = (s[r] >> 14) & 0xFFu;
+  if (threadIdx.x < 256) {
+    const unsigned c = samp[threadIdx.x];
+    unsigned rank = 0;
+    for (int j = 0; j < 256; ++j) {
+      const unsigned o = samp[j];
+      rank += (o < c || (o == c && j < (int)threadIdx.x)) ? 1u : 0u;
+    }
+    sorted[rank] = c;
   }
-  counting_pass(digit, dest, tab, scan_tmp);  // (its barriers also cover the reads of seq above)
-#pragma unroll
-  for (int r = 0; r < kSortItems; ++r) seq[dest[r]] = ((s[r] >> 22) << 14) | (s[r] & 0x3FFFu);
   __syncthreads();
+  unsigned split[kSortBuckets - 1];
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
-    s[r] = seq[p0 + 64 * r];
-    digit[r] = (s[r] >> 14) & 0xFFu;
+  for (int k = 1; k < kSortBuckets; ++k) split[k - 1] = sorted[k * (256 / kSortBuckets)];
+  // ---- scan of the segment in wave-blocked order: count, then keep this block's key range in position order
+  unsigned key[SCAN];
+  unsigned cm = 0, cl = 0;
+  unsigned long long mine_bits = 0;  // bit r: element r of this thread belongs to this block
+#pragma unroll
+  for (int r = 0; r < SCAN; ++r) {
+    const int p = wave * (SCAN * 64) + r * 64 + lane;
+    key[r] = keys[e0 + p];
+    int b = 0;
+#pragma unroll
+    for (int k = 0; k < kSortBuckets - 1; ++k) b += key[r] >= split[k] ? 1 : 0;
+    const bool mine = b == bk;
+    cm += (unsigned)__popcll(__ballot(mine));
+    cl += (unsigned)__popcll(__ballot(b < bk));
+    mine_bits |= mine ? (1ULL << r) : 0ULL;
   }
-  counting_pass(digit, dest, tab, scan_tmp);
+  if (lane == 0) {
+    wcnt[wave] = cm;
+    wlow[wave] = cl;
+  }
+  __syncthreads();
+  unsigned wbase = 0, m = 0, lower = 0;
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r)
-    if ((int)dest[r] < n) index_out[e0 + dest[r]] = draws[e0 + (s[r] & 0x3FFFu)];
+  for (int w = 0; w < kSortWaves; ++w) {
+    wbase += w < wave ? wcnt[w] : 0u;
+    m += wcnt[w];
+    lower += wlow[w];
+  }
+  const bool overflow = m > (unsigned)CAP;  // (block-uniform) a key range more than twice the mean: keeps the draw order
+  unsigned run = wbase;
+#pragma unroll
+  for (int r = 0; r < SCAN; ++r) {
+    const bool mine = (mine_bits >> r) & 1ULL;
+    const unsigned long long bal = __ballot(mine);
+    const unsigned slot = run + (unsigned)__popcll(bal & ((1ULL << lane) - 1ULL));
+    const unsigned p = (unsigned)(wave * (SCAN * 64) + r * 64 + lane);
+    if (mine) {
+      if (overflow) {
+        index_out[e0 + lower + slot] = draws[e0 + p];
+      } else {
+        sel_key[slot] = key[r];
+        sel_pos[slot] = p;
+      }
+    }
+    run += (unsigned)__popcll(bal);
+  }
+  if (overflow) return;
+  __syncthreads();
+  unsigned k4[ITEMS], pos[ITEMS], dest[ITEMS];
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    const unsigned i = (unsigned)(wave * (ITEMS * 64) + r * 64 + lane);
+    k4[r] = i < m ? sel_key[i] : 0xFFFFFFu;  // padding: behind every real element
+    pos[r] = i < m ? sel_pos[i] : 0x3FFFu;
+  }
+  sort_pairs<ITEMS>(k4, pos, dest, tab, seq, scan_tmp);
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r)
+    if (dest[r] < m) index_out[e0 + lower + dest[r]] = draws[e0 + pos[r]];
 }
 
 extern "C" int64_t clid_mapping_prep_workspace_bytes(int32_t iters, int32_t bs) {
@@ -801,8 +911,9 @@ extern "C" int clid_mapping_prep(float* zero_base, int64_t zero_floats, int64_t*
   const long long n_index = index_out ? (long long)iters * bs : 0;
   const long long work = (zero_floats / 4 > n_index ? zero_floats / 4 : n_index);
   if (work == 0) return CLID_OK;
-  const long long sort_blocks = (long long)iters * ((bs + kSortSeg - 1) / kSortSeg);
-  const bool sorted = sort_workspace && n_index > 0 && sort_blocks <= 65535;
+  const int full_segs = bs / kSortSeg, tail = bs - full_segs * kSortSeg;
+  const long long sort_blocks = (long long)iters * full_segs * kSortBuckets;
+  const bool sorted = sort_workspace && n_index > 0 && sort_blocks < (1LL << 31);
   char* ws = static_cast<char*>(sort_workspace);
   long long* draws = sorted ? reinterpret_cast<long long*>(ws) : reinterpret_cast<long long*>(index_out);
   unsigned* keys = sorted ? reinterpret_cast<unsigned*>(ws + align256((size_t)n_index * 8)) : nullptr;
@@ -812,9 +923,12 @@ extern "C" int clid_mapping_prep(float* zero_base, int64_t zero_floats, int64_t*
                      (long long)(zero_floats / 4), draws, n_index, bs, bs_new, (unsigned long long)pool_count,
                      reinterpret_cast<const long long*>(new_idx), (unsigned long long)n_new, (unsigned long long)seed,
                      (unsigned long long)counter, pool_coord, resolution, keys);
-  if (sorted)
-    hipLaunchKernelGGL(k_batch_sort, dim3((unsigned)sort_blocks), dim3(kSortThreads), 0, s, draws, keys,
-                       reinterpret_cast<long long*>(index_out), bs);
+  if (sorted && full_segs > 0)
+    hipLaunchKernelGGL(k_batch_sort_bucket, dim3((unsigned)sort_blocks), dim3(kSortThreads), 0, s, draws, keys,
+                       reinterpret_cast<long long*>(index_out), bs, full_segs);
+  if (sorted && tail > 0)
+    hipLaunchKernelGGL(k_batch_sort_tail, dim3((unsigned)iters), dim3(kSortThreads), 0, s, draws, keys,
+                       reinterpret_cast<long long*>(index_out), bs, full_segs * kSortSeg);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

@@ -145,7 +145,7 @@ class Mapper:
             return torch.randint(0, self.pool_sample_count, (iters, bs), device=dev, generator=self._gen, out=out)
         return torch.randint(0, self.pool_sample_count, (iters, bs), device=dev, generator=self._gen)
 
-    SORT_BATCH_MIN_ITERS = 32
+    SORT_BATCH_MIN_ITERS = 6
 
     def _prepare_call(self, iters: int, bs: int, n_rows: int, dev, lib):
         """Workspace reset + batch draw of one `mapping()` call in ONE launch (`clid_mapping_prep`): the composition rule
@@ -171,7 +171,8 @@ class Mapper:
         # draw order.
         coord_ptr, sort_ptr = None, None
         sort_mode = os.environ.get("CLID_SORT_BATCH", "auto")  # auto: calls long enough for the kernels' gain (3 us per
-        # iteration at 16 384 samples) to exceed the ordering launch (54 us); 1: always; 0: never
+        # iteration at 16 384 samples) to exceed the exposed part of the ordering launch (28 us, mostly under the host's
+        # argument assembly); 1: always; 0: never
         if ((sort_mode == "1" or (sort_mode != "0" and iters >= self.SORT_BATCH_MIN_ITERS))
                 and self.global_coord_pool.dtype == torch.float32):
             need = int(lib.clid_mapping_prep_workspace_bytes(iters, bs))

@@ -828,6 +828,26 @@ def test_mapping_prep_resets_and_draws_like_the_host_restatement():
     same = np.nonzero(np.diff(keys[0]) == 0)[0]
     assert all(pos_in_draw[int(g3[0, i])] <= pos_in_draw[int(g3[0, i + 1])] for i in same[:200])
 
+    # full 16 384-sample segments are shared by 8 blocks (splitters + per-range sort), the tail goes to one block: every
+    # segment is a permutation of its draws, ordered by (Morton code, draw position); clustered coordinates give long ties
+    iters2, bs2 = 2, 2 * 16384 + 1000
+    coords2 = coords.clone()
+    coords2[: pool // 2] = torch.floor(coords2[: pool // 2] / 3.2) * 3.2 + 0.1  # half of the pool shares a few hundred voxels
+    raw = torch.empty((iters2, bs2), device=dev, dtype=torch.int64)
+    _lib.check(lib.clid_mapping_prep(None, 0, raw.data_ptr(), iters2, bs2, 0, pool, None, 0, seed, 77, None, 0.4, None,
+                                     _lib.stream()), "clid_mapping_prep")
+    srt = torch.empty_like(raw)
+    ws2 = torch.empty(int(lib.clid_mapping_prep_workspace_bytes(iters2, bs2)), device=dev, dtype=torch.uint8)
+    _lib.check(lib.clid_mapping_prep(None, 0, srt.data_ptr(), iters2, bs2, 0, pool, None, 0, seed, 77, coords2.data_ptr(), 0.4,
+                                     ws2.data_ptr(), _lib.stream()), "clid_mapping_prep")
+    raw_n, srt_n, c2 = raw.cpu().numpy(), srt.cpu().numpy(), coords2.cpu().numpy()
+    for it in range(iters2):
+        for lo in range(0, bs2, 16384):
+            a, b = raw_n[it, lo:lo + 16384], srt_n[it, lo:lo + 16384]
+            ka = morton(np.floor(c2[a] / np.float32(0.4)).astype(np.int64) & 255)
+            want = a[np.argsort(ka, kind="stable")]  # stable: ties keep the draw order
+            assert np.array_equal(b, want), (it, lo, int((b != want).sum()))
+
     # through the Mapper: two calls draw different batches, a second Mapper with the same seed reproduces them
     import bench
     from clid_slam_amd import HotPathConfig
