@@ -93,6 +93,9 @@ class Mapper:
         n_idx = iter_count * int(cfg.bs)
         if getattr(self, "_idx_buf", None) is None or self._idx_buf.numel() < n_idx or self._idx_buf.device != dev:
             self._idx_buf = torch.empty(n_idx, device=dev, dtype=torch.int64)
+        need = int(lib.clid_mapping_prep_workspace_bytes(iter_count, int(cfg.bs)))  # batch ordering: unsorted draws | keys
+        if getattr(self, "_sort_ws", None) is None or self._sort_ws.numel() < need or self._sort_ws.device != dev:
+            self._sort_ws = torch.empty(need + 256, device=dev, dtype=torch.uint8)
 
     def _loop_buffers(self, n_rows: int, iters: int, dev, zero: bool = True):
         """Views [grad | m | v | m_mlp | v_mlp | losses] of one flat fp32 buffer, zeroed (zero=False: the caller resets
