@@ -96,6 +96,11 @@ class Mapper:
         need = int(lib.clid_mapping_prep_workspace_bytes(iter_count, int(cfg.bs)))  # batch ordering: unsorted draws | keys
         if getattr(self, "_sort_ws", None) is None or self._sort_ws.numel() < need or self._sort_ws.device != dev:
             self._sort_ws = torch.empty(need + 256, device=dev, dtype=torch.uint8)
+        if self.pool_sample_count > 0 and self.global_coord_pool.is_cuda and self.global_coord_pool.dtype == torch.float32:
+            # first launch of the draw / ordering kernels into the reserved buffers (code-object load, LDS configuration)
+            _lib.check(lib.clid_mapping_prep(None, 0, self._idx_buf.data_ptr(), iter_count, int(cfg.bs), 0,
+                                             int(self.pool_sample_count), None, 0, 0, 0, self.global_coord_pool.data_ptr(),
+                                             float(nm.resolution), self._sort_ws.data_ptr(), _lib.stream()), "clid_mapping_prep")
 
     def _loop_buffers(self, n_rows: int, iters: int, dev, zero: bool = True):
         """Views [grad | m | v | m_mlp | v_mlp | losses] of one flat fp32 buffer, zeroed (zero=False: the caller resets
