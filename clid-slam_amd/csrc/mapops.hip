@@ -219,22 +219,57 @@ struct PoolSrc {
 __device__ __forceinline__ const float* pool_gcoord(const PoolSrc& a, const PoolSrc& b, long long i) {
   return i < a.n ? a.gcoord + i * 3 : b.gcoord + (i - a.n) * 3;
 }
+// Compaction by per-block counts: the flag pass leaves one byte per sample and one count per 256-sample block; a scan over
+// the 40 k block counts (not over 1e7 samples: two 52-us device scans per frame) gives every block its offset and the
+// consumers rebuild the position inside the block from ballots.
+__device__ __forceinline__ int block_prefix256(bool f, int* total) {  // exclusive prefix of f over the block, 256 threads
+  __shared__ int wsum[4];
+  const unsigned long long bal = __ballot(f);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wsum[wave] = (int)__popcll(bal);
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    base += w < wave ? wsum[w] : 0;
+    tot += wsum[w];
+  }
+  __syncthreads();
+  if (total) *total = tot;
+  return base + (int)__popcll(bal & ((1ULL << lane) - 1ULL));
+}
 __global__ void __launch_bounds__(256)
-k_pool_flags(PoolSrc a, PoolSrc b, double ox, double oy, double oz, double r2, int* __restrict__ flag) {
+k_pool_flags(PoolSrc a, PoolSrc b, double ox, double oy, double oz, double r2, unsigned char* __restrict__ flag,
+             int* __restrict__ block_cnt) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n + b.n) return;
-  const float* g = pool_gcoord(a, b, i);
-  const double dx = (double)g[0] - ox, dy = (double)g[1] - oy, dz = (double)g[2] - oz;  // mapper.py:346-349, float64
-  flag[i] = ((dx * dx + dy * dy) + dz * dz) < r2 ? 1 : 0;
+  bool f = false;
+  if (i < a.n + b.n) {
+    const float* g = pool_gcoord(a, b, i);
+    const double dx = (double)g[0] - ox, dy = (double)g[1] - oy, dz = (double)g[2] - oz;  // mapper.py:346-349, float64
+    f = ((dx * dx + dy * dy) + dz * dz) < r2;
+    flag[i] = f ? 1 : 0;
+  }
+  int tot;
+  block_prefix256(f, &tot);
+  if (threadIdx.x == 0) block_cnt[blockIdx.x] = tot;
+}
+// per-block counts of the flags (after the capacity drop cleared some)
+__global__ void __launch_bounds__(256)
+k_pool_count(const unsigned char* __restrict__ flag, long long n, int* __restrict__ block_cnt) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int tot;
+  block_prefix256(i < n && flag[i], &tot);
+  if (threadIdx.x == 0) block_cnt[blockIdx.x] = tot;
 }
 // kept_list[rank] = index for the samples that passed the window test; counts[2] = kept (before the capacity drop)
 __global__ void __launch_bounds__(256)
-k_pool_list(const int* __restrict__ flag, const int* __restrict__ pos, long long n, int* __restrict__ kept_list,
-            long long* __restrict__ counts) {
+k_pool_list(const unsigned char* __restrict__ flag, const int* __restrict__ block_off, const int* __restrict__ block_cnt,
+            long long n, int* __restrict__ kept_list, long long* __restrict__ counts) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (flag[i]) kept_list[pos[i]] = (int)i;
-  if (i == n - 1) counts[2] = pos[i] + flag[i];
+  const bool f = i < n && flag[i];
+  const int r = block_prefix256(f, nullptr);
+  if (f) kept_list[block_off[blockIdx.x] + r] = (int)i;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counts[2] = (long long)block_off[blockIdx.x] + block_cnt[blockIdx.x];
 }
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
   x += 0x9E3779B97F4A7C15ULL;
@@ -244,8 +279,8 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
 }
 // mapper.py:352-361: `kept - capacity` uniform picks WITH replacement among the kept samples are dropped
 __global__ void __launch_bounds__(256)
-k_pool_drop(int* __restrict__ flag, const int* __restrict__ kept_list, const long long* __restrict__ counts, long long capacity,
-            unsigned long long seed) {
+k_pool_drop(unsigned char* __restrict__ flag, const int* __restrict__ kept_list, const long long* __restrict__ counts,
+            long long capacity, unsigned long long seed) {
   const long long kept = counts[2];
   const long long excess = kept - capacity;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < excess; t += (long long)gridDim.x * blockDim.x) {
@@ -257,17 +292,25 @@ struct PoolDst {
   float* coord; float* gcoord; float* label; float* weight; int* time;
 };
 __global__ void __launch_bounds__(256)
-k_pool_scatter(PoolSrc a, PoolSrc b, const int* __restrict__ flag, const int* __restrict__ pos, PoolDst d,
-               long long* __restrict__ counts) {
+k_pool_scatter(PoolSrc a, PoolSrc b, const unsigned char* __restrict__ flag, const int* __restrict__ block_off,
+               const int* __restrict__ block_cnt, PoolDst d, long long* __restrict__ counts) {
   const long long n = a.n + b.n;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (i == n - 1) {
-    counts[0] = pos[i] + flag[i];                               // samples kept in total
-    counts[1] = counts[0] - (a.n > 0 ? pos[a.n - 1] + flag[a.n - 1] : 0);  // ... of which from this frame (the tail)
+  const bool f = i < n && flag[i];
+  const long long j = (long long)block_off[blockIdx.x] + block_prefix256(f, nullptr);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    const long long kept = (long long)block_off[blockIdx.x] + block_cnt[blockIdx.x];
+    counts[0] = kept;  // samples kept in total
+    // ... of which from this frame (the tail): kept minus what survived of the old pool (positions < a.n)
+    long long kept_old = 0;
+    if (a.n > 0) {
+      const long long ba = a.n / 256;
+      kept_old = ba < (long long)gridDim.x ? (long long)block_off[ba] : kept;
+      for (long long q = ba * 256; q < a.n && ba < (long long)gridDim.x; ++q) kept_old += flag[q];
+    }
+    counts[1] = kept - kept_old;
   }
-  if (!flag[i]) return;
-  const long long j = pos[i];
+  if (!f) return;
   const bool old = i < a.n;
   const PoolSrc& s = old ? a : b;
   const long long k = old ? i : i - a.n;
@@ -947,7 +990,9 @@ static size_t pool_scan_bytes(long long n) {
 }
 extern "C" int64_t clid_pool_workspace_bytes(int64_t n_total) {
   if (n_total <= 0) return 256;
-  return (int64_t)(3 * align256((size_t)n_total * 4) + align256(pool_scan_bytes(n_total)) + 256);
+  const size_t nblk = ((size_t)n_total + 255) / 256;  // flags (1 B) | block counts | block offsets | kept list | scan scratch
+  return (int64_t)(align256((size_t)n_total) + 2 * align256(nblk * 4) + align256((size_t)n_total * 4) +
+                   align256(pool_scan_bytes((long long)nblk)) + 256);
 }
 
 extern "C" int clid_pool_filter(const float* coord_a, const float* gcoord_a, const float* label_a, const float* weight_a,
@@ -968,29 +1013,33 @@ extern "C" int clid_pool_filter(const float* coord_a, const float* gcoord_a, con
   long long* counts = reinterpret_cast<long long*>(counts_out);
   if (n == 0) return hipMemsetAsync(counts, 0, 3 * sizeof(long long), s) == hipSuccess ? CLID_OK : CLID_E_HIP;
   char* ws = static_cast<char*>(workspace);
-  int* flag = reinterpret_cast<int*>(ws);
-  int* pos = reinterpret_cast<int*>(ws + align256((size_t)n * 4));
-  int* kept_list = reinterpret_cast<int*>(ws + 2 * align256((size_t)n * 4));
-  void* cub = ws + 3 * align256((size_t)n * 4);
-  size_t cub_bytes = pool_scan_bytes(n);
+  const long long nblk = (n + 255) / 256;
+  unsigned char* flag = reinterpret_cast<unsigned char*>(ws);
+  int* block_cnt = reinterpret_cast<int*>(ws + align256((size_t)n));
+  int* block_off = reinterpret_cast<int*>(ws + align256((size_t)n) + align256((size_t)nblk * 4));
+  int* kept_list = reinterpret_cast<int*>(ws + align256((size_t)n) + 2 * align256((size_t)nblk * 4));
+  void* cub = ws + align256((size_t)n) + 2 * align256((size_t)nblk * 4) + align256((size_t)n * 4);
+  size_t cub_bytes = pool_scan_bytes(nblk);
   const PoolSrc a{coord_a, gcoord_a, label_a, weight_a, time_a, n_a}, b{coord_b, gcoord_b, label_b, weight_b, time_b, n_b};
-  const unsigned blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_pool_flags, dim3(blocks), dim3(256), 0, s, a, b, origin_host[0], origin_host[1], origin_host[2], radius2, flag);
-  if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)n, s) != hipSuccess) {
+  const unsigned blocks = (unsigned)nblk;
+  hipLaunchKernelGGL(k_pool_flags, dim3(blocks), dim3(256), 0, s, a, b, origin_host[0], origin_host[1], origin_host[2], radius2,
+                     flag, block_cnt);
+  if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, block_cnt, block_off, (int)nblk, s) != hipSuccess) {
     clid_set_error("clid_pool_filter: scan failed");
     return CLID_E_HIP;
   }
   if (n > capacity) {  // only then can more than `capacity` samples survive the window test
-    hipLaunchKernelGGL(k_pool_list, dim3(blocks), dim3(256), 0, s, flag, pos, n, kept_list, counts);
+    hipLaunchKernelGGL(k_pool_list, dim3(blocks), dim3(256), 0, s, flag, block_off, block_cnt, n, kept_list, counts);
     hipLaunchKernelGGL(k_pool_drop, dim3(1024), dim3(256), 0, s, flag, kept_list, counts, (long long)capacity,
                        (unsigned long long)seed);
-    if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)n, s) != hipSuccess) {
+    hipLaunchKernelGGL(k_pool_count, dim3(blocks), dim3(256), 0, s, flag, n, block_cnt);
+    if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, block_cnt, block_off, (int)nblk, s) != hipSuccess) {
       clid_set_error("clid_pool_filter: scan failed");
       return CLID_E_HIP;
     }
   }
   const PoolDst d{coord_out, gcoord_out, label_out, weight_out, time_out};
-  hipLaunchKernelGGL(k_pool_scatter, dim3(blocks), dim3(256), 0, s, a, b, flag, pos, d, counts);
+  hipLaunchKernelGGL(k_pool_scatter, dim3(blocks), dim3(256), 0, s, a, b, flag, block_off, block_cnt, d, counts);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

@@ -19,7 +19,7 @@ import torch, bench
 from clid_slam_amd import HotPathConfig
 cfg = HotPathConfig(); cfg.device = "cuda:0"
 nm, dec, mp, scene = bench.build_scene(cfg, "cuda:0")
-mp.mapping(5); torch.cuda.synchronize()
+mp.mapping(8); torch.cuda.synchronize()  # (>= 6 iterations: batches in Morton order)
 lib = C.CDLL(out)
 buf = (C.c_longlong * (256 * 32))()
 assert lib.clid_debug_read_stamps(buf) == 0
@@ -33,9 +33,11 @@ names = names8
 if os.environ.get("CLID_DECODE", "1") != "0":  # the tile (matrix-core) decode kernel has its own stamps
     assert lib.clid_debug_read_stamps_tile(buf) == 0
     a = np.array(buf, dtype=np.int64).reshape(256, 32)
-    names = {0: "start", 1: "weights", 2: "record", 3: "gathered", 4: "blended", 5: "mlp fwd", 6: "loss", 7: "dh+df", 8: "lds fence",
+    names = {0: "start", 1: "weights", 2: "record", 8: "numbered", 3: "gathered", 4: "blended", 5: "mlp fwd", 6: "loss", 7: "dh+df",
              9: "atomics", 10: "stamps", 11: "dW1", 12: "loop end", 13: "flushed"}
 keys = sorted(names)
+if 13 in names:
+    keys = [0, 1, 2, 8, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13]  # program order of the tile kernel's stamps
 print("phase deltas (median / p90 cycles at 100 MHz s_memtime? raw units), relative to previous stamp:")
 prev = None
 for k in keys:
