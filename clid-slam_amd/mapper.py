@@ -591,6 +591,12 @@ class Mapper:
         # launches are small and separated by its read-backs; joined before anything reads the pool.
         overlap = fused_pool and gcoord is not None and os.environ.get("CLID_POOL_OVERLAP", "1") != "0"
         if overlap:
+            # the map growth starts with a voxel down-sampling whose kernels starve next to the pool's 230-us five-array
+            # compaction (k_vox_compact: 15 -> 187 us): it runs first, alone, and the pool work is forked behind it, next to
+            # the insert / window launches that are small and separated by read-backs
+            from .tools import voxel_down_sample_torch
+
+            nm._presampled = (update_points, update_points[voxel_down_sample_torch(update_points, nm.resolution)])
             main = torch.cuda.current_stream(coord.device)
             side = getattr(self, "_side_stream", None)
             if side is None or side.device != coord.device:

@@ -168,7 +168,7 @@ class NeuralPoints(nn.Module):
         st = dict(st)
         st["_tables"] = {}
         st.pop("_replica_gens", None)  # torch.Generator objects do not pickle
-        for k in ("_sensor_pos_host", "_win_ws", "_win_counts", "_ins_ws", "_ins_count", "_gbuf", "_stencils"):
+        for k in ("_sensor_pos_host", "_win_ws", "_win_counts", "_ins_ws", "_ins_count", "_gbuf", "_stencils", "_presampled"):
             st.pop(k, None)
         for k in self._GLOBAL_ARRAYS:  # views of the capacity buffers would drag the whole buffers into the pickle
             t = st.get(k)
@@ -200,7 +200,11 @@ class NeuralPoints(nn.Module):
     def update(self, points: torch.Tensor, sensor_position: torch.Tensor, sensor_orientation: torch.Tensor, cur_ts: int):
         """Insert new neural points for `points` [N,3] (model/neural_points.py:324-437)."""
         res = self.resolution
-        sample_points = points[voxel_down_sample_torch(points, res)]
+        pre = self.__dict__.pop("_presampled", None)  # (points tensor, its voxel-down-sampled rows) left by Mapper.process_frame
+        if pre is not None and pre[0] is points:
+            sample_points = pre[1]
+        else:
+            sample_points = points[voxel_down_sample_torch(points, res)]
         if (sample_points.is_cuda and self.color_features is None and sample_points.dtype == torch.float32
                 and self.buffer_pt_index is not None and self.buffer_pt_index.is_cuda and int(self.buffer_size) < (1 << 30)
                 and self.geo_features.shape[1] == _lib.F and self.point_ts_create.dtype == torch.int32):
