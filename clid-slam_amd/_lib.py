@@ -124,7 +124,7 @@ _SIGS = {
     "clid_sample_compact": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, C.c_float, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clid_new_sample_workspace_bytes": (_i64, [_i64]),
     "clid_new_sample_select": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, C.c_float, C.c_float, _vp, _vp, _i64, C.c_float,
-                                         C.c_float, _i64, _vp, _vp, _vp, _vp]),
+                                         C.c_float, _i64, _vp, _vp, _vp, _vp, _vp]),
     "clid_read_back": (C.c_int, [_vp, _i32, _vp, _vp]),
     "clid_mapping_prep_workspace_bytes": (_i64, [_i32, _i32]),
     "clid_mapping_prep": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i64, _vp, _i64, C.c_uint64, C.c_uint64, _vp, C.c_float,

@@ -1138,9 +1138,18 @@ __global__ void __launch_bounds__(256)
 k_new_sample_flags(const long long* __restrict__ table, int buffer_size, const float* __restrict__ points,
                    const float* __restrict__ cert, const int* __restrict__ delta, int P, float resolution,
                    float max_valid_dist2, const float* __restrict__ x, const float* __restrict__ label, int n,
-                   float cert_thre, float label_max, int* __restrict__ flag) {
+                   float cert_thre, float label_max, int* __restrict__ flag, const long long* __restrict__ pool_counts) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (pool_counts) {  // x / label are the POOL arrays; this frame's samples are their last pool_counts[1] rows (device-side)
+    const long long cur = pool_counts[1], first = pool_counts[0] - cur;
+    if (i >= cur) {
+      flag[i] = 0;
+      return;
+    }
+    x += first * 3;
+    label += first;
+  }
   const float px = x[i * 3 + 0], py = x[i * 3 + 1], pz = x[i * 3 + 2];
   const int r0 = base_slot(px, py, pz, resolution, buffer_size);
   float best = 0.f;  // NeuralPoints.query_certainty (model/neural_points.py:1032-1051)
@@ -1159,9 +1168,10 @@ k_new_sample_flags(const long long* __restrict__ table, int buffer_size, const f
 
 __global__ void __launch_bounds__(256)
 k_new_sample_list(const int* __restrict__ flag, const int* __restrict__ pos, int n, long long offset,
-                  long long* __restrict__ idx_out, long long* __restrict__ count) {
+                  long long* __restrict__ idx_out, long long* __restrict__ count, const long long* __restrict__ pool_counts) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (pool_counts) offset = pool_counts[0] - pool_counts[1];
   if (i == n - 1) count[0] = (long long)pos[i] + flag[i];
   if (flag[i]) idx_out[pos[i]] = offset + i;
 }
@@ -1175,7 +1185,7 @@ extern "C" int clid_new_sample_select(const int64_t* buffer_pt_index, int64_t bu
                                       const float* point_certainties, const int32_t* delta, int32_t P, float resolution,
                                       float max_valid_dist2, const float* x, const float* sdf_label, int64_t n,
                                       float certainty_thre, float label_max, int64_t index_offset, int64_t* idx_out,
-                                      int64_t* count_out, void* workspace, void* stream) {
+                                      int64_t* count_out, const int64_t* pool_counts, void* workspace, void* stream) {
   if (n < 0 || n >= (1LL << 31) || buffer_size <= 0 || buffer_size >= (1LL << 30) || P <= 0 || !count_out || !workspace ||
       (n > 0 && (!buffer_pt_index || !neural_points || !point_certainties || !delta || !x || !sdf_label || !idx_out))) {
     clid_set_error("clid_new_sample_select: bad argument");
@@ -1192,13 +1202,13 @@ extern "C" int clid_new_sample_select(const int64_t* buffer_pt_index, int64_t bu
   const unsigned blocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_new_sample_flags, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const long long*>(buffer_pt_index),
                      (int)buffer_size, neural_points, point_certainties, delta, P, resolution, max_valid_dist2, x, sdf_label,
-                     (int)n, certainty_thre, label_max, flag);
+                     (int)n, certainty_thre, label_max, flag, reinterpret_cast<const long long*>(pool_counts));
   if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)n, s) != hipSuccess) {
     clid_set_error("clid_new_sample_select: scan failed");
     return CLID_E_HIP;
   }
   hipLaunchKernelGGL(k_new_sample_list, dim3(blocks), dim3(256), 0, s, flag, pos, (int)n, (long long)index_offset,
-                     reinterpret_cast<long long*>(idx_out), count);
+                     reinterpret_cast<long long*>(idx_out), count, reinterpret_cast<const long long*>(pool_counts));
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

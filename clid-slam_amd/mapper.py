@@ -607,8 +607,13 @@ class Mapper:
         self.cur_new_point_ratio = nm.update(update_points, origin, orientation, frame_id)
 
         self.determine_used_pose()
+        new_pending = None
         if overlap:
             main.wait_stream(side)
+            if cfg.bs_new_sample > 0:
+                # the new-sample selection (below) launched on the pool arrays still in flight: it reads the two pool counts on
+                # the device, so ONE read-back serves the pool maintenance and the selection
+                new_pending = self._new_sample_launch_pending(coord.shape[0])
             self._pool_filter_finish()
         elif fused_pool:
             self._pool_append_filter_fused(coord, gcoord if gcoord is not None else transform_torch(coord, cur_pose_torch),
@@ -623,7 +628,9 @@ class Mapper:
             cur_label = self.sdf_label_pool[self.sdf_label_pool.shape[0] - self.cur_sample_count:]
             nm.set_search_neighborhood(num_nei_cells=1, search_alpha=0.0)
             try:
-                if self._new_sample_fused_ok(cur, cur_label):
+                if new_pending is not None:
+                    self.new_idx = new_pending[: _lib.read_counts(self._new_count, 1)[0]]
+                elif self._new_sample_fused_ok(cur, cur_label):
                     self.new_idx = self._new_sample_select_fused(cur, cur_label)
                 else:
                     certainty = torch.zeros(cur.shape[0], device=cur.device)
@@ -678,6 +685,36 @@ class Mapper:
                 and big.dtype == torch.int64 and int(nm.buffer_size) < (1 << 30) and nm.point_certainties.dtype == torch.float32
                 and nm.neural_points.dtype == torch.float32 and os.environ.get("CLID_FUSED_NEWSEL", "1") != "0")
 
+    def _new_sample_launch_pending(self, n_upper: int):
+        """`clid_new_sample_select` on the output arrays of the pool call that is still in flight (the frame's samples are
+        their last counts[1] rows, read on the device); returns the index buffer, or None when the fused path does not apply.
+        The count is read after the pool's (`process_frame`)."""
+        cfg, nm = self.config, self.neural_points
+        _, out, _ = self._pool_pending
+        if not self._new_sample_fused_ok(out["gcoord"], out["label"]) or n_upper <= 0:
+            return None
+        lib = _lib.load()
+        dev = out["gcoord"].device
+        need = int(lib.clid_new_sample_workspace_bytes(n_upper))
+        if getattr(self, "_new_ws", None) is None or self._new_ws.numel() < need or self._new_ws.device != dev:
+            self._new_ws = torch.empty(int(need * 1.3) + 256, device=dev, dtype=torch.uint8)
+            self._new_count = torch.zeros(1, device=dev, dtype=torch.int64)
+        idx = torch.empty(n_upper, device=dev, dtype=torch.int64)
+        nm.set_search_neighborhood(num_nei_cells=1, search_alpha=0.0)
+        try:
+            if nm._delta.device != dev:
+                nm._delta = nm._delta.to(dev)
+            _lib.check(lib.clid_new_sample_select(
+                nm.buffer_pt_index.data_ptr(), int(nm.buffer_size), _lib.require_cuda(nm.neural_points, "neural_points", torch.float32).data_ptr(),
+                nm.point_certainties.contiguous().data_ptr(), nm._delta.data_ptr(), int(nm.neighbor_K), float(nm.resolution),
+                float(nm.max_valid_dist2), out["gcoord"].data_ptr(), out["label"].data_ptr(), n_upper,
+                float(getattr(cfg, "new_certainty_thre", 1.0)), float(cfg.surface_sample_range_m * 3.0), 0, idx.data_ptr(),
+                self._new_count.data_ptr(), self._pool_counts.data_ptr(), self._new_ws.data_ptr(), _lib.stream()),
+                "clid_new_sample_select")
+        finally:
+            nm.set_search_neighborhood(num_nei_cells=cfg.num_nei_cells, search_alpha=cfg.search_alpha)
+        return idx
+
     def _new_sample_select_fused(self, cur, cur_label):
         """utils/mapper.py:409-423 in one enqueue (`clid_new_sample_select`): certainty probe of the global map with the
         current stencil, the two tests, the ascending pool indices of the selected samples; ONE read-back (their count)."""
@@ -697,7 +734,7 @@ class Mapper:
             nm.point_certainties.contiguous().data_ptr(), nm._delta.data_ptr(), int(nm.neighbor_K), float(nm.resolution),
             float(nm.max_valid_dist2), x.data_ptr(), lab.data_ptr(), n, float(getattr(cfg, "new_certainty_thre", 1.0)),
             float(cfg.surface_sample_range_m * 3.0), int(self.pool_sample_count - self.cur_sample_count), idx.data_ptr(),
-            self._new_count.data_ptr(), self._new_ws.data_ptr(), _lib.stream()), "clid_new_sample_select")
+            self._new_count.data_ptr(), None, self._new_ws.data_ptr(), _lib.stream()), "clid_new_sample_select")
         return idx[: _lib.read_counts(self._new_count, 1)[0]]
 
     def _pool_append_filter_torch(self, coord, sdf_label, weight, stamp, sem_label, color_label, normal_label,

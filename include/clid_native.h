@@ -417,13 +417,15 @@ int clid_sample_compact(const float* coord, const float* label, const float* wei
 /* Newly observed samples of a frame (utils/mapper.py:400-423): certainty of the sample's probe cells in the GLOBAL map
  * (NeuralPoints.query_certainty with the stencil `delta` [P], model/neural_points.py:1032-1051) < certainty_thre and
  * |sdf_label| < label_max; idx_out = index_offset + position of the selected samples, ascending; count_out (device, 1 x
- * int64). */
+ * int64).  pool_counts != NULL (device, the counts_out of clid_pool_filter still in flight): x / sdf_label are the whole
+ * pool arrays, the frame's samples are their last pool_counts[1] of pool_counts[0] rows, n is an upper bound of that
+ * number and index_offset is ignored -- the selection then needs no read-back between the two calls. */
 int64_t clid_new_sample_workspace_bytes(int64_t n);
 int clid_new_sample_select(const int64_t* buffer_pt_index, int64_t buffer_size, const float* neural_points,
                            const float* point_certainties, const int32_t* delta, int32_t P, float resolution,
                            float max_valid_dist2, const float* x, const float* sdf_label, int64_t n, float certainty_thre,
-                           float label_max, int64_t index_offset, int64_t* idx_out, int64_t* count_out, void* workspace,
-                           void* stream);
+                           float label_max, int64_t index_offset, int64_t* idx_out, int64_t* count_out,
+                           const int64_t* pool_counts, void* workspace, void* stream);
 
 /* Per-call preparation of Mapper.mapping in one launch: zero `zero_floats` floats at `zero_base` (16-byte aligned,
  * multiple of 4: the fused gradient buffer, the Adam state and the loss rows restart every call, utils/mapper.py:634) and
