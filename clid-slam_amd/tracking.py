@@ -29,8 +29,9 @@ def _launch(neural_points, geo_decoder, config, rot, pos, pc_imu, per_point: boo
     dev = x.device
     view, keep = neural_points._map_view(True)
     W1, b1, W2, b2 = geo_decoder.flat_params()
-    r = (C.c_float * 9)(*torch.as_tensor(rot).detach().to("cpu", torch.float32).reshape(-1).tolist())
-    t = (C.c_float * 3)(*torch.as_tensor(pos).detach().to("cpu", torch.float32).reshape(-1).tolist())
+    # (the state lives on the device in the reference's filter: 12 numbers through the pinned landing buffer)
+    r = (C.c_float * 9)(*_lib.small_to_host(torch.as_tensor(rot).contiguous()).to(torch.float32).reshape(-1).tolist())
+    t = (C.c_float * 3)(*_lib.small_to_host(torch.as_tensor(pos).contiguous()).to(torch.float32).reshape(-1).tolist())
     out = {}
     if per_point:
         out["sdf"] = torch.empty(n, device=dev, dtype=torch.float32)
@@ -77,7 +78,7 @@ def normal_equations(neural_points, geo_decoder, config, rot, pos, pc_imu):
     S[iu[1], iu[0]] = ne[:21]
     b = torch.zeros(18, device=x.device, dtype=torch.float64)
     b[:6] = ne[21:27]
-    return S, b, int(ne[27].item())
+    return S, b, int(ne[27].item())  # (the caller solves the 6 x 6 system on the host next: this read-back is its input)
 
 
 class IEKFOMMeasurement:
