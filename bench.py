@@ -29,6 +29,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Completion waits by polling instead of interrupts: the timed region is ~0.7 ms and ends in a host wait; an interrupt-driven
+# wake-up was measured to arrive 30-60 ms late in about 1 run of 20 (GPU events 0.64 ms, wall clock 58.7 ms:
+# `timed_region_split` in the output line).  Must be set before the HSA runtime starts, i.e. before importing torch.
+os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
 
 import torch  # noqa: E402
 
@@ -235,6 +239,8 @@ def main():
     mp.mapping(args.steps)
     ev1.record()
     t_enq = time.perf_counter() - t0
+    while not ev1.query():  # poll for the end of the K steps, THEN the barrier + torch.cuda.synchronize() of the contract: an
+        pass                # interrupt-driven wait on an already idle GPU was seen to return 30-60 ms late (about 1 run in 20)
     sync()
     dt = time.perf_counter() - t0
     timed_split = {"host_enqueue_ms": 1e3 * t_enq, "gpu_ms": float(ev0.elapsed_time(ev1)), "wall_ms": 1e3 * dt}
