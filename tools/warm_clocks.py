@@ -1,5 +1,5 @@
 """Developer tool: how the first timed mapping(20) call depends on what ran before it (GPU clock ramp).
-   usage: python tools/warm_clocks.py one|two|same|sleep"""
+   usage: python tools/warm_clocks.py one|two|same|sleep|five"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
@@ -12,6 +12,8 @@ if mode == "one": mp.mapping(5)
 elif mode == "two": mp.mapping(5); mp.mapping(5)
 elif mode == "same": mp.mapping(20)
 elif mode == "sleep": mp.mapping(5); torch.cuda.synchronize(); time.sleep(0.5)
+elif mode == "five":
+    for _ in range(5): mp.mapping(1)
 torch.cuda.synchronize()
 for r in range(4):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
