@@ -157,7 +157,7 @@ __device__ __forceinline__ bool search8(const clid_map_view& mv, const DeltaLds&
     for (int t = 0; t < kProbeRows8; ++t) {  // straight-line (predicated) so all loads of the chunk batch
       const int o = o0 + 8 * t + lane8;
       int sl = r0 + dl.d[o];
-      if (sl >= B) sl -= B;
+      sl = (int)min((unsigned)sl, (unsigned)(sl - B));  // sl < 2 B: one conditional subtraction as add / sub / min
       bool in = o < mv.P;
       slot[t] = in ? sl : -2;
       home[t] = tab_home(sl, mv.log2cap);
