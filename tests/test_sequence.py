@@ -115,3 +115,68 @@ def test_subt_sequence_harness_first_frames_vs_oracle():
             # a certainty increment is one neighbour weight: a pair of near-equidistant 6th / 7th neighbours that swaps
             # between two correct fp32 evaluation orders moves one row by up to ~0.02 (observed: exactly one such row)
             assert c["max_ddecoder"] <= (1e-4 if c["n_dtheta_gt_1e4"] == 0 else 3e-3) and c["max_dcert"] <= 5e-2, c
+
+
+@pytest.mark.parametrize("layer_norm", [False, True])
+def test_large_local_map_tracks_the_oracle(layer_norm):
+    """A local map of > 2^17 neural points: the search then reads its probe prefilter from global memory and deals the
+    tasks to the XCDs by region (csrc/train.hip), paths no smaller scene reaches.  Four 96 m x 96 m planes of 0.4 m voxels
+    (~230 k points), samples scattered +-0.3 m around them; two iterations with given batches against the CPU oracle."""
+    from clid_slam_amd import Decoder, HotPathConfig, Mapper, NeuralPoints
+
+    class DS:
+        lose_track = False
+        stop_status = False
+        processed_frame = 0
+        gt_pose_provided = False
+
+    dev = "cuda:0"
+    cfg = HotPathConfig()
+    cfg.device, cfg.bs, cfg.bs_new_sample, cfg.layer_norm_on = dev, 4096, 0, layer_norm
+    cfg.buffer_size = 8_000_009
+    cfg.feature_std = 0.05
+    torch.manual_seed(11)
+    nm = NeuralPoints(cfg)
+    nm.local_map_radius = 500.0
+    nm.travel_dist = torch.zeros(4, device=dev)
+    g = torch.Generator().manual_seed(5)
+    u = torch.arange(240, dtype=torch.float32) * 0.4 - 48.0
+    uu, vv = torch.meshgrid(u, u, indexing="ij")
+    planes = []
+    for k, z in enumerate((0.1, 3.3, 6.5, 9.7)):  # one point per voxel: 4 x 57 600
+        jit = (torch.rand((uu.numel(), 3), generator=g) - 0.5) * 0.2
+        planes.append(torch.stack((uu.reshape(-1) + 0.2, vv.reshape(-1) + 0.2, torch.full((uu.numel(),), z)), 1) + jit)
+    pts = torch.cat(planes)
+    nm.update(pts.to(dev), torch.zeros(3, device=dev), torch.eye(3, device=dev), 0)
+    assert nm.local_count() > (1 << 17)
+    dec = Decoder(cfg, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, 1)
+    mp = Mapper(cfg, DS(), nm, None, dec)
+    n_pool = 60_000
+    base = pts[torch.randint(0, pts.shape[0], (n_pool,), generator=g)]
+    off = (torch.rand((n_pool, 3), generator=g) - 0.5) * 0.6
+    coord = base + off
+    label = off[:, 2].clone()
+    weight = torch.rand(n_pool, generator=g) * 0.5 + 0.5
+    mp.set_pool(coord, label, weight, torch.zeros(n_pool, dtype=torch.int32))
+    iters = 2
+    idx = torch.randint(0, n_pool, (iters, cfg.bs), generator=g).to(dev)
+    st = _oracle_state(nm, cfg)
+    od = O.DecoderParams(*[p.detach().cpu().clone() for p in dec.flat_params()], sdf_scale=dec.sdf_scale)
+    opool = O.SamplePool(coord.clone(), label.clone(), torch.zeros(n_pool, dtype=torch.int32), weight.clone())
+    recs = O.mapping_iters(st, od, opool, idx.cpu(), O.LoopConfig(sigma=mp.sdf_scale), record=True)
+    mp.mapping(iters, index_seq=idx)
+    view, _ = nm._map_view(True)
+    assert view.log2filter > 18  # the global-memory prefilter (and with it the XCD-aware task mapping) was in use
+    got = mp.last_losses.cpu()
+    for it, r in enumerate(recs):
+        assert abs(float(got[it, 0]) - float(r["loss"])) <= 2e-5, (it, got[it], r["loss"])
+    noise = torch.zeros_like(recs[-1]["theta"], dtype=torch.bool)
+    for r in recs:
+        ga = r["grad_theta"].abs()
+        noise |= (ga < 1e-10) & (ga.max(dim=1, keepdim=True).values > 0)
+    err = (nm.local_geo_features.detach().cpu() - recs[-1]["theta"]).abs()
+    assert float(err[~noise].max()) <= 1e-4 and int((err > 1e-4).sum()) <= 8
+    for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
+        assert float((t.detach().cpu() - o).abs().max()) <= 1e-4
+    assert float((nm.local_point_certainties.cpu() - recs[-1]["certainties"]).abs().max()) <= 2e-3
+    assert torch.equal(nm.local_point_ts_update.cpu(), recs[-1]["ts_update"])
