@@ -848,6 +848,21 @@ def test_mapping_prep_resets_and_draws_like_the_host_restatement():
             want = a[np.argsort(ka, kind="stable")]  # stable: ties keep the draw order
             assert np.array_equal(b, want), (it, lo, int((b != want).sum()))
 
+    # degenerate scene (60 % of the pool in ONE voxel): a key range then exceeds a sorting block's capacity and keeps its
+    # draw order -- the batch is still a permutation of the draws, and the same one every time
+    coords3 = coords.clone()
+    coords3[: int(pool * 0.6)] = torch.tensor([1.0, 2.0, 3.0], device=dev)
+    outs = []
+    for _ in range(2):
+        o3 = torch.empty_like(raw)
+        _lib.check(lib.clid_mapping_prep(None, 0, o3.data_ptr(), iters2, bs2, 0, pool, None, 0, seed, 77, coords3.data_ptr(), 0.4,
+                                         ws2.data_ptr(), _lib.stream()), "clid_mapping_prep")
+        outs.append(o3.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    for it in range(iters2):
+        for lo in range(0, bs2, 16384):
+            assert np.array_equal(np.sort(outs[0][it, lo:lo + 16384]), np.sort(raw_n[it, lo:lo + 16384]))
+
     # through the Mapper: two calls draw different batches, a second Mapper with the same seed reproduces them
     import bench
     from clid_slam_amd import HotPathConfig
