@@ -73,3 +73,59 @@ def test_prune_and_recreate_hash_on_the_gpu_match_the_reference():
     from test_host_logic import _g11_run
 
     _g11_run("cuda")
+
+
+def _splitmix64(x):
+    M = (1 << 64) - 1
+    x = (x + 0x9E3779B97F4A7C15) & M
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
+    return x ^ (x >> 31)
+
+
+@pytest.mark.parametrize("n_a,n_b,capacity", [(50_000, 10_000, 30_000), (1000, 300, 10_000_000), (0, 5000, 2000), (70_001, 0, 1000)])
+def test_pool_filter_window_capacity_and_order(n_a, n_b, capacity):
+    """clid_pool_filter (utils/mapper.py:297-392): append, float64 window test, `kept - capacity` uniform picks WITH
+    replacement among the kept samples dropped (:352-361), stable compaction of the five arrays; the two counts.  The drop
+    uses a counter-based generator (splitmix64(seed + t) mod kept), restated here."""
+    import ctypes as C
+
+    from clid_slam_amd import _lib
+
+    lib = _lib.load()
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(n_a + n_b)
+    n = n_a + n_b
+    gcoord = (torch.rand((n, 3), generator=g) * 40.0 - 20.0)
+    coord = torch.rand((n, 3), generator=g)
+    label, weight = torch.randn(n, generator=g), torch.rand(n, generator=g)
+    stamp = torch.randint(0, 50, (n,), generator=g, dtype=torch.int32)
+    origin = (1.5, -2.0, 0.5)
+    radius = 15.0
+    d = [t.to(dev).contiguous() for t in (coord, gcoord, label, weight, stamp)]
+    a = [t[:n_a] for t in d]
+    b = [t[n_a:] for t in d]
+    out = [torch.empty((n + 8, 3), device=dev), torch.empty((n + 8, 3), device=dev), torch.empty(n + 8, device=dev),
+           torch.empty(n + 8, device=dev), torch.empty(n + 8, device=dev, dtype=torch.int32)]
+    ws = torch.empty(int(lib.clid_pool_workspace_bytes(n)), device=dev, dtype=torch.uint8)
+    counts = torch.zeros(3, device=dev, dtype=torch.int64)
+    seed = 0x1234ABCD
+    ptr = lambda t: t.data_ptr() if t.numel() else None
+    _lib.check(lib.clid_pool_filter(ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]), ptr(a[4]), n_a, ptr(b[0]), ptr(b[1]), ptr(b[2]),
+                                    ptr(b[3]), ptr(b[4]), n_b, (C.c_double * 3)(*origin), radius * radius, capacity, seed,
+                                    out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), out[4].data_ptr(),
+                                    counts.data_ptr(), ws.data_ptr(), _lib.stream()), "clid_pool_filter")
+    kept, kept_cur = [int(v) for v in counts[:2].tolist()]
+    # host restatement
+    dist2 = ((gcoord.double() - torch.tensor(origin, dtype=torch.float64)) ** 2).sum(1)
+    flag = (dist2 < radius * radius).numpy()
+    win = np.nonzero(flag)[0]
+    if n > capacity and len(win) > capacity:
+        for t in range(len(win) - capacity):
+            flag[win[_splitmix64(seed + t) % len(win)]] = False
+    want = np.nonzero(flag)[0]
+    assert kept == len(want) and kept_cur == int((want >= n_a).sum())
+    if n > capacity and len(win) > capacity:
+        assert capacity <= kept < len(win)
+    for got, src in zip(out, (coord, gcoord, label, weight, stamp)):
+        assert torch.equal(got[:kept].cpu(), src[want])
