@@ -168,7 +168,7 @@ class NeuralPoints(nn.Module):
         st = dict(st)
         st["_tables"] = {}
         st.pop("_replica_gens", None)  # torch.Generator objects do not pickle
-        for k in ("_sensor_pos_host", "_win_ws", "_win_counts", "_ins_ws", "_ins_count", "_gbuf", "_stencils", "_presampled"):
+        for k in ("_sensor_pos_host", "_win_ws", "_win_counts", "_ins_ws", "_ins_count", "_gbuf", "_stencils", "_presampled", "_track_scratch"):
             st.pop(k, None)
         for k in self._GLOBAL_ARRAYS:  # views of the capacity buffers would drag the whole buffers into the pickle
             t = st.get(k)

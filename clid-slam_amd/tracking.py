@@ -34,10 +34,16 @@ def _launch(neural_points, geo_decoder, config, rot, pos, pc_imu, per_point: boo
     t = (C.c_float * 3)(*_lib.small_to_host(torch.as_tensor(pos).contiguous()).to(torch.float32).reshape(-1).tolist())
     out = {}
     if per_point:
-        out["sdf"] = torch.empty(n, device=dev, dtype=torch.float32)
-        out["grad"] = torch.empty((n, 3), device=dev, dtype=torch.float32)
-        out["pmap"] = torch.empty((n, 3), device=dev, dtype=torch.float32)
-        out["valid"] = torch.empty(n, device=dev, dtype=torch.int32)
+        # raw per-point outputs: a cached scratch set per (n, device) -- everything handed to the caller below is derived
+        # by masked indexing, i.e. copied (the filter calls this 5-20 times per scan)
+        cache = neural_points.__dict__.setdefault("_track_scratch", {})
+        out = cache.get((n, str(dev)))
+        if out is None:
+            if len(cache) >= 4:
+                cache.clear()
+            out = cache[(n, str(dev))] = {
+                "sdf": torch.empty(n, device=dev, dtype=torch.float32), "grad": torch.empty((n, 3), device=dev, dtype=torch.float32),
+                "pmap": torch.empty((n, 3), device=dev, dtype=torch.float32), "valid": torch.empty(n, device=dev, dtype=torch.int32)}
     ne = torch.zeros(28, device=dev, dtype=torch.float64) if reduce else None
     _lib.check(
         lib.clid_track_model(C.byref(view), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
