@@ -10,7 +10,8 @@ points, decode, BCE + numerical eikonal loss, backward, Adam.  Workloads (BASELI
   cfg2 (default)  run_ncd128.yaml defaults: fp32, 16384 samples per GPU per step (weak scaling for N > 1)
   cfg3            65536 samples per step, decoder contractions on bf16 MFMA (fp32 accumulation / master weights)
   cfg4            262144 samples per step GLOBAL, sharded over the N ranks (strong scaling), fp32
-(cfg5, the SubT_MRS sequence, is a multi-frame run: tools/sequence_bench.py.)
+(cfg5, the SubT_MRS sequence, is a multi-frame run: bench_sequence.py [--gpus N].)
+`--gpus N` without a launcher around it (WORLD_SIZE unset) starts the N ranks itself through torch.distributed.run.
 The timed region is EXACTLY `--steps` iterations of one `mapping()` call between two barrier+synchronize pairs, all
 inputs resident in HBM.  Also reported: the reference's per-frame regime (`mapping(10)` calls, slam.py:187-200, median
 of 100), the per-kernel durations / roofline fractions of a profiled pass (hipExtLaunchKernelGGL start/stop events =
@@ -21,6 +22,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import statistics
@@ -122,12 +124,16 @@ def kernel_report(lib, mp, steps, bs_local, decim, M, decode_variant):
     """Profiled pass: average dispatch duration per kernel + roofline fraction on the section-8(d) bytes."""
     from clid_slam_amd import _lib
 
-    lib.clid_profile_enable(1)
-    mp.mapping(steps)
-    out = (C.c_double * 5)()
+    prof = lib.clid_profile_create()  # handed to the loop through clid_train_args.prof (no state inside the library)
+    mp._prof = prof
+    out = (C.c_double * 6)()
     n = C.c_int(0)
-    _lib.check(lib.clid_profile_read(out, C.byref(n), _lib.stream()), "clid_profile_read")
-    lib.clid_profile_enable(0)
+    try:
+        mp.mapping(steps)
+        _lib.check(lib.clid_profile_read(prof, out, C.byref(n), _lib.stream()), "clid_profile_read")
+    finally:
+        mp._prof = None
+        lib.clid_profile_destroy(prof)
     iters = max(n.value, 1)
     Q = bs_local + 6 * ((bs_local + decim - 1) // decim)
     hoisted = out[1] > 0.0
@@ -138,7 +144,8 @@ def kernel_report(lib, mp, steps, bs_local, decim, M, decode_variant):
          "752 B/query (316 fwd after the search + 436 bwd) x %d query points" % Q if hoisted else "1440 B/query + 24 B/sample"),
         ("k_train_fused8<1> (search, per iteration of a <=32-iteration launch)", out[1] / iters,
          Q * B_SEARCH_Q + bs_local * B_POOL_SAMPLE, "688 B/query x %d + 24 B x %d samples" % (Q, bs_local)),
-        ("k_reduce_partials", out[2] / iters, 0.0, ""),
+        ("k_reduce_partials (+ pack of the touched rows)", out[2] / iters, 0.0, ""),
+        ("k_touch_bits + k_touch_scan (per iteration of a chunk)", out[5] / iters, 0.0, ""),
         ("k_adam_all", out[3] / iters, B_ADAM_ROW * (M + 1) + 833 * B_ADAM_PARAM, "256 B/row x %d rows + 28 B x 833" % (M + 1)),
     ]
     kernels = []
@@ -159,12 +166,14 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--bs", type=int, default=None, help="override the samples per step (per GPU for weak scaling)")
     ap.add_argument("--scaling", default=None, choices=("weak", "strong"))
-    ap.add_argument("--decode", type=int, default=None, choices=(0, 1, 2), help="override the decode kernel (clid_decode_variant)")
+    ap.add_argument("--decode", type=int, default=None, choices=(0, 1, 2), help="override the decode kernel (clid_train_args.decode_variant)")
     ap.add_argument("--frame-calls", type=int, default=100, help="repetitions of mapping(10) for the per-frame regime (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layer-norm", action="store_true", help="layer_norm_on: True (run_SubT_MRS.yaml:27) instead of the ncd128 default")
     ap.add_argument("--freeze-decoder", action="store_true",
                     help="steady-state variant: decoder frozen (freeze_model, slam.py:193-196); not the headline config")
+    ap.add_argument("--diag", action="store_true", help="extra host time stamps around the timed region (start latency of the "
+                    "first launch, poll vs synchronize); adds two event polls to the region: measurement aid only")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for single-GPU dry runs)")
     args = ap.parse_args()
     wl = dict(CONFIGS[args.config])
@@ -177,14 +186,23 @@ def main():
     elif "CLID_DECODE" in os.environ and args.config == "cfg2":
         wl["decode"] = int(os.environ["CLID_DECODE"])
 
+    if args.gpus < 1:
+        raise SystemExit(f"--gpus {args.gpus}")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) ourselves
+        from clid_slam_amd.dist import respawn_under_torchrun
+
+        raise SystemExit(respawn_under_torchrun(os.path.abspath(__file__), sys.argv[1:], args.gpus, args.backend))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would report the wrong n_gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    local_dev = local_rank % torch.cuda.device_count()  # dry runs may put several ranks on one GPU
+    if world > 1 and args.backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} over RCCL but only {torch.cuda.device_count()} GPU(s) visible (one device per rank)")
+    local_dev = local_rank % torch.cuda.device_count()  # gloo dry runs may put several ranks on one GPU
     torch.cuda.set_device(local_dev)
     device = f"cuda:{local_dev}"
     dist = None
@@ -212,11 +230,12 @@ def main():
     cfg.bs = bs_global
     nm, dec, mp, scene = build_scene(cfg, device)
     lib = _lib.load()
-    lib.clid_decode_variant(wl["decode"])
     rccl_ranks = 0
     if dist:  # RCCL communicator behind the C ABI (csrc/comm.hip): the sharded loop then needs no Python per iteration
         comm = _lib.rccl_comm(dist)
         rccl_ranks = int(lib.clid_comm_size(comm)) if comm is not None else 0
+        if args.backend == "nccl" and rccl_ranks != world:
+            raise SystemExit(f"rank {rank}: the RCCL communicator behind the C ABI has {rccl_ranks} ranks, expected {world}")
     M = nm.local_count()
     decim = cfg.gradient_decimation
 
@@ -229,21 +248,37 @@ def main():
         from clid_slam_amd.tools import freeze_model
 
         freeze_model(dec)
+    mp.decode_variant = wl["decode"]
     mp.reserve(max(args.steps, args.warmup, 10))  # workspaces sized once: nothing is allocated inside a timed region
     for _ in range(args.warmup):  # W untimed steps, one per call: the GPU's clocks ramp over several hundred us of work
         mp.mapping(1)             # (a single 5-iteration call leaves the first timed call 14 % slow: tools/warm_clocks.py)
     sync()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # no collector pause inside the 0.7 ms region (what `timeit` does too): a full collection of this process' ~10^6
+    # objects takes several ms -- one run in ~25 showed 5 ms of wall clock around 0.65 ms of GPU time
+    gc.collect()
+    gc.disable()
+    sync()
     t0 = time.perf_counter()
     ev0.record()
+    t_start = None
+    if args.diag:
+        while not ev0.query():
+            pass
+        t_start = time.perf_counter() - t0
     mp.mapping(args.steps)
     ev1.record()
     t_enq = time.perf_counter() - t0
     while not ev1.query():  # poll for the end of the K steps, THEN the barrier + torch.cuda.synchronize() of the contract: an
         pass                # interrupt-driven wait on an already idle GPU was seen to return 30-60 ms late (about 1 run in 20)
+    t_poll = time.perf_counter() - t0
     sync()
     dt = time.perf_counter() - t0
-    timed_split = {"host_enqueue_ms": 1e3 * t_enq, "gpu_ms": float(ev0.elapsed_time(ev1)), "wall_ms": 1e3 * dt}
+    gc.enable()
+    timed_split = {"host_enqueue_ms": 1e3 * t_enq, "gpu_ms": float(ev0.elapsed_time(ev1)), "wall_ms": 1e3 * dt,
+                   "poll_done_ms": 1e3 * t_poll}
+    if t_start is not None:
+        timed_split["first_event_done_ms"] = 1e3 * t_start
     if dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

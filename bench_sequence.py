@@ -2,7 +2,7 @@
 """BASELINE.json configs[4]: the run_SubT_MRS.yaml sequence workload -- online mapping at scan rate with the eikonal
 term -- on a synthetic 200-frame sweep (the datasets are not shipped; SURVEY.md section 8d "Sequence").
 
-    python bench_sequence.py [--frames 200] [--check-frames 0]
+    python bench_sequence.py [--frames 200] [--check-frames 0] [--gpus N [--backend nccl|gloo]]
 
 Per frame, exactly as slam.py:135-200 drives the objects (tracking is out of scope: the known poses play the role of
 `gt_poses`): new `travel_dist` tensor -> `Mapper.process_frame` (raw-point map, `DataSampler.sample` with the
@@ -10,6 +10,11 @@ region-specific SDF labels, `NeuralPoints.update`, pool append / window filter, 
 iteration offset) -> iterations = iters * init_iter_ratio on frame 0, else iters (+ offset) -> `freeze_model` at
 frame `freeze_after_frame` -> `Mapper.mapping`.  Config values = what the reference's Config.load resolves for
 config/run_SubT_MRS.yaml (tests/golden/g13_config_resolved.json: layer_norm_on True, free_sample_begin_ratio 0.8).
+`--gpus N` (one process per GPU, started here through torch.distributed.run when no launcher is around it, or by the
+driver's `python -m torch.distributed.run ... bench_sequence.py --gpus N`): every rank processes the SAME frames -- the map
+and the pool are replicas (across scans the path is "replicas only", SURVEY.md section 8e: every scan mutates the shared
+map) -- and `Mapper.mapping` shards each batch over the ranks with the gradient exchange per iteration; frame times are
+the maximum over the ranks, and the line reports what the exchange moved per iteration.
 Prints one JSON line: scans/s and sampled-points/s over frames 1..N-1 (frame 0 with its 400 iterations separately),
 per-frame time split, and the growth of the local map.  `--check-frames K` also replays the mapping() calls of the
 first K frames on the CPU oracle from a snapshot of the state (slow; tests/test_sequence.py does this under -m gpu).
@@ -121,7 +126,11 @@ def run(frames, device, check_frames=0, seed=42, quiet=False, breakdown=None, af
         sync()
         t2 = time.perf_counter()
         n_it = int(mp.last_losses.shape[0])
+        ex = getattr(mp, "last_exchange", None)
         rows.append(dict(frame=fid, rays=int(pts.shape[0]), t_process_ms=1e3 * (t1 - t0), t_mapping_ms=1e3 * (t2 - t1), iters=n_it,
+                         exchange_bytes_per_iter=None if ex is None else ex["bytes_per_iter"],
+                         dense_bytes_per_iter=None if ex is None else ex["dense_bytes_per_iter"],
+                         exchange_mode=None if ex is None else ex["mode"],
                          pool=int(mp.pool_sample_count), new=int(0 if mp.new_idx is None else mp.new_idx.shape[0]),
                          M_global=int(nm.count()), M_local=int(nm.local_count()), loss=float(mp.last_losses[-1, 0])))
         if snap is not None:
@@ -181,15 +190,51 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="synchronised per-stage timers inside process_frame (perturbs the totals)")
     ap.add_argument("--profile-last", action="store_true",
                     help="per-kernel dispatch durations of 10 more iterations on the final state (large local map, full pool)")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks (one process per GPU); every rank feeds the same frames, mapping() shards")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for dry runs on fewer GPUs)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        from clid_slam_amd.dist import respawn_under_torchrun
+
+        raise SystemExit(respawn_under_torchrun(os.path.abspath(__file__), sys.argv[1:], args.gpus, args.backend))
     if not torch.cuda.is_available():
         raise SystemExit("bench_sequence.py needs a GPU (the HIP path has no CPU fallback)")
-    device = "cuda:0"
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1 and args.backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} over RCCL but only {torch.cuda.device_count()} GPU(s) visible (one device per rank)")
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    device = f"cuda:{local_dev}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(args.backend)
     import clid_slam_amd  # noqa: F401
+    from clid_slam_amd import _lib
+
+    rccl_ranks = 0
+    if dist:
+        comm = _lib.rccl_comm(dist)
+        rccl_ranks = int(_lib.load().clid_comm_size(comm)) if comm is not None else 0
+        if args.backend == "nccl" and rccl_ranks != world:
+            raise SystemExit(f"rank {rank}: the RCCL communicator behind the C ABI has {rccl_ranks} ranks, expected {world}")
 
     t_all = time.perf_counter()
     acc = {} if args.breakdown else None
-    cfg, rows, checks, objs = run(args.frames, device, args.check_frames, quiet=args.quiet, breakdown=acc)
+    cfg, rows, checks, objs = run(args.frames, device, args.check_frames, quiet=args.quiet or rank != 0, breakdown=acc)
+    if dist:  # a frame is done when its slowest rank is
+        t = torch.tensor([[r["t_process_ms"], r["t_mapping_ms"]] for r in rows], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        for r, (tp, tm) in zip(rows, t.tolist()):
+            r["t_process_ms"], r["t_mapping_ms"] = tp, tm
     large = None
     if args.profile_last:
         import bench
@@ -210,7 +255,15 @@ def main():
               "median_mapping_ms": sorted(r["t_mapping_ms"] for r in tail)[len(tail) // 2]}
     line = {
         "metric": "online mapping rate on the run_SubT_MRS.yaml sequence workload (synthetic 1 m/frame sweep)",
-        "value": len(steady) / t_frames, "unit": "scans/s", "frames": len(rows), "data": "synthetic", "dtype": "f32", "n_gpus": 1,
+        "value": len(steady) / t_frames, "unit": "scans/s", "frames": len(rows), "data": "synthetic", "dtype": "f32", "n_gpus": world,
+        "scaling": "strong" if world > 1 else None, "rccl_ranks_in_c_abi": rccl_ranks,
+        "gradient_exchange": None if world == 1 else {
+            "mode": rows[-1]["exchange_mode"], "M_local_last": rows[-1]["M_local"],
+            "bytes_per_iter_last_frame": rows[-1]["exchange_bytes_per_iter"], "dense_bytes_per_iter_last_frame": rows[-1]["dense_bytes_per_iter"],
+            "bytes_per_iter_max": max(r["exchange_bytes_per_iter"] for r in rows),
+            "note": "4-byte words this rank put into all-reduces per iteration, averaged over the frame's mapping() call: the "
+                    "per-iteration [848 | 9 x touched rows] floats + the chunk's touched-row flags (1 byte per map row per "
+                    "iteration, MAX); dense = the 848 + 16 x (M + 1) float buffer of round 2"},
         "scan_rate_required_hz": 10.0, "realtime_factor": len(steady) / t_frames / 10.0, "steady_state": steady_report,
         "sampled_points_per_s_in_mapping": cfg.bs * n_iters / t_map, "sampled_points_per_s_end_to_end": cfg.bs * n_iters / t_frames,
         "ms_per_frame": {"process_frame": 1e3 * (t_frames - t_map) / len(steady), "mapping": 1e3 * t_map / len(steady),
@@ -226,7 +279,10 @@ def main():
         "process_frame_stage_ms": None if acc is None else {k: 1e3 * sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in acc.items()}, "wall_s": time.perf_counter() - t_all,
         "every_25th_frame": [rows[i] for i in range(0, len(rows), 25)],
     }
-    print(json.dumps(line))
+    if rank == 0:
+        print(json.dumps(line))
+    if dist:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -49,6 +49,10 @@ class TrainArgs(C.Structure):
         ("sdf_scale", _f32), ("defer_reduce", _i32),
         ("grad", _vp), ("ws", _vp), ("loss_out", _vp),
         ("debug_flags", _i32), ("grad_stride", _i32),
+        # per-call switches and aids (ABI 3: no process-global state in the library)
+        ("decode_variant", _i32), ("pipeline", _i32), ("sdf_dbg", _vp), ("prof", _vp),
+        # touched-row bookkeeping of the hoisted-search loop (NULL = dense exchange / dense Adam sweep)
+        ("touch_ws", _vp), ("touch_stride", _i64), ("touch_iter", _i32), ("touch_pad", _i32), ("cbuf", _vp),
     ]
 
 
@@ -128,28 +132,45 @@ _SIGS = {
     "clid_read_back": (C.c_int, [_vp, _i32, _vp, _vp]),
     "clid_mapping_prep_workspace_bytes": (_i64, [_i32, _i32]),
     "clid_mapping_prep": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i64, _vp, _i64, C.c_uint64, C.c_uint64, _vp, C.c_float,
-                                    _vp, _vp]),
+                                    _vp, _i32, _i32, _vp]),
     "clid_debug_prep_draw": (_i64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
     "clid_comm_unique_id": (C.c_int, [_vp]),
     "clid_comm_init": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
     "clid_comm_size": (C.c_int, [_vp]),
+    "clid_comm_available": (C.c_int, []),
     "clid_comm_allreduce": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "clid_comm_destroy": (C.c_int, [_vp]),
     "clid_mapping_run_dist": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), C.POINTER(AdamArgs), _i32, _vp, _i64, _vp,
-                                        _vp, _i64, _vp]),
-    "clid_mapping_pipeline": (C.c_int, [C.c_int]),
-    "clid_decode_variant": (C.c_int, [C.c_int]),
-    "clid_debug_decode_sdf_out": (C.c_int, [_vp]),
+                                        _vp, _i64, C.POINTER(_i64), _vp]),
+    "clid_touch_stride": (_i64, [_i32]),
+    "clid_touch_workspace_bytes": (_i64, [_i32, _i32]),
+    "clid_train_touch_scan": (C.c_int, [C.POINTER(TrainArgs), _i32, _i32, _i32, C.POINTER(_i32), _vp]),
+    "clid_train_chunk_iters": (_i32, [C.POINTER(TrainArgs)]),
     "clid_train_decode_kernel": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs)]),
     "clid_train_search_floats": (_i64, [_i32, _i64, _i32, _i32, _i32]),
     "clid_train_search": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), _i32, _vp, _i64, _vp, _vp]),
     "clid_train_decode": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), _vp, _vp]),
-    "clid_profile_enable": (C.c_int, [C.c_int]),
-    "clid_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int), _vp]),
+    "clid_profile_create": (_vp, []),
+    "clid_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int), _vp]),
+    "clid_profile_destroy": (None, [_vp]),
 }
 
 EXPORTS = tuple(_SIGS)
 _lib = None
+
+
+def _env_int(name: str, default: int, lo: int, hi: int) -> int:
+    try:
+        v = int(os.environ.get(name, default))
+    except ValueError:
+        return default
+    return v if lo <= v <= hi else default
+
+
+# Defaults of the loop's per-call switches (clid_train_args.decode_variant / .pipeline); a `Mapper` may override them with
+# its attributes of the same names.  They were process-global setters inside the library in ABI 2.
+DECODE_VARIANT = _env_int("CLID_DECODE", 1, 0, 2)   # 0 VALU kernel, 1 tile kernel fp32 MFMA, 2 tile kernel bf16 MFMA
+PIPELINE = _env_int("CLID_PIPELINE", 1, 0, 1)       # 1 hoisted searches, 0 one fused search+decode launch per iteration
 
 
 def load():
@@ -167,7 +188,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.clid_abi_version() != 2:
+    if lib.clid_abi_version() != 3:
         raise RuntimeError("libclid_native.so ABI version mismatch; rebuild")
     _lib = lib
     return lib
@@ -208,6 +229,12 @@ def rccl_comm(dist):
     lib = load()
     dev = torch.device("cuda", torch.cuda.current_device())
     rank, world = dist.get_rank(), dist.get_world_size()
+    # every rank must be able to resolve librccl BEFORE anyone enters the collective ncclCommInitRank: a rank whose dlopen
+    # fails would return at once and leave the others waiting inside it
+    ok = torch.tensor([1 if lib.clid_comm_available() == 1 else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) != 1:
+        return None
     ident = torch.zeros(129, dtype=torch.uint8, device=dev)  # [128] id | ok flag
     if rank == 0:
         buf = (C.c_uint8 * 128)()

@@ -15,7 +15,7 @@ extern "C" void clid_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* clid_last_error(void) { return g_err; }
-extern "C" int clid_abi_version(void) { return 2; }
+extern "C" int clid_abi_version(void) { return 3; }
 
 // Small device -> host read-back through a pinned landing buffer (a pageable destination makes the runtime stage the
 // copy and block for ~100 us): the data-dependent counts of the map-maintenance calls.  Synchronises `stream`.
@@ -32,18 +32,26 @@ extern "C" int clid_read_back(const void* device_src, int32_t bytes, void* host_
     return CLID_E_HIP;
   }
   hipStream_t s = (hipStream_t)stream;
-  static thread_local hipEvent_t ev = nullptr;
-  bool ok = hipMemcpyAsync(pinned, device_src, (size_t)bytes, hipMemcpyDeviceToHost, s) == hipSuccess;
+  // the polled event belongs to a device: one per (host thread, device), created on the device that is current now (a
+  // thread that reads back on another GPU's stream would otherwise record a foreign-device event)
+  static thread_local hipEvent_t evs[16] = {};
+  int dev = 0;
+  bool ok = hipGetDevice(&dev) == hipSuccess && dev >= 0;
+  hipEvent_t* evp = (ok && dev < 16) ? &evs[dev] : nullptr;
+  ok = ok && hipMemcpyAsync(pinned, device_src, (size_t)bytes, hipMemcpyDeviceToHost, s) == hipSuccess;
   if (ok) {
     // the host is about to size the next launches with these numbers: poll an event instead of hipStreamSynchronize
-    // (20 us per frame of eight read-backs on the sequence workload)
-    if (!ev) ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventRecord(ev, s) == hipSuccess;
-    if (ok) {
+    // (20 us per frame of eight read-backs on the sequence workload); anything unexpected falls back to the synchronise
+    bool polled = false;
+    if (evp && (*evp || hipEventCreateWithFlags(evp, hipEventDisableTiming) == hipSuccess) && hipEventRecord(*evp, s) == hipSuccess) {
       hipError_t q;
-      while ((q = hipEventQuery(ev)) == hipErrorNotReady) {
+      while ((q = hipEventQuery(*evp)) == hipErrorNotReady) {
       }
-      ok = q == hipSuccess;
+      polled = q == hipSuccess;
+    }
+    if (!polled) {
+      (void)hipGetLastError();
+      ok = hipStreamSynchronize(s) == hipSuccess;
     }
   }
   if (!ok) {

@@ -13,8 +13,8 @@ namespace {
 
 typedef struct { char internal[128]; } nccl_uid;  // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128, rccl.h:40-43)
 typedef void* nccl_comm;
-// rccl.h: ncclSum = 0, ncclMax = 2; ncclInt32 = 2, ncclFloat32 = 7
-constexpr int kNcclSum = 0, kNcclMax = 2, kNcclInt32 = 2, kNcclFloat32 = 7;
+// rccl.h: ncclSum = 0, ncclMax = 2; ncclUint8 = 1, ncclInt32 = 2, ncclFloat32 = 7
+constexpr int kNcclSum = 0, kNcclMax = 2, kNcclUint8 = 1, kNcclInt32 = 2, kNcclFloat32 = 7;
 
 struct Rccl {
   void* handle = nullptr;
@@ -99,18 +99,22 @@ extern "C" int clid_comm_size(const clid_comm* comm) {
   return n;
 }
 
-extern "C" int clid_comm_allreduce(clid_comm* comm, void* buf, int64_t count, int32_t is_int32, int32_t op_max,
+extern "C" int clid_comm_allreduce(clid_comm* comm, void* buf, int64_t count, int32_t dtype, int32_t op_max,
                                    void* stream) {
-  if (!comm || !buf || count < 0) {
+  if (!comm || !buf || count < 0 || dtype < 0 || dtype > 2) {
     clid_set_error("clid_comm_allreduce: bad argument");
     return CLID_E_ARG;
   }
   if (count == 0) return CLID_OK;
-  if (int rc = rccl().AllReduce(buf, buf, (size_t)count, is_int32 ? kNcclInt32 : kNcclFloat32, op_max ? kNcclMax : kNcclSum,
-                                comm->comm, (hipStream_t)stream))
+  const int nd = dtype == 0 ? kNcclFloat32 : (dtype == 1 ? kNcclInt32 : kNcclUint8);
+  if (int rc = rccl().AllReduce(buf, buf, (size_t)count, nd, op_max ? kNcclMax : kNcclSum, comm->comm, (hipStream_t)stream))
     return fail("ncclAllReduce", rc);
   return CLID_OK;
 }
+
+// 1 when librccl resolves in this process (dlopen + every symbol): lets the ranks agree BEFORE anyone enters the collective
+// ncclCommInitRank, where a rank that could not load RCCL would leave the others waiting forever
+extern "C" int clid_comm_available(void) { return rccl().ok ? 1 : 0; }
 
 extern "C" int clid_comm_destroy(clid_comm* comm) {
   if (!comm) return CLID_OK;

@@ -638,7 +638,9 @@ extern "C" int clid_transform_points(const float* points, int32_t n, const float
 extern "C" int clid_local_to_global(const int64_t* ids, int32_t n, int64_t pad_row, const float* local_feat,
                                     const float* local_cert, const int32_t* local_ts, float* global_feat,
                                     float* global_cert, int32_t* global_ts, void* stream) {
-  if (n < 0 || !ids || !local_feat || !local_cert || !local_ts || !global_feat || !global_cert || !global_ts) {
+  // an empty local map (n == 0) still copies the padding row, which needs the feature arrays only: the id / certainty /
+  // stamp tensors of an empty map have no storage (data_ptr() == 0)
+  if (n < 0 || !local_feat || !global_feat || (n > 0 && (!ids || !local_cert || !local_ts || !global_cert || !global_ts))) {
     clid_set_error("clid_local_to_global: bad argument");
     return CLID_E_ARG;
   }
@@ -683,13 +685,17 @@ __global__ void __launch_bounds__(256)
 k_mapping_prep(float4* __restrict__ zero4, long long n_zero4, long long* __restrict__ index_out, long long n_index, int bs,
                int bs_new, unsigned long long pool_count, const long long* __restrict__ new_idx, unsigned long long n_new,
                unsigned long long seed, unsigned long long counter, const float* __restrict__ pool_coord, float resolution,
-               unsigned* __restrict__ key_out) {
+               unsigned* __restrict__ key_out, int col0, int ncols) {
   const long long stride = (long long)gridDim.x * 256;
   const long long t0 = (long long)blockIdx.x * 256 + threadIdx.x;
   for (long long i = t0; i < n_zero4; i += stride) zero4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int n_hist = bs - bs_new;
-  for (long long e = t0; e < n_index; e += stride) {
-    const int col = (int)(e % bs);
+  // n_index counts the elements of the column window [col0, col0 + ncols) of every iteration; the draw is a function of the
+  // element's position e in the FULL [iters][bs] array, so a rank that draws only its shard draws the same values
+  for (long long u = t0; u < n_index; u += stride) {
+    const long long it = u / ncols;
+    const int col = col0 + (int)(u - it * ncols);
+    const long long e = it * bs + col;
     const unsigned long long r = clid_mix64(seed, counter, (unsigned long long)e);
     long long v;
     if (col < n_hist) v = (long long)__umul64hi(r, pool_count);
@@ -845,7 +851,7 @@ k_batch_sort_tail(const long long* __restrict__ draws, const unsigned* __restric
 // behind the smaller ranges.  No communication between the blocks.
 __global__ void __launch_bounds__(kSortThreads)
 k_batch_sort_bucket(const long long* __restrict__ draws, const unsigned* __restrict__ keys, long long* __restrict__ index_out,
-                    int bs, int full_segs) {
+                    int bs, int full_segs, int seg0) {
   constexpr int ITEMS = kSortBucketItems, CAP = ITEMS * kSortThreads, SCAN = kSortSeg / kSortThreads;
   __shared__ unsigned tab[kSortBins * kSortWaves];
   __shared__ unsigned seq[CAP];
@@ -854,7 +860,7 @@ k_batch_sort_bucket(const long long* __restrict__ draws, const unsigned* __restr
   __shared__ typename BinScan::TempStorage scan_tmp;
   const int bk = blockIdx.x % kSortBuckets;
   const int sg = blockIdx.x / kSortBuckets;
-  const int it = sg / full_segs, seg = sg - it * full_segs;
+  const int it = sg / full_segs, seg = seg0 + (sg - it * full_segs);
   const long long e0 = (long long)it * bs + (long long)seg * kSortSeg;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // ---- splitters: the 256 keys at positions 0, 64, 128, ... ranked by (key, sample number)
@@ -943,35 +949,55 @@ extern "C" int64_t clid_mapping_prep_workspace_bytes(int32_t iters, int32_t bs) 
 extern "C" int clid_mapping_prep(float* zero_base, int64_t zero_floats, int64_t* index_out, int32_t iters, int32_t bs,
                                  int32_t bs_new, int64_t pool_count, const int64_t* new_idx, int64_t n_new, uint64_t seed,
                                  uint64_t counter, const float* pool_coord, float resolution, void* sort_workspace,
-                                 void* stream) {
+                                 int32_t col0, int32_t ncols, void* stream) {
   if (zero_floats < 0 || (zero_floats && (!zero_base || (zero_floats & 3) || ((uintptr_t)zero_base & 15))) || iters < 0 ||
       bs < 0 || bs_new < 0 || bs_new > bs || (iters && bs && !index_out) || (index_out && iters && bs && pool_count <= 0) ||
-      (bs_new > 0 && (!new_idx || n_new <= 0)) || (sort_workspace && (!pool_coord || !(resolution > 0.f)))) {
+      (bs_new > 0 && (!new_idx || n_new <= 0)) || (sort_workspace && (!pool_coord || !(resolution > 0.f))) ||
+      (ncols > 0 && (col0 < 0 || col0 + (long long)ncols > bs))) {
     clid_set_error("clid_mapping_prep: bad argument");
     return CLID_E_ARG;
   }
   hipStream_t s = (hipStream_t)stream;
-  const long long n_index = index_out ? (long long)iters * bs : 0;
+  const bool want_sort = sort_workspace != nullptr;
+  // the column window of every iteration that gets written: all of them, or the caller's shard -- widened to whole
+  // 16 384-sample segments when the batches are ordered (a segment is ordered as a unit)
+  int c0 = 0, nc = bs;
+  if (ncols > 0 && index_out) {
+    c0 = col0;
+    int c1 = col0 + ncols;
+    if (want_sort) {
+      c0 = c0 / kSortSeg * kSortSeg;
+      c1 = (c1 + kSortSeg - 1) / kSortSeg * kSortSeg;
+      if (c1 > bs) c1 = bs;
+    }
+    nc = c1 - c0;
+  }
+  const long long n_index = index_out ? (long long)iters * nc : 0;
   const long long work = (zero_floats / 4 > n_index ? zero_floats / 4 : n_index);
   if (work == 0) return CLID_OK;
-  const int full_segs = bs / kSortSeg, tail = bs - full_segs * kSortSeg;
+  const int seg0 = c0 / kSortSeg;                          // first segment of the window
+  const int seg_full_end = (c0 + nc) / kSortSeg;           // one past its last FULL segment
+  const int full_segs = seg_full_end > seg0 ? seg_full_end - seg0 : 0;
+  const int tail_base = seg_full_end * kSortSeg;           // a shorter last segment exists iff the window reaches bs
+  const int tail = (c0 + nc) - tail_base;                  // > 0 only then (c0 + nc == bs, bs no multiple of the segment)
   const long long sort_blocks = (long long)iters * full_segs * kSortBuckets;
-  const bool sorted = sort_workspace && n_index > 0 && sort_blocks < (1LL << 31);
+  const bool sorted = want_sort && n_index > 0 && sort_blocks < (1LL << 31);
   char* ws = static_cast<char*>(sort_workspace);
+  const long long n_all = (long long)iters * bs;
   long long* draws = sorted ? reinterpret_cast<long long*>(ws) : reinterpret_cast<long long*>(index_out);
-  unsigned* keys = sorted ? reinterpret_cast<unsigned*>(ws + align256((size_t)n_index * 8)) : nullptr;
+  unsigned* keys = sorted ? reinterpret_cast<unsigned*>(ws + align256((size_t)n_all * 8)) : nullptr;
   long long blocks = (work + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_mapping_prep, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<float4*>(zero_base),
                      (long long)(zero_floats / 4), draws, n_index, bs, bs_new, (unsigned long long)pool_count,
                      reinterpret_cast<const long long*>(new_idx), (unsigned long long)n_new, (unsigned long long)seed,
-                     (unsigned long long)counter, pool_coord, resolution, keys);
+                     (unsigned long long)counter, pool_coord, resolution, keys, c0, nc > 0 ? nc : 1);
   if (sorted && full_segs > 0)
     hipLaunchKernelGGL(k_batch_sort_bucket, dim3((unsigned)sort_blocks), dim3(kSortThreads), 0, s, draws, keys,
-                       reinterpret_cast<long long*>(index_out), bs, full_segs);
+                       reinterpret_cast<long long*>(index_out), bs, full_segs, seg0);
   if (sorted && tail > 0)
     hipLaunchKernelGGL(k_batch_sort_tail, dim3((unsigned)iters), dim3(kSortThreads), 0, s, draws, keys,
-                       reinterpret_cast<long long*>(index_out), bs, full_segs * kSortSeg);
+                       reinterpret_cast<long long*>(index_out), bs, tail_base);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

@@ -279,8 +279,8 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
     int gtask = w;
     int task = w;
     const long long* index = reinterpret_cast<const long long*>(ta.index);
+    int it = 0;  // iteration of the chunk (MODE 1)
     if constexpr (MODE == 1) {
-      int it;
       if (xmap) {
         it = w / xlen;
         const int u = w - it * xlen;
@@ -339,6 +339,11 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
         const float osum = group8_sum(om);
         const float w = valid ? fmul(om, fdiv(1.0f, osum)) : 0.f;        // np.py:699-706
         const float4 pk = pos4[valid ? id : 0];
+        if constexpr (MODE == 1) {
+          // touched-row flag of (iteration of the chunk, map row): a plain byte store -- racing writers store the same
+          // value -- that the chunk's scan turns into the iteration's row set (sparse exchange / Adam, train_common.hpp)
+          if (ta.touch_ws && valid && live) ta.touch_ws[(size_t)it * ta.touch_stride + id] = 1;
+        }
         const float rx = group8_sum(fsub(px, pk.x) * w), ry = group8_sum(fsub(py, pk.y) * w),
                     rz = group8_sum(fsub(pz, pk.z) * w);
         wave_lds_fence();
@@ -624,17 +629,103 @@ __device__ __forceinline__ void finish_loss(int p, float tot, float* loss_out, f
   }
 }
 
-// multi-GPU path: partial[nb][840] -> grad[0:833] (=), loss_out (+=), so the host can all-reduce `grad`
+// ---- touched rows: flags -> bit sets / prefix sums / counts (clid_train_touch_scan) ----------------------------------
+// One thread per 32-row word column, over the chunk's iterations: 32 flag bytes -> one bit word, the running union of the
+// call, the word's population count (scanned along the row axis by k_touch_scan); the flags are cleared for the next chunk.
+__device__ __forceinline__ unsigned flags_to_nibble(unsigned d) {  // 4 flag bytes (0 / 1) -> 4 bits, byte i -> bit i
+  return (((d & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+}
+__global__ void __launch_bounds__(256) k_touch_bits(TouchWs tw, long long stride, int n_it, int it0) {
+  const long long W = stride / 32;
+  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (w >= W) return;
+  unsigned seen = it0 > 0 ? tw.cum[w] : 0u;
+  for (int it = 0; it < n_it; ++it) {
+    uint4* f = reinterpret_cast<uint4*>(tw.flags + (size_t)it * stride + (size_t)w * 32);
+    const uint4 a = f[0], b = f[1];
+    const unsigned word = flags_to_nibble(a.x) | (flags_to_nibble(a.y) << 4) | (flags_to_nibble(a.z) << 8) |
+                          (flags_to_nibble(a.w) << 12) | (flags_to_nibble(b.x) << 16) | (flags_to_nibble(b.y) << 20) |
+                          (flags_to_nibble(b.z) << 24) | (flags_to_nibble(b.w) << 28);
+    if (word) f[0] = f[1] = make_uint4(0u, 0u, 0u, 0u);
+    seen |= word;
+    tw.bits[(size_t)it * W + w] = word;
+    tw.cumb[(size_t)it * W + w] = seen;
+    tw.wpre[(size_t)it * W + w] = (unsigned)__popc(word);
+  }
+  tw.cum[w] = seen;
+}
+// one block per iteration of the chunk: exclusive scan of the word counts in place, total -> counts[it]
+__global__ void __launch_bounds__(1024) k_touch_scan(TouchWs tw, long long stride) {
+  __shared__ unsigned wsum[16];
+  __shared__ unsigned carry;
+  const long long W = stride / 32;
+  unsigned* x = tw.wpre + (size_t)blockIdx.x * W;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0u;
+  __syncthreads();
+  for (long long base = 0; base < W; base += 1024) {
+    const long long i = base + threadIdx.x;
+    const unsigned v = i < W ? x[i] : 0u;
+    unsigned inc = v;  // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = (unsigned)__shfl_up((int)inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned off = carry;
+    for (int k = 0; k < wave; ++k) off += wsum[k];
+    if (i < W) x[i] = off + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = off + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tw.counts[blockIdx.x] = (int)carry;
+}
+
+// what an iteration's launches read of the touched-row workspace
+struct TouchIter {
+  const unsigned* bits;  // [stride / 32] rows touched by this iteration (NULL: bookkeeping off)
+  const unsigned* cumb;  // [stride / 32] rows touched so far in the call
+  const unsigned* wpre;  // [stride / 32]
+  const int* count;      // rows touched by this iteration
+};
+__device__ __forceinline__ int touch_pos(const TouchIter& ti, long long row) {  // position of a touched row in the iteration's list
+  const unsigned word = ti.bits[row >> 5];
+  return (int)(ti.wpre[row >> 5] + (unsigned)__popc(word & ((1u << (row & 31)) - 1u)));
+}
+
+// multi-GPU path: partial[nb][840] -> dst[0:833] (=), loss_out (+=), so the host can all-reduce the gradients.
+// Blocks beyond the column blocks (sparse exchange, clid_train_args.cbuf): the accumulation rows this iteration touched are
+// packed in ascending row order behind the decoder gradients, [848 | 8 n gradient columns | n certainty increments], and
+// zeroed -- the all-reduce then moves 36 bytes per touched row instead of 64 per row of the local map.
 __global__ void __launch_bounds__(256)
-k_reduce_partials(const float* __restrict__ partial, int nb, float* __restrict__ grad,
+k_reduce_partials(const float* __restrict__ partial, int nb, float* __restrict__ dst,
                   float* __restrict__ loss_out, float inv_n_main, float inv_n_eik, float weight_e,
-                  int train_decoder) {
+                  int train_decoder, TouchIter ti, float* __restrict__ rows, float* __restrict__ cbuf, long long n_rows) {
+  if ((int)blockIdx.x >= kColBlocks) {
+    const long long idx = (long long)((int)blockIdx.x - kColBlocks) * 256 + threadIdx.x;
+    const long long row = idx >> 1;
+    const int half = (int)(idx & 1);
+    if (row >= n_rows) return;
+    if (!((ti.bits[row >> 5] >> (row & 31)) & 1u)) return;
+    const int pos = touch_pos(ti, row), n = *ti.count;
+    float* gr = rows + row * CLID_GRAD_ROW16 + 4 * half;
+    *reinterpret_cast<float4*>(cbuf + CLID_GRAD_FEAT_OFFSET16 + (size_t)pos * CLID_F + 4 * half) = *reinterpret_cast<float4*>(gr);
+    *reinterpret_cast<float4*>(gr) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (half) {
+      cbuf[CLID_GRAD_FEAT_OFFSET16 + (size_t)n * CLID_F + pos] = gr[4];
+      gr[4] = 0.f;
+    }
+    return;
+  }
   const int p = blockIdx.x * kColsPerBlock + (threadIdx.x >> 6);
   if (p >= CLID_MLP_PARAMS + 2) return;
   if (!train_decoder && p < CLID_MLP_PARAMS) return;  // frozen decoder: only the loss columns carry data
   const float tot = column_sum_wave(partial, nb, p);
   if ((threadIdx.x & 63) != 0) return;
-  if (p < CLID_MLP_PARAMS) grad[p] = tot;
+  if (p < CLID_MLP_PARAMS) dst[p] = tot;
   else finish_loss(p, tot, loss_out, inv_n_main, inv_n_eik, weight_e);
 }
 
@@ -647,6 +738,8 @@ struct AdamLaunch {
   int gstride;             // floats per accumulation row of `grad`: CLID_F, or CLID_GRAD_ROW16 (column 8 = certainty increment)
   float* cert; int n_cert;
   AdamK k;
+  TouchIter ti;            // ti.bits != NULL: only rows touched so far in the call are visited (16-float rows only)
+  const float* cbuf;       // non-null (with ti): gradients / certainty increments / decoder gradients from the compact buffer
 };
 
 // blocks [0, kColBlocks): 4 decoder parameters / loss columns each (reduce partial rows or read grad), Adam
@@ -656,6 +749,46 @@ __global__ void __launch_bounds__(256) k_adam_all(AdamLaunch a) {
   if ((int)blockIdx.x >= kColBlocks) {
     const long long i4 = ((long long)((int)blockIdx.x - kColBlocks) * 256 + threadIdx.x) * 4;
     float* g = a.grad + CLID_GRAD_OFFSET(a.gstride);
+    if (a.gstride == CLID_GRAD_ROW16 && a.ti.bits) {
+      // touched-row bookkeeping on: a row the call has not touched yet has g = m = v = 0 and its update is exactly zero --
+      // it costs one cached bit test; a row touched earlier but not by this iteration carries momentum only (g = 0: no
+      // gradient read, nothing to zero); a row of this iteration reads its gradient from the accumulation row (single GPU)
+      // or from the all-reduced compact buffer
+      if (i4 >= a.n_feat) return;
+      const long long row = i4 >> 3;
+      const unsigned sh = (unsigned)(row & 31);
+      if (!((a.ti.cumb[row >> 5] >> sh) & 1u)) return;
+      const bool now = (a.ti.bits[row >> 5] >> sh) & 1u;
+      float4 G = make_float4(0.f, 0.f, 0.f, 0.f);
+      float inc = 0.f;
+      const bool cert_lane = (i4 & 7) == 4 && a.cert && row < a.n_cert;
+      if (now) {
+        if (a.cbuf) {
+          const int pos = touch_pos(a.ti, row);
+          G = *reinterpret_cast<const float4*>(a.cbuf + CLID_GRAD_FEAT_OFFSET16 + (size_t)pos * CLID_F + (i4 & 7));
+          if (cert_lane) inc = a.cbuf[CLID_GRAD_FEAT_OFFSET16 + (size_t)(*a.ti.count) * CLID_F + pos];
+        } else {
+          float* gr = g + row * CLID_GRAD_ROW16 + (i4 & 7);
+          G = *reinterpret_cast<float4*>(gr);
+          *reinterpret_cast<float4*>(gr) = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (cert_lane) {
+            inc = gr[4];
+            gr[4] = 0.f;
+          }
+        }
+      }
+      float4 P = *reinterpret_cast<float4*>(a.feat + i4);
+      float4 M = *reinterpret_cast<float4*>(a.m + i4), V = *reinterpret_cast<float4*>(a.v + i4);
+      adam_update(P.x, G.x, M.x, V.x, a.k, 0.f);
+      adam_update(P.y, G.y, M.y, V.y, a.k, 0.f);
+      adam_update(P.z, G.z, M.z, V.z, a.k, 0.f);
+      adam_update(P.w, G.w, M.w, V.w, a.k, 0.f);
+      *reinterpret_cast<float4*>(a.feat + i4) = P;
+      *reinterpret_cast<float4*>(a.m + i4) = M;
+      *reinterpret_cast<float4*>(a.v + i4) = V;
+      if (inc != 0.f) a.cert[row] += inc;  // np.py:714
+      return;
+    }
     if (a.gstride == CLID_GRAD_ROW16) {  // 16-float accumulation rows: gradients in columns 0..7, certainty increment in 8
       if (i4 >= a.n_feat) return;
       const long long row = i4 >> 3;
@@ -726,14 +859,14 @@ __global__ void __launch_bounds__(256) k_adam_all(AdamLaunch a) {
   }
   float gsum;
   if (a.partial) gsum = column_sum_wave(a.partial, a.nb, p);
-  else gsum = (p < CLID_MLP_PARAMS) ? a.grad[p] : 0.f;
+  else gsum = (p < CLID_MLP_PARAMS) ? (a.cbuf ? a.cbuf[p] : a.grad[p]) : 0.f;
   if ((threadIdx.x & 63) != 0) return;
   if (p < CLID_MLP_PARAMS) {
     if (a.train_decoder) {
       adam_update(P, gsum, M, V, a.k, 0.f);
       *dst = P; a.m_mlp[p] = M; a.v_mlp[p] = V;
     }
-    a.grad[p] = 0.f;
+    if (!a.cbuf) a.grad[p] = 0.f;  // (the compact buffer is rewritten by the next iteration's pack)
   } else if (a.partial) {
     finish_loss(p, gsum, a.loss_out, a.inv_n_main, a.inv_n_eik, a.weight_e);
   }
@@ -754,47 +887,31 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
 
 using namespace clid;
 
-// ---- optional per-kernel timing (bench.py roofline leg): hipEvents on the launch stream ------------
+// ---- optional per-kernel timing (bench.py roofline leg): a profiler object handed in through clid_train_args.prof ----
 #include <cstdlib>
 #include <vector>
-namespace {
-// rows of per-block partials the most recent clid_train_fwd_bwd / clid_train_decode launch of this host thread left in
-// the workspace (with defer_reduce the following clid_train_adam folds their reduction into its launch)
-thread_local int g_last_partial_rows = 0;
-bool g_prof = false;
 struct ProfSpan {
-  int tag;  // 0 fused / decode kernel, 1 search kernel (hoisted-search loop), 2 partial reduce, 3 adam
+  int tag;  // 0 fused / decode kernel, 1 search kernel (hoisted-search loop), 2 partial reduce (+ pack), 3 adam, 5 touch scan
   hipEvent_t a, b;
 };
-std::vector<ProfSpan> g_spans;
-thread_local hipEvent_t g_pend_a = nullptr, g_pend_b = nullptr;  // events of the bracket opened by prof_begin
-// opens a bracket: the next CLID_KLAUNCH on this host thread is issued through hipExtLaunchKernelGGL with the
-// bracket's start / stop events, i.e. they carry the dispatch's own begin / end time stamps (what rocprofv3
-// --kernel-trace reports), not the stream time around an event pair
-int prof_begin(int tag, hipStream_t) {
-  if (!g_prof) return -1;
+struct clid_prof {
+  std::vector<ProfSpan> spans;
+};
+// CLID_KLAUNCH asks for a (start, stop) event pair: the launch then goes out through hipExtLaunchKernelGGL and the pair
+// carries the dispatch's own begin / end time stamps (what rocprofv3 --kernel-trace reports)
+bool clid_prof_open(clid_prof* prof, int tag, hipEvent_t* a, hipEvent_t* b) {
+  if (!prof) return false;
   ProfSpan sp;
   sp.tag = tag;
-  hipEventCreate(&sp.a);
-  hipEventCreate(&sp.b);
-  g_spans.push_back(sp);
-  g_pend_a = sp.a;
-  g_pend_b = sp.b;
-  return (int)g_spans.size() - 1;
-}
-void prof_end(int h, hipStream_t s) {
-  if (h >= 0 && g_pend_a) {  // no CLID_KLAUNCH consumed the bracket: plain event pair around whatever was enqueued
-    hipEventRecord(g_spans[h].b, s);
+  if (hipEventCreate(&sp.a) != hipSuccess) return false;
+  if (hipEventCreate(&sp.b) != hipSuccess) {
+    hipEventDestroy(sp.a);
+    return false;
   }
-  g_pend_a = g_pend_b = nullptr;
-}
-}  // namespace
-
-bool clid_prof_take(hipEvent_t* a, hipEvent_t* b) {
-  *a = g_pend_a;
-  *b = g_pend_b;
-  g_pend_a = g_pend_b = nullptr;
-  return *a != nullptr;
+  prof->spans.push_back(sp);
+  *a = sp.a;
+  *b = sp.b;
+  return true;
 }
 
 #ifdef CLID_TIMING
@@ -803,31 +920,41 @@ extern "C" int clid_debug_read_stamps(long long* out_host) {
 }
 #endif
 
-extern "C" int clid_profile_enable(int on) {
-  for (ProfSpan& sp : g_spans) {
+extern "C" clid_prof* clid_profile_create(void) { return new clid_prof(); }
+static void prof_clear(clid_prof* p) {
+  for (ProfSpan& sp : p->spans) {
     hipEventDestroy(sp.a);
     hipEventDestroy(sp.b);
   }
-  g_spans.clear();
-  g_prof = on != 0;
-  return CLID_OK;
+  p->spans.clear();
+}
+extern "C" void clid_profile_destroy(clid_prof* prof) {
+  if (!prof) return;
+  prof_clear(prof);
+  delete prof;
 }
 
-// sums of elapsed ms per kernel over all recorded iterations: out[0] = fused (or decode) kernel, out[1] =
-// search kernel of the hoisted-search loop, out[2] = partial reduce, out[3] = adam; out[4] = back-to-back
-// event-pair overhead (ms, mean) measured now; *iters = iterations recorded
-extern "C" int clid_profile_read(double* out, int* iters, void* stream) {
+// sums of elapsed ms per kernel over all recorded launches: out[0] = fused (or decode) kernel, out[1] = search kernel of
+// the hoisted-search loop, out[2] = partial reduce (+ pack), out[3] = adam, out[5] = touched-row scan; out[4] = back-to-back
+// event-pair overhead (ms, mean) measured now; *iters = decode launches recorded.  The spans are dropped.
+extern "C" int clid_profile_read(clid_prof* prof, double* out, int* iters, void* stream) {
+  if (!prof || !out || !iters) {
+    clid_set_error("clid_profile_read: null argument");
+    return CLID_E_ARG;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (hipDeviceSynchronize() != hipSuccess) return CLID_E_HIP;
-  for (int i = 0; i < 5; ++i) out[i] = 0.0;
+  for (int i = 0; i < 6; ++i) out[i] = 0.0;
   int n = 0;
-  for (const ProfSpan& sp : g_spans) {
+  for (const ProfSpan& sp : prof->spans) {
     float ms = 0.f;
+    if (sp.tag < 0 || sp.tag > 5 || sp.tag == 4) continue;
     if (hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) continue;
     out[sp.tag] += ms;
     n += sp.tag == 0;
   }
   *iters = n;
+  prof_clear(prof);
   // marginal cost of an (event, event) bracket in a BUSY stream: 64 consecutive records, one sync
   {
     hipEvent_t ev[64];
@@ -856,7 +983,7 @@ static int n_queries(const clid_train_args* a, int* n_fd, int* first) {
 // (CUs x 4 SIMDs x CLID_SEARCH_WAVES / waves per block = 768 on MI355X), so every block stages the 32 KB prefilter into
 // LDS once per launch.  A 2048-block grid re-staged it 2.7 times: 42.5 -> 39.2 us per iteration in the mapping(10) regime.
 static int search_blocks() {
-  static thread_local int dev_cached = -1, blocks = 0;
+  static thread_local int dev_cached = -1, blocks = 0;  // (a cache of a device attribute, not state of the loop)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 768;
   if (dev != dev_cached) {
@@ -873,11 +1000,123 @@ static int fused_blocks(int n_tasks, int block = kFusedBlock) {
   return nb > kMaxBwdBlocks ? kMaxBwdBlocks : (nb < 1 ? 1 : nb);
 }
 
+// the tile kernels cover the numerical / no-eikonal modes on 16-float accumulation rows; everything else runs on the
+// 16-lanes-per-query kernel
+static int decode_variant_for(const clid_train_args* a) {
+  const int v = a->decode_variant < 0 ? 0 : (a->decode_variant > 2 ? 2 : a->decode_variant);
+  if (v == 0 || a->eikonal_mode == 2 || a->grad_stride != CLID_GRAD_ROW16) return 0;
+  return v;
+}
+extern "C" int clid_train_decode_kernel(const clid_map_view* mv, const clid_train_args* a) {
+  return (mv && a) ? decode_variant_for(a) : CLID_E_ARG;
+}
+static bool hoisted(const clid_train_args* a) { return a->eikonal_mode != 2 && a->pipeline != 0; }
+// Rows of per-block partials the forward/backward launch of an iteration leaves in the workspace -- a function of the
+// arguments alone (ABI 2 handed it from clid_train_decode to clid_train_adam through a thread_local): the analytic kernel,
+// the tile kernels (hoisted schedule) and the 16-lane kernel each have their own grid rule.
+static int partial_rows(const clid_train_args* a) {
+  if (a->eikonal_mode == 2) return clid_train_analytic_blocks(a->bs);
+  int n_fd, first;
+  n_queries(a, &n_fd, &first);
+  const TaskMap tmap = make_task_map(a->bs, n_fd, first, a->decimation);
+  if (hoisted(a) && decode_variant_for(a)) return clid_decode_tile_blocks(tmap.n_tasks);
+  return fused_blocks(tmap.n_tasks);
+}
+
 extern "C" int64_t clid_train_workspace_floats(int32_t bs, int32_t decimation, int32_t eikonal_mode) {
   if (bs <= 0 || decimation <= 0) return -1;
   const long long nfd = eikonal_mode == 1 ? (bs + decimation - 1) / decimation : 0;
   const long long Q = bs + 6 * nfd;
   return (long long)kMaxBwdBlocks * kPartialStride + (long long)rec_buffer_floats((int)Q) + 64;
+}
+
+static float eik_weight(const clid_train_args* a, int n_fd) {
+  return (a->eikonal_mode == 2 || (a->eikonal_mode == 1 && n_fd > 0)) ? a->weight_e : 0.f;
+}
+
+// ---- touched-row workspace --------------------------------------------------------------------------------------------
+extern "C" int64_t clid_touch_stride(int32_t M) { return M < 0 ? -1 : (int64_t)touch_stride_of(M); }
+extern "C" int64_t clid_touch_workspace_bytes(int32_t M, int32_t chunk_iters) {
+  if (M < 0 || chunk_iters < 1 || chunk_iters > kMaxChunkIters) return -1;
+  return (int64_t)((touch_bytes(touch_stride_of(M), chunk_iters) + 255) & ~size_t(255));
+}
+extern "C" int64_t clid_train_search_floats(int32_t bs, int64_t batch_offset, int32_t decimation,
+                                            int32_t eikonal_mode, int32_t n_iter) {
+  if (bs <= 0 || decimation <= 0 || n_iter < 0 || eikonal_mode == 2) return -1;
+  const int first = fd_first(batch_offset, decimation);
+  const int n_fd = eikonal_mode == 1 ? fd_count(bs, batch_offset, decimation) : 0;
+  return (int64_t)make_task_map(bs, n_fd, first, decimation).n_tasks * kRecFloatsPerTask * n_iter;
+}
+extern "C" int32_t clid_train_chunk_iters(const clid_train_args* a) {
+  if (!a || a->bs <= 0 || a->decimation <= 0 || a->eikonal_mode == 2) return 0;
+  int n_fd, first;
+  const int Q = n_queries(a, &n_fd, &first);
+  const size_t per_iter = (size_t)clid_train_search_floats(a->bs, a->batch_offset, a->decimation, a->eikonal_mode, 1);
+  long long chunk = (long long)(rec_buffer_floats(Q) / per_iter);
+  if (chunk > kMaxChunkIters) chunk = kMaxChunkIters;
+  return chunk < 1 ? 0 : (int32_t)chunk;
+}
+// the iteration's view of the workspace (bookkeeping off: all NULL)
+static TouchIter touch_iter_of(const clid_train_args* a) {
+  TouchIter ti{nullptr, nullptr, nullptr, nullptr};
+  if (!a || !a->touch_ws || !hoisted(a)) return ti;
+  const int chunk = clid_train_chunk_iters(a);
+  const TouchWs tw = touch_carve(a->touch_ws, a->touch_stride, chunk);
+  const size_t W = (size_t)(a->touch_stride / 32);
+  ti.bits = tw.bits + (size_t)a->touch_iter * W;
+  ti.cumb = tw.cumb + (size_t)a->touch_iter * W;
+  ti.wpre = tw.wpre + (size_t)a->touch_iter * W;
+  ti.count = tw.counts + a->touch_iter;
+  return ti;
+}
+static int check_touch(const clid_train_args* a, int M, const char* who) {
+  if (!a->touch_ws) return CLID_OK;
+  if (a->touch_stride < touch_stride_of(M) || (a->touch_stride & 255) || ((uintptr_t)a->touch_ws & 15) ||
+      a->grad_stride != CLID_GRAD_ROW16 || a->touch_iter < 0 || a->touch_iter >= kMaxChunkIters) {
+    clid_set_error("%s: touched-row workspace needs touch_stride >= clid_touch_stride(M) = %lld in multiples of 256 (got %lld), "
+                   "16-byte alignment, 16-float accumulation rows and 0 <= touch_iter < %d", who, (long long)touch_stride_of(M),
+                   (long long)a->touch_stride, kMaxChunkIters);
+    return CLID_E_ARG;
+  }
+  return CLID_OK;
+}
+
+extern "C" int clid_train_touch_scan(const clid_train_args* a, int32_t M, int32_t n_it, int32_t it0, int32_t* counts_host,
+                                     void* stream) {
+  if (!a || !a->touch_ws || M < 0 || n_it < 1 || it0 < 0) {
+    clid_set_error("clid_train_touch_scan: bad argument");
+    return CLID_E_ARG;
+  }
+  if (int e = check_touch(a, M, "clid_train_touch_scan")) return e;
+  const int chunk = clid_train_chunk_iters(a);
+  if (n_it > chunk) {
+    clid_set_error("clid_train_touch_scan: %d iterations exceed the chunk of %d", n_it, chunk);
+    return CLID_E_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const TouchWs tw = touch_carve(a->touch_ws, a->touch_stride, chunk);
+  const long long W = a->touch_stride / 32;
+  CLID_KLAUNCH(a->prof, 5, k_touch_bits, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, s, tw, (long long)a->touch_stride,
+               (int)n_it, (int)it0);
+  CLID_KLAUNCH(a->prof, 5, k_touch_scan, dim3((unsigned)n_it), dim3(1024), 0, s, tw, (long long)a->touch_stride);
+  CLID_CHECK_LAUNCH();
+  if (counts_host)  // (kMaxChunkIters x 4 bytes: fits the pinned landing buffer; synchronises the stream)
+    if (int e = clid_read_back(tw.counts, (int32_t)sizeof(int32_t) * n_it, counts_host, stream)) return e;
+  return CLID_OK;
+}
+
+// partial reduction (+ pack of the touched accumulation rows into the compact exchange buffer) in front of an all-reduce
+static int launch_reduce(const clid_map_view* mv, const clid_train_args* a, const float* partial, int nb, int n_fd,
+                         hipStream_t s) {
+  const TouchIter ti = a->cbuf ? touch_iter_of(a) : TouchIter{nullptr, nullptr, nullptr, nullptr};
+  const bool pack = ti.bits != nullptr;
+  const long long n_rows = pack ? (long long)mv->M + 1 : 0;
+  const unsigned row_blocks = pack ? (unsigned)((n_rows * 2 + 255) / 256) : 0u;
+  CLID_KLAUNCH(a->prof, 2, k_reduce_partials, dim3(kColBlocks + row_blocks), dim3(256), 0, s, partial, nb,
+               pack ? a->cbuf : a->grad, a->loss_out, a->inv_n_main, a->inv_n_eik, eik_weight(a, n_fd), a->train_decoder, ti,
+               a->grad + CLID_GRAD_FEAT_OFFSET16, a->cbuf, n_rows);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
 }
 
 extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args* a, void* stream) {
@@ -898,25 +1137,18 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
   const int Q = n_queries(a, &n_fd, &first);
   TrainWs ws = carve(a->ws, Q);
   const TaskMap tmap = make_task_map(a->bs, n_fd, first, a->decimation);
-  const int nb = a->eikonal_mode == 2 ? clid_train_analytic_blocks(a->bs) : fused_blocks(tmap.n_tasks);
-  g_last_partial_rows = nb;
-  int h = prof_begin(0, s);
+  clid_train_args fa = *a;
+  fa.pipeline = 0;  // this entry IS the fused schedule (partial_rows / touched-row bookkeeping follow it)
+  const int nb = partial_rows(&fa);
   if (a->eikonal_mode == 2) {  // loss.numerical_grad_on: False (utils/mapper.py:57-69, 660-661, 695-696)
     if (int e = clid_launch_train_analytic(mv, a, ws.partial, s)) return e;
   } else {
-    CLID_KLAUNCH(k_train_fused8<0>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap,
-                       (float4*)nullptr, 1, 0LL, 0);
+    CLID_KLAUNCH(a->prof, 0, k_train_fused8<0>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap,
+                 (float4*)nullptr, 1, 0LL, 0);
     CLID_CHECK_LAUNCH();
   }
-  prof_end(h, s);
-  if (!a->defer_reduce) {
-    h = prof_begin(2, s);
-    CLID_KLAUNCH(k_reduce_partials, dim3(kColBlocks), dim3(256), 0, s, ws.partial,
-                       nb, a->grad, a->loss_out, a->inv_n_main, a->inv_n_eik,
-                       (a->eikonal_mode == 2 || (a->eikonal_mode == 1 && n_fd > 0)) ? a->weight_e : 0.f, a->train_decoder);
-    CLID_CHECK_LAUNCH();
-    prof_end(h, s);
-  }
+  if (!a->defer_reduce)
+    if (int e = launch_reduce(mv, &fa, ws.partial, nb, n_fd, s)) return e;
   return CLID_OK;
 }
 
@@ -964,16 +1196,18 @@ extern "C" int clid_train_adam(const clid_adam_args* a, const clid_train_args* t
   L.feat = a->feat; L.grad = a->grad; L.m = a->m; L.v = a->v; L.n_feat = a->n_feat;
   L.W1 = a->W1; L.b1 = a->b1; L.W2 = a->W2; L.b2 = a->b2; L.m_mlp = a->m_mlp; L.v_mlp = a->v_mlp;
   L.partial = nullptr; L.nb = 0; L.loss_out = nullptr; L.inv_n_main = L.inv_n_eik = L.weight_e = 0.f;
-  if (t && t->defer_reduce) {  // single-GPU: fold the partial reduction of clid_train_fwd_bwd(t) into this launch
+  L.ti = TouchIter{nullptr, nullptr, nullptr, nullptr};
+  L.cbuf = nullptr;
+  if (t && t->defer_reduce) {  // single-GPU: fold the partial reduction of the forward/backward launch of `t` into this one
     int n_fd, first;
     const int Q = n_queries(t, &n_fd, &first);
     TrainWs ws = carve(t->ws, Q);
     L.partial = ws.partial;
-    L.nb = g_last_partial_rows;
+    L.nb = partial_rows(t);
     L.loss_out = t->loss_out;
     L.inv_n_main = t->inv_n_main;
     L.inv_n_eik = t->inv_n_eik;
-    L.weight_e = (t->eikonal_mode == 2 || (t->eikonal_mode == 1 && n_fd > 0)) ? t->weight_e : 0.f;
+    L.weight_e = eik_weight(t, n_fd);
   }
   L.train_decoder = a->train_decoder;
   L.gstride = a->grad_stride == CLID_GRAD_ROW16 ? CLID_GRAD_ROW16 : CLID_F;
@@ -983,12 +1217,19 @@ extern "C" int clid_train_adam(const clid_adam_args* a, const clid_train_args* t
     clid_set_error("clid_train_adam: n_feat=%lld is not a whole number of rows", (long long)a->n_feat);
     return CLID_E_ARG;
   }
+  if (t && t->touch_ws && hoisted(t)) {  // visit only the rows this mapping() call has touched so far
+    if (int e = check_touch(t, (int)(a->n_feat / CLID_F) - 1, "clid_train_adam")) return e;
+    if (a->weight_decay != 0.f || L.gstride != CLID_GRAD_ROW16) {
+      clid_set_error("clid_train_adam: the touched-row sweep needs weight_decay == 0 (every row moves otherwise) and 16-float rows");
+      return CLID_E_ARG;
+    }
+    L.ti = touch_iter_of(t);
+    if (!t->defer_reduce) L.cbuf = t->cbuf;  // (sharded: the all-reduced compact buffer; NULL = the caller reduced `grad`)
+  }
   L.n_feat_blocks = (int)(((a->n_feat + 3) / 4 + 255) / 256);
   L.k = adam_scalars(a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->step);
-  const int h = prof_begin(3, s);
-  CLID_KLAUNCH(k_adam_all, dim3(L.n_feat_blocks + kColBlocks), dim3(256), 0, s, L);
+  CLID_KLAUNCH(t ? t->prof : nullptr, 3, k_adam_all, dim3(L.n_feat_blocks + kColBlocks), dim3(256), 0, s, L);
   CLID_CHECK_LAUNCH();
-  prof_end(h, s);
   return CLID_OK;
 }
 
@@ -999,55 +1240,7 @@ extern "C" int clid_train_adam(const clid_adam_args* a, const clid_train_args* t
 // per chunk of iterations (a grid that fills the chip and runs at the memory system's gather rate, unlike a
 // single iteration's 3.3 k latency-bound waves) parks the winners in HBM, then the chunk's decode/backward +
 // Adam launches run back to back.
-namespace {
-int g_pipeline = -1;  // -1: read CLID_PIPELINE on first use; 0 fused per-iteration kernel, 1 hoisted searches
-}
-
-extern "C" int clid_mapping_pipeline(int mode) {
-  const int prev = g_pipeline;
-  g_pipeline = mode < 0 ? -1 : (mode != 0);
-  return prev;
-}
-
-static int pipeline_mode() {
-  if (g_pipeline < 0) {
-    const char* e = getenv("CLID_PIPELINE");
-    g_pipeline = (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : 1;
-  }
-  return g_pipeline;
-}
-
-namespace {
-int g_decode = -2;  // -2: read CLID_DECODE on first use; 0 VALU kernel, 1 tile kernel fp32 MFMA, 2 tile kernel bf16 MFMA
-}
-static int decode_variant() {
-  if (g_decode == -2) {
-    const char* e = getenv("CLID_DECODE");
-    g_decode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
-  }
-  return g_decode;
-}
-extern "C" int clid_decode_variant(int mode) {
-  const int prev = decode_variant();
-  g_decode = mode < 0 ? -2 : (mode > 2 ? 2 : mode);
-  return prev;
-}
-// the tile kernels cover the numerical / no-eikonal modes on 16-float accumulation rows;
-// everything else runs on the 16-lanes-per-query kernel
-static int decode_variant_for(const clid_map_view* mv, const clid_train_args* a) {
-  const int v = decode_variant();
-  if (v == 0 || a->eikonal_mode == 2 || a->grad_stride != CLID_GRAD_ROW16) return 0;
-  return v;
-}
-extern "C" int clid_train_decode_kernel(const clid_map_view* mv, const clid_train_args* a) {
-  return (mv && a) ? decode_variant_for(mv, a) : CLID_E_ARG;
-}
-// partial rows the decode launch of this iteration leaves in the workspace
-static int decode_blocks(const clid_map_view* mv, const clid_train_args* a, const TaskMap& tmap) {
-  return decode_variant_for(mv, a) ? clid_decode_tile_blocks(tmap.n_tasks) : fused_blocks(tmap.n_tasks);
-}
-
-static bool filter_enabled() {  // CLID_FILTER=0 turns the probe prefilter off (measurement aid)
+static bool filter_enabled() {  // CLID_FILTER=0 turns the probe prefilter off (measurement aid; results are unchanged)
   static int on = -1;
   if (on < 0) {
     const char* e = getenv("CLID_FILTER");
@@ -1069,15 +1262,7 @@ static int check_train_args(const clid_map_view* mv, const clid_train_args* a, c
     clid_set_error("%s: bs=%d decimation=%d eikonal_mode=%d", who, a->bs, a->decimation, a->eikonal_mode);
     return CLID_E_ARG;
   }
-  return CLID_OK;
-}
-
-extern "C" int64_t clid_train_search_floats(int32_t bs, int64_t batch_offset, int32_t decimation,
-                                            int32_t eikonal_mode, int32_t n_iter) {
-  if (bs <= 0 || decimation <= 0 || n_iter < 0 || eikonal_mode == 2) return -1;
-  const int first = fd_first(batch_offset, decimation);
-  const int n_fd = eikonal_mode == 1 ? fd_count(bs, batch_offset, decimation) : 0;
-  return (int64_t)make_task_map(bs, n_fd, first, decimation).n_tasks * kRecFloatsPerTask * n_iter;
+  return check_touch(a, mv->M, who);
 }
 
 extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args* a, int32_t n_iter,
@@ -1085,6 +1270,10 @@ extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args*
   if (int e = check_train_args(mv, a, "clid_train_search")) return e;
   if (n_iter <= 0 || !index_base || !rec_out || !a->pool_coord) {
     clid_set_error("clid_train_search: bad argument");
+    return CLID_E_ARG;
+  }
+  if (a->touch_ws && n_iter > clid_train_chunk_iters(a)) {
+    clid_set_error("clid_train_search: %d iterations exceed the touched-row workspace's chunk of %d", n_iter, clid_train_chunk_iters(a));
     return CLID_E_ARG;
   }
   hipStream_t s = (hipStream_t)stream;
@@ -1099,7 +1288,6 @@ extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args*
   t2.index = index_base;
   long long sb = ((long long)tmap.n_tasks * n_iter + kFusedBlock / 64 - 1) / (kFusedBlock / 64);
   if (sb > search_blocks()) sb = search_blocks();
-  const int h = prof_begin(1, s);
   // probe prefilter (a one-hash Bloom filter over the stored slots; 59 of the 81 probes of a typical query hit nothing):
   // staged in LDS when it fits (<= 32 KB) and the launch is large enough to amortise staging it per block; for large
   // local maps (> 2^17 points: the filter is up to 2 MB, the key table 8+ MB) it is read from global memory, where it
@@ -1110,10 +1298,9 @@ extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args*
     else use_filter = 2;
   }
   const size_t dyn = use_filter == 1 ? ((size_t)1 << mv->log2filter) / 8 : 0;
-  CLID_KLAUNCH(k_train_fused8<1>, dim3((unsigned)sb), dim3(kFusedBlock), dyn, s, *mv, t2, (float*)nullptr, tmap,
-                     reinterpret_cast<float4*>(rec_out), n_iter, (long long)index_stride, use_filter);
+  CLID_KLAUNCH(a->prof, 1, k_train_fused8<1>, dim3((unsigned)sb), dim3(kFusedBlock), dyn, s, *mv, t2, (float*)nullptr, tmap,
+               reinterpret_cast<float4*>(rec_out), n_iter, (long long)index_stride, use_filter);
   CLID_CHECK_LAUNCH();
-  prof_end(h, s);
   return CLID_OK;
 }
 
@@ -1129,25 +1316,23 @@ extern "C" int clid_train_decode(const clid_map_view* mv, const clid_train_args*
   const int Q = n_queries(a, &n_fd, &first);
   TrainWs ws = carve(a->ws, Q);
   const TaskMap tmap = make_task_map(a->bs, n_fd, first, a->decimation);
-  const int variant = decode_variant_for(mv, a);
-  const int nb = decode_blocks(mv, a, tmap);
-  g_last_partial_rows = nb;
-  int h = prof_begin(0, s);
+  clid_train_args da = *a;
+  da.pipeline = 1;  // this entry IS the hoisted schedule
+  const int variant = decode_variant_for(&da);
+  const int nb = partial_rows(&da);
   if (variant) {
     if (int e = clid_launch_decode_tile(mv, a, ws.partial, tmap, rec, variant == 2 ? 1 : 0, s)) return e;
   } else {
-    CLID_KLAUNCH(k_train_fused8<2>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap,
-                       reinterpret_cast<float4*>(const_cast<float*>(rec)), 1, 0LL, 0);
+    CLID_KLAUNCH(a->prof, 0, k_train_fused8<2>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap,
+                 reinterpret_cast<float4*>(const_cast<float*>(rec)), 1, 0LL, 0);
     CLID_CHECK_LAUNCH();
   }
-  prof_end(h, s);
   if (!a->defer_reduce) {
-    h = prof_begin(2, s);
-    CLID_KLAUNCH(k_reduce_partials, dim3(kColBlocks), dim3(256), 0, s, ws.partial,
-                       nb, a->grad, a->loss_out, a->inv_n_main, a->inv_n_eik,
-                       (a->eikonal_mode == 1 && n_fd > 0) ? a->weight_e : 0.f, a->train_decoder);
-    CLID_CHECK_LAUNCH();
-    prof_end(h, s);
+    if (a->cbuf && a->touch_ws && !variant) {
+      clid_set_error("clid_train_decode: the compact exchange needs the tile decode kernels (certainty increments in the rows)");
+      return CLID_E_ARG;
+    }
+    if (int e = launch_reduce(mv, &da, ws.partial, nb, n_fd, s)) return e;
   }
   return CLID_OK;
 }
@@ -1158,20 +1343,22 @@ static int mapping_run_hoisted(const clid_map_view* mv, clid_train_args& ta, cli
   const int Q = n_queries(&ta, &n_fd, &first);
   TrainWs ws = carve(ta.ws, Q);
   const size_t per_iter = (size_t)clid_train_search_floats(ta.bs, ta.batch_offset, ta.decimation, ta.eikonal_mode, 1);
-  long long chunk = (long long)(rec_buffer_floats(Q) / per_iter);
+  const int chunk = clid_train_chunk_iters(&ta);
   if (chunk < 1) {
     clid_set_error("clid_mapping_run: the task records exceed the workspace bound");
     return CLID_E_SHAPE;
   }
-  if (chunk > kMaxChunkIters) chunk = kMaxChunkIters;
-  for (int it0 = 0; it0 < iters; it0 += (int)chunk) {
-    const int n_it = (iters - it0) < chunk ? (iters - it0) : (int)chunk;
+  for (int it0 = 0; it0 < iters; it0 += chunk) {
+    const int n_it = (iters - it0) < chunk ? (iters - it0) : chunk;
     if (int e = clid_train_search(mv, &ta, n_it, index_base + (int64_t)it0 * index_stride, index_stride, ws.rec,
                                   stream))
       return e;
+    if (ta.touch_ws)
+      if (int e = clid_train_touch_scan(&ta, mv->M, n_it, it0, nullptr, stream)) return e;
     for (int it = it0; it < it0 + n_it; ++it) {
       ta.index = index_base + (int64_t)it * index_stride;
       ta.loss_out = loss_base + (size_t)it * 4;
+      ta.touch_iter = it - it0;
       if (int e = clid_train_decode(mv, &ta, ws.rec + (size_t)(it - it0) * per_iter, stream)) return e;
       aa.step = it + 1;
       if (int e = clid_train_adam(&aa, &ta, stream)) return e;
@@ -1181,10 +1368,9 @@ static int mapping_run_hoisted(const clid_map_view* mv, clid_train_args& ta, cli
 }
 
 // The whole single-GPU loop of Mapper.mapping (utils/mapper.py:642-860) enqueued by ONE host call:
-// mode 1 (default) = the neighbour searches hoisted into one launch per chunk of iterations, then per
-// iteration the decode/backward kernel and the reduce+Adam kernel; mode 0 = per iteration the fused
-// search+decode kernel and the reduce+Adam kernel (CLID_PIPELINE / clid_mapping_pipeline select; the results
-// are identical up to the order of the atomic accumulations).
+// t->pipeline 1 = the neighbour searches hoisted into one launch per chunk of iterations, then per iteration the
+// decode/backward kernel and the reduce+Adam kernel; 0 = per iteration the fused search+decode kernel and the reduce+Adam
+// kernel (the results are identical up to the order of the atomic accumulations).
 extern "C" int clid_mapping_run(const clid_map_view* mv, const clid_train_args* t, const clid_adam_args* a,
                                 int32_t iters, const int64_t* index_base, int64_t index_stride,
                                 float* loss_base, void* stream) {
@@ -1195,8 +1381,10 @@ extern "C" int clid_mapping_run(const clid_map_view* mv, const clid_train_args* 
   clid_train_args ta = *t;
   clid_adam_args aa = *a;
   ta.defer_reduce = 1;
-  if (ta.eikonal_mode != 2 && pipeline_mode() == 1 && iters > 0)
+  ta.cbuf = nullptr;
+  if (hoisted(&ta) && iters > 0)
     return mapping_run_hoisted(mv, ta, aa, iters, index_base, index_stride, loss_base, stream);
+  ta.pipeline = 0;
   for (int it = 0; it < iters; ++it) {
     ta.index = index_base + (int64_t)it * index_stride;
     ta.loss_out = loss_base + (size_t)it * 4;
@@ -1208,51 +1396,74 @@ extern "C" int clid_mapping_run(const clid_map_view* mv, const clid_train_args* 
 }
 
 // The sharded loop of one rank, stream-resident: hoisted searches of this rank's slice of every
-// batch, then per iteration decode/backward -> partial reduction -> RCCL all-reduce of the fused gradient buffer
-// [decoder | accumulation rows] ON THE LAUNCH STREAM -> the identical Adam step on every replica.  `index_base` points at
-// this rank's slice of iteration 0 (row stride index_stride); t->batch_offset / inv_n_* carry the global lattice phase
-// and normalisers.  After the loop the per-iteration losses (SUM) and the update stamps (MAX) are merged once.
+// batch, then per iteration decode/backward -> partial reduction -> RCCL all-reduce ON THE LAUNCH STREAM -> the identical
+// Adam step on every replica.  `index_base` points at this rank's slice of iteration 0 (row stride index_stride);
+// t->batch_offset / inv_n_* carry the global lattice phase and normalisers.  After the loop the per-iteration losses (SUM)
+// and the update stamps (MAX) are merged once.
+//   Exchange.  Dense (t->touch_ws / t->cbuf NULL): the whole fused buffer `grad` [grad_floats] = 848 + 16 (M + 1) floats per
+//   iteration.  Compact: the chunk's searches flag every row every iteration will touch; the flags are MAX-reduced over
+//   the ranks once per chunk (M bytes per iteration), scanned into per-iteration row lists whose lengths come back to the
+//   host (ONE synchronisation per chunk), and each iteration all-reduces [848 | 9 x rows it touches] floats.
 struct clid_comm;
-extern "C" int clid_comm_allreduce(clid_comm* comm, void* buf, int64_t count, int32_t is_int32, int32_t op_max, void* stream);
+extern "C" int clid_comm_allreduce(clid_comm* comm, void* buf, int64_t count, int32_t dtype, int32_t op_max, void* stream);
 
 extern "C" int clid_mapping_run_dist(const clid_map_view* mv, const clid_train_args* t, const clid_adam_args* a,
                                      int32_t iters, const int64_t* index_base, int64_t index_stride, float* loss_base,
-                                     clid_comm* comm, int64_t grad_floats, void* stream) {
+                                     clid_comm* comm, int64_t grad_floats, int64_t* exchanged_floats_host, void* stream) {
   if (!mv || !t || !a || iters < 0 || !index_base || !loss_base || !comm || grad_floats <= 0) {
     clid_set_error("clid_mapping_run_dist: bad argument");
     return CLID_E_ARG;
   }
   clid_train_args ta = *t;
   clid_adam_args aa = *a;
-  ta.defer_reduce = 0;  // the decoder gradients must sit in `grad` before the all-reduce
-  const bool hoist = ta.eikonal_mode != 2 && pipeline_mode() == 1;
+  ta.defer_reduce = 0;  // the decoder gradients must sit in `grad` / `cbuf` before the all-reduce
+  const bool hoist = hoisted(&ta);
+  if (!hoist) ta.pipeline = 0;
+  const bool compact = hoist && ta.touch_ws && ta.cbuf;
+  if (!compact) ta.cbuf = nullptr;
+  if (!hoist) ta.touch_ws = nullptr;
   int n_fd, first;
   const int Q = n_queries(&ta, &n_fd, &first);
   TrainWs ws = carve(ta.ws, Q);
   size_t per_iter = 0;
-  long long chunk = 1;
+  int chunk = 1;
   if (hoist) {
     per_iter = (size_t)clid_train_search_floats(ta.bs, ta.batch_offset, ta.decimation, ta.eikonal_mode, 1);
-    chunk = (long long)(rec_buffer_floats(Q) / per_iter);
+    chunk = clid_train_chunk_iters(&ta);
     if (chunk < 1) {
       clid_set_error("clid_mapping_run_dist: the task records exceed the workspace bound");
       return CLID_E_SHAPE;
     }
-    if (chunk > kMaxChunkIters) chunk = kMaxChunkIters;
   }
+  int32_t counts[kMaxChunkIters];
+  long long moved = 0;
   for (int it = 0; it < iters; ++it) {
     ta.index = index_base + (int64_t)it * index_stride;
     ta.loss_out = loss_base + (size_t)it * 4;
+    ta.touch_iter = it % chunk;
     if (hoist) {
       if (it % chunk == 0) {
-        const int n_it = (iters - it) < chunk ? (iters - it) : (int)chunk;
+        const int n_it = (iters - it) < chunk ? (iters - it) : chunk;
         if (int e = clid_train_search(mv, &ta, n_it, ta.index, index_stride, ws.rec, stream)) return e;
+        if (ta.touch_ws) {
+          // the union over the ranks of the rows each iteration touches: every rank then packs the same list
+          if (int e = clid_comm_allreduce(comm, ta.touch_ws, (int64_t)n_it * ta.touch_stride, 2, 1, stream)) return e;
+          moved += ((long long)n_it * ta.touch_stride + 3) / 4;
+          if (int e = clid_train_touch_scan(&ta, mv->M, n_it, it, compact ? counts : nullptr, stream)) return e;
+        }
       }
       if (int e = clid_train_decode(mv, &ta, ws.rec + (size_t)(it % chunk) * per_iter, stream)) return e;
     } else {
       if (int e = clid_train_fwd_bwd(mv, &ta, stream)) return e;
     }
-    if (int e = clid_comm_allreduce(comm, ta.grad, grad_floats, 0, 0, stream)) return e;
+    if (compact) {
+      const int64_t n = CLID_GRAD_FEAT_OFFSET16 + 9LL * counts[it % chunk];
+      if (int e = clid_comm_allreduce(comm, ta.cbuf, n, 0, 0, stream)) return e;
+      moved += n;
+    } else {
+      if (int e = clid_comm_allreduce(comm, ta.grad, grad_floats, 0, 0, stream)) return e;
+      moved += grad_floats;
+    }
     aa.step = it + 1;
     if (int e = clid_train_adam(&aa, &ta, stream)) return e;
   }
@@ -1261,6 +1472,7 @@ extern "C" int clid_mapping_run_dist(const clid_map_view* mv, const clid_train_a
     if (mv->ts_update && mv->M > 0)
       if (int e = clid_comm_allreduce(comm, mv->ts_update, mv->M, 1, 1, stream)) return e;
   }
+  if (exchanged_floats_host) *exchanged_floats_host = moved;
   return CLID_OK;
 }
 

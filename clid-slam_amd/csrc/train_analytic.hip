@@ -215,7 +215,7 @@ int clid_launch_train_analytic(const clid_map_view* mv, const clid_train_args* a
     return CLID_E_ARG;
   }
   const int rounds = (a->bs + 3) / 4;
-  CLID_KLAUNCH(clid::k_train_analytic, dim3(clid_train_analytic_blocks(a->bs)), dim3(CLID_BLOCK), 0, s, *mv, *a,
+  CLID_KLAUNCH(a->prof, 0, clid::k_train_analytic, dim3(clid_train_analytic_blocks(a->bs)), dim3(CLID_BLOCK), 0, s, *mv, *a,
                      partial, rounds);
   CLID_CHECK_LAUNCH();
   return CLID_OK;

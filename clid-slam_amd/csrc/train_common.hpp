@@ -228,19 +228,49 @@ __device__ __forceinline__ void mlp_backward(const MlpLds& s, const float (&f)[C
 
 }  // namespace clid
 
-// ---- launches under the optional per-kernel timing of clid_profile_enable (train.hip) -------------------------
-// Inside a prof_begin / prof_end bracket the kernel goes out through hipExtLaunchKernelGGL with the bracket's start and
-// stop events, which then hold the DISPATCH's begin / end time stamps (the same clock rocprofv3 --kernel-trace reads).
+// ---- launches under the optional per-kernel timing (clid_train_args.prof, train.hip) ------------------------------------
+// With a profiler object the kernel goes out through hipExtLaunchKernelGGL with a start and a stop event that the object
+// keeps: they hold the DISPATCH's begin / end time stamps (the same clock rocprofv3 --kernel-trace reads).
+// tag: 0 fused / decode kernel, 1 search kernel, 2 partial reduce (+ pack), 3 adam, 5 touched-row scan
 #include <hip/hip_ext.h>
-bool clid_prof_take(hipEvent_t* a, hipEvent_t* b);
-#define CLID_KLAUNCH(kernel, grid, block, shmem, stream, ...)                                        \
+bool clid_prof_open(struct clid_prof* prof, int tag, hipEvent_t* a, hipEvent_t* b);
+#define CLID_KLAUNCH(prof, tag, kernel, grid, block, shmem, stream, ...)                             \
   do {                                                                                               \
     hipEvent_t ea__, eb__;                                                                           \
-    if (clid_prof_take(&ea__, &eb__))                                                                \
+    if (clid_prof_open(prof, tag, &ea__, &eb__))                                                     \
       hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, ea__, eb__, 0, __VA_ARGS__);         \
     else                                                                                             \
       hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                           \
   } while (0)
+
+// ---- touched-row workspace (clid_train_args.touch_ws; include/clid_native.h) -------------------------------------------
+namespace clid {
+constexpr int kTouchCountSlots = 64;  // >= kMaxChunkIters
+__host__ __device__ inline long long touch_stride_of(int M) { return ((long long)M + 1 + 255) & ~255LL; }
+struct TouchWs {
+  uint8_t* flags;    // [chunk][stride]: set by the search launch, cleared again by the scan
+  unsigned* bits;    // [chunk][stride / 32]: rows touched by iteration i of the chunk
+  unsigned* cumb;    // [chunk][stride / 32]: rows touched by any iteration of the mapping() call up to and including i
+  unsigned* wpre;    // [chunk][stride / 32]: exclusive prefix of popcount(bits) along the row axis
+  int* counts;       // [kTouchCountSlots]: rows touched by iteration i
+  unsigned* cum;     // [stride / 32]: rows touched by the call's earlier chunks
+};
+__host__ __device__ inline TouchWs touch_carve(uint8_t* ws, long long stride, int chunk) {
+  TouchWs t;
+  const size_t W = (size_t)(stride / 32);
+  t.flags = ws;
+  t.bits = reinterpret_cast<unsigned*>(ws + (size_t)chunk * stride);
+  t.cumb = t.bits + (size_t)chunk * W;
+  t.wpre = t.cumb + (size_t)chunk * W;
+  t.counts = reinterpret_cast<int*>(t.wpre + (size_t)chunk * W);
+  t.cum = reinterpret_cast<unsigned*>(t.counts + kTouchCountSlots);
+  return t;
+}
+__host__ inline size_t touch_bytes(long long stride, int chunk) {
+  const size_t W = (size_t)(stride / 32);
+  return (size_t)chunk * stride + 3 * (size_t)chunk * W * 4 + kTouchCountSlots * 4 + W * 4;
+}
+}  // namespace clid
 
 // host-side launchers of the tile (matrix-core) decode kernels (train_tile.hip); prec 0 = fp32, 1 = bf16 operands
 int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, float* partial, const clid::TaskMap& tmap,

@@ -509,20 +509,11 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
 
 using namespace clid;
 
-namespace {
-float* g_sdf_dbg = nullptr;
-}
 #ifdef CLID_TIMING
 extern "C" int clid_debug_read_stamps_tile(long long* out_host) {
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(clid::clid_stamps), sizeof(long long) * 256 * 32) == hipSuccess ? 0 : -3;
 }
 #endif
-// test aid: the tile kernels also store the predicted SDF of every record slot ([n_tasks][8] floats, device memory)
-extern "C" int clid_debug_decode_sdf_out(float* sdf_out) {
-  g_sdf_dbg = sdf_out;
-  return CLID_OK;
-}
-
 int clid_decode_tile_blocks(int n_tasks) {
   const int tiles = (n_tasks + 1) / 2;
   const int tw = tile_waves_for(tiles);
@@ -546,11 +537,11 @@ int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, f
 #define CLID_TILE_LAUNCH(P, L)                                                                                        \
   do {                                                                                                                \
     if (tile_waves_for(n_tiles) == kTileWavesSmall)                                                                   \
-      CLID_KLAUNCH((k_decode_tile<P, L, kTileWavesSmall>), dim3(nb), dim3(kTileWavesSmall * 64), 0, s, *mv, *a,       \
-                   partial, tmap, r4, n_tiles, g_sdf_dbg);                                                            \
+      CLID_KLAUNCH(a->prof, 0, (k_decode_tile<P, L, kTileWavesSmall>), dim3(nb), dim3(kTileWavesSmall * 64), 0, s, *mv, *a,       \
+                   partial, tmap, r4, n_tiles, a->sdf_dbg);                                                            \
     else                                                                                                              \
-      CLID_KLAUNCH((k_decode_tile<P, L, kTileWavesLarge>), dim3(nb), dim3(kTileWavesLarge * 64), 0, s, *mv, *a,       \
-                   partial, tmap, r4, n_tiles, g_sdf_dbg);                                                            \
+      CLID_KLAUNCH(a->prof, 0, (k_decode_tile<P, L, kTileWavesLarge>), dim3(nb), dim3(kTileWavesLarge * 64), 0, s, *mv, *a,       \
+                   partial, tmap, r4, n_tiles, a->sdf_dbg);                                                            \
   } while (0)
   if (prec == 1) {
     if (mv->layer_norm) CLID_TILE_LAUNCH(1, true);

@@ -76,6 +76,12 @@ class Mapper:
         self._ws = None
         self._gen = None
         self._seed = int(getattr(config, "seed", 42))
+        # per-call switches of the fused loop (None = the process defaults _lib.DECODE_VARIANT / _lib.PIPELINE, i.e. the
+        # environment variables CLID_DECODE / CLID_PIPELINE): the decode kernel (0 VALU, 1 tile fp32 MFMA, 2 tile bf16
+        # MFMA) and the schedule (1 hoisted searches, 0 one fused launch per iteration).  They travel in clid_train_args.
+        self.decode_variant = None
+        self.pipeline = None
+        self.last_exchange = None  # world > 1: what the last mapping() call all-reduced (floats, mode)
 
     def reserve(self, iter_count: int):
         """Size the cached workspaces of `mapping()` for calls of up to `iter_count` iterations on the current local
@@ -100,7 +106,8 @@ class Mapper:
             # first launch of the draw / ordering kernels into the reserved buffers (code-object load, LDS configuration)
             _lib.check(lib.clid_mapping_prep(None, 0, self._idx_buf.data_ptr(), iter_count, int(cfg.bs), 0,
                                              int(self.pool_sample_count), None, 0, 0, 0, self.global_coord_pool.data_ptr(),
-                                             float(nm.resolution), self._sort_ws.data_ptr(), _lib.stream()), "clid_mapping_prep")
+                                             float(nm.resolution), self._sort_ws.data_ptr(), 0, 0, _lib.stream()),
+                       "clid_mapping_prep")
 
     def _loop_buffers(self, n_rows: int, iters: int, dev, zero: bool = True):
         """Views [grad | m | v | m_mlp | v_mlp | losses] of one flat fp32 buffer, zeroed (zero=False: the caller resets
@@ -158,10 +165,11 @@ class Mapper:
 
     SORT_BATCH_MIN_ITERS = 6
 
-    def _prepare_call(self, iters: int, bs: int, n_rows: int, dev, lib):
+    def _prepare_call(self, iters: int, bs: int, n_rows: int, dev, lib, col0: int = 0, ncols: int = 0):
         """Workspace reset + batch draw of one `mapping()` call in ONE launch (`clid_mapping_prep`): the composition rule
-        of `_draw_index` (utils/mapper.py:473-500) with a counter-based generator keyed on (seed, call number), so every
-        rank of a multi-GPU run draws the same batches.  Returns (loop buffers, index_seq [iters, bs])."""
+        of `_draw_index` (utils/mapper.py:473-500) with a counter-based generator keyed on (seed, call number, position),
+        so every rank of a multi-GPU run draws the same batches -- and draws / orders only the columns [col0, col0 + ncols)
+        it trains on (its shard; widened to whole ordering segments).  Returns (loop buffers, index_seq [iters, bs])."""
         bufs = self._loop_buffers(n_rows, iters, dev, zero=False)
         buf = getattr(self, "_idx_buf", None)
         if buf is None or buf.numel() < iters * bs or buf.device != torch.device(dev):
@@ -194,7 +202,7 @@ class Mapper:
             sort_ptr = ws.data_ptr()
         _lib.check(lib.clid_mapping_prep(self._flat.data_ptr(), self._flat_used, buf.data_ptr(), iters, bs, bs_new,
                                          int(self.pool_sample_count), new_ptr, n_new, seed, self._draw_calls, coord_ptr,
-                                         float(self.neural_points.resolution), sort_ptr, _lib.stream()),
+                                         float(self.neural_points.resolution), sort_ptr, int(col0), int(ncols), _lib.stream()),
                    "clid_mapping_prep")
         return bufs, index_seq
 
@@ -255,7 +263,8 @@ class Mapper:
         if index_seq is None:
             if self.pool_sample_count <= 0:
                 raise RuntimeError("mapping(): the sample pool is empty")
-            bufs, index_seq = self._prepare_call(iter_count, bs_global, n_feat // _lib.F, dev, lib)
+            bufs, index_seq = self._prepare_call(iter_count, bs_global, n_feat // _lib.F, dev, lib,
+                                                 rank * bs_local if dist else 0, bs_local if dist else 0)
         else:
             iter_count = index_seq.shape[0]
             index_seq = _lib.require_cuda(index_seq.to(torch.int64).contiguous(), "index_seq", torch.int64)
@@ -278,7 +287,6 @@ class Mapper:
         need = int(lib.clid_train_workspace_floats(bs_local, decim, eik_mode))
         if getattr(self, "_ws", None) is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(need, device=dev, dtype=torch.float32)
-        cert0 = nm.local_point_certainties.clone() if dist else None
 
         view, keep = nm._map_view(True)
         pool_coord = _lib.require_cuda(self.global_coord_pool, "global_coord_pool", torch.float32)
@@ -300,6 +308,14 @@ class Mapper:
         ta.defer_reduce = 0 if dist else 1
         ta.debug_flags = int(os.environ.get('CLID_DEBUG_FLAGS', '0'))
         ta.grad_stride = gstride
+        # per-call switches: ONE place decides the schedule and the kernel for Python and C alike
+        ta.decode_variant = int(_lib.DECODE_VARIANT if getattr(self, "decode_variant", None) is None else self.decode_variant)
+        ta.pipeline = int(_lib.PIPELINE if getattr(self, "pipeline", None) is None else self.pipeline)
+        sdf_dbg = getattr(self, "_sdf_dbg", None)   # test aid: SDF per record slot (tile kernels)
+        ta.sdf_dbg = None if sdf_dbg is None else sdf_dbg.data_ptr()
+        ta.prof = getattr(self, "_prof", None)      # measurement aid: clid_profile_create() object
+        hoist = eik_mode != 2 and ta.pipeline == 1
+        tile = hoist and lib.clid_train_decode_kernel(C.byref(view), C.byref(ta)) > 0
 
         aa = _lib.AdamArgs()
         aa.feat, aa.grad, aa.m, aa.v = theta.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr()
@@ -312,34 +328,70 @@ class Mapper:
         aa.grad_stride = gstride
         aa.cert, aa.n_cert = nm.local_point_certainties.data_ptr(), int(nm.local_point_certainties.shape[0])
 
+        # Touched-row bookkeeping (include/clid_native.h clid_train_args.touch_ws): the hoisted searches flag every map
+        # row every iteration will touch.  Single GPU: Adam visits only rows touched so far in this call (exact: the
+        # optimiser restarts per call, utils/mapper.py:634) -- pays on local maps much larger than a batch's footprint.
+        # Sharded: each iteration all-reduces [848 | 9 floats per row IT touches] instead of 64 bytes per row of the
+        # local map.  CLID_SPARSE = 0 / 1 / auto.
+        M_local = n_feat // _lib.F - 1
+        mode = os.environ.get("CLID_SPARSE", "auto")
+        want = mode == "1" or (mode != "0" and M_local >= (self.SPARSE_MIN_ROWS_DIST if dist else self.SPARSE_MIN_ROWS))
+        use_touch = bool(want and tile and float(cfg.weight_decay) == 0.0)
+        cbuf = None
+        if use_touch:
+            chunk = int(lib.clid_train_chunk_iters(C.byref(ta)))
+            tw = getattr(self, "_touch_ws", None)  # (buffer, row capacity, chunk, device): laid out for a capacity, so
+            if tw is None or tw[1] < M_local or tw[2] != chunk or tw[3] != str(dev):  # it stays put while the map grows
+                m_cap = int(M_local * 1.25) + 1024
+                tw = self._touch_ws = (torch.zeros(int(lib.clid_touch_workspace_bytes(m_cap, chunk)), device=dev, dtype=torch.uint8),
+                                       m_cap, chunk, str(dev))
+            ta.touch_ws, ta.touch_stride = tw[0].data_ptr(), int(lib.clid_touch_stride(tw[1]))
+            if dist:
+                n_c = _lib.GRAD_FEAT_OFFSET16 + 9 * (M_local + 1) + 16
+                cbuf = getattr(self, "_cbuf", None)
+                if cbuf is None or cbuf.numel() < n_c or cbuf.device != dev:
+                    cbuf = self._cbuf = torch.zeros(n_c, device=dev, dtype=torch.float32)
+                ta.cbuf = cbuf.data_ptr()
+
         stream = _lib.stream()
         idx_base, row_bytes = index_seq.data_ptr(), bs_global * 8
         loss_base = losses.data_ptr()
-        if not dist:
-            # single GPU: the whole loop is enqueued by one C call (hoisted searches + 2 launches per iteration)
-            ta.index, ta.loss_out = idx_base, loss_base
-            _lib.check(lib.clid_mapping_run(C.byref(view), C.byref(ta), C.byref(aa), iter_count, idx_base, bs_global,
-                                            loss_base, stream), "clid_mapping_run")
-        else:
-            # the neighbour searches do not depend on the training state: one launch per chunk of iterations
-            # resolves this rank's shard of every batch, then decode/backward -> all-reduce -> Adam per iteration
-            hoist = eik_mode != 2 and os.environ.get("CLID_PIPELINE", "1") != "0"
-            # with the tile kernels the certainty increments ride in the all-reduced accumulation rows (every rank's
-            # Adam launch applies the global sum); the 16-lane kernel adds this rank's share to the array directly
-            cert_in_rows = hoist and lib.clid_train_decode_kernel(C.byref(view), C.byref(ta)) > 0
-            comm = _lib.rccl_comm(dist)
-            shard_base = idx_base + batch_offset * 8
-            if comm is not None:
-                # RCCL behind the C ABI: the whole sharded loop is ONE host call, the all-reduce sits on the launch
-                # stream between the partial reduction and Adam (csrc/train.hip clid_mapping_run_dist)
-                ta.index, ta.loss_out = shard_base, loss_base
-                _lib.check(lib.clid_mapping_run_dist(C.byref(view), C.byref(ta), C.byref(aa), iter_count, shard_base, bs_global,
-                                                     loss_base, comm, grad.numel(), stream), "clid_mapping_run_dist")
-                merged = True  # losses (SUM) and update stamps (MAX) were merged by the call
+        cert_in_rows = True
+        try:
+            if not dist:
+                # single GPU: the whole loop is enqueued by one C call (hoisted searches + 2 launches per iteration)
+                ta.index, ta.loss_out = idx_base, loss_base
+                _lib.check(lib.clid_mapping_run(C.byref(view), C.byref(ta), C.byref(aa), iter_count, idx_base, bs_global,
+                                                loss_base, stream), "clid_mapping_run")
             else:
-                merged = False
-                self._mapping_loop_torch_dist(lib, dist, view, ta, aa, grad, iter_count, shard_base, row_bytes, loss_base,
-                                              hoist, bs_local, batch_offset, decim, eik_mode, dev, stream)
+                # the neighbour searches do not depend on the training state: one launch per chunk of iterations
+                # resolves this rank's shard of every batch, then decode/backward -> all-reduce -> Adam per iteration.
+                # With the tile kernels the certainty increments ride in the all-reduced accumulation rows (every rank's
+                # Adam launch applies the global sum); the 16-lane kernel adds this rank's share to the array directly
+                cert_in_rows = tile
+                cert0 = None if cert_in_rows else nm.local_point_certainties.clone()
+                comm = _lib.rccl_comm(dist)
+                shard_base = idx_base + batch_offset * 8
+                if comm is not None:
+                    # RCCL behind the C ABI: the whole sharded loop is ONE host call, the all-reduce sits on the launch
+                    # stream between the partial reduction and Adam (csrc/train.hip clid_mapping_run_dist)
+                    ta.index, ta.loss_out = shard_base, loss_base
+                    moved = C.c_int64(0)
+                    _lib.check(lib.clid_mapping_run_dist(C.byref(view), C.byref(ta), C.byref(aa), iter_count, shard_base,
+                                                         bs_global, loss_base, comm, grad.numel(), C.byref(moved), stream),
+                               "clid_mapping_run_dist")
+                    merged = True  # losses (SUM) and update stamps (MAX) were merged by the call
+                    moved = int(moved.value)
+                else:
+                    merged = False
+                    moved = self._mapping_loop_torch_dist(lib, dist, view, ta, aa, grad, cbuf, iter_count, shard_base, row_bytes,
+                                                          loss_base, hoist, bs_local, batch_offset, decim, eik_mode, dev, stream)
+                self.last_exchange = {"mode": "compact" if (use_touch and hoist) else "dense", "iters": iter_count,
+                                      "floats": moved, "bytes_per_iter": 4.0 * moved / max(iter_count, 1),
+                                      "dense_bytes_per_iter": 4.0 * grad.numel(), "rows": M_local + 1}
+        except Exception:
+            self._touch_ws = None  # its flags may be half-written: the next call starts from a zeroed workspace
+            raise
         self.total_iter += iter_count
         if dist:
             # merge the replicas' side effects once per call (not read inside the loop's loss)
@@ -350,55 +402,87 @@ class Mapper:
             if not merged:
                 dist.all_reduce(nm.local_point_ts_update, op=dist.ReduceOp.MAX)
                 dist.all_reduce(losses)
-            self._check_replicas(dist)
+            self._mapping_calls = getattr(self, "_mapping_calls", 0) + 1
+            if (self._mapping_calls - 1) % max(int(getattr(self, "replica_check_every", 16)), 1) == 0:
+                self._check_replicas(dist)
         self.last_losses = losses
         self._keep = (keep, index_seq, grad, m, v, m_mlp, v_mlp)
         nm.assign_local_to_global()
 
-    def _mapping_loop_torch_dist(self, lib, dist, view, ta, aa, grad, iter_count, shard_base, row_bytes, loss_base, hoist,
-                                 bs_local, batch_offset, decim, eik_mode, dev, stream):
+    SPARSE_MIN_ROWS = 1 << 16       # single GPU: local maps from this size on run the touched-row Adam sweep
+    SPARSE_MIN_ROWS_DIST = 1 << 15  # sharded: from here on the compact exchange (dense payload 64 B x rows > 2 MB)
+
+    def _mapping_loop_torch_dist(self, lib, dist, view, ta, aa, grad, cbuf, iter_count, shard_base, row_bytes, loss_base,
+                                 hoist, bs_local, batch_offset, decim, eik_mode, dev, stream):
         """The sharded loop with torch.distributed's all-reduce between two C calls per iteration: the path for
-        non-RCCL backends (gloo dry runs / tests with several ranks on one GPU)."""
-        chunk = min(iter_count, 32)
+        non-RCCL backends (gloo dry runs / tests with several ranks on one GPU).  The same sequence as
+        clid_mapping_run_dist (csrc/train.hip), exchange included; returns the 4-byte words this rank all-reduced."""
+        moved = 0
+        compact = bool(hoist and ta.touch_ws and cbuf is not None)
+        ta.pipeline = 1 if hoist else 0
+        if not hoist:
+            ta.touch_ws, ta.cbuf = None, None
+        elif not compact:
+            ta.cbuf = None
+        chunk = 1
         if hoist:
+            chunk = int(lib.clid_train_chunk_iters(C.byref(ta)))
             per_iter = int(lib.clid_train_search_floats(bs_local, batch_offset, decim, eik_mode, 1))
             if getattr(self, "_rec", None) is None or self._rec.numel() < per_iter * chunk or self._rec.device != dev:
                 self._rec = torch.empty(per_iter * chunk, device=dev, dtype=torch.float32)
+        counts = (C.c_int32 * 32)()
+        M_local = int(view.M)
         for it in range(iter_count):
             ta.index = shard_base + it * row_bytes
             ta.loss_out = loss_base + it * 16
+            ta.touch_iter = it % chunk
             if hoist:
                 if it % chunk == 0:
-                    _lib.check(lib.clid_train_search(C.byref(view), C.byref(ta), min(chunk, iter_count - it),
-                                                     ta.index, row_bytes // 8, self._rec.data_ptr(), stream),
-                               "clid_train_search")
+                    n_it = min(chunk, iter_count - it)
+                    _lib.check(lib.clid_train_search(C.byref(view), C.byref(ta), n_it, ta.index, row_bytes // 8,
+                                                     self._rec.data_ptr(), stream), "clid_train_search")
+                    if ta.touch_ws:
+                        flags = self._touch_ws[0][: n_it * int(ta.touch_stride)]
+                        dist.all_reduce(flags, op=dist.ReduceOp.MAX)  # union over the ranks of each iteration's rows
+                        moved += (flags.numel() + 3) // 4
+                        _lib.check(lib.clid_train_touch_scan(C.byref(ta), M_local, n_it, it, counts if compact else None, stream),
+                                   "clid_train_touch_scan")
                 _lib.check(lib.clid_train_decode(C.byref(view), C.byref(ta),
                                                  self._rec.data_ptr() + (it % chunk) * per_iter * 4, stream),
                            "clid_train_decode")
             else:
                 _lib.check(lib.clid_train_fwd_bwd(C.byref(view), C.byref(ta), stream), "clid_train_fwd_bwd")
-            dist.all_reduce(grad)
+            if compact:
+                n = _lib.GRAD_FEAT_OFFSET16 + 9 * int(counts[it % chunk])
+                dist.all_reduce(cbuf[:n])
+                moved += n
+            else:
+                dist.all_reduce(grad)
+                moved += grad.numel()
             aa.step = it + 1
             _lib.check(lib.clid_train_adam(C.byref(aa), C.byref(ta), stream), "clid_train_adam")
+        return moved
 
     def _check_replicas(self, dist):
         """Data parallelism here relies on every rank holding a bit-identical replica of the map and the pool (same
-        seeds, same frames).  A cheap consistency check once per `mapping()` call: pool size, local map size and a
-        checksum of the drawn batch must agree on all ranks (MIN == MAX), else the gradients that were just averaged
-        belong to different samples / rows."""
+        seeds, same frames).  A consistency check on the first and then every `replica_check_every`-th (default 16)
+        `mapping()` call -- it costs four device reductions, a collective and a host synchronisation --: pool size, local
+        map size, the pool's labels, the features and the certainties must agree on all ranks (MIN == MAX), else the
+        gradients that were just summed belong to different samples / rows."""
         nm = self.neural_points
         dev = nm.local_geo_features.device
         sig = torch.stack((
             torch.tensor([float(self.pool_sample_count), float(nm.local_count()), float(nm.count()),
                           float(0 if self.new_idx is None else self.new_idx.shape[0])], device=dev, dtype=torch.float64).sum(),
             self.sdf_label_pool.sum(dtype=torch.float64),                 # pool CONTENT (the samplers' draws)
-            nm.local_geo_features.data.sum(dtype=torch.float64)))         # features after the identical Adam steps
+            nm.local_geo_features.data.sum(dtype=torch.float64),          # features after the identical Adam steps
+            nm.local_point_certainties.sum(dtype=torch.float64)))         # side effects merged by the call
         both = torch.cat((sig, -sig))
         dist.all_reduce(both, op=dist.ReduceOp.MIN)  # one collective: min(x) and -max(x)
-        lo, hi = both[:3], -both[3:]
+        lo, hi = both[:4], -both[4:]
         if not torch.equal(lo, hi):
             raise RuntimeError(
-                f"data-parallel replicas diverged ([counts, pool label sum, feature sum] min {lo.tolist()} max {hi.tolist()}): "
+                f"data-parallel replicas diverged ([counts, pool label sum, feature sum, certainty sum] min {lo.tolist()} max {hi.tolist()}): "
                 "every rank must process the same frames with the same seeds (clid_slam_amd seeds its own generators from "
                 "config.seed; see INTEGRATION.md)")
 

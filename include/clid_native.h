@@ -205,7 +205,50 @@ typedef struct clid_train_args {
   int32_t debug_flags;       /* 0 in production; bit 0 / bit 1 suppress the certainty / gradient atomics (timing ablation);
                                 bit 2 makes clid_train_search take its full-depth path for every wave (tests) */
   int32_t grad_stride;       /* floats per feature row of `grad`: 0 or 8 (compact), 16 (see CLID_GRAD_ROW16) */
+  /* ---- per-call switches (ABI 3: these were process-global setters in ABI 2; the library now keeps NO state between
+   * calls except what the caller's buffers hold) */
+  int32_t decode_variant;    /* kernel of clid_train_decode (numerical-eikonal / no-eikonal modes):
+                                  0  k_train_fused8<2>: 16 lanes per query, decoder on the VALU, dW1 on fp32 MFMA (round 1);
+                                  1  k_decode_tile<f32>: one wave per 16-query tile, the decoder contractions of
+                                     model/decoder.py:58-82 and their transposes on v_mfma_f32_16x16x4_f32 (exact fp32);
+                                  2  k_decode_tile<bf16>: the same on v_mfma_f32_16x16x32_bf16, fp32 accumulation
+                                     (BASELINE.json configs[2]; outside the 1e-4 parity bar, reports its own error).
+                                1 / 2 need grad_stride == 16 and fall back to 0 otherwise (clid_train_decode_kernel tells) */
+  int32_t pipeline;          /* schedule of clid_mapping_run / clid_mapping_run_dist: 1 = clid_train_search over a chunk of
+                                iterations, then per iteration clid_train_decode + Adam; 0 = per iteration the fused
+                                search+decode kernel of clid_train_fwd_bwd + Adam */
+  float* sdf_dbg;            /* test aid, normally NULL: the tile decode kernels also store the SDF they predict for every
+                                record slot, [n_tasks][8] floats in the order of the search records */
+  struct clid_prof* prof;    /* measurement aid, normally NULL: clid_profile_create() */
+  /* ---- touched-row bookkeeping of the hoisted-search loop (NULL = off: dense all-reduce payload, dense Adam sweep).
+   * The searches of a chunk know every map row the chunk's iterations will touch before the first decode runs:
+   *   touch_ws  clid_touch_workspace_bytes(Mcap, chunk) bytes, ALL ZERO when first handed over and owned by the loop until
+   *             the mapping() call ends.  Layout: flags u8 [chunk][touch_stride] first (clid_train_search sets
+   *             flags[i][j] = 1 for every neighbour row j of iteration i of the chunk; with several ranks the caller
+   *             MAX-all-reduces this block before clid_train_touch_scan), the rest is internal (bit words, word prefix
+   *             sums, per-iteration counts, first-touch iteration per row).
+   *   touch_iter  the iteration's position inside its chunk (clid_train_decode / clid_train_adam).
+   *   cbuf      world > 1 only: the compact exchange buffer [848 decoder gradients | 8 x n gradient columns | n certainty
+   *             increments] of the iteration's n touched rows in ascending row order, capacity 848 + 9 (M + 1) floats;
+   *             clid_train_decode (defer_reduce == 0) packs into it and zeroes the accumulation rows it read, the caller
+   *             all-reduces 848 + 9 n floats, clid_train_adam reads the gradients from it. */
+  uint8_t* touch_ws;
+  int64_t touch_stride;      /* clid_touch_stride(Mcap) of a capacity Mcap >= M: the layout stays put while the map grows */
+  int32_t touch_iter;
+  int32_t touch_pad;
+  float* cbuf;
 } clid_train_args;
+
+/* Touched-row workspace (see clid_train_args.touch_ws).  clid_train_touch_scan turns the chunk's flags (after the
+ * cross-rank MAX when sharded) into per-iteration bit sets + prefix sums + counts and the per-row first-touch iteration
+ * (call-global: it0 = index of the chunk's first iteration in the mapping() call; it0 == 0 resets it), and clears the
+ * flags for the next chunk.  counts_host != NULL: the n_it per-iteration row counts are copied back and `stream` is
+ * synchronised (the sharded loop needs them to size its all-reduces); NULL: nothing synchronises. */
+int64_t clid_touch_stride(int32_t M);
+int64_t clid_touch_workspace_bytes(int32_t M, int32_t chunk_iters);
+int clid_train_touch_scan(const clid_train_args* t, int32_t M, int32_t n_it, int32_t it0, int32_t* counts_host, void* stream);
+/* iterations clid_mapping_run / clid_mapping_run_dist put into one search launch for these arguments (<= 32) */
+int32_t clid_train_chunk_iters(const clid_train_args* t);
 
 int64_t clid_train_workspace_floats(int32_t bs, int32_t decimation, int32_t eikonal_mode);
 /* forward + loss + backward of one iteration; leaves summed gradients in args->grad */
@@ -224,7 +267,12 @@ typedef struct clid_adam_args {
   int32_t n_cert;                                      /* M (0 / NULL with 8-float rows) */
   int32_t pad0;
 } clid_adam_args;
-/* `t` = the args of the clid_train_fwd_bwd call this step belongs to (NULL unless t->defer_reduce) */
+/* `t` = the args of the clid_train_fwd_bwd / clid_train_decode call this step belongs to (may be NULL for a stand-alone
+ * step on a complete `grad`).  t->defer_reduce: the reduction of that launch's per-block partials (their number is a
+ * function of t) is folded into this launch.  t->touch_ws: only rows touched so far in this mapping() call are
+ * visited -- exact, because a row never touched has g = m = v = 0 and receives a zero update (utils/tools.py:205-255
+ * semantics unchanged; weight_decay != 0 disables the skip) -- and rows not touched by THIS iteration skip the gradient
+ * read; t->cbuf: gradients and certainty increments come from the all-reduced compact buffer. */
 int clid_train_adam(const clid_adam_args* a, const clid_train_args* t, void* stream);
 
 /* Single-GPU Mapper.mapping loop in one call: iteration `it` uses index_base + it*index_stride (int64
@@ -248,40 +296,35 @@ int clid_train_decode(const clid_map_view* mv, const clid_train_args* t, const f
 /* ---- multi-GPU: RCCL inside the C ABI (new; the reference is single-GPU, slam.py:11) ---------------------------
  * One process per GPU.  Rank 0 creates a 128-byte id (clid_comm_unique_id), the host distributes it (e.g.
  * torch.distributed.broadcast), every rank calls clid_comm_init (collective: ncclCommInitRank on the current HIP
- * device).  clid_comm_allreduce is ncclAllReduce in place on `stream` (float32 SUM, or int32 / MAX).  RCCL is
- * resolved with dlopen at first use: the library loads without it, these calls then return an error. */
+ * device).  clid_comm_allreduce is ncclAllReduce in place on `stream`: dtype 0 = float32, 1 = int32, 2 = uint8; op_max 0 =
+ * SUM, 1 = MAX.  RCCL is resolved with dlopen at first use: the library loads without it, these calls then return an
+ * error; clid_comm_available() tells (1 / 0) whether it resolves in this process, so that the ranks can agree BEFORE
+ * anyone enters the collective clid_comm_init (a rank that cannot load RCCL would leave the others waiting in it). */
 typedef struct clid_comm clid_comm;
 int clid_comm_unique_id(uint8_t* id_out_host /* [128] */);
 int clid_comm_init(const uint8_t* id_host /* [128] */, int32_t rank, int32_t world, clid_comm** comm_out);
 int clid_comm_size(const clid_comm* comm); /* number of ranks (ncclCommCount), < 0 on error */
-int clid_comm_allreduce(clid_comm* comm, void* buf, int64_t count, int32_t is_int32, int32_t op_max, void* stream);
+int clid_comm_available(void);
+int clid_comm_allreduce(clid_comm* comm, void* buf, int64_t count, int32_t dtype, int32_t op_max, void* stream);
 int clid_comm_destroy(clid_comm* comm);
 
 /* Mapper.mapping on one rank of a data-parallel group in ONE host call: this rank's slice of
  * every batch (index_base = its first element of iteration 0, row stride index_stride; t->batch_offset, t->inv_n_main,
- * t->inv_n_eik carry the global lattice phase and normalisers), per iteration decode/backward -> RCCL all-reduce (SUM)
- * of the fused gradient buffer `t->grad` [grad_floats] on `stream` -> the identical Adam step; afterwards the losses
- * [iters][4] (SUM) and mv->ts_update [M] (MAX) are merged.  With the tile decode kernels the certainty increments travel
- * inside the all-reduced accumulation rows; with kernel 0 the caller merges its certainty deltas itself. */
+ * t->inv_n_eik carry the global lattice phase and normalisers), per iteration decode/backward -> RCCL all-reduce (SUM) on
+ * `stream` -> the identical Adam step; afterwards the losses [iters][4] (SUM) and mv->ts_update [M] (MAX) are merged.
+ * What is all-reduced per iteration:
+ *   dense    (t->touch_ws or t->cbuf NULL) the fused gradient buffer `t->grad` [grad_floats = 848 + 16 (M + 1)];
+ *   compact  (both given) [848 decoder gradients | 9 floats per map row THIS iteration touches]: once per chunk of
+ *            iterations the touched-row flags (M bytes per iteration) are MAX-reduced over the ranks and the list lengths
+ *            come back to the host (one synchronisation per chunk); see clid_train_args.touch_ws.
+ * With the tile decode kernels the certainty increments travel with the gradient rows; with kernel 0 (dense only) the
+ * caller merges its certainty deltas itself.  exchanged_floats_host (may be NULL): 4-byte words this rank contributed to
+ * all-reduces during the loop (payload accounting for the benches). */
 int clid_mapping_run_dist(const clid_map_view* mv, const clid_train_args* t, const clid_adam_args* a, int32_t iters,
                           const int64_t* index_base, int64_t index_stride, float* loss_base, clid_comm* comm,
-                          int64_t grad_floats, void* stream);
+                          int64_t grad_floats, int64_t* exchanged_floats_host, void* stream);
 
-/* How clid_mapping_run schedules the loop (numerical-eikonal / no-eikonal modes):
- *   1  (default) clid_train_search over a chunk of iterations, then per iteration clid_train_decode + Adam;
- *   0  per iteration the fused search+decode kernel of clid_train_fwd_bwd + Adam.
- * mode < 0 re-reads the environment variable CLID_PIPELINE; returns the previous setting. */
-int clid_mapping_pipeline(int mode);
-
-/* Which kernel clid_train_decode launches (numerical-eikonal / no-eikonal modes):
- *   0  k_train_fused8<2>: 16 lanes per query, decoder on the VALU, dW1 on fp32 MFMA (round 1);
- *   1  k_decode_tile<f32>: one wave per 16-query tile, all three decoder contractions of model/decoder.py:58-82
- *      and their transposes on v_mfma_f32_16x16x4_f32 (exact fp32) -- needs grad_stride == 16;
- *   2  k_decode_tile<bf16>: the same with bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulation
- *      (BASELINE.json configs[2]; NOT within the 1e-4 parity bar, reports its own error).
- * mode < 0 re-reads the environment variable CLID_DECODE; returns the previous setting. */
-int clid_decode_variant(int mode);
-/* the kernel (0 / 1 / 2 as above) clid_train_decode would launch for these arguments: the tile kernels cover the
+/* the kernel (0 / 1 / 2, clid_train_args.decode_variant) clid_train_decode launches for these arguments: the tile kernels cover the
  * numerical / no-eikonal modes on 16-float accumulation rows, the rest runs on kernel 0.  With
  * kernels 1 / 2 the certainty increments travel in column 8 of the accumulation rows (merged by clid_train_adam,
  * and all-reduced with the gradients when world > 1); kernel 0 adds them to `cert` directly. */
@@ -439,24 +482,28 @@ int clid_new_sample_select(const int64_t* buffer_pt_index, int64_t buffer_size, 
  * position): a function of the draws alone, identical on every rank).  The loss and gradient sums do not depend on the
  * order; neighbouring queries then share neural points, which is what the kernels' per-tile row merging and the caches
  * feed on.  The `[::decimation]` eikonal subset becomes a systematic subsample of the ordered batch (each sample still has
- * probability 1/decimation).  clid_debug_prep_draw is the host restatement of one uniform draw (tests). */
+ * probability 1/decimation).  clid_debug_prep_draw is the host restatement of one uniform draw (tests).
+ * [col0, col0 + ncols) (ncols <= 0: all of them) = the columns of every iteration's batch this rank needs (its shard of
+ * a sharded run): only they are guaranteed to be written -- widened to whole 16 384-sample segments when ordering, because
+ * a segment is ordered as a unit -- so a rank of a data-parallel group pays for its slice, not for the global batch. */
 int64_t clid_mapping_prep_workspace_bytes(int32_t iters, int32_t bs);
 int clid_mapping_prep(float* zero_base, int64_t zero_floats, int64_t* index_out, int32_t iters, int32_t bs, int32_t bs_new,
                       int64_t pool_count, const int64_t* new_idx, int64_t n_new, uint64_t seed, uint64_t counter,
-                      const float* pool_coord, float resolution, void* sort_workspace, void* stream);
+                      const float* pool_coord, float resolution, void* sort_workspace, int32_t col0, int32_t ncols,
+                      void* stream);
 int64_t clid_debug_prep_draw(uint64_t seed, uint64_t counter, uint64_t e, uint64_t range);
 
 /* ---- measurement aid (bench.py roofline leg; not part of the reference's interface) -----------
- * When enabled, clid_train_fwd_bwd / clid_train_adam bracket each kernel with hipEvents on the
- * launch stream.  clid_profile_read synchronises and returns summed elapsed ms per kernel:
- * out[0] = fused (or decode) kernel, out[1] = search kernel of the hoisted-search loop, out[2] = partial reduce,
- * out[3] = adam; out[4] = empty event-pair overhead (ms). */
-int clid_profile_enable(int on);
-int clid_profile_read(double* out_host, int* iters_host, void* stream);
-
-/* Test aid: while a non-NULL device buffer is registered, the tile decode kernels (clid_decode_variant 1 / 2) also
- * store the SDF they predict for every record slot, [n_tasks][8] floats in the order of the search records. */
-int clid_debug_decode_sdf_out(float* sdf_out);
+ * A profiler object handed in through clid_train_args.prof: the training entry points then issue each kernel through
+ * hipExtLaunchKernelGGL with start / stop events (the dispatch's own begin / end time stamps, the clock rocprofv3
+ * --kernel-trace reads).  clid_profile_read synchronises the device and returns summed elapsed ms per kernel:
+ * out[0] = fused (or decode) kernel, out[1] = search kernel of the hoisted-search loop, out[2] = partial reduce (+ pack),
+ * out[3] = adam, out[4] = empty event-pair overhead (ms), out[5] = touched-row scan; *iters_host = decode launches
+ * recorded; the recorded spans are dropped.  One object per host thread that launches. */
+typedef struct clid_prof clid_prof;
+clid_prof* clid_profile_create(void);
+int clid_profile_read(clid_prof* prof, double* out_host /* [6] */, int* iters_host, void* stream);
+void clid_profile_destroy(clid_prof* prof);
 
 /* CPU-only test aid: enumerate the fused kernel's task -> query mapping (see csrc/train.hip). */
 int clid_debug_task_cover(int32_t bs, int64_t batch_offset, int32_t decimation, int32_t eikonal_mode,

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in clid_native.h but not exported"
     assert sorted(_lib.EXPORTS) == [n for n in names]  # the ctypes table covers the whole header
-    assert lib.clid_abi_version() == 2
+    assert lib.clid_abi_version() == 3
 
 
 def test_struct_layout_matches_the_header(tmp_path):
@@ -131,5 +131,5 @@ def test_batch_draw_generator_host_restatement():
     a = np.array([lib.clid_debug_prep_draw(42, 3, e, 1 << 20) for e in range(4000)], dtype=np.float64)
     b = np.array([lib.clid_debug_prep_draw(42, 4, e, 1 << 20) for e in range(4000)], dtype=np.float64)
     assert abs(np.corrcoef(a[:-1], a[1:])[0, 1]) < 0.06 and abs(np.corrcoef(a, b)[0, 1]) < 0.06
-    rc = lib.clid_mapping_prep(None, 8, None, 0, 0, 0, 0, None, 0, 0, 0, None, 0.4, None, None)
+    rc = lib.clid_mapping_prep(None, 8, None, 0, 0, 0, 0, None, 0, 0, 0, None, 0.4, None, 0, 0, None)
     assert rc == -1 and b"clid_mapping_prep" in lib.clid_last_error()

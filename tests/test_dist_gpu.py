@@ -15,12 +15,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(rank, world, port, out_dir, mode):
+def _run(rank, world, port, out_dir, mode, sparse="0"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import golden_io as gio
     import shim_io
 
+    os.environ["CLID_SPARSE"] = sparse  # "1": compact exchange [848 | 9 floats per touched row] + touched-row Adam sweep
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -43,17 +44,20 @@ def _run(rank, world, port, out_dir, mode):
         np.savez(os.path.join(out_dir, f"w{world}.npz"), theta=nm.local_geo_features.detach().cpu().numpy(),
                  W1=dec.flat_params()[0].detach().cpu().numpy(), b2=dec.flat_params()[3].detach().cpu().numpy(),
                  cert=nm.local_point_certainties.cpu().numpy(), ts=nm.local_point_ts_update.cpu().numpy(),
-                 loss=mpr.last_losses.cpu().numpy())
+                 loss=mpr.last_losses.cpu().numpy(),
+                 exchange=np.array([0 if mpr.last_exchange is None else mpr.last_exchange["floats"],
+                                    0 if mpr.last_exchange is None else int(mpr.last_exchange["mode"] == "compact")]))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["numerical", "analytic"])
-def test_two_ranks_equal_one(tmp_path, mode):
-    port = 29700 + (os.getpid() % 1000) + (0 if mode == "numerical" else 1)
+@pytest.mark.parametrize("mode,sparse", [("numerical", "0"), ("analytic", "0"), ("numerical", "1")])
+def test_two_ranks_equal_one(tmp_path, mode, sparse):
+    port = 29700 + (os.getpid() % 1000) + (0 if mode == "numerical" else 1) + 2 * int(sparse)
     _run(0, 1, port, str(tmp_path), mode)
-    mp.spawn(_run, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
+    os.environ.pop("CLID_SPARSE", None)
+    mp.spawn(_run, args=(2, port, str(tmp_path), mode, sparse), nprocs=2, join=True)
     a = np.load(os.path.join(tmp_path, "w1.npz"))
     b = np.load(os.path.join(tmp_path, "w2.npz"))
     assert np.abs(a["loss"] - b["loss"]).max() <= 2e-6
@@ -61,3 +65,9 @@ def test_two_ranks_equal_one(tmp_path, mode):
     assert np.abs(a["W1"] - b["W1"]).max() <= 2e-5 and np.abs(a["b2"] - b["b2"]).max() <= 2e-5
     assert np.abs(a["cert"] - b["cert"]).max() <= 2e-3
     assert np.array_equal(a["ts"], b["ts"])
+    n_rows = a["theta"].shape[0]
+    dense = 3 * (848 + 16 * n_rows)
+    if sparse == "1":  # the compact exchange ran, and moved less than the dense buffer would have
+        assert int(b["exchange"][1]) == 1 and 0 < int(b["exchange"][0]) < dense
+    elif mode == "numerical":
+        assert int(b["exchange"][1]) == 0 and int(b["exchange"][0]) == dense

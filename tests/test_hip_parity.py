@@ -225,7 +225,7 @@ def _fused_grads(env, cfg, p, g, index, batch_offset=0, n_main=None, n_eik=None,
                  variant=0, sdf_out=None):
     """Run clid_train_fwd_bwd (or, split=True, clid_train_search + clid_train_decode) once (no Adam) and
     return (grad buffer, loss[4], certainties, ts).  `variant` selects the decode kernel of the split form
-    (include/clid_native.h clid_decode_variant): the tile kernels accumulate into 16-float rows whose column 8
+    (include/clid_native.h clid_train_args.decode_variant): the tile kernels accumulate into 16-float rows whose column 8
     carries the certainty increments; the result is converted back to the compact layout here.  `sdf_out`
     (tile kernels): list that receives (records, sdf per record slot)."""
     import ctypes as C
@@ -265,18 +265,14 @@ def _fused_grads(env, cfg, p, g, index, batch_offset=0, n_main=None, n_eik=None,
         rec = torch.empty(int(lib.clid_train_search_floats(bs, batch_offset, decim, 1, 1)), device="cuda")
         _lib.check(lib.clid_train_search(C.byref(view), C.byref(ta), 1, idx.data_ptr(), bs, rec.data_ptr(),
                                          _lib.stream()), "clid_train_search")
-        prev = lib.clid_decode_variant(variant)
+        ta.decode_variant, ta.pipeline = variant, 1
         sdf = None
         if sdf_out is not None and tile:
             sdf = torch.zeros(rec.numel() // 192 * 8, device="cuda")
-            lib.clid_debug_decode_sdf_out(sdf.data_ptr())
-        try:
-            assert lib.clid_train_decode_kernel(C.byref(view), C.byref(ta)) == variant
-            _lib.check(lib.clid_train_decode(C.byref(view), C.byref(ta), rec.data_ptr(), _lib.stream()), "clid_train_decode")
-            torch.cuda.synchronize()
-        finally:
-            lib.clid_decode_variant(prev)
-            lib.clid_debug_decode_sdf_out(None)
+            ta.sdf_dbg = sdf.data_ptr()
+        assert lib.clid_train_decode_kernel(C.byref(view), C.byref(ta)) == variant
+        _lib.check(lib.clid_train_decode(C.byref(view), C.byref(ta), rec.data_ptr(), _lib.stream()), "clid_train_decode")
+        torch.cuda.synchronize()
         if sdf is not None:
             sdf_out.append((rec.view(-1, 48, 4).cpu(), sdf.view(-1, 8).cpu()))
     else:
@@ -313,12 +309,11 @@ def test_mapping_loop_fused_schedule_matches_hoisted(env):
     """CLID_PIPELINE=0 schedule of clid_mapping_run (fused kernel per iteration) against the golden loop too."""
     from clid_slam_amd import _lib
 
-    lib = _lib.load()
-    prev = lib.clid_mapping_pipeline(0)
+    prev, _lib.PIPELINE = _lib.PIPELINE, 0  # the process default a Mapper without its own `pipeline` attribute uses
     try:
         test_mapping_loop_g6(env, "numerical", False, 0)
     finally:
-        lib.clid_mapping_pipeline(prev)
+        _lib.PIPELINE = prev
 
 
 def test_fused_iteration_gradients_vs_reference(env):
@@ -788,7 +783,7 @@ def test_mapping_prep_resets_and_draws_like_the_host_restatement():
     idx = torch.full((iters, bs), -5, device=dev, dtype=torch.int64)
     seed, counter = 42, 9
     _lib.check(lib.clid_mapping_prep(flat.data_ptr(), 4096, idx.data_ptr(), iters, bs, bs_new, pool, new_idx.data_ptr(),
-                                     new_idx.shape[0], seed, counter, None, 0.4, None, _lib.stream()), "clid_mapping_prep")
+                                     new_idx.shape[0], seed, counter, None, 0.4, None, 0, 0, _lib.stream()), "clid_mapping_prep")
     torch.cuda.synchronize()
     assert float(flat[:4096].abs().max()) == 0.0 and float(flat[4096:].min()) == 3.0
     got = idx.cpu().numpy()
@@ -801,7 +796,7 @@ def test_mapping_prep_resets_and_draws_like_the_host_restatement():
     assert abs(got[:, :700].mean() / pool - 0.5) < 0.02 and len(np.unique(got[:, :700])) > 0.99 * 4900
     idx2 = torch.empty_like(idx)
     _lib.check(lib.clid_mapping_prep(None, 0, idx2.data_ptr(), iters, bs, 0, pool, None, 0, seed, counter + 1, None, 0.4, None,
-                                     _lib.stream()), "clid_mapping_prep")
+                                     0, 0, _lib.stream()), "clid_mapping_prep")
     g2 = idx2.cpu().numpy()
     assert (g2 != got).mean() > 0.99 and g2.max() < pool
     # spatially ordered variant: per iteration the SAME draws, in Morton order of the samples' voxels (stable)
@@ -809,7 +804,7 @@ def test_mapping_prep_resets_and_draws_like_the_host_restatement():
     idx3 = torch.empty_like(idx)
     ws = torch.empty(int(lib.clid_mapping_prep_workspace_bytes(iters, bs)), device=dev, dtype=torch.uint8)
     _lib.check(lib.clid_mapping_prep(None, 0, idx3.data_ptr(), iters, bs, bs_new, pool, new_idx.data_ptr(), new_idx.shape[0], seed,
-                                     counter, coords.data_ptr(), 0.4, ws.data_ptr(), _lib.stream()), "clid_mapping_prep")
+                                     counter, coords.data_ptr(), 0.4, ws.data_ptr(), 0, 0, _lib.stream()), "clid_mapping_prep")
     g3 = idx3.cpu().numpy()
     assert np.array_equal(np.sort(g3, axis=1), np.sort(got, axis=1))  # a permutation of every iteration's draws
 
@@ -835,11 +830,11 @@ def test_mapping_prep_resets_and_draws_like_the_host_restatement():
     coords2[: pool // 2] = torch.floor(coords2[: pool // 2] / 3.2) * 3.2 + 0.1  # half of the pool shares a few hundred voxels
     raw = torch.empty((iters2, bs2), device=dev, dtype=torch.int64)
     _lib.check(lib.clid_mapping_prep(None, 0, raw.data_ptr(), iters2, bs2, 0, pool, None, 0, seed, 77, None, 0.4, None,
-                                     _lib.stream()), "clid_mapping_prep")
+                                     0, 0, _lib.stream()), "clid_mapping_prep")
     srt = torch.empty_like(raw)
     ws2 = torch.empty(int(lib.clid_mapping_prep_workspace_bytes(iters2, bs2)), device=dev, dtype=torch.uint8)
     _lib.check(lib.clid_mapping_prep(None, 0, srt.data_ptr(), iters2, bs2, 0, pool, None, 0, seed, 77, coords2.data_ptr(), 0.4,
-                                     ws2.data_ptr(), _lib.stream()), "clid_mapping_prep")
+                                     ws2.data_ptr(), 0, 0, _lib.stream()), "clid_mapping_prep")
     raw_n, srt_n, c2 = raw.cpu().numpy(), srt.cpu().numpy(), coords2.cpu().numpy()
     for it in range(iters2):
         for lo in range(0, bs2, 16384):
@@ -847,6 +842,22 @@ def test_mapping_prep_resets_and_draws_like_the_host_restatement():
             ka = morton(np.floor(c2[a] / np.float32(0.4)).astype(np.int64) & 255)
             want = a[np.argsort(ka, kind="stable")]  # stable: ties keep the draw order
             assert np.array_equal(b, want), (it, lo, int((b != want).sum()))
+
+    # a rank's column window (a shard of a data-parallel run): the same values as the full call on the window -- widened to
+    # whole 16 384-sample segments when ordering --, nothing written outside it
+    for c0, nc, w0, w1 in ((16384, 16384, 16384, 32768), (20000, 5000, 16384, 32768), (30000, bs2 - 30000, 16384, bs2),
+                           (0, 100, 0, 16384)):
+        part = torch.full_like(raw, -7)
+        _lib.check(lib.clid_mapping_prep(None, 0, part.data_ptr(), iters2, bs2, 0, pool, None, 0, seed, 77, coords2.data_ptr(),
+                                         0.4, ws2.data_ptr(), c0, nc, _lib.stream()), "clid_mapping_prep")
+        pn = part.cpu().numpy()
+        assert np.array_equal(pn[:, w0:w1], srt_n[:, w0:w1]), (c0, nc)
+        assert (pn[:, :w0] == -7).all() and (pn[:, w1:] == -7).all(), (c0, nc)
+    part = torch.full_like(raw, -7)
+    _lib.check(lib.clid_mapping_prep(None, 0, part.data_ptr(), iters2, bs2, 0, pool, None, 0, seed, 77, None, 0.4, None, 777, 4321,
+                                     _lib.stream()), "clid_mapping_prep")
+    pn = part.cpu().numpy()
+    assert np.array_equal(pn[:, 777:777 + 4321], raw_n[:, 777:777 + 4321]) and (pn[:, :777] == -7).all() and (pn[:, 777 + 4321:] == -7).all()
 
     # degenerate scene (60 % of the pool in ONE voxel): a key range then exceeds a sorting block's capacity and keeps its
     # draw order -- the batch is still a permutation of the draws, and the same one every time
@@ -856,7 +867,7 @@ def test_mapping_prep_resets_and_draws_like_the_host_restatement():
     for _ in range(2):
         o3 = torch.empty_like(raw)
         _lib.check(lib.clid_mapping_prep(None, 0, o3.data_ptr(), iters2, bs2, 0, pool, None, 0, seed, 77, coords3.data_ptr(), 0.4,
-                                         ws2.data_ptr(), _lib.stream()), "clid_mapping_prep")
+                                         ws2.data_ptr(), 0, 0, _lib.stream()), "clid_mapping_prep")
         outs.append(o3.cpu().numpy())
     assert np.array_equal(outs[0], outs[1])
     for it in range(iters2):

@@ -36,12 +36,13 @@ def test_single_rank_communicator_allreduce():
     assert lib.clid_comm_allreduce(None, x.data_ptr(), 4, 0, 0, None) < 0  # errors are reported, not crashed on
 
 
-def _run(rank, world, port, out_dir, backend, ln):
+def _run(rank, world, port, out_dir, backend, ln, sparse="0"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import golden_io as gio
     import shim_io
 
+    os.environ["CLID_SPARSE"] = sparse
     if backend:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -68,7 +69,8 @@ def _run(rank, world, port, out_dir, backend, ln):
     if rank == 0:
         np.savez(os.path.join(out_dir, f"{backend or 'single'}_w{world}.npz"), theta=nm.local_geo_features.detach().cpu().numpy(),
                  W1=dec.flat_params()[0].detach().cpu().numpy(), cert=nm.local_point_certainties.cpu().numpy(),
-                 ts=nm.local_point_ts_update.cpu().numpy(), loss=mpr.last_losses.cpu().numpy(), rccl=np.array(used_rccl))
+                 ts=nm.local_point_ts_update.cpu().numpy(), loss=mpr.last_losses.cpu().numpy(), rccl=np.array(used_rccl),
+                 compact=np.array(bool(mpr.last_exchange and mpr.last_exchange["mode"] == "compact")))
     if backend:
         dist.barrier()
         dist.destroy_process_group()
@@ -82,13 +84,17 @@ def _compare(a, b):
     assert np.array_equal(a["ts"], b["ts"])
 
 
-@pytest.mark.parametrize("ln", [0, 1])
-def test_sharded_loop_in_c_with_one_shard_equals_the_single_gpu_loop(tmp_path, ln):
-    port = 29300 + (os.getpid() % 500) + ln
+@pytest.mark.parametrize("ln,sparse", [(0, "0"), (1, "0"), (0, "1"), (1, "1")])
+def test_sharded_loop_in_c_with_one_shard_equals_the_single_gpu_loop(tmp_path, ln, sparse):
+    """sparse = "1": the compact exchange of clid_mapping_run_dist -- uint8 MAX all-reduce of the touched-row flags, count
+    read-back per chunk, [848 | 9 x rows] float all-reduce per iteration -- through RCCL itself (one rank)."""
+    port = 29300 + (os.getpid() % 500) + ln + 2 * int(sparse)
     _run(0, 1, port, str(tmp_path), None, ln)
-    mp.spawn(_run, args=(1, port, str(tmp_path), "nccl", ln), nprocs=1, join=True)
+    os.environ.pop("CLID_SPARSE", None)
+    mp.spawn(_run, args=(1, port, str(tmp_path), "nccl", ln, sparse), nprocs=1, join=True)
     a, b = np.load(os.path.join(tmp_path, "single_w1.npz")), np.load(os.path.join(tmp_path, "nccl_w1.npz"))
     assert bool(b["rccl"]), "the RCCL communicator behind the C ABI was not used"
+    assert bool(b["compact"]) == (sparse == "1")
     _compare(a, b)
 
 
@@ -96,7 +102,8 @@ def test_sharded_loop_in_c_with_one_shard_equals_the_single_gpu_loop(tmp_path, l
 def test_two_ranks_over_rccl_equal_one(tmp_path):
     port = 29800 + (os.getpid() % 500)
     _run(0, 1, port, str(tmp_path), None, 0)
-    mp.spawn(_run, args=(2, port, str(tmp_path), "nccl", 0), nprocs=2, join=True)
-    a, b = np.load(os.path.join(tmp_path, "single_w1.npz")), np.load(os.path.join(tmp_path, "nccl_w2.npz"))
-    assert bool(b["rccl"])
-    _compare(a, b)
+    for sparse in ("0", "1"):
+        mp.spawn(_run, args=(2, port + int(sparse), str(tmp_path), "nccl", 0, sparse), nprocs=2, join=True)
+        a, b = np.load(os.path.join(tmp_path, "single_w1.npz")), np.load(os.path.join(tmp_path, "nccl_w2.npz"))
+        assert bool(b["rccl"]) and bool(b["compact"]) == (sparse == "1")
+        _compare(a, b)
