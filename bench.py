@@ -250,15 +250,16 @@ def main():
         freeze_model(dec)
     mp.decode_variant = wl["decode"]
     mp.reserve(max(args.steps, args.warmup, 10))  # workspaces sized once: nothing is allocated inside a timed region
+    # No collector pause inside the 0.7 ms region (what `timeit` does too): a full collection of this process' ~10^6 objects
+    # takes several ms -- one run in ~25 showed 5 ms of wall clock around 0.65 ms of GPU time.  Collected and switched off
+    # BEFORE the warm-up: a collection between warm-up and timed region idles the GPU for ~100 ms and its clocks drop again
+    # (measured: 0.044 instead of 0.035 ms per step).
+    gc.collect()
+    gc.disable()
     for _ in range(args.warmup):  # W untimed steps, one per call: the GPU's clocks ramp over several hundred us of work
         mp.mapping(1)             # (a single 5-iteration call leaves the first timed call 14 % slow: tools/warm_clocks.py)
     sync()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    # no collector pause inside the 0.7 ms region (what `timeit` does too): a full collection of this process' ~10^6
-    # objects takes several ms -- one run in ~25 showed 5 ms of wall clock around 0.65 ms of GPU time
-    gc.collect()
-    gc.disable()
-    sync()
     t0 = time.perf_counter()
     ev0.record()
     t_start = None

@@ -120,6 +120,12 @@ def run(frames, device, check_frames=0, seed=42, quiet=False, breakdown=None, af
         if fid < check_frames:
             snap = _snapshot(nm, dec, mp, cfg)
             idx = mp._draw_index(max(1, iters + mp.adaptive_iter_offset), cfg.bs)
+            mp._grad_probe = True  # gradients of the call's first iteration on the untouched state (no optimiser step)
+            try:
+                probe = mp.mapping(1, index_seq=idx[:1])
+            finally:
+                mp._grad_probe = False
+            snap = snap + (probe,)
             mp.mapping(iters, index_seq=idx)
         else:
             mp.mapping(iters)
@@ -160,10 +166,29 @@ def _snapshot(nm, dec, mp, cfg):
     return st, od, pool, frozen
 
 
+def chaos_bounds(iters: int, entries: int, frozen: bool):
+    """Bounds on the parameter drift between two CORRECT evaluations of the loop on a layer-norm state, derived from
+    tests/golden/eps_chaos_calibration.json (oracle against itself, 1 vs 16 threads: oracle/calibrate_eps_chaos.py).  Adam's
+    eps = 1e-15 turns the sign of a cancellation residue into a +-lr step, so a fraction of the entries differs by up to
+    lr * iters between any two summation orders -- the reference's own included.  Returned: (max number of entries beyond
+    1e-4, max decoder drift) = 4 x the calibrated figures of the worst layer-norm case at that iteration count (the last
+    calibrated count, scaled linearly, beyond it)."""
+    cal = json.load(open(os.path.join(ROOT, "tests", "golden", "eps_chaos_calibration.json")))["cases"]
+    names = ["zero_features_layer_norm_frozen_decoder"] if frozen else ["zero_features_layer_norm", "random_features_layer_norm"]
+    frac, decd = 0.0, 0.0
+    for n in names:
+        rows = cal[n]
+        r = rows[min(iters, len(rows)) - 1]
+        scale = max(1.0, iters / r["iters"])
+        frac = max(frac, r["frac_gt_1e4"] * scale)
+        decd = max(decd, r["decoder_max"] * scale)
+    return max(8, int(4 * frac * entries) + 1), (0.0 if frozen else max(1e-4, 4 * decd))
+
+
 def _check_against_oracle(snap, idx, nm, dec, mp, cfg, fid):
     from oracle import cpu_ref as O
 
-    st, od, pool, frozen = snap
+    st, od, pool, frozen, probe = snap
     lc = O.LoopConfig(sigma=mp.sdf_scale, gradient_decimation=cfg.gradient_decimation,
                       fd_eps=cfg.voxel_size_m * cfg.num_grad_step_ratio, lr=cfg.lr, adam_eps=cfg.adam_eps)
     if frozen:
@@ -172,12 +197,29 @@ def _check_against_oracle(snap, idx, nm, dec, mp, cfg, fid):
     n_rep = min(n_all, 16)  # the 400-iteration call of frame 0 is replayed for its first iterations only (losses)
     recs = O.mapping_iters(st, od, pool, idx.cpu()[:n_rep], lc, record=True)
     got = mp.last_losses.cpu()
-    out = dict(frame=fid, iters=n_all, replayed=n_rep,
+    out = dict(frame=fid, iters=n_all, replayed=n_rep, frozen=bool(frozen),
                max_dloss=max(abs(float(got[i, 0]) - float(r["loss"])) for i, r in enumerate(recs)))
+    # The gradients of the first iteration (HIP: search + decode on the snapshot state, no optimiser step) against the
+    # oracle's, EVERY entry: gradients are sums of per-query terms -- no eps = 1e-15 amplification -- so a defect in any
+    # row shows here at the 1e-4 relative bar, which the drift of the parameters after several Adam steps cannot show.
+    g0 = recs[0]["grad_theta"]
+    dg = (probe["theta"].cpu() - g0).abs()
+    out["grad_theta_max"] = float(g0.abs().max())
+    out["max_dgrad_theta_rel"] = float(dg.max()) / max(float(g0.abs().max()), 1e-30)
+    # rows the oracle never gathers receive exactly zero in the HIP path too (anything else would become a +-lr step); a
+    # gathered row whose eight sums cancel to exactly 0 in one summation order and to 1e-20 in the other may differ
+    nz_hip, nz_ref = (probe["theta"].cpu() != 0).any(1), (g0 != 0).any(1)
+    out["rows_nonzero_only_in_hip"] = int((nz_hip & ~nz_ref).sum())
+    out["rows_nonzero_only_in_oracle"] = int((nz_ref & ~nz_hip).sum())
+    if not frozen:
+        gd = torch.cat([recs[0]["grad_" + n].reshape(-1) for n in ("W1", "b1", "W2", "b2")])
+        out["max_dgrad_decoder_rel"] = float((probe["decoder"].cpu() - gd).abs().max()) / max(float(gd.abs().max()), 1e-30)
     if n_rep == n_all:  # same number of Adam steps: parameters are comparable
         dth = (nm.local_geo_features.detach().cpu() - recs[-1]["theta"]).abs()
-        out.update(max_dtheta=float(dth.max()), n_dtheta_gt_1e4=int((dth > 1e-4).sum()),
+        n_max, dec_max = chaos_bounds(n_all, dth.numel(), frozen)
+        out.update(max_dtheta=float(dth.max()), n_dtheta_gt_1e4=int((dth > 1e-4).sum()), n_dtheta_gt_1e4_bound=n_max,
                    max_ddecoder=max(float((t.detach().cpu() - o).abs().max()) for t, o in zip(dec.flat_params(), recs[-1]["dec"])),
+                   max_ddecoder_bound=dec_max,
                    max_dcert=float((nm.local_point_certainties.cpu() - recs[-1]["certainties"]).abs().max()))
     return out
 

@@ -635,37 +635,58 @@ __device__ __forceinline__ void finish_loss(int p, float tot, float* loss_out, f
 __device__ __forceinline__ unsigned flags_to_nibble(unsigned d) {  // 4 flag bytes (0 / 1) -> 4 bits, byte i -> bit i
   return (((d & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
 }
-__global__ void __launch_bounds__(256) k_touch_bits(TouchWs tw, long long stride, int n_it, int it0) {
+__global__ void __launch_bounds__(64) k_touch_bits(TouchWs tw, long long stride, int n_it, int it0) {
   const long long W = stride / 32;
-  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long w = (long long)blockIdx.x * 64 + threadIdx.x;
   if (w >= W) return;
   unsigned seen = it0 > 0 ? tw.cum[w] : 0u;
-  for (int it = 0; it < n_it; ++it) {
-    uint4* f = reinterpret_cast<uint4*>(tw.flags + (size_t)it * stride + (size_t)w * 32);
-    const uint4 a = f[0], b = f[1];
-    const unsigned word = flags_to_nibble(a.x) | (flags_to_nibble(a.y) << 4) | (flags_to_nibble(a.z) << 8) |
-                          (flags_to_nibble(a.w) << 12) | (flags_to_nibble(b.x) << 16) | (flags_to_nibble(b.y) << 20) |
-                          (flags_to_nibble(b.z) << 24) | (flags_to_nibble(b.w) << 28);
-    if (word) f[0] = f[1] = make_uint4(0u, 0u, 0u, 0u);
-    seen |= word;
-    tw.bits[(size_t)it * W + w] = word;
-    tw.cumb[(size_t)it * W + w] = seen;
-    tw.wpre[(size_t)it * W + w] = (unsigned)__popc(word);
+  uint8_t* __restrict__ flags = tw.flags;
+  for (int b0 = 0; b0 < n_it; b0 += 8) {  // 8 iterations' flag words requested together (16 loads in flight per thread:
+    uint4 a[8], b[8];                     // the kernel is a handful of waves deep, i.e. pure load latency)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int it = b0 + k < n_it ? b0 + k : n_it - 1;
+      const uint4* f = reinterpret_cast<const uint4*>(flags + (size_t)it * stride + (size_t)w * 32);
+      a[k] = f[0];
+      b[k] = f[1];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int it = b0 + k;
+      if (it >= n_it) break;
+      const unsigned word = flags_to_nibble(a[k].x) | (flags_to_nibble(a[k].y) << 4) | (flags_to_nibble(a[k].z) << 8) |
+                            (flags_to_nibble(a[k].w) << 12) | (flags_to_nibble(b[k].x) << 16) | (flags_to_nibble(b[k].y) << 20) |
+                            (flags_to_nibble(b[k].z) << 24) | (flags_to_nibble(b[k].w) << 28);
+      if (word) {
+        uint4* f = reinterpret_cast<uint4*>(flags + (size_t)it * stride + (size_t)w * 32);
+        f[0] = f[1] = make_uint4(0u, 0u, 0u, 0u);
+      }
+      seen |= word;
+      tw.bits[(size_t)it * W + w] = word;
+      tw.cumb[(size_t)it * W + w] = seen;
+      tw.wpre[(size_t)it * W + w] = (unsigned)__popc(word);
+    }
   }
   tw.cum[w] = seen;
 }
-// one block per iteration of the chunk: exclusive scan of the word counts in place, total -> counts[it]
+// one block per iteration of the chunk: exclusive scan of the word counts in place, total -> counts[it].  A thread takes 8
+// consecutive words per round (two 16-byte loads), so a local map of 262 144 rows is ONE round of the block.
 __global__ void __launch_bounds__(1024) k_touch_scan(TouchWs tw, long long stride) {
   __shared__ unsigned wsum[16];
   __shared__ unsigned carry;
-  const long long W = stride / 32;
+  const long long W = stride / 32;  // a multiple of 8 (stride is a multiple of 256)
   unsigned* x = tw.wpre + (size_t)blockIdx.x * W;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) carry = 0u;
   __syncthreads();
-  for (long long base = 0; base < W; base += 1024) {
-    const long long i = base + threadIdx.x;
-    const unsigned v = i < W ? x[i] : 0u;
+  for (long long base = 0; base < W; base += 8192) {
+    const long long i = base + (long long)threadIdx.x * 8;
+    uint4 p = make_uint4(0u, 0u, 0u, 0u), q = p;
+    if (i < W) {
+      p = *reinterpret_cast<const uint4*>(x + i);
+      q = *reinterpret_cast<const uint4*>(x + i + 4);
+    }
+    const unsigned v = p.x + p.y + p.z + p.w + q.x + q.y + q.z + q.w;
     unsigned inc = v;  // inclusive scan inside the wave
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -676,7 +697,14 @@ __global__ void __launch_bounds__(1024) k_touch_scan(TouchWs tw, long long strid
     __syncthreads();
     unsigned off = carry;
     for (int k = 0; k < wave; ++k) off += wsum[k];
-    if (i < W) x[i] = off + inc - v;
+    if (i < W) {
+      unsigned e = off + inc - v;
+      uint4 po, qo;
+      po.x = e; e += p.x; po.y = e; e += p.y; po.z = e; e += p.z; po.w = e; e += p.w;
+      qo.x = e; e += q.x; qo.y = e; e += q.y; qo.z = e; e += q.z; qo.w = e;
+      *reinterpret_cast<uint4*>(x + i) = po;
+      *reinterpret_cast<uint4*>(x + i + 4) = qo;
+    }
     __syncthreads();
     if (threadIdx.x == 1023) carry = off + inc;
     __syncthreads();
@@ -1096,7 +1124,7 @@ extern "C" int clid_train_touch_scan(const clid_train_args* a, int32_t M, int32_
   hipStream_t s = (hipStream_t)stream;
   const TouchWs tw = touch_carve(a->touch_ws, a->touch_stride, chunk);
   const long long W = a->touch_stride / 32;
-  CLID_KLAUNCH(a->prof, 5, k_touch_bits, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, s, tw, (long long)a->touch_stride,
+  CLID_KLAUNCH(a->prof, 5, k_touch_bits, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, s, tw, (long long)a->touch_stride,
                (int)n_it, (int)it0);
   CLID_KLAUNCH(a->prof, 5, k_touch_scan, dim3((unsigned)n_it), dim3(1024), 0, s, tw, (long long)a->touch_stride);
   CLID_CHECK_LAUNCH();

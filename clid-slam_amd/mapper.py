@@ -356,6 +356,8 @@ class Mapper:
         stream = _lib.stream()
         idx_base, row_bytes = index_seq.data_ptr(), bs_global * 8
         loss_base = losses.data_ptr()
+        if getattr(self, "_grad_probe", False):
+            return self._probe_gradients(lib, view, keep, ta, grad, losses, idx_base, bs_global, n_feat // _lib.F, dev, stream)
         cert_in_rows = True
         try:
             if not dist:
@@ -408,6 +410,31 @@ class Mapper:
         self.last_losses = losses
         self._keep = (keep, index_seq, grad, m, v, m_mlp, v_mlp)
         nm.assign_local_to_global()
+
+    def _probe_gradients(self, lib, view, keep, ta, grad, losses, idx_base, bs, n_rows, dev, stream):
+        """Checker aid (tests, bench_sequence --check-frames; `self._grad_probe = True` then `mapping(1, index_seq=...)`):
+        the gradients of ONE iteration on the current state -- search + decode through the C ABI, NO optimiser step --
+        as {"theta": [rows, 8], "decoder": [833], "cert_inc": [rows], "loss": [4]}.  Gradients are linear in the per-query
+        terms, so unlike parameters after several eps = 1e-15 Adam steps they can be compared entry by entry with the
+        oracle's."""
+        if ta.eikonal_mode == 2 or ta.pipeline != 1 or _dist() is not None:
+            raise NotImplementedError("gradient probe: hoisted single-GPU schedule only")
+        ta.defer_reduce, ta.touch_ws, ta.cbuf = 0, None, None
+        ta.index, ta.loss_out = idx_base, losses.data_ptr()
+        rec = torch.empty(int(lib.clid_train_search_floats(ta.bs, ta.batch_offset, ta.decimation, ta.eikonal_mode, 1)),
+                          device=dev, dtype=torch.float32)
+        ts_before = self.neural_points.local_point_ts_update.clone()
+        _lib.check(lib.clid_train_search(C.byref(view), C.byref(ta), 1, idx_base, bs, rec.data_ptr(), stream), "clid_train_search")
+        _lib.check(lib.clid_train_decode(C.byref(view), C.byref(ta), rec.data_ptr(), stream), "clid_train_decode")
+        torch.cuda.synchronize()
+        rows = grad[_lib.GRAD_FEAT_OFFSET16:_lib.GRAD_FEAT_OFFSET16 + n_rows * _lib.GRAD_ROW16].view(n_rows, _lib.GRAD_ROW16)
+        out = {"theta": rows[:, :_lib.F].clone(), "decoder": grad[:_lib.MLP_PARAMS].clone(), "cert_inc": rows[:, _lib.F].clone(),
+               "loss": losses[0].clone()}
+        grad.zero_()
+        losses.zero_()
+        self.neural_points.local_point_ts_update.copy_(ts_before)  # (the decode's only direct side effect with the tile kernels)
+        del keep
+        return out
 
     SPARSE_MIN_ROWS = 1 << 16       # single GPU: local maps from this size on run the touched-row Adam sweep
     SPARSE_MIN_ROWS_DIST = 1 << 15  # sharded: from here on the compact exchange (dense payload 64 B x rows > 2 MB)
