@@ -415,8 +415,8 @@ class Mapper:
         """Checker aid (tests, bench_sequence --check-frames; `self._grad_probe = True` then `mapping(1, index_seq=...)`):
         the gradients of ONE iteration on the current state -- search + decode through the C ABI, NO optimiser step --
         as {"theta": [rows, 8], "decoder": [833], "cert_inc": [rows], "loss": [4]}.  Gradients are linear in the per-query
-        terms, so unlike parameters after several eps = 1e-15 Adam steps they can be compared entry by entry with the
-        oracle's."""
+        terms, so unlike parameters after several eps = 1e-15 Adam steps they can be compared entry by entry with a CPU
+        evaluation of the reference's loop."""
         if ta.eikonal_mode == 2 or ta.pipeline != 1 or _dist() is not None:
             raise NotImplementedError("gradient probe: hoisted single-GPU schedule only")
         ta.defer_reduce, ta.touch_ws, ta.cbuf = 0, None, None
