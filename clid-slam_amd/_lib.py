@@ -148,6 +148,7 @@ _SIGS = {
     "clid_train_chunk_iters": (_i32, [C.POINTER(TrainArgs)]),
     "clid_train_decode_kernel": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs)]),
     "clid_train_search_floats": (_i64, [_i32, _i64, _i32, _i32, _i32]),
+    "clid_train_search_tasks": (_i32, [_i32, _i64, _i32, _i32]),
     "clid_train_search": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), _i32, _vp, _i64, _vp, _vp]),
     "clid_train_decode": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), _vp, _vp]),
     "clid_profile_create": (_vp, []),

@@ -212,28 +212,25 @@ __device__ __forceinline__ bool search8(const clid_map_view& mv, const DeltaLds&
 }
 
 constexpr int kFusedBlock = 512;  // 8 waves share one partial row: half as many rows for k_adam_all to reduce
-// MODE 0: search + decode in one launch.  MODE 1 / 2: the same two phases as separate kernels with the
-// searches' winners (kRecFloat4 float4 per task: qinfo | qdesc | win, the head of WaveLds) parked in HBM: the
-// search reads nothing that training writes (positions, table and sample indices only), so one MODE 1 launch
+// MODE 0: search + decode in one launch (clid_train_fwd_bwd).  MODE 2: the decode phase alone, from the records the
+// hoisted search launch (k_search_tiles below) parked in HBM: kRecFloat4 float4 per task = qinfo | qdesc | win, the head of
+// WaveLds.  The search reads nothing that training writes (positions, table and sample indices only), so one search launch
 // resolves a whole chunk of iterations ahead of the dependent decode -> Adam chain (clid_train_search).
 constexpr int kRecFloat4 = 48;
+#ifndef CLID_XCD_MAP
+#define CLID_XCD_MAP 1
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(kFusedBlock, MODE == 1 ? CLID_SEARCH_WAVES : CLID_FUSED_WAVES)
+__global__ void __launch_bounds__(kFusedBlock, CLID_FUSED_WAVES)
 k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap,
-               float4* __restrict__ rec, int n_iter, long long index_stride, int use_filter) {
+               float4* __restrict__ rec) {
+  static_assert(MODE == 0 || MODE == 2, "MODE 1 (search only) is k_search_tiles");
   __shared__ MlpLds mlp;
   __shared__ DeltaLds dl;
-  __shared__ WaveLds wlds[MODE == 1 ? 1 : kFusedBlock / 64];
-  __shared__ WaveHead heads[MODE == 1 ? kFusedBlock / 64 : 1];  // the search-only kernel keeps just the record
+  __shared__ WaveLds wlds[kFusedBlock / 64];
   __shared__ float red[(kFusedBlock / 64) * kRedFloats];
-  extern __shared__ unsigned filt_lds[];  // MODE 1 with a prefilter: 2^log2filter bits (dynamic LDS)
   static_assert(sizeof(WaveHead) == kRecFloat4 * sizeof(float4), "record layout");
-  if constexpr (MODE == 1) {
-    stage_delta(dl, mv);
-    if (use_filter == 1)
-      for (int i = threadIdx.x; i < (1 << mv.log2filter) / 32; i += kFusedBlock) filt_lds[i] = mv.filter[i];
-    __syncthreads();
-  } else if constexpr (MODE == 2) {
+  if constexpr (MODE == 2) {
     stage_mlp(mlp, ta.W1, ta.b1, ta.W2, ta.b2);
   } else {
     stage_mlp_and_delta(mlp, dl, mv, ta.W1, ta.b1, ta.W2, ta.b2);
@@ -243,8 +240,8 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
   const int wave = threadIdx.x >> 6, waves_per_block = kFusedBlock / 64;
   const int my_k = lane16 >> 1;
   const bool odd = lane16 & 1;
-  WaveLds& wl = wlds[MODE == 1 ? 0 : wave];
-  WaveHead& hd = MODE == 1 ? heads[wave] : static_cast<WaveHead&>(wl);
+  WaveLds& wl = wlds[wave];
+  WaveHead& hd = static_cast<WaveHead&>(wl);
   MlpAcc acc;
   acc.zero();
   float bce_acc = 0.f, eik_acc = 0.f;
@@ -255,43 +252,8 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
   const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
   const float sc = ta.sdf_scale;
 
-  // MODE 1 searches n_iter iterations' batches in one launch (iteration `it` draws from ta.index + it*index_stride)
-  const int total = MODE == 1 ? tmap.n_tasks * n_iter : tmap.n_tasks;
-#ifndef CLID_XCD_MAP
-#define CLID_XCD_MAP 1
-#endif
-  // MODE 1, XCD-aware task mapping: block b runs on XCD b % 8 (observed dispatch order; a speed matter only), and every XCD
-  // has its own 4 MB L2.  On batches in Morton order consecutive tasks are neighbours in space, so XCD x takes the x-th
-  // eighth of the bundle tasks and of the plain tasks of EVERY iteration: its L2 then serves one eighth of the map (probe
-  // table, positions) instead of all of it -- what matters once the local map has outgrown one L2 (M = 243 k: 12 MB;
-  // search 18.9 -> 17.5 us per iteration there).
-  const int xcd = blockIdx.x & 7, xb = blockIdx.x >> 3, xnb = ((int)gridDim.x + 7 - xcd) >> 3;
-  const int n_rest = tmap.n_tasks - tmap.n_fd;
-  const int xb0 = (int)((long long)tmap.n_fd * xcd / 8), xb1 = (int)((long long)tmap.n_fd * (xcd + 1) / 8);
-  const int xr0 = (int)((long long)n_rest * xcd / 8), xr1 = (int)((long long)n_rest * (xcd + 1) / 8);
-  const int xlen = (xb1 - xb0) + (xr1 - xr0);
-  // (only for maps beyond one L2 -- the launcher's use_filter == 2 --: below that it costs 0.2 us per iteration at 16 384 samples)
-  const bool xmap = MODE == 1 && CLID_XCD_MAP && use_filter == 2 && gridDim.x >= 8;
-  const int w_first = xmap ? xb * waves_per_block + wave : blockIdx.x * waves_per_block + wave;
-  const int w_step = xmap ? xnb * waves_per_block : gridDim.x * waves_per_block;
-  const int w_total = xmap ? xlen * n_iter : total;
-  for (int w = w_first; w < w_total; w += w_step) {
-    int gtask = w;
-    int task = w;
+  for (int task = blockIdx.x * waves_per_block + wave; task < tmap.n_tasks; task += gridDim.x * waves_per_block) {
     const long long* index = reinterpret_cast<const long long*>(ta.index);
-    int it = 0;  // iteration of the chunk (MODE 1)
-    if constexpr (MODE == 1) {
-      if (xmap) {
-        it = w / xlen;
-        const int u = w - it * xlen;
-        task = u < xb1 - xb0 ? xb0 + u : tmap.n_fd + xr0 + (u - (xb1 - xb0));
-        gtask = it * tmap.n_tasks + task;
-      } else {
-        it = w / tmap.n_tasks;
-        task = w - it * tmap.n_tasks;
-      }
-      index += (long long)it * index_stride;
-    }
     const bool bundle = task < tmap.n_fd;
     CLID_STAMP(0);
     // ================= search: 8 slots x 8 lanes
@@ -319,16 +281,7 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
       }
       asm volatile("" ::"v"(px), "v"(py), "v"(pz));
       CLID_STAMP(1);
-      if constexpr (MODE == 1) {
-        bool redo;
-        if (use_filter == 1) redo = search8<true, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], filt_lds);
-        else if (use_filter == 2) redo = search8<true, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], mv.filter);
-        else redo = search8<false, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
-        if (__any(redo) || (ta.debug_flags & 4))  // rare (debug bit 2 forces it: tests compare the two paths)
-          search8<false, CLID_K>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
-      } else {
-        search8<false, CLID_K>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
-      }
+      search8<false, CLID_K>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
       // (d2, id) -> (IDW weight, id) + blended offset (np.py:653-706), lane8 = k
       wave_lds_fence();
       {
@@ -339,11 +292,6 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
         const float osum = group8_sum(om);
         const float w = valid ? fmul(om, fdiv(1.0f, osum)) : 0.f;        // np.py:699-706
         const float4 pk = pos4[valid ? id : 0];
-        if constexpr (MODE == 1) {
-          // touched-row flag of (iteration of the chunk, map row): a plain byte store -- racing writers store the same
-          // value -- that the chunk's scan turns into the iteration's row set (sparse exchange / Adam, train_common.hpp)
-          if (ta.touch_ws && valid && live) ta.touch_ws[(size_t)it * ta.touch_stride + id] = 1;
-        }
         const float rx = group8_sum(fsub(px, pk.x) * w), ry = group8_sum(fsub(py, pk.y) * w),
                     rz = group8_sum(fsub(pz, pk.z) * w);
         wave_lds_fence();
@@ -352,12 +300,6 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
       }
     }
     CLID_STAMP(3);
-    if constexpr (MODE == 1) {
-      wave_lds_fence();
-      if (lane < kRecFloat4) rec[(size_t)gtask * kRecFloat4 + lane] = reinterpret_cast<const float4*>(&hd)[lane];
-      wave_lds_fence();
-      continue;
-    }
     if (bundle) {
       if (lane < CLID_K * CLID_F) (&wl.cacc[0][0])[lane] = 0.f;
       if (lane < 8) wl.ccert[lane] = 0.f;
@@ -569,9 +511,185 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
     CLID_STAMP(10);
   }
   CLID_STAMP(24);
-  if constexpr (MODE != 1)
-    flush_mlp_acc(acc, bce_acc, eik_acc, red, partial + (size_t)blockIdx.x * kPartialStride, ta.train_decoder != 0);
+  flush_mlp_acc(acc, bce_acc, eik_acc, red, partial + (size_t)blockIdx.x * kPartialStride, ta.train_decoder != 0);
   CLID_STAMP(25);
+}
+
+// ---- the hoisted search launch (clid_train_search): tasks in pairs, tiles numbered in the same pass ------------------------
+// The search phase of k_train_fused8 per TILE (= two consecutive tasks, the unit of the matrix-core
+// decode kernels): the wave searches both tasks, writes their records, and -- with both records still in LDS -- numbers the
+// tile's (query, neighbour) pairs per distinct map row into the tile's number block (train_common.hpp kTileNumWords).  The
+// numbering depends on the records only, so it belongs here, once per chunk, not in every decode launch's dependent chain
+// (decode 14.5 -> 12.6 us at 16 384 samples; the search launch pays 1.0 us per iteration for it -- 8.2 instead of 7.2 -- and
+// the step over 200 iterations goes from 29.3 to 28.4 us); a separate pass over the records cost 1.5 us per iteration.
+constexpr int kNumHash = 128;  // LDS hash slots for the <= 96 distinct map rows of a tile
+struct TileNumLds {
+  int hkey[kNumHash];            // hash slot -> map row id, -1 empty
+  unsigned char hrow[kNumHash];  // hash slot -> row number inside the tile
+};
+
+// one wave task: pool gathers, 81-cell search of its 8 query slots, IDW weights / blended offsets -> record in `hd`
+__device__ __forceinline__ void search_task(const clid_map_view& mv, const clid_train_args& ta, const TaskMap& tmap,
+                                            const DeltaLds& dl, const long long* __restrict__ index, int task, int it, int use_filter,
+                                            const unsigned* __restrict__ filt_lds, WaveHead& hd) {
+  const int lane = threadIdx.x & 63, lane8 = lane & 7, slot8 = lane >> 3;
+  const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
+  const QDesc qd = task_query(tmap, task, slot8 >> 2, slot8 & 3);
+  const bool live = qd.p >= 0;
+  const long long s = index[live ? qd.p : 0];
+  float px = ta.pool_coord[s * 3 + 0], py = ta.pool_coord[s * 3 + 1], pz = ta.pool_coord[s * 3 + 2];
+  if (qd.axis == 0) px = fadd(px, qd.sign * ta.fd_eps);  // x + [eps,0,0] in fp32 (mapper.py:988-999)
+  if (qd.axis == 1) py = fadd(py, qd.sign * ta.fd_eps);
+  if (qd.axis == 2) pz = fadd(pz, qd.sign * ta.fd_eps);
+  if (lane8 == 0) {
+    float label = 0.f, wt = 1.f;
+    int ts = live ? 0 : -1;
+    if (live && qd.axis < 0) {  // the sample itself: its label, weight (mapper.py:747-749) and time stamp
+      label = ta.pool_label[s];
+      if (ta.loss_weight_on) wt = fabsf(ta.pool_weight[s]);
+      if (ta.pool_ts) ts = ta.pool_ts[s];
+    }
+    const int code = qd.axis < 0 ? -1 : 2 * qd.axis + (qd.sign > 0.f ? 1 : 0);
+    hd.qinfo[slot8] = make_float4(px, py, pz, __int_as_float(ts));
+    hd.qdesc[slot8] = make_float4(__int_as_float(qd.p), __int_as_float(code), label, wt);
+  }
+  asm volatile("" ::"v"(px), "v"(py), "v"(pz));
+  bool redo;
+  if (use_filter == 1) redo = search8<true, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], filt_lds);
+  else if (use_filter == 2) redo = search8<true, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], mv.filter);
+  else redo = search8<false, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
+  if (__any(redo) || (ta.debug_flags & 4))  // rare (debug bit 2 forces it: tests compare the two paths)
+    search8<false, CLID_K>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
+  // (d2, id) -> (IDW weight, id) + blended offset (np.py:653-706), lane8 = k
+  wave_lds_fence();
+  const float2 wn = hd.win[slot8][lane8 < CLID_K ? lane8 : 0];
+  const int id = __float_as_int(wn.y);
+  const bool valid = lane8 < CLID_K && id >= 0;
+  const float om = valid ? fdiv(1.0f, fadd(wn.x, 1e-15f)) : 0.f;   // np.py:688-693
+  const float osum = group8_sum(om);
+  const float w = valid ? fmul(om, fdiv(1.0f, osum)) : 0.f;        // np.py:699-706
+  const float4 pk = pos4[valid ? id : 0];
+  // touched-row flag of (iteration of the chunk, map row): a plain byte store -- racing writers store the same value --
+  // that the chunk's scan turns into the iteration's row set (sparse exchange / Adam, train_common.hpp)
+  if (ta.touch_ws && valid && live) ta.touch_ws[(size_t)it * ta.touch_stride + id] = 1;
+  const float rx = group8_sum(fsub(px, pk.x) * w), ry = group8_sum(fsub(py, pk.y) * w), rz = group8_sum(fsub(pz, pk.z) * w);
+  wave_lds_fence();
+  hd.win[slot8][lane8] = lane8 < CLID_K ? make_float2(w, wn.y) : (lane8 == CLID_K ? make_float2(rx, ry) : make_float2(rz, 0.f));
+  wave_lds_fence();
+}
+
+// The tile's pairs numbered per distinct map row: lane = (q = lane & 15, g = lane >> 4) as in k_decode_tile, lane (q, g)
+// owns neighbours k = g and (g < 2) k = g + 4 of query slot q of the tile.  The ids go through a 128-slot LDS hash (integer
+// ds_cmpst; the first pair of a row wins its slot), the winners take consecutive row numbers from two ballots.  Measured
+// against a variant without LDS atomics (plain-store arbitration in rounds, linear or double hashing): 8.16 vs 8.42 / 8.43 us
+// per iteration for the search launch (7.3 without any numbering); in the decode kernel itself the round-based variant was
+// slower than the CAS loop it replaced (16.2 vs 14.5 us).  (Its own function: it keeps the search loop's registers apart.)
+__device__ __noinline__ void number_tile(const WaveHead& h0, const WaveHead& h1, TileNumLds& nl, int* __restrict__ tn,
+                                         bool second_live) {
+  const int lane = threadIdx.x & 63;
+  const int q = lane & 15, g = lane >> 4;
+  const bool tlive = (q >> 3) == 0 || second_live;
+  const WaveHead& hq = (q >> 3) ? h1 : h0;
+  const bool qlive = tlive && __float_as_int(hq.qinfo[q & 7].w) >= 0;  // (padding slots carry a search nobody reads)
+  nl.hkey[lane] = -1;
+  nl.hkey[lane + 64] = -1;
+  int jk[2], hs[2];
+  bool won[2] = {false, false};
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int k = g + 4 * t;
+    jk[t] = (k < CLID_K && qlive) ? __float_as_int(hq.win[q & 7][k < CLID_K ? k : 0].y) : -1;
+    hs[t] = (int)(((unsigned)jk[t] * 2654435761u) >> 25);  // 7 bits
+  }
+  wave_lds_fence();
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+    if (jk[t] >= 0) {
+      for (;;) {
+        const int old = atomicCAS(&nl.hkey[hs[t]], -1, jk[t]);
+        if (old == -1) {  // first pair of this row in the tile
+          won[t] = true;
+          break;
+        }
+        if (old == jk[t]) break;
+        hs[t] = (hs[t] + 1) & (kNumHash - 1);
+      }
+    }
+  // the winners take consecutive row numbers from two ballots (no counter to contend for)
+  const unsigned long long b0 = __ballot(won[0]), b1 = __ballot(won[1]);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const int n0 = __popcll(b0), count = n0 + __popcll(b1);
+  if (won[0]) {
+    const int d = __popcll(b0 & below);
+    nl.hrow[hs[0]] = (unsigned char)d;
+    tn[d] = jk[0];
+  }
+  if (won[1]) {
+    const int d = n0 + __popcll(b1 & below);
+    nl.hrow[hs[1]] = (unsigned char)d;
+    tn[d] = jk[1];
+  }
+  wave_lds_fence();
+  unsigned char* rbytes = reinterpret_cast<unsigned char*>(tn + kTileNumBytes);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int k = g + 4 * t;
+    if (k < CLID_K) rbytes[q * CLID_K + k] = jk[t] >= 0 ? nl.hrow[hs[t]] : (unsigned char)255;
+  }
+  if (lane == 0) tn[kTileNumCount] = count;
+  wave_lds_fence();
+}
+
+template <bool XMAP>
+__global__ void __launch_bounds__(kFusedBlock, CLID_SEARCH_WAVES)
+k_search_tiles(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __restrict__ rec, int n_iter, long long index_stride,
+               int use_filter) {
+  __shared__ DeltaLds dl;
+  __shared__ WaveHead heads[kFusedBlock / 64][2];
+  __shared__ TileNumLds nums[kFusedBlock / 64];
+  extern __shared__ unsigned filt_lds[];  // with a prefilter of <= 32 KB: 2^log2filter bits (dynamic LDS)
+  stage_delta(dl, mv);
+  if (use_filter == 1)
+    for (int i = threadIdx.x; i < (1 << mv.log2filter) / 32; i += kFusedBlock) filt_lds[i] = mv.filter[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves_per_block = kFusedBlock / 64;
+  const int n_tiles = (tmap.n_tasks + 1) / 2;
+  const size_t iter_f4 = rec_floats_per_iter(tmap.n_tasks) / 4;
+  // XCD-aware tile mapping for maps beyond one L2 (the launcher's use_filter == 2): block b runs on XCD b % 8 (observed
+  // dispatch order; a speed matter only) and every XCD has its own 4 MB L2.  On batches in Morton order consecutive tasks are
+  // neighbours in space, so XCD x takes the x-th eighth of the bundle tiles and of the plain tiles of EVERY iteration: its
+  // L2 then serves one eighth of the map (M = 243 k: search 18.9 -> 17.5 us per iteration; at M = 23 k it costs 0.2 us)
+  const int xcd = blockIdx.x & 7, xb = blockIdx.x >> 3, xnb = ((int)gridDim.x + 7 - xcd) >> 3;
+  const int nb_t = (tmap.n_fd + 1) / 2, n_rest = n_tiles - nb_t;
+  const int xb0 = (int)((long long)nb_t * xcd / 8), xb1 = (int)((long long)nb_t * (xcd + 1) / 8);
+  const int xr0 = (int)((long long)n_rest * xcd / 8), xr1 = (int)((long long)n_rest * (xcd + 1) / 8);
+  const int xlen = (xb1 - xb0) + (xr1 - xr0);
+  constexpr bool xmap = XMAP;  // (its own instantiation: the mapping's scalars cost the small-map kernel registers it has to spill)
+  const int w_first = xmap ? xb * waves_per_block + wave : blockIdx.x * waves_per_block + wave;
+  const int w_step = xmap ? xnb * waves_per_block : gridDim.x * waves_per_block;
+  const int w_total = xmap ? xlen * n_iter : n_tiles * n_iter;
+  for (int w = w_first; w < w_total; w += w_step) {
+    int it, tile;
+    if (xmap) {
+      it = w / xlen;
+      const int u = w - it * xlen;
+      tile = u < xb1 - xb0 ? xb0 + u : nb_t + xr0 + (u - (xb1 - xb0));
+    } else {
+      it = w / n_tiles;
+      tile = w - it * n_tiles;
+    }
+    const long long* index = reinterpret_cast<const long long*>(ta.index) + (long long)it * index_stride;
+    float4* __restrict__ out = rec + (size_t)it * iter_f4;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      const int task = 2 * tile + half;
+      if (task >= tmap.n_tasks) break;
+      search_task(mv, ta, tmap, dl, index, task, it, use_filter, filt_lds, heads[wave][half]);
+      if (lane < kRecFloat4) out[(size_t)task * kRecFloat4 + lane] = reinterpret_cast<const float4*>(&heads[wave][half])[lane];
+    }
+    number_tile(heads[wave][0], heads[wave][1], nums[wave],
+                reinterpret_cast<int*>(out + (size_t)tmap.n_tasks * kRecFloat4) + (size_t)tile * kTileNumWords, 2 * tile + 1 < tmap.n_tasks);
+  }
 }
 
 // ---- partial reduction + Adam ---------------------------------------------------------------------------
@@ -1073,7 +1191,13 @@ extern "C" int64_t clid_train_search_floats(int32_t bs, int64_t batch_offset, in
   if (bs <= 0 || decimation <= 0 || n_iter < 0 || eikonal_mode == 2) return -1;
   const int first = fd_first(batch_offset, decimation);
   const int n_fd = eikonal_mode == 1 ? fd_count(bs, batch_offset, decimation) : 0;
-  return (int64_t)make_task_map(bs, n_fd, first, decimation).n_tasks * kRecFloatsPerTask * n_iter;
+  return (int64_t)rec_floats_per_iter(make_task_map(bs, n_fd, first, decimation).n_tasks) * n_iter;
+}
+extern "C" int32_t clid_train_search_tasks(int32_t bs, int64_t batch_offset, int32_t decimation, int32_t eikonal_mode) {
+  if (bs <= 0 || decimation <= 0 || eikonal_mode == 2) return -1;
+  const int first = fd_first(batch_offset, decimation);
+  const int n_fd = eikonal_mode == 1 ? fd_count(bs, batch_offset, decimation) : 0;
+  return make_task_map(bs, n_fd, first, decimation).n_tasks;
 }
 extern "C" int32_t clid_train_chunk_iters(const clid_train_args* a) {
   if (!a || a->bs <= 0 || a->decimation <= 0 || a->eikonal_mode == 2) return 0;
@@ -1171,8 +1295,7 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
   if (a->eikonal_mode == 2) {  // loss.numerical_grad_on: False (utils/mapper.py:57-69, 660-661, 695-696)
     if (int e = clid_launch_train_analytic(mv, a, ws.partial, s)) return e;
   } else {
-    CLID_KLAUNCH(a->prof, 0, k_train_fused8<0>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap,
-                 (float4*)nullptr, 1, 0LL, 0);
+    CLID_KLAUNCH(a->prof, 0, k_train_fused8<0>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap, (float4*)nullptr);
     CLID_CHECK_LAUNCH();
   }
   if (!a->defer_reduce)
@@ -1314,7 +1437,7 @@ extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args*
   }
   clid_train_args t2 = *a;
   t2.index = index_base;
-  long long sb = ((long long)tmap.n_tasks * n_iter + kFusedBlock / 64 - 1) / (kFusedBlock / 64);
+  long long sb = ((long long)((tmap.n_tasks + 1) / 2) * n_iter + kFusedBlock / 64 - 1) / (kFusedBlock / 64);  // a wave per tile
   if (sb > search_blocks()) sb = search_blocks();
   // probe prefilter (a one-hash Bloom filter over the stored slots; 59 of the 81 probes of a typical query hit nothing):
   // staged in LDS when it fits (<= 32 KB) and the launch is large enough to amortise staging it per block; for large
@@ -1326,8 +1449,12 @@ extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args*
     else use_filter = 2;
   }
   const size_t dyn = use_filter == 1 ? ((size_t)1 << mv->log2filter) / 8 : 0;
-  CLID_KLAUNCH(a->prof, 1, k_train_fused8<1>, dim3((unsigned)sb), dim3(kFusedBlock), dyn, s, *mv, t2, (float*)nullptr, tmap,
-               reinterpret_cast<float4*>(rec_out), n_iter, (long long)index_stride, use_filter);
+  if (CLID_XCD_MAP && use_filter == 2 && sb >= 8)
+    CLID_KLAUNCH(a->prof, 1, k_search_tiles<true>, dim3((unsigned)sb), dim3(kFusedBlock), dyn, s, *mv, t2, tmap,
+                 reinterpret_cast<float4*>(rec_out), n_iter, (long long)index_stride, use_filter);
+  else
+    CLID_KLAUNCH(a->prof, 1, k_search_tiles<false>, dim3((unsigned)sb), dim3(kFusedBlock), dyn, s, *mv, t2, tmap,
+                 reinterpret_cast<float4*>(rec_out), n_iter, (long long)index_stride, use_filter);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }
@@ -1352,7 +1479,7 @@ extern "C" int clid_train_decode(const clid_map_view* mv, const clid_train_args*
     if (int e = clid_launch_decode_tile(mv, a, ws.partial, tmap, rec, variant == 2 ? 1 : 0, s)) return e;
   } else {
     CLID_KLAUNCH(a->prof, 0, k_train_fused8<2>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap,
-                 reinterpret_cast<float4*>(const_cast<float*>(rec)), 1, 0LL, 0);
+                 reinterpret_cast<float4*>(const_cast<float*>(rec)));
     CLID_CHECK_LAUNCH();
   }
   if (!a->defer_reduce) {

@@ -7,9 +7,21 @@
 namespace clid {
 
 constexpr int kPartialStride = 840;  // 833 decoder grads | bce sum | eik sum | pad
-constexpr int kMaxBwdBlocks = 1024;
+#ifndef CLID_MAX_BWD_BLOCKS
+#define CLID_MAX_BWD_BLOCKS 1024
+#endif
+constexpr int kMaxBwdBlocks = CLID_MAX_BWD_BLOCKS;
 
 constexpr int kRecFloatsPerTask = 192;  // qinfo[8] | qdesc[8] | win[8][8]: what the search phase hands the decode phase
+// Behind an iteration's task records: one block of kTileNumWords 32-bit words per TILE (= two consecutive tasks, the unit of
+// the matrix-core decode kernel): the tile's (query, neighbour) pairs numbered per distinct map row -- state-independent,
+// so it is resolved once next to the searches instead of in every decode launch's dependent chain (k_search_tiles):
+//   [0, 96)   map row id of the tile's row number r (r < count)        [96] count
+//   [100, 124) 96 bytes: row number of pair (query q, neighbour k) at byte 6 q + k, 255 = no neighbour
+constexpr int kTileNumWords = 128, kTileNumCount = 96, kTileNumBytes = 100;
+__host__ __device__ inline size_t rec_floats_per_iter(int n_tasks) {
+  return (size_t)n_tasks * kRecFloatsPerTask + (size_t)((n_tasks + 1) / 2) * kTileNumWords;
+}
 
 struct TrainWs {
   float* partial;  // [kMaxBwdBlocks][kPartialStride]
@@ -23,7 +35,7 @@ __host__ inline size_t max_tasks(int Q) { return (size_t)Q / 4 + 16; }
 // ~32 at the actual task count), capped at 1 GiB for very large batches, never less than one iteration
 constexpr int kMaxChunkIters = 32;
 __host__ inline size_t rec_buffer_floats(int Q) {
-  const size_t one = max_tasks(Q) * kRecFloatsPerTask;
+  const size_t one = rec_floats_per_iter((int)max_tasks(Q));
   size_t it = (size_t(1) << 28) / one;
   if (it > 16) it = 16;
   if (it < 1) it = 1;

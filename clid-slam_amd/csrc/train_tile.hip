@@ -38,7 +38,10 @@ namespace clid {
 
 // waves (= tiles in flight) per block: 4 while one round of blocks covers the batch (the reference's 16 384 samples: one
 // partial row per 4 tiles keeps k_adam_all's column sums short), 2 beyond that (finer tail; 45.1 -> 41.1 us at 65 536)
-constexpr int kTileWavesSmall = 4, kTileWavesLarge = 2;
+#ifndef CLID_TILE_WAVES_SMALL
+#define CLID_TILE_WAVES_SMALL 4
+#endif
+constexpr int kTileWavesSmall = CLID_TILE_WAVES_SMALL, kTileWavesLarge = 2;
 constexpr int kTileLargeFrom = 2048;  // tiles
 __host__ inline int tile_waves_for(int n_tiles) { return n_tiles > kTileLargeFrom ? kTileWavesLarge : kTileWavesSmall; }
 constexpr int kRecF4 = 48;       // float4 per search record (== kRecFloat4 of train.hip)
@@ -50,18 +53,14 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kHash = 128;      // LDS hash slots for the <= 96 distinct map rows of a tile
 constexpr int kMaxRows = 96;
 struct alignas(16) TileLds {
   float dh[16 * kDhStride];  // [q][h]
   float f[16 * kFStride];    // [q][c], c = 0..15 (11 = the bias input 1, 12..15 = 0)
   float wm[kMaxRows * 16];   // [row][q]: weight of query q on the tile's distinct map row `row`
-  int hkey[kHash];           // hash slot -> map row id, -1 empty
-  int hrow[kHash];           // hash slot -> row number inside the tile
-  int rowid[kMaxRows];       // row number -> map row id
-  int count;                 // distinct rows of the tile
-  int pad_[3];
+  int rowid[kMaxRows];       // row number -> map row id (from the tile's number block)
 };
+
 // layer-norm variants: what F.layer_norm's backward needs of every distinct row, saved by the forward pass
 struct alignas(16) TileLnLds {
   float xh[kMaxRows * CLID_F];  // [row][c]: normalised features
@@ -98,7 +97,7 @@ __device__ __forceinline__ void tile_lds_fence() {
 template <int PREC, bool LN, int TW>
 __global__ void __launch_bounds__(TW * 64, CLID_TILE_WAVES)
 k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap,
-              const float4* __restrict__ rec, int n_tiles, float* __restrict__ sdf_dbg) {
+              const float4* __restrict__ rec, const int* __restrict__ tnum, int n_tiles, float* __restrict__ sdf_dbg) {
   __shared__ TileLds tls[TW];
   __shared__ TileLnLds lns[LN ? TW : 1];
   static_assert(sizeof(TileLds) % 16 == 0 && sizeof(TileLds) * TW >= TW * kRedFloats * sizeof(float), "LDS plan");
@@ -178,6 +177,11 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
     const float4 qq = r[8 + slot];
     const float4 w01 = r[16 + slot * 4], w23 = r[16 + slot * 4 + 1], w45 = r[16 + slot * 4 + 2];
     const float4 wf = r[16 + slot * 4 + 3];              // (fx, fy | fz, -): blended offset, decoder inputs 8..10
+    const int* __restrict__ tn = tnum + (size_t)tile * kTileNumWords;  // the tile's number block (behind the task records)
+    const int4 rid4 = lane < kMaxRows / 4 ? *reinterpret_cast<const int4*>(tn + 4 * lane) : make_int4(0, 0, 0, 0);
+    const int n_rows = tn[kTileNumCount];
+    const unsigned char* __restrict__ rbytes = reinterpret_cast<const unsigned char*>(tn + kTileNumBytes);
+    const unsigned char rnum[2] = {rbytes[q * CLID_K + g], g < 2 ? rbytes[q * CLID_K + g + 4] : (unsigned char)255};
     const int sidx = tlive ? __float_as_int(qi.w) : -1;  // time stamp of the sample, -1 = padding slot
     const bool bundle = tlive && task < tmap.n_fd;
     // IDW weights and neighbour ids come from the search record (np.py:688-706)
@@ -201,20 +205,16 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
       if (g < 2) v[k] = feat4[(size_t)jc * 2 + g];
       else if (g == 3 && mv.ts_update && j[k] >= 0) ts_old[k] = mv.ts_update[jc];
     }
-    // ================= ... and in their shadow the tile's (query, neighbour) pairs are numbered per distinct map row
-    // through the LDS hash (ids and weights come from the record, not from the gather), and Wm[row][query] is filled
-    tl.hkey[lane] = -1;
-    tl.hkey[lane + 64] = -1;
-    if (lane == 0) tl.count = 0;
+    // ================= ... and in their shadow Wm[row][query] is filled from the tile's number block (k_search_tiles, train.hip: the
+    // pairs numbered per distinct map row, resolved once per chunk next to the searches -- ids and weights never depend on
+    // the training state)
 #pragma unroll
     for (int i = 0; i < kMaxRows * 16 / (64 * 4); ++i)
       *reinterpret_cast<float4*>(&tl.wm[(i * 64 + lane) * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < kMaxRows / 4) *reinterpret_cast<int4*>(&tl.rowid[4 * lane]) = rid4;
     tile_lds_fence();
-    // lane (q, g) numbers neighbours k = g and (g < 2) k = g + 4 of its query.  A query's own list may name a row twice
+    // lane (q, g) places neighbours k = g and (g < 2) k = g + 4 of its query.  A query's own list may name a row twice
     // (two colliding cells returning the same point): the first occurrence carries the sum of the weights
-    int hs[2] = {-1, -1};
-    float wsum[2] = {0.f, 0.f};
-    bool first[2] = {false, false};
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int k = g + 4 * t;
@@ -229,30 +229,8 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
         if (same && kk < k) fst = false;
         if (same) tot += w[kk];
       }
-      if (k < CLID_K && jk >= 0) {
-        unsigned h = ((unsigned)jk * 2654435761u) >> 25;  // 7 bits
-        for (;;) {
-          const int old = atomicCAS(&tl.hkey[h], -1, jk);
-          if (old == -1) {  // first pair of this row in the tile: take the next row number
-            const int d = atomicAdd(&tl.count, 1);
-            tl.hrow[h] = d;
-            tl.rowid[d] = jk;
-            break;
-          }
-          if (old == jk) break;
-          h = (h + 1) & (kHash - 1);
-        }
-        hs[t] = (int)h;
-        first[t] = fst;
-        wsum[t] = tot;
-      }
-    }
-    tile_lds_fence();
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int k = g + 4 * t;
-      const int row = hs[t] >= 0 ? tl.hrow[hs[t]] : -1;
-      if (first[t]) tl.wm[row * 16 + q] = wsum[t];
+      const int row = (k < CLID_K && jk >= 0) ? (int)rnum[t] : -1;
+      if (row >= 0 && fst) tl.wm[row * 16 + q] = tot;
       if (LN && k < CLID_K) ln.rown[q * 8 + k] = row;
     }
     tile_lds_fence();
@@ -401,7 +379,6 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
     {
       const bool do_cert = !(ta.debug_flags & 1), do_grad = !(ta.debug_flags & 2);
       const bool act = q < CLID_F ? do_grad : (q == CLID_F && do_cert);
-      const int n_rows = tl.count;
       // B[k = G][j = c] of K-step rr = d f[c] of query 4G + rr (the registers as they are); column 8 = 1
       float Bx[4];
 #pragma unroll
@@ -534,14 +511,15 @@ int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, f
   const int n_tiles = (tmap.n_tasks + 1) / 2;
   const int nb = clid_decode_tile_blocks(tmap.n_tasks);
   const float4* r4 = reinterpret_cast<const float4*>(rec);
+  const int* tn = reinterpret_cast<const int*>(rec + (size_t)tmap.n_tasks * kRecFloatsPerTask);  // (rec_floats_per_iter layout)
 #define CLID_TILE_LAUNCH(P, L)                                                                                        \
   do {                                                                                                                \
     if (tile_waves_for(n_tiles) == kTileWavesSmall)                                                                   \
       CLID_KLAUNCH(a->prof, 0, (k_decode_tile<P, L, kTileWavesSmall>), dim3(nb), dim3(kTileWavesSmall * 64), 0, s, *mv, *a,       \
-                   partial, tmap, r4, n_tiles, a->sdf_dbg);                                                            \
+                   partial, tmap, r4, tn, n_tiles, a->sdf_dbg);                                                            \
     else                                                                                                              \
       CLID_KLAUNCH(a->prof, 0, (k_decode_tile<P, L, kTileWavesLarge>), dim3(nb), dim3(kTileWavesLarge * 64), 0, s, *mv, *a,       \
-                   partial, tmap, r4, n_tiles, a->sdf_dbg);                                                            \
+                   partial, tmap, r4, tn, n_tiles, a->sdf_dbg);                                                            \
   } while (0)
   if (prec == 1) {
     if (mv->layer_norm) CLID_TILE_LAUNCH(1, true);

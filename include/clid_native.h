@@ -289,6 +289,11 @@ int clid_mapping_run(const clid_map_view* mv, const clid_train_args* t, const cl
  * clid_train_decode is clid_train_fwd_bwd for one iteration starting from its records. */
 int64_t clid_train_search_floats(int32_t bs, int64_t batch_offset, int32_t decimation, int32_t eikonal_mode,
                                  int32_t n_iter);
+/* wave tasks (records of 192 floats: 8 query slots each) of one iteration.  An iteration's block in rec_out is
+ * [tasks x 192 floats of records | ceil(tasks / 2) x 128 words of tile number blocks]: the second part holds, per tile of
+ * the matrix-core decode kernels (two consecutive tasks), the tile's (query, neighbour) pairs numbered per distinct map row
+ * -- resolved by clid_train_search because it depends on the records only, not on the training state. */
+int32_t clid_train_search_tasks(int32_t bs, int64_t batch_offset, int32_t decimation, int32_t eikonal_mode);
 int clid_train_search(const clid_map_view* mv, const clid_train_args* t, int32_t n_iter,
                       const int64_t* index_base, int64_t index_stride, float* rec_out, void* stream);
 int clid_train_decode(const clid_map_view* mv, const clid_train_args* t, const float* rec, void* stream);

@@ -76,3 +76,10 @@ def mapper(cfg, nm, dec, new_idx=None):
     mp = Mapper(cfg, DatasetStub(), nm, None, dec)
     mp.set_pool(gio.T(p["coord"]), gio.T(p["sdf_label"]), gio.T(p["weight"]), gio.T(p["time"]), new_idx)
     return mp, p
+
+
+def task_records(rec, n_it, n_tasks):
+    """[n_it, n_tasks, 48, 4] view of the task records clid_train_search wrote (an iteration's block = its n_tasks x 192
+    floats of records followed by its tile number blocks, include/clid_native.h clid_train_search_tasks)."""
+    per = rec.numel() // n_it
+    return rec.view(n_it, per)[:, : n_tasks * 192].reshape(n_it, n_tasks, 48, 4)

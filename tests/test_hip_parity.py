@@ -267,14 +267,15 @@ def _fused_grads(env, cfg, p, g, index, batch_offset=0, n_main=None, n_eik=None,
                                          _lib.stream()), "clid_train_search")
         ta.decode_variant, ta.pipeline = variant, 1
         sdf = None
+        n_tasks = int(lib.clid_train_search_tasks(bs, batch_offset, decim, 1))
         if sdf_out is not None and tile:
-            sdf = torch.zeros(rec.numel() // 192 * 8, device="cuda")
+            sdf = torch.zeros(n_tasks * 8, device="cuda")
             ta.sdf_dbg = sdf.data_ptr()
         assert lib.clid_train_decode_kernel(C.byref(view), C.byref(ta)) == variant
         _lib.check(lib.clid_train_decode(C.byref(view), C.byref(ta), rec.data_ptr(), _lib.stream()), "clid_train_decode")
         torch.cuda.synchronize()
         if sdf is not None:
-            sdf_out.append((rec.view(-1, 48, 4).cpu(), sdf.view(-1, 8).cpu()))
+            sdf_out.append((env.task_records(rec, 1, n_tasks)[0].cpu(), sdf.view(-1, 8).cpu()))
     else:
         _lib.check(lib.clid_train_fwd_bwd(C.byref(view), C.byref(ta), _lib.stream()), "clid_train_fwd_bwd")
     torch.cuda.synchronize()
@@ -668,7 +669,8 @@ def test_search_records_short_lists_equal_full_depth():
         _lib.check(lib.clid_train_search(C.byref(view), C.byref(ta), iters, idx.data_ptr(), bs, rec.data_ptr(),
                                          _lib.stream()), "clid_train_search")
         torch.cuda.synchronize()
-        recs.append(rec.view(-1, 48, 4).cpu())
+        import shim_io
+        recs.append(shim_io.task_records(rec, iters, int(lib.clid_train_search_tasks(bs, 0, decim, 1))).reshape(-1, 48, 4).cpu())
     a, b = recs
     assert torch.equal(a[:, :16].contiguous().view(torch.int32), b[:, :16].contiguous().view(torch.int32))  # positions, descriptors, labels (bit patterns)
     wa, wb = a[:, 16:].reshape(-1, 8, 8, 2)[:, :, :6], b[:, 16:].reshape(-1, 8, 8, 2)[:, :, :6]

@@ -84,6 +84,32 @@ def test_touched_row_sweep_equals_the_dense_sweep(env, iters, bs, ln, frozen):
     assert 0 < int(moved.sum()) < moved.numel()
 
 
+def _check_tile_number_blocks(rec, n_it, n_tasks, ids, live):
+    """The number blocks behind every iteration's records (k_tile_number): per tile (two consecutive tasks) the pairs
+    (query, neighbour) numbered per distinct map row -- rowid[number of pair (q, k)] == id of the pair, the numbers are a
+    bijection onto the tile's distinct ids, 255 marks pairs without a neighbour (or of a padding slot)."""
+    n_tiles = (n_tasks + 1) // 2
+    per = rec.numel() // n_it
+    blocks = rec.view(n_it, per)[:, n_tasks * 192:].contiguous().view(torch.int32).cpu().numpy().reshape(n_it, n_tiles, 128)
+    for it in range(n_it):
+        for tile in range(0, n_tiles, 7):
+            b = blocks[it, tile]
+            count = int(b[96])
+            rows = b[:count]
+            nums = b[100:124].view(np.uint8).reshape(16, 6)
+            want_ids = set()
+            for q in range(16):
+                task = 2 * tile + q // 8
+                for k in range(6):
+                    j = int(ids[it, task, q % 8, k]) if task < n_tasks and live[it, task, q % 8] else -1
+                    if j < 0:
+                        assert nums[q, k] == 255, (it, tile, q, k)
+                    else:
+                        assert nums[q, k] < count and rows[nums[q, k]] == j, (it, tile, q, k)
+                        want_ids.add(j)
+            assert len(set(rows.tolist())) == count == len(want_ids) and set(rows.tolist()) == want_ids
+
+
 def test_flag_sets_equal_the_neighbour_ids_of_the_records(env):
     """clid_train_search + clid_train_touch_scan against a host restatement: bit i of iteration t = some live query of
     iteration t has neighbour i; counts = popcounts; prefix = exclusive scan; the running union carries over chunks."""
@@ -122,7 +148,7 @@ def test_flag_sets_equal_the_neighbour_ids_of_the_records(env):
                    "clid_train_search")
         torch.cuda.synchronize()
         flags = ws[: n_it * stride].view(n_it, stride).cpu().numpy().copy()
-        r = rec.view(n_it, -1, 48, 4).cpu()
+        r = env.task_records(rec, n_it, int(lib.clid_train_search_tasks(bs, 0, 10, 1))).cpu()
         live = r[:, :, 0:8, 3].contiguous().view(torch.int32) >= 0                        # [it, task, slot]
         ids = r[:, :, 16:48, :].reshape(n_it, -1, 8, 8, 2)[..., :6, 1].contiguous().view(torch.int32)  # [it, task, slot, k]
         want = np.zeros((n_it, stride), bool)
@@ -130,6 +156,8 @@ def test_flag_sets_equal_the_neighbour_ids_of_the_records(env):
             j = ids[it][live[it]].reshape(-1).numpy()
             want[it, j[j >= 0]] = True
         assert np.array_equal(flags.astype(bool), want)
+        if it0 == 0:
+            _check_tile_number_blocks(rec, n_it, int(lib.clid_train_search_tasks(bs, 0, 10, 1)), ids.numpy(), live.numpy())
         counts = (C.c_int32 * 32)()
         _lib.check(lib.clid_train_touch_scan(C.byref(ta), M, n_it, it0, counts, _lib.stream()), "clid_train_touch_scan")
         assert not ws[: chunk * stride].any()  # cleared for the next chunk
