@@ -688,7 +688,52 @@ k_search_tiles(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
       if (lane < kRecFloat4) out[(size_t)task * kRecFloat4 + lane] = reinterpret_cast<const float4*>(&heads[wave][half])[lane];
     }
     number_tile(heads[wave][0], heads[wave][1], nums[wave],
-                reinterpret_cast<int*>(out + (size_t)tmap.n_tasks * kRecFloat4) + (size_t)tile * kTileNumWords, 2 * tile + 1 < tmap.n_tasks);
+                reinterpret_cast<int*>(out + (size_t)tmap.n_tasks * kRecFloat4) + (size_t)tile * kTileNumWords,
+                2 * tile + 1 < tmap.n_tasks);
+  }
+}
+
+// The same search per TASK, without numbering: iterations of more than kTileLargeFrom tiles (65 536 samples and up), whose
+// decode launch numbers its tiles in place.  (Pairing the tasks costs the search 5-8 % by itself, the numbering another
+// 13 %: 105 -> 113 -> 126 us per iteration at 262 144 samples.)
+template <bool XMAP>
+__global__ void __launch_bounds__(kFusedBlock, CLID_SEARCH_WAVES)
+k_search_tasks(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __restrict__ rec, int n_iter, long long index_stride,
+               int use_filter) {
+  __shared__ DeltaLds dl;
+  __shared__ WaveHead heads[kFusedBlock / 64];
+  extern __shared__ unsigned filt_lds[];
+  stage_delta(dl, mv);
+  if (use_filter == 1)
+    for (int i = threadIdx.x; i < (1 << mv.log2filter) / 32; i += kFusedBlock) filt_lds[i] = mv.filter[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves_per_block = kFusedBlock / 64;
+  const size_t iter_f4 = rec_floats_per_iter(tmap.n_tasks) / 4;
+  // XCD x takes the x-th eighth of the bundle tasks and of the plain tasks of every iteration (see k_search_tiles)
+  const int xcd = blockIdx.x & 7, xb = blockIdx.x >> 3, xnb = ((int)gridDim.x + 7 - xcd) >> 3;
+  const int n_rest = tmap.n_tasks - tmap.n_fd;
+  const int xb0 = (int)((long long)tmap.n_fd * xcd / 8), xb1 = (int)((long long)tmap.n_fd * (xcd + 1) / 8);
+  const int xr0 = (int)((long long)n_rest * xcd / 8), xr1 = (int)((long long)n_rest * (xcd + 1) / 8);
+  const int xlen = (xb1 - xb0) + (xr1 - xr0);
+  constexpr bool xmap = XMAP;
+  const int w_first = xmap ? xb * waves_per_block + wave : blockIdx.x * waves_per_block + wave;
+  const int w_step = xmap ? xnb * waves_per_block : gridDim.x * waves_per_block;
+  const int w_total = xmap ? xlen * n_iter : tmap.n_tasks * n_iter;
+  for (int w = w_first; w < w_total; w += w_step) {
+    int it, task;
+    if (xmap) {
+      it = w / xlen;
+      const int u = w - it * xlen;
+      task = u < xb1 - xb0 ? xb0 + u : tmap.n_fd + xr0 + (u - (xb1 - xb0));
+    } else {
+      it = w / tmap.n_tasks;
+      task = w - it * tmap.n_tasks;
+    }
+    const long long* index = reinterpret_cast<const long long*>(ta.index) + (long long)it * index_stride;
+    search_task(mv, ta, tmap, dl, index, task, it, use_filter, filt_lds, heads[wave]);
+    if (lane < kRecFloat4)
+      rec[(size_t)it * iter_f4 + (size_t)task * kRecFloat4 + lane] = reinterpret_cast<const float4*>(&heads[wave])[lane];
+    wave_lds_fence();
   }
 }
 
@@ -1437,8 +1482,6 @@ extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args*
   }
   clid_train_args t2 = *a;
   t2.index = index_base;
-  long long sb = ((long long)((tmap.n_tasks + 1) / 2) * n_iter + kFusedBlock / 64 - 1) / (kFusedBlock / 64);  // a wave per tile
-  if (sb > search_blocks()) sb = search_blocks();
   // probe prefilter (a one-hash Bloom filter over the stored slots; 59 of the 81 probes of a typical query hit nothing):
   // staged in LDS when it fits (<= 32 KB) and the launch is large enough to amortise staging it per block; for large
   // local maps (> 2^17 points: the filter is up to 2 MB, the key table 8+ MB) it is read from global memory, where it
@@ -1449,12 +1492,21 @@ extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args*
     else use_filter = 2;
   }
   const size_t dyn = use_filter == 1 ? ((size_t)1 << mv->log2filter) / 8 : 0;
-  if (CLID_XCD_MAP && use_filter == 2 && sb >= 8)
-    CLID_KLAUNCH(a->prof, 1, k_search_tiles<true>, dim3((unsigned)sb), dim3(kFusedBlock), dyn, s, *mv, t2, tmap,
-                 reinterpret_cast<float4*>(rec_out), n_iter, (long long)index_stride, use_filter);
-  else
-    CLID_KLAUNCH(a->prof, 1, k_search_tiles<false>, dim3((unsigned)sb), dim3(kFusedBlock), dyn, s, *mv, t2, tmap,
-                 reinterpret_cast<float4*>(rec_out), n_iter, (long long)index_stride, use_filter);
+  // iterations of at most kTileLargeFrom tiles: tasks in pairs, the tile's pairs numbered for the decode launch (one tile
+  // per wave there); larger ones: per task, the decode kernel numbers in place (train_common.hpp tiles_prenumbered)
+  const bool num = clid_tiles_prenumbered(tmap.n_tasks);
+  long long sb = num ? ((long long)((tmap.n_tasks + 1) / 2) * n_iter + kFusedBlock / 64 - 1) / (kFusedBlock / 64)
+                     : ((long long)tmap.n_tasks * n_iter + kFusedBlock / 64 - 1) / (kFusedBlock / 64);
+  if (sb > search_blocks()) sb = search_blocks();
+  const bool xm = CLID_XCD_MAP && use_filter == 2 && sb >= 8;
+#define CLID_SEARCH_LAUNCH(K)                                                                                    \
+  CLID_KLAUNCH(a->prof, 1, K, dim3((unsigned)sb), dim3(kFusedBlock), dyn, s, *mv, t2, tmap,                     \
+               reinterpret_cast<float4*>(rec_out), n_iter, (long long)index_stride, use_filter)
+  if (num && xm) CLID_SEARCH_LAUNCH(k_search_tiles<true>);
+  else if (num) CLID_SEARCH_LAUNCH(k_search_tiles<false>);
+  else if (xm) CLID_SEARCH_LAUNCH(k_search_tasks<true>);
+  else CLID_SEARCH_LAUNCH(k_search_tasks<false>);
+#undef CLID_SEARCH_LAUNCH
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

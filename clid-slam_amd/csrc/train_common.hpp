@@ -18,9 +18,15 @@ constexpr int kRecFloatsPerTask = 192;  // qinfo[8] | qdesc[8] | win[8][8]: what
 // so it is resolved once next to the searches instead of in every decode launch's dependent chain (k_search_tiles):
 //   [0, 96)   map row id of the tile's row number r (r < count)        [96] count
 //   [100, 124) 96 bytes: row number of pair (query q, neighbour k) at byte 6 q + k, 255 = no neighbour
+// Only iterations of at most kTileLargeFrom tiles carry number blocks: their decode launch runs one tile per wave and is
+// one tile's dependent chain long, so taking the numbering out of it pays (14.5 -> 12.5 us at 16 384 samples); larger
+// launches number in place (the SIMD's other waves hide it; numbering in the search launch cost 65 536 / 262 144-sample
+// iterations +6 / +24 us there for -1 / -8 us in the decode).
 constexpr int kTileNumWords = 128, kTileNumCount = 96, kTileNumBytes = 100;
+constexpr int kTileLargeFrom = 2048;  // tiles
+__host__ __device__ inline bool tiles_prenumbered(int n_tasks) { return (n_tasks + 1) / 2 <= kTileLargeFrom; }
 __host__ __device__ inline size_t rec_floats_per_iter(int n_tasks) {
-  return (size_t)n_tasks * kRecFloatsPerTask + (size_t)((n_tasks + 1) / 2) * kTileNumWords;
+  return (size_t)n_tasks * kRecFloatsPerTask + (tiles_prenumbered(n_tasks) ? (size_t)((n_tasks + 1) / 2) * kTileNumWords : 0);
 }
 
 struct TrainWs {
@@ -288,6 +294,7 @@ __host__ inline size_t touch_bytes(long long stride, int chunk) {
 int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, float* partial, const clid::TaskMap& tmap,
                             const float* rec, int prec, hipStream_t s);
 int clid_decode_tile_blocks(int n_tasks);
+bool clid_tiles_prenumbered(int n_tasks);  // launches of one tile per wave read the search launch's number blocks
 // host-side launchers of the analytic-eikonal iteration (train_analytic.hip)
 int clid_launch_train_analytic(const clid_map_view* mv, const clid_train_args* a, float* partial, hipStream_t s);
 int clid_train_analytic_blocks(int bs);

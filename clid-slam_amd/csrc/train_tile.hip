@@ -42,7 +42,6 @@ namespace clid {
 #define CLID_TILE_WAVES_SMALL 4
 #endif
 constexpr int kTileWavesSmall = CLID_TILE_WAVES_SMALL, kTileWavesLarge = 2;
-constexpr int kTileLargeFrom = 2048;  // tiles
 __host__ inline int tile_waves_for(int n_tiles) { return n_tiles > kTileLargeFrom ? kTileWavesLarge : kTileWavesSmall; }
 constexpr int kRecF4 = 48;       // float4 per search record (== kRecFloat4 of train.hip)
 constexpr int kDhStride = 84;    // floats per query row of the dh transposition buffer (conflict-free b128 stores)
@@ -53,12 +52,17 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int kHash = 128;      // LDS hash slots for the <= 96 distinct map rows of a tile
 constexpr int kMaxRows = 96;
 struct alignas(16) TileLds {
   float dh[16 * kDhStride];  // [q][h]
   float f[16 * kFStride];    // [q][c], c = 0..15 (11 = the bias input 1, 12..15 = 0)
   float wm[kMaxRows * 16];   // [row][q]: weight of query q on the tile's distinct map row `row`
-  int rowid[kMaxRows];       // row number -> map row id (from the tile's number block)
+  int hkey[kHash];           // (in-kernel numbering only) hash slot -> map row id, -1 empty
+  int hrow[kHash];           // (in-kernel numbering only) hash slot -> row number inside the tile
+  int rowid[kMaxRows];       // row number -> map row id
+  int count;                 // (in-kernel numbering only) distinct rows of the tile
+  int pad_[3];
 };
 
 // layer-norm variants: what F.layer_norm's backward needs of every distinct row, saved by the forward pass
@@ -94,6 +98,7 @@ __device__ __forceinline__ void tile_lds_fence() {
 #ifndef CLID_TILE_WAVES
 #define CLID_TILE_WAVES (LN ? 2 : 1)  // layer norm: pin 2 waves per SIMD (VGPRs + AGPRs <= 256; it lands on 1 otherwise)
 #endif
+constexpr bool tiles_prenumbered_tw(int tw) { return tw == kTileWavesSmall; }
 template <int PREC, bool LN, int TW>
 __global__ void __launch_bounds__(TW * 64, CLID_TILE_WAVES)
 k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap,
@@ -103,6 +108,7 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
   static_assert(sizeof(TileLds) % 16 == 0 && sizeof(TileLds) * TW >= TW * kRedFloats * sizeof(float), "LDS plan");
   float* red = reinterpret_cast<float*>(tls);  // the block flush reuses the tile buffers (after a barrier)
   const int lane = threadIdx.x & 63, q = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+  constexpr bool PRE = tiles_prenumbered_tw(TW);
   TileLds& tl = tls[wave];
   TileLnLds& ln = lns[LN ? wave : 0];
   const bool train = ta.train_decoder != 0;
@@ -177,13 +183,21 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
     const float4 qq = r[8 + slot];
     const float4 w01 = r[16 + slot * 4], w23 = r[16 + slot * 4 + 1], w45 = r[16 + slot * 4 + 2];
     const float4 wf = r[16 + slot * 4 + 3];              // (fx, fy | fz, -): blended offset, decoder inputs 8..10
-    const int* __restrict__ tn = tnum + (size_t)tile * kTileNumWords;  // the tile's number block (behind the task records)
-    const int4 rid4 = lane < kMaxRows / 4 ? *reinterpret_cast<const int4*>(tn + 4 * lane) : make_int4(0, 0, 0, 0);
-    const int n_rows = tn[kTileNumCount];
-    const unsigned char* __restrict__ rbytes = reinterpret_cast<const unsigned char*>(tn + kTileNumBytes);
-    const unsigned char rnum[2] = {rbytes[q * CLID_K + g], g < 2 ? rbytes[q * CLID_K + g + 4] : (unsigned char)255};
     const int sidx = tlive ? __float_as_int(qi.w) : -1;  // time stamp of the sample, -1 = padding slot
     const bool bundle = tlive && task < tmap.n_fd;
+    // PRE (launches of one tile per wave): the tile's pairs were numbered per distinct map row by the search launch
+    // (k_search_tiles, train.hip) -- the number block sits behind the iteration's task records
+    int4 rid4 = make_int4(0, 0, 0, 0);
+    int n_rows = 0;
+    int rnum[2] = {255, 255};
+    if constexpr (PRE) {
+      const int* __restrict__ tn = tnum + (size_t)tile * kTileNumWords;
+      if (lane < kMaxRows / 4) rid4 = *reinterpret_cast<const int4*>(tn + 4 * lane);
+      n_rows = tn[kTileNumCount];
+      const unsigned char* __restrict__ rbytes = reinterpret_cast<const unsigned char*>(tn + kTileNumBytes);
+      rnum[0] = rbytes[q * CLID_K + g];
+      if (g < 2) rnum[1] = rbytes[q * CLID_K + g + 4];
+    }
     // IDW weights and neighbour ids come from the search record (np.py:688-706)
     float w[CLID_K] = {w01.x, w01.z, w23.x, w23.z, w45.x, w45.z};
     int j[CLID_K] = {__float_as_int(w01.y), __float_as_int(w01.w), __float_as_int(w23.y),
@@ -205,35 +219,92 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
       if (g < 2) v[k] = feat4[(size_t)jc * 2 + g];
       else if (g == 3 && mv.ts_update && j[k] >= 0) ts_old[k] = mv.ts_update[jc];
     }
-    // ================= ... and in their shadow Wm[row][query] is filled from the tile's number block (k_search_tiles, train.hip: the
-    // pairs numbered per distinct map row, resolved once per chunk next to the searches -- ids and weights never depend on
-    // the training state)
+    // ================= ... and in their shadow Wm[row][query] is filled.  The pairs' row numbers depend on the records only,
+    // never on the training state: small launches (one tile per wave: the launch is one tile's dependent chain long) read
+    // them from the number block the search launch wrote; large launches number in place through the LDS hash -- there the
+    // other waves of the SIMD hide it, while numbering every tile in the search costs that launch more than this one gains
+    // (65 536 samples: search +6 us, decode -1 us per iteration).
+    if constexpr (PRE) {
 #pragma unroll
-    for (int i = 0; i < kMaxRows * 16 / (64 * 4); ++i)
-      *reinterpret_cast<float4*>(&tl.wm[(i * 64 + lane) * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < kMaxRows / 4) *reinterpret_cast<int4*>(&tl.rowid[4 * lane]) = rid4;
-    tile_lds_fence();
-    // lane (q, g) places neighbours k = g and (g < 2) k = g + 4 of its query.  A query's own list may name a row twice
-    // (two colliding cells returning the same point): the first occurrence carries the sum of the weights
+      for (int i = 0; i < kMaxRows * 16 / (64 * 4); ++i)
+        *reinterpret_cast<float4*>(&tl.wm[(i * 64 + lane) * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane < kMaxRows / 4) *reinterpret_cast<int4*>(&tl.rowid[4 * lane]) = rid4;
+      tile_lds_fence();
+      // lane (q, g) places neighbours k = g and (g < 2) k = g + 4 of its query.  A query's own list may name a row twice
+      // (two colliding cells returning the same point): the first occurrence carries the sum of the weights
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int k = g + 4 * t;
-      int jk = -1;
+      for (int t = 0; t < 2; ++t) {
+        const int k = g + 4 * t;
+        int jk = -1;
 #pragma unroll
-      for (int kk = 0; kk < CLID_K; ++kk) jk = (kk == k) ? j[kk] : jk;
-      bool fst = true;
-      float tot = 0.f;
+        for (int kk = 0; kk < CLID_K; ++kk) jk = (kk == k) ? j[kk] : jk;
+        bool fst = true;
+        float tot = 0.f;
 #pragma unroll
-      for (int kk = 0; kk < CLID_K; ++kk) {  // ascending, so the sum has the order of a sequential fold
-        const bool same = j[kk] == jk;
-        if (same && kk < k) fst = false;
-        if (same) tot += w[kk];
+        for (int kk = 0; kk < CLID_K; ++kk) {  // ascending, so the sum has the order of a sequential fold
+          const bool same = j[kk] == jk;
+          if (same && kk < k) fst = false;
+          if (same) tot += w[kk];
+        }
+        const int row = (k < CLID_K && jk >= 0) ? rnum[t] : -1;
+        if (row >= 0 && fst) tl.wm[row * 16 + q] = tot;
+        if (LN && k < CLID_K) ln.rown[q * 8 + k] = row;
       }
-      const int row = (k < CLID_K && jk >= 0) ? (int)rnum[t] : -1;
-      if (row >= 0 && fst) tl.wm[row * 16 + q] = tot;
-      if (LN && k < CLID_K) ln.rown[q * 8 + k] = row;
+      tile_lds_fence();
+    } else {
+      tl.hkey[lane] = -1;
+      tl.hkey[lane + 64] = -1;
+      if (lane == 0) tl.count = 0;
+#pragma unroll
+      for (int i = 0; i < kMaxRows * 16 / (64 * 4); ++i)
+        *reinterpret_cast<float4*>(&tl.wm[(i * 64 + lane) * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+      tile_lds_fence();
+      // lane (q, g) numbers neighbours k = g and (g < 2) k = g + 4 of its query through the LDS hash (integer ds_cmpst)
+      int hs[2] = {-1, -1};
+      float wsum[2] = {0.f, 0.f};
+      bool first[2] = {false, false};
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int k = g + 4 * t;
+        int jk = -1;
+#pragma unroll
+        for (int kk = 0; kk < CLID_K; ++kk) jk = (kk == k) ? j[kk] : jk;
+        bool fst = true;
+        float tot = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < CLID_K; ++kk) {  // ascending, so the sum has the order of a sequential fold
+          const bool same = j[kk] == jk;
+          if (same && kk < k) fst = false;
+          if (same) tot += w[kk];
+        }
+        if (k < CLID_K && jk >= 0) {
+          unsigned h = ((unsigned)jk * 2654435761u) >> 25;  // 7 bits
+          for (;;) {
+            const int old = atomicCAS(&tl.hkey[h], -1, jk);
+            if (old == -1) {  // first pair of this row in the tile: take the next row number
+              const int d = atomicAdd(&tl.count, 1);
+              tl.hrow[h] = d;
+              tl.rowid[d] = jk;
+              break;
+            }
+            if (old == jk) break;
+            h = (h + 1) & (kHash - 1);
+          }
+          hs[t] = (int)h;
+          first[t] = fst;
+          wsum[t] = tot;
+        }
+      }
+      tile_lds_fence();
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int k = g + 4 * t;
+        const int row = hs[t] >= 0 ? tl.hrow[hs[t]] : -1;
+        if (first[t]) tl.wm[row * 16 + q] = wsum[t];
+        if (LN && k < CLID_K) ln.rown[q * 8 + k] = row;
+      }
+      tile_lds_fence();
     }
-    tile_lds_fence();
     CLID_STAMP(8);
     if (LN) {  // F.layer_norm over the 8 features of every neighbour row (np.py:632-633); lanes g = 0,1 hold the halves
 #pragma unroll
@@ -379,6 +450,7 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
     {
       const bool do_cert = !(ta.debug_flags & 1), do_grad = !(ta.debug_flags & 2);
       const bool act = q < CLID_F ? do_grad : (q == CLID_F && do_cert);
+      if constexpr (!PRE) n_rows = tl.count;
       // B[k = G][j = c] of K-step rr = d f[c] of query 4G + rr (the registers as they are); column 8 = 1
       float Bx[4];
 #pragma unroll
@@ -491,6 +563,12 @@ extern "C" int clid_debug_read_stamps_tile(long long* out_host) {
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(clid::clid_stamps), sizeof(long long) * 256 * 32) == hipSuccess ? 0 : -3;
 }
 #endif
+// do the tiles of a launch over n_tasks tasks read their row numbers from the search launch's number blocks?
+bool clid_tiles_prenumbered(int n_tasks) {
+  static_assert(kTileWavesSmall != kTileWavesLarge, "the waves-per-block choice doubles as the numbering choice");
+  return tiles_prenumbered(n_tasks);
+}
+
 int clid_decode_tile_blocks(int n_tasks) {
   const int tiles = (n_tasks + 1) / 2;
   const int tw = tile_waves_for(tiles);
