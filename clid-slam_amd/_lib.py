@@ -36,6 +36,7 @@ class MapView(C.Structure):
         ("filter", _vp),
         ("log2cap", _i32), ("M", _i32), ("P", _i32), ("buffer_size", _i32),
         ("resolution", _f32), ("max_valid_dist2", _f32), ("layer_norm", _i32), ("log2filter", _i32),
+        ("weighted_first", _i32), ("reserved0", _i32),
     ]
 
 
@@ -99,7 +100,7 @@ _SIGS = {
     "clid_sdf_grad_x": (C.c_int, [C.POINTER(MapView), _vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "clid_sdf_query": (C.c_int, [C.POINTER(MapView), _vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _vp, _vp]),
     "clid_track_model": (C.c_int, [C.POINTER(MapView), _vp, _vp, _vp, _vp, _f32, C.POINTER(_f32), C.POINTER(_f32), _i32,
-                         _f32, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+                         _f32, _f32, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clid_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _f32, _i32, _vp, _i32, _f32, _vp, _vp, _vp, _vp]),
     "clid_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _i32, _vp]),
     "clid_train_workspace_floats": (_i64, [_i32, _i32, _i32]),

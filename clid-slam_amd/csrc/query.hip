@@ -310,6 +310,74 @@ __device__ __forceinline__ PointEval eval_point(const clid_map_view& mv, const M
   return r;
 }
 
+// weighted_first = False (utils/mapper.py:107-112, utils/error_state_iekf.py:217-225, utils/mesher.py:130-138): every
+// neighbour's own decoder input [feat_k | x - p_k] is decoded, the K SDFs are blended with the IDW weights:
+//   sdf = sum_k w_k sdf_k,  std = sqrt(sum_k w_k (sdf_k - sdf)^2)
+//   d sdf / d x = sum_k [ w_k d sdf_k / d x + sdf_k d w_k / d x ],  d sdf_k / d x = u_k[F:F+3] (the input's last 3 columns are
+//   x - p_k), u_k = scale (W2 .* act_k) W1,  d w_k / d x = w_k (abar - alpha_k) with alpha_k = 2 r_k omega_k.
+// Six decoder evaluations per point instead of one; no shipped config uses it.
+__device__ __forceinline__ PointEval eval_point_nf(const clid_map_view& mv, const MlpLds& mlp, const DeltaLds& dl,
+                                                   float scale, float px, float py, float pz, int lane16, int gbase,
+                                                   float* sdf_std) {
+  TopK t;
+  search_topk(mv, dl, px, py, pz, lane16, gbase, t);
+  float w[CLID_K], omega[CLID_K];
+  idw_weights(t, w, omega);
+  const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
+  float sk[CLID_K], ux[CLID_K], uy[CLID_K], uz[CLID_K], rx[CLID_K], ry[CLID_K], rz[CLID_K];
+  float cert = 0.f, abx = 0.f, aby = 0.f, abz = 0.f, mean = 0.f;
+#pragma unroll
+  for (int k = 0; k < CLID_K; ++k) {
+    sk[k] = ux[k] = uy[k] = uz[k] = rx[k] = ry[k] = rz[k] = 0.f;
+    if (t.j[k] >= 0) {  // (group-uniform: t is replicated across the 16 lanes)
+      float f[CLID_D];
+      {
+        float fe[CLID_F];
+        load_feat(mv.feat, t.j[k], fe);
+        if (mv.layer_norm) {
+          float rstd;
+          layer_norm8(fe, rstd);
+        }
+#pragma unroll
+        for (int c = 0; c < CLID_F; ++c) f[c] = fe[c];
+      }
+      const float4 p = pos4[t.j[k]];
+      rx[k] = fsub(px, p.x); ry[k] = fsub(py, p.y); rz[k] = fsub(pz, p.z);
+      f[CLID_F] = rx[k]; f[CLID_F + 1] = ry[k]; f[CLID_F + 2] = rz[k];
+      float pre[CLID_HPL];
+      sk[k] = mlp_forward(mlp, f, lane16, scale, pre);
+      float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+      for (int uu = 0; uu < CLID_HPL; ++uu) {
+        const int h = lane16 + CLID_G * uu;
+        const float a = pre[uu] > 0.f ? mlp.w[CLID_H * CLID_D + CLID_H + h] : 0.f;
+        p0 = fmaf(a, mlp.w[h * CLID_D + CLID_F], p0);
+        p1 = fmaf(a, mlp.w[h * CLID_D + CLID_F + 1], p1);
+        p2 = fmaf(a, mlp.w[h * CLID_D + CLID_F + 2], p2);
+      }
+      ux[k] = scale * group_sum(p0); uy[k] = scale * group_sum(p1); uz[k] = scale * group_sum(p2);
+      cert = fadd(cert, fmul(mv.cert[t.j[k]], w[k]));
+      abx += w[k] * 2.f * rx[k] * omega[k];
+      aby += w[k] * 2.f * ry[k] * omega[k];
+      abz += w[k] * 2.f * rz[k] * omega[k];
+      mean = fadd(mean, fmul(sk[k], w[k]));
+    }
+  }
+  float var = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+  for (int k = 0; k < CLID_K; ++k) {
+    const float d = sk[k] - mean;
+    var += w[k] * d * d;
+    gx += w[k] * (ux[k] + sk[k] * (abx - 2.f * rx[k] * omega[k]));
+    gy += w[k] * (uy[k] + sk[k] * (aby - 2.f * ry[k] * omega[k]));
+    gz += w[k] * (uz[k] + sk[k] * (abz - 2.f * rz[k] * omega[k]));
+  }
+  PointEval r;
+  r.sdf = mean; r.gx = gx; r.gy = gy; r.gz = gz; r.cert = cert; r.nn = t.nn;
+  if (sdf_std) *sdf_std = sqrtf(var);
+  return r;
+}
+
 __global__ void __launch_bounds__(CLID_BLOCK)
 k_sdf_grad_x(clid_map_view mv, const float* W1, const float* b1, const float* W2, const float* b2,
              float scale, const float* __restrict__ x, int N, float* __restrict__ sdf_out,
@@ -321,7 +389,8 @@ k_sdf_grad_x(clid_map_view mv, const float* W1, const float* b1, const float* W2
   const int q_raw = blockIdx.x * CLID_QPB + (threadIdx.x >> 4);
   const bool live = q_raw < N;
   const int q = live ? q_raw : (N - 1);
-  const PointEval r = eval_point(mv, mlp, dl, scale, x[q * 3 + 0], x[q * 3 + 1], x[q * 3 + 2], lane16, gbase);
+  const PointEval r = mv.weighted_first ? eval_point(mv, mlp, dl, scale, x[q * 3 + 0], x[q * 3 + 1], x[q * 3 + 2], lane16, gbase)
+                                        : eval_point_nf(mv, mlp, dl, scale, x[q * 3 + 0], x[q * 3 + 1], x[q * 3 + 2], lane16, gbase, nullptr);
   if (live && lane16 == 0) {
     sdf_out[q] = r.sdf;
     grad_out[q * 3 + 0] = r.gx; grad_out[q * 3 + 1] = r.gy; grad_out[q * 3 + 2] = r.gz;
@@ -349,6 +418,14 @@ k_sdf_query(clid_map_view mv, const float* W1, const float* b1, const float* W2,
     const bool live = q_raw < N;
     const int q = live ? q_raw : (N - 1);
     const float px = x[(size_t)q * 3 + 0], py = x[(size_t)q * 3 + 1], pz = x[(size_t)q * 3 + 2];
+    if (!mv.weighted_first) {  // decode every neighbour, blend the SDFs (utils/mesher.py:130-138)
+      const PointEval r = eval_point_nf(mv, mlp, dl, scale, px, py, pz, lane16, gbase, nullptr);
+      if (live && lane16 == 0) {
+        sdf_out[q] = r.nn >= 1 ? r.sdf : 0.f;
+        nn_out[q] = r.nn;
+      }
+      continue;
+    }
     TopK t;
     search_topk(mv, dl, px, py, pz, lane16, gbase, t);
     float w[CLID_K], omega[CLID_K];
@@ -406,6 +483,7 @@ struct TrackParams {
   float scale;
   float min_grad_norm, max_grad_norm;
   int min_nn;
+  float max_sdf_std;  // weighted_first = False only: surface_sample_range_m * max_sdf_std_ratio (error_state_iekf.py:236)
 };
 
 __global__ void __launch_bounds__(CLID_BLOCK)
@@ -424,9 +502,11 @@ k_track_model(clid_map_view mv, const float* W1, const float* b1, const float* W
   const float px = tp.R[0] * ix + tp.R[1] * iy + tp.R[2] * iz + tp.t[0];
   const float py = tp.R[3] * ix + tp.R[4] * iy + tp.R[5] * iz + tp.t[1];
   const float pz = tp.R[6] * ix + tp.R[7] * iy + tp.R[8] * iz + tp.t[2];
-  const PointEval r = eval_point(mv, mlp, dl, tp.scale, px, py, pz, lane16, gbase);
+  float sdf_std = 0.f;  // stays 0 for weighted_first configs (error_state_iekf.py:188)
+  const PointEval r = mv.weighted_first ? eval_point(mv, mlp, dl, tp.scale, px, py, pz, lane16, gbase)
+                                        : eval_point_nf(mv, mlp, dl, tp.scale, px, py, pz, lane16, gbase, &sdf_std);
   const float gn = sqrtf(r.gx * r.gx + r.gy * r.gy + r.gz * r.gz);
-  const bool valid = live && r.nn >= tp.min_nn && gn < tp.max_grad_norm && gn > tp.min_grad_norm;
+  const bool valid = live && r.nn >= tp.min_nn && gn < tp.max_grad_norm && gn > tp.min_grad_norm && sdf_std < tp.max_sdf_std;
   if (live && lane16 == 0) {
     if (sdf_out) sdf_out[q] = r.sdf;
     if (grad_out) { grad_out[q * 3 + 0] = r.gx; grad_out[q * 3 + 1] = r.gy; grad_out[q * 3 + 2] = r.gz; }
@@ -546,8 +626,8 @@ extern "C" int clid_sdf_grad_x(const clid_map_view* mv, const float* W1, const f
 
 extern "C" int clid_track_model(const clid_map_view* mv, const float* W1, const float* b1, const float* W2,
                                 const float* b2, float sdf_scale, const float* rot_host, const float* pos_host,
-                                int32_t min_nn, float min_grad_norm, float max_grad_norm, const float* pc_imu,
-                                int32_t N, float* sdf_out, float* grad_out, float* pmap_out, int32_t* valid_out,
+                                int32_t min_nn, float min_grad_norm, float max_grad_norm, float max_sdf_std,
+                                const float* pc_imu, int32_t N, float* sdf_out, float* grad_out, float* pmap_out, int32_t* valid_out,
                                 double* normal_eq, void* stream) {
   if (int e = check_view(mv, "clid_track_model")) return e;
   if (!rot_host || !pos_host || !pc_imu || N < 0) {
@@ -562,6 +642,7 @@ extern "C" int clid_track_model(const clid_map_view* mv, const float* W1, const 
   tp.min_grad_norm = min_grad_norm;
   tp.max_grad_norm = max_grad_norm;
   tp.min_nn = min_nn;
+  tp.max_sdf_std = max_sdf_std;
   hipLaunchKernelGGL(clid::k_track_model, dim3((N + CLID_QPB - 1) / CLID_QPB), dim3(CLID_BLOCK), 0,
                      (hipStream_t)stream, *mv, W1, b1, W2, b2, tp, pc_imu, N, sdf_out, grad_out, pmap_out, valid_out,
                      normal_eq);

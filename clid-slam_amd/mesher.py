@@ -17,8 +17,6 @@ def query_points(neural_points, sdf_mlp, config, coord, bs=None, query_sdf=True,
     returns numpy arrays.  Semantic / colour heads are outside the hot-path scope."""
     if query_sem or query_color:
         raise NotImplementedError("semantic / colour queries are outside the hot-path scope")
-    if not config.weighted_first:
-        raise NotImplementedError("fused dense query serves weighted_first configs (all shipped ones)")
     lib = _lib.load()
     bs = int(bs or config.infer_bs)
     n = coord.shape[0]

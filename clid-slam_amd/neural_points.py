@@ -642,6 +642,7 @@ class NeuralPoints(nn.Module):
         v.resolution = float(self.resolution)
         v.max_valid_dist2 = float(self.max_valid_dist2)
         v.layer_norm = int(bool(self.config.layer_norm_on))
+        v.weighted_first = int(bool(getattr(self.config, "weighted_first", True)))
         return v, (tab, tab_pos, filt, pos4, feat, cert, tsu, self._delta)
 
     # ------------------------------------------------------------------ hot methods
@@ -698,13 +699,9 @@ class NeuralPoints(nn.Module):
 
     def query_sdf_and_gradient(self, decoder, query_points: torch.Tensor):
         """Fused inference used by tracking-style callers: query (training_mode=False, local map)
-        -> Decoder.sdf -> analytic d sdf / d x, i.e. utils/error_state_iekf.py:209-227 in ONE kernel.
+        -> Decoder.sdf -> analytic d sdf / d x, i.e. utils/error_state_iekf.py:209-227 in ONE kernel (either
+        `weighted_first` setting: blended inputs decoded once, or every neighbour decoded and the SDFs blended).
         Returns (sdf [N], grad [N,3], nn_counts [N] int64, certainty [N])."""
-        if not self.config.weighted_first:
-            # the fused kernel blends the neighbours' features, then decodes once (weighted_first semantics); decoding
-            # every neighbour and blending the SDFs (utils/mapper.py:107-112) would give a different value
-            raise NotImplementedError("query_sdf_and_gradient serves weighted_first configs (all shipped ones); use "
-                                      "query_feature + Decoder.sdf + get_gradient for weighted_first=False")
         lib = _lib.load()
         x = _lib.require_cuda(query_points.detach().contiguous(), "query_points", torch.float32)
         view, keep = self._map_view(True)

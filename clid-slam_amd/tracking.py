@@ -20,9 +20,6 @@ from . import _lib
 
 
 def _launch(neural_points, geo_decoder, config, rot, pos, pc_imu, per_point: bool, reduce: bool):
-    if not config.weighted_first:
-        raise NotImplementedError("fused h_model serves weighted_first configs (all shipped ones); "
-                                  "use query_feature / Decoder.sdf / get_gradient otherwise")
     lib = _lib.load()
     x = _lib.require_cuda(pc_imu.detach().to(torch.float32).contiguous(), "pc_imu", torch.float32)
     n = x.shape[0]
@@ -48,7 +45,8 @@ def _launch(neural_points, geo_decoder, config, rot, pos, pc_imu, per_point: boo
     _lib.check(
         lib.clid_track_model(C.byref(view), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
                              float(geo_decoder.sdf_scale), r, t, int(config.track_mask_query_nn_k),
-                             float(config.reg_min_grad_norm), float(config.reg_max_grad_norm), _lib.ptr(x), n,
+                             float(config.reg_min_grad_norm), float(config.reg_max_grad_norm),
+                             float(config.surface_sample_range_m * getattr(config, "max_sdf_std_ratio", 1.0)), _lib.ptr(x), n,
                              _lib.ptr(out.get("sdf")), _lib.ptr(out.get("grad")), _lib.ptr(out.get("pmap")),
                              _lib.ptr(out.get("valid")), _lib.ptr(ne), _lib.stream()),
         "clid_track_model",

@@ -77,6 +77,10 @@ typedef struct clid_map_view {
   float max_valid_dist2;   /* 3*((num_nei_cells+1)*res)^2 */
   int32_t layer_norm;      /* config.layer_norm_on */
   int32_t log2filter;      /* bits of `filter`, >= 8 per key recommended (false-positive rate <= 12 %) */
+  int32_t weighted_first;  /* config.weighted_first (utils/config.py; True in every shipped config), read by the fused inference
+                              entries clid_sdf_grad_x / clid_sdf_query / clid_track_model: 1 = blend the neighbours'
+                              decoder inputs, decode once; 0 = decode every neighbour, blend the K SDFs */
+  int32_t reserved0;
 } clid_map_view;
 
 /* Builds the compact probe table for one (map, window, time-filter) state.
@@ -147,8 +151,9 @@ int clid_sdf_query(const clid_map_view* mv, const float* W1, const float* b1, co
                    const float* b2, float sdf_scale, const float* x, int32_t N, float* sdf_out,
                    int32_t* nn_out, void* stream);
 
-/* Tracking measurement model, IEKFOM.h_model (utils/error_state_iekf.py:176-264), weighted_first configs:
- * p_map = R p_imu + t, sdf + analytic gradient at p_map, validity mask (nn >= min_nn, min < |g| < max),
+/* Tracking measurement model, IEKFOM.h_model (utils/error_state_iekf.py:176-264):
+ * p_map = R p_imu + t, sdf + analytic gradient at p_map, validity mask (nn >= min_nn, min < |g| < max, and -- with
+ * mv->weighted_first == 0 -- std of the neighbours' SDFs < max_sdf_std, :217-225 / :236-241),
  * and -- when normal_eq != NULL -- the float64 sums update_iterated (:299-305) needs instead of the N x 18 H:
  *   normal_eq[0..20]  upper triangle (row-major) of the 6x6 block of S = H^T R_inv H   (+=, zero it first)
  *   normal_eq[21..26] H^T R_inv z,   normal_eq[27] number of valid points
@@ -156,7 +161,7 @@ int clid_sdf_query(const clid_map_view* mv, const float* W1, const float* b1, co
  * Per-point outputs (any may be NULL): sdf [N], grad [N][3], pmap [N][3], valid [N] int32. */
 int clid_track_model(const clid_map_view* mv, const float* W1, const float* b1, const float* W2,
                      const float* b2, float sdf_scale, const float* rot_host, const float* pos_host,
-                     int32_t min_nn, float min_grad_norm, float max_grad_norm, const float* pc_imu,
+                     int32_t min_nn, float min_grad_norm, float max_grad_norm, float max_sdf_std, const float* pc_imu,
                      int32_t N, float* sdf_out, float* grad_out, float* pmap_out, int32_t* valid_out,
                      double* normal_eq, void* stream);
 

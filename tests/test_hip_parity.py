@@ -533,24 +533,28 @@ def test_sharded_gradients_at_large_batches(env, bs):
     assert float((loss - loss_full).abs().max()) <= 2e-6
 
 
-@pytest.mark.parametrize("ln", [0, 1])
-def test_tracking_measurement_model_g8(env, ln):
+@pytest.mark.parametrize("ln,wf", [(0, 1), (1, 1), (0, 0), (1, 0)])
+def test_tracking_measurement_model_g8(env, ln, wf):
     """Row N1: fused h_model kernel (per-point outputs and the float64 normal equations) against the
-    reference's IEKFOM.h_model fixture."""
+    reference's IEKFOM.h_model fixture, for both `weighted_first` settings (wf = 0: every neighbour decoded, SDFs
+    blended, the std mask of utils/error_state_iekf.py:217-241 with a threshold inside the std's range)."""
     from clid_slam_amd import tracking
 
     g = gio.load("g8_tracking.npz")
-    cfg = env.config(layer_norm_on=bool(ln))
+    cfg = env.config(layer_norm_on=bool(ln), weighted_first=bool(wf))
     cfg.reg_min_grad_norm, cfg.reg_max_grad_norm = float(g["grad_window"][0]), float(g["grad_window"][1])
+    if not wf:
+        cfg.max_sdf_std_ratio = float(g["max_sdf_std_ratio_wf0"][ln])
+    tag = f"ln{ln}" + ("" if wf else "_wf0")
     nm = env.neural_points(cfg)
     dec = env.decoder(cfg)
     rot, pos, pc = gio.T(g["rot"]), gio.T(g["pos"]), gio.T(g["pc_imu"]).cuda()
     z, H, vp, r_inv = tracking.h_model(nm, dec, cfg, rot, pos, pc)
-    Hr, zr, rr = g[f"H6_ln{ln}"], g[f"z_ln{ln}"], g[f"R_inv_ln{ln}"]
+    Hr, zr, rr = g[f"H6_{tag}"], g[f"z_{tag}"], g[f"R_inv_{tag}"]
     assert H.dtype == torch.float64 and H.shape == (Hr.shape[0], 18)
     assert maxerr(z, zr) <= 2e-6
     assert maxerr(H[:, :6], Hr) <= 5e-5 and float(H[:, 6:].abs().max()) == 0.0
-    assert maxerr(vp, g[f"valid_points_ln{ln}"]) <= 1e-5
+    assert maxerr(vp, g[f"valid_points_{tag}"]) <= 1e-5
     assert maxerr(r_inv, rr) <= 2e-2
     S, b, n = tracking.normal_equations(nm, dec, cfg, rot, pos, pc)
     assert n == Hr.shape[0]
@@ -605,22 +609,44 @@ def test_dense_sdf_query_vs_oracle(env, ln, loc):
     assert (nn == 0).any() and (nn >= 4).any()
 
 
-@pytest.mark.parametrize("ln,loc", [(0, 0), (0, 1), (1, 0), (1, 1)])
-def test_mesher_query_points_vs_reference_g12(env, ln, loc):
-    """Row N3 against the reference's own `Mesher.query_points` output (fixture G12), through the `Mesher` drop-in."""
+@pytest.mark.parametrize("ln,loc,wf", [(0, 0, 1), (0, 1, 1), (1, 0, 1), (1, 1, 1), (0, 0, 0), (0, 1, 0), (1, 0, 0), (1, 1, 0)])
+def test_mesher_query_points_vs_reference_g12(env, ln, loc, wf):
+    """Row N3 against the reference's own `Mesher.query_points` output (fixture G12), through the `Mesher` drop-in, for both
+    `weighted_first` settings (utils/mesher.py:130-138)."""
     from clid_slam_amd.mesher import Mesher
 
     g = gio.load("g12_mesher.npz")
-    cfg = env.config(layer_norm_on=bool(ln))
+    cfg = env.config(layer_norm_on=bool(ln), weighted_first=bool(wf))
+    tag = f"ln{ln}_loc{loc}" + ("" if wf else "_wf0")
     nm = env.neural_points(cfg)
     dec = env.decoder(cfg)
     mesher = Mesher(cfg, nm, {"sdf": dec, "semantic": None, "color": None})
     sdf, sem, col, mask = mesher.query_points(gio.T(g["x"]).cuda(), 700, query_locally=bool(loc), mask_min_nn_count=4, out_torch=True)
     assert sem is None and col is None
-    assert maxerr(sdf, g[f"sdf_ln{ln}_loc{loc}"]) <= 2e-6
-    assert np.array_equal(mask.cpu().numpy().astype(np.uint8), g[f"mask_ln{ln}_loc{loc}"])
+    assert maxerr(sdf, g[f"sdf_{tag}"]) <= 2e-6
+    assert np.array_equal(mask.cpu().numpy().astype(np.uint8), g[f"mask_{tag}"])
     sdf_np, _, _, mask_np = mesher.query_points(gio.T(g["x"]).cuda(), 10_000, query_locally=bool(loc), out_torch=False)
-    assert isinstance(sdf_np, np.ndarray) and maxerr(sdf_np, g[f"sdf_ln{ln}_loc{loc}"]) <= 2e-6
+    assert isinstance(sdf_np, np.ndarray) and maxerr(sdf_np, g[f"sdf_{tag}"]) <= 2e-6
+
+
+@pytest.mark.parametrize("ln", [0, 1])
+def test_query_sdf_and_gradient_neighbour_first_vs_oracle(env, ln):
+    """`weighted_first: False` through NeuralPoints.query_sdf_and_gradient (the fused inference kernel): SDF and analytic
+    d SDF / d x against the oracle's autograd through query_feature -> per-neighbour decode -> blend."""
+    g = gio.load("g2_query.npz")
+    cfg = env.config(layer_norm_on=bool(ln), weighted_first=False)
+    nm = env.neural_points(cfg)
+    dec = env.decoder(cfg)
+    x = gio.T(g["x"])
+    sdf, grad, nn, cert = nm.query_sdf_and_gradient(dec, x.cuda())
+    st = gio.map_state(layer_norm_on=bool(ln), weighted_first=False)
+    xr = x.clone().requires_grad_(True)
+    f, w, nn_ref, cert_ref, _ = O.query_feature(st, xr, training_mode=False)
+    s = (O.mlp_sdf(gio.decoder(), f) * w).sum(dim=1).squeeze(1)
+    gr = torch.autograd.grad(s.sum(), xr)[0]
+    assert maxerr(sdf, s.detach()) <= 2e-6 and maxerr(grad, gr) <= 5e-5
+    assert torch.equal(nn.cpu(), nn_ref) and maxerr(cert, cert_ref) <= 1e-5
+    assert float(gr.abs().max()) > 1e-3
 
 
 @pytest.mark.parametrize("cells,alpha", [(1, 0.0), (2, 0.5)])

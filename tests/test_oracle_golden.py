@@ -163,21 +163,24 @@ def test_g6_mapping_loop(mode, frozen, ln):
     assert np.array_equal(tsu.numpy(), g["final_point_ts_update"])
 
 
-@pytest.mark.parametrize("ln", [0, 1])
-def test_g8_tracking_measurement_model(ln):
-    """Row N1: the oracle's h_model against the reference's own IEKFOM.h_model output."""
+@pytest.mark.parametrize("ln,wf", [(0, 1), (1, 1), (0, 0), (1, 0)])
+def test_g8_tracking_measurement_model(ln, wf):
+    """Row N1: the oracle's h_model against the reference's own IEKFOM.h_model output, for both `weighted_first` settings
+    (wf = 0: every neighbour decoded, SDFs blended, the std-of-SDFs mask of utils/error_state_iekf.py:217-241 active)."""
     g = gio.load("g8_tracking.npz")
-    st = gio.map_state(layer_norm_on=bool(ln))
+    st = gio.map_state(layer_norm_on=bool(ln), weighted_first=bool(wf))
     dec = gio.decoder()
     lo, hi = g["grad_window"]
+    tag = f"ln{ln}" + ("" if wf else "_wf0")
+    std_max = 0.25 if wf else 0.25 * float(g["max_sdf_std_ratio_wf0"][ln])
     z, H, vp, r_inv, valid = O.h_model(st, dec, gio.T(g["rot"]), gio.T(g["pos"]), gio.T(g["pc_imu"]),
-                                       min_grad_norm=float(lo), max_grad_norm=float(hi))
-    assert H.shape[0] == g[f"H6_ln{ln}"].shape[0] > 100
-    close(z, g[f"z_ln{ln}"], 1e-6, "residual")
-    close(H[:, :6], g[f"H6_ln{ln}"], 2e-5, "Jacobian")
+                                       min_grad_norm=float(lo), max_grad_norm=float(hi), max_sdf_std=std_max)
+    assert H.shape[0] == g[f"H6_{tag}"].shape[0] > 100
+    close(z, g[f"z_{tag}"], 1e-6, "residual")
+    close(H[:, :6], g[f"H6_{tag}"], 2e-5, "Jacobian")
     assert float(H[:, 6:].abs().max()) == 0.0
-    close(vp, g[f"valid_points_ln{ln}"], 1e-5, "valid points")
-    close(r_inv, g[f"R_inv_ln{ln}"], 1e-2, "R_inv")  # values ~1e3
+    close(vp, g[f"valid_points_{tag}"], 1e-5, "valid points")
+    close(r_inv, g[f"R_inv_{tag}"], 1e-2, "R_inv")  # values ~1e3
 
 
 def test_oracle_query_composition_vs_reference_mesher_g12():
@@ -185,10 +188,15 @@ def test_oracle_query_composition_vs_reference_mesher_g12():
     (fixture G12: global + local map, with and without layer norm, nn >= 1 / nn >= 4 masks)."""
     g = gio.load("g12_mesher.npz")
     x = gio.T(g["x"])
-    for ln in (0, 1):
-        for loc in (0, 1):
-            st = gio.map_state(layer_norm_on=bool(ln))
-            f, _, nn, _, _ = O.query_feature(st, x, training_mode=False, query_locally=bool(loc))
-            sdf = torch.where(nn >= 1, O.mlp_sdf(gio.decoder(), f), torch.zeros(()))
-            assert float((sdf - gio.T(g[f"sdf_ln{ln}_loc{loc}"])).abs().max()) <= 1e-6, (ln, loc)
-            assert torch.equal((nn >= 4), gio.T(g[f"mask_ln{ln}_loc{loc}"]).bool()), (ln, loc)
+    for wf in (1, 0):
+        for ln in (0, 1):
+            for loc in (0, 1):
+                st = gio.map_state(layer_norm_on=bool(ln), weighted_first=bool(wf))
+                f, w, nn, _, _ = O.query_feature(st, x, training_mode=False, query_locally=bool(loc))
+                sdf = O.mlp_sdf(gio.decoder(), f)
+                if not wf:  # utils/mesher.py:130-138
+                    sdf = (sdf * w).sum(dim=1).squeeze(1)
+                sdf = torch.where(nn >= 1, sdf, torch.zeros(()))
+                tag = f"ln{ln}_loc{loc}" + ("" if wf else "_wf0")
+                assert float((sdf - gio.T(g[f"sdf_{tag}"])).abs().max()) <= 1e-6, tag
+                assert torch.equal((nn >= 4), gio.T(g[f"mask_{tag}"]).bool()), tag
