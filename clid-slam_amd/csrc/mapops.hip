@@ -327,16 +327,19 @@ k_pool_scatter(PoolSrc a, PoolSrc b, const unsigned char* __restrict__ flag, con
 // trips.  Here: flags (+ count of the time window) -> scan -> one gather pass; the caller reads ONE count.
 struct WindowArgs {
   const float* points; const int* ts_create; const int* ts_update; const float* travel; long long n;
+  const long long* n_extra;  // device, may be NULL: the map holds n + *n_extra points (the count of an insert still in flight)
   int cur_ts, use_mid_ts, temporal, use_travel, diff_ts_local, reboot_ts, reboot_map;
   float diff_travel;
   double sx, sy, sz, r2;
   int pos_f64;  // the sensor position is float64 (pose dtype): the distance test then runs in float64 by type promotion
 };
+__device__ __forceinline__ long long window_n(const WindowArgs& a) { return a.n + (a.n_extra ? *a.n_extra : 0); }
 __global__ void __launch_bounds__(256) k_window_flags(WindowArgs a, unsigned char* __restrict__ bits, long long* __restrict__ counts) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = window_n(a);
   bool t_ok = true;
   bool d_ok = false;
-  if (i < a.n) {
+  if (i < n) {
     if (a.temporal) {
       int ts = a.ts_create[i];
       if (a.use_mid_ts) ts = (int)(((float)a.ts_create[i] + (float)a.ts_update[i]) / 2.0f);  // ((a + b) / 2).int(), :449
@@ -356,7 +359,7 @@ __global__ void __launch_bounds__(256) k_window_flags(WindowArgs a, unsigned cha
   }
   // one same-address atomic per BLOCK (per wave it was 10.8 k contended atomics at 690 k points: 56 us of a 5 us kernel)
   __shared__ int wave_cnt[4];
-  const unsigned long long b = __ballot(i < a.n && t_ok);
+  const unsigned long long b = __ballot(i < n && t_ok);
   if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(b);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -365,11 +368,15 @@ __global__ void __launch_bounds__(256) k_window_flags(WindowArgs a, unsigned cha
   }
 }
 // fewer than 100 points inside the time window -> the window is dropped (:462-466)
-__global__ void __launch_bounds__(256) k_window_combine(const unsigned char* __restrict__ bits, long long n, int temporal,
+__global__ void __launch_bounds__(256) k_window_combine(WindowArgs a, const unsigned char* __restrict__ bits, long long n_upper,
                                                         const long long* __restrict__ counts, int* __restrict__ flag) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const bool use_time = temporal && counts[0] >= 100;
+  if (i >= n_upper) return;
+  if (i >= window_n(a)) {  // rows of the capacity beyond the map: nothing there (the scan runs over the upper bound)
+    flag[i] = 0;
+    return;
+  }
+  const bool use_time = a.temporal && counts[0] >= 100;
   flag[i] = ((bits[i] & 2) && (!use_time || (bits[i] & 1))) ? 1 : 0;
 }
 struct WindowOut {
@@ -380,13 +387,14 @@ struct WindowOut {
 __global__ void __launch_bounds__(256) k_window_gather(WindowArgs a, const int* __restrict__ flag, const int* __restrict__ pos,
                                                        WindowOut o, long long* __restrict__ counts) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i > a.n) return;
-  if (i == a.n) {  // the padding element: always part of the mask, never of the map (:518-530)
-    const long long m = a.n > 0 ? pos[a.n - 1] + flag[a.n - 1] : 0;
+  const long long n = window_n(a);
+  if (i > n) return;
+  if (i == n) {  // the padding element: always part of the mask, never of the map (:518-530)
+    const long long m = n > 0 ? pos[n - 1] + flag[n - 1] : 0;
     counts[1] = m;
     o.g2l[i] = -1;
     o.local_mask[i] = 1;
-    for (int c = 0; c < CLID_F; ++c) o.l_feat[m * CLID_F + c] = o.g_feat[a.n * CLID_F + c];
+    for (int c = 0; c < CLID_F; ++c) o.l_feat[m * CLID_F + c] = o.g_feat[n * CLID_F + c];
     return;
   }
   const bool in = flag[i] != 0;
@@ -1253,8 +1261,10 @@ extern "C" int clid_local_window(const float* neural_points, const int32_t* ts_c
                                  const float* point_certainties, const float* geo_features, int64_t* local_ids_out,
                                  int64_t* global2local_out, uint8_t* local_mask_out, float* local_points_out,
                                  float* local_orient_out, float* local_cert_out, int32_t* local_ts_out, float* local_feat_out,
-                                 int64_t* counts_out, void* workspace, void* stream) {
-  if (n < 0 || n >= (1LL << 31) || !sensor_pos_host || !counts_out || !workspace || !global2local_out || !local_mask_out ||
+                                 int64_t* counts_out, void* workspace, const int64_t* n_extra_dev, int64_t n_upper,
+                                 void* stream) {
+  if (!n_extra_dev) n_upper = n;
+  if (n < 0 || n_upper < n || n_upper >= (1LL << 31) || !sensor_pos_host || !counts_out || !workspace || !global2local_out || !local_mask_out ||
       !geo_features || !local_feat_out ||
       (n > 0 && (!neural_points || !ts_create || !ts_update || !point_orientations || !point_certainties || !local_ids_out ||
                  !local_points_out || !local_orient_out || !local_cert_out || !local_ts_out)) ||
@@ -1266,19 +1276,20 @@ extern "C" int clid_local_window(const float* neural_points, const int32_t* ts_c
   long long* counts = reinterpret_cast<long long*>(counts_out);
   if (hipMemsetAsync(counts, 0, 2 * sizeof(long long), s) != hipSuccess) return CLID_E_HIP;
   char* ws = static_cast<char*>(workspace);
+  const long long nu = n_upper;  // grids, scan and workspace cover the upper bound; the kernels read the exact size
   unsigned char* bits = reinterpret_cast<unsigned char*>(ws);
-  int* flag = reinterpret_cast<int*>(ws + align256((size_t)n));
-  int* pos = reinterpret_cast<int*>(ws + align256((size_t)n) + align256((size_t)n * 4));
-  void* cub = ws + align256((size_t)n) + 2 * align256((size_t)n * 4);
-  size_t cub_bytes = n > 0 ? pool_scan_bytes(n) : 0;
-  WindowArgs a{neural_points, ts_create, ts_update, travel_dist, n, cur_ts, use_mid_ts, temporal, use_travel_dist,
-               diff_ts_local, reboot_ts, reboot_map, diff_travel, sensor_pos_host[0], sensor_pos_host[1], sensor_pos_host[2],
-               radius2, pos_is_f64};
-  if (n > 0) {
-    const unsigned blocks = (unsigned)((n + 255) / 256);
+  int* flag = reinterpret_cast<int*>(ws + align256((size_t)nu));
+  int* pos = reinterpret_cast<int*>(ws + align256((size_t)nu) + align256((size_t)nu * 4));
+  void* cub = ws + align256((size_t)nu) + 2 * align256((size_t)nu * 4);
+  size_t cub_bytes = nu > 0 ? pool_scan_bytes(nu) : 0;
+  WindowArgs a{neural_points, ts_create, ts_update, travel_dist, n, reinterpret_cast<const long long*>(n_extra_dev), cur_ts,
+               use_mid_ts, temporal, use_travel_dist, diff_ts_local, reboot_ts, reboot_map, diff_travel, sensor_pos_host[0],
+               sensor_pos_host[1], sensor_pos_host[2], radius2, pos_is_f64};
+  if (nu > 0) {
+    const unsigned blocks = (unsigned)((nu + 255) / 256);
     hipLaunchKernelGGL(k_window_flags, dim3(blocks), dim3(256), 0, s, a, bits, counts);
-    hipLaunchKernelGGL(k_window_combine, dim3(blocks), dim3(256), 0, s, bits, n, temporal, counts, flag);
-    if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)n, s) != hipSuccess) {
+    hipLaunchKernelGGL(k_window_combine, dim3(blocks), dim3(256), 0, s, a, bits, nu, counts, flag);
+    if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)nu, s) != hipSuccess) {
       clid_set_error("clid_local_window: scan failed");
       return CLID_E_HIP;
     }
@@ -1286,7 +1297,7 @@ extern "C" int clid_local_window(const float* neural_points, const int32_t* ts_c
   WindowOut o{reinterpret_cast<long long*>(local_ids_out), reinterpret_cast<long long*>(global2local_out), local_mask_out,
               local_points_out, local_orient_out, local_cert_out, local_ts_out, local_feat_out, point_orientations,
               point_certainties, geo_features};
-  hipLaunchKernelGGL(k_window_gather, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s, a, flag, pos, o, counts);
+  hipLaunchKernelGGL(k_window_gather, dim3((unsigned)((nu + 1 + 255) / 256)), dim3(256), 0, s, a, flag, pos, o, counts);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

@@ -23,7 +23,10 @@ constexpr int kRecFloatsPerTask = 192;  // qinfo[8] | qdesc[8] | win[8][8]: what
 // launches number in place (the SIMD's other waves hide it; numbering in the search launch cost 65 536 / 262 144-sample
 // iterations +6 / +24 us there for -1 / -8 us in the decode).
 constexpr int kTileNumWords = 128, kTileNumCount = 96, kTileNumBytes = 100;
-constexpr int kTileLargeFrom = 2048;  // tiles
+#ifndef CLID_TILE_LARGE_FROM
+#define CLID_TILE_LARGE_FROM 2048
+#endif
+constexpr int kTileLargeFrom = CLID_TILE_LARGE_FROM;  // tiles
 __host__ __device__ inline bool tiles_prenumbered(int n_tasks) { return (n_tasks + 1) / 2 <= kTileLargeFrom; }
 __host__ __device__ inline size_t rec_floats_per_iter(int n_tasks) {
   return (size_t)n_tasks * kRecFloatsPerTask + (tiles_prenumbered(n_tasks) ? (size_t)((n_tasks + 1) / 2) * kTileNumWords : 0);

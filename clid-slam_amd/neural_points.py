@@ -15,6 +15,7 @@ time-filter) state by `clid_table_build` (csrc/table.hip) and cached; see DESIGN
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 
 import torch
@@ -168,12 +169,22 @@ class NeuralPoints(nn.Module):
         st = dict(st)
         st["_tables"] = {}
         st.pop("_replica_gens", None)  # torch.Generator objects do not pickle
-        for k in ("_sensor_pos_host", "_win_ws", "_win_counts", "_ins_ws", "_ins_count", "_gbuf", "_stencils", "_presampled", "_track_scratch"):
+        for k in ("_sensor_pos_host", "_win_ws", "_win_counts", "_ins_ws", "_ins_count", "_ins_win_counts", "_gbuf", "_stencils", "_presampled", "_track_scratch"):
             st.pop(k, None)
-        for k in self._GLOBAL_ARRAYS:  # views of the capacity buffers would drag the whole buffers into the pickle
+        # views of capacity / upper-bound buffers would drag the whole buffers into the pickle: the global arrays (capacity
+        # buffers of the in-place insert) and the local arrays, mask and index map (outputs of the window selection, allocated
+        # at the size of the global map)
+        for k in self._GLOBAL_ARRAYS + ("local_neural_points", "local_point_orientations", "local_point_certainties",
+                                        "local_point_ts_update", "local_mask", "global2local", "_local_ids"):
             t = st.get(k)
             if isinstance(t, torch.Tensor) and t.numel() and t.untyped_storage().nbytes() > t.numel() * t.element_size():
                 st[k] = t.clone()
+        params = st.get("_parameters")
+        if params:  # local_geo_features is a view of the window selection's feature output too
+            st["_parameters"] = type(params)(
+                (k, nn.Parameter(p.detach().clone(), requires_grad=p.requires_grad)
+                 if isinstance(p, torch.Tensor) and p.numel() and p.untyped_storage().nbytes() > p.numel() * p.element_size() else p)
+                for k, p in params.items())
         return st
 
     # ------------------------------------------------------------------ search region
@@ -295,7 +306,9 @@ class NeuralPoints(nn.Module):
         need = int(lib.clid_map_insert_workspace_bytes(n))
         if getattr(self, "_ins_ws", None) is None or self._ins_ws.numel() < need or self._ins_ws.device != dev:
             self._ins_ws = torch.empty(int(need * 1.5) + 1024, device=dev, dtype=torch.uint8)
-            self._ins_count = torch.zeros(1, device=dev, dtype=torch.int64)
+        if getattr(self, "_ins_win_counts", None) is None or self._ins_win_counts.device != dev:
+            self._ins_win_counts = torch.zeros(3, device=dev, dtype=torch.int64)  # [added | in the time window, local points]
+            self._ins_count, self._win_counts = self._ins_win_counts[:1], self._ins_win_counts[1:]
         res = float(self.resolution)
         _lib.check(lib.clid_map_insert(
             sample_points.data_ptr(), n, self.buffer_pt_index.data_ptr(), int(self.buffer_size), res,
@@ -303,9 +316,18 @@ class NeuralPoints(nn.Module):
             buf["point_ts_update"].data_ptr(), buf["point_certainties"].data_ptr(), base, _lib.ptr(travel), int(cur_ts), test_on,
             temporal, float(3 * res**2), float(self.diff_travel_dist_local), self._ins_count.data_ptr(), self._ins_ws.data_ptr(),
             _lib.stream()), "clid_map_insert")
+        feat = buf["geo_features"]
+        if self.geo_feature_std == 0 and os.environ.get("CLID_FUSED_INSERT_WINDOW", "1") != "0":
+            # zero-initialised features (every shipped config): nothing between the insert and the window selection needs
+            # the number of added points on the host, so the window is enqueued on the insert's device-side count and the
+            # two share ONE read-back (model/neural_points.py:324-437 + :439-536)
+            feat[base:base + n + 1].zero_()
+            got = self._reset_local_map_fused(sensor_position, sensor_orientation, cur_ts, True, 50, True,
+                                              pending=(buf, base, n, self._ins_count))
+            if got is not None:
+                return got / max(n, 1)
         n_new = _lib.read_counts(self._ins_count, 1)[0]  # the one host round trip of the insert (sizes the views)
         total = base + n_new
-        feat = buf["geo_features"]
         if self.geo_feature_std != 0:
             gen = _lib.replica_generator(self, self.config, self.device, 2)  # None = global RNG unless data-parallel
             feat[base:total + 1] = self.geo_feature_std * torch.randn(n_new + 1, feat.shape[1], device=dev, dtype=torch.float32,
@@ -378,15 +400,26 @@ class NeuralPoints(nn.Module):
         self._local_ids = local_ids.contiguous()
         self._map_version += 1
 
-    def _reset_local_map_fused(self, sensor_position, sensor_orientation, cur_ts, use_travel_dist, diff_ts_local, reboot_map):
+    def _reset_local_map_fused(self, sensor_position, sensor_orientation, cur_ts, use_travel_dist, diff_ts_local, reboot_map,
+                               pending=None):
         """The window selection and the gathers of reset_local_map in one enqueue (csrc/mapops.hip clid_local_window) with
-        ONE count read back; False = not applicable here (CPU tensors, colour features), the torch path runs."""
+        ONE count read back; False = not applicable here (CPU tensors, colour features), the torch path runs.
+        `pending` = (capacity buffers, base, n_samples, device count) of a `clid_map_insert` still in flight: the window runs
+        on the capacity buffers with the device-side count, the read-back returns both counts, the global views are set
+        here and the number of inserted points is returned (None: not applicable, nothing was enqueued)."""
         pts = self.neural_points
-        if not (pts.is_cuda and self.color_features is None and pts.dtype == torch.float32 and self.count() > 0
-                and self.geo_features.shape[1] == _lib.F and self.point_ts_create.dtype == torch.int32):
+        if pending is not None:
+            buf, base, n_add, ins_count = pending
+            if not (self.color_features is None and base + n_add > 0):
+                return None
+            self.cur_ts = cur_ts
+            self.max_ts = max(self.max_ts, cur_ts)
+            pts = buf["neural_points"]
+        elif not (pts.is_cuda and self.color_features is None and pts.dtype == torch.float32 and self.count() > 0
+                  and self.geo_features.shape[1] == _lib.F and self.point_ts_create.dtype == torch.int32):
             return False
         lib = _lib.load()
-        dev, n = pts.device, int(self.count())
+        dev, n = pts.device, (int(self.count()) if pending is None else base + n_add)
         hint = getattr(self, "_sensor_pos_host", None)  # (tensor, host tuple) left by Mapper.process_frame: no read-back
         if hint is not None and hint[0] is sensor_position:
             sp = hint[1]
@@ -398,7 +431,9 @@ class NeuralPoints(nn.Module):
         need = int(lib.clid_local_window_workspace_bytes(n))
         if getattr(self, "_win_ws", None) is None or self._win_ws.numel() < need or self._win_ws.device != dev:
             self._win_ws = torch.empty(int(need * 1.3) + 1024, device=dev, dtype=torch.uint8)
-            self._win_counts = torch.zeros(2, device=dev, dtype=torch.int64)
+        if getattr(self, "_ins_win_counts", None) is None or self._ins_win_counts.device != dev:
+            self._ins_win_counts = torch.zeros(3, device=dev, dtype=torch.int64)
+            self._ins_count, self._win_counts = self._ins_win_counts[:1], self._ins_win_counts[1:]
         ids = torch.empty(n, device=dev, dtype=torch.int64)
         g2l = torch.empty(n + 1, device=dev, dtype=torch.int64)
         mask = torch.empty(n + 1, device=dev, dtype=torch.bool)
@@ -407,16 +442,33 @@ class NeuralPoints(nn.Module):
         l_cert = torch.empty(n, device=dev, dtype=torch.float32)
         l_ts = torch.empty(n, device=dev, dtype=torch.int32)
         l_feat = torch.empty((n + 1, _lib.F), device=dev, dtype=torch.float32)
-        for name in ("point_orientations", "point_certainties", "geo_features", "point_ts_update", "point_ts_create"):
-            _lib.require_cuda(getattr(self, name), name)
+        if pending is None:
+            for name in ("point_orientations", "point_certainties", "geo_features", "point_ts_update", "point_ts_create"):
+                _lib.require_cuda(getattr(self, name), name)
+            src = {k: getattr(self, k) for k in ("point_ts_create", "point_ts_update", "point_orientations", "point_certainties",
+                                                 "geo_features")}
+            n_base, extra = n, None
+        else:
+            src, n_base, extra = buf, base, ins_count.data_ptr()
         _lib.check(lib.clid_local_window(
-            pts.contiguous().data_ptr(), self.point_ts_create.data_ptr(), self.point_ts_update.data_ptr(), _lib.ptr(travel), n,
+            pts.contiguous().data_ptr(), src["point_ts_create"].data_ptr(), src["point_ts_update"].data_ptr(), _lib.ptr(travel), n_base,
             int(cur_ts), int(bool(self.config.use_mid_ts)), temporal, int(bool(use_travel_dist)), float(self.diff_travel_dist_local),
             int(diff_ts_local), int(self.reboot_ts), int(bool(reboot_map)), (C.c_double * 3)(*sp), float(self.local_map_radius) ** 2, f64,
-            self.point_orientations.data_ptr(), self.point_certainties.data_ptr(), self.geo_features.data_ptr(),
+            src["point_orientations"].data_ptr(), src["point_certainties"].data_ptr(), src["geo_features"].data_ptr(),
             ids.data_ptr(), g2l.data_ptr(), mask.data_ptr(), l_pts.data_ptr(), l_ori.data_ptr(), l_cert.data_ptr(),
-            l_ts.data_ptr(), l_feat.data_ptr(), self._win_counts.data_ptr(), self._win_ws.data_ptr(), _lib.stream()), "clid_local_window")
-        m = _lib.read_counts(self._win_counts, 2)[1]  # the one host round trip: sizes the local arrays
+            l_ts.data_ptr(), l_feat.data_ptr(), self._win_counts.data_ptr(), self._win_ws.data_ptr(), extra, n, _lib.stream()),
+            "clid_local_window")
+        n_new = None
+        if pending is None:
+            m = _lib.read_counts(self._win_counts, 2)[1]  # the one host round trip: sizes the local arrays
+        else:
+            # ONE read-back for the insert and the window: the window's count pair sits next to the insert's count
+            n_new, _, m = _lib.read_counts(self._ins_win_counts, 3)
+            total = base + n_new
+            self.neural_points, self.point_orientations = buf["neural_points"][:total], buf["point_orientations"][:total]
+            self.point_ts_create, self.point_ts_update = buf["point_ts_create"][:total], buf["point_ts_update"][:total]
+            self.point_certainties, self.geo_features = buf["point_certainties"][:total], buf["geo_features"][:total + 1]
+            mask, g2l = mask[:total + 1], g2l[:total + 1]
         self.local_neural_points, self.local_point_orientations = l_pts[:m], l_ori[:m]
         self.local_point_certainties, self.local_point_ts_update = l_cert[:m], l_ts[:m]
         self.local_mask, self.global2local = mask, g2l
@@ -425,7 +477,7 @@ class NeuralPoints(nn.Module):
         self._local_ids_pad = None
         self.local_orientation = sensor_orientation
         self._map_version += 1
-        return True
+        return True if pending is None else n_new
 
     def assign_local_to_global(self):
         """model/neural_points.py:538-549."""
