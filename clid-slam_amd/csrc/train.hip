@@ -1494,7 +1494,7 @@ extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args*
   const size_t dyn = use_filter == 1 ? ((size_t)1 << mv->log2filter) / 8 : 0;
   // iterations of at most kTileLargeFrom tiles: tasks in pairs, the tile's pairs numbered for the decode launch (one tile
   // per wave there); larger ones: per task, the decode kernel numbers in place (train_common.hpp tiles_prenumbered)
-  const bool num = clid_tiles_prenumbered(tmap.n_tasks);
+  const bool num = clid_tiles_prenumbered(tmap.n_tasks, mv);
   long long sb = num ? ((long long)((tmap.n_tasks + 1) / 2) * n_iter + kFusedBlock / 64 - 1) / (kFusedBlock / 64)
                      : ((long long)tmap.n_tasks * n_iter + kFusedBlock / 64 - 1) / (kFusedBlock / 64);
   if (sb > search_blocks()) sb = search_blocks();

@@ -297,7 +297,7 @@ __host__ inline size_t touch_bytes(long long stride, int chunk) {
 int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, float* partial, const clid::TaskMap& tmap,
                             const float* rec, int prec, hipStream_t s);
 int clid_decode_tile_blocks(int n_tasks);
-bool clid_tiles_prenumbered(int n_tasks);  // launches of one tile per wave read the search launch's number blocks
+bool clid_tiles_prenumbered(int n_tasks, const clid_map_view* mv);  // does the decode launch read the search launch's number blocks?
 // host-side launchers of the analytic-eikonal iteration (train_analytic.hip)
 int clid_launch_train_analytic(const clid_map_view* mv, const clid_train_args* a, float* partial, hipStream_t s);
 int clid_train_analytic_blocks(int bs);

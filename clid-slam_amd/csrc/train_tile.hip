@@ -98,8 +98,9 @@ __device__ __forceinline__ void tile_lds_fence() {
 #ifndef CLID_TILE_WAVES
 #define CLID_TILE_WAVES (LN ? 2 : 1)  // layer norm: pin 2 waves per SIMD (VGPRs + AGPRs <= 256; it lands on 1 otherwise)
 #endif
-constexpr bool tiles_prenumbered_tw(int tw) { return tw == kTileWavesSmall; }
-template <int PREC, bool LN, int TW>
+// PRE: the tiles' row numbers come from the search launch's number blocks (small launches on maps within one L2: see
+// clid_tiles_prenumbered); otherwise the kernel numbers in place
+template <int PREC, bool LN, int TW, bool PRE>
 __global__ void __launch_bounds__(TW * 64, CLID_TILE_WAVES)
 k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap,
               const float4* __restrict__ rec, const int* __restrict__ tnum, int n_tiles, float* __restrict__ sdf_dbg) {
@@ -108,7 +109,6 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
   static_assert(sizeof(TileLds) % 16 == 0 && sizeof(TileLds) * TW >= TW * kRedFloats * sizeof(float), "LDS plan");
   float* red = reinterpret_cast<float*>(tls);  // the block flush reuses the tile buffers (after a barrier)
   const int lane = threadIdx.x & 63, q = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
-  constexpr bool PRE = tiles_prenumbered_tw(TW);
   TileLds& tl = tls[wave];
   TileLnLds& ln = lns[LN ? wave : 0];
   const bool train = ta.train_decoder != 0;
@@ -564,9 +564,12 @@ extern "C" int clid_debug_read_stamps_tile(long long* out_host) {
 }
 #endif
 // do the tiles of a launch over n_tasks tasks read their row numbers from the search launch's number blocks?
-bool clid_tiles_prenumbered(int n_tasks) {
-  static_assert(kTileWavesSmall != kTileWavesLarge, "the waves-per-block choice doubles as the numbering choice");
-  return tiles_prenumbered(n_tasks);
+bool clid_tiles_prenumbered(int n_tasks, const clid_map_view* mv) {
+  // (i) at most kTileLargeFrom tiles: the decode launch then runs one tile per wave and is one tile's dependent chain long
+  // (14.5 -> 12.6 us at 16 384 samples for +1.0 us per iteration in the search launch); (ii) a local map whose probe table
+  // still sits in one L2 (the launcher's LDS-prefilter regime, M <= 2^17): at M = 243 k the search pays 4.5 us per
+  // iteration for the numbering and the decode gains 4.4 -- no gain, and the call's searches come first.
+  return tiles_prenumbered(n_tasks) && !(mv->filter && mv->log2filter > 18);
 }
 
 int clid_decode_tile_blocks(int n_tasks) {
@@ -590,14 +593,18 @@ int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, f
   const int nb = clid_decode_tile_blocks(tmap.n_tasks);
   const float4* r4 = reinterpret_cast<const float4*>(rec);
   const int* tn = reinterpret_cast<const int*>(rec + (size_t)tmap.n_tasks * kRecFloatsPerTask);  // (rec_floats_per_iter layout)
+  const bool pre = clid_tiles_prenumbered(tmap.n_tasks, mv);
 #define CLID_TILE_LAUNCH(P, L)                                                                                        \
   do {                                                                                                                \
-    if (tile_waves_for(n_tiles) == kTileWavesSmall)                                                                   \
-      CLID_KLAUNCH(a->prof, 0, (k_decode_tile<P, L, kTileWavesSmall>), dim3(nb), dim3(kTileWavesSmall * 64), 0, s, *mv, *a,       \
-                   partial, tmap, r4, tn, n_tiles, a->sdf_dbg);                                                            \
+    if (tile_waves_for(n_tiles) == kTileWavesSmall && pre)                                                            \
+      CLID_KLAUNCH(a->prof, 0, (k_decode_tile<P, L, kTileWavesSmall, true>), dim3(nb), dim3(kTileWavesSmall * 64), 0, s, *mv,  \
+                   *a, partial, tmap, r4, tn, n_tiles, a->sdf_dbg);                                                   \
+    else if (tile_waves_for(n_tiles) == kTileWavesSmall)                                                              \
+      CLID_KLAUNCH(a->prof, 0, (k_decode_tile<P, L, kTileWavesSmall, false>), dim3(nb), dim3(kTileWavesSmall * 64), 0, s, *mv, \
+                   *a, partial, tmap, r4, tn, n_tiles, a->sdf_dbg);                                                   \
     else                                                                                                              \
-      CLID_KLAUNCH(a->prof, 0, (k_decode_tile<P, L, kTileWavesLarge>), dim3(nb), dim3(kTileWavesLarge * 64), 0, s, *mv, *a,       \
-                   partial, tmap, r4, tn, n_tiles, a->sdf_dbg);                                                            \
+      CLID_KLAUNCH(a->prof, 0, (k_decode_tile<P, L, kTileWavesLarge, false>), dim3(nb), dim3(kTileWavesLarge * 64), 0, s, *mv, \
+                   *a, partial, tmap, r4, tn, n_tiles, a->sdf_dbg);                                                   \
   } while (0)
   if (prec == 1) {
     if (mv->layer_norm) CLID_TILE_LAUNCH(1, true);

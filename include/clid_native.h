@@ -299,7 +299,8 @@ int64_t clid_train_search_floats(int32_t bs, int64_t batch_offset, int32_t decim
  * the matrix-core decode kernels (two consecutive tasks), the tile's (query, neighbour) pairs numbered per distinct map row
  * -- resolved by clid_train_search because it depends on the records only, not on the training state.  Written for
  * iterations of at most 2048 tiles (one tile per wave in the decode launch, whose length is then one tile's dependent
- * chain); larger decode launches number their tiles in place and leave the blocks unwritten. */
+ * chain) on local maps of at most 2^17 points (probe table within one L2); otherwise the decode launch numbers its tiles
+ * in place and the blocks stay unwritten (larger iterations do not even carry them). */
 int32_t clid_train_search_tasks(int32_t bs, int64_t batch_offset, int32_t decimation, int32_t eikonal_mode);
 int clid_train_search(const clid_map_view* mv, const clid_train_args* t, int32_t n_iter,
                       const int64_t* index_base, int64_t index_stride, float* rec_out, void* stream);
