@@ -44,7 +44,7 @@ __host__ inline size_t max_tasks(int Q) { return (size_t)Q / 4 + 16; }
 // ~32 at the actual task count), capped at 1 GiB for very large batches, never less than one iteration
 constexpr int kMaxChunkIters = 32;
 __host__ inline size_t rec_buffer_floats(int Q) {
-  const size_t one = rec_floats_per_iter((int)max_tasks(Q));
+  const size_t one = max_tasks(Q) * (kRecFloatsPerTask + kTileNumWords / 2);  // (records + number blocks at the task bound)
   size_t it = (size_t(1) << 28) / one;
   if (it > 16) it = 16;
   if (it < 1) it = 1;
