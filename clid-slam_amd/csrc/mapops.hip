@@ -46,13 +46,17 @@ __device__ __forceinline__ float centre_dist(float x, float y, float z, float v,
   return sqrtf(fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz)));
 }
 
-__global__ void __launch_bounds__(256) k_vox_stats(const float* __restrict__ pts, int n, float v, VoxStats* st) {
+// `value` != NULL: the per-point score of voxel_down_sample_min_value_torch (utils/tools.py:685-724; non-negative)
+// takes the place of the distance to the voxel centre.
+__global__ void __launch_bounds__(256) k_vox_stats(const float* __restrict__ pts, int n, float v, VoxStats* st,
+                                                   const float* __restrict__ value) {
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
   unsigned dm = 0u;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
     float cx, cy, cz;
-    const float d = centre_dist(x, y, z, v, &cx, &cy, &cz);
+    float d = centre_dist(x, y, z, v, &cx, &cy, &cz);
+    if (value) d = value[i];
     const int ox = ordered(x), oy = ordered(y), oz = ordered(z);
     lo[0] = min(lo[0], ox); lo[1] = min(lo[1], oy); lo[2] = min(lo[2], oz);
     hi[0] = max(hi[0], ox); hi[1] = max(hi[1], oy); hi[2] = max(hi[2], oz);
@@ -111,7 +115,8 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long k) {
 }
 
 __global__ void __launch_bounds__(256) k_vox_insert(const float* __restrict__ pts, int n, float v, VoxStats* st,
-                                                    long long* keys, unsigned long long* vals, int log2cap) {
+                                                    long long* keys, unsigned long long* vals, int log2cap,
+                                                    const float* __restrict__ value) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   // tools.py:653, :661-663: offset = floor(min / v); stride = max(cell - offset) over ALL axes (not max + 1: voxels
@@ -126,7 +131,8 @@ __global__ void __launch_bounds__(256) k_vox_insert(const float* __restrict__ pt
   if (i == 0) st->stride = stride;
   const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
   float cx, cy, cz;
-  const float d = centre_dist(x, y, z, v, &cx, &cy, &cz);
+  float d = centre_dist(x, y, z, v, &cx, &cy, &cz);
+  if (value) d = value[i];
   const float dmax = __int_as_float((int)st->dmax);
   const long long q = dmax > 0.f ? (long long)fmul(fdiv(d, dmax), 999.0f) : 0;  // :657-659
   const long long gx = (long long)cx - off[0], gy = (long long)cy - off[1], gz = (long long)cz - off[2];
@@ -532,6 +538,67 @@ __global__ void __launch_bounds__(256) k_cloud_scatter(CloudArgs a, const int* _
   atomicMax(&a.table_new[cloud_slot(p[0], p[1], p[2], a.res, a.buffer_size)], j);
 }
 
+
+// ---- NeuralPoints.recreate_hash / prune_map (model/neural_points.py:771-812, 840-929) ---------------------------------
+// Table fill of recreate_hash (:886-892 keeping, :918-925 merging): buffer_pt_index[slot(points[src])] = src for the
+// list entries p = 0..m-1 (src = idx[p], or p without a list).  Several entries may name one slot; the reference's
+// indexed assignment keeps the LAST one on the CPU.  Two launches: every entry bids (p + 1, src) with an atomicMax,
+// then the winner replaces its bid by src (a loser sees either the winning bid or a bare index, whose upper half is 0).
+__global__ void __launch_bounds__(256) k_rehash_claim(const float* __restrict__ pts, const long long* __restrict__ idx, int m,
+                                                      float res, long long* __restrict__ table, int B) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= m) return;
+  const long long src = idx ? idx[p] : (long long)p;
+  const int slot = base_slot(pts[src * 3 + 0], pts[src * 3 + 1], pts[src * 3 + 2], res, B);
+  atomicMax(&table[slot], ((long long)(p + 1) << 32) | src);
+}
+__global__ void __launch_bounds__(256) k_rehash_commit(const float* __restrict__ pts, const long long* __restrict__ idx, int m,
+                                                       float res, long long* __restrict__ table, int B) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= m) return;
+  const long long src = idx ? idx[p] : (long long)p;
+  const int slot = base_slot(pts[src * 3 + 0], pts[src * 3 + 1], pts[src * 3 + 2], res, B);
+  if ((table[slot] >> 32) == (long long)(p + 1)) table[slot] = src;
+}
+
+// rows idx[0..m) of the global arrays into fresh arrays (prune_map :795-808, the merging branch of recreate_hash
+// :898-913); feature row m (the padding row) comes from row `pad_src`.  One thread per (row, 16-byte half of the feature row).
+struct MapRows {
+  const float* points; const float4* orient; const int* ts_create; const int* ts_update; const float* cert; const float4* feat;
+};
+struct MapRowsOut {
+  float* points; float4* orient; int* ts_create; int* ts_update; float* cert; float4* feat;
+};
+__global__ void __launch_bounds__(256) k_map_gather(const long long* __restrict__ idx, int m, long long pad_src, MapRows a,
+                                                    MapRowsOut o) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = t >> 1, half = t & 1;
+  if (p > m) return;
+  const long long src = p < m ? idx[p] : pad_src;
+  o.feat[(long long)p * 2 + half] = a.feat[src * 2 + half];
+  if (p == m) return;
+  if (half == 0) {
+    o.points[(long long)p * 3 + 0] = a.points[src * 3 + 0];
+    o.points[(long long)p * 3 + 1] = a.points[src * 3 + 1];
+    o.points[(long long)p * 3 + 2] = a.points[src * 3 + 2];
+    o.cert[p] = a.cert[src];
+  } else {
+    o.orient[p] = a.orient[src];
+    o.ts_create[p] = a.ts_create[src];
+    o.ts_update[p] = a.ts_update[src];
+  }
+}
+
+// prune_map :779-789: a point goes when it is uncertain and (unless `global`) has left the travel-distance window
+__global__ void __launch_bounds__(256) k_prune_flags(const int* __restrict__ ts_update, const float* __restrict__ cert, int n,
+                                                     const float* __restrict__ travel, int cur_ts, float thre, float diff_travel,
+                                                     int global, int* __restrict__ keep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool prune = cert[i] < thre;
+  if (prune && !global) prune = fabsf(fsub(travel[cur_ts], travel[ts_update[i]])) > diff_travel;
+  keep[i] = prune ? 0 : 1;
+}
 static int vox_log2cap(int n) {
   int l = 10;
   while ((1LL << l) < 2LL * n) ++l;
@@ -572,8 +639,8 @@ extern "C" int64_t clid_voxel_workspace_bytes(int32_t n) {
   return (int64_t)vox_layout(n).total;
 }
 
-extern "C" int clid_voxel_down_sample(const float* points, int32_t n, float voxel_size, void* workspace,
-                                      int64_t* idx_out, void* stream) {
+static int vox_down_sample(const float* points, int32_t n, float voxel_size, const float* value, void* workspace,
+                           int64_t* idx_out, void* stream) {
   if (n < 0 || !(voxel_size > 0.f) || (n > 0 && (!points || !workspace || !idx_out))) {
     clid_set_error("clid_voxel_down_sample: bad argument");
     return CLID_E_ARG;
@@ -596,8 +663,9 @@ extern "C" int clid_voxel_down_sample(const float* points, int32_t n, float voxe
   hipLaunchKernelGGL(k_vox_init, dim3(1), dim3(64), 0, s, st);
   int sb = (n + 255) / 256;
   if (sb > 64) sb = 64;  // every block ends in 8 same-address atomics: 512 blocks spent 15 of 18 us on them
-  hipLaunchKernelGGL(k_vox_stats, dim3(sb), dim3(256), 0, s, points, n, voxel_size, st);
-  hipLaunchKernelGGL(k_vox_insert, dim3((n + 255) / 256), dim3(256), 0, s, points, n, voxel_size, st, keys, vals, log2cap);
+  hipLaunchKernelGGL(k_vox_stats, dim3(sb), dim3(256), 0, s, points, n, voxel_size, st, value);
+  hipLaunchKernelGGL(k_vox_insert, dim3((n + 255) / 256), dim3(256), 0, s, points, n, voxel_size, st, keys, vals, log2cap,
+                     value);
   hipLaunchKernelGGL(k_vox_compact, dim3((unsigned)((((size_t)1 << log2cap) + 1023) / 1024)), dim3(1024), 0, s, keys, vals,
                      log2cap, st, flat_a, idx_a);
   CLID_CHECK_LAUNCH();
@@ -628,6 +696,20 @@ extern "C" int clid_voxel_down_sample(const float* points, int32_t n, float voxe
     return CLID_E_HIP;
   }
   return m;
+}
+
+extern "C" int clid_voxel_down_sample(const float* points, int32_t n, float voxel_size, void* workspace,
+                                      int64_t* idx_out, void* stream) {
+  return vox_down_sample(points, n, voxel_size, nullptr, workspace, idx_out, stream);
+}
+
+extern "C" int clid_voxel_down_sample_min_value(const float* points, int32_t n, float voxel_size, const float* value,
+                                                void* workspace, int64_t* idx_out, void* stream) {
+  if (n > 0 && !value) {
+    clid_set_error("clid_voxel_down_sample_min_value: bad argument");
+    return CLID_E_ARG;
+  }
+  return vox_down_sample(points, n, voxel_size, value, workspace, idx_out, stream);
 }
 
 extern "C" int clid_transform_points(const float* points, int32_t n, const float* pose12_host, float* out, void* stream) {
@@ -1384,6 +1466,79 @@ extern "C" int clid_cloud_update(const float* map_points, int64_t n_map, const f
     return CLID_E_HIP;
   }
   hipLaunchKernelGGL(k_cloud_scatter, dim3(blocks), dim3(256), 0, s, a, flag, pos, points_out, counts);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+// ---- recreate_hash / prune_map entries ---------------------------------------------------------------------------------
+extern "C" int clid_map_rehash(const float* points, const int64_t* idx, int32_t m, float resolution, int64_t* buffer_pt_index,
+                               int64_t buffer_size, void* stream) {
+  if (m < 0 || !(resolution > 0.f) || !buffer_pt_index || buffer_size <= 0 || buffer_size >= (1LL << 30) || (m > 0 && !points)) {
+    clid_set_error("clid_map_rehash: bad argument");
+    return CLID_E_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(buffer_pt_index, 0xFF, (size_t)buffer_size * 8, s) != hipSuccess) {  // -1 everywhere (:858-860)
+    clid_set_error("clid_map_rehash: table reset failed");
+    return CLID_E_HIP;
+  }
+  if (m == 0) return CLID_OK;
+  const unsigned blocks = (unsigned)((m + 255) / 256);
+  long long* table = reinterpret_cast<long long*>(buffer_pt_index);
+  const long long* list = reinterpret_cast<const long long*>(idx);
+  hipLaunchKernelGGL(k_rehash_claim, dim3(blocks), dim3(256), 0, s, points, list, m, resolution, table, (int)buffer_size);
+  hipLaunchKernelGGL(k_rehash_commit, dim3(blocks), dim3(256), 0, s, points, list, m, resolution, table, (int)buffer_size);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+extern "C" int clid_map_gather(const int64_t* idx, int32_t m, int64_t pad_src_row, const float* points, const float* orient,
+                               const int32_t* ts_create, const int32_t* ts_update, const float* cert, const float* feat,
+                               float* points_out, float* orient_out, int32_t* ts_create_out, int32_t* ts_update_out,
+                               float* cert_out, float* feat_out, void* stream) {
+  if (m < 0 || pad_src_row < 0 || !feat || !feat_out ||
+      (m > 0 && (!idx || !points || !orient || !ts_create || !ts_update || !cert || !points_out || !orient_out || !ts_create_out ||
+                 !ts_update_out || !cert_out))) {
+    clid_set_error("clid_map_gather: bad argument");
+    return CLID_E_ARG;
+  }
+  MapRows a{points, reinterpret_cast<const float4*>(orient), ts_create, ts_update, cert, reinterpret_cast<const float4*>(feat)};
+  MapRowsOut o{points_out, reinterpret_cast<float4*>(orient_out), ts_create_out, ts_update_out, cert_out,
+               reinterpret_cast<float4*>(feat_out)};
+  const long long threads = 2LL * ((long long)m + 1);
+  hipLaunchKernelGGL(k_map_gather, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(idx), m, (long long)pad_src_row, a, o);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+extern "C" int64_t clid_map_prune_workspace_bytes(int64_t n) { return clid_new_sample_workspace_bytes(n); }
+
+extern "C" int clid_map_prune_select(const int32_t* ts_update, const float* cert, int64_t n, const float* travel_dist,
+                                     int32_t cur_ts, float certainty_thre, float diff_travel_dist, int32_t global_prune,
+                                     int64_t* keep_idx_out, int64_t* count_out, void* workspace, void* stream) {
+  if (n < 0 || n >= (1LL << 31) || !count_out || !workspace || cur_ts < 0 ||
+      (n > 0 && (!ts_update || !cert || !keep_idx_out || (!global_prune && !travel_dist)))) {
+    clid_set_error("clid_map_prune_select: bad argument");
+    return CLID_E_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  long long* count = reinterpret_cast<long long*>(count_out);
+  if (n == 0) return hipMemsetAsync(count, 0, sizeof(long long), s) == hipSuccess ? CLID_OK : CLID_E_HIP;
+  char* ws = static_cast<char*>(workspace);
+  int* flag = reinterpret_cast<int*>(ws);
+  int* pos = reinterpret_cast<int*>(ws + align256((size_t)n * 4));
+  void* cub = ws + 2 * align256((size_t)n * 4);
+  size_t cub_bytes = pool_scan_bytes(n);
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_prune_flags, dim3(blocks), dim3(256), 0, s, ts_update, cert, (int)n, travel_dist, cur_ts, certainty_thre,
+                     diff_travel_dist, global_prune, flag);
+  if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)n, s) != hipSuccess) {
+    clid_set_error("clid_map_prune_select: scan failed");
+    return CLID_E_HIP;
+  }
+  hipLaunchKernelGGL(k_new_sample_list, dim3(blocks), dim3(256), 0, s, flag, pos, (int)n, 0LL,
+                     reinterpret_cast<long long*>(keep_idx_out), count, (const long long*)nullptr);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

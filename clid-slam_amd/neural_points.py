@@ -511,30 +511,76 @@ class NeuralPoints(nn.Module):
         the others (map merging, as vis_pin_map.py:121-123 does after loading a map)."""
         from .tools import voxel_down_sample_min_value_torch
 
-        self.buffer_pt_index = torch.full((self.buffer_size,), -1, dtype=self.idx_dtype, device=self.device)
         if with_ts:
             ts_used = ((self.point_ts_create + self.point_ts_update) / 2).int() if self.config.use_mid_ts else self.point_ts_create
             score = torch.abs(ts_used - cur_ts).float()
         else:
             score = self.point_certainties.max() - self.point_certainties
-        keep = voxel_down_sample_min_value_torch(self.neural_points, self.resolution, score)
-        if not kept_points:
-            self.neural_points = self.neural_points[keep]
-            self.point_orientations = self.point_orientations[keep]
-            self.point_ts_create = self.point_ts_create[keep]
-            self.point_ts_update = self.point_ts_update[keep]
-            self.point_certainties = self.point_certainties[keep]
-            pad = torch.cat((keep, torch.full((1,), -1, dtype=keep.dtype, device=keep.device)))
-            self.geo_features = self.geo_features[pad]
-            if self.color_features is not None:
-                self.color_features = self.color_features[pad]
-            keep = torch.arange(self.count(), dtype=self.idx_dtype, device=self.device)
-        cells = torch.floor(self.neural_points[keep] / self.resolution).to(self.primes)
-        slot = torch.fmod((cells * self.primes).sum(-1), int(self.buffer_size))
-        self._assign_slots(slot, keep.to(self.idx_dtype))
+        keep = voxel_down_sample_min_value_torch(self.neural_points, self.resolution, score)  # HIP kernels for device tensors
+        if self._maintenance_fused_ok():
+            self._recreate_hash_fused(keep, kept_points)
+        else:
+            self.buffer_pt_index = torch.full((self.buffer_size,), -1, dtype=self.idx_dtype, device=self.device)
+            if not kept_points:
+                self.neural_points = self.neural_points[keep]
+                self.point_orientations = self.point_orientations[keep]
+                self.point_ts_create = self.point_ts_create[keep]
+                self.point_ts_update = self.point_ts_update[keep]
+                self.point_certainties = self.point_certainties[keep]
+                pad = torch.cat((keep, torch.full((1,), -1, dtype=keep.dtype, device=keep.device)))
+                self.geo_features = self.geo_features[pad]
+                if self.color_features is not None:
+                    self.color_features = self.color_features[pad]
+                keep = torch.arange(self.count(), dtype=self.idx_dtype, device=self.device)
+            cells = torch.floor(self.neural_points[keep] / self.resolution).to(self.primes)
+            slot = torch.fmod((cells * self.primes).sum(-1), int(self.buffer_size))
+            self._assign_slots(slot, keep.to(self.idx_dtype))
         self._map_version += 1
         if sensor_position is not None:
             self.reset_local_map(sensor_position, sensor_orientation, cur_ts)
+
+    def _maintenance_fused_ok(self) -> bool:
+        """prune_map / recreate_hash through csrc/mapops.hip: device-resident fp32 / int32 / int64 arrays, 8 feature
+        channels, a table the kernels can address."""
+        return (self.neural_points.is_cuda and self.neural_points.dtype == torch.float32 and self.idx_dtype == torch.int64
+                and self.geo_features.dtype == torch.float32 and self.geo_features.shape[1] == 8
+                and self.point_ts_create.dtype == torch.int32 and self.point_ts_update.dtype == torch.int32
+                and self.point_certainties.dtype == torch.float32 and self.point_orientations.dtype == torch.float32
+                and int(self.buffer_size) < (1 << 30) and os.environ.get("CLID_FUSED_MAINTENANCE", "1") != "0")
+
+    def _gather_rows_fused(self, keep: torch.Tensor, pad_src_row: int) -> None:
+        """Rows `keep` of the six global arrays into fresh, exactly sized tensors in ONE launch (`clid_map_gather`); the
+        padding row of the feature table comes from row `pad_src_row`."""
+        lib = _lib.load()
+        m, dev = int(keep.shape[0]), self.neural_points.device
+        src = [t.contiguous() for t in (self.neural_points, self.point_orientations, self.point_ts_create, self.point_ts_update,
+                                        self.point_certainties, self.geo_features)]
+        out = [torch.empty((m, 3), device=dev, dtype=torch.float32), torch.empty((m, 4), device=dev, dtype=torch.float32),
+               torch.empty(m, device=dev, dtype=torch.int32), torch.empty(m, device=dev, dtype=torch.int32),
+               torch.empty(m, device=dev, dtype=torch.float32), torch.empty((m + 1, 8), device=dev, dtype=torch.float32)]
+        keep = keep.contiguous()
+        _lib.check(lib.clid_map_gather(_lib.ptr(keep) if m else None, m, int(pad_src_row), *[_lib.ptr(t) if t.numel() else None for t in src],
+                                       *[_lib.ptr(t) if t.numel() else None for t in out], _lib.stream()), "clid_map_gather")
+        if self.color_features is not None:
+            pad = torch.cat((keep, torch.full((1,), int(pad_src_row), dtype=keep.dtype, device=dev)))
+            self.color_features = self.color_features.index_select(0, pad)
+        (self.neural_points, self.point_orientations, self.point_ts_create, self.point_ts_update, self.point_certainties,
+         self.geo_features) = out
+
+    def _recreate_hash_fused(self, keep: torch.Tensor, kept_points: bool) -> None:
+        """model/neural_points.py:858-925 behind the selection: (merging) one gather launch, then the table reset and
+        the last-writer fill (`clid_map_rehash`: memset + two launches instead of a sort over the slots)."""
+        lib = _lib.load()
+        if self.buffer_pt_index is None or self.buffer_pt_index.numel() != int(self.buffer_size) or not self.buffer_pt_index.is_cuda:
+            self.buffer_pt_index = torch.empty((self.buffer_size,), dtype=self.idx_dtype, device=self.device)
+        if not kept_points:
+            self._gather_rows_fused(keep, self.geo_features.shape[0] - 1)
+            keep = None
+        m = int(self.count()) if keep is None else int(keep.shape[0])
+        pts = self.neural_points.contiguous()
+        _lib.check(lib.clid_map_rehash(_lib.ptr(pts) if m else None, None if keep is None else keep.contiguous().data_ptr(), m,
+                                       float(self.resolution), self.buffer_pt_index.data_ptr(), int(self.buffer_size), _lib.stream()),
+                   "clid_map_rehash")
 
     def clear_temp(self, clean_more: bool = False):
         """model/neural_points.py:1053-1075."""
@@ -557,6 +603,8 @@ class NeuralPoints(nn.Module):
     def prune_map(self, prune_certainty_thre, min_prune_count=500, global_prune=False):
         """model/neural_points.py:771-812: drop uncertain points that have left the travel-distance window (or all
         uncertain ones); returns True when something was pruned (the caller then recreates the hash)."""
+        if self._maintenance_fused_ok() and self.count() > 0:
+            return self._prune_map_fused(prune_certainty_thre, min_prune_count, global_prune)
         uncertain = self.point_certainties < prune_certainty_thre
         if global_prune:
             prune = uncertain
@@ -575,6 +623,27 @@ class NeuralPoints(nn.Module):
         self.geo_features = self.geo_features.index_select(0, pad)
         if self.color_features is not None:
             self.color_features = self.color_features.index_select(0, pad)
+        self._map_version += 1
+        return True
+
+    def _prune_map_fused(self, prune_certainty_thre, min_prune_count, global_prune) -> bool:
+        """model/neural_points.py:779-808 as flags -> scan -> index list (`clid_map_prune_select`), ONE read-back (the
+        number of points that stay), and -- only when enough points go -- one gather launch over the six arrays."""
+        lib = _lib.load()
+        n, dev = int(self.count()), self.neural_points.device
+        need = int(lib.clid_map_prune_workspace_bytes(n))
+        ws = torch.empty(need + 256, device=dev, dtype=torch.uint8)
+        keep = torch.empty(n, device=dev, dtype=torch.int64)
+        count = torch.zeros(1, device=dev, dtype=torch.int64)
+        travel = None if global_prune else self.travel_dist.to(device=dev, dtype=torch.float32).contiguous()
+        _lib.check(lib.clid_map_prune_select(
+            self.point_ts_update.contiguous().data_ptr(), self.point_certainties.contiguous().data_ptr(), n, _lib.ptr(travel),
+            int(self.cur_ts), float(prune_certainty_thre), float(self.diff_travel_dist_local), int(bool(global_prune)),
+            keep.data_ptr(), count.data_ptr(), ws.data_ptr(), _lib.stream()), "clid_map_prune_select")
+        kept = _lib.read_counts(count, 1)[0]
+        if n - kept <= min_prune_count:
+            return False
+        self._gather_rows_fused(keep[:kept], self.geo_features.shape[0] - 1)
         self._map_version += 1
         return True
 

@@ -8,6 +8,7 @@ library.
 """
 from __future__ import annotations
 
+import os
 import time
 
 import torch
@@ -68,9 +69,10 @@ def get_time():
 _VOX_WS = {}
 
 
-def _voxel_down_sample_hip(points: torch.Tensor, voxel_size: float):
-    """`clid_voxel_down_sample` (csrc/mapops.hip): bounding box -> hash insert with a 64-bit atomicMin per voxel ->
-    compaction -> radix sort of the occupied voxels; 6 launches and one host round trip instead of ~40 torch ops."""
+def _voxel_down_sample_hip(points: torch.Tensor, voxel_size: float, value: torch.Tensor = None):
+    """`clid_voxel_down_sample` / `clid_voxel_down_sample_min_value` (csrc/mapops.hip): bounding box -> hash insert with
+    a 64-bit atomicMin per voxel -> compaction -> radix sort of the occupied voxels; 6 launches and one host round trip
+    instead of ~40 torch ops."""
     import ctypes as C  # noqa: F401
 
     from . import _lib
@@ -85,7 +87,12 @@ def _voxel_down_sample_hip(points: torch.Tensor, voxel_size: float):
     if ws is None or ws.numel() < need:
         ws = _VOX_WS[pts.device] = torch.empty(int(need * 1.25) + 256, device=pts.device, dtype=torch.uint8)
     out = torch.empty(n, device=pts.device, dtype=torch.int64)
-    m = lib.clid_voxel_down_sample(pts.data_ptr(), n, float(voxel_size), ws.data_ptr(), out.data_ptr(), _lib.stream())
+    if value is None:
+        m = lib.clid_voxel_down_sample(pts.data_ptr(), n, float(voxel_size), ws.data_ptr(), out.data_ptr(), _lib.stream())
+    else:
+        val = value.detach().to(device=pts.device, dtype=torch.float32).contiguous()
+        m = lib.clid_voxel_down_sample_min_value(pts.data_ptr(), n, float(voxel_size), val.data_ptr(), ws.data_ptr(),
+                                                 out.data_ptr(), _lib.stream())
     if m < 0:
         _lib.check(m, "clid_voxel_down_sample")
     return out[:m]
@@ -123,7 +130,11 @@ def voxel_down_sample_torch(points: torch.Tensor, voxel_size: float):
 def voxel_down_sample_min_value_torch(points: torch.Tensor, voxel_size: float, value: torch.Tensor):
     """Indices of one point per voxel: the one with the smallest `value` (quantised to 1000 levels of value.max()),
     lowest index among equals; voxels in ascending order of the reference's linear voxel id (stride = max cell
-    coordinate, as above).  Selection rule of utils/tools.py:685-724, written with sorts (deterministic)."""
+    coordinate, as above).  Selection rule of utils/tools.py:685-724; device tensors through the HIP kernels, host
+    tensors written with sorts (deterministic)."""
+    if (points.is_cuda and points.shape[0] > 0 and points.dim() == 2 and points.shape[1] == 3 and value.shape[0] == points.shape[0]
+            and os.environ.get("CLID_FUSED_MAINTENANCE", "1") != "0"):
+        return _voxel_down_sample_hip(points, voxel_size, value)
     cell = torch.floor(points / voxel_size).long() - torch.floor(points.min(dim=0)[0] / voxel_size).long()
     v = cell.max()
     flat = cell[:, 0] + cell[:, 1] * v + cell[:, 2] * v * v

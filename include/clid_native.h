@@ -396,6 +396,32 @@ int clid_transform_points(const float* points, int32_t n, const float* pose12_ho
 int64_t clid_voxel_workspace_bytes(int32_t n);
 int clid_voxel_down_sample(const float* points, int32_t n, float voxel_size, void* workspace, int64_t* idx_out,
                            void* stream);
+/* voxel_down_sample_min_value_torch (utils/tools.py:685-724): as above, but the point of a voxel with the smallest
+ * `value` [n] (>= 0; quantised to 1000 levels of its maximum, lowest index among equals) is taken -- the selection
+ * NeuralPoints.recreate_hash makes with |ts - cur_ts| or (max certainty - certainty) (model/neural_points.py:864-882).
+ * A maximum of 0 (the reference divides 0 / 0 there) selects the lowest index of every voxel. */
+int clid_voxel_down_sample_min_value(const float* points, int32_t n, float voxel_size, const float* value, void* workspace,
+                                     int64_t* idx_out, void* stream);
+
+/* Table fill of NeuralPoints.recreate_hash (model/neural_points.py:858-860, 886-892 / 918-925): buffer_pt_index[:] = -1,
+ * then buffer_pt_index[slot(points[src])] = src for p = 0..m-1 with src = idx[p] (idx == NULL: src = p); of several
+ * entries naming one slot the last one stays (the reference's CPU result).  points [.][3]. */
+int clid_map_rehash(const float* points, const int64_t* idx, int32_t m, float resolution, int64_t* buffer_pt_index,
+                    int64_t buffer_size, void* stream);
+/* Rows idx[0..m) of the global arrays into fresh ones (NeuralPoints.prune_map :795-808, the merging branch of
+ * recreate_hash :898-913): points [.,3], orient [.,4], ts_create / ts_update i32, cert f32, feat [.,8] whose output row m
+ * (the padding row) is input row `pad_src_row`. */
+int clid_map_gather(const int64_t* idx, int32_t m, int64_t pad_src_row, const float* points, const float* orient,
+                    const int32_t* ts_create, const int32_t* ts_update, const float* cert, const float* feat,
+                    float* points_out, float* orient_out, int32_t* ts_create_out, int32_t* ts_update_out, float* cert_out,
+                    float* feat_out, void* stream);
+/* Selection of NeuralPoints.prune_map (model/neural_points.py:779-791): ascending indices of the points that STAY
+ * (certainty >= thre, or -- unless global_prune -- still inside the travel-distance window) -> keep_idx_out [n capacity],
+ * their number -> count_out[0] (device).  workspace: clid_map_prune_workspace_bytes(n). */
+int64_t clid_map_prune_workspace_bytes(int64_t n);
+int clid_map_prune_select(const int32_t* ts_update, const float* cert, int64_t n, const float* travel_dist, int32_t cur_ts,
+                          float certainty_thre, float diff_travel_dist, int32_t global_prune, int64_t* keep_idx_out,
+                          int64_t* count_out, void* workspace, void* stream);
 
 /* Training-pool maintenance of Mapper.process_frame (utils/mapper.py:297-392) in one enqueue: the pool `a` (n_a samples)
  * followed by this frame's samples `b` (n_b) -- coord / global_coord [.,3] f32, sdf label, weight f32, time i32 -- are

@@ -75,6 +75,66 @@ def test_prune_and_recreate_hash_on_the_gpu_match_the_reference():
     _g11_run("cuda")
 
 
+def _random_map(n, buffer_size, seed):
+    from clid_slam_amd import NeuralPoints
+    from clid_slam_amd.config import HotPathConfig
+
+    cfg = HotPathConfig()
+    cfg.device = "cuda"
+    cfg.buffer_size = buffer_size
+    nm = NeuralPoints(cfg)
+    g = torch.Generator().manual_seed(seed)
+    nm.neural_points = ((torch.rand((n, 3), generator=g) - 0.5) * torch.tensor([60.0, 40.0, 6.0])).cuda()
+    nm.point_orientations = torch.nn.functional.normalize(torch.randn((n, 4), generator=g), dim=1).cuda()
+    nm.point_ts_create = torch.randint(0, 40, (n,), generator=g, dtype=torch.int32).cuda()
+    nm.point_ts_update = (nm.point_ts_create + torch.randint(0, 10, (n,), generator=g, dtype=torch.int32).cuda()).int()
+    nm.point_certainties = (torch.rand(n, generator=g) * 4.0).cuda()
+    nm.geo_features = torch.cat((torch.randn((n, 8), generator=g), torch.zeros(1, 8)), 0).cuda()
+    nm.travel_dist = (torch.arange(64, dtype=torch.float32) * 1.7).cuda()
+    nm.cur_ts = 49
+    nm.diff_travel_dist_local = 30.0
+    return nm
+
+
+_MAP_ARRAYS = ("neural_points", "point_orientations", "point_ts_create", "point_ts_update", "point_certainties", "geo_features",
+               "buffer_pt_index")
+
+
+@pytest.mark.parametrize("n,buffer_size", [(40_000, 1 << 22), (25_000, 4093), (3, 1 << 16)])
+@pytest.mark.parametrize("global_prune", [False, True])
+def test_prune_and_recreate_hash_kernels_vs_the_torch_chain(monkeypatch, n, buffer_size, global_prune):
+    """NeuralPoints.prune_map / recreate_hash (model/neural_points.py:771-812, 840-929) through clid_map_prune_select /
+    clid_map_gather / clid_voxel_down_sample_min_value / clid_map_rehash against the same methods as torch op chains
+    (CLID_FUSED_MAINTENANCE=0; pinned on the reference by G11): every array and the whole slot table bit for bit, incl. a
+    table of 4093 slots where most slots are named by several points (last writer stays)."""
+    got = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("CLID_FUSED_MAINTENANCE", fused)
+        nm = _random_map(n, buffer_size, seed=n)
+        out = [nm.prune_map(1.5, min_prune_count=2 if n > 3 else 0, global_prune=global_prune)]
+        nm.recreate_hash(None, None, True, True, 49)
+        out += [getattr(nm, k).clone() for k in _MAP_ARRAYS]
+        nm.recreate_hash(None, None, True, False, 49)
+        out += [nm.buffer_pt_index.clone()]
+        nm.recreate_hash(torch.zeros(3, device="cuda"), torch.eye(3, device="cuda"), False, False, 49)
+        out += [getattr(nm, k).clone() for k in _MAP_ARRAYS] + [nm.local_neural_points.clone(), nm.global2local.clone()]
+        got[fused] = out
+    assert got["1"][0] == got["0"][0] and (n <= 3 or got["1"][0] is True)
+    assert len(got["1"]) == len(got["0"])
+    for a, b in zip(got["1"][1:], got["0"][1:]):
+        assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b)
+    m = got["1"][1].shape[0]
+    assert got["1"][6].shape[0] == m + 1 and (n <= 3 or m < n)
+
+
+def test_prune_map_below_the_minimum_count_changes_nothing():
+    nm = _random_map(5000, 1 << 20, seed=5)
+    before = [getattr(nm, k).clone() for k in _MAP_ARRAYS[:-1]]
+    assert nm.prune_map(1.5, min_prune_count=5000) is False
+    for k, b in zip(_MAP_ARRAYS[:-1], before):
+        assert torch.equal(getattr(nm, k), b)
+
+
 def _splitmix64(x):
     M = (1 << 64) - 1
     x = (x + 0x9E3779B97F4A7C15) & M
