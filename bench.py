@@ -357,6 +357,8 @@ def main():
                 "neural_points_local": M, "pool_samples": int(mp.pool_sample_count), "buffer_size": cfg.buffer_size,
                 "parallelism": f"dp{world} (batch sharded, RCCL all-reduce of [decoder|feature] grads)" if world > 1 else "single GPU",
                 "rccl_ranks_in_c_abi": rccl_ranks,
+                "gradient_exchange": None if world == 1 or not mp.last_exchange else {
+                    k: mp.last_exchange[k] for k in ("mode", "transport", "bytes_per_iter", "dense_bytes_per_iter")},
             },
             "final_loss": {"total": losses[0], "bce": losses[1], "eikonal": losses[2]},
             "per_frame_regime": frame, "roofline": roof, "cpu_baseline": base,

@@ -53,7 +53,7 @@ class TrainArgs(C.Structure):
         # per-call switches and aids (ABI 3: no process-global state in the library)
         ("decode_variant", _i32), ("pipeline", _i32), ("sdf_dbg", _vp), ("prof", _vp),
         # touched-row bookkeeping of the hoisted-search loop (NULL = dense exchange / dense Adam sweep)
-        ("touch_ws", _vp), ("touch_stride", _i64), ("touch_iter", _i32), ("touch_pad", _i32), ("cbuf", _vp),
+        ("touch_ws", _vp), ("touch_stride", _i64), ("touch_iter", _i32), ("touch_pad", _i32), ("cbuf", _vp), ("p2p", _vp),
     ]
 
 
@@ -143,6 +143,17 @@ _SIGS = {
     "clid_comm_unique_id": (C.c_int, [_vp]),
     "clid_comm_init": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
     "clid_comm_size": (C.c_int, [_vp]),
+    "clid_p2p_blob_bytes": (_i64, []),
+    "clid_p2p_create": (C.c_int, [_i32, _i32, _i64, _vp, _vp]),
+    "clid_p2p_connect": (C.c_int, [_vp, _vp]),
+    "clid_p2p_selftest": (C.c_int, [_vp, _vp]),
+    "clid_p2p_world": (_i32, [_vp]),
+    "clid_p2p_capacity": (_i64, [_vp]),
+    "clid_p2p_buffer": (_vp, [_vp]),
+    "clid_p2p_allreduce": (C.c_int, [_vp, _i64, _vp]),
+    "clid_p2p_status": (C.c_int, [_vp, _vp]),
+    "clid_p2p_destroy": (C.c_int, [_vp]),
+    "clid_debug_copy": (C.c_int, [_vp, _vp, _i64, _vp]),
     "clid_comm_available": (C.c_int, []),
     "clid_comm_allreduce": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "clid_comm_destroy": (C.c_int, [_vp]),
@@ -263,6 +274,66 @@ def rccl_comm(dist):
     if ptr_out:
         lib.clid_comm_destroy(ptr_out)
     return None
+
+
+_p2p = None  # peer-mapped exchange object of this process: None = not tried, False = unavailable, else (pointer, capacity)
+
+
+def p2p_exchange(dist, need_bytes: int):
+    """The process-wide peer-mapped exchange object behind the C ABI (clid_p2p_*, csrc/p2p.hip), created collectively on
+    first use (and re-created when `need_bytes` outgrows it -- every rank sees the same map, so every rank decides alike):
+    each rank allocates its exchange buffers, the HIP IPC blobs are gathered over torch.distributed, every rank maps its
+    peers and runs the collective self-test; the object is used only if EVERY rank reports success (MIN), else None and the
+    callers keep RCCL / torch.distributed for the payload.  CLID_P2P=0 switches it off."""
+    global _p2p
+    if _p2p is False:
+        return None
+    if _p2p is not None and _p2p[1] >= need_bytes:
+        return _p2p[0]
+    lib = load()
+    old = _p2p
+    _p2p = False
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if os.environ.get("CLID_P2P", "1") == "0" or world > 8:
+        return None
+    dev = torch.device("cuda", torch.cuda.current_device())
+    wire = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+
+    def agree(flag: bool) -> bool:
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=wire)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    torch.cuda.synchronize(dev)
+    if old:
+        lib.clid_p2p_destroy(old[0])
+    cap = max(2 * int(need_bytes), 16 << 20)
+    nb = int(lib.clid_p2p_blob_bytes())
+    blob = (C.c_uint8 * nb)()
+    obj = _vp()
+    made = lib.clid_p2p_create(rank, world, cap, C.byref(obj), blob) == 0
+    mine = torch.tensor(list(blob), dtype=torch.uint8, device=wire)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    ok = agree(made)
+    if ok:
+        flat = torch.cat(parts).cpu().tolist()
+        ok = agree(lib.clid_p2p_connect(obj, (C.c_uint8 * (nb * world))(*flat)) == 0)
+    if ok:
+        ok = agree(lib.clid_p2p_selftest(obj, stream()) == 0)
+    if not ok:
+        if made:
+            torch.cuda.synchronize(dev)
+            lib.clid_p2p_destroy(obj)
+        return None
+    _p2p = (obj, cap)
+    return obj
+
+
+def p2p_likely(dist) -> bool:
+    """True while the peer-mapped exchange has not been ruled out for this process (not yet tried, or set up): the sharded
+    loop then prefers the compact exchange at every map size, because that is the payload the object carries."""
+    return _p2p is not False and os.environ.get("CLID_P2P", "1") != "0" and dist.get_world_size() <= 8
 
 
 def check(rc: int, what: str) -> None:

@@ -1644,7 +1644,14 @@ extern "C" int clid_mapping_run_dist(const clid_map_view* mv, const clid_train_a
   }
   int32_t counts[kMaxChunkIters];
   long long moved = 0;
+  // peer-mapped exchange (csrc/p2p.hip) for the compact buffer when the object fits this call -- a decision every rank
+  // makes alike (same world, same M, same capacity)
+  clid_p2p* px = compact ? ta.p2p : nullptr;
+  if (px && (clid_p2p_world(px) != clid_comm_size(comm) ||
+             clid_p2p_capacity(px) < (int64_t)sizeof(float) * (CLID_GRAD_FEAT_OFFSET16 + 9LL * (mv->M + 1) + 4)))
+    px = nullptr;
   for (int it = 0; it < iters; ++it) {
+    if (px) ta.cbuf = static_cast<float*>(clid_p2p_buffer(px));
     ta.index = index_base + (int64_t)it * index_stride;
     ta.loss_out = loss_base + (size_t)it * 4;
     ta.touch_iter = it % chunk;
@@ -1665,7 +1672,11 @@ extern "C" int clid_mapping_run_dist(const clid_map_view* mv, const clid_train_a
     }
     if (compact) {
       const int64_t n = CLID_GRAD_FEAT_OFFSET16 + 9LL * counts[it % chunk];
-      if (int e = clid_comm_allreduce(comm, ta.cbuf, n, 0, 0, stream)) return e;
+      if (px) {
+        if (int e = clid_p2p_allreduce(px, n, stream)) return e;
+      } else if (int e = clid_comm_allreduce(comm, ta.cbuf, n, 0, 0, stream)) {
+        return e;
+      }
       moved += n;
     } else {
       if (int e = clid_comm_allreduce(comm, ta.grad, grad_floats, 0, 0, stream)) return e;
@@ -1680,6 +1691,8 @@ extern "C" int clid_mapping_run_dist(const clid_map_view* mv, const clid_train_a
       if (int e = clid_comm_allreduce(comm, mv->ts_update, mv->M, 1, 1, stream)) return e;
   }
   if (exchanged_floats_host) *exchanged_floats_host = moved;
+  if (px && iters > 0)
+    if (int e = clid_p2p_status(px, stream)) return e;
   return CLID_OK;
 }
 

@@ -335,7 +335,8 @@ class Mapper:
         # local map.  CLID_SPARSE = 0 / 1 / auto.
         M_local = n_feat // _lib.F - 1
         mode = os.environ.get("CLID_SPARSE", "auto")
-        want = mode == "1" or (mode != "0" and M_local >= (self.SPARSE_MIN_ROWS_DIST if dist else self.SPARSE_MIN_ROWS))
+        floor = self.SPARSE_MIN_ROWS if not dist else (0 if _lib.p2p_likely(dist) else self.SPARSE_MIN_ROWS_DIST)
+        want = mode == "1" or (mode != "0" and M_local >= floor)
         use_touch = bool(want and tile and float(cfg.weight_decay) == 0.0)
         cbuf = None
         if use_touch:
@@ -373,6 +374,10 @@ class Mapper:
                 cert_in_rows = tile
                 cert0 = None if cert_in_rows else nm.local_point_certainties.clone()
                 comm = _lib.rccl_comm(dist)
+                if cbuf is not None and hoist:
+                    # compact exchange: the per-iteration payload goes over peer-mapped buffers when every rank could set
+                    # them up (csrc/p2p.hip: one launch per rank instead of an RCCL ring), RCCL / torch.distributed otherwise
+                    ta.p2p = _lib.p2p_exchange(dist, 4 * cbuf.numel())
                 shard_base = idx_base + batch_offset * 8
                 if comm is not None:
                     # RCCL behind the C ABI: the whole sharded loop is ONE host call, the all-reduce sits on the launch
@@ -389,6 +394,7 @@ class Mapper:
                     moved = self._mapping_loop_torch_dist(lib, dist, view, ta, aa, grad, cbuf, iter_count, shard_base, row_bytes,
                                                           loss_base, hoist, bs_local, batch_offset, decim, eik_mode, dev, stream)
                 self.last_exchange = {"mode": "compact" if (use_touch and hoist) else "dense", "iters": iter_count,
+                                      "transport": "peer-mapped" if ta.p2p else ("rccl" if comm is not None else "torch.distributed"),
                                       "floats": moved, "bytes_per_iter": 4.0 * moved / max(iter_count, 1),
                                       "dense_bytes_per_iter": 4.0 * grad.numel(), "rows": M_local + 1}
         except Exception:
@@ -459,7 +465,10 @@ class Mapper:
                 self._rec = torch.empty(per_iter * chunk, device=dev, dtype=torch.float32)
         counts = (C.c_int32 * 32)()
         M_local = int(view.M)
+        px = ta.p2p if compact else None
         for it in range(iter_count):
+            if px:
+                ta.cbuf = lib.clid_p2p_buffer(px)
             ta.index = shard_base + it * row_bytes
             ta.loss_out = loss_base + it * 16
             ta.touch_iter = it % chunk
@@ -481,13 +490,18 @@ class Mapper:
                 _lib.check(lib.clid_train_fwd_bwd(C.byref(view), C.byref(ta), stream), "clid_train_fwd_bwd")
             if compact:
                 n = _lib.GRAD_FEAT_OFFSET16 + 9 * int(counts[it % chunk])
-                dist.all_reduce(cbuf[:n])
+                if px:
+                    _lib.check(lib.clid_p2p_allreduce(px, n, stream), "clid_p2p_allreduce")
+                else:
+                    dist.all_reduce(cbuf[:n])
                 moved += n
             else:
                 dist.all_reduce(grad)
                 moved += grad.numel()
             aa.step = it + 1
             _lib.check(lib.clid_train_adam(C.byref(aa), C.byref(ta), stream), "clid_train_adam")
+        if px and iter_count > 0:
+            _lib.check(lib.clid_p2p_status(px, stream), "clid_p2p_status")
         return moved
 
     def _check_replicas(self, dist):

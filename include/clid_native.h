@@ -242,6 +242,11 @@ typedef struct clid_train_args {
   int32_t touch_iter;
   int32_t touch_pad;
   float* cbuf;
+  /* world > 1, compact exchange only: peer-mapped exchange buffers (clid_p2p_*, below).  clid_mapping_run_dist then packs
+   * every iteration into the object's current buffer instead of `cbuf` and sums it over the ranks with ONE launch per
+   * rank instead of an RCCL ring; NULL, a rank count other than the communicator's, or a capacity below
+   * 848 + 9 (M + 1) floats keep RCCL for the call. */
+  struct clid_p2p* p2p;
 } clid_train_args;
 
 /* Touched-row workspace (see clid_train_args.touch_ws).  clid_train_touch_scan turns the chunk's flags (after the
@@ -321,6 +326,38 @@ int clid_comm_available(void);
 int clid_comm_allreduce(clid_comm* comm, void* buf, int64_t count, int32_t dtype, int32_t op_max, void* stream);
 int clid_comm_destroy(clid_comm* comm);
 
+/* ---- gradient exchange over peer-mapped buffers (csrc/p2p.hip; new -- the reference is single-GPU) --------------------
+ * The per-iteration payload of the sharded loop is 0.1 - 2.5 MB: a ring all-reduce over P GPUs is bound by its 2 (P - 1)
+ * latency steps there.  xGMI is all-to-all, so one launch per rank does: barrier | rank r sums slice r of every rank's
+ * buffer in rank order into its own | barrier | copies the other slices from their owners -- two hops, bit-identical
+ * sums on every rank.
+ *   clid_p2p_create    allocates 2 exchange buffers of capacity_bytes (used alternately) + flag words on the current device
+ *                      and writes this rank's export blob (clid_p2p_blob_bytes() bytes, HIP IPC handles);
+ *   clid_p2p_connect   takes the blobs of ALL ranks in rank order (the host gathers them with its own mechanism, like the
+ *                      RCCL id) and maps the peers' memory;
+ *   clid_p2p_selftest  collective: exchanges of exactly representable patterns on both buffers, verified on the device;
+ *                      0 = every element right and no wait timed out on this rank.  The caller agrees on the result over
+ *                      the ranks (MIN) before handing the object to clid_train_args.p2p;
+ *   clid_p2p_buffer    the buffer the NEXT clid_p2p_allreduce works on: fill it, exchange, read the sums from it;
+ *   clid_p2p_allreduce in-place SUM of its first count_floats floats over the ranks (one launch on `stream`; collective:
+ *                      every rank issues the same sequence of exchanges);
+ *   clid_p2p_status    0 unless a flag wait gave up (a peer did not arrive within ~2 s: the exchange's result is then
+ *                      undefined and the object must not be used further); synchronises `stream`.
+ * At most 8 ranks, one node. */
+typedef struct clid_p2p clid_p2p;
+int64_t clid_p2p_blob_bytes(void);
+int clid_p2p_create(int32_t rank, int32_t world, int64_t capacity_bytes, clid_p2p** out, uint8_t* blob_out_host);
+int clid_p2p_connect(clid_p2p* p, const uint8_t* blobs_host /* [world][clid_p2p_blob_bytes()] */);
+int clid_p2p_selftest(clid_p2p* p, void* stream);
+int32_t clid_p2p_world(const clid_p2p* p);
+int64_t clid_p2p_capacity(const clid_p2p* p); /* bytes of one exchange buffer */
+void* clid_p2p_buffer(clid_p2p* p);
+int clid_p2p_allreduce(clid_p2p* p, int64_t count_floats, void* stream);
+int clid_p2p_status(clid_p2p* p, void* stream);
+int clid_p2p_destroy(clid_p2p* p);
+/* test aid: device-to-device copy on `stream` (the exchange buffers are not tensors of the host framework) */
+int clid_debug_copy(void* dst, const void* src, int64_t bytes, void* stream);
+
 /* Mapper.mapping on one rank of a data-parallel group in ONE host call: this rank's slice of
  * every batch (index_base = its first element of iteration 0, row stride index_stride; t->batch_offset, t->inv_n_main,
  * t->inv_n_eik carry the global lattice phase and normalisers), per iteration decode/backward -> RCCL all-reduce (SUM) on
@@ -329,7 +366,9 @@ int clid_comm_destroy(clid_comm* comm);
  *   dense    (t->touch_ws or t->cbuf NULL) the fused gradient buffer `t->grad` [grad_floats = 848 + 16 (M + 1)];
  *   compact  (both given) [848 decoder gradients | 9 floats per map row THIS iteration touches]: once per chunk of
  *            iterations the touched-row flags (M bytes per iteration) are MAX-reduced over the ranks and the list lengths
- *            come back to the host (one synchronisation per chunk); see clid_train_args.touch_ws.
+ *            come back to the host (one synchronisation per chunk); see clid_train_args.touch_ws.  With t->p2p the
+ *            compact buffer is summed over peer-mapped memory instead of by RCCL (the flags, losses and stamps still go
+ *            through `comm`), and the call ends with clid_p2p_status (one more synchronisation).
  * With the tile decode kernels the certainty increments travel with the gradient rows; with kernel 0 (dense only) the
  * caller merges its certainty deltas itself.  exchanged_floats_host (may be NULL): 4-byte words this rank contributed to
  * all-reduces during the loop (payload accounting for the benches). */

@@ -70,7 +70,8 @@ def _run(rank, world, port, out_dir, backend, ln, sparse="0"):
         np.savez(os.path.join(out_dir, f"{backend or 'single'}_w{world}.npz"), theta=nm.local_geo_features.detach().cpu().numpy(),
                  W1=dec.flat_params()[0].detach().cpu().numpy(), cert=nm.local_point_certainties.cpu().numpy(),
                  ts=nm.local_point_ts_update.cpu().numpy(), loss=mpr.last_losses.cpu().numpy(), rccl=np.array(used_rccl),
-                 compact=np.array(bool(mpr.last_exchange and mpr.last_exchange["mode"] == "compact")))
+                 compact=np.array(bool(mpr.last_exchange and mpr.last_exchange["mode"] == "compact")),
+                 peer=np.array(bool(mpr.last_exchange and mpr.last_exchange["transport"] == "peer-mapped")))
     if backend:
         dist.barrier()
         dist.destroy_process_group()
@@ -95,6 +96,9 @@ def test_sharded_loop_in_c_with_one_shard_equals_the_single_gpu_loop(tmp_path, l
     a, b = np.load(os.path.join(tmp_path, "single_w1.npz")), np.load(os.path.join(tmp_path, "nccl_w1.npz"))
     assert bool(b["rccl"]), "the RCCL communicator behind the C ABI was not used"
     assert bool(b["compact"]) == (sparse == "1")
+    # the compact payload goes through the peer-mapped exchange object inside clid_mapping_run_dist (buffer alternation,
+    # Adam reading the exchange buffers, the closing status check; with one rank the exchange itself is the identity)
+    assert bool(b["peer"]) == (sparse == "1")
     _compare(a, b)
 
 
@@ -105,5 +109,5 @@ def test_two_ranks_over_rccl_equal_one(tmp_path):
     for sparse in ("0", "1"):
         mp.spawn(_run, args=(2, port + int(sparse), str(tmp_path), "nccl", 0, sparse), nprocs=2, join=True)
         a, b = np.load(os.path.join(tmp_path, "single_w1.npz")), np.load(os.path.join(tmp_path, "nccl_w2.npz"))
-        assert bool(b["rccl"]) and bool(b["compact"]) == (sparse == "1")
+        assert bool(b["rccl"]) and bool(b["compact"]) == (sparse == "1") and bool(b["peer"]) == (sparse == "1")
         _compare(a, b)
