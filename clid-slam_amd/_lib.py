@@ -53,7 +53,7 @@ class TrainArgs(C.Structure):
         # per-call switches and aids (ABI 3: no process-global state in the library)
         ("decode_variant", _i32), ("pipeline", _i32), ("sdf_dbg", _vp), ("prof", _vp),
         # touched-row bookkeeping of the hoisted-search loop (NULL = dense exchange / dense Adam sweep)
-        ("touch_ws", _vp), ("touch_stride", _i64), ("touch_iter", _i32), ("touch_pad", _i32), ("cbuf", _vp), ("p2p", _vp),
+        ("touch_ws", _vp), ("touch_stride", _i64), ("touch_iter", _i32), ("touch_all", _i32), ("cbuf", _vp), ("p2p", _vp),
     ]
 
 

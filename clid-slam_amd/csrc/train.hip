@@ -1659,7 +1659,16 @@ extern "C" int clid_mapping_run_dist(const clid_map_view* mv, const clid_train_a
       if (it % chunk == 0) {
         const int n_it = (iters - it) < chunk ? (iters - it) : chunk;
         if (int e = clid_train_search(mv, &ta, n_it, ta.index, index_stride, ws.rec, stream)) return e;
-        if (ta.touch_ws) {
+        if (ta.touch_ws && ta.touch_all && compact) {
+          // small local map: every row is on every iteration's list (nothing to agree on, nothing to read back)
+          if (mv->M > 0 && hipMemset2DAsync(ta.touch_ws, (size_t)ta.touch_stride, 1, (size_t)mv->M, (size_t)n_it,
+                                            (hipStream_t)stream) != hipSuccess) {
+            clid_set_error("clid_mapping_run_dist: flag fill failed");
+            return CLID_E_HIP;
+          }
+          if (int e = clid_train_touch_scan(&ta, mv->M, n_it, it, nullptr, stream)) return e;
+          for (int i = 0; i < n_it; ++i) counts[i] = mv->M;
+        } else if (ta.touch_ws) {
           // the union over the ranks of the rows each iteration touches: every rank then packs the same list
           if (int e = clid_comm_allreduce(comm, ta.touch_ws, (int64_t)n_it * ta.touch_stride, 2, 1, stream)) return e;
           moved += ((long long)n_it * ta.touch_stride + 3) / 4;

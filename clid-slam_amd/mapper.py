@@ -353,6 +353,10 @@ class Mapper:
                 if cbuf is None or cbuf.numel() < n_c or cbuf.device != dev:
                     cbuf = self._cbuf = torch.zeros(n_c, device=dev, dtype=torch.float32)
                 ta.cbuf = cbuf.data_ptr()
+                # small local maps: the ranks' batches reach (nearly) every row every iteration -- all rows on every list,
+                # no flag exchange and no read-back per chunk (CLID_TOUCH_ALL = 0 / 1 / auto)
+                every = os.environ.get("CLID_TOUCH_ALL", "auto")
+                ta.touch_all = int(every == "1" or (every != "0" and M_local < self.SPARSE_MIN_ROWS_DIST))
 
         stream = _lib.stream()
         idx_base, row_bytes = index_seq.data_ptr(), bs_global * 8
@@ -394,6 +398,7 @@ class Mapper:
                     moved = self._mapping_loop_torch_dist(lib, dist, view, ta, aa, grad, cbuf, iter_count, shard_base, row_bytes,
                                                           loss_base, hoist, bs_local, batch_offset, decim, eik_mode, dev, stream)
                 self.last_exchange = {"mode": "compact" if (use_touch and hoist) else "dense", "iters": iter_count,
+                                      "every_row": bool(ta.touch_all) and use_touch and hoist,
                                       "transport": "peer-mapped" if ta.p2p else ("rccl" if comm is not None else "torch.distributed"),
                                       "floats": moved, "bytes_per_iter": 4.0 * moved / max(iter_count, 1),
                                       "dense_bytes_per_iter": 4.0 * grad.numel(), "rows": M_local + 1}
@@ -477,7 +482,12 @@ class Mapper:
                     n_it = min(chunk, iter_count - it)
                     _lib.check(lib.clid_train_search(C.byref(view), C.byref(ta), n_it, ta.index, row_bytes // 8,
                                                      self._rec.data_ptr(), stream), "clid_train_search")
-                    if ta.touch_ws:
+                    if ta.touch_ws and ta.touch_all and compact:
+                        self._touch_ws[0][: n_it * int(ta.touch_stride)].view(n_it, int(ta.touch_stride))[:, :M_local] = 1
+                        _lib.check(lib.clid_train_touch_scan(C.byref(ta), M_local, n_it, it, None, stream), "clid_train_touch_scan")
+                        for i in range(n_it):
+                            counts[i] = M_local
+                    elif ta.touch_ws:
                         flags = self._touch_ws[0][: n_it * int(ta.touch_stride)]
                         dist.all_reduce(flags, op=dist.ReduceOp.MAX)  # union over the ranks of each iteration's rows
                         moved += (flags.numel() + 3) // 4

@@ -240,7 +240,10 @@ typedef struct clid_train_args {
   uint8_t* touch_ws;
   int64_t touch_stride;      /* clid_touch_stride(Mcap) of a capacity Mcap >= M: the layout stays put while the map grows */
   int32_t touch_iter;
-  int32_t touch_pad;
+  int32_t touch_all;         /* clid_mapping_run_dist, compact exchange: 1 = every row of the local map counts as touched in
+                              * every iteration (lists of M rows: no flag exchange, no count read-back -- for local maps
+                              * small enough that the ranks' batches reach all of it anyway; the packed layout and the
+                              * peer-mapped transport stay).  Rows nobody touched carry zero gradients: their update is zero. */
   float* cbuf;
   /* world > 1, compact exchange only: peer-mapped exchange buffers (clid_p2p_*, below).  clid_mapping_run_dist then packs
    * every iteration into the object's current buffer instead of `cbuf` and sums it over the ranks with ONE launch per

@@ -15,13 +15,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(rank, world, port, out_dir, mode, sparse="0", p2p="1"):
+def _run(rank, world, port, out_dir, mode, sparse="0", p2p="1", every="0"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import golden_io as gio
     import shim_io
 
     os.environ["CLID_P2P"] = p2p        # "1": the compact payload over peer-mapped buffers (csrc/p2p.hip) when they can be set up
+    os.environ["CLID_TOUCH_ALL"] = every  # "1": every row on every iteration's list (no flag exchange / read-back per chunk)
     os.environ["CLID_SPARSE"] = sparse  # "1": compact exchange [848 | 9 floats per touched row] + touched-row Adam sweep
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -48,18 +49,20 @@ def _run(rank, world, port, out_dir, mode, sparse="0", p2p="1"):
                  loss=mpr.last_losses.cpu().numpy(),
                  exchange=np.array([0 if mpr.last_exchange is None else mpr.last_exchange["floats"],
                                     0 if mpr.last_exchange is None else int(mpr.last_exchange["mode"] == "compact"),
-                                    0 if mpr.last_exchange is None else int(mpr.last_exchange["transport"] == "peer-mapped")]))
+                                    0 if mpr.last_exchange is None else int(mpr.last_exchange["transport"] == "peer-mapped"),
+                                    0 if mpr.last_exchange is None else int(mpr.last_exchange["every_row"])]))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,sparse,p2p", [("numerical", "0", "1"), ("analytic", "0", "1"), ("numerical", "1", "0"), ("numerical", "1", "1")])
-def test_two_ranks_equal_one(tmp_path, mode, sparse, p2p):
-    port = 29700 + (os.getpid() % 1000) + (0 if mode == "numerical" else 1) + 2 * int(sparse) + 4 * int(p2p)
+@pytest.mark.parametrize("mode,sparse,p2p,every", [("numerical", "0", "1", "0"), ("analytic", "0", "1", "0"), ("numerical", "1", "0", "0"),
+                                                   ("numerical", "1", "1", "0"), ("numerical", "1", "1", "1"), ("numerical", "1", "0", "1")])
+def test_two_ranks_equal_one(tmp_path, mode, sparse, p2p, every):
+    port = 29700 + (os.getpid() % 1000) + (0 if mode == "numerical" else 1) + 2 * int(sparse) + 4 * int(p2p) + 8 * int(every)
     _run(0, 1, port, str(tmp_path), mode)
     os.environ.pop("CLID_SPARSE", None)
-    mp.spawn(_run, args=(2, port, str(tmp_path), mode, sparse, p2p), nprocs=2, join=True)
+    mp.spawn(_run, args=(2, port, str(tmp_path), mode, sparse, p2p, every), nprocs=2, join=True)
     a = np.load(os.path.join(tmp_path, "w1.npz"))
     b = np.load(os.path.join(tmp_path, "w2.npz"))
     assert np.abs(a["loss"] - b["loss"]).max() <= 2e-6
@@ -72,5 +75,8 @@ def test_two_ranks_equal_one(tmp_path, mode, sparse, p2p):
     if sparse == "1":  # the compact exchange ran, and moved less than the dense buffer would have
         assert int(b["exchange"][1]) == 1 and 0 < int(b["exchange"][0]) < dense
         assert int(b["exchange"][2]) == int(p2p)  # over the peer-mapped buffers / over torch.distributed
+        assert int(b["exchange"][3]) == int(every)
+        if every == "1":  # [848 | 9 x every row] per iteration, nothing else
+            assert int(b["exchange"][0]) == 3 * (848 + 9 * (n_rows - 1))
     elif mode == "numerical":
         assert int(b["exchange"][1]) == 0 and int(b["exchange"][0]) == dense
