@@ -22,6 +22,8 @@ struct VoxStats {
   unsigned dmax;     // max distance to the voxel centre (non-negative float bits order like unsigned ints)
   unsigned count;    // number of occupied voxels (filled by the compaction)
   long long stride;  // v = max over axes of (cell - offset), the reference's linearisation stride
+  unsigned overflow; // the bucketed ordering gave up (a bucket beyond its capacity): the caller orders with the library
+  unsigned pad;
 };
 
 __device__ __forceinline__ int ordered(float f) {
@@ -106,6 +108,7 @@ __global__ void k_vox_init(VoxStats* st) {
     st->dmax = 0u;
     st->count = 0u;
     st->stride = 0;
+    st->overflow = 0u;
   }
 }
 
@@ -179,6 +182,154 @@ __global__ void __launch_bounds__(1024) k_vox_compact(const long long* __restric
   const unsigned pos = block_base + wave_cnt[wave] + (unsigned)__popcll(m & ((1ULL << lane) - 1ULL));
   flat_out[pos] = k;
   idx_out[pos] = (long long)(vals[h] & 0xffffffffULL);
+}
+
+
+// ---- ordering of the occupied voxels by their linear id in three small launches (work proportional to m) ------------------
+// The library sort of m ~ 1e5 (id, index) pairs is a block sort and seven dependent merge launches (70 - 90 us, twice per
+// frame) behind a host round trip (it needs m on the host).  Here: (1) ONE block derives 511 splitters from the ids of
+// 1024 sampled input points; (2) the pass over the hash table that used to compact the occupied slots appends every
+// (id, index) to the list of its splitter bucket instead (one atomic per voxel on 512 counters); (3) one block per
+// bucket orders its list in registers / LDS (bitonic network over packed 64-bit values, lane shuffles for partners inside
+// a wave) and writes the indices behind the smaller buckets.  Buckets have a fixed capacity (8 x the mean at 1.3e5
+// voxels); a bucket beyond it raises VoxStats.overflow and the host orders with the library as before (first frame,
+// whole-map rebuilds).  Everything runs on the device-side count: the one round trip comes after the last launch.
+constexpr int kVbBuckets = 512, kVbCap = 4096, kVbThreads = 1024, kVbSamples = 1024;
+constexpr int kVbPerBucket = kVbSamples / kVbBuckets;  // samples per bucket
+constexpr int kVbPosBits = 12;  // position inside a bucket list
+constexpr int kVbCntStride = 32;  // one bucket counter per 128-byte line: atomics on ONE line retire one after the other
+                                  // (256 adjacent counters = 8 lines: the partition launch took 93 us for 1e5 voxels)
+constexpr unsigned long long kVbPad = ~0ULL;
+
+// bitonic network over the first P (power of two, <= E * 1024) of E * 1024 values, element r * 1024 + tid in register r
+template <int E>
+__device__ __forceinline__ void vb_bitonic(unsigned long long (&v)[E], unsigned long long* sval, int P) {
+  const int tid = threadIdx.x;
+  for (int kk = 2; kk <= P; kk <<= 1) {
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      if (j >= 64) {
+#pragma unroll
+        for (int r = 0; r < E; ++r)
+          if (r * kVbThreads + tid < P) sval[r * kVbThreads + tid] = v[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const int i = r * kVbThreads + tid;
+          if (i < P) {
+            const unsigned long long o = sval[i ^ j];
+            const bool keep_min = ((i & j) == 0) == ((i & kk) == 0);
+            v[r] = (keep_min == (o < v[r])) ? o : v[r];
+          }
+        }
+        __syncthreads();
+      } else if ((tid & ~63) < P) {  // (waves entirely beyond P idle: the network's cost follows P)
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const int i = r * kVbThreads + tid;
+          const unsigned long long o = __shfl_xor(v[r], j, 64);
+          const bool keep_min = ((i & j) == 0) == ((i & kk) == 0);
+          if (i < P) v[r] = (keep_min == (o < v[r])) ? o : v[r];
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ long long vox_flat(const float* __restrict__ pts, int i, float v, const VoxStats* st) {
+  long long off[3], stride = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    off[a] = (long long)floorf(fdiv(unordered(st->lo[a]), v));
+    const long long top = (long long)floorf(fdiv(unordered(st->hi[a]), v)) - off[a];
+    stride = top > stride ? top : stride;
+  }
+  const long long gx = (long long)floorf(fdiv(pts[i * 3 + 0], v)) - off[0], gy = (long long)floorf(fdiv(pts[i * 3 + 1], v)) - off[1],
+                  gz = (long long)floorf(fdiv(pts[i * 3 + 2], v)) - off[2];
+  return gx + gy * stride + gz * stride * stride;
+}
+
+// splitters[k] = sample of rank kVbPerBucket (k + 1), k = 0 .. kVbBuckets - 2, among the ids of 1024 evenly spaced input points
+__global__ void __launch_bounds__(kVbThreads) k_vox_splitters(const float* __restrict__ pts, int n, float v, const VoxStats* st,
+                                                              long long* __restrict__ split, unsigned* __restrict__ bucket_cnt) {
+  __shared__ unsigned long long sval[kVbSamples];
+  const int tid = threadIdx.x;
+  if (tid < kVbBuckets) bucket_cnt[tid * kVbCntStride] = 0u;
+  unsigned long long sk[1];
+  sk[0] = (unsigned long long)vox_flat(pts, (int)((long long)tid * n / kVbSamples), v, st);
+  vb_bitonic<1>(sk, sval, kVbSamples);
+  if (tid % kVbPerBucket == 0 && tid > 0) split[tid / kVbPerBucket - 1] = (long long)sk[0];
+}
+
+// occupied slots of the hash table -> bucket lists
+__global__ void __launch_bounds__(256) k_vox_partition(const long long* __restrict__ keys, const unsigned long long* __restrict__ vals,
+                                                       int log2cap, VoxStats* st, const long long* __restrict__ split,
+                                                       unsigned* __restrict__ bucket_cnt, long long* __restrict__ bkeys,
+                                                       long long* __restrict__ bidx) {
+  __shared__ long long sp[kVbBuckets];
+  for (int i = threadIdx.x; i < kVbBuckets - 1; i += blockDim.x) sp[i] = split[i];
+  __syncthreads();
+  const long long h = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long k = h < (1LL << log2cap) ? keys[h] : -1LL;
+  if (k == -1LL) return;
+  int b = 0;  // number of splitters <= k
+#pragma unroll
+  for (int step = kVbBuckets / 2; step >= 1; step >>= 1)
+    if (b + step <= kVbBuckets - 1 && sp[b + step - 1] <= k) b += step;
+  const unsigned pos = atomicAdd(&bucket_cnt[b * kVbCntStride], 1u);
+  if (pos >= (unsigned)kVbCap) {
+    st->overflow = 1u;
+    return;
+  }
+  bkeys[(size_t)b * kVbCap + pos] = k;
+  bidx[(size_t)b * kVbCap + pos] = (long long)(vals[h] & 0xffffffffULL);
+}
+
+template <int E>
+__device__ __forceinline__ void vb_emit(int c, long long below, const long long* __restrict__ bk, const long long* __restrict__ bi,
+                                        unsigned long long* sval, long long* __restrict__ out) {
+  const int tid = threadIdx.x;
+  int P = 64;
+  while (P < c) P <<= 1;
+  unsigned long long v[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int i = r * kVbThreads + tid;
+    v[r] = i < c ? (((unsigned long long)bk[i] << kVbPosBits) | (unsigned)i) : kVbPad;
+  }
+  vb_bitonic<E>(v, sval, P);
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int i = r * kVbThreads + tid;
+    if (i < c) out[below + i] = bi[v[r] & ((1ULL << kVbPosBits) - 1ULL)];
+  }
+}
+
+__global__ void __launch_bounds__(kVbThreads) k_vox_bucket_sort(const unsigned* __restrict__ bucket_cnt, const long long* __restrict__ bkeys,
+                                                                const long long* __restrict__ bidx, VoxStats* st,
+                                                                long long* __restrict__ out) {
+  __shared__ unsigned long long sval[kVbCap];
+  __shared__ unsigned wsum[kVbThreads / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  // the number of voxels below this bucket -- and, from the last block, the total (the counters count every arrival, also
+  // the ones an overflowing bucket could not store)
+  unsigned mine = tid < (b == kVbBuckets - 1 ? kVbBuckets : b) ? bucket_cnt[tid * kVbCntStride] : 0u;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if ((tid & 63) == 0) wsum[tid >> 6] = mine;
+  __syncthreads();
+  long long below = 0;
+  for (int w = 0; w < kVbThreads / 64; ++w) below += wsum[w];
+  const int c = (int)bucket_cnt[b * kVbCntStride];
+  if (b == kVbBuckets - 1) {
+    if (tid == 0) st->count = (unsigned)below;
+    below -= c;
+  }
+  if (st->overflow || c == 0) return;  // (block-uniform)
+  const long long* bk = bkeys + (size_t)b * kVbCap;
+  const long long* bi = bidx + (size_t)b * kVbCap;
+  if (c <= kVbThreads) vb_emit<1>(c, below, bk, bi, sval, out);
+  else if (c <= 2 * kVbThreads) vb_emit<2>(c, below, bk, bi, sval, out);
+  else vb_emit<4>(c, below, bk, bi, sval, out);
 }
 
 struct Pose12 {
@@ -612,7 +763,7 @@ using namespace clid;
 static size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
 
 struct VoxLayout {
-  size_t stats, keys, vals, flat_a, idx_a, flat_b, cub, total, cub_bytes;
+  size_t stats, keys, vals, flat_a, idx_a, flat_b, cub, split, bcnt, bkeys, bidx, total, cub_bytes;
 };
 
 static VoxLayout vox_layout(int n) {
@@ -630,6 +781,10 @@ static VoxLayout vox_layout(int n) {
                                      (long long*)nullptr, n);
   L.cub_bytes = tmp;
   L.cub = o; o += align256(tmp);
+  L.split = o; o += align256(kVbBuckets * 8);
+  L.bcnt = o; o += align256((size_t)kVbBuckets * kVbCntStride * 4);
+  L.bkeys = o; o += align256((size_t)kVbBuckets * kVbCap * 8);
+  L.bidx = o; o += align256((size_t)kVbBuckets * kVbCap * 8);
   L.total = o;
   return L;
 }
@@ -666,8 +821,20 @@ static int vox_down_sample(const float* points, int32_t n, float voxel_size, con
   hipLaunchKernelGGL(k_vox_stats, dim3(sb), dim3(256), 0, s, points, n, voxel_size, st, value);
   hipLaunchKernelGGL(k_vox_insert, dim3((n + 255) / 256), dim3(256), 0, s, points, n, voxel_size, st, keys, vals, log2cap,
                      value);
-  hipLaunchKernelGGL(k_vox_compact, dim3((unsigned)((((size_t)1 << log2cap) + 1023) / 1024)), dim3(1024), 0, s, keys, vals,
-                     log2cap, st, flat_a, idx_a);
+  long long* split = reinterpret_cast<long long*>(ws + L.split);
+  unsigned* bcnt = reinterpret_cast<unsigned*>(ws + L.bcnt);
+  long long* bkeys = reinterpret_cast<long long*>(ws + L.bkeys);
+  long long* bidx = reinterpret_cast<long long*>(ws + L.bidx);
+  const unsigned table_blocks1k = (unsigned)((((size_t)1 << log2cap) + 1023) / 1024);
+  const bool bucketed = n <= (1 << 21);  // beyond: the buckets would overflow anyway
+  if (bucketed) {
+    hipLaunchKernelGGL(k_vox_splitters, dim3(1), dim3(kVbThreads), 0, s, points, n, voxel_size, st, split, bcnt);
+    hipLaunchKernelGGL(k_vox_partition, dim3(table_blocks1k * 4), dim3(256), 0, s, keys, vals, log2cap, st, split, bcnt, bkeys, bidx);
+    hipLaunchKernelGGL(k_vox_bucket_sort, dim3(kVbBuckets), dim3(kVbThreads), 0, s, bcnt, bkeys, bidx, st,
+                       reinterpret_cast<long long*>(idx_out));
+  } else {
+    hipLaunchKernelGGL(k_vox_compact, dim3(table_blocks1k), dim3(1024), 0, s, keys, vals, log2cap, st, flat_a, idx_a);
+  }
   CLID_CHECK_LAUNCH();
   // the output size is data dependent: ONE host round trip (the caller sizes its tensors with it), through a
   // pinned landing buffer (a pageable destination makes hipMemcpyAsync stage and block for ~150 us)
@@ -688,6 +855,13 @@ static int vox_down_sample(const float* points, int32_t n, float voxel_size, con
     const unsigned long long top = (unsigned long long)got.stride * (1ULL + (unsigned long long)got.stride +
                                                                      (unsigned long long)got.stride * got.stride);
     while (bits < 63 && (top >> bits)) ++bits;
+  }
+  if (bucketed) {
+    if (!got.overflow && bits <= 64 - kVbPosBits - 1) return m;  // ordered on the device already
+    // a bucket beyond its capacity (or ids too wide for the packed sort values): the library orders the compacted slots
+    if (hipMemsetAsync(&st->count, 0, sizeof(unsigned), s) != hipSuccess) return CLID_E_HIP;
+    hipLaunchKernelGGL(k_vox_compact, dim3(table_blocks1k), dim3(1024), 0, s, keys, vals, log2cap, st, flat_a, idx_a);
+    CLID_CHECK_LAUNCH();
   }
   size_t tmp = L.cub_bytes;
   if (hipcub::DeviceRadixSort::SortPairs(ws + L.cub, tmp, flat_a, flat_b, idx_a, reinterpret_cast<long long*>(idx_out), m,

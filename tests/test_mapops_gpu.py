@@ -9,7 +9,8 @@ from oracle import sampler_ref as R
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,voxel,seed", [(1, 0.2, 0), (7, 0.4, 1), (5000, 0.2, 2), (200000, 0.4, 3), (450000, 0.1, 4)])
+@pytest.mark.parametrize("n,voxel,seed", [(1, 0.2, 0), (7, 0.4, 1), (5000, 0.2, 2), (200000, 0.4, 3), (450000, 0.1, 4),
+                                          (1_500_000, 0.08, 5)])  # the last one overflows the ordering buckets: library sort
 def test_voxel_down_sample_kernel_matches_the_reference_rule(n, voxel, seed):
     """clid_voxel_down_sample == the oracle's restatement of utils/tools.py:639-682 (scatter-amin on the CPU) on
     identical points: same indices in the same order, including the stride-aliasing quirk."""
