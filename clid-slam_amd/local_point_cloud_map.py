@@ -77,6 +77,8 @@ class LocalPointCloudMap:
             return False
         lib = _lib.load()
         dev = points.device
+        if getattr(self, "_count_pending", False):
+            self._finish_count()
         samples = points[voxel_down_sample_torch(points, self.resolution)].contiguous()
         old = self.local_point_cloud_map.contiguous()
         n_a, n_s = int(old.shape[0]), int(samples.shape[0])
@@ -99,15 +101,32 @@ class LocalPointCloudMap:
         if getattr(self, "_cloud_ws", None) is None or self._cloud_ws.numel() < need or self._cloud_ws.device != dev:
             self._cloud_ws = torch.empty(int(need * 1.5) + 1024, device=dev, dtype=torch.uint8)
             self._cloud_counts = torch.zeros(2, device=dev, dtype=torch.int64)
+        defer = getattr(self, "_defer_counts", None)
+        self._defer_counts = None
+        counts = defer if defer is not None else self._cloud_counts
         _lib.check(lib.clid_cloud_update(
             old.data_ptr(), n_a, samples.data_ptr(), n_s, self.buffer_pt_index.data_ptr(), out_tab.data_ptr(), self.buffer_size,
             float(self.resolution), (C.c_double * 3)(*sp), float(self.map_size), int(sensor_position.dtype == torch.float64),
-            out_pts.data_ptr(), self._cloud_counts.data_ptr(), self._cloud_ws.data_ptr(), _lib.stream()), "clid_cloud_update")
-        kept = _lib.read_counts(self._cloud_counts, 1)[0]  # the one host round trip (sizes the map)
+            out_pts.data_ptr(), counts.data_ptr(), self._cloud_ws.data_ptr(), _lib.stream()), "clid_cloud_update")
         state["side"] = side
-        self.local_point_cloud_map = out_pts[:kept]
         self.buffer_pt_index = out_tab
+        if defer is not None:
+            # the caller reads the count later (Mapper.process_frame: with the frame's last read-back); until then the map is
+            # its first n rows -- an upper bound: rows beyond the true count are referenced by no slot of the table
+            self.local_point_cloud_map = out_pts[:n]
+            self._count_pending, self._pending = True, (out_pts, defer)
+            return True
+        kept = _lib.read_counts(self._cloud_counts, 1)[0]  # the one host round trip (sizes the map)
+        self.local_point_cloud_map = out_pts[:kept]
         return True
+
+    def _finish_count(self, kept=None):
+        """Settle a deferred update_map: `kept` as read by the caller, or one read-back here."""
+        out_pts, counts = self._pending
+        if kept is None:
+            kept = _lib.read_counts(counts, 1)[0]
+        self.local_point_cloud_map = out_pts[:int(kept)]
+        self._count_pending, self._pending = False, None
 
     def set_search_neighborhood(self, num_nei_cells: int = 1, search_alpha: float = 0.2) -> None:
         """:74-96: the cells within (num_nei_cells + search_alpha) of the centre cell (7 by default)."""

@@ -671,6 +671,10 @@ class Mapper:
         use_pin = bool(getattr(cfg, "use_pin_mapper", False))
         if not use_pin:  # :178-183
             self.local_point_cloud_map._sensor_pos_host = (origin, tuple(float(v) for v in cur_pose_torch[:3, 3].tolist()))
+            # the raw-point map's new size is needed by nobody before the frame's last read-back: it lands in the frame's
+            # count block and is read there (the sampler's kernels take the upper bound meanwhile)
+            self.local_point_cloud_map._defer_counts = (
+                self._frame_count_block(pts.device)[4:6] if pts.is_cuda and os.environ.get("CLID_DEFER_CLOUD_COUNT", "1") != "0" else None)
             self.local_point_cloud_map.update_map(origin, transform_torch(pts, cur_pose_torch))
         self.static_mask = torch.ones(pts.shape[0], dtype=torch.bool, device=pts.device)
         if filter_dynamic:  # :189-204
@@ -752,7 +756,7 @@ class Mapper:
                 # the new-sample selection (below) launched on the pool arrays still in flight: it reads the two pool counts on
                 # the device, so ONE read-back serves the pool maintenance and the selection
                 new_pending = self._new_sample_launch_pending(coord.shape[0])
-            self._pool_filter_finish()
+            self._pool_filter_finish(with_tail=new_pending is not None)
         elif fused_pool:
             self._pool_append_filter_fused(coord, gcoord if gcoord is not None else transform_torch(coord, cur_pose_torch),
                                            sdf_label, weight, stamp, cur_pose_torch, frame_id)
@@ -760,6 +764,8 @@ class Mapper:
             self._pool_append_filter_torch(coord, sdf_label, weight, stamp, sem_label, color_label, normal_label,
                                            cur_pose_torch, origin, frame_id, n_cur)
 
+        if getattr(self.local_point_cloud_map, "_count_pending", False):  # (paths without the merged tail read-back)
+            self.local_point_cloud_map._finish_count()
         # newly observed region: samples of this frame whose neighbourhood is still uncertain (:400-462)
         if cfg.bs_new_sample > 0:
             cur = self.global_coord_pool[self.global_coord_pool.shape[0] - self.cur_sample_count:]
@@ -767,7 +773,7 @@ class Mapper:
             nm.set_search_neighborhood(num_nei_cells=1, search_alpha=0.0)
             try:
                 if new_pending is not None:
-                    self.new_idx = new_pending[: _lib.read_counts(self._new_count, 1)[0]]
+                    self.new_idx = new_pending[: self._new_count_host]  # (read with the pool counts)
                 elif self._new_sample_fused_ok(cur, cur_label):
                     self.new_idx = self._new_sample_select_fused(cur, cur_label)
                 else:
@@ -836,7 +842,7 @@ class Mapper:
         need = int(lib.clid_new_sample_workspace_bytes(n_upper))
         if getattr(self, "_new_ws", None) is None or self._new_ws.numel() < need or self._new_ws.device != dev:
             self._new_ws = torch.empty(int(need * 1.3) + 256, device=dev, dtype=torch.uint8)
-            self._new_count = torch.zeros(1, device=dev, dtype=torch.int64)
+        self._frame_count_block(dev)
         idx = torch.empty(n_upper, device=dev, dtype=torch.int64)
         nm.set_search_neighborhood(num_nei_cells=1, search_alpha=0.0)
         try:
@@ -862,7 +868,7 @@ class Mapper:
         need = int(lib.clid_new_sample_workspace_bytes(n))
         if getattr(self, "_new_ws", None) is None or self._new_ws.numel() < need or self._new_ws.device != dev:
             self._new_ws = torch.empty(int(need * 1.3) + 256, device=dev, dtype=torch.uint8)
-            self._new_count = torch.zeros(1, device=dev, dtype=torch.int64)
+        self._frame_count_block(dev)
         idx = torch.empty(max(n, 1), device=dev, dtype=torch.int64)
         if nm._delta.device != dev:
             nm._delta = nm._delta.to(dev)
@@ -954,7 +960,7 @@ class Mapper:
         need = int(lib.clid_pool_workspace_bytes(n))
         if getattr(self, "_pool_ws", None) is None or self._pool_ws.numel() < need or self._pool_ws.device != dev:
             self._pool_ws = torch.empty(int(need * 1.2) + 256, device=dev, dtype=torch.uint8)
-            self._pool_counts = torch.zeros(3, device=dev, dtype=torch.int64)
+        self._frame_count_block(dev)
         a = [_lib.require_cuda(t, nme, dt) for t, nme, dt in (
             (self.coord_pool, "coord_pool", torch.float32), (self.global_coord_pool, "global_coord_pool", torch.float32),
             (self.sdf_label_pool, "sdf_label_pool", torch.float32), (self.weight_pool, "weight_pool", torch.float32),
@@ -972,10 +978,28 @@ class Mapper:
         if not defer:
             self._pool_filter_finish()
 
-    def _pool_filter_finish(self):
+    def _frame_count_block(self, dev):
+        """One device block for the data-dependent counts of a frame's tail -- [pool kept, kept of this frame, -, new samples,
+        raw-point map size, -, -, -] -- so that ONE read-back serves the pool maintenance, the new-sample selection and the
+        raw-point map (whose count nothing needs before the end of process_frame)."""
+        fc = getattr(self, "_frame_counts", None)
+        if fc is None or fc.device != torch.device(dev):
+            fc = self._frame_counts = torch.zeros(8, device=dev, dtype=torch.int64)
+            self._pool_counts, self._new_count = fc[0:3], fc[3:4]
+        return fc
+
+    def _pool_filter_finish(self, with_tail: bool = False):
         side, out, _ = self._pool_pending
         self._pool_pending = None
-        kept, kept_cur = _lib.read_counts(self._pool_counts, 2)  # the one host round trip of the pool maintenance
+        if with_tail:  # the new-sample selection was launched on the pool arrays in flight; the raw-point map's count rides along
+            got = _lib.read_counts(self._frame_counts, 5)
+            kept, kept_cur = got[0], got[1]
+            self._new_count_host = got[3]
+            lpm = self.local_point_cloud_map
+            if getattr(lpm, "_count_pending", False):
+                lpm._finish_count(got[4])
+        else:
+            kept, kept_cur = _lib.read_counts(self._pool_counts, 2)  # the one host round trip of the pool maintenance
         self._pool_side = side
         self.coord_pool, self.global_coord_pool = out["coord"][:kept], out["gcoord"][:kept]
         self.sdf_label_pool, self.weight_pool, self.time_pool = out["label"][:kept], out["weight"][:kept], out["time"][:kept]
