@@ -836,19 +836,10 @@ static int vox_down_sample(const float* points, int32_t n, float voxel_size, con
     hipLaunchKernelGGL(k_vox_compact, dim3(table_blocks1k), dim3(1024), 0, s, keys, vals, log2cap, st, flat_a, idx_a);
   }
   CLID_CHECK_LAUNCH();
-  // the output size is data dependent: ONE host round trip (the caller sizes its tensors with it), through a
+  // the output size is data dependent: ONE host round trip (the caller sizes its tensors with it), through the library's
   // pinned landing buffer (a pageable destination makes hipMemcpyAsync stage and block for ~150 us)
-  static thread_local VoxStats* pinned = nullptr;
-  if (!pinned && hipHostMalloc(reinterpret_cast<void**>(&pinned), sizeof(VoxStats), hipHostMallocDefault) != hipSuccess) {
-    clid_set_error("clid_voxel_down_sample: cannot allocate the pinned read-back buffer");
-    return CLID_E_HIP;
-  }
-  if (hipMemcpyAsync(pinned, st, sizeof(VoxStats), hipMemcpyDeviceToHost, s) != hipSuccess ||
-      hipStreamSynchronize(s) != hipSuccess) {
-    clid_set_error("clid_voxel_down_sample: read-back failed");
-    return CLID_E_HIP;
-  }
-  const VoxStats got = *pinned;
+  VoxStats got;
+  if (int rc = clid_read_back(st, (int32_t)sizeof(VoxStats), &got, stream)) return rc;  // (polls an event: no interrupt wake-up)
   const int m = (int)got.count;
   int bits = 1;
   {

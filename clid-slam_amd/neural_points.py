@@ -80,7 +80,22 @@ class _QueryFeature(torch.autograd.Function):
         return g_x, g_theta, None, None, None, None, None
 
 
+_PLAIN_TYPES = (torch.Tensor, int, float, bool, type(None), tuple)
+
+
 class NeuralPoints(nn.Module):
+    def __setattr__(self, name, value):
+        # nn.Module.__setattr__ walks its parameter / buffer / module registries for every assignment (~2.5 us; a frame
+        # assigns ~40 attributes here).  Re-assigning an attribute that already lives in the instance dict with a plain
+        # tensor / scalar ends in the same dict entry: take it directly.  Parameters, modules and first assignments go
+        # the registered way.
+        if type(value) in _PLAIN_TYPES:
+            d = self.__dict__
+            if name in d:
+                d[name] = value
+                return
+        super().__setattr__(name, value)
+
     def __init__(self, config) -> None:
         super().__init__()
         self.config = config
