@@ -114,6 +114,8 @@ _SIGS = {
     "clid_transform_points": (C.c_int, [_vp, _i32, C.POINTER(_f32), _vp, _vp]),
     "clid_voxel_workspace_bytes": (_i64, [_i32]),
     "clid_voxel_down_sample": (C.c_int, [_vp, _i32, _f32, _vp, _vp, _vp]),
+    "clid_voxel_down_sample_launch": (C.c_int, [_vp, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "clid_voxel_down_sample_finish": (C.c_int, [_i32, _vp, _vp, _vp]),
     "clid_voxel_down_sample_min_value": (C.c_int, [_vp, _i32, _f32, _vp, _vp, _vp, _vp]),
     "clid_map_rehash": (C.c_int, [_vp, _vp, _i32, _f32, _vp, _i64, _vp]),
     "clid_map_gather": (C.c_int, [_vp, _i32, _i64] + [_vp] * 13),

@@ -794,13 +794,13 @@ extern "C" int64_t clid_voxel_workspace_bytes(int32_t n) {
   return (int64_t)vox_layout(n).total;
 }
 
-static int vox_down_sample(const float* points, int32_t n, float voxel_size, const float* value, void* workspace,
-                           int64_t* idx_out, void* stream) {
+static int vox_launch(const float* points, int32_t n, float voxel_size, const float* value, void* workspace,
+                      int64_t* idx_out, void* stream) {
   if (n < 0 || !(voxel_size > 0.f) || (n > 0 && (!points || !workspace || !idx_out))) {
     clid_set_error("clid_voxel_down_sample: bad argument");
     return CLID_E_ARG;
   }
-  if (n == 0) return 0;
+  if (n == 0) return CLID_OK;
   hipStream_t s = (hipStream_t)stream;
   const VoxLayout L = vox_layout(n);
   char* ws = static_cast<char*>(workspace);
@@ -836,6 +836,28 @@ static int vox_down_sample(const float* points, int32_t n, float voxel_size, con
     hipLaunchKernelGGL(k_vox_compact, dim3(table_blocks1k), dim3(1024), 0, s, keys, vals, log2cap, st, flat_a, idx_a);
   }
   CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+// second half: the one round trip (sizes the caller's tensors) and, where the bucketed ordering gave up, the library sort
+static int vox_finish(int32_t n, void* workspace, int64_t* idx_out, void* stream) {
+  if (n < 0 || (n > 0 && (!workspace || !idx_out))) {
+    clid_set_error("clid_voxel_down_sample: bad argument");
+    return CLID_E_ARG;
+  }
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const VoxLayout L = vox_layout(n);
+  char* ws = static_cast<char*>(workspace);
+  VoxStats* st = reinterpret_cast<VoxStats*>(ws + L.stats);
+  long long* keys = reinterpret_cast<long long*>(ws + L.keys);
+  unsigned long long* vals = reinterpret_cast<unsigned long long*>(ws + L.vals);
+  long long* flat_a = reinterpret_cast<long long*>(ws + L.flat_a);
+  long long* idx_a = reinterpret_cast<long long*>(ws + L.idx_a);
+  long long* flat_b = reinterpret_cast<long long*>(ws + L.flat_b);
+  const int log2cap = vox_log2cap(n);
+  const unsigned table_blocks1k = (unsigned)((((size_t)1 << log2cap) + 1023) / 1024);
+  const bool bucketed = n <= (1 << 21);
   // the output size is data dependent: ONE host round trip (the caller sizes its tensors with it), through the library's
   // pinned landing buffer (a pageable destination makes hipMemcpyAsync stage and block for ~150 us)
   VoxStats got;
@@ -861,6 +883,23 @@ static int vox_down_sample(const float* points, int32_t n, float voxel_size, con
     return CLID_E_HIP;
   }
   return m;
+}
+
+
+static int vox_down_sample(const float* points, int32_t n, float voxel_size, const float* value, void* workspace,
+                           int64_t* idx_out, void* stream) {
+  if (int e = vox_launch(points, n, voxel_size, value, workspace, idx_out, stream)) return e;
+  return vox_finish(n, workspace, idx_out, stream);
+}
+
+// the two halves on their own: a caller that has other work to enqueue puts it between them (it then runs on the device /
+// is prepared on the host while the first half executes); nothing else may use `workspace` in between
+extern "C" int clid_voxel_down_sample_launch(const float* points, int32_t n, float voxel_size, const float* value,
+                                             void* workspace, int64_t* idx_out, void* stream) {
+  return vox_launch(points, n, voxel_size, value, workspace, idx_out, stream);
+}
+extern "C" int clid_voxel_down_sample_finish(int32_t n, void* workspace, int64_t* idx_out, void* stream) {
+  return vox_finish(n, workspace, idx_out, stream);
 }
 
 extern "C" int clid_voxel_down_sample(const float* points, int32_t n, float voxel_size, void* workspace,

@@ -32,11 +32,12 @@ class DataSampler:
         R = pts.shape[0]
         ns, nf, nb = int(cfg.surface_sample_n), int(cfg.free_front_n), int(cfg.free_behind_n)
         n_all = 1 + ns + nf + nb
-        if noise is None:  # utils/data_sampler.py:47, :72, :93 (this order)
-            gen = _lib.replica_generator(self, cfg, dev, 1)  # None (global RNG, as the reference) unless data-parallel
-            z_s = torch.randn(R * ns, 1, device=dev, generator=gen)
-            u_f = torch.rand(R * nf, 1, device=dev, generator=gen)
-            u_b = torch.rand(R * nb, 1, device=dev, generator=gen)
+        pre = getattr(self, "_predrawn", None)
+        self._predrawn = None
+        if noise is None and pre is not None and pre[0] == (R, str(dev)):
+            z_s, u_f, u_b = pre[1]
+        elif noise is None:  # utils/data_sampler.py:47, :72, :93 (this order)
+            z_s, u_f, u_b = self._draw(R, dev)
         else:
             z_s, u_f, u_b = (t.to(dev, torch.float32).contiguous() for t in noise)
         p = _lib.SamplerParams()
@@ -61,6 +62,20 @@ class DataSampler:
             "clid_sample_frame",
         )
         return coord, label, weight, keep, n_all
+
+    def _draw(self, R, dev):
+        cfg = self.config
+        ns, nf, nb = int(cfg.surface_sample_n), int(cfg.free_front_n), int(cfg.free_behind_n)
+        gen = _lib.replica_generator(self, cfg, dev, 1)  # None (global RNG, as the reference) unless data-parallel
+        z_s = torch.randn(R * ns, 1, device=dev, generator=gen)
+        u_f = torch.rand(R * nf, 1, device=dev, generator=gen)
+        u_b = torch.rand(R * nb, 1, device=dev, generator=gen)
+        return z_s, u_f, u_b
+
+    def predraw(self, n_rays: int, dev) -> None:
+        """The next `_run`'s random draws for `n_rays` rays, enqueued ahead of time (Mapper.process_frame: before the raw-point
+        map update, whose round trips they then overlap); consumed by the next `_run` with that ray count, dropped otherwise."""
+        self._predrawn = ((int(n_rays), str(torch.device(dev) if not isinstance(dev, torch.device) else dev)), self._draw(int(n_rays), dev))
 
     def sample(self, points_torch, local_point_cloud_map, cur_pose_torch, noise=None):
         """utils/data_sampler.py:260-402: (coord [S,3] sensor frame, sdf_label [S], weight [S]); near-surface

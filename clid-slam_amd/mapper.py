@@ -669,6 +669,10 @@ class Mapper:
         cur_pose_torch = _lib.small_to_host(cur_pose_torch)  # one read-back: the kernels take the 12 pose numbers by value
         pts = point_cloud_torch[:, :3]
         use_pin = bool(getattr(cfg, "use_pin_mapper", False))
+        if not use_pin and not filter_dynamic and pts.is_cuda and hasattr(self.sampler, "predraw"):
+            # the sampler's draws do not depend on the raw-point map: enqueued now, they are generated while the host waits
+            # for the map update's round trips (same generator, same order as at their old place: nothing in between draws)
+            self.sampler.predraw(pts.shape[0], pts.device)
         if not use_pin:  # :178-183
             self.local_point_cloud_map._sensor_pos_host = (origin, tuple(float(v) for v in cur_pose_torch[:3, 3].tolist()))
             # the raw-point map's new size is needed by nobody before the frame's last read-back: it lands in the frame's
@@ -736,9 +740,12 @@ class Mapper:
             # the map growth starts with a voxel down-sampling whose kernels starve next to the pool's 230-us five-array
             # compaction (k_vox_compact: 15 -> 187 us): it runs first, alone, and the pool work is forked behind it, next to
             # the insert / window launches that are small and separated by read-backs
-            from .tools import voxel_down_sample_torch
+            # Its launches go out first; the pool's launches (a side stream that waits for them) are prepared on the host
+            # while they execute, and only then the down-sampling's round trip is made.
+            from .tools import voxel_down_sample_finish, voxel_down_sample_launch, voxel_down_sample_torch
 
-            nm._presampled = (update_points, update_points[voxel_down_sample_torch(update_points, nm.resolution)])
+            two_phase = update_points.is_cuda and update_points.shape[0] > 0
+            pending_vox = voxel_down_sample_launch(update_points, nm.resolution) if two_phase else None
             main = torch.cuda.current_stream(coord.device)
             side = getattr(self, "_side_stream", None)
             if side is None or side.device != coord.device:
@@ -746,6 +753,8 @@ class Mapper:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 self._pool_append_filter_fused(coord, gcoord, sdf_label, weight, stamp, cur_pose_torch, frame_id, defer=True)
+            keep_idx = voxel_down_sample_finish(pending_vox) if two_phase else voxel_down_sample_torch(update_points, nm.resolution)
+            nm._presampled = (update_points, update_points[keep_idx])
         self.cur_new_point_ratio = nm.update(update_points, origin, orientation, frame_id)
 
         self.determine_used_pose()

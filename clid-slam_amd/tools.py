@@ -69,12 +69,10 @@ def get_time():
 _VOX_WS = {}
 
 
-def _voxel_down_sample_hip(points: torch.Tensor, voxel_size: float, value: torch.Tensor = None):
-    """`clid_voxel_down_sample` / `clid_voxel_down_sample_min_value` (csrc/mapops.hip): bounding box -> hash insert with
-    a 64-bit atomicMin per voxel -> compaction -> radix sort of the occupied voxels; 6 launches and one host round trip
-    instead of ~40 torch ops."""
-    import ctypes as C  # noqa: F401
-
+def voxel_down_sample_launch(points: torch.Tensor, voxel_size: float, value: torch.Tensor = None):
+    """First half of the voxel down-sampling on device tensors (`clid_voxel_down_sample_launch`): everything is enqueued,
+    nothing is waited for.  Returns a handle for `voxel_down_sample_finish`; no other voxel down-sampling may run on the
+    device in between (they share one workspace)."""
     from . import _lib
 
     lib = _lib.load()
@@ -87,15 +85,27 @@ def _voxel_down_sample_hip(points: torch.Tensor, voxel_size: float, value: torch
     if ws is None or ws.numel() < need:
         ws = _VOX_WS[pts.device] = torch.empty(int(need * 1.25) + 256, device=pts.device, dtype=torch.uint8)
     out = torch.empty(n, device=pts.device, dtype=torch.int64)
-    if value is None:
-        m = lib.clid_voxel_down_sample(pts.data_ptr(), n, float(voxel_size), ws.data_ptr(), out.data_ptr(), _lib.stream())
-    else:
-        val = value.detach().to(device=pts.device, dtype=torch.float32).contiguous()
-        m = lib.clid_voxel_down_sample_min_value(pts.data_ptr(), n, float(voxel_size), val.data_ptr(), ws.data_ptr(),
-                                                 out.data_ptr(), _lib.stream())
+    val = None if value is None else value.detach().to(device=pts.device, dtype=torch.float32).contiguous()
+    _lib.check(lib.clid_voxel_down_sample_launch(pts.data_ptr(), n, float(voxel_size), _lib.ptr(val), ws.data_ptr(), out.data_ptr(),
+                                                 _lib.stream()), "clid_voxel_down_sample_launch")
+    return (pts, val, ws, out, n)
+
+
+def voxel_down_sample_finish(handle):
+    """Second half: the one host round trip; returns the indices (ascending linear voxel id)."""
+    from . import _lib
+
+    _, _, ws, out, n = handle
+    m = _lib.load().clid_voxel_down_sample_finish(n, ws.data_ptr(), out.data_ptr(), _lib.stream())
     if m < 0:
-        _lib.check(m, "clid_voxel_down_sample")
+        _lib.check(m, "clid_voxel_down_sample_finish")
     return out[:m]
+
+
+def _voxel_down_sample_hip(points: torch.Tensor, voxel_size: float, value: torch.Tensor = None):
+    """`clid_voxel_down_sample` (csrc/mapops.hip): bounding box -> hash insert with a 64-bit atomicMin per voxel ->
+    splitters / partition / bucket sort of the occupied voxels; one host round trip instead of ~40 torch ops."""
+    return voxel_down_sample_finish(voxel_down_sample_launch(points, voxel_size, value))
 
 
 def voxel_down_sample_torch(points: torch.Tensor, voxel_size: float):

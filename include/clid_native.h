@@ -438,6 +438,12 @@ int clid_transform_points(const float* points, int32_t n, const float* pose12_ho
 int64_t clid_voxel_workspace_bytes(int32_t n);
 int clid_voxel_down_sample(const float* points, int32_t n, float voxel_size, void* workspace, int64_t* idx_out,
                            void* stream);
+/* The same in two halves: _launch enqueues everything (value may be NULL: distance to the voxel centre), _finish makes
+ * the round trip (and orders with the library sort where the device-side ordering gave up) and returns m.  A caller with
+ * other work to enqueue puts it between the two; nothing else may use `workspace` in between. */
+int clid_voxel_down_sample_launch(const float* points, int32_t n, float voxel_size, const float* value, void* workspace,
+                                  int64_t* idx_out, void* stream);
+int clid_voxel_down_sample_finish(int32_t n, void* workspace, int64_t* idx_out, void* stream);
 /* voxel_down_sample_min_value_torch (utils/tools.py:685-724): as above, but the point of a voxel with the smallest
  * `value` [n] (>= 0; quantised to 1000 levels of its maximum, lowest index among equals) is taken -- the selection
  * NeuralPoints.recreate_hash makes with |ts - cur_ts| or (max certainty - certainty) (model/neural_points.py:864-882).
