@@ -482,6 +482,7 @@ k_pool_scatter(PoolSrc a, PoolSrc b, const unsigned char* __restrict__ flag, con
 // reset_local_map: travel-distance (or frame-count) window AND distance to the sensor select the trainable local map;
 // the reference then builds global2local / local_mask and gathers six local arrays with ~40 torch ops and two host round
 // trips.  Here: flags (+ count of the time window) -> scan -> one gather pass; the caller reads ONE count.
+constexpr unsigned kFlagBlocks = 512;  // blocks of the flag kernels that end in a same-address atomic
 struct WindowArgs {
   const float* points; const int* ts_create; const int* ts_update; const float* travel; long long n;
   const long long* n_extra;  // device, may be NULL: the map holds n + *n_extra points (the count of an insert still in flight)
@@ -492,11 +493,13 @@ struct WindowArgs {
 };
 __device__ __forceinline__ long long window_n(const WindowArgs& a) { return a.n + (a.n_extra ? *a.n_extra : 0); }
 __global__ void __launch_bounds__(256) k_window_flags(WindowArgs a, unsigned char* __restrict__ bits, long long* __restrict__ counts) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long n = window_n(a);
-  bool t_ok = true;
-  bool d_ok = false;
-  if (i < n) {
+  int mine = 0;
+  // grid-stride over at most kFlagBlocks blocks: the launch ends in ONE same-address atomic per block, and those retire
+  // one after the other (2.7 k blocks at 690 k points: 27 us of a 5 us kernel; per wave it was 56 us)
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    bool t_ok = true;
+    bool d_ok = false;
     if (a.temporal) {
       int ts = a.ts_create[i];
       if (a.use_mid_ts) ts = (int)(((float)a.ts_create[i] + (float)a.ts_update[i]) / 2.0f);  // ((a + b) / 2).int(), :449
@@ -513,11 +516,12 @@ __global__ void __launch_bounds__(256) k_window_flags(WindowArgs a, unsigned cha
       d_ok = fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz)) < (float)a.r2;
     }
     bits[i] = (unsigned char)((t_ok ? 1 : 0) | (d_ok ? 2 : 0));
+    mine += t_ok ? 1 : 0;
   }
-  // one same-address atomic per BLOCK (per wave it was 10.8 k contended atomics at 690 k points: 56 us of a 5 us kernel)
   __shared__ int wave_cnt[4];
-  const unsigned long long b = __ballot(i < n && t_ok);
-  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(b);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = mine;
   __syncthreads();
   if (threadIdx.x == 0) {
     const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
@@ -659,10 +663,10 @@ __device__ __forceinline__ bool cloud_near(const CloudArgs& a, const float* p) {
   return sqrtf(fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz))) < (float)a.map_size;
 }
 __global__ void __launch_bounds__(256) k_cloud_flags(CloudArgs a, int* __restrict__ flag, long long* __restrict__ counts) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long n = a.n_a + a.n_s;
-  bool fresh = false, keep = false;
-  if (i < n) {
+  int mine = 0;  // (grid-stride, one same-address atomic per block: see k_window_flags)
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    bool fresh = false, keep = false;
     if (i < a.n_a) {
       keep = cloud_near(a, a.old_pts + i * 3);
     } else {
@@ -671,9 +675,17 @@ __global__ void __launch_bounds__(256) k_cloud_flags(CloudArgs a, int* __restric
       keep = fresh && cloud_near(a, p);
     }
     flag[i] = keep ? 1 : 0;
+    mine += fresh ? 1 : 0;
   }
-  const unsigned long long b = __ballot(fresh);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[1]), (unsigned long long)__popcll(b));
+  __shared__ int wave_cnt[4];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    if (tot) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[1]), (unsigned long long)tot);
+  }
 }
 __global__ void __launch_bounds__(256) k_cloud_scatter(CloudArgs a, const int* __restrict__ flag, const int* __restrict__ pos,
                                                        float* __restrict__ out, long long* __restrict__ counts) {
@@ -1573,7 +1585,7 @@ extern "C" int clid_local_window(const float* neural_points, const int32_t* ts_c
                sensor_pos_host[1], sensor_pos_host[2], radius2, pos_is_f64};
   if (nu > 0) {
     const unsigned blocks = (unsigned)((nu + 255) / 256);
-    hipLaunchKernelGGL(k_window_flags, dim3(blocks), dim3(256), 0, s, a, bits, counts);
+    hipLaunchKernelGGL(k_window_flags, dim3(blocks < kFlagBlocks ? blocks : kFlagBlocks), dim3(256), 0, s, a, bits, counts);
     hipLaunchKernelGGL(k_window_combine, dim3(blocks), dim3(256), 0, s, a, bits, nu, counts, flag);
     if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)nu, s) != hipSuccess) {
       clid_set_error("clid_local_window: scan failed");
@@ -1664,7 +1676,7 @@ extern "C" int clid_cloud_update(const float* map_points, int64_t n_map, const f
               reinterpret_cast<long long*>(table_new), (int)buffer_size, resolution, sensor_pos_host[0], sensor_pos_host[1],
               sensor_pos_host[2], map_size, pos_is_f64};
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_cloud_flags, dim3(blocks), dim3(256), 0, s, a, flag, counts);
+  hipLaunchKernelGGL(k_cloud_flags, dim3(blocks < kFlagBlocks ? blocks : kFlagBlocks), dim3(256), 0, s, a, flag, counts);
   if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)n, s) != hipSuccess) {
     clid_set_error("clid_cloud_update: scan failed");
     return CLID_E_HIP;
