@@ -16,7 +16,7 @@
 // iteration t's result out of the other buffer, and nobody can be two exchanges ahead (barrier A).
 //
 // Memory is exported / imported with HIP IPC handles; the host distributes the handle blobs with its own mechanism
-// (torch.distributed all_gather), exactly as it distributes the RCCL id.  A flag wait gives up after ~2 s of wall clock
+// (torch.distributed all_gather), exactly as it distributes the RCCL id.  A flag wait gives up after ~10 s of wall clock
 // and raises the object's error word instead of hanging the GPU; clid_p2p_selftest runs exchanges of exactly representable
 // values before the object is trusted (the caller takes the MIN over the ranks and keeps RCCL otherwise).
 #include <string.h>
@@ -30,7 +30,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kP2pMaxWorld = 8, kP2pBlocks = 64, kP2pThreads = 256;
 constexpr size_t kP2pFlagBytes = (size_t)kP2pBlocks * kP2pMaxWorld * sizeof(unsigned) * 2;  // + room for the error word
-constexpr long long kP2pTimeoutTicks = 200000000LL;  // wall_clock64 runs at 100 MHz: 2 s
+constexpr long long kP2pTimeoutTicks = 1000000000LL;  // wall_clock64 runs at 100 MHz: 10 s (ranks may be seconds apart at first use)
 
 struct P2pBlob {  // what one rank exports
   hipIpcMemHandle_t data, flags;
@@ -254,7 +254,7 @@ extern "C" int clid_p2p_status(clid_p2p* p, void* stream) {
   int32_t e = 0;
   if (int rc = clid_read_back(p2p_err_word(p), 4, &e, stream)) return rc;
   if (e) {
-    clid_set_error("clid_p2p: a peer did not arrive at an exchange within 2 s (rank %d of %d)", p->rank, p->world);
+    clid_set_error("clid_p2p: a peer did not arrive at an exchange within 10 s (rank %d of %d)", p->rank, p->world);
     return CLID_E_HIP;
   }
   return CLID_OK;

@@ -344,7 +344,7 @@ int clid_comm_destroy(clid_comm* comm);
  *   clid_p2p_buffer    the buffer the NEXT clid_p2p_allreduce works on: fill it, exchange, read the sums from it;
  *   clid_p2p_allreduce in-place SUM of its first count_floats floats over the ranks (one launch on `stream`; collective:
  *                      every rank issues the same sequence of exchanges);
- *   clid_p2p_status    0 unless a flag wait gave up (a peer did not arrive within ~2 s: the exchange's result is then
+ *   clid_p2p_status    0 unless a flag wait gave up (a peer did not arrive within ~10 s: the exchange's result is then
  *                      undefined and the object must not be used further); synchronises `stream`.
  * At most 8 ranks, one node. */
 typedef struct clid_p2p clid_p2p;
