@@ -6,7 +6,7 @@ import csv
 rows=[r for r in csv.DictReader(open("gpurun_out/ft/ft_kernel_stats.csv"))]
 for r in rows:
     n=r["Name"]
-    if "k_pool" in n: print(n[:40], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"])
+    if "k_vox" in n: print(n[:40], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"])
 PY
 rm -rf gpurun_out/ft
 for r in 1 2 3; do for d in . _old; do (cd $d; python bench_sequence.py --frames 120 --quiet 2>/dev/null | python -c "
