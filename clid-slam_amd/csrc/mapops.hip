@@ -16,6 +16,9 @@
 
 namespace clid {
 
+// the seven reduced values of the bounding-box pass, ONE per 128-byte line (atomics on one line retire one after the other
+// whichever word they hit): [lo x, lo y, lo z, hi x, hi y, hi z, dmax] at box[k * kBoxStride]
+constexpr int kBoxStride = 32;
 struct VoxStats {
   int lo[3];         // min coordinate per axis, order-preserving int encoding of the float
   int hi[3];         // max coordinate per axis
@@ -50,7 +53,7 @@ __device__ __forceinline__ float centre_dist(float x, float y, float z, float v,
 
 // `value` != NULL: the per-point score of voxel_down_sample_min_value_torch (utils/tools.py:685-724; non-negative)
 // takes the place of the distance to the voxel centre.
-__global__ void __launch_bounds__(256) k_vox_stats(const float* __restrict__ pts, int n, float v, VoxStats* st,
+__global__ void __launch_bounds__(256) k_vox_stats(const float* __restrict__ pts, int n, float v, int* __restrict__ box,
                                                    const float* __restrict__ value) {
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
   unsigned dm = 0u;
@@ -93,19 +96,22 @@ __global__ void __launch_bounds__(256) k_vox_stats(const float* __restrict__ pts
       const int o = part[w][c];
       v0 = c < 3 ? min(v0, o) : (c < 6 ? max(v0, o) : (int)max((unsigned)v0, (unsigned)o));
     }
-    if (c < 3) atomicMin(&st->lo[c], v0);
-    else if (c < 6) atomicMax(&st->hi[c - 3], v0);
-    else atomicMax(&st->dmax, (unsigned)v0);
+    if (c < 6) {
+      if (c < 3) atomicMin(&box[c * kBoxStride], v0);
+      else atomicMax(&box[c * kBoxStride], v0);
+    } else {
+      atomicMax(reinterpret_cast<unsigned*>(&box[6 * kBoxStride]), (unsigned)v0);
+    }
   }
 }
 
-__global__ void k_vox_init(VoxStats* st) {
+__global__ void k_vox_init(VoxStats* st, int* box) {
   if (threadIdx.x == 0) {
     for (int a = 0; a < 3; ++a) {
-      st->lo[a] = 0x7fffffff;
-      st->hi[a] = (int)0x80000000;
+      box[a * kBoxStride] = 0x7fffffff;
+      box[(3 + a) * kBoxStride] = (int)0x80000000;
     }
-    st->dmax = 0u;
+    box[6 * kBoxStride] = 0;
     st->count = 0u;
     st->stride = 0;
     st->overflow = 0u;
@@ -119,7 +125,7 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long k) {
 
 __global__ void __launch_bounds__(256) k_vox_insert(const float* __restrict__ pts, int n, float v, VoxStats* st,
                                                     long long* keys, unsigned long long* vals, int log2cap,
-                                                    const float* __restrict__ value) {
+                                                    const float* __restrict__ value, const int* __restrict__ box) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   // tools.py:653, :661-663: offset = floor(min / v); stride = max(cell - offset) over ALL axes (not max + 1: voxels
@@ -127,8 +133,8 @@ __global__ void __launch_bounds__(256) k_vox_insert(const float* __restrict__ pt
   long long off[3], stride = 0;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    off[a] = (long long)floorf(fdiv(unordered(st->lo[a]), v));
-    const long long top = (long long)floorf(fdiv(unordered(st->hi[a]), v)) - off[a];
+    off[a] = (long long)floorf(fdiv(unordered(box[a * kBoxStride]), v));
+    const long long top = (long long)floorf(fdiv(unordered(box[(3 + a) * kBoxStride]), v)) - off[a];
     stride = top > stride ? top : stride;
   }
   if (i == 0) st->stride = stride;
@@ -136,7 +142,7 @@ __global__ void __launch_bounds__(256) k_vox_insert(const float* __restrict__ pt
   float cx, cy, cz;
   float d = centre_dist(x, y, z, v, &cx, &cy, &cz);
   if (value) d = value[i];
-  const float dmax = __int_as_float((int)st->dmax);
+  const float dmax = __int_as_float(box[6 * kBoxStride]);
   const long long q = dmax > 0.f ? (long long)fmul(fdiv(d, dmax), 999.0f) : 0;  // :657-659
   const long long gx = (long long)cx - off[0], gy = (long long)cy - off[1], gz = (long long)cz - off[2];
   const long long flat = gx + gy * stride + gz * stride * stride;
@@ -235,12 +241,12 @@ __device__ __forceinline__ void vb_bitonic(unsigned long long (&v)[E], unsigned 
   }
 }
 
-__device__ __forceinline__ long long vox_flat(const float* __restrict__ pts, int i, float v, const VoxStats* st) {
+__device__ __forceinline__ long long vox_flat(const float* __restrict__ pts, int i, float v, const int* __restrict__ box) {
   long long off[3], stride = 0;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    off[a] = (long long)floorf(fdiv(unordered(st->lo[a]), v));
-    const long long top = (long long)floorf(fdiv(unordered(st->hi[a]), v)) - off[a];
+    off[a] = (long long)floorf(fdiv(unordered(box[a * kBoxStride]), v));
+    const long long top = (long long)floorf(fdiv(unordered(box[(3 + a) * kBoxStride]), v)) - off[a];
     stride = top > stride ? top : stride;
   }
   const long long gx = (long long)floorf(fdiv(pts[i * 3 + 0], v)) - off[0], gy = (long long)floorf(fdiv(pts[i * 3 + 1], v)) - off[1],
@@ -249,13 +255,13 @@ __device__ __forceinline__ long long vox_flat(const float* __restrict__ pts, int
 }
 
 // splitters[k] = sample of rank kVbPerBucket (k + 1), k = 0 .. kVbBuckets - 2, among the ids of 1024 evenly spaced input points
-__global__ void __launch_bounds__(kVbThreads) k_vox_splitters(const float* __restrict__ pts, int n, float v, const VoxStats* st,
+__global__ void __launch_bounds__(kVbThreads) k_vox_splitters(const float* __restrict__ pts, int n, float v, const int* __restrict__ box,
                                                               long long* __restrict__ split, unsigned* __restrict__ bucket_cnt) {
   __shared__ unsigned long long sval[kVbSamples];
   const int tid = threadIdx.x;
   if (tid < kVbBuckets) bucket_cnt[tid * kVbCntStride] = 0u;
   unsigned long long sk[1];
-  sk[0] = (unsigned long long)vox_flat(pts, (int)((long long)tid * n / kVbSamples), v, st);
+  sk[0] = (unsigned long long)vox_flat(pts, (int)((long long)tid * n / kVbSamples), v, box);
   vb_bitonic<1>(sk, sval, kVbSamples);
   if (tid % kVbPerBucket == 0 && tid > 0) split[tid / kVbPerBucket - 1] = (long long)sk[0];
 }
@@ -789,7 +795,7 @@ using namespace clid;
 static size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
 
 struct VoxLayout {
-  size_t stats, keys, vals, flat_a, idx_a, flat_b, cub, split, bcnt, bkeys, bidx, total, cub_bytes;
+  size_t stats, box, keys, vals, flat_a, idx_a, flat_b, cub, split, bcnt, bkeys, bidx, total, cub_bytes;
 };
 
 static VoxLayout vox_layout(int n) {
@@ -797,6 +803,7 @@ static VoxLayout vox_layout(int n) {
   const size_t cap = (size_t)1 << vox_log2cap(n);
   size_t o = 0;
   L.stats = o; o += align256(sizeof(VoxStats));
+  L.box = o; o += align256(7 * kBoxStride * sizeof(int));
   L.keys = o; o += align256(cap * 8);
   L.vals = o; o += align256(cap * 8);
   L.flat_a = o; o += align256((size_t)n * 8);
@@ -841,12 +848,13 @@ static int vox_launch(const float* points, int32_t n, float voxel_size, const fl
     clid_set_error("clid_voxel_down_sample: workspace init failed");
     return CLID_E_HIP;
   }
-  hipLaunchKernelGGL(k_vox_init, dim3(1), dim3(64), 0, s, st);
+  int* box = reinterpret_cast<int*>(ws + L.box);
+  hipLaunchKernelGGL(k_vox_init, dim3(1), dim3(64), 0, s, st, box);
   int sb = (n + 255) / 256;
-  if (sb > 64) sb = 64;  // every block ends in 8 same-address atomics: 512 blocks spent 15 of 18 us on them
-  hipLaunchKernelGGL(k_vox_stats, dim3(sb), dim3(256), 0, s, points, n, voxel_size, st, value);
+  if (sb > 256) sb = 256;  // every block ends in 7 atomics, one per cache line (on ONE line 512 blocks spent 15 of 18 us there)
+  hipLaunchKernelGGL(k_vox_stats, dim3(sb), dim3(256), 0, s, points, n, voxel_size, box, value);
   hipLaunchKernelGGL(k_vox_insert, dim3((n + 255) / 256), dim3(256), 0, s, points, n, voxel_size, st, keys, vals, log2cap,
-                     value);
+                     value, box);
   long long* split = reinterpret_cast<long long*>(ws + L.split);
   unsigned* bcnt = reinterpret_cast<unsigned*>(ws + L.bcnt);
   long long* bkeys = reinterpret_cast<long long*>(ws + L.bkeys);
@@ -854,7 +862,7 @@ static int vox_launch(const float* points, int32_t n, float voxel_size, const fl
   const unsigned table_blocks1k = (unsigned)((((size_t)1 << log2cap) + 1023) / 1024);
   const bool bucketed = n <= (1 << 21);  // beyond: the buckets would overflow anyway
   if (bucketed) {
-    hipLaunchKernelGGL(k_vox_splitters, dim3(1), dim3(kVbThreads), 0, s, points, n, voxel_size, st, split, bcnt);
+    hipLaunchKernelGGL(k_vox_splitters, dim3(1), dim3(kVbThreads), 0, s, points, n, voxel_size, box, split, bcnt);
     hipLaunchKernelGGL(k_vox_partition, dim3(table_blocks1k * 4), dim3(256), 0, s, keys, vals, log2cap, st, split, bcnt, bkeys, bidx);
     hipLaunchKernelGGL(k_vox_bucket_sort, dim3(kVbBuckets), dim3(kVbThreads), 0, s, bcnt, bkeys, bidx, st,
                        reinterpret_cast<long long*>(idx_out));
