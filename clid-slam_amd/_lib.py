@@ -130,7 +130,7 @@ _SIGS = {
     "clid_map_insert": (C.c_int, [_vp, _i32, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp]),
     "clid_local_window_workspace_bytes": (_i64, [_i64]),
     "clid_local_window": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _i32, C.POINTER(C.c_double), C.c_double, _i32,
-                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "clid_local_to_global": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clid_sample_compact_workspace_bytes": (_i64, [_i64]),
     "clid_sample_compact": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, C.c_float, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

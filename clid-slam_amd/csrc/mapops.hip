@@ -561,6 +561,7 @@ struct WindowFlag {
   }
 };
 struct WindowOut {
+  long long cap;  // rows the local arrays can hold (local_ids, points, ..., features cap + 1): rows beyond it are not written
   long long* local_ids; long long* g2l; unsigned char* local_mask;
   float* l_points; float* l_orient; float* l_cert; int* l_ts; float* l_feat;
   const float* g_orient; const float* g_cert; const float* g_feat;
@@ -575,7 +576,8 @@ __global__ void __launch_bounds__(256) k_window_gather(WindowArgs a, WindowFlag 
     counts[1] = m;
     o.g2l[i] = -1;
     o.local_mask[i] = 1;
-    for (int c = 0; c < CLID_F; ++c) o.l_feat[m * CLID_F + c] = o.g_feat[n * CLID_F + c];
+    if (m <= o.cap)
+      for (int c = 0; c < CLID_F; ++c) o.l_feat[m * CLID_F + c] = o.g_feat[n * CLID_F + c];
     return;
   }
   const bool in = flag(i) != 0;
@@ -583,6 +585,7 @@ __global__ void __launch_bounds__(256) k_window_gather(WindowArgs a, WindowFlag 
   o.g2l[i] = in ? (long long)pos[i] : -1;
   if (!in) return;
   const long long j = pos[i];
+  if (j >= o.cap) return;  // (the caller sees m > capacity in counts[1] and repeats the call with room for m rows)
   o.local_ids[j] = i;
   o.l_points[j * 3 + 0] = a.points[i * 3 + 0]; o.l_points[j * 3 + 1] = a.points[i * 3 + 1]; o.l_points[j * 3 + 2] = a.points[i * 3 + 2];
   reinterpret_cast<float4*>(o.l_orient)[j] = reinterpret_cast<const float4*>(o.g_orient)[i];
@@ -1582,8 +1585,9 @@ extern "C" int clid_local_window(const float* neural_points, const int32_t* ts_c
                                  int64_t* global2local_out, uint8_t* local_mask_out, float* local_points_out,
                                  float* local_orient_out, float* local_cert_out, int32_t* local_ts_out, float* local_feat_out,
                                  int64_t* counts_out, void* workspace, const int64_t* n_extra_dev, int64_t n_upper,
-                                 void* stream) {
+                                 int64_t local_capacity, void* stream) {
   if (!n_extra_dev) n_upper = n;
+  if (local_capacity < 0 || local_capacity > n_upper) local_capacity = n_upper;
   if (n < 0 || n_upper < n || n_upper >= (1LL << 31) || !sensor_pos_host || !counts_out || !workspace || !global2local_out || !local_mask_out ||
       !geo_features || !local_feat_out ||
       (n > 0 && (!neural_points || !ts_create || !ts_update || !point_orientations || !point_certainties || !local_ids_out ||
@@ -1615,7 +1619,7 @@ extern "C" int clid_local_window(const float* neural_points, const int32_t* ts_c
       return CLID_E_HIP;
     }
   }
-  WindowOut o{reinterpret_cast<long long*>(local_ids_out), reinterpret_cast<long long*>(global2local_out), local_mask_out,
+  WindowOut o{(long long)local_capacity, reinterpret_cast<long long*>(local_ids_out), reinterpret_cast<long long*>(global2local_out), local_mask_out,
               local_points_out, local_orient_out, local_cert_out, local_ts_out, local_feat_out, point_orientations,
               point_certainties, geo_features};
   hipLaunchKernelGGL(k_window_gather, dim3((unsigned)((nu + 1 + 255) / 256)), dim3(256), 0, s, a, wf, pos, o, counts);

@@ -449,14 +449,6 @@ class NeuralPoints(nn.Module):
         if getattr(self, "_ins_win_counts", None) is None or self._ins_win_counts.device != dev:
             self._ins_win_counts = torch.zeros(3, device=dev, dtype=torch.int64)
             self._ins_count, self._win_counts = self._ins_win_counts[:1], self._ins_win_counts[1:]
-        ids = torch.empty(n, device=dev, dtype=torch.int64)
-        g2l = torch.empty(n + 1, device=dev, dtype=torch.int64)
-        mask = torch.empty(n + 1, device=dev, dtype=torch.bool)
-        l_pts = torch.empty((n, 3), device=dev, dtype=torch.float32)
-        l_ori = torch.empty((n, 4), device=dev, dtype=torch.float32)
-        l_cert = torch.empty(n, device=dev, dtype=torch.float32)
-        l_ts = torch.empty(n, device=dev, dtype=torch.int32)
-        l_feat = torch.empty((n + 1, _lib.F), device=dev, dtype=torch.float32)
         if pending is None:
             for name in ("point_orientations", "point_certainties", "geo_features", "point_ts_update", "point_ts_create"):
                 _lib.require_cuda(getattr(self, name), name)
@@ -465,20 +457,40 @@ class NeuralPoints(nn.Module):
             n_base, extra = n, None
         else:
             src, n_base, extra = buf, base, ins_count.data_ptr()
-        _lib.check(lib.clid_local_window(
-            pts.contiguous().data_ptr(), src["point_ts_create"].data_ptr(), src["point_ts_update"].data_ptr(), _lib.ptr(travel), n_base,
-            int(cur_ts), int(bool(self.config.use_mid_ts)), temporal, int(bool(use_travel_dist)), float(self.diff_travel_dist_local),
-            int(diff_ts_local), int(self.reboot_ts), int(bool(reboot_map)), (C.c_double * 3)(*sp), float(self.local_map_radius) ** 2, f64,
-            src["point_orientations"].data_ptr(), src["point_certainties"].data_ptr(), src["geo_features"].data_ptr(),
-            ids.data_ptr(), g2l.data_ptr(), mask.data_ptr(), l_pts.data_ptr(), l_ori.data_ptr(), l_cert.data_ptr(),
-            l_ts.data_ptr(), l_feat.data_ptr(), self._win_counts.data_ptr(), self._win_ws.data_ptr(), extra, n, _lib.stream()),
-            "clid_local_window")
-        n_new = None
-        if pending is None:
-            m = _lib.read_counts(self._win_counts, 2)[1]  # the one host round trip: sizes the local arrays
-        else:
-            # ONE read-back for the insert and the window: the window's count pair sits next to the insert's count
-            n_new, _, m = _lib.read_counts(self._ins_win_counts, 3)
+        g2l = torch.empty(n + 1, device=dev, dtype=torch.int64)
+        mask = torch.empty(n + 1, device=dev, dtype=torch.bool)
+        # The local arrays are sized from the previous window (the local map changes by a few per cent per frame), not from
+        # the whole map: a map of millions of points would otherwise pin ~76 bytes per GLOBAL point per frame behind the
+        # [:m] views.  The kernel does not write beyond the capacity and reports m: one repeat with room for m if it grew past it.
+        last_m = getattr(self, "_last_local_m", None)
+        cap = n if last_m is None else min(n, int(last_m * 1.25) + 16384)
+        while True:
+            ids = torch.empty(cap, device=dev, dtype=torch.int64)
+            l_pts = torch.empty((cap, 3), device=dev, dtype=torch.float32)
+            l_ori = torch.empty((cap, 4), device=dev, dtype=torch.float32)
+            l_cert = torch.empty(cap, device=dev, dtype=torch.float32)
+            l_ts = torch.empty(cap, device=dev, dtype=torch.int32)
+            l_feat = torch.empty((cap + 1, _lib.F), device=dev, dtype=torch.float32)
+            _lib.check(lib.clid_local_window(
+                pts.contiguous().data_ptr(), src["point_ts_create"].data_ptr(), src["point_ts_update"].data_ptr(), _lib.ptr(travel), n_base,
+                int(cur_ts), int(bool(self.config.use_mid_ts)), temporal, int(bool(use_travel_dist)), float(self.diff_travel_dist_local),
+                int(diff_ts_local), int(self.reboot_ts), int(bool(reboot_map)), (C.c_double * 3)(*sp), float(self.local_map_radius) ** 2, f64,
+                src["point_orientations"].data_ptr(), src["point_certainties"].data_ptr(), src["geo_features"].data_ptr(),
+                _lib.ptr(ids) if cap else None, g2l.data_ptr(), mask.data_ptr(), _lib.ptr(l_pts) if cap else None,
+                _lib.ptr(l_ori) if cap else None, _lib.ptr(l_cert) if cap else None, _lib.ptr(l_ts) if cap else None, l_feat.data_ptr(),
+                self._win_counts.data_ptr(), self._win_ws.data_ptr(), extra, n, cap, _lib.stream()),
+                "clid_local_window")
+            n_new = None
+            if pending is None:
+                m = _lib.read_counts(self._win_counts, 2)[1]  # the one host round trip: sizes the local arrays
+            else:
+                # ONE read-back for the insert and the window: the window's count pair sits next to the insert's count
+                n_new, _, m = _lib.read_counts(self._ins_win_counts, 3)
+            if m <= cap:
+                break
+            cap = n  # (grew by more than a quarter since the last frame: once more with room for everything)
+        self._last_local_m = int(m)
+        if pending is not None:
             total = base + n_new
             self.neural_points, self.point_orientations = buf["neural_points"][:total], buf["point_orientations"][:total]
             self.point_ts_create, self.point_ts_update = buf["point_ts_create"][:total], buf["point_ts_update"][:total]

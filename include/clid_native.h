@@ -518,7 +518,11 @@ int clid_map_insert(const float* samples, int32_t n, int64_t* buffer_pt_index, i
  * n_extra_dev != NULL (device int64, e.g. the count_out of a clid_map_insert still in flight): the map holds n + *n_extra_dev
  * points, at most n_upper -- grids, the scan, the workspace (clid_local_window_workspace_bytes(n_upper)) and the output
  * capacities then cover n_upper rows and the kernels read the exact size on the device, so the insert and the window
- * selection of a frame share ONE read-back. */
+ * selection of a frame share ONE read-back.
+ * local_capacity (< 0: n_upper): rows the LOCAL output arrays hold (local_ids, points, orientations, certainties, stamps;
+ * features local_capacity + 1) -- a caller that knows the local map is much smaller than the map sizes them from its last m;
+ * rows beyond the capacity are not written, counts_out[1] still reports m, and the caller repeats the call when m exceeds it
+ * (global2local / local_mask are always n_upper + 1). */
 int64_t clid_local_window_workspace_bytes(int64_t n);
 int clid_local_window(const float* neural_points, const int32_t* ts_create, const int32_t* ts_update, const float* travel_dist,
                       int64_t n, int32_t cur_ts, int32_t use_mid_ts, int32_t temporal, int32_t use_travel_dist,
@@ -527,7 +531,7 @@ int clid_local_window(const float* neural_points, const int32_t* ts_create, cons
                       const float* point_certainties, const float* geo_features, int64_t* local_ids_out,
                       int64_t* global2local_out, uint8_t* local_mask_out, float* local_points_out, float* local_orient_out,
                       float* local_cert_out, int32_t* local_ts_out, float* local_feat_out, int64_t* counts_out,
-                      void* workspace, const int64_t* n_extra_dev, int64_t n_upper, void* stream);
+                      void* workspace, const int64_t* n_extra_dev, int64_t n_upper, int64_t local_capacity, void* stream);
 
 /* NeuralPoints.assign_local_to_global (model/neural_points.py:538-549) in one launch: local features (n + 1 rows of
  * F, the last one the padding row -> global row pad_row), certainties and update stamps back to the global arrays

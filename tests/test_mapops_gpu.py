@@ -128,6 +128,27 @@ def test_prune_and_recreate_hash_kernels_vs_the_torch_chain(monkeypatch, n, buff
     assert got["1"][6].shape[0] == m + 1 and (n <= 3 or m < n)
 
 
+def test_local_window_repeats_when_the_local_map_outgrew_its_capacity():
+    """reset_local_map sizes the local arrays from the previous window (not from the whole map); a window that grew past that
+    capacity is detected from the device-side count and gathered again: same result as with room for everything."""
+    got = []
+    for last in (None, 10, 39_000):
+        nm = _random_map(40_000, 1 << 22, seed=7)
+        nm.recreate_hash(None, None, True, True, 49)
+        nm.local_map_radius = 1000.0
+        nm.diff_travel_dist_local = 1e9
+        nm._last_local_m = last
+        nm.reset_local_map(torch.zeros(3, device="cuda"), torch.eye(3, device="cuda"), 49)
+        assert nm.local_neural_points.shape[0] == 40_000 and nm._last_local_m == 40_000
+        got.append([t.clone() for t in (nm.local_neural_points, nm.local_point_orientations, nm.local_point_certainties,
+                                        nm.local_point_ts_update, nm.local_geo_features.data, nm.global2local, nm.local_mask)])
+        if last is not None:  # capacity = min(n, 1.25 * last + 16384): 16 396 rows the first time, everything the second
+            assert nm.local_neural_points.untyped_storage().nbytes() <= 40_000 * 12
+    for other in got[1:]:
+        for a, b in zip(got[0], other):
+            assert torch.equal(a, b)
+
+
 def test_prune_map_below_the_minimum_count_changes_nothing():
     nm = _random_map(5000, 1 << 20, seed=5)
     before = [getattr(nm, k).clone() for k in _MAP_ARRAYS[:-1]]
