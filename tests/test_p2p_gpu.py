@@ -46,6 +46,23 @@ def _run(rank, world, port, out_dir):
             torch.cuda.synchronize()
             bad += int((out.cpu() != want).sum())
             assert int(lib.clid_p2p_buffer(obj)) != ptr  # the buffers alternate
+        # many exchanges back to back without any host synchronisation in between (the training loop's pattern: fill the
+        # current buffer, exchange, read the sums, next buffer), sizes changing every time; verified on the device
+        gen = torch.Generator().manual_seed(77)
+        sizes2 = torch.randint(1, 200_000, (150,), generator=gen).tolist()
+        wrong = torch.zeros(1, device="cuda", dtype=torch.int64)
+        base = torch.arange(200_000, device="cuda", dtype=torch.float32)
+        for k, n in enumerate(sizes2):
+            ptr = int(lib.clid_p2p_buffer(obj))
+            mine = ((base[:n] * (k % 7 + 1) + rank * 3 + k) % 1021).contiguous()  # small integers: sums exact in any order
+            _lib.check(lib.clid_debug_copy(ptr, mine.data_ptr(), n * 4, _lib.stream()), "copy in")
+            _lib.check(lib.clid_p2p_allreduce(obj, n, _lib.stream()), "clid_p2p_allreduce")
+            out = torch.empty(n, device="cuda")
+            _lib.check(lib.clid_debug_copy(out.data_ptr(), ptr, n * 4, _lib.stream()), "copy out")
+            want = sum(((base[:n] * (k % 7 + 1) + r * 3 + k) % 1021) for r in range(world))
+            wrong += (out != want).sum()
+        torch.cuda.synchronize()
+        bad += int(wrong.item())
         _lib.check(lib.clid_p2p_status(obj, _lib.stream()), "clid_p2p_status")
         result["bad"] = bad
     np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([int(result["made"]), result.get("bad", -1)]))
