@@ -546,33 +546,31 @@ __global__ void __launch_bounds__(256) k_window_flags(WindowArgs a, unsigned cha
     if (tot) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[0]), (unsigned long long)tot);
   }
 }
-// in the local map?  inside the radius and -- unless fewer than 100 points are inside the time window, which drops the
-// window (:462-466) -- inside the time window.  Evaluated where it is needed (the scan's input iterator, the gather) instead
-// of by a launch of its own that wrote a 4-byte flag per row of the capacity.
-struct WindowFlag {
-  WindowArgs a;
-  const unsigned char* bits;
-  const long long* counts;
-  __device__ __forceinline__ int operator()(long long i) const {
-    if (i >= window_n(a)) return 0;  // rows of the capacity beyond the map: nothing there (the scan runs over the upper bound)
-    const bool use_time = a.temporal && counts[0] >= 100;
-    const unsigned char b = bits[i];
-    return ((b & 2) && (!use_time || (b & 1))) ? 1 : 0;
+// fewer than 100 points inside the time window -> the window is dropped (:462-466)
+__global__ void __launch_bounds__(256) k_window_combine(WindowArgs a, const unsigned char* __restrict__ bits, long long n_upper,
+                                                        const long long* __restrict__ counts, int* __restrict__ flag) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_upper) return;
+  if (i >= window_n(a)) {  // rows of the capacity beyond the map: nothing there (the scan runs over the upper bound)
+    flag[i] = 0;
+    return;
   }
-};
+  const bool use_time = a.temporal && counts[0] >= 100;
+  flag[i] = ((bits[i] & 2) && (!use_time || (bits[i] & 1))) ? 1 : 0;
+}
 struct WindowOut {
   long long cap;  // rows the local arrays can hold (local_ids, points, ..., features cap + 1): rows beyond it are not written
   long long* local_ids; long long* g2l; unsigned char* local_mask;
   float* l_points; float* l_orient; float* l_cert; int* l_ts; float* l_feat;
   const float* g_orient; const float* g_cert; const float* g_feat;
 };
-__global__ void __launch_bounds__(256) k_window_gather(WindowArgs a, WindowFlag flag, const int* __restrict__ pos,
+__global__ void __launch_bounds__(256) k_window_gather(WindowArgs a, const int* __restrict__ flag, const int* __restrict__ pos,
                                                        WindowOut o, long long* __restrict__ counts) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long n = window_n(a);
   if (i > n) return;
   if (i == n) {  // the padding element: always part of the mask, never of the map (:518-530)
-    const long long m = n > 0 ? pos[n - 1] + flag(n - 1) : 0;
+    const long long m = n > 0 ? pos[n - 1] + flag[n - 1] : 0;
     counts[1] = m;
     o.g2l[i] = -1;
     o.local_mask[i] = 1;
@@ -580,7 +578,7 @@ __global__ void __launch_bounds__(256) k_window_gather(WindowArgs a, WindowFlag 
       for (int c = 0; c < CLID_F; ++c) o.l_feat[m * CLID_F + c] = o.g_feat[n * CLID_F + c];
     return;
   }
-  const bool in = flag(i) != 0;
+  const bool in = flag[i] != 0;
   o.local_mask[i] = in ? 1 : 0;
   o.g2l[i] = in ? (long long)pos[i] : -1;
   if (!in) return;
@@ -1602,19 +1600,18 @@ extern "C" int clid_local_window(const float* neural_points, const int32_t* ts_c
   char* ws = static_cast<char*>(workspace);
   const long long nu = n_upper;  // grids, scan and workspace cover the upper bound; the kernels read the exact size
   unsigned char* bits = reinterpret_cast<unsigned char*>(ws);
+  int* flag = reinterpret_cast<int*>(ws + align256((size_t)nu));
   int* pos = reinterpret_cast<int*>(ws + align256((size_t)nu) + align256((size_t)nu * 4));
   void* cub = ws + align256((size_t)nu) + 2 * align256((size_t)nu * 4);
   size_t cub_bytes = nu > 0 ? pool_scan_bytes(nu) : 0;
   WindowArgs a{neural_points, ts_create, ts_update, travel_dist, n, reinterpret_cast<const long long*>(n_extra_dev), cur_ts,
                use_mid_ts, temporal, use_travel_dist, diff_ts_local, reboot_ts, reboot_map, diff_travel, sensor_pos_host[0],
                sensor_pos_host[1], sensor_pos_host[2], radius2, pos_is_f64};
-  const WindowFlag wf{a, bits, counts};
   if (nu > 0) {
     const unsigned blocks = (unsigned)((nu + 255) / 256);
     hipLaunchKernelGGL(k_window_flags, dim3(blocks < kFlagBlocks ? blocks : kFlagBlocks), dim3(256), 0, s, a, bits, counts);
-    hipcub::TransformInputIterator<int, WindowFlag, hipcub::CountingInputIterator<long long>> in_flags(
-        hipcub::CountingInputIterator<long long>(0), wf);
-    if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, in_flags, pos, (int)nu, s) != hipSuccess) {
+    hipLaunchKernelGGL(k_window_combine, dim3(blocks), dim3(256), 0, s, a, bits, nu, counts, flag);
+    if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)nu, s) != hipSuccess) {
       clid_set_error("clid_local_window: scan failed");
       return CLID_E_HIP;
     }
@@ -1622,7 +1619,7 @@ extern "C" int clid_local_window(const float* neural_points, const int32_t* ts_c
   WindowOut o{(long long)local_capacity, reinterpret_cast<long long*>(local_ids_out), reinterpret_cast<long long*>(global2local_out), local_mask_out,
               local_points_out, local_orient_out, local_cert_out, local_ts_out, local_feat_out, point_orientations,
               point_certainties, geo_features};
-  hipLaunchKernelGGL(k_window_gather, dim3((unsigned)((nu + 1 + 255) / 256)), dim3(256), 0, s, a, wf, pos, o, counts);
+  hipLaunchKernelGGL(k_window_gather, dim3((unsigned)((nu + 1 + 255) / 256)), dim3(256), 0, s, a, flag, pos, o, counts);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }
