@@ -765,6 +765,14 @@ class Mapper:
                 # the new-sample selection (below) launched on the pool arrays still in flight: it reads the two pool counts on
                 # the device, so ONE read-back serves the pool maintenance and the selection
                 new_pending = self._new_sample_launch_pending(coord.shape[0])
+            if os.environ.get("CLID_TABLE_PREFETCH", "1") != "0":
+                # the local probe table of the mapping() call that follows (csrc/table.hip, ~30 us at 250 k local points) depends on
+                # the map only: built now on a third stream, next to the pool's compaction, instead of in front of the searches
+                third = getattr(self, "_third_stream", None)
+                if third is None or third.device != coord.device:
+                    third = self._third_stream = torch.cuda.Stream(device=coord.device)
+                third.wait_stream(main)
+                nm.prefetch_local_table(third)
             self._pool_filter_finish(with_tail=new_pending is not None)
         elif fused_pool:
             self._pool_append_filter_fused(coord, gcoord if gcoord is not None else transform_torch(coord, cur_pose_torch),

@@ -730,6 +730,10 @@ class NeuralPoints(nn.Module):
         slot = (locally, time_filtering)
         hit = self._tables.get(slot)
         if hit is not None and hit[0] == key:
+            ev = self.__dict__.get("_table_event")  # built ahead on another stream (Mapper.process_frame): order behind it
+            if ev is not None and ev[0] == slot:
+                torch.cuda.current_stream(hit[2].device).wait_event(ev[1])
+                self.__dict__["_table_event"] = None
             return hit[1], hit[2], hit[3]
         lib = _lib.load()
         _lib.require_cuda(big, "buffer_pt_index", torch.int64)
@@ -765,6 +769,15 @@ class NeuralPoints(nn.Module):
         )
         self._tables[slot] = (key, (tab, tab_pos, filt, log2filter), pos4, log2cap)
         return (tab, tab_pos, filt, log2filter), pos4, log2cap
+
+    def prefetch_local_table(self, stream) -> None:
+        """Build the local probe table for the current map state on `stream` (which the caller has ordered behind the
+        map update) so that it executes next to whatever the caller's stream still runs; the next `_map_view(True)` finds it
+        cached and orders itself behind the build."""
+        slot = (True, bool(self.temporal_local_map_on))
+        with torch.cuda.stream(stream):
+            self._table(*slot)
+            self._table_event = (slot, stream.record_event())
 
     def _map_view(self, query_locally: bool, time_filtering=None):
         """Fill a clid_map_view for the current tensors.  Returns (view, keep_alive)."""
