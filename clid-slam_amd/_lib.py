@@ -153,6 +153,7 @@ _SIGS = {
     "clid_p2p_capacity": (_i64, [_vp]),
     "clid_p2p_buffer": (_vp, [_vp]),
     "clid_p2p_allreduce": (C.c_int, [_vp, _i64, _vp]),
+    "clid_p2p_allreduce_or": (C.c_int, [_vp, _vp, _i64, _vp]),
     "clid_p2p_status": (C.c_int, [_vp, _vp]),
     "clid_p2p_destroy": (C.c_int, [_vp]),
     "clid_debug_copy": (C.c_int, [_vp, _vp, _i64, _vp]),

@@ -65,6 +65,8 @@ __device__ __forceinline__ void p2p_barrier(const P2pPtrs& p, int rank, int worl
   __scoped_atomic_thread_fence(__ATOMIC_ACQUIRE, __MEMORY_SCOPE_SYSTEM);  // nothing read from a peer before this point is reused
 }
 
+// OR_BITS: the 16-byte words are combined with a bitwise OR instead of four float additions (0 / 1 flag bytes: OR == MAX)
+template <bool OR_BITS>
 __global__ void __launch_bounds__(kP2pThreads) k_p2p_allreduce(P2pPtrs p, int rank, int world, long long n4, unsigned epoch,
                                                                int* err) {
   const long long per = (n4 + world - 1) / world;  // float4 per slice
@@ -78,10 +80,17 @@ __global__ void __launch_bounds__(kP2pThreads) k_p2p_allreduce(P2pPtrs p, int ra
       f32x4 acc = __builtin_nontemporal_load(&p.data[0][off + i]);
       for (int r = 1; r < world; ++r) {
         const f32x4 v = __builtin_nontemporal_load(&p.data[r][off + i]);
-        acc.x = __fadd_rn(acc.x, v.x);
-        acc.y = __fadd_rn(acc.y, v.y);
-        acc.z = __fadd_rn(acc.z, v.z);
-        acc.w = __fadd_rn(acc.w, v.w);
+        if (OR_BITS) {
+          acc.x = __uint_as_float(__float_as_uint(acc.x) | __float_as_uint(v.x));
+          acc.y = __uint_as_float(__float_as_uint(acc.y) | __float_as_uint(v.y));
+          acc.z = __uint_as_float(__float_as_uint(acc.z) | __float_as_uint(v.z));
+          acc.w = __uint_as_float(__float_as_uint(acc.w) | __float_as_uint(v.w));
+        } else {
+          acc.x = __fadd_rn(acc.x, v.x);
+          acc.y = __fadd_rn(acc.y, v.y);
+          acc.z = __fadd_rn(acc.z, v.z);
+          acc.w = __fadd_rn(acc.w, v.w);
+        }
       }
       p.data[rank][off + i] = acc;
     }
@@ -222,7 +231,7 @@ extern "C" void* clid_p2p_buffer(clid_p2p* p) {
   return p->data + (size_t)p->cur * p->capacity;
 }
 
-extern "C" int clid_p2p_allreduce(clid_p2p* p, int64_t count_floats, void* stream) {
+static int p2p_exchange(clid_p2p* p, int64_t count_floats, bool or_bits, void* stream) {
   if (!p || count_floats < 0 || count_floats * 4 > p->capacity) {
     clid_set_error("clid_p2p_allreduce: bad argument (%lld floats, capacity %lld bytes)", (long long)count_floats,
                    p ? (long long)p->capacity : 0LL);
@@ -241,10 +250,42 @@ extern "C" int clid_p2p_allreduce(clid_p2p* p, int64_t count_floats, void* strea
     ptrs.flags[r] = r < p->world ? static_cast<unsigned*>(p->peer_flags[r]) : nullptr;
   }
   const long long n4 = (count_floats + 3) / 4;
-  hipLaunchKernelGGL(k_p2p_allreduce, dim3(kP2pBlocks), dim3(kP2pThreads), 0, (hipStream_t)stream, ptrs, p->rank, p->world, n4,
-                     p->epoch, p2p_err_word(p));
+  if (or_bits)
+    hipLaunchKernelGGL(k_p2p_allreduce<true>, dim3(kP2pBlocks), dim3(kP2pThreads), 0, (hipStream_t)stream, ptrs, p->rank, p->world,
+                       n4, p->epoch, p2p_err_word(p));
+  else
+    hipLaunchKernelGGL(k_p2p_allreduce<false>, dim3(kP2pBlocks), dim3(kP2pThreads), 0, (hipStream_t)stream, ptrs, p->rank, p->world,
+                       n4, p->epoch, p2p_err_word(p));
   p->epoch += 2;
   CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+extern "C" int clid_p2p_allreduce(clid_p2p* p, int64_t count_floats, void* stream) {
+  return p2p_exchange(p, count_floats, false, stream);
+}
+
+// bitwise OR over the ranks of `bytes` bytes at `buf` (any device memory: staged through the current exchange buffer), in
+// place -- the MAX of 0 / 1 flag bytes (the touched-row flags of a chunk, clid_mapping_run_dist)
+extern "C" int clid_p2p_allreduce_or(clid_p2p* p, void* buf, int64_t bytes, void* stream) {
+  if (!p || !buf || bytes < 0 || bytes + 16 > p->capacity) {
+    clid_set_error("clid_p2p_allreduce_or: bad argument (%lld bytes, capacity %lld)", (long long)bytes, p ? (long long)p->capacity : 0LL);
+    return CLID_E_ARG;
+  }
+  if (bytes == 0 || p->world == 1) return CLID_OK;
+  hipStream_t s = (hipStream_t)stream;
+  char* x = p->data + (size_t)p->cur * p->capacity;
+  const int64_t padded = (bytes + 15) & ~(int64_t)15;
+  if (hipMemcpyAsync(x, buf, (size_t)bytes, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+      (padded > bytes && hipMemsetAsync(x + bytes, 0, (size_t)(padded - bytes), s) != hipSuccess)) {
+    clid_set_error("clid_p2p_allreduce_or: staging failed");
+    return CLID_E_HIP;
+  }
+  if (int e = p2p_exchange(p, padded / 4, true, stream)) return e;
+  if (hipMemcpyAsync(buf, x, (size_t)bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    clid_set_error("clid_p2p_allreduce_or: copy back failed");
+    return CLID_E_HIP;
+  }
   return CLID_OK;
 }
 

@@ -1651,7 +1651,6 @@ extern "C" int clid_mapping_run_dist(const clid_map_view* mv, const clid_train_a
              clid_p2p_capacity(px) < (int64_t)sizeof(float) * (CLID_GRAD_FEAT_OFFSET16 + 9LL * (mv->M + 1) + 4)))
     px = nullptr;
   for (int it = 0; it < iters; ++it) {
-    if (px) ta.cbuf = static_cast<float*>(clid_p2p_buffer(px));
     ta.index = index_base + (int64_t)it * index_stride;
     ta.loss_out = loss_base + (size_t)it * 4;
     ta.touch_iter = it % chunk;
@@ -1670,11 +1669,18 @@ extern "C" int clid_mapping_run_dist(const clid_map_view* mv, const clid_train_a
           for (int i = 0; i < n_it; ++i) counts[i] = mv->M;
         } else if (ta.touch_ws) {
           // the union over the ranks of the rows each iteration touches: every rank then packs the same list
-          if (int e = clid_comm_allreduce(comm, ta.touch_ws, (int64_t)n_it * ta.touch_stride, 2, 1, stream)) return e;
-          moved += ((long long)n_it * ta.touch_stride + 3) / 4;
+          const int64_t flag_bytes = (int64_t)n_it * ta.touch_stride;
+          if (px && flag_bytes + 16 <= clid_p2p_capacity(px)) {
+            if (int e = clid_p2p_allreduce_or(px, ta.touch_ws, flag_bytes, stream)) return e;
+          } else if (int e = clid_comm_allreduce(comm, ta.touch_ws, flag_bytes, 2, 1, stream)) {
+            return e;
+          }
+          moved += (flag_bytes + 3) / 4;
           if (int e = clid_train_touch_scan(&ta, mv->M, n_it, it, compact ? counts : nullptr, stream)) return e;
         }
       }
+      // (after the chunk's flag exchange, which takes one turn of the two exchange buffers itself)
+      if (px) ta.cbuf = static_cast<float*>(clid_p2p_buffer(px));
       if (int e = clid_train_decode(mv, &ta, ws.rec + (size_t)(it % chunk) * per_iter, stream)) return e;
     } else {
       if (int e = clid_train_fwd_bwd(mv, &ta, stream)) return e;

@@ -472,8 +472,6 @@ class Mapper:
         M_local = int(view.M)
         px = ta.p2p if compact else None
         for it in range(iter_count):
-            if px:
-                ta.cbuf = lib.clid_p2p_buffer(px)
             ta.index = shard_base + it * row_bytes
             ta.loss_out = loss_base + it * 16
             ta.touch_iter = it % chunk
@@ -489,10 +487,15 @@ class Mapper:
                             counts[i] = M_local
                     elif ta.touch_ws:
                         flags = self._touch_ws[0][: n_it * int(ta.touch_stride)]
-                        dist.all_reduce(flags, op=dist.ReduceOp.MAX)  # union over the ranks of each iteration's rows
+                        if px and flags.numel() + 16 <= int(lib.clid_p2p_capacity(px)):
+                            _lib.check(lib.clid_p2p_allreduce_or(px, flags.data_ptr(), flags.numel(), stream), "clid_p2p_allreduce_or")
+                        else:
+                            dist.all_reduce(flags, op=dist.ReduceOp.MAX)  # union over the ranks of each iteration's rows
                         moved += (flags.numel() + 3) // 4
                         _lib.check(lib.clid_train_touch_scan(C.byref(ta), M_local, n_it, it, counts if compact else None, stream),
                                    "clid_train_touch_scan")
+                if px:  # (after the chunk's flag exchange, which takes one turn of the two exchange buffers itself)
+                    ta.cbuf = lib.clid_p2p_buffer(px)
                 _lib.check(lib.clid_train_decode(C.byref(view), C.byref(ta),
                                                  self._rec.data_ptr() + (it % chunk) * per_iter * 4, stream),
                            "clid_train_decode")

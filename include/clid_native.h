@@ -356,6 +356,9 @@ int32_t clid_p2p_world(const clid_p2p* p);
 int64_t clid_p2p_capacity(const clid_p2p* p); /* bytes of one exchange buffer */
 void* clid_p2p_buffer(clid_p2p* p);
 int clid_p2p_allreduce(clid_p2p* p, int64_t count_floats, void* stream);
+/* bitwise OR over the ranks of `bytes` bytes at `buf` (any device memory; staged through the current exchange buffer), in
+ * place: the MAX of 0 / 1 flag bytes -- the touched-row flags of a chunk in clid_mapping_run_dist. */
+int clid_p2p_allreduce_or(clid_p2p* p, void* buf, int64_t bytes, void* stream);
 int clid_p2p_status(clid_p2p* p, void* stream);
 int clid_p2p_destroy(clid_p2p* p);
 /* test aid: device-to-device copy on `stream` (the exchange buffers are not tensors of the host framework) */

@@ -46,6 +46,17 @@ def _run(rank, world, port, out_dir):
             torch.cuda.synchronize()
             bad += int((out.cpu() != want).sum())
             assert int(lib.clid_p2p_buffer(obj)) != ptr  # the buffers alternate
+        # bitwise OR of flag bytes held in ordinary device memory (the touched-row flags of a chunk): odd sizes, both buffers
+        for k, nbytes in enumerate((1, 17, 23_497 * 3, 1_000_003)):
+            g = torch.Generator().manual_seed(500 + k)
+            flags = [(torch.rand(nbytes, generator=g) < 0.2).to(torch.uint8) for _ in range(world)]
+            want = flags[0].clone()
+            for r in range(1, world):
+                want |= flags[r]
+            mine = flags[rank].cuda()
+            _lib.check(lib.clid_p2p_allreduce_or(obj, mine.data_ptr(), nbytes, _lib.stream()), "clid_p2p_allreduce_or")
+            torch.cuda.synchronize()
+            bad += int((mine.cpu() != want).sum())
         # many exchanges back to back without any host synchronisation in between (the training loop's pattern: fill the
         # current buffer, exchange, read the sums, next buffer), sizes changing every time; verified on the device
         gen = torch.Generator().manual_seed(77)
