@@ -53,8 +53,16 @@ __device__ __forceinline__ float centre_dist(float x, float y, float z, float v,
 
 // `value` != NULL: the per-point score of voxel_down_sample_min_value_torch (utils/tools.py:685-724; non-negative)
 // takes the place of the distance to the voxel centre.
-__global__ void __launch_bounds__(256) k_vox_stats(const float* __restrict__ pts, int n, float v, int* __restrict__ box,
-                                                   const float* __restrict__ value) {
+// n_dev != NULL: the number of points is read on the device (at most n: the grid's bound) -- a caller that has not read the
+// count of the pass that produced the points (Mapper.process_frame: the sampler's compaction)
+__device__ __forceinline__ int vox_n(int n, const long long* __restrict__ n_dev) {
+  if (!n_dev) return n;
+  const long long m = *n_dev;
+  return m < (long long)n ? (int)m : n;
+}
+__global__ void __launch_bounds__(256) k_vox_stats(const float* __restrict__ pts, int n_bound, float v, int* __restrict__ box,
+                                                   const float* __restrict__ value, const long long* __restrict__ n_dev) {
+  const int n = vox_n(n_bound, n_dev);
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
   unsigned dm = 0u;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -123,11 +131,12 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long k) {
   return k;
 }
 
-__global__ void __launch_bounds__(256) k_vox_insert(const float* __restrict__ pts, int n, float v, VoxStats* st,
+__global__ void __launch_bounds__(256) k_vox_insert(const float* __restrict__ pts, int n_bound, float v, VoxStats* st,
                                                     long long* keys, unsigned long long* vals, int log2cap,
-                                                    const float* __restrict__ value, const int* __restrict__ box) {
+                                                    const float* __restrict__ value, const int* __restrict__ box,
+                                                    const long long* __restrict__ n_dev) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= vox_n(n_bound, n_dev)) return;
   // tools.py:653, :661-663: offset = floor(min / v); stride = max(cell - offset) over ALL axes (not max + 1: voxels
   // whose coordinate equals the stride alias another voxel, reproduced on purpose -- it decides which points exist)
   long long off[3], stride = 0;
@@ -255,13 +264,15 @@ __device__ __forceinline__ long long vox_flat(const float* __restrict__ pts, int
 }
 
 // splitters[k] = sample of rank kVbPerBucket (k + 1), k = 0 .. kVbBuckets - 2, among the ids of 1024 evenly spaced input points
-__global__ void __launch_bounds__(kVbThreads) k_vox_splitters(const float* __restrict__ pts, int n, float v, const int* __restrict__ box,
-                                                              long long* __restrict__ split, unsigned* __restrict__ bucket_cnt) {
+__global__ void __launch_bounds__(kVbThreads) k_vox_splitters(const float* __restrict__ pts, int n_bound, float v, const int* __restrict__ box,
+                                                              long long* __restrict__ split, unsigned* __restrict__ bucket_cnt,
+                                                              const long long* __restrict__ n_dev) {
   __shared__ unsigned long long sval[kVbSamples];
   const int tid = threadIdx.x;
+  const int n = vox_n(n_bound, n_dev);
   if (tid < kVbBuckets) bucket_cnt[tid * kVbCntStride] = 0u;
   unsigned long long sk[1];
-  sk[0] = (unsigned long long)vox_flat(pts, (int)((long long)tid * n / kVbSamples), v, box);
+  sk[0] = n > 0 ? (unsigned long long)vox_flat(pts, (int)((long long)tid * n / kVbSamples), v, box) : 0ULL;
   vb_bitonic<1>(sk, sval, kVbSamples);
   if (tid % kVbPerBucket == 0 && tid > 0) split[tid / kVbPerBucket - 1] = (long long)sk[0];
 }
@@ -378,6 +389,7 @@ k_local_to_global(const long long* __restrict__ ids, int n, long long pad_row, c
 struct PoolSrc {
   const float* coord; const float* gcoord; const float* label; const float* weight; const int* time;
   long long n;
+  const long long* ndev;  // device, may be NULL: only the first min(*ndev, n) samples exist (n is then the arrays' bound)
 };
 __device__ __forceinline__ const float* pool_gcoord(const PoolSrc& a, const PoolSrc& b, long long i) {
   return i < a.n ? a.gcoord + i * 3 : b.gcoord + (i - a.n) * 3;
@@ -406,7 +418,10 @@ k_pool_flags(PoolSrc a, PoolSrc b, double ox, double oy, double oz, double r2, u
              int* __restrict__ block_cnt) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   bool f = false;
-  if (i < a.n + b.n) {
+  long long nb = b.n;
+  if (b.ndev) nb = *b.ndev < nb ? *b.ndev : nb;
+  if (i >= a.n + nb && i < a.n + b.n) flag[i] = 0;  // rows of the bound beyond the frame's samples: the later passes skip them
+  if (i < a.n + nb) {
     const float* g = pool_gcoord(a, b, i);
     const double dx = (double)g[0] - ox, dy = (double)g[1] - oy, dz = (double)g[2] - oz;  // mapper.py:346-349, float64
     f = ((dx * dx + dy * dy) + dz * dz) < r2;
@@ -829,7 +844,8 @@ extern "C" int64_t clid_voxel_workspace_bytes(int32_t n) {
 }
 
 static int vox_launch(const float* points, int32_t n, float voxel_size, const float* value, void* workspace,
-                      int64_t* idx_out, void* stream) {
+                      int64_t* idx_out, void* stream, const int64_t* n_dev_in = nullptr) {
+  const long long* n_dev = reinterpret_cast<const long long*>(n_dev_in);
   if (n < 0 || !(voxel_size > 0.f) || (n > 0 && (!points || !workspace || !idx_out))) {
     clid_set_error("clid_voxel_down_sample: bad argument");
     return CLID_E_ARG;
@@ -853,9 +869,9 @@ static int vox_launch(const float* points, int32_t n, float voxel_size, const fl
   hipLaunchKernelGGL(k_vox_init, dim3(1), dim3(64), 0, s, st, box);
   int sb = (n + 255) / 256;
   if (sb > 256) sb = 256;  // every block ends in 7 atomics, one per cache line (on ONE line 512 blocks spent 15 of 18 us there)
-  hipLaunchKernelGGL(k_vox_stats, dim3(sb), dim3(256), 0, s, points, n, voxel_size, box, value);
+  hipLaunchKernelGGL(k_vox_stats, dim3(sb), dim3(256), 0, s, points, n, voxel_size, box, value, n_dev);
   hipLaunchKernelGGL(k_vox_insert, dim3((n + 255) / 256), dim3(256), 0, s, points, n, voxel_size, st, keys, vals, log2cap,
-                     value, box);
+                     value, box, n_dev);
   long long* split = reinterpret_cast<long long*>(ws + L.split);
   unsigned* bcnt = reinterpret_cast<unsigned*>(ws + L.bcnt);
   long long* bkeys = reinterpret_cast<long long*>(ws + L.bkeys);
@@ -863,7 +879,7 @@ static int vox_launch(const float* points, int32_t n, float voxel_size, const fl
   const unsigned table_blocks1k = (unsigned)((((size_t)1 << log2cap) + 1023) / 1024);
   const bool bucketed = n <= (1 << 21);  // beyond: the buckets would overflow anyway
   if (bucketed) {
-    hipLaunchKernelGGL(k_vox_splitters, dim3(1), dim3(kVbThreads), 0, s, points, n, voxel_size, box, split, bcnt);
+    hipLaunchKernelGGL(k_vox_splitters, dim3(1), dim3(kVbThreads), 0, s, points, n, voxel_size, box, split, bcnt, n_dev);
     hipLaunchKernelGGL(k_vox_partition, dim3(table_blocks1k * 4), dim3(256), 0, s, keys, vals, log2cap, st, split, bcnt, bkeys, bidx);
     hipLaunchKernelGGL(k_vox_bucket_sort, dim3(kVbBuckets), dim3(kVbThreads), 0, s, bcnt, bkeys, bidx, st,
                        reinterpret_cast<long long*>(idx_out));
@@ -930,8 +946,8 @@ static int vox_down_sample(const float* points, int32_t n, float voxel_size, con
 // the two halves on their own: a caller that has other work to enqueue puts it between them (it then runs on the device /
 // is prepared on the host while the first half executes); nothing else may use `workspace` in between
 extern "C" int clid_voxel_down_sample_launch(const float* points, int32_t n, float voxel_size, const float* value,
-                                             void* workspace, int64_t* idx_out, void* stream) {
-  return vox_launch(points, n, voxel_size, value, workspace, idx_out, stream);
+                                             const int64_t* n_dev, void* workspace, int64_t* idx_out, void* stream) {
+  return vox_launch(points, n, voxel_size, value, workspace, idx_out, stream, n_dev);
 }
 extern "C" int clid_voxel_down_sample_finish(int32_t n, void* workspace, int64_t* idx_out, void* stream) {
   return vox_finish(n, workspace, idx_out, stream);
@@ -1355,7 +1371,7 @@ extern "C" int clid_pool_filter(const float* coord_a, const float* gcoord_a, con
                                 const float* label_b, const float* weight_b, const int32_t* time_b, int64_t n_b,
                                 const double* origin_host, double radius2, int64_t capacity, uint64_t seed, float* coord_out,
                                 float* gcoord_out, float* label_out, float* weight_out, int32_t* time_out,
-                                int64_t* counts_out, void* workspace, void* stream) {
+                                int64_t* counts_out, void* workspace, const int64_t* n_b_dev, void* stream) {
   const long long n = n_a + n_b;
   if (n_a < 0 || n_b < 0 || n >= (1LL << 31) || !origin_host || !counts_out || !workspace || capacity < 0 ||
       (n_a > 0 && (!coord_a || !gcoord_a || !label_a || !weight_a || !time_a)) ||
@@ -1375,7 +1391,8 @@ extern "C" int clid_pool_filter(const float* coord_a, const float* gcoord_a, con
   int* kept_list = reinterpret_cast<int*>(ws + align256((size_t)n) + 2 * align256((size_t)nblk * 4));
   void* cub = ws + align256((size_t)n) + 2 * align256((size_t)nblk * 4) + align256((size_t)n * 4);
   size_t cub_bytes = pool_scan_bytes(nblk);
-  const PoolSrc a{coord_a, gcoord_a, label_a, weight_a, time_a, n_a}, b{coord_b, gcoord_b, label_b, weight_b, time_b, n_b};
+  const PoolSrc a{coord_a, gcoord_a, label_a, weight_a, time_a, n_a, nullptr},
+      b{coord_b, gcoord_b, label_b, weight_b, time_b, n_b, reinterpret_cast<const long long*>(n_b_dev)};
   const unsigned blocks = (unsigned)nblk;
   hipLaunchKernelGGL(k_pool_flags, dim3(blocks), dim3(256), 0, s, a, b, origin_host[0], origin_host[1], origin_host[2], radius2,
                      flag, block_cnt);

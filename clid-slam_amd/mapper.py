@@ -698,6 +698,7 @@ class Mapper:
 
         normal_label = sem_label = color_label = None
         gcoord = None
+        defer_cmp = False
         fused_compact = (not use_pin and pts.is_cuda and hasattr(self.sampler, "_run") and getattr(cfg, "from_sample_points", True)
                          and not getattr(cfg, "from_all_samples", False) and os.environ.get("CLID_FUSED_COMPACT", "1") != "0")
         if use_pin:  # :224-239
@@ -706,7 +707,15 @@ class Mapper:
         elif fused_compact:
             # :240-283 + :297-310 in one enqueue: compaction of the sampler's rows, frame stamps, world-frame coordinates for
             # the pool and the near-surface world-frame subset that grows the map; ONE read-back for the two counts
-            coord, gcoord, sdf_label, weight, stamp, update_points = self._sample_compact_fused(pts, cur_pose_torch, frame_id)
+            # Where the pool maintenance will run on the side stream (below), nothing needs the compaction's two counts before
+            # the map growth's voxel count is read: they stay on the device for the launches in between and are read then.
+            defer_cmp = (self.sem_label_pool is None and self.color_pool is None and self.normal_label_pool is None
+                         and not self.ba_done_flag and (frame_id + 1) % getattr(cfg, "pool_filter_freq", 1) == 0
+                         and cur_pose_torch.dtype == torch.float64 and self.coord_pool.shape[0] + 8 * pts.shape[0] < (1 << 31)
+                         and os.environ.get("CLID_FUSED_POOL", "1") != "0" and os.environ.get("CLID_POOL_OVERLAP", "1") != "0"
+                         and os.environ.get("CLID_DEFER_COMPACT_COUNT", "1") != "0" and pts.shape[0] > 0)
+            coord, gcoord, sdf_label, weight, stamp, update_points = self._sample_compact_fused(pts, cur_pose_torch, frame_id,
+                                                                                               defer_counts=defer_cmp)
         else:  # :240-245, the region-specific SDF estimation
             coord, sdf_label, weight = self.sampler.sample(pts, self.local_point_cloud_map, cur_pose_torch)
         n_cur = coord.shape[0]
@@ -748,16 +757,30 @@ class Mapper:
             from .tools import voxel_down_sample_finish, voxel_down_sample_launch, voxel_down_sample_torch
 
             two_phase = update_points.is_cuda and update_points.shape[0] > 0
-            pending_vox = voxel_down_sample_launch(update_points, nm.resolution) if two_phase else None
+            cmp_dev = self._cmp_counts if defer_cmp else None  # [kept rows, near-surface rows] of the compaction, on the device
+            pending_vox = (voxel_down_sample_launch(update_points, nm.resolution, n_dev=None if cmp_dev is None else cmp_dev[1:2])
+                           if two_phase else None)
             main = torch.cuda.current_stream(coord.device)
             side = getattr(self, "_side_stream", None)
             if side is None or side.device != coord.device:
                 side = self._side_stream = torch.cuda.Stream(device=coord.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                self._pool_append_filter_fused(coord, gcoord, sdf_label, weight, stamp, cur_pose_torch, frame_id, defer=True)
+                self._pool_append_filter_fused(coord, gcoord, sdf_label, weight, stamp, cur_pose_torch, frame_id, defer=True,
+                                               n_b_dev=None if cmp_dev is None else cmp_dev[0:1])
             keep_idx = voxel_down_sample_finish(pending_vox) if two_phase else voxel_down_sample_torch(update_points, nm.resolution)
+            if defer_cmp:  # (the stream has just been drained by the voxel count's round trip: this one finds its data ready)
+                kept, n_near = _lib.read_counts(self._cmp_counts, 2)
+                coord, gcoord, sdf_label, weight, stamp = coord[:kept], gcoord[:kept], sdf_label[:kept], weight[:kept], stamp[:kept]
+                update_points = update_points[:n_near]
+                n_cur = self.cur_sample_count = kept
+                defer_cmp = False
             nm._presampled = (update_points, update_points[keep_idx])
+        if defer_cmp:  # (not reached with the conditions above; kept for safety: settle the counts before anything uses the rows)
+            kept, n_near = _lib.read_counts(self._cmp_counts, 2)
+            coord, gcoord, sdf_label, weight, stamp = coord[:kept], gcoord[:kept], sdf_label[:kept], weight[:kept], stamp[:kept]
+            update_points = update_points[:n_near]
+            n_cur = self.cur_sample_count = kept
         self.cur_new_point_ratio = nm.update(update_points, origin, orientation, frame_id)
 
         self.determine_used_pose()
@@ -816,7 +839,7 @@ class Mapper:
                     if frame_id > cfg.freeze_after_frame and ratio > getattr(cfg, "new_sample_ratio_restart", 0.3):
                         self.adaptive_iter_offset = 10
 
-    def _sample_compact_fused(self, pts, cur_pose_torch, frame_id):
+    def _sample_compact_fused(self, pts, cur_pose_torch, frame_id, defer_counts=False):
         """Sampler launch + `clid_sample_compact`: (coord, gcoord, sdf_label, weight, stamp, update_points) of this frame
         as utils/mapper.py:240-283 / :297-310 produce them (kept rows in order; update_points = world-frame rows with
         |sdf| < surface_sample_range_m * map_surface_ratio)."""
@@ -839,6 +862,10 @@ class Mapper:
                                            out1[1].data_ptr(), stamp.data_ptr(), out3[2].data_ptr(),
                                            self._cmp_counts.data_ptr(), self._cmp_ws.data_ptr(), _lib.stream()),
                    "clid_sample_compact")
+        if defer_counts:
+            # the caller reads the two counts later (with the map growth's voxel count) and slices then: full-capacity tensors,
+            # the device counts for the launches in between
+            return out3[0], out3[1], out1[0], out1[1], stamp, out3[2]
         kept, n_near = _lib.read_counts(self._cmp_counts, 2)  # the one host round trip (sizes the views)
         return out3[0][:kept], out3[1][:kept], out1[0][:kept], out1[1][:kept], stamp[:kept], out3[2][:n_near]
 
@@ -956,7 +983,8 @@ class Mapper:
             self.pool_sample_count = self.coord_pool.shape[0]
 
 
-    def _pool_append_filter_fused(self, coord, gcoord, sdf_label, weight, stamp, cur_pose_torch, frame_id, defer=False):
+    def _pool_append_filter_fused(self, coord, gcoord, sdf_label, weight, stamp, cur_pose_torch, frame_id, defer=False,
+                                  n_b_dev=None):
         """utils/mapper.py:297-392 in one enqueue (csrc/mapops.hip clid_pool_filter): append this frame's samples, window
         test in float64, random drop above `pool_capacity`, stable compaction of the five arrays into the other half of a
         ping-pong buffer; ONE small read-back for the two counts the host needs (pool size for the batch draws, number
@@ -993,7 +1021,7 @@ class Mapper:
             b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), b[3].data_ptr(), b[4].data_ptr(), n_b,
             origin, float(cfg.window_radius) ** 2, int(cfg.pool_capacity), self._pool_drop_seed,
             out["coord"].data_ptr(), out["gcoord"].data_ptr(), out["label"].data_ptr(), out["weight"].data_ptr(),
-            out["time"].data_ptr(), self._pool_counts.data_ptr(), self._pool_ws.data_ptr(), _lib.stream()), "clid_pool_filter")
+            out["time"].data_ptr(), self._pool_counts.data_ptr(), self._pool_ws.data_ptr(), _lib.ptr(n_b_dev), _lib.stream()), "clid_pool_filter")
         self._pool_pending = (side, out, (a, b))  # (inputs stay referenced until the launches have been joined)
         if not defer:
             self._pool_filter_finish()

@@ -69,7 +69,7 @@ def get_time():
 _VOX_WS = {}
 
 
-def voxel_down_sample_launch(points: torch.Tensor, voxel_size: float, value: torch.Tensor = None):
+def voxel_down_sample_launch(points: torch.Tensor, voxel_size: float, value: torch.Tensor = None, n_dev: torch.Tensor = None):
     """First half of the voxel down-sampling on device tensors (`clid_voxel_down_sample_launch`): everything is enqueued,
     nothing is waited for.  Returns a handle for `voxel_down_sample_finish`; no other voxel down-sampling may run on the
     device in between (they share one workspace)."""
@@ -86,8 +86,9 @@ def voxel_down_sample_launch(points: torch.Tensor, voxel_size: float, value: tor
         ws = _VOX_WS[pts.device] = torch.empty(int(need * 1.25) + 256, device=pts.device, dtype=torch.uint8)
     out = torch.empty(n, device=pts.device, dtype=torch.int64)
     val = None if value is None else value.detach().to(device=pts.device, dtype=torch.float32).contiguous()
-    _lib.check(lib.clid_voxel_down_sample_launch(pts.data_ptr(), n, float(voxel_size), _lib.ptr(val), ws.data_ptr(), out.data_ptr(),
-                                                 _lib.stream()), "clid_voxel_down_sample_launch")
+    # n_dev (device int64[1]): only the first *n_dev rows of `points` count (a count the caller has not read back yet)
+    _lib.check(lib.clid_voxel_down_sample_launch(pts.data_ptr(), n, float(voxel_size), _lib.ptr(val), _lib.ptr(n_dev), ws.data_ptr(),
+                                                 out.data_ptr(), _lib.stream()), "clid_voxel_down_sample_launch")
     return (pts, val, ws, out, n)
 
 

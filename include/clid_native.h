@@ -443,9 +443,11 @@ int clid_voxel_down_sample(const float* points, int32_t n, float voxel_size, voi
                            void* stream);
 /* The same in two halves: _launch enqueues everything (value may be NULL: distance to the voxel centre), _finish makes
  * the round trip (and orders with the library sort where the device-side ordering gave up) and returns m.  A caller with
- * other work to enqueue puts it between the two; nothing else may use `workspace` in between. */
-int clid_voxel_down_sample_launch(const float* points, int32_t n, float voxel_size, const float* value, void* workspace,
-                                  int64_t* idx_out, void* stream);
+ * other work to enqueue puts it between the two; nothing else may use `workspace` in between.  n_dev != NULL (device int64):
+ * the number of points is *n_dev <= n, read on the device -- for points whose count the caller has not read back yet (the
+ * k_vox_insert fallback inside _finish needs the same points and count still in place). */
+int clid_voxel_down_sample_launch(const float* points, int32_t n, float voxel_size, const float* value, const int64_t* n_dev,
+                                  void* workspace, int64_t* idx_out, void* stream);
 int clid_voxel_down_sample_finish(int32_t n, void* workspace, int64_t* idx_out, void* stream);
 /* voxel_down_sample_min_value_torch (utils/tools.py:685-724): as above, but the point of a voxel with the smallest
  * `value` [n] (>= 0; quantised to 1000 levels of its maximum, lowest index among equals) is taken -- the selection
@@ -486,7 +488,8 @@ int clid_pool_filter(const float* coord_a, const float* gcoord_a, const float* l
                      const int32_t* time_a, int64_t n_a, const float* coord_b, const float* gcoord_b, const float* label_b,
                      const float* weight_b, const int32_t* time_b, int64_t n_b, const double* origin_host, double radius2,
                      int64_t capacity, uint64_t seed, float* coord_out, float* gcoord_out, float* label_out,
-                     float* weight_out, int32_t* time_out, int64_t* counts_out, void* workspace, void* stream);
+                     float* weight_out, int32_t* time_out, int64_t* counts_out, void* workspace, const int64_t* n_b_dev,
+                     void* stream); /* n_b_dev != NULL (device int64): only the first min(*n_b_dev, n_b) samples of `b` exist */
 
 /* LocalPointCloudMap.update_map (model/local_point_cloud_map.py:43-72) after the voxel down-sampling of the scan: the
  * `samples` whose voxel slot in table_old is still empty are appended to the map, the map is cropped to `map_size` around

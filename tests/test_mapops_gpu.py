@@ -196,7 +196,7 @@ def test_pool_filter_window_capacity_and_order(n_a, n_b, capacity):
     _lib.check(lib.clid_pool_filter(ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]), ptr(a[4]), n_a, ptr(b[0]), ptr(b[1]), ptr(b[2]),
                                     ptr(b[3]), ptr(b[4]), n_b, (C.c_double * 3)(*origin), radius * radius, capacity, seed,
                                     out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), out[4].data_ptr(),
-                                    counts.data_ptr(), ws.data_ptr(), _lib.stream()), "clid_pool_filter")
+                                    counts.data_ptr(), ws.data_ptr(), None, _lib.stream()), "clid_pool_filter")
     kept, kept_cur = [int(v) for v in counts[:2].tolist()]
     # host restatement
     dist2 = ((gcoord.double() - torch.tensor(origin, dtype=torch.float64)) ** 2).sum(1)
