@@ -35,6 +35,9 @@ sys.path.insert(0, ROOT)
 # wake-up was measured to arrive 30-60 ms late in about 1 run of 20 (GPU events 0.64 ms, wall clock 58.7 ms:
 # `timed_region_split` in the output line).  Must be set before the HSA runtime starts, i.e. before importing torch.
 os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+# the peer-mapped A/B leg of a multi-GPU run: a flag wait gives up after 20 s here (library default 600 s) and the call is
+# repeated over RCCL, so a transport that does not work on this node costs seconds, not the run
+os.environ.setdefault("CLID_P2P_TIMEOUT_S", "20")
 
 import torch  # noqa: E402
 
@@ -256,35 +259,69 @@ def main():
     # (measured: 0.044 instead of 0.035 ms per step).
     gc.collect()
     gc.disable()
-    for _ in range(args.warmup):  # W untimed steps, one per call: the GPU's clocks ramp over several hundred us of work
-        mp.mapping(1)             # (a single 5-iteration call leaves the first timed call 14 % slow: tools/warm_clocks.py)
-    sync()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    t_start = None
-    if args.diag:
-        while not ev0.query():
-            pass
-        t_start = time.perf_counter() - t0
-    mp.mapping(args.steps)
-    ev1.record()
-    t_enq = time.perf_counter() - t0
-    while not ev1.query():  # poll for the end of the K steps, THEN the barrier + torch.cuda.synchronize() of the contract: an
-        pass                # interrupt-driven wait on an already idle GPU was seen to return 30-60 ms late (about 1 run in 20)
-    t_poll = time.perf_counter() - t0
-    sync()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    timed_split = {"host_enqueue_ms": 1e3 * t_enq, "gpu_ms": float(ev0.elapsed_time(ev1)), "wall_ms": 1e3 * dt,
-                   "poll_done_ms": 1e3 * t_poll}
-    if t_start is not None:
-        timed_split["first_event_done_ms"] = 1e3 * t_start
-    if dist:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+
+    def timed_region():
+        """W untimed warm-up steps, then EXACTLY K steps of one mapping() call between two barrier + synchronize pairs;
+        returns (seconds = max over the ranks, split of the region on this rank)."""
+        for _ in range(args.warmup):  # W untimed steps, one per call: the GPU's clocks ramp over several hundred us of work
+            mp.mapping(1)             # (a single 5-iteration call leaves the first timed call 14 % slow: tools/warm_clocks.py)
+        sync()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        t_start = None
+        if args.diag:
+            while not ev0.query():
+                pass
+            t_start = time.perf_counter() - t0
+        mp.mapping(args.steps)
+        ev1.record()
+        t_enq = time.perf_counter() - t0
+        while not ev1.query():  # poll for the end of the K steps, THEN the barrier + torch.cuda.synchronize() of the contract: an
+            pass                # interrupt-driven wait on an already idle GPU was seen to return 30-60 ms late (about 1 run in 20)
+        t_poll = time.perf_counter() - t0
+        sync()
+        dt = time.perf_counter() - t0
+        split = {"host_enqueue_ms": 1e3 * t_enq, "gpu_ms": float(ev0.elapsed_time(ev1)), "wall_ms": 1e3 * dt,
+                 "poll_done_ms": 1e3 * t_poll}
+        if t_start is not None:
+            split["first_event_done_ms"] = 1e3 * t_start
+        if dist:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, split
+
+    def exchange_report(dt):
+        ex = mp.last_exchange or {}
+        return {"ms_per_step": 1e3 * dt / args.steps, "value": bs_global * args.steps / dt,
+                "mode": ex.get("mode"), "transport": ex.get("transport"), "bytes_per_iter": ex.get("bytes_per_iter"),
+                "dense_bytes_per_iter": ex.get("dense_bytes_per_iter"), "p2p_fallbacks": int(mp.p2p_fallbacks)}
+
+    # ---- the headline leg: the default exchange -- RCCL all-reduce (north_star), dense or compact by map size
+    dt, timed_split = timed_region()
     losses = mp.last_losses[-1].tolist()
+    legs = None
+    if dist:
+        # ---- A/B of the gradient exchange in the SAME processes (one SCALE run answers which transport to keep): every
+        # leg is a full W-warm-up + K-step region like the headline.  A timed-out flag wait of the peer-mapped transport
+        # does not abort: Mapper.mapping restores, falls back to RCCL and the leg reports `p2p_fallbacks` (and the
+        # transport it actually ended on).
+        headline = exchange_report(dt)
+        legs = {}
+        plan = (("rccl_dense", "dense", "rccl"), ("rccl_compact", "compact", "rccl"), ("p2p_compact", "compact", "p2p"))
+        for name, mode, transport in plan:
+            if headline["mode"] == mode and transport == "rccl":
+                legs[name] = dict(headline, headline=True)
+                continue
+            mp.exchange_mode, mp.exchange_transport = mode, transport
+            leg_dt, _ = timed_region()
+            legs[name] = exchange_report(leg_dt)
+        mp.exchange_mode, mp.exchange_transport = None, None
+        if any(v["p2p_fallbacks"] for v in legs.values()):
+            legs["p2p_error"] = getattr(mp, "last_p2p_error", None)
+        mp.mapping(1)  # (the remaining legs of this file run on the default exchange again)
+    gc.enable()
 
     # ---- the reference's per-frame regime: mapping(10) per scan (slam.py:187-200), each call timed on its own
     frame = None
@@ -357,8 +394,7 @@ def main():
                 "neural_points_local": M, "pool_samples": int(mp.pool_sample_count), "buffer_size": cfg.buffer_size,
                 "parallelism": f"dp{world} (batch sharded, RCCL all-reduce of [decoder|feature] grads)" if world > 1 else "single GPU",
                 "rccl_ranks_in_c_abi": rccl_ranks,
-                "gradient_exchange": None if world == 1 or not mp.last_exchange else {
-                    k: mp.last_exchange[k] for k in ("mode", "transport", "bytes_per_iter", "dense_bytes_per_iter")},
+                "gradient_exchange": legs,
             },
             "final_loss": {"total": losses[0], "bce": losses[1], "eikonal": losses[2]},
             "per_frame_regime": frame, "roofline": roof, "cpu_baseline": base,

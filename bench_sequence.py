@@ -83,12 +83,15 @@ def _wrap_stages(mp, nm, lpm, acc):
     wrap(nm, "assign_local_to_global", "assign_local_to_global")
 
 
-def run(frames, device, check_frames=0, seed=42, quiet=False, breakdown=None, after_process=None):
+def run(frames, device, check_frames=0, seed=42, quiet=False, breakdown=None, after_process=None, freeze_after_frame=None,
+        teacher_iters=10):
     from clid_slam_amd import Decoder, LocalPointCloudMap, Mapper, NeuralPoints
     from clid_slam_amd.synth import hall_scan, sweep_poses
     from clid_slam_amd.tools import freeze_model
 
     cfg = subt_config(device)
+    if freeze_after_frame is not None:  # tests: reach the frozen-decoder steady state (slam.py:193-196) within a few frames
+        cfg.freeze_after_frame = int(freeze_after_frame)
     torch.manual_seed(seed)
     nm = NeuralPoints(cfg)
     dec = Decoder(cfg, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, 1)
@@ -121,12 +124,8 @@ def run(frames, device, check_frames=0, seed=42, quiet=False, breakdown=None, af
         if fid < check_frames:
             snap = _snapshot(nm, dec, mp, cfg)
             idx = mp._draw_index(max(1, iters + mp.adaptive_iter_offset), cfg.bs)
-            mp._grad_probe = True  # gradients of the call's first iteration on the untouched state (no optimiser step)
-            try:
-                probe = mp.mapping(1, index_seq=idx[:1])
-            finally:
-                mp._grad_probe = False
-            snap = snap + (probe,)
+            recs = _oracle_replay(snap, idx, mp, cfg)
+            snap = snap + (_teacher_forced_probes(recs, idx, nm, dec, mp, teacher_iters), recs)
             mp.mapping(iters, index_seq=idx)
         else:
             mp.mapping(iters)
@@ -186,36 +185,89 @@ def chaos_bounds(iters: int, entries: int, frozen: bool):
     return max(8, int(4 * frac * entries) + 1), (0.0 if frozen else max(1e-4, 4 * decd))
 
 
-def _check_against_oracle(snap, idx, nm, dec, mp, cfg, fid):
+def _oracle_replay(snap, idx, mp, cfg, n_max=16):
+    """The CPU oracle's loop (utils/mapper.py:642-836 restated) on the snapshot, teacher-forced with the call's batches;
+    the 400-iteration call of frame 0 is replayed for its first `n_max` iterations only."""
     from oracle import cpu_ref as O
 
-    st, od, pool, frozen, probe = snap
+    st, od, pool, frozen = snap
     lc = O.LoopConfig(sigma=mp.sdf_scale, gradient_decimation=cfg.gradient_decimation,
                       fd_eps=cfg.voxel_size_m * cfg.num_grad_step_ratio, lr=cfg.lr, adam_eps=cfg.adam_eps)
     if frozen:
         lc.train_decoder = False
-    n_all = idx.shape[0]
-    n_rep = min(n_all, 16)  # the 400-iteration call of frame 0 is replayed for its first iterations only (losses)
-    recs = O.mapping_iters(st, od, pool, idx.cpu()[:n_rep], lc, record=True)
+    return O.mapping_iters(st, od, pool, idx.cpu()[: min(idx.shape[0], n_max)], lc, record=True)
+
+
+def _teacher_forced_probes(recs, idx, nm, dec, mp, n_iters):
+    """Gradients of iteration t of the call on the ORACLE's state at the start of iteration t (theta_t, decoder_t loaded
+    into the HIP state; search + decode through the C ABI, no optimiser step: `Mapper._grad_probe`), t = 0 .. n_iters-1.
+    Adam's eps = 1e-15 amplification never enters: every iteration is compared on identical parameters, so a defect that
+    touches any row at any iteration shows at the gradient bar.  The state is restored afterwards."""
+    theta = nm.local_geo_features
+    theta0 = theta.data.clone()
+    dec0 = [p.data.clone() for p in dec.flat_params()]
+    cert0 = nm.local_point_certainties.clone()
+    probes = []
+    mp._grad_probe = True
+    try:
+        for t in range(min(len(recs), n_iters)):
+            if t > 0:
+                theta.data.copy_(recs[t - 1]["theta"].to(theta.device))
+                for p, o in zip(dec.flat_params(), recs[t - 1]["dec"]):
+                    p.data.copy_(o.to(p.device).view_as(p))
+            probes.append({k: v.cpu() for k, v in mp.mapping(1, index_seq=idx[t:t + 1]).items()})
+    finally:
+        mp._grad_probe = False
+        theta.data.copy_(theta0)
+        for p, o in zip(dec.flat_params(), dec0):
+            p.data.copy_(o)
+        nm.local_point_certainties.copy_(cert0)
+    return probes
+
+
+def _grad_row(probe, rec, frozen):
+    """One iteration's gradient comparison: every entry against the oracle's, relative to the largest entry of that
+    gradient tensor (gradients are sums of per-query terms; nothing amplifies them)."""
+    g0 = rec["grad_theta"]
+    gh = probe["theta"]
+    gmax = max(float(g0.abs().max()), 1e-30)
+    nz_hip, nz_ref = (gh != 0).any(1), (g0 != 0).any(1)
+    only_hip, only_ref = nz_hip & ~nz_ref, nz_ref & ~nz_hip
+    row = {"grad_theta_max": gmax, "dgrad_theta_rel": float((gh - g0).abs().max()) / gmax,
+           # rows the oracle never gathers get exactly zero here too (anything else would become a +-lr step); a gathered
+           # row whose eight sums cancel to exactly 0 in one summation order and to 1e-20 in another may differ: such rows
+           # are counted and their magnitude (relative to the largest gradient entry) is reported
+           "rows_nonzero_only_in_hip": int(only_hip.sum()), "rows_nonzero_only_in_oracle": int(only_ref.sum()),
+           "residue_rel": max(float(gh[only_hip].abs().max()) if bool(only_hip.any()) else 0.0,
+                              float(g0[only_ref].abs().max()) if bool(only_ref.any()) else 0.0) / gmax,
+           "dloss": abs(float(probe["loss"][0]) - float(rec["loss"]))}
+    if not frozen:
+        gd = torch.cat([rec["grad_" + n].reshape(-1) for n in ("W1", "b1", "W2", "b2")])
+        row["dgrad_decoder_rel"] = float((probe["decoder"] - gd).abs().max()) / max(float(gd.abs().max()), 1e-30)
+    elif float(probe["decoder"].abs().max()) != 0.0:
+        row["dgrad_decoder_rel"] = float("inf")  # a frozen decoder must receive no gradient at all
+    return row
+
+
+def _check_against_oracle(snap, idx, nm, dec, mp, cfg, fid):
+    st, od, pool, frozen, probes, recs = snap
+    n_all, n_rep = idx.shape[0], len(recs)
     got = mp.last_losses.cpu()
     out = dict(frame=fid, iters=n_all, replayed=n_rep, frozen=bool(frozen),
                max_dloss=max(abs(float(got[i, 0]) - float(r["loss"])) for i, r in enumerate(recs)))
-    # The gradients of the first iteration (HIP: search + decode on the snapshot state, no optimiser step) against the
-    # oracle's, EVERY entry: gradients are sums of per-query terms -- no eps = 1e-15 amplification -- so a defect in any
-    # row shows here at the 1e-4 relative bar, which the drift of the parameters after several Adam steps cannot show.
-    g0 = recs[0]["grad_theta"]
-    dg = (probe["theta"].cpu() - g0).abs()
-    out["grad_theta_max"] = float(g0.abs().max())
-    out["max_dgrad_theta_rel"] = float(dg.max()) / max(float(g0.abs().max()), 1e-30)
-    # rows the oracle never gathers receive exactly zero in the HIP path too (anything else would become a +-lr step); a
-    # gathered row whose eight sums cancel to exactly 0 in one summation order and to 1e-20 in the other may differ
-    nz_hip, nz_ref = (probe["theta"].cpu() != 0).any(1), (g0 != 0).any(1)
-    out["rows_nonzero_only_in_hip"] = int((nz_hip & ~nz_ref).sum())
-    out["rows_nonzero_only_in_oracle"] = int((nz_ref & ~nz_hip).sum())
-    if not frozen:
-        gd = torch.cat([recs[0]["grad_" + n].reshape(-1) for n in ("W1", "b1", "W2", "b2")])
-        out["max_dgrad_decoder_rel"] = float((probe["decoder"].cpu() - gd).abs().max()) / max(float(gd.abs().max()), 1e-30)
-    if n_rep == n_all:  # same number of Adam steps: parameters are comparable
+    # PRIMARY: teacher-forced gradients, every iteration, every entry (the loop of utils/mapper.py:642-836 with the
+    # oracle's parameters loaded before each iteration)
+    per_iter = [_grad_row(p, recs[t], frozen) for t, p in enumerate(probes)]
+    out["teacher_forced"] = per_iter
+    out["teacher_forced_iters"] = len(per_iter)
+    out["grad_theta_max"] = per_iter[0]["grad_theta_max"]
+    out["max_dgrad_theta_rel"] = max(r["dgrad_theta_rel"] for r in per_iter)
+    out["max_dgrad_decoder_rel"] = max(r.get("dgrad_decoder_rel", 0.0) for r in per_iter)
+    out["max_probe_dloss"] = max(r["dloss"] for r in per_iter)
+    out["rows_nonzero_only_in_hip"] = max(r["rows_nonzero_only_in_hip"] for r in per_iter)
+    out["rows_nonzero_only_in_oracle"] = max(r["rows_nonzero_only_in_oracle"] for r in per_iter)
+    out["max_residue_rel"] = max(r["residue_rel"] for r in per_iter)
+    if n_rep == n_all:  # SECONDARY (reported, not a pass/fail gate any more): free-running parameter drift
         dth = (nm.local_geo_features.detach().cpu() - recs[-1]["theta"]).abs()
         n_max, dec_max = chaos_bounds(n_all, dth.numel(), frozen)
         out.update(max_dtheta=float(dth.max()), n_dtheta_gt_1e4=int((dth > 1e-4).sum()), n_dtheta_gt_1e4_bound=n_max,

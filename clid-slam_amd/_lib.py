@@ -155,6 +155,9 @@ _SIGS = {
     "clid_p2p_allreduce": (C.c_int, [_vp, _i64, _vp]),
     "clid_p2p_allreduce_or": (C.c_int, [_vp, _vp, _i64, _vp]),
     "clid_p2p_status": (C.c_int, [_vp, _vp]),
+    "clid_p2p_set_timeout": (C.c_int, [_vp, C.c_double]),
+    "clid_p2p_agree": (C.c_int, [_vp, _vp, _vp]),
+    "clid_debug_p2p_fail": (C.c_int, [_vp, _vp]),
     "clid_p2p_destroy": (C.c_int, [_vp]),
     "clid_debug_copy": (C.c_int, [_vp, _vp, _i64, _vp]),
     "clid_comm_available": (C.c_int, []),
@@ -280,6 +283,26 @@ def rccl_comm(dist):
 
 
 _p2p = None  # peer-mapped exchange object of this process: None = not tried, False = unavailable, else (pointer, capacity)
+E_P2P_TIMEOUT = -4  # include/clid_native.h CLID_E_P2P_TIMEOUT
+
+
+class P2pTimeout(RuntimeError):
+    """A flag wait of the peer-mapped exchange gave up on some rank (agreed across the ranks: every rank raises).  The
+    sums of the call are invalid; `Mapper.mapping` restores its saved state and repeats the call over RCCL."""
+
+
+def p2p_default() -> bool:
+    """The per-iteration payload of a sharded run goes over RCCL (what north_star names) unless the peer-mapped transport
+    is asked for: CLID_P2P=1, or `Mapper.exchange_transport = "p2p"`."""
+    return os.environ.get("CLID_P2P", "0") == "1"
+
+
+def p2p_disable() -> None:
+    """Rule the peer-mapped exchange out for the rest of this process (after a timeout: its epoch counters and error word
+    are no longer trustworthy).  The object stays allocated -- peers may still have it mapped."""
+    global _p2p
+    _p2p = False
+
 
 
 def p2p_exchange(dist, need_bytes: int):
@@ -297,7 +320,7 @@ def p2p_exchange(dist, need_bytes: int):
     old = _p2p
     _p2p = False
     rank, world = dist.get_rank(), dist.get_world_size()
-    if os.environ.get("CLID_P2P", "1") == "0" or world > 8:
+    if world > 8:
         return None
     dev = torch.device("cuda", torch.cuda.current_device())
     wire = dev if dist.get_backend() == "nccl" else torch.device("cpu")
@@ -323,6 +346,10 @@ def p2p_exchange(dist, need_bytes: int):
         flat = torch.cat(parts).cpu().tolist()
         ok = agree(lib.clid_p2p_connect(obj, (C.c_uint8 * (nb * world))(*flat)) == 0)
     if ok:
+        try:  # how long a flag wait polls before it gives up (default 600 s: a benign skew between ranks must not abort a run)
+            lib.clid_p2p_set_timeout(obj, float(os.environ.get("CLID_P2P_TIMEOUT_S", "600")))
+        except ValueError:
+            pass
         ok = agree(lib.clid_p2p_selftest(obj, stream()) == 0)
     if not ok:
         if made:
@@ -333,16 +360,21 @@ def p2p_exchange(dist, need_bytes: int):
     return obj
 
 
-def p2p_likely(dist) -> bool:
-    """True while the peer-mapped exchange has not been ruled out for this process (not yet tried, or set up): the sharded
-    loop then prefers the compact exchange at every map size, because that is the payload the object carries."""
-    return _p2p is not False and os.environ.get("CLID_P2P", "1") != "0" and dist.get_world_size() <= 8
+def p2p_likely(dist, wanted=None) -> bool:
+    """True while the peer-mapped exchange is asked for (`wanted`, default CLID_P2P=1) and has not been ruled out for this
+    process (not yet tried, or set up): the sharded loop then prefers the compact exchange at every map size, because that is
+    the payload the object carries."""
+    wanted = p2p_default() if wanted is None else bool(wanted)
+    return wanted and _p2p is not False and dist.get_world_size() <= 8
 
 
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().clid_last_error()
-        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+        text = f"{what} failed ({rc}): {msg.decode() if msg else ''}"
+        if rc == E_P2P_TIMEOUT:
+            raise P2pTimeout(text)
+        raise RuntimeError(text)
 
 
 def ptr(t) -> int:

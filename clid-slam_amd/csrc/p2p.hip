@@ -16,9 +16,13 @@
 // iteration t's result out of the other buffer, and nobody can be two exchanges ahead (barrier A).
 //
 // Memory is exported / imported with HIP IPC handles; the host distributes the handle blobs with its own mechanism
-// (torch.distributed all_gather), exactly as it distributes the RCCL id.  A flag wait gives up after ~10 s of wall clock
-// and raises the object's error word instead of hanging the GPU; clid_p2p_selftest runs exchanges of exactly representable
-// values before the object is trusted (the caller takes the MIN over the ranks and keeps RCCL otherwise).
+// (torch.distributed all_gather), exactly as it distributes the RCCL id.  A flag wait gives up after the object's timeout
+// (default 600 s like an RCCL collective's watchdog; clid_p2p_set_timeout) and raises the object's error word instead of
+// hanging the GPU for ever.  The error word is LOCAL: a caller must agree on it across the ranks (clid_mapping_run_dist does,
+// through the RCCL communicator, and returns CLID_E_P2P_TIMEOUT on EVERY rank) before it decides anything, and the sums
+// of a timed-out exchange are garbage -- the host restores its pre-call state and repeats the call over RCCL
+// (Mapper.mapping).  clid_p2p_selftest runs exchanges of exactly representable values before the object is trusted (the
+// caller takes the MIN over the ranks and keeps RCCL otherwise).
 #include <string.h>
 #include <unistd.h>
 
@@ -30,7 +34,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kP2pMaxWorld = 8, kP2pBlocks = 64, kP2pThreads = 256;
 constexpr size_t kP2pFlagBytes = (size_t)kP2pBlocks * kP2pMaxWorld * sizeof(unsigned) * 2;  // + room for the error word
-constexpr long long kP2pTimeoutTicks = 1000000000LL;  // wall_clock64 runs at 100 MHz: 10 s (ranks may be seconds apart at first use)
+constexpr double kP2pTicksPerSecond = 1.0e8;  // wall_clock64 runs at 100 MHz
+constexpr double kP2pDefaultTimeoutS = 600.0;  // a benign skew between ranks (one of them saves a mesh, evaluates, ...) is
+                                               // minutes at most: the default matches the RCCL watchdog's order of magnitude
 
 struct P2pBlob {  // what one rank exports
   hipIpcMemHandle_t data, flags;
@@ -43,7 +49,8 @@ struct P2pPtrs {
   unsigned* flags[kP2pMaxWorld];
 };
 
-__device__ __forceinline__ void p2p_barrier(const P2pPtrs& p, int rank, int world, unsigned epoch, int* err) {
+__device__ __forceinline__ void p2p_barrier(const P2pPtrs& p, int rank, int world, unsigned epoch, int* err,
+                                            long long timeout_ticks) {
   // every thread publishes its own stores first (write-back to memory, system scope), then the block meets, then one
   // thread per peer raises this block's flag at the peer and waits for the peer's flag here
   __scoped_atomic_thread_fence(__ATOMIC_RELEASE, __MEMORY_SCOPE_SYSTEM);
@@ -54,7 +61,7 @@ __device__ __forceinline__ void p2p_barrier(const P2pPtrs& p, int rank, int worl
     const unsigned* mine = &p.flags[rank][blockIdx.x * kP2pMaxWorld + peer];
     const long long t0 = wall_clock64();
     while ((int)(__scoped_atomic_load_n(mine, __ATOMIC_RELAXED, __MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
-      if (wall_clock64() - t0 > kP2pTimeoutTicks || __scoped_atomic_load_n(err, __ATOMIC_RELAXED, __MEMORY_SCOPE_SYSTEM)) {  // (one timeout fails the object: no further waits)
+      if (wall_clock64() - t0 > timeout_ticks || __scoped_atomic_load_n(err, __ATOMIC_RELAXED, __MEMORY_SCOPE_SYSTEM)) {  // (one timeout fails the object: no further waits)
         atomicExch(err, 1);
         break;
       }
@@ -68,11 +75,11 @@ __device__ __forceinline__ void p2p_barrier(const P2pPtrs& p, int rank, int worl
 // OR_BITS: the 16-byte words are combined with a bitwise OR instead of four float additions (0 / 1 flag bytes: OR == MAX)
 template <bool OR_BITS>
 __global__ void __launch_bounds__(kP2pThreads) k_p2p_allreduce(P2pPtrs p, int rank, int world, long long n4, unsigned epoch,
-                                                               int* err) {
+                                                               int* err, long long timeout_ticks) {
   const long long per = (n4 + world - 1) / world;  // float4 per slice
   const long long stride = (long long)gridDim.x * kP2pThreads;
   const long long t = (long long)blockIdx.x * kP2pThreads + threadIdx.x;
-  p2p_barrier(p, rank, world, epoch + 1, err);
+  p2p_barrier(p, rank, world, epoch + 1, err, timeout_ticks);
   {
     const long long off = per * rank;
     const long long len = (off + per <= n4 ? per : (n4 > off ? n4 - off : 0));
@@ -95,7 +102,7 @@ __global__ void __launch_bounds__(kP2pThreads) k_p2p_allreduce(P2pPtrs p, int ra
       p.data[rank][off + i] = acc;
     }
   }
-  p2p_barrier(p, rank, world, epoch + 2, err);
+  p2p_barrier(p, rank, world, epoch + 2, err, timeout_ticks);
   for (int s = 0; s < world; ++s) {
     if (s == rank) continue;
     const long long off = per * s;
@@ -132,6 +139,8 @@ struct clid_p2p {
   bool connected;
   unsigned epoch;
   int cur;                // the buffer the next exchange runs on
+  long long timeout_ticks;
+  int* agree;             // one int32 in ordinary device memory: the error word as the communicator's MAX sees it
 };
 
 static int* p2p_err_word(clid_p2p* p) { return reinterpret_cast<int*>(p->flags + kP2pBlocks * kP2pMaxWorld); }
@@ -150,6 +159,8 @@ extern "C" int clid_p2p_create(int32_t rank, int32_t world, int64_t capacity_byt
   p->connected = false;
   p->epoch = 0;
   p->cur = 0;
+  p->timeout_ticks = (long long)(kP2pDefaultTimeoutS * kP2pTicksPerSecond);
+  p->agree = nullptr;
   for (int r = 0; r < kP2pMaxWorld; ++r) p->peer_data[r] = p->peer_flags[r] = nullptr;
   void* d = nullptr;
   void* f = nullptr;
@@ -168,6 +179,15 @@ extern "C" int clid_p2p_create(int32_t rank, int32_t world, int64_t capacity_byt
       return CLID_E_HIP;
     }
   }
+  void* ag = nullptr;
+  if (hipMalloc(&ag, 256) != hipSuccess || hipMemset(ag, 0, 256) != hipSuccess) {
+    clid_set_error("clid_p2p_create: cannot allocate the agreement word");
+    (void)hipFree(d);
+    (void)hipFree(f);
+    delete p;
+    return CLID_E_HIP;
+  }
+  p->agree = static_cast<int*>(ag);
   if (hipMemset(f, 0, kP2pFlagBytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
     clid_set_error("clid_p2p_create: flag reset failed");
     (void)hipFree(d);
@@ -252,10 +272,10 @@ static int p2p_exchange(clid_p2p* p, int64_t count_floats, bool or_bits, void* s
   const long long n4 = (count_floats + 3) / 4;
   if (or_bits)
     hipLaunchKernelGGL(k_p2p_allreduce<true>, dim3(kP2pBlocks), dim3(kP2pThreads), 0, (hipStream_t)stream, ptrs, p->rank, p->world,
-                       n4, p->epoch, p2p_err_word(p));
+                       n4, p->epoch, p2p_err_word(p), p->timeout_ticks);
   else
     hipLaunchKernelGGL(k_p2p_allreduce<false>, dim3(kP2pBlocks), dim3(kP2pThreads), 0, (hipStream_t)stream, ptrs, p->rank, p->world,
-                       n4, p->epoch, p2p_err_word(p));
+                       n4, p->epoch, p2p_err_word(p), p->timeout_ticks);
   p->epoch += 2;
   CLID_CHECK_LAUNCH();
   return CLID_OK;
@@ -289,13 +309,61 @@ extern "C" int clid_p2p_allreduce_or(clid_p2p* p, void* buf, int64_t bytes, void
   return CLID_OK;
 }
 
-// 0 = no flag wait has timed out since the object was created (synchronises `stream`)
+// flag waits of later exchanges give up after `seconds` of wall clock (same value on every rank, please)
+extern "C" int clid_p2p_set_timeout(clid_p2p* p, double seconds) {
+  if (!p || !(seconds > 0.0) || seconds > 86400.0) {
+    clid_set_error("clid_p2p_set_timeout: bad argument");
+    return CLID_E_ARG;
+  }
+  p->timeout_ticks = (long long)(seconds * kP2pTicksPerSecond);
+  return CLID_OK;
+}
+
+// 0 = no flag wait has timed out ON THIS RANK since the object was created (synchronises `stream`); CLID_E_P2P_TIMEOUT
+// otherwise.  Local knowledge: agree on it across the ranks before acting (clid_p2p_agree).
 extern "C" int clid_p2p_status(clid_p2p* p, void* stream) {
   if (!p) return CLID_E_ARG;
   int32_t e = 0;
   if (int rc = clid_read_back(p2p_err_word(p), 4, &e, stream)) return rc;
   if (e) {
-    clid_set_error("clid_p2p: a peer did not arrive at an exchange within 10 s (rank %d of %d)", p->rank, p->world);
+    clid_set_error("clid_p2p: a peer did not arrive at an exchange within %.0f s (rank %d of %d)",
+                   (double)p->timeout_ticks / kP2pTicksPerSecond, p->rank, p->world);
+    return CLID_E_P2P_TIMEOUT;
+  }
+  return CLID_OK;
+}
+
+// Collective over `comm` (the RCCL communicator of the same ranks): the MAX of the ranks' error words, so EVERY rank
+// returns CLID_E_P2P_TIMEOUT when ANY rank saw a flag wait give up, and CLID_OK on all of them otherwise.  Synchronises
+// `stream`.
+extern "C" int clid_p2p_agree(clid_p2p* p, clid_comm* comm, void* stream) {
+  if (!p || !comm) {
+    clid_set_error("clid_p2p_agree: null argument");
+    return CLID_E_ARG;
+  }
+  if (hipMemcpyAsync(p->agree, p2p_err_word(p), 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+    clid_set_error("clid_p2p_agree: copy failed");
+    return CLID_E_HIP;
+  }
+  if (int e = clid_comm_allreduce(comm, p->agree, 1, 1, 1, stream)) return e;
+  int32_t e = 0;
+  if (int rc = clid_read_back(p->agree, 4, &e, stream)) return rc;
+  if (e) {
+    clid_set_error("clid_p2p: a rank of the group gave up waiting at an exchange (timeout %.0f s; seen from rank %d of %d): "
+                   "the sums of this call are invalid on every rank",
+                   (double)p->timeout_ticks / kP2pTicksPerSecond, p->rank, p->world);
+    return CLID_E_P2P_TIMEOUT;
+  }
+  return CLID_OK;
+}
+
+// test aid: raise this rank's error word as a timed-out flag wait would (the fallback path of the hosts is tested with it)
+extern "C" int clid_debug_p2p_fail(clid_p2p* p, void* stream) {
+  if (!p) return CLID_E_ARG;
+  const int32_t one = 1;
+  if (hipMemcpyAsync(p2p_err_word(p), &one, 4, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+    clid_set_error("clid_debug_p2p_fail: copy failed");
     return CLID_E_HIP;
   }
   return CLID_OK;
@@ -351,6 +419,7 @@ extern "C" int clid_p2p_destroy(clid_p2p* p) {
   }
   (void)hipFree(p->data);
   (void)hipFree(p->flags);
+  (void)hipFree(p->agree);
   delete p;
   return CLID_OK;
 }

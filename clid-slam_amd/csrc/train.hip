@@ -1706,8 +1706,10 @@ extern "C" int clid_mapping_run_dist(const clid_map_view* mv, const clid_train_a
       if (int e = clid_comm_allreduce(comm, mv->ts_update, mv->M, 1, 1, stream)) return e;
   }
   if (exchanged_floats_host) *exchanged_floats_host = moved;
+  // a flag wait that gave up on ANY rank invalidates the call on EVERY rank: agreed through the communicator, so all ranks
+  // return the same code and the host repeats the call over RCCL from its saved state
   if (px && iters > 0)
-    if (int e = clid_p2p_status(px, stream)) return e;
+    if (int e = clid_p2p_agree(px, comm, stream)) return e;
   return CLID_OK;
 }
 

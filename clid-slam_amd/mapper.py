@@ -82,6 +82,11 @@ class Mapper:
         self.decode_variant = None
         self.pipeline = None
         self.last_exchange = None  # world > 1: what the last mapping() call all-reduced (floats, mode)
+        # world > 1: how the per-iteration gradient payload travels.  transport None = RCCL unless CLID_P2P=1 ("rccl" / "p2p":
+        # peer-mapped buffers, csrc/p2p.hip); mode None = by map size, CLID_SPARSE ("dense" / "compact")
+        self.exchange_transport = None
+        self.exchange_mode = None
+        self.p2p_fallbacks = 0     # calls repeated over RCCL after a timed-out flag wait of the peer-mapped exchange
 
     def reserve(self, iter_count: int):
         """Size the cached workspaces of `mapping()` for calls of up to `iter_count` iterations on the current local
@@ -335,7 +340,11 @@ class Mapper:
         # local map.  CLID_SPARSE = 0 / 1 / auto.
         M_local = n_feat // _lib.F - 1
         mode = os.environ.get("CLID_SPARSE", "auto")
-        floor = self.SPARSE_MIN_ROWS if not dist else (0 if _lib.p2p_likely(dist) else self.SPARSE_MIN_ROWS_DIST)
+        if dist and getattr(self, "exchange_mode", None) in ("dense", "compact"):
+            mode = "1" if self.exchange_mode == "compact" else "0"
+        transport = getattr(self, "exchange_transport", None)
+        want_p2p = bool(dist) and _lib.p2p_likely(dist, None if transport is None else transport == "p2p")
+        floor = self.SPARSE_MIN_ROWS if not dist else (0 if want_p2p else self.SPARSE_MIN_ROWS_DIST)
         want = mode == "1" or (mode != "0" and M_local >= floor)
         use_touch = bool(want and tile and float(cfg.weight_decay) == 0.0)
         cbuf = None
@@ -364,6 +373,7 @@ class Mapper:
         if getattr(self, "_grad_probe", False):
             return self._probe_gradients(lib, view, keep, ta, grad, losses, idx_base, bs_global, n_feat // _lib.F, dev, stream)
         cert_in_rows = True
+        saved = None
         try:
             if not dist:
                 # single GPU: the whole loop is enqueued by one C call (hoisted searches + 2 launches per iteration)
@@ -378,10 +388,14 @@ class Mapper:
                 cert_in_rows = tile
                 cert0 = None if cert_in_rows else nm.local_point_certainties.clone()
                 comm = _lib.rccl_comm(dist)
-                if cbuf is not None and hoist:
-                    # compact exchange: the per-iteration payload goes over peer-mapped buffers when every rank could set
-                    # them up (csrc/p2p.hip: one launch per rank instead of an RCCL ring), RCCL / torch.distributed otherwise
+                if cbuf is not None and hoist and want_p2p:
+                    # compact exchange over peer-mapped buffers when asked for and every rank could set them up
+                    # (csrc/p2p.hip: one launch per rank instead of an RCCL ring); RCCL / torch.distributed otherwise
                     ta.p2p = _lib.p2p_exchange(dist, 4 * cbuf.numel())
+                    if ta.p2p:
+                        # a flag wait that gives up leaves garbage sums behind Adam steps already taken: keep what the
+                        # loop mutates, so the call can be repeated over RCCL (four small device copies per call)
+                        saved = self._save_trained_state(nm, (W1, b1, W2, b2))
                 shard_base = idx_base + batch_offset * 8
                 if comm is not None:
                     # RCCL behind the C ABI: the whole sharded loop is ONE host call, the all-reduce sits on the launch
@@ -402,6 +416,18 @@ class Mapper:
                                       "transport": "peer-mapped" if ta.p2p else ("rccl" if comm is not None else "torch.distributed"),
                                       "floats": moved, "bytes_per_iter": 4.0 * moved / max(iter_count, 1),
                                       "dense_bytes_per_iter": 4.0 * grad.numel(), "rows": M_local + 1}
+        except _lib.P2pTimeout as exc:
+            # agreed across the ranks (clid_p2p_agree / the MAX below): EVERY rank is here.  Restore, rule the transport
+            # out for this process, repeat the same batches over RCCL.
+            self._touch_ws = None
+            if saved is None:
+                raise
+            self._restore_trained_state(nm, (W1, b1, W2, b2), saved)
+            _lib.p2p_disable()
+            self.p2p_fallbacks += 1
+            self.last_p2p_error = str(exc)
+            del keep
+            return self.mapping(0, index_seq=index_seq)
         except Exception:
             self._touch_ws = None  # its flags may be half-written: the next call starts from a zeroed workspace
             raise
@@ -421,6 +447,22 @@ class Mapper:
         self.last_losses = losses
         self._keep = (keep, index_seq, grad, m, v, m_mlp, v_mlp)
         nm.assign_local_to_global()
+
+    def _save_trained_state(self, nm, dec_params):
+        """Copies of everything a mapping() call mutates (features, decoder, certainties, update stamps) in cached
+        buffers."""
+        src = [nm.local_geo_features.data, nm.local_point_certainties, nm.local_point_ts_update] + [p.data for p in dec_params]
+        bufs = getattr(self, "_saved_state", None)
+        if bufs is None or any(b.shape != t.shape or b.device != t.device or b.dtype != t.dtype for b, t in zip(bufs, src)):
+            bufs = self._saved_state = [torch.empty_like(t) for t in src]
+        for b, t in zip(bufs, src):
+            b.copy_(t)
+        return bufs
+
+    def _restore_trained_state(self, nm, dec_params, bufs):
+        dst = [nm.local_geo_features.data, nm.local_point_certainties, nm.local_point_ts_update] + [p.data for p in dec_params]
+        for b, t in zip(bufs, dst):
+            t.copy_(b)
 
     def _probe_gradients(self, lib, view, keep, ta, grad, losses, idx_base, bs, n_rows, dev, stream):
         """Checker aid (tests, bench_sequence --check-frames; `self._grad_probe = True` then `mapping(1, index_seq=...)`):
@@ -514,7 +556,14 @@ class Mapper:
             aa.step = it + 1
             _lib.check(lib.clid_train_adam(C.byref(aa), C.byref(ta), stream), "clid_train_adam")
         if px and iter_count > 0:
-            _lib.check(lib.clid_p2p_status(px, stream), "clid_p2p_status")
+            # a flag wait that gave up on ANY rank invalidates the call on EVERY rank: agree (MAX) before anybody decides
+            rc = int(lib.clid_p2p_status(px, stream))
+            if rc not in (0, _lib.E_P2P_TIMEOUT):
+                _lib.check(rc, "clid_p2p_status")
+            bad = torch.tensor([1 if rc else 0], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if int(bad.item()):
+                raise _lib.P2pTimeout("clid_p2p: a rank of the group gave up waiting at an exchange; the call's sums are invalid")
         return moved
 
     def _check_replicas(self, dist):

@@ -49,6 +49,7 @@ extern "C" {
 #define CLID_E_ARG (-1)
 #define CLID_E_SHAPE (-2)
 #define CLID_E_HIP (-3)
+#define CLID_E_P2P_TIMEOUT (-4) /* a flag wait of the peer-mapped exchange gave up: the call's sums are invalid, repeat it over RCCL */
 
 const char* clid_last_error(void);
 int clid_abi_version(void);
@@ -344,8 +345,12 @@ int clid_comm_destroy(clid_comm* comm);
  *   clid_p2p_buffer    the buffer the NEXT clid_p2p_allreduce works on: fill it, exchange, read the sums from it;
  *   clid_p2p_allreduce in-place SUM of its first count_floats floats over the ranks (one launch on `stream`; collective:
  *                      every rank issues the same sequence of exchanges);
- *   clid_p2p_status    0 unless a flag wait gave up (a peer did not arrive within ~10 s: the exchange's result is then
- *                      undefined and the object must not be used further); synchronises `stream`.
+ *   clid_p2p_set_timeout  how long a flag wait polls before it gives up (default 600 s, the order of an RCCL watchdog);
+ *   clid_p2p_status    CLID_OK unless a flag wait gave up ON THIS RANK (CLID_E_P2P_TIMEOUT: the sums since then are
+ *                      undefined and the object must not be used further); synchronises `stream`;
+ *   clid_p2p_agree     collective over the RCCL communicator of the same ranks: MAX of the error words, so every rank
+ *                      gets CLID_E_P2P_TIMEOUT when any rank timed out (clid_mapping_run_dist ends with it: the host then
+ *                      restores the state it saved before the call and repeats the call over RCCL -- Mapper.mapping).
  * At most 8 ranks, one node. */
 typedef struct clid_p2p clid_p2p;
 int64_t clid_p2p_blob_bytes(void);
@@ -360,7 +365,11 @@ int clid_p2p_allreduce(clid_p2p* p, int64_t count_floats, void* stream);
  * place: the MAX of 0 / 1 flag bytes -- the touched-row flags of a chunk in clid_mapping_run_dist. */
 int clid_p2p_allreduce_or(clid_p2p* p, void* buf, int64_t bytes, void* stream);
 int clid_p2p_status(clid_p2p* p, void* stream);
+int clid_p2p_set_timeout(clid_p2p* p, double seconds);
+int clid_p2p_agree(clid_p2p* p, clid_comm* comm, void* stream);
 int clid_p2p_destroy(clid_p2p* p);
+/* test aid: raise this rank's error word as a timed-out flag wait would */
+int clid_debug_p2p_fail(clid_p2p* p, void* stream);
 /* test aid: device-to-device copy on `stream` (the exchange buffers are not tensors of the host framework) */
 int clid_debug_copy(void* dst, const void* src, int64_t bytes, void* stream);
 
@@ -374,7 +383,8 @@ int clid_debug_copy(void* dst, const void* src, int64_t bytes, void* stream);
  *            iterations the touched-row flags (M bytes per iteration) are MAX-reduced over the ranks and the list lengths
  *            come back to the host (one synchronisation per chunk); see clid_train_args.touch_ws.  With t->p2p the
  *            compact buffer is summed over peer-mapped memory instead of by RCCL (the flags, losses and stamps still go
- *            through `comm`), and the call ends with clid_p2p_status (one more synchronisation).
+ *            through `comm`), and the call ends with clid_p2p_agree (one more synchronisation; CLID_E_P2P_TIMEOUT on
+ *            every rank if a flag wait gave up on any).
  * With the tile decode kernels the certainty increments travel with the gradient rows; with kernel 0 (dense only) the
  * caller merges its certainty deltas itself.  exchanged_floats_host (may be NULL): 4-byte words this rank contributed to
  * all-reduces during the loop (payload accounting for the benches). */

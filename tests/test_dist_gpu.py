@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(rank, world, port, out_dir, mode, sparse="0", p2p="1", every="0"):
+def _run(rank, world, port, out_dir, mode, sparse="0", p2p="1", every="0", fail_rank=-1):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import golden_io as gio
@@ -40,8 +40,20 @@ def _run(rank, world, port, out_dir, mode, sparse="0", p2p="1", every="0"):
     mpr, _ = shim_io.mapper(cfg, nm, dec)
     gen = torch.Generator().manual_seed(21)
     idx = torch.randint(0, p["coord"].shape[0], (iters, bs), generator=gen).cuda()
+    if fail_rank >= 0:
+        # the peer-mapped exchange object is set up (collectively), then ONE rank's error word is raised the way a flag
+        # wait that gave up raises it: every rank must notice, restore its state and repeat the call over the fallback
+        from clid_slam_amd import _lib
+
+        obj = _lib.p2p_exchange(dist, 1 << 20)
+        assert obj is not None
+        if rank == fail_rank:
+            _lib.check(_lib.load().clid_debug_p2p_fail(obj, _lib.stream()), "clid_debug_p2p_fail")
     mpr.mapping(iters, index_seq=idx)
     torch.cuda.synchronize()
+    if fail_rank >= 0:
+        assert mpr.p2p_fallbacks == 1 and mpr.last_exchange["transport"] != "peer-mapped", (rank, mpr.p2p_fallbacks, mpr.last_exchange)
+        assert _lib._p2p is False  # the transport stays ruled out for this process
     if rank == 0:
         np.savez(os.path.join(out_dir, f"w{world}.npz"), theta=nm.local_geo_features.detach().cpu().numpy(),
                  W1=dec.flat_params()[0].detach().cpu().numpy(), b2=dec.flat_params()[3].detach().cpu().numpy(),
@@ -80,3 +92,20 @@ def test_two_ranks_equal_one(tmp_path, mode, sparse, p2p, every):
             assert int(b["exchange"][0]) == 3 * (848 + 9 * (n_rows - 1))
     elif mode == "numerical":
         assert int(b["exchange"][1]) == 0 and int(b["exchange"][0]) == dense
+
+
+def test_p2p_timeout_falls_back_to_the_collective_on_every_rank(tmp_path):
+    """ADVICE r3 (csrc/p2p.hip): a flag wait that gives up on ONE rank must not leave that rank raising and its peers hanging
+    in the next collective with garbage sums applied.  The error word is agreed across the ranks at the end of the call;
+    every rank restores the state it saved before the call, rules the transport out and repeats the call over the
+    collective path -- the result equals the single-process one."""
+    port = 29900 + (os.getpid() % 1000)
+    _run(0, 1, port, str(tmp_path), "numerical")
+    a = dict(np.load(os.path.join(tmp_path, "w1.npz")))
+    os.environ.pop("CLID_SPARSE", None)
+    mp.spawn(_run, args=(2, port, str(tmp_path), "numerical", "1", "1", "1", 1), nprocs=2, join=True)
+    b = np.load(os.path.join(tmp_path, "w2.npz"))
+    assert np.abs(a["loss"] - b["loss"]).max() <= 2e-6
+    assert np.abs(a["theta"] - b["theta"]).max() <= 2e-5 and np.abs(a["W1"] - b["W1"]).max() <= 2e-5
+    assert np.abs(a["cert"] - b["cert"]).max() <= 2e-3 and np.array_equal(a["ts"], b["ts"])
+    assert int(b["exchange"][2]) == 0  # the repeated call did not use the peer-mapped buffers

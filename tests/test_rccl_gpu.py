@@ -36,13 +36,14 @@ def test_single_rank_communicator_allreduce():
     assert lib.clid_comm_allreduce(None, x.data_ptr(), 4, 0, 0, None) < 0  # errors are reported, not crashed on
 
 
-def _run(rank, world, port, out_dir, backend, ln, sparse="0"):
+def _run(rank, world, port, out_dir, backend, ln, sparse="0", p2p="0"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import golden_io as gio
     import shim_io
 
     os.environ["CLID_SPARSE"] = sparse
+    os.environ["CLID_P2P"] = p2p  # "1": the compact payload over the peer-mapped buffers; default: RCCL carries everything
     if backend:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -85,20 +86,22 @@ def _compare(a, b):
     assert np.array_equal(a["ts"], b["ts"])
 
 
-@pytest.mark.parametrize("ln,sparse", [(0, "0"), (1, "0"), (0, "1"), (1, "1")])
-def test_sharded_loop_in_c_with_one_shard_equals_the_single_gpu_loop(tmp_path, ln, sparse):
+@pytest.mark.parametrize("ln,sparse,p2p", [(0, "0", "0"), (1, "0", "0"), (0, "1", "0"), (1, "1", "0"), (0, "1", "1"), (1, "1", "1")])
+def test_sharded_loop_in_c_with_one_shard_equals_the_single_gpu_loop(tmp_path, ln, sparse, p2p):
     """sparse = "1": the compact exchange of clid_mapping_run_dist -- uint8 MAX all-reduce of the touched-row flags, count
     read-back per chunk, [848 | 9 x rows] float all-reduce per iteration -- through RCCL itself (one rank)."""
-    port = 29300 + (os.getpid() % 500) + ln + 2 * int(sparse)
+    port = 29300 + (os.getpid() % 500) + ln + 2 * int(sparse) + 4 * int(p2p)
     _run(0, 1, port, str(tmp_path), None, ln)
     os.environ.pop("CLID_SPARSE", None)
-    mp.spawn(_run, args=(1, port, str(tmp_path), "nccl", ln, sparse), nprocs=1, join=True)
+    os.environ.pop("CLID_P2P", None)
+    mp.spawn(_run, args=(1, port, str(tmp_path), "nccl", ln, sparse, p2p), nprocs=1, join=True)
     a, b = np.load(os.path.join(tmp_path, "single_w1.npz")), np.load(os.path.join(tmp_path, "nccl_w1.npz"))
     assert bool(b["rccl"]), "the RCCL communicator behind the C ABI was not used"
     assert bool(b["compact"]) == (sparse == "1")
-    # the compact payload goes through the peer-mapped exchange object inside clid_mapping_run_dist (buffer alternation,
-    # Adam reading the exchange buffers, the closing status check; with one rank the exchange itself is the identity)
-    assert bool(b["peer"]) == (sparse == "1")
+    # p2p = "1": the compact payload goes through the peer-mapped exchange object inside clid_mapping_run_dist (buffer
+    # alternation, Adam reading the exchange buffers, the closing agreement on the error word through RCCL; with one rank the
+    # exchange itself is the identity).  Default: RCCL carries the payload (north_star's all-reduce)
+    assert bool(b["peer"]) == (p2p == "1")
     _compare(a, b)
 
 
@@ -106,8 +109,9 @@ def test_sharded_loop_in_c_with_one_shard_equals_the_single_gpu_loop(tmp_path, l
 def test_two_ranks_over_rccl_equal_one(tmp_path):
     port = 29800 + (os.getpid() % 500)
     _run(0, 1, port, str(tmp_path), None, 0)
-    for sparse in ("0", "1"):
-        mp.spawn(_run, args=(2, port + int(sparse), str(tmp_path), "nccl", 0, sparse), nprocs=2, join=True)
+    os.environ.pop("CLID_P2P", None)
+    for k, (sparse, p2p) in enumerate((("0", "0"), ("1", "0"), ("1", "1"))):  # rccl dense | rccl compact | peer-mapped compact
+        mp.spawn(_run, args=(2, port + k, str(tmp_path), "nccl", 0, sparse, p2p), nprocs=2, join=True)
         a, b = np.load(os.path.join(tmp_path, "single_w1.npz")), np.load(os.path.join(tmp_path, "nccl_w2.npz"))
-        assert bool(b["rccl"]) and bool(b["compact"]) == (sparse == "1") and bool(b["peer"]) == (sparse == "1")
+        assert bool(b["rccl"]) and bool(b["compact"]) == (sparse == "1") and bool(b["peer"]) == (p2p == "1")
         _compare(a, b)

@@ -94,32 +94,38 @@ def test_multi_frame_mapping_tracks_the_oracle(layer_norm):
     assert sizes[-1][0] > sizes[0][0] and any(l < g for g, l in sizes[1:])
 
 
-def test_subt_sequence_harness_first_frames_vs_oracle():
+@pytest.mark.parametrize("freeze_after", [None, 1])
+def test_subt_sequence_harness_first_frames_vs_oracle(freeze_after):
     """BASELINE configs[4] workload: the run_SubT_MRS.yaml values (fixture G13: layer norm, free_sample_begin_ratio 0.8)
-    driving process_frame -> mapping per frame as slam.py:135-200 (bench_sequence.py); the mapping() calls of the first
-    frames are replayed on the CPU oracle from a snapshot of the state before each call."""
+    driving process_frame -> mapping per frame as slam.py:135-200 (bench_sequence.py).  The mapping() calls of the first
+    frames are replayed on the CPU oracle from a snapshot of the state before each call, TEACHER-FORCED: before iteration
+    t the oracle's parameters theta_t / decoder_t are loaded into the HIP state and the gradients of that iteration
+    (search + decode through the C ABI, no optimiser step) are compared with the oracle's, every entry, for >= 10
+    iterations per call -- layer norm on a zero-feature map (frame 0), on a trained map (frames 1, 2), and with the decoder
+    frozen (`freeze_after` = 1: slam.py:193-196).  utils/mapper.py:642-836, model/neural_points.py:632-633."""
     import bench_sequence as BS
 
-    cfg, rows, checks, _ = BS.run(3, "cuda:0", check_frames=3, quiet=True)
+    cfg, rows, checks, _ = BS.run(3, "cuda:0", check_frames=3, quiet=True, freeze_after_frame=freeze_after, teacher_iters=12)
     assert cfg.layer_norm_on and cfg.free_sample_begin_ratio == 0.8 and cfg.bs == 16384
     assert rows[0]["iters"] >= cfg.iters * cfg.init_iter_ratio - 10 and rows[1]["iters"] <= cfg.iters + 10
     assert rows[2]["M_local"] > rows[0]["M_local"] and rows[2]["pool"] > rows[0]["pool"]
+    assert [c["frozen"] for c in checks] == ([False, True, True] if freeze_after == 1 else [False] * 3)
     for c in checks:
-        assert c["max_dloss"] <= 2e-5, c
-        # every gradient entry of the call's first iteration at the 1e-4 relative bar (no eps = 1e-15 amplification in a
-        # gradient), and the rows the oracle leaves at exactly zero are zero here too: a defect in ANY row fails
-        assert c["max_dgrad_theta_rel"] <= 1e-4 and c["rows_nonzero_only_in_hip"] <= 4 and c["rows_nonzero_only_in_oracle"] <= 4, c
-        assert c.get("max_dgrad_decoder_rel", 0.0) <= 1e-4, c
+        assert c["teacher_forced_iters"] >= min(10, c["iters"]), c
+        assert c["max_dloss"] <= 2e-5 and c["max_probe_dloss"] <= 2e-5, c
+        for t, r in enumerate(c["teacher_forced"]):
+            # every gradient entry of every iteration at the 1e-4 relative bar (no eps = 1e-15 amplification in a
+            # gradient); rows the oracle leaves at exactly zero are zero here too, up to a handful of gathered rows whose
+            # eight sums cancel exactly in one summation order only -- and those hold nothing but rounding residue
+            assert r["dgrad_theta_rel"] <= 1e-4, (c["frame"], t, r)
+            assert r.get("dgrad_decoder_rel", 0.0) <= 1e-4, (c["frame"], t, r)
+            assert r["rows_nonzero_only_in_hip"] <= 4 and r["rows_nonzero_only_in_oracle"] <= 4 and r["residue_rel"] <= 1e-6, (c["frame"], t, r)
         if "max_dtheta" in c:
-            # parameters after the call: Adam with eps = 1e-15 moves an entry whose gradient is cancellation residue by up
-            # to lr * iters differently in ANY two correct summation orders; the count of such entries and the decoder
-            # drift they cause are bounded by 4 x what the oracle shows against itself (1 vs 16 threads) on a layer-norm
-            # state: tests/golden/eps_chaos_calibration.json, oracle/calibrate_eps_chaos.py, bench_sequence.chaos_bounds
+            # free-running parameters after the call: Adam with eps = 1e-15 moves an entry whose gradient is cancellation
+            # residue by up to lr * iters differently in ANY two correct summation orders, so only that hard bound gates;
+            # the count of drifting entries against the oracle-vs-oracle calibration (bench_sequence.chaos_bounds) is
+            # reported in the check record, the teacher-forced gradients above are what decides
             assert c["max_dtheta"] <= cfg.lr * c["iters"] * 1.01, c
-            assert c["n_dtheta_gt_1e4"] <= c["n_dtheta_gt_1e4_bound"], c
-            assert c["max_ddecoder"] <= c["max_ddecoder_bound"], c
-            # a certainty increment is one neighbour weight: a pair of near-equidistant 6th / 7th neighbours that swaps
-            # between two correct fp32 evaluation orders moves one row by up to ~0.02 (observed: exactly one such row)
             assert c["max_dcert"] <= 5e-2, c
 
 

@@ -276,6 +276,15 @@ def test_bench_spawns_its_ranks(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4096 and line["config"]["bs_per_gpu"] == 2048
+    # one run = the A/B of the gradient exchange: the headline on the default (collective, dense at this map size), the
+    # compact payload over the collective, and the compact payload over the peer-mapped buffers, ms per step each
+    legs = line["config"]["gradient_exchange"]
+    assert set(legs) >= {"rccl_dense", "rccl_compact", "p2p_compact"}
+    assert legs["rccl_dense"].get("headline") and abs(legs["rccl_dense"]["ms_per_step"] - line["ms_per_step"]) < 1e-9
+    assert legs["rccl_dense"]["mode"] == "dense" and legs["rccl_compact"]["mode"] == "compact"
+    assert legs["rccl_compact"]["transport"] != "peer-mapped" and legs["p2p_compact"]["transport"] == "peer-mapped"
+    assert legs["rccl_compact"]["bytes_per_iter"] < legs["rccl_dense"]["bytes_per_iter"]
+    assert all(legs[k]["ms_per_step"] > 0 and legs[k]["p2p_fallbacks"] == 0 for k in ("rccl_dense", "rccl_compact", "p2p_compact"))
     if torch.cuda.device_count() < 2:
         out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
         assert out.returncode != 0 and "GPU(s) visible" in (out.stderr + out.stdout)
