@@ -185,6 +185,11 @@ def chaos_bounds(iters: int, entries: int, frozen: bool):
     return max(8, int(4 * frac * entries) + 1), (0.0 if frozen else max(1e-4, 4 * decd))
 
 
+# |pre-activation| below which a hidden unit of the decoder counts as sitting ON the ReLU kink: ~32 ulp of a 12-term fp32 dot
+# product of O(1) terms.  Two correct fp32 evaluations may gate such a unit differently (oracle.cpu_ref.relu_ambiguous_rows).
+RELU_TAU = 4e-6
+
+
 def _oracle_replay(snap, idx, mp, cfg, n_max=16):
     """The CPU oracle's loop (utils/mapper.py:642-836 restated) on the snapshot, teacher-forced with the call's batches;
     the 400-iteration call of frame 0 is replayed for its first `n_max` iterations only."""
@@ -195,7 +200,7 @@ def _oracle_replay(snap, idx, mp, cfg, n_max=16):
                       fd_eps=cfg.voxel_size_m * cfg.num_grad_step_ratio, lr=cfg.lr, adam_eps=cfg.adam_eps)
     if frozen:
         lc.train_decoder = False
-    return O.mapping_iters(st, od, pool, idx.cpu()[: min(idx.shape[0], n_max)], lc, record=True)
+    return O.mapping_iters(st, od, pool, idx.cpu()[: min(idx.shape[0], n_max)], lc, record=True, ambiguity_tau=RELU_TAU)
 
 
 def _teacher_forced_probes(recs, idx, nm, dec, mp, n_iters):
@@ -233,7 +238,17 @@ def _grad_row(probe, rec, frozen):
     gmax = max(float(g0.abs().max()), 1e-30)
     nz_hip, nz_ref = (gh != 0).any(1), (g0 != 0).any(1)
     only_hip, only_ref = nz_hip & ~nz_ref, nz_ref & ~nz_hip
-    row = {"grad_theta_max": gmax, "dgrad_theta_rel": float((gh - g0).abs().max()) / gmax,
+    # rows gathered by a query with a decoder pre-activation on the ReLU kink (|pre| < RELU_TAU in the oracle) are compared
+    # at a looser bar: which side of the kink an fp32 evaluation lands on depends on its summation order, and the row's
+    # gradient jumps by that hidden unit's contribution.  Counted and reported; every other row at the strict bar.
+    kink = torch.zeros(g0.shape[0], dtype=torch.bool)
+    if "ambiguous_rows" in rec:
+        kink[rec["ambiguous_rows"]] = True
+    d = (gh - g0).abs().max(1).values
+    row = {"grad_theta_max": gmax, "dgrad_theta_rel": float(d[~kink].max()) / gmax,
+           "kink_rows": int(kink.sum()), "kink_queries": int(rec.get("ambiguous_queries", 0)),
+           "dgrad_theta_rel_kink_rows": (float(d[kink].max()) / gmax) if bool(kink.any()) else 0.0,
+           "dgrad_theta_rel_all_rows": float(d.max()) / gmax,
            # rows the oracle never gathers get exactly zero here too (anything else would become a +-lr step); a gathered
            # row whose eight sums cancel to exactly 0 in one summation order and to 1e-20 in another may differ: such rows
            # are counted and their magnitude (relative to the largest gradient entry) is reported
@@ -262,6 +277,8 @@ def _check_against_oracle(snap, idx, nm, dec, mp, cfg, fid):
     out["teacher_forced_iters"] = len(per_iter)
     out["grad_theta_max"] = per_iter[0]["grad_theta_max"]
     out["max_dgrad_theta_rel"] = max(r["dgrad_theta_rel"] for r in per_iter)
+    out["max_dgrad_theta_rel_kink_rows"] = max(r["dgrad_theta_rel_kink_rows"] for r in per_iter)
+    out["max_kink_rows"] = max(r["kink_rows"] for r in per_iter)
     out["max_dgrad_decoder_rel"] = max(r.get("dgrad_decoder_rel", 0.0) for r in per_iter)
     out["max_probe_dloss"] = max(r["dloss"] for r in per_iter)
     out["rows_nonzero_only_in_hip"] = max(r["rows_nonzero_only_in_hip"] for r in per_iter)

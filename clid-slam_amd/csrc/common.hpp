@@ -187,16 +187,22 @@ __device__ __forceinline__ void search_topk(const clid_map_view& mv, const Delta
   c.init();
   int nvalid = 0;
   const float4* __restrict__ tpos = reinterpret_cast<const float4*>(mv.tab_pos);
-  for (int o0 = 0; o0 < mv.P; o0 += kProbeChunk) {
+  // lane l owns the contiguous probes [R l, R (l + 1)), R = ceil(P / 16), in ascending order: with the strict < of the insert
+  // and the lowest lane winning ties in the selection below, equal distances are resolved by probe index -- a stable sort
+  // of the reference's dist2 row (np.py:607-609, whose torch.sort leaves the order of equal distances undefined)
+  const int R = (mv.P + CLID_G - 1) / CLID_G;
+  const int obase = R * lane16;
+  for (int o0 = 0; o0 < R; o0 += kProbesPerLane) {
     int slot[kProbesPerLane];
     unsigned home[kProbesPerLane];
     int4 bk[kProbesPerLane];
 #pragma unroll
     for (int t = 0; t < kProbesPerLane; ++t) {
-      const int o = o0 + t * CLID_G + lane16;
-      int sl = r0 + dl.d[o];
+      const int o = obase + o0 + t;
+      const bool in = (o0 + t < R) && (o < mv.P);
+      int sl = r0 + dl.d[in ? o : 0];
       if (sl >= B) sl -= B;
-      slot[t] = (o < mv.P) ? sl : -2;  // -2 never matches a key
+      slot[t] = in ? sl : -2;  // -2 never matches a key
       home[t] = tab_home(sl, mv.log2cap);
       bk[t] = tab[slot[t] != -2 ? home[t] : 0];
     }

@@ -149,16 +149,22 @@ __device__ __forceinline__ bool search8(const clid_map_view& mv, const DeltaLds&
   CandN<DEPTH> c;
   c.init();
   if (lane8 < CLID_K) win[lane8] = make_float2(9e3f, __int_as_float(-1));  // np.py:606
-  for (int o0 = 0; o0 < mv.P; o0 += 8 * kProbeRows8) {
+  // Lane l owns the CONTIGUOUS probes [R l, R (l + 1)), R = ceil(P / 8), and takes them in ascending order: a lane's list
+  // then keeps equal distances in probe order (strict < in insert) and the selection below hands ties to the lowest lane, so
+  // equal distances are resolved by probe index -- the order of a STABLE sort of the reference's dist2 row (np.py:607-609;
+  // torch's own sort there is unstable: its choice among equidistant candidates at the K-th place is implementation-defined)
+  const int R = (mv.P + 7) >> 3;
+  const int obase = R * lane8;
+  for (int o0 = 0; o0 < R; o0 += kProbeRows8) {
     int slot[kProbeRows8];
     unsigned home[kProbeRows8];
     int4 bk[kProbeRows8];
 #pragma unroll
     for (int t = 0; t < kProbeRows8; ++t) {  // straight-line (predicated) so all loads of the chunk batch
-      const int o = o0 + 8 * t + lane8;
-      int sl = r0 + dl.d[o];
+      const int o = obase + o0 + t;
+      bool in = (o0 + t < R) && (o < mv.P);
+      int sl = r0 + dl.d[in ? o : 0];
       sl = (int)min((unsigned)sl, (unsigned)(sl - B));  // sl < 2 B: one conditional subtraction as add / sub / min
-      bool in = o < mv.P;
       slot[t] = in ? sl : -2;
       home[t] = tab_home(sl, mv.log2cap);
       if constexpr (FILTER) {

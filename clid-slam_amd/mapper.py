@@ -477,12 +477,20 @@ class Mapper:
         rec = torch.empty(int(lib.clid_train_search_floats(ta.bs, ta.batch_offset, ta.decimation, ta.eikonal_mode, 1)),
                           device=dev, dtype=torch.float32)
         ts_before = self.neural_points.local_point_ts_update.clone()
+        sdf_slots = None
+        if getattr(self, "_probe_sdf", False):  # also hand back the task records and the SDF of every record slot
+            n_tasks = int(lib.clid_train_search_tasks(ta.bs, ta.batch_offset, ta.decimation, ta.eikonal_mode))
+            sdf_slots = torch.zeros(n_tasks * 8, device=dev)
+            ta.sdf_dbg = sdf_slots.data_ptr()
         _lib.check(lib.clid_train_search(C.byref(view), C.byref(ta), 1, idx_base, bs, rec.data_ptr(), stream), "clid_train_search")
         _lib.check(lib.clid_train_decode(C.byref(view), C.byref(ta), rec.data_ptr(), stream), "clid_train_decode")
         torch.cuda.synchronize()
         rows = grad[_lib.GRAD_FEAT_OFFSET16:_lib.GRAD_FEAT_OFFSET16 + n_rows * _lib.GRAD_ROW16].view(n_rows, _lib.GRAD_ROW16)
         out = {"theta": rows[:, :_lib.F].clone(), "decoder": grad[:_lib.MLP_PARAMS].clone(), "cert_inc": rows[:, _lib.F].clone(),
                "loss": losses[0].clone()}
+        if sdf_slots is not None:
+            out["records"] = rec[: sdf_slots.numel() // 8 * 192].view(-1, 48, 4).clone()
+            out["sdf_slots"] = sdf_slots.view(-1, 8)
         grad.zero_()
         losses.zero_()
         self.neural_points.local_point_ts_update.copy_(ts_before)  # (the decode's only direct side effect with the tile kernels)

@@ -121,6 +121,11 @@ def query_feature(
 
     Returns (geo_feat [N,D] or [N,K,D], weight [N,K,1], nn_counts [N], certainty [N],
              idx [N,K] (local or global ids, -1 invalid)).
+    TIES: the reference sorts with torch.sort's default (unstable) algorithm, so which of several EQUIDISTANT candidates
+    takes the K-th place is implementation-defined there (CPU and CUDA differ, and so do row lengths).  The restatement
+    fixes the choice to the stable order -- the candidate with the lower probe index wins -- which is also the rule of the
+    HIP kernels (csrc/train.hip search8, csrc/common.hpp search_topk); on the reference's own golden vectors (no
+    equidistant pair of different points at the cut) both orders give the same result.
     Differentiable w.r.t. `query_points` (through r_k and the IDW weights) and the feature table.
     """
     K = st.nn_k
@@ -134,7 +139,7 @@ def query_feature(
         feats_tab, pts_tab, cert_tab = st.geo_features, st.neural_points, st.point_certainties
     nn_counts = (idx >= 0).sum(-1)  # :600-602 (over all P probes)
     dist2 = torch.where(idx == -1, torch.full_like(dist2, 9e3), dist2)  # :606
-    dist2, order = torch.sort(dist2, dim=1)  # :607-609
+    dist2, order = torch.sort(dist2, dim=1, stable=True)  # :607-609 (equal distances: see TIES below)
     idx = idx.gather(1, order)[:, :K]
     dist2 = dist2[:, :K]
     valid = idx >= 0
@@ -230,7 +235,7 @@ def closed_form_sdf_and_gradient(st: MapState, dec: DecoderParams, x: torch.Tens
         idx = st.global2local[idx]
         nn_counts = (idx >= 0).sum(-1)
         dist2 = torch.where(idx == -1, torch.full_like(dist2, 9e3), dist2)
-        dist2, order = torch.sort(dist2, dim=1)
+        dist2, order = torch.sort(dist2, dim=1, stable=True)
         idx = idx.gather(1, order)[:, :K]
         dist2 = dist2[:, :K]
         valid = (idx >= 0).to(x.dtype)
@@ -390,17 +395,52 @@ def loss_and_grads(st: MapState, dec: DecoderParams, pool: SamplePool, index: to
     return out
 
 
-def mapping_iters(st: MapState, dec: DecoderParams, pool: SamplePool, index_seq, lc: LoopConfig, record=False):
+def relu_ambiguous_rows(st: MapState, dec: DecoderParams, pool: SamplePool, index: torch.Tensor, lc: LoopConfig, tau: float):
+    """Checker aid (no reference counterpart): the map rows whose gradient of this iteration is NOT a continuous function of
+    the fp32 rounding -- rows gathered by a query point (batch sample or finite-difference copy, utils/mapper.py:697-704)
+    that has a hidden pre-activation of the decoder (model/decoder.py:58-82) within `tau` of the ReLU kink.  Two correct
+    fp32 evaluations of such a query (different summation orders in W1 f + b1) may open / close that unit, which moves the
+    gradient of the query's <= K neighbour rows by one hidden unit's whole contribution.  Returns (rows int64, queries)."""
+    with torch.no_grad():
+        coord = pool.global_coord[index]
+        pts = [coord]
+        if lc.ekional_loss_on and lc.numerical_grad:
+            x = coord[lc.fd_first :: lc.gradient_decimation]
+            for a in range(3):
+                e = torch.zeros(3, dtype=x.dtype)
+                e[a] = lc.fd_eps
+                pts += [x + e, x - e]
+        allp = torch.cat(pts, dim=0)
+        cert = st.local_point_certainties.clone()
+        f, _, _, _, idx = query_feature(st, allp, None, training_mode=False)
+        st.local_point_certainties.copy_(cert)
+        if not st.weighted_first:
+            f = f.reshape(-1, f.shape[-1])
+            idx_q = idx.reshape(-1, 1)
+        else:
+            idx_q = idx
+        pre = F.linear(f, dec.W1, dec.b1)
+        amb = pre.abs().min(dim=1).values < tau
+        rows = idx_q[amb].reshape(-1)
+        return torch.unique(rows[rows >= 0]), int(amb.sum())
+
+
+def mapping_iters(st: MapState, dec: DecoderParams, pool: SamplePool, index_seq, lc: LoopConfig, record=False,
+                  ambiguity_tau: Optional[float] = None):
     """utils/mapper.py:620-862 with a teacher-forced batch-index sequence (`index_seq` [iters,bs]).
 
     A NEW Adam state is created per call (utils/mapper.py:634).  Returns the per-iteration records
-    when `record`, else the list of loss triples."""
+    when `record`, else the list of loss triples.  `ambiguity_tau`: also record `relu_ambiguous_rows` of every
+    iteration (evaluated on the parameters the iteration starts from)."""
     theta = st.local_geo_features
     ad_theta = AdamState(torch.zeros_like(theta), torch.zeros_like(theta))
     ad_dec = [AdamState(torch.zeros_like(t), torch.zeros_like(t)) for t in dec.tensors()]
     recs = []
     for it in range(len(index_seq)):
+        amb = relu_ambiguous_rows(st, dec, pool, index_seq[it], lc, ambiguity_tau) if (record and ambiguity_tau) else None
         out = loss_and_grads(st, dec, pool, index_seq[it], lc)
+        if amb is not None:
+            out["ambiguous_rows"], out["ambiguous_queries"] = amb
         with torch.no_grad():
             if lc.train_decoder:
                 for name, t, s in zip(("W1", "b1", "W2", "b2"), dec.tensors(), ad_dec):

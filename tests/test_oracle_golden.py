@@ -200,3 +200,28 @@ def test_oracle_query_composition_vs_reference_mesher_g12():
                 tag = f"ln{ln}_loc{loc}" + ("" if wf else "_wf0")
                 assert float((sdf - gio.T(g[f"sdf_{tag}"])).abs().max()) <= 1e-6, tag
                 assert torch.equal((nn >= 4), gio.T(g[f"mask_{tag}"]).bool()), tag
+
+
+@pytest.mark.parametrize("ln", [0, 1])
+def test_relu_ambiguous_rows_is_a_pure_checker_aid(ln):
+    """`relu_ambiguous_rows` (the rows whose gradient may legitimately jump between two fp32 evaluations: gathered by a query
+    with a decoder pre-activation on the ReLU kink) leaves the state untouched, is empty for tau = 0, grows with tau, only
+    names rows the iteration really gathers, and recording it does not change the loop's records."""
+    g = gio.load(f"g6_loop_numerical_train_ln{ln}.npz")
+    st = gio.map_state(layer_norm_on=bool(ln))
+    pool, _ = gio.sample_pool()
+    dec = gio.decoder(g, "init_")
+    lc = O.LoopConfig()
+    index_seq = gio.T(g["index_seq"]).to(torch.int64)
+    cert0, ts0 = st.local_point_certainties.clone(), st.local_point_ts_update.clone()
+    r0, q0 = O.relu_ambiguous_rows(st, dec, pool, index_seq[0], lc, 0.0)
+    r1, q1 = O.relu_ambiguous_rows(st, dec, pool, index_seq[0], lc, 1e-4)
+    r2, q2 = O.relu_ambiguous_rows(st, dec, pool, index_seq[0], lc, 1e-2)
+    assert torch.equal(st.local_point_certainties, cert0) and torch.equal(st.local_point_ts_update, ts0)
+    assert r0.numel() == 0 and q0 == 0 and q1 <= q2 and q2 > 0
+    assert set(r1.tolist()) <= set(r2.tolist())
+    recs = O.mapping_iters(st, dec, pool, index_seq[:2], lc, record=True, ambiguity_tau=1e-2)
+    touched = torch.nonzero((recs[0]["grad_theta"] != 0).any(1)).flatten()
+    assert set(recs[0]["ambiguous_rows"].tolist()) <= set(touched.tolist()) | {int(st.local_geo_features.shape[0]) - 1}
+    assert torch.equal(recs[0]["ambiguous_rows"], r2)
+    close(recs[1]["loss"], g["loss_total"][1], 2e-6, "records unchanged by the ambiguity pass")
