@@ -36,7 +36,8 @@ class MapView(C.Structure):
         ("filter", _vp),
         ("log2cap", _i32), ("M", _i32), ("P", _i32), ("buffer_size", _i32),
         ("resolution", _f32), ("max_valid_dist2", _f32), ("layer_norm", _i32), ("log2filter", _i32),
-        ("weighted_first", _i32), ("reserved0", _i32),
+        ("weighted_first", _i32), ("stencil_nc", _i32),
+        ("cdir_hdr", _vp), ("cdir_words", _vp), ("cdir_pos", _vp), ("stencil_rows", _vp),
     ]
 
 
@@ -91,6 +92,7 @@ _SIGS = {
     "clid_last_error": (C.c_char_p, []),
     "clid_table_build": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _f32, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _i32, _vp, _vp, _i32,
                                    _vp]),
+    "clid_cdir_build": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i64, _f32, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "clid_radius_search": (C.c_int, [C.POINTER(MapView), _vp, _i32, _vp, _vp, _vp]),
     "clid_query_certainty": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _i32, _vp, _vp]),
     "clid_query_fwd": (C.c_int, [C.POINTER(MapView), _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -212,7 +214,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.clid_abi_version() != 3:
+    if lib.clid_abi_version() != 4:
         raise RuntimeError("libclid_native.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -93,6 +93,7 @@ __device__ __forceinline__ int match_base(const WaveLds& wl, int j) {
 #define CLID_PROBE_ROWS 6
 #endif
 constexpr int kProbeRows8 = CLID_PROBE_ROWS;  // probes per lane per chunk; chunk = 8 * rows slots
+constexpr int kProbeShift = 22;  // search8's candidates: local id (< 2^22) | probe index (< 384 = kMaxProbes) << 22
 
 // Per-lane sorted candidate list of DEPTH entries.  The 81 probes of a query are spread over 8 lanes, so a lane
 // almost never owns more than 3 of the 6 winners: the throughput (search-only) kernel runs with DEPTH = 3 -- half
@@ -135,6 +136,35 @@ struct CandN {
   }
 };
 
+// The K winners of the group's sorted per-lane lists -> win[0..K), ascending distance.  Candidates carry their probe index
+// above their id (kProbeShift): when several lanes hold the same distance the lowest index wins -- a stable sort of the
+// reference's dist2 row (np.py:607-609).  Returns the distance of the K-th winner (inf when fewer were found).
+template <int DEPTH>
+__device__ __forceinline__ float select_packed(CandN<DEPTH>& c, int lane8, int gshift, float2* __restrict__ win) {
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < CLID_K; ++k) {
+    const float head = c.d[0];
+    m = group8_min(head);
+    const bool mine = (head == m) && (c.j[0] >= 0);
+    const unsigned long long b = __ballot(mine);
+    const unsigned gb = (unsigned)(b >> gshift) & 0xFFu;
+    bool take = gb && lane8 == (int)(__ffs(gb) - 1);
+    if (__any((gb & (gb - 1u)) != 0u)) {  // rare: several lanes hold the same distance
+      const int key = mine ? (c.j[0] >> kProbeShift) : 0x7fffffff;
+      int kmin = min(key, __builtin_amdgcn_update_dpp(0x7fffffff, key, 0xB1, 0xF, 0xF, false));
+      kmin = min(kmin, __builtin_amdgcn_update_dpp(0x7fffffff, kmin, 0x4E, 0xF, 0xF, false));
+      kmin = min(kmin, __builtin_amdgcn_update_dpp(0x7fffffff, kmin, 0x141, 0xF, 0xF, false));
+      take = mine && key == kmin;
+    }
+    if (take) {
+      win[k] = make_float2(m, __int_as_float(c.j[0] & ((1 << kProbeShift) - 1)));
+      c.pop();
+    }
+  }
+  return m;
+}
+
 // 81-cell search of one query by the 8 lanes of a group; winners -> win[0..K).  Returns true when a DEPTH < K
 // list may have lost a winner (the caller then repeats with DEPTH = K).
 // `filt` (optional, LDS): bit per stored slot; a probe whose bit is clear cannot match and is not loaded
@@ -149,22 +179,22 @@ __device__ __forceinline__ bool search8(const clid_map_view& mv, const DeltaLds&
   CandN<DEPTH> c;
   c.init();
   if (lane8 < CLID_K) win[lane8] = make_float2(9e3f, __int_as_float(-1));  // np.py:606
-  // Lane l owns the CONTIGUOUS probes [R l, R (l + 1)), R = ceil(P / 8), and takes them in ascending order: a lane's list
-  // then keeps equal distances in probe order (strict < in insert) and the selection below hands ties to the lowest lane, so
-  // equal distances are resolved by probe index -- the order of a STABLE sort of the reference's dist2 row (np.py:607-609;
-  // torch's own sort there is unstable: its choice among equidistant candidates at the K-th place is implementation-defined)
-  const int R = (mv.P + 7) >> 3;
-  const int obase = R * lane8;
-  for (int o0 = 0; o0 < R; o0 += kProbeRows8) {
+  // Lane l takes the probes o = l, l + 8, l + 16, ... in ascending order (interleaved: the winners of a query, which cluster in
+  // the middle of the probe order, spread evenly over the lanes -- with contiguous ranges per lane a DEPTH-3 list overflowed in
+  // most waves: search 8.3 -> 15.1 us).  A candidate carries its probe index next to its id (kProbeShift), so that equal
+  // distances can be resolved by probe index -- the order of a STABLE sort of the reference's dist2 row (np.py:607-609; torch's
+  // own sort there is unstable: its choice among equidistant candidates at the K-th place is implementation-defined).  Inside
+  // a lane the strict < of the insert keeps equals in probe order; between lanes the selection below compares the indices.
+  for (int o0 = 0; o0 < mv.P; o0 += 8 * kProbeRows8) {
     int slot[kProbeRows8];
     unsigned home[kProbeRows8];
     int4 bk[kProbeRows8];
 #pragma unroll
     for (int t = 0; t < kProbeRows8; ++t) {  // straight-line (predicated) so all loads of the chunk batch
-      const int o = obase + o0 + t;
-      bool in = (o0 + t < R) && (o < mv.P);
-      int sl = r0 + dl.d[in ? o : 0];
+      const int o = o0 + 8 * t + lane8;
+      int sl = r0 + dl.d[o];
       sl = (int)min((unsigned)sl, (unsigned)(sl - B));  // sl < 2 B: one conditional subtraction as add / sub / min
+      bool in = o < mv.P;
       slot[t] = in ? sl : -2;
       home[t] = tab_home(sl, mv.log2cap);
       if constexpr (FILTER) {
@@ -196,25 +226,140 @@ __device__ __forceinline__ bool search8(const clid_map_view& mv, const DeltaLds&
     for (int t = 0; t < kProbeRows8; ++t) {
       const float ax = fsub(pp[t].x, x), ay = fsub(pp[t].y, y), az = fsub(pp[t].z, z);
       const float d2 = fadd(fadd(fmul(ax, ax), fmul(ay, ay)), fmul(az, az));
-      if (cell[t] >= 0 && !(d2 > mv.max_valid_dist2)) c.insert(d2, __float_as_int(pp[t].w));  // np.py:1016-1020
+      if (cell[t] >= 0 && !(d2 > mv.max_valid_dist2))  // np.py:1016-1020
+        c.insert(d2, __float_as_int(pp[t].w) | ((o0 + 8 * t + lane8) << kProbeShift));
     }
   }
   CLID_STAMP(2);
-  float m = 0.f;
-#pragma unroll
-  for (int k = 0; k < CLID_K; ++k) {
-    const float head = c.d[0];
-    m = group8_min(head);
-    const bool mine = (head == m) && (c.j[0] >= 0);
-    const unsigned long long b = __ballot(mine);
-    const unsigned gb = (unsigned)(b >> gshift) & 0xFFu;
-    if (gb && lane8 == (int)(__ffs(gb) - 1)) {
-      win[k] = make_float2(m, __int_as_float(c.j[0]));
-      c.pop();
-    }
-  }
+  const float m = select_packed(c, lane8, gshift, win);
   // m = distance of the 6th winner (inf when fewer were found): anything pushed out at or below it is suspect
   return DEPTH < CLID_K && c.dropped <= m && c.dropped < __builtin_inff();
+}
+
+// ---- the same search over the window's CELL DIRECTORY (csrc/celldir.hip) ------------------------------------------------
+// search8 pays per PROBE: slot arithmetic, a prefilter bit, a 4-key bucket compare -- 81 times per query although 3 of 4
+// probed cells are empty.  The directory answers a whole stencil row of 2 nc + 1 z-adjacent cells with ONE 8-byte load:
+// occupancy bits of 32 cells | rank of the word's first hit (the straddling bits of the next word packed beside it); the
+// hits of a row are consecutive rows of `cdir_pos`.  Row-major (dx, dy) with dz fastest IS the probe order of np.py:931-969,
+// so hit number g of a query is its g-th valid probe.  Lane l of the query's 8 lanes takes rows [4 l, 4 l + 4), the lanes
+// agree on the hits' numbering with one 8-lane scan, expand their rows' rank ranges into an LDS list, and then every lane
+// takes an equal share of the hits (l, l + 8, ...): one position load + distance + insert per hit instead of per probe.
+constexpr int kCdRows = 32;  // staged stencil rows: (2 nc + 1)^2 <= 25 for nc <= 2, the rest empty
+constexpr int kCdHits = 88;  // list entries per query slot (>= 81 probes)
+struct CellLds {
+  int4 row[kCdRows];  // per (dx, dy) row: word offset (dx ny + dy) nzw | stencil bits along z | bits below the first stencil bit | -
+  int ox, oy, oz, nx, ny, nz, nzw, valid, nc;
+};
+__device__ __forceinline__ void stage_cells(CellLds& cl, const clid_map_view& mv, bool want) {
+  const bool have = want && mv.cdir_hdr && mv.cdir_words && mv.cdir_pos && mv.stencil_rows && mv.stencil_nc >= 1 && mv.stencil_nc <= 2;
+  const int nc = have ? mv.stencil_nc : 1, S = 2 * nc + 1;
+  if (threadIdx.x < kCdRows) {
+    const int r = threadIdx.x;
+    int4 e = make_int4(0, 0, 0, 0);
+    if (have && r < S * S) {
+      const int dx = r / S - nc, dy = r % S - nc;
+      const unsigned zm = mv.stencil_rows[r];
+      e.x = (dx * mv.cdir_hdr[4] + dy) * mv.cdir_hdr[6];
+      e.y = (int)zm;
+      e.z = (int)((zm & (0u - zm)) - 1u);
+    }
+    cl.row[r] = e;
+  }
+  if (threadIdx.x == 0) {
+    cl.ox = have ? mv.cdir_hdr[0] : 0; cl.oy = have ? mv.cdir_hdr[1] : 0; cl.oz = have ? mv.cdir_hdr[2] : 0;
+    cl.nx = have ? mv.cdir_hdr[3] : 0; cl.ny = have ? mv.cdir_hdr[4] : 0; cl.nz = have ? mv.cdir_hdr[5] : 0;
+    cl.nzw = have ? mv.cdir_hdr[6] : 0;
+    cl.valid = have ? mv.cdir_hdr[8] : 0;
+    cl.nc = nc;
+  }
+}
+// inclusive sum over the lanes 0 .. lane8 of an 8-lane group (row_shr never reaches across the group: guarded by lane8)
+__device__ __forceinline__ int group8_scan_i(int v, int lane8) {
+  int t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+  v += lane8 >= 1 ? t : 0;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+  v += lane8 >= 2 ? t : 0;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+  v += lane8 >= 4 ? t : 0;
+  return v;
+}
+// The hits of one query, listed in LDS by rank in probe order: lane l takes the hits l, l + 8, ... (interleaved like search8's
+// probes: the winners spread over the lanes), kCdBatch position loads in flight per lane and trip; candidates carry their hit
+// number above the id, ties resolve as in search8.  `trips` is the wave's maximum (uniform).  Returns search8's "repeat at full depth".
+constexpr int kCdBatch = 3;
+template <int DEPTH>
+__device__ __forceinline__ bool consume_hits(const clid_map_view& mv, const int* __restrict__ list, int H, int trips, float x, float y,
+                                             float z, int lane8, int gshift, float2* __restrict__ win) {
+  const float4* __restrict__ cpos = reinterpret_cast<const float4*>(mv.cdir_pos);
+  CandN<DEPTH> c;
+  c.init();
+  for (int i0 = 0; i0 < trips; ++i0) {
+    float4 pp[kCdBatch];
+    int g[kCdBatch];
+#pragma unroll
+    for (int t = 0; t < kCdBatch; ++t) {
+      g[t] = lane8 + 8 * (kCdBatch * i0 + t);
+      const bool ok = g[t] < H;
+      pp[t] = cpos[ok ? list[ok ? g[t] : 0] : 0];
+    }
+#pragma unroll
+    for (int t = 0; t < kCdBatch; ++t) {
+      const float ax = fsub(pp[t].x, x), ay = fsub(pp[t].y, y), az = fsub(pp[t].z, z);
+      const float d2 = fadd(fadd(fmul(ax, ax), fmul(ay, ay)), fmul(az, az));
+      if (g[t] < H && !(d2 > mv.max_valid_dist2)) c.insert(d2, __float_as_int(pp[t].w) | (g[t] << kProbeShift));  // np.py:1016-1020
+    }
+  }
+  const float m = select_packed(c, lane8, gshift, win);
+  return DEPTH < CLID_K && c.dropped <= m && c.dropped < __builtin_inff();
+}
+// One query of the task: (rx, ry) = cell - origin, rz0 = cell_z - origin_z - nc (all in range: the caller checked).  `list`:
+// this query slot's kCdHits ints in LDS.
+__device__ __forceinline__ void search_cells(const clid_map_view& mv, const CellLds& cl, int* __restrict__ list, float x, float y,
+                                             float z, int rx, int ry, int rz0, int lane8, int gshift, float2* __restrict__ win,
+                                             bool full_depth) {
+  const uint2* __restrict__ words = reinterpret_cast<const uint2*>(mv.cdir_words);
+  const int sh = rz0 & 31;
+  const int qbase = (rx * cl.ny + ry) * cl.nzw + (rz0 >> 5);
+  const unsigned low = (1u << sh) - 1u;
+  int4 rw[4];
+  uint2 e[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    rw[t] = cl.row[4 * lane8 + t];
+    e[t] = make_uint2(0u, 0u);
+    if (rw[t].y) e[t] = words[qbase + rw[t].x];
+  }
+  int rf[4], cnt[4], n_l = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const unsigned a = __builtin_amdgcn_alignbit(e[t].y >> 24, e[t].x, (unsigned)sh);  // cells rz0 .. of the row's column
+    cnt[t] = __popc(a & (unsigned)rw[t].y);
+    rf[t] = (int)(e[t].y & 0xFFFFFFu) + __popc(e[t].x & low) + __popc(a & (unsigned)rw[t].z);  // rank of the row's first hit
+    n_l += cnt[t];
+  }
+  const int incl = group8_scan_i(n_l, lane8);
+  const int H = group8_sum_i(n_l);
+  int p = incl - n_l;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {  // the stencil bits of a row are one run (a ball), so its hits have consecutive ranks
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+      if (k < cnt[t]) list[p + k] = rf[t] + k;
+    p += cnt[t];
+  }
+  wave_lds_fence();
+  int hmax = H;  // the wave's largest hit count -> uniform trip count
+  hmax = max(hmax, __shfl_xor(hmax, 8, 64));
+  hmax = max(hmax, __shfl_xor(hmax, 16, 64));
+  hmax = max(hmax, __shfl_xor(hmax, 32, 64));
+  const int trips = (__builtin_amdgcn_readfirstlane(hmax) + 8 * kCdBatch - 1) / (8 * kCdBatch);
+  if (lane8 < CLID_K) win[lane8] = make_float2(9e3f, __int_as_float(-1));  // np.py:606
+  bool redo = full_depth;
+  if (!full_depth) redo = consume_hits<3>(mv, list, H, trips, x, y, z, lane8, gshift, win);
+  if (__any(redo)) {  // a 3-deep list may have pushed a winner out (or debug bit 2): once more at full depth, from the same list
+    if (lane8 < CLID_K) win[lane8] = make_float2(9e3f, __int_as_float(-1));
+    consume_hits<CLID_K>(mv, list, H, trips, x, y, z, lane8, gshift, win);
+  }
 }
 
 constexpr int kFusedBlock = 512;  // 8 waves share one partial row: half as many rows for k_adam_all to reduce
@@ -537,7 +682,7 @@ struct TileNumLds {
 // one wave task: pool gathers, 81-cell search of its 8 query slots, IDW weights / blended offsets -> record in `hd`
 __device__ __forceinline__ void search_task(const clid_map_view& mv, const clid_train_args& ta, const TaskMap& tmap,
                                             const DeltaLds& dl, const long long* __restrict__ index, int task, int it, int use_filter,
-                                            const unsigned* __restrict__ filt_lds, WaveHead& hd) {
+                                            const unsigned* __restrict__ filt_lds, WaveHead& hd, const CellLds& cl) {
   const int lane = threadIdx.x & 63, lane8 = lane & 7, slot8 = lane >> 3;
   const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
   const QDesc qd = task_query(tmap, task, slot8 >> 2, slot8 & 3);
@@ -561,10 +706,23 @@ __device__ __forceinline__ void search_task(const clid_map_view& mv, const clid_
   }
   asm volatile("" ::"v"(px), "v"(py), "v"(pz));
   bool redo;
-  if (use_filter == 1) redo = search8<true, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], filt_lds);
+  if (use_filter == 3) {
+    // the window's cell directory: (use_filter == 3 lends the dynamic LDS to the hit lists, see the kernels)
+    const int nc = cl.nc;
+    const int rx = (int)floorf(fdiv(px, mv.resolution)) - cl.ox, ry = (int)floorf(fdiv(py, mv.resolution)) - cl.oy;
+    const int rz0 = (int)floorf(fdiv(pz, mv.resolution)) - cl.oz - nc;
+    // all 2 nc + 1 cells per axis inside the box?  (outside it a probe can only meet a foreign collision: search8 handles it)
+    const bool inside = (unsigned)(rx - nc) < (unsigned)(cl.nx - 2 * nc) && (unsigned)(ry - nc) < (unsigned)(cl.ny - 2 * nc) &&
+                        (unsigned)rz0 < (unsigned)(cl.nz - 2 * nc);
+    redo = !inside;  // (padding slots search the coordinates of sample 0 like the probing kernels: identical records)
+    if (!__any(redo)) {
+      int* list = const_cast<int*>(reinterpret_cast<const int*>(filt_lds)) + ((threadIdx.x >> 6) * 8 + slot8) * kCdHits;
+      search_cells(mv, cl, list, px, py, pz, rx, ry, rz0, lane8, lane & 56, hd.win[slot8], (ta.debug_flags & 4) != 0);
+    }
+  } else if (use_filter == 1) redo = search8<true, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], filt_lds);
   else if (use_filter == 2) redo = search8<true, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], mv.filter);
   else redo = search8<false, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
-  if (__any(redo) || (ta.debug_flags & 4))  // rare (debug bit 2 forces it: tests compare the two paths)
+  if (__any(redo) || ((ta.debug_flags & 4) && use_filter != 3))  // rare (debug bit 2 forces it: tests compare the two paths)
     search8<false, CLID_K>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
   // (d2, id) -> (IDW weight, id) + blended offset (np.py:653-706), lane8 = k
   wave_lds_fence();
@@ -651,13 +809,16 @@ __global__ void __launch_bounds__(kFusedBlock, CLID_SEARCH_WAVES)
 k_search_tiles(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __restrict__ rec, int n_iter, long long index_stride,
                int use_filter) {
   __shared__ DeltaLds dl;
+  __shared__ CellLds cl;
   __shared__ WaveHead heads[kFusedBlock / 64][2];
   __shared__ TileNumLds nums[kFusedBlock / 64];
-  extern __shared__ unsigned filt_lds[];  // with a prefilter of <= 32 KB: 2^log2filter bits (dynamic LDS)
+  extern __shared__ unsigned filt_lds[];  // with a prefilter of <= 32 KB: 2^log2filter bits (dynamic LDS); use_filter == 3: hit lists
   stage_delta(dl, mv);
+  stage_cells(cl, mv, use_filter == 3);
   if (use_filter == 1)
     for (int i = threadIdx.x; i < (1 << mv.log2filter) / 32; i += kFusedBlock) filt_lds[i] = mv.filter[i];
   __syncthreads();
+  if (use_filter == 3 && !cl.valid) use_filter = 0;  // the window did not fit the directory's capacity: probe the table
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves_per_block = kFusedBlock / 64;
   const int n_tiles = (tmap.n_tasks + 1) / 2;
   const size_t iter_f4 = rec_floats_per_iter(tmap.n_tasks) / 4;
@@ -690,7 +851,7 @@ k_search_tiles(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
     for (int half = 0; half < 2; ++half) {
       const int task = 2 * tile + half;
       if (task >= tmap.n_tasks) break;
-      search_task(mv, ta, tmap, dl, index, task, it, use_filter, filt_lds, heads[wave][half]);
+      search_task(mv, ta, tmap, dl, index, task, it, use_filter, filt_lds, heads[wave][half], cl);
       if (lane < kRecFloat4) out[(size_t)task * kRecFloat4 + lane] = reinterpret_cast<const float4*>(&heads[wave][half])[lane];
     }
     number_tile(heads[wave][0], heads[wave][1], nums[wave],
@@ -707,12 +868,15 @@ __global__ void __launch_bounds__(kFusedBlock, CLID_SEARCH_WAVES)
 k_search_tasks(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __restrict__ rec, int n_iter, long long index_stride,
                int use_filter) {
   __shared__ DeltaLds dl;
+  __shared__ CellLds cl;
   __shared__ WaveHead heads[kFusedBlock / 64];
   extern __shared__ unsigned filt_lds[];
   stage_delta(dl, mv);
+  stage_cells(cl, mv, use_filter == 3);
   if (use_filter == 1)
     for (int i = threadIdx.x; i < (1 << mv.log2filter) / 32; i += kFusedBlock) filt_lds[i] = mv.filter[i];
   __syncthreads();
+  if (use_filter == 3 && !cl.valid) use_filter = 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves_per_block = kFusedBlock / 64;
   const size_t iter_f4 = rec_floats_per_iter(tmap.n_tasks) / 4;
   // XCD x takes the x-th eighth of the bundle tasks and of the plain tasks of every iteration (see k_search_tiles)
@@ -736,7 +900,7 @@ k_search_tasks(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
       task = w - it * tmap.n_tasks;
     }
     const long long* index = reinterpret_cast<const long long*>(ta.index) + (long long)it * index_stride;
-    search_task(mv, ta, tmap, dl, index, task, it, use_filter, filt_lds, heads[wave]);
+    search_task(mv, ta, tmap, dl, index, task, it, use_filter, filt_lds, heads[wave], cl);
     if (lane < kRecFloat4)
       rec[(size_t)it * iter_f4 + (size_t)task * kRecFloat4 + lane] = reinterpret_cast<const float4*>(&heads[wave])[lane];
     wave_lds_fence();
@@ -1327,6 +1491,10 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
     clid_set_error("clid_train_fwd_bwd: null argument");
     return CLID_E_ARG;
   }
+  if (mv->M >= (1 << kProbeShift)) {
+    clid_set_error("clid_train_fwd_bwd: a local map of %d points exceeds the %d the search's packed candidates address", mv->M, 1 << kProbeShift);
+    return CLID_E_SHAPE;
+  }
   if (mv->P > kMaxProbes) {
     clid_set_error("clid_train_fwd_bwd: neighbourhood of %d cells exceeds the supported %d", mv->P, kMaxProbes);
     return CLID_E_SHAPE;
@@ -1456,6 +1624,10 @@ static int check_train_args(const clid_map_view* mv, const clid_train_args* a, c
     clid_set_error("%s: null argument", who);
     return CLID_E_ARG;
   }
+  if (mv->M >= (1 << kProbeShift)) {
+    clid_set_error("%s: a local map of %d points exceeds the %d the search's packed candidates address", who, mv->M, 1 << kProbeShift);
+    return CLID_E_SHAPE;
+  }
   if (mv->P > kMaxProbes) {
     clid_set_error("%s: neighbourhood of %d cells exceeds the supported %d", who, mv->P, kMaxProbes);
     return CLID_E_SHAPE;
@@ -1497,14 +1669,21 @@ extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args*
     if (mv->log2filter <= 18) use_filter = 1;
     else use_filter = 2;
   }
-  const size_t dyn = use_filter == 1 ? ((size_t)1 << mv->log2filter) / 8 : 0;
+  // the window's cell directory (csrc/celldir.hip) when the view carries one: a stencil row is one load + bit tests
+  // instead of 2 nc + 1 probes; debug bit 3 keeps the probe kernels (A/B, tests)
+  const bool big_map = use_filter == 2;
+  if (mv->cdir_hdr && mv->cdir_words && mv->cdir_pos && mv->stencil_rows && mv->stencil_nc >= 1 && mv->stencil_nc <= 2 &&
+      !(a->debug_flags & 8))
+    use_filter = 3;
+  const size_t dyn = use_filter == 1 ? ((size_t)1 << mv->log2filter) / 8
+                                     : (use_filter == 3 ? (size_t)(kFusedBlock / 64) * 8 * kCdHits * sizeof(int) : 0);
   // iterations of at most kTileLargeFrom tiles: tasks in pairs, the tile's pairs numbered for the decode launch (one tile
   // per wave there); larger ones: per task, the decode kernel numbers in place (train_common.hpp tiles_prenumbered)
   const bool num = clid_tiles_prenumbered(tmap.n_tasks, mv);
   long long sb = num ? ((long long)((tmap.n_tasks + 1) / 2) * n_iter + kFusedBlock / 64 - 1) / (kFusedBlock / 64)
                      : ((long long)tmap.n_tasks * n_iter + kFusedBlock / 64 - 1) / (kFusedBlock / 64);
   if (sb > search_blocks()) sb = search_blocks();
-  const bool xm = CLID_XCD_MAP && use_filter == 2 && sb >= 8;
+  const bool xm = CLID_XCD_MAP && big_map && sb >= 8;
 #define CLID_SEARCH_LAUNCH(K)                                                                                    \
   CLID_KLAUNCH(a->prof, 1, K, dim3((unsigned)sb), dim3(kFusedBlock), dyn, s, *mv, t2, tmap,                     \
                reinterpret_cast<float4*>(rec_out), n_iter, (long long)index_stride, use_filter)

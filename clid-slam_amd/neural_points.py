@@ -184,7 +184,7 @@ class NeuralPoints(nn.Module):
         st = dict(st)
         st["_tables"] = {}
         st.pop("_replica_gens", None)  # torch.Generator objects do not pickle
-        for k in ("_sensor_pos_host", "_win_ws", "_win_counts", "_ins_ws", "_ins_count", "_ins_win_counts", "_gbuf", "_stencils", "_presampled", "_track_scratch"):
+        for k in ("_sensor_pos_host", "_win_ws", "_win_counts", "_ins_ws", "_ins_count", "_ins_win_counts", "_gbuf", "_stencils", "_presampled", "_track_scratch", "_cdir_bufs", "_stencil_rows"):
             st.pop(k, None)
         # views of capacity / upper-bound buffers would drag the whole buffers into the pickle: the global arrays (capacity
         # buffers of the in-place insert) and the local arrays, mask and index map (outputs of the window selection, allocated
@@ -211,7 +211,7 @@ class NeuralPoints(nn.Module):
         cache = self.__dict__.setdefault("_stencils", {})
         hit = cache.get(key)
         if hit is not None:
-            self.neighbor_dx, self.neighbor_K, self.max_valid_dist2, self._delta = hit
+            self.neighbor_dx, self.neighbor_K, self.max_valid_dist2, self._delta, self._stencil_rows, self._stencil_nc = hit
             return
         r = torch.arange(-num_nei_cells, num_nei_cells + 1, device=self.primes.device, dtype=self.primes.dtype)
         gx, gy, gz = torch.meshgrid(r, r, r, indexing="ij")
@@ -220,7 +220,25 @@ class NeuralPoints(nn.Module):
         self.neighbor_K = self.neighbor_dx.shape[0]
         self.max_valid_dist2 = 3 * ((num_nei_cells + 1) * self.resolution) ** 2
         self._delta = torch.remainder((self.neighbor_dx * self.primes).sum(-1), int(self.buffer_size)).to(torch.int32).contiguous()
-        cache[key] = (self.neighbor_dx, self.neighbor_K, self.max_valid_dist2, self._delta)
+        # the same stencil per (dx, dy) row as a bit mask along z (bit b <=> dz = b - nc), row-major in (dx, dy): the order of
+        # `neighbor_dx` (meshgrid "ij", z fastest), which the cell-directory search (csrc/train.hip search_cells) walks.  Host
+        # arithmetic on the two Python numbers; None when a row is not one run of bits (never for a ball) or nc > 2
+        nc = int(num_nei_cells)
+        rows, total, runs = [], 0, True
+        for dx in range(-nc, nc + 1):
+            for dy in range(-nc, nc + 1):
+                m = 0
+                for dz in range(-nc, nc + 1):
+                    if dx * dx + dy * dy + dz * dz < (num_nei_cells + search_alpha) ** 2:
+                        m |= 1 << (dz + nc)
+                total += bin(m).count("1")
+                low = m & -m
+                runs = runs and (m == 0 or ((m // low) & (m // low + 1)) == 0)
+                rows.append(m)
+        self._stencil_rows, self._stencil_nc = None, nc
+        if runs and nc <= 2 and total == int(self.neighbor_K):
+            self._stencil_rows = torch.tensor(rows, dtype=torch.int32, device=self.primes.device)
+        cache[key] = (self.neighbor_dx, self.neighbor_K, self.max_valid_dist2, self._delta, self._stencil_rows, self._stencil_nc)
 
     # ------------------------------------------------------------------ map maintenance (host logic)
     def update(self, points: torch.Tensor, sensor_position: torch.Tensor, sensor_orientation: torch.Tensor, cur_ts: int):
@@ -767,7 +785,28 @@ class NeuralPoints(nn.Module):
                                  _lib.ptr(pos4), _lib.ptr(filt), log2filter, _lib.stream()),
             "clid_table_build",
         )
-        self._tables[slot] = (key, (tab, tab_pos, filt, log2filter), pos4, log2cap)
+        cdir = None
+        if locally and os.environ.get("CLID_CELLDIR", "1") != "0":
+            # cell directory of the window (csrc/celldir.hip): occupancy bits + ranks over the bounding box of its points,
+            # sized on the device against these capacities (no read-back); cached buffers, they grow with the window
+            words_cap = max(1 << 18, 16 * n)
+            hits_cap = 4 * n + 4096
+            pool = self.__dict__.setdefault("_cdir_bufs", {})  # per table slot: two cached tables never share a directory
+            bufs = pool.get(slot)
+            if bufs is None or bufs[0] < words_cap or bufs[1] < hits_cap or bufs[2].device != pts.device:
+                wc, hc = int(words_cap * 1.5), int(hits_cap * 1.5)
+                bufs = pool[slot] = (wc, hc, torch.empty((wc + 1, 2), device=pts.device, dtype=torch.int32),
+                                     torch.empty((hc, 4), device=pts.device, dtype=torch.float32),
+                                     torch.empty((wc // 256 + 2,), device=pts.device, dtype=torch.int32))
+            hdr = torch.empty((16,), device=pts.device, dtype=torch.int32)  # (per table: a cached table keeps its own header)
+            _lib.check(
+                lib.clid_cdir_build(_lib.ptr(pos4), n, _lib.ptr(tab), _lib.ptr(tab_pos), log2cap, _lib.ptr(filt), log2filter,
+                                    int(self.buffer_size), float(self.resolution), _lib.ptr(hdr), _lib.ptr(bufs[2]), bufs[0],
+                                    _lib.ptr(bufs[3]), bufs[1], _lib.ptr(bufs[4]), _lib.stream()),
+                "clid_cdir_build",
+            )
+            cdir = (hdr, bufs[2], bufs[3])
+        self._tables[slot] = (key, (tab, tab_pos, filt, log2filter), pos4, log2cap, cdir)
         return (tab, tab_pos, filt, log2filter), pos4, log2cap
 
     def prefetch_local_table(self, stream) -> None:
@@ -784,6 +823,7 @@ class NeuralPoints(nn.Module):
         if time_filtering is None:
             time_filtering = bool(self.temporal_local_map_on and query_locally)
         (tab, tab_pos, filt, log2filter), pos4, log2cap = self._table(query_locally, time_filtering)
+        cdir = self._tables[(query_locally, time_filtering)][4]
         if query_locally:
             feat, cert, tsu = self.local_geo_features.data, self.local_point_certainties, self.local_point_ts_update
         else:
@@ -804,7 +844,13 @@ class NeuralPoints(nn.Module):
         v.max_valid_dist2 = float(self.max_valid_dist2)
         v.layer_norm = int(bool(self.config.layer_norm_on))
         v.weighted_first = int(bool(getattr(self.config, "weighted_first", True)))
-        return v, (tab, tab_pos, filt, pos4, feat, cert, tsu, self._delta)
+        rows = getattr(self, "_stencil_rows", None)
+        v.stencil_nc = int(getattr(self, "_stencil_nc", 0) or 0)
+        if cdir is not None and rows is not None:
+            if rows.device != tab.device:
+                rows = self._stencil_rows = rows.to(tab.device)
+            v.cdir_hdr, v.cdir_words, v.cdir_pos, v.stencil_rows = cdir[0].data_ptr(), cdir[1].data_ptr(), cdir[2].data_ptr(), rows.data_ptr()
+        return v, (tab, tab_pos, filt, pos4, feat, cert, tsu, self._delta, cdir, rows)
 
     # ------------------------------------------------------------------ hot methods
     def query_feature(self, query_points: torch.Tensor, query_ts: torch.Tensor = None, training_mode: bool = True,

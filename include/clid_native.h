@@ -81,8 +81,37 @@ typedef struct clid_map_view {
   int32_t weighted_first;  /* config.weighted_first (utils/config.py; True in every shipped config), read by the fused inference
                               entries clid_sdf_grad_x / clid_sdf_query / clid_track_model: 1 = blend the neighbours'
                               decoder inputs, decode once; 0 = decode every neighbour, blend the K SDFs */
-  int32_t reserved0;
+  int32_t stencil_nc;      /* num_nei_cells of the search neighbourhood (np.py:931-969): `stencil_rows` has (2 nc + 1)^2 entries */
+  /* cell directory (clid_cdir_build; all three NULL = not built): the local window's voxel occupancy as the searches see it */
+  const int32_t* cdir_hdr;     /* [CLID_CDIR_HDR_INTS] device-resident header: origin, dims, validity (written by the build) */
+  const uint32_t* cdir_words;  /* [words + 1][2] per 32 z-adjacent cells: occupancy bits | rank of the first hit (24 bits) + the
+                                  next word's low 8 bits */
+  const float* cdir_pos;       /* [hits][4] x, y, z, point id (int bits) of every occupied cell, in cell order */
+  const uint32_t* stencil_rows; /* [(2 nc + 1)^2] per (dx, dy) row of the search neighbourhood: bit b set <=> (dx, dy, b - nc) is
+                                  one of the P probe offsets */
 } clid_map_view;
+
+/* ---- cell directory of the local window (csrc/celldir.hip) ---------------------------------------------------------
+ * A probe of cell c in the reference is buffer_pt_index[hash(c) mod B] -> travel-distance filter -> global2local
+ * (model/neural_points.py:984-1009, 595-598), 81 times per query, and 3 of 4 probes find nothing.  Which cells yield a
+ * local point does not depend on the query, so it is resolved once per table: over the bounding box of the window's points
+ * (+ 4 cells) one bit per voxel = "the reference's chain for this cell's slot yields a local id >= 0" -- evaluated by
+ * looking the cell's slot up in the compact table, so a point returned by a foreign colliding cell, a point shadowed in its
+ * slot and the same point returned by two cells are all reproduced exactly -- plus, per 32 z-adjacent cells, the rank of the
+ * word's first hit in `cdir_pos`, the (x, y, z, id) rows of all hits in cell order (x-major, then y, then z: the probe order
+ * of np.py:931-969).  A stencil row of 2 nc + 1 z-adjacent cells is then ONE 8-byte load + bit tests instead of 2 nc + 1 x
+ * (hash fold, prefilter bit, 4-key bucket compare), and the hits of a row are consecutive rows of `cdir_pos`.
+ * Everything is sized on the device (no read-back): `words_cap` / `hits_cap` bound the arrays, the header's `valid` word
+ * says whether the window fitted; the searches fall back to probing the table itself when it did not, and for query points
+ * farther than nc cells outside the box (whose probes can only meet foreign collisions).
+ *   hdr_out    [CLID_CDIR_HDR_INTS] i32, words_out [words_cap + 1][2] u32, pos_out [hits_cap][4] f32,
+ *   scratch    [words_cap / 256 + 2] i32 (block sums of the rank scan)
+ *   pos4 / n   the window's points (clid_table_build's pos4_out), tab / tab_pos / filter: its table */
+#define CLID_CDIR_HDR_INTS 16
+#define CLID_CDIR_MARGIN 4
+int clid_cdir_build(const float* pos4, int32_t n, const int32_t* tab, const float* tab_pos, int32_t log2cap,
+                    const uint32_t* filter, int32_t log2filter, int64_t buffer_size, float resolution, int32_t* hdr_out,
+                    uint32_t* words_out, int64_t words_cap, float* pos_out, int64_t hits_cap, int32_t* scratch, void* stream);
 
 /* Builds the compact probe table for one (map, window, time-filter) state.
  * Replaces nothing in the reference by itself: it is the exact, smaller equivalent of indexing

@@ -1,0 +1,190 @@
+"""GPU: the cell directory of the local window (csrc/celldir.hip) and the search that walks it (csrc/train.hip search_cells).
+
+The directory must be the reference's probe chain cell by cell -- `buffer_pt_index[hash(cell) mod B]` -> travel-distance
+filter -> `global2local` (model/neural_points.py:984-1009, 595-598) -- including every collision of the big table: on the
+golden map (`buffer_size = 100003`, real collisions, shadowed points, points outside the window, time-filtered points) it is
+compared with a numpy evaluation of that chain over EVERY cell of its box.  The search records built from it must be bit
+for bit the records of the probing kernels (debug bit 3 keeps those), for query points inside, at the rim of and far outside
+the box, and at the 5e7-slot size of the shipped configs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io as gio
+import shim_io
+
+pytestmark = pytest.mark.gpu
+PRIMES = np.array([73856093, 19349669, 83492791], dtype=np.int64)
+
+
+def _directory(nm, time_filtering=True):
+    view, keep = nm._map_view(True, time_filtering)
+    torch.cuda.synchronize()
+    cdir = keep[8]
+    assert cdir is not None and view.cdir_hdr
+    hdr = cdir[0].cpu().numpy()
+    ox, oy, oz, nx, ny, nz, nzw, words, valid, n_hits = [int(v) for v in hdr[:10]]
+    w = cdir[1][:words].cpu().numpy().view(np.uint32)
+    pos = cdir[2][:n_hits].cpu().numpy()
+    return view, keep, dict(o=(ox, oy, oz), n=(nx, ny, nz), nzw=nzw, words=words, valid=valid, n_hits=n_hits, w=w, pos=pos)
+
+
+def _chain(nm, cells, time_filtering):
+    """local id (or -1) the reference's chain yields for every cell [N,3] int64 (numpy)."""
+    B = int(nm.buffer_size)
+    slot = np.mod((cells * PRIMES).sum(-1), B)
+    big = nm.buffer_pt_index.cpu().numpy()
+    gi = big[slot]
+    ok = gi >= 0
+    if time_filtering:
+        travel = nm.travel_dist.cpu().numpy().astype(np.float32)
+        created = nm.point_ts_create.cpu().numpy()
+        gap = np.abs(travel[int(nm.cur_ts)] - travel[created[np.where(ok, gi, 0)]])
+        ok &= gap < np.float32(nm.diff_travel_dist_local)
+    g2l = nm.global2local.cpu().numpy()
+    return np.where(ok, g2l[np.where(ok, gi, 0)], -1)
+
+
+@pytest.mark.parametrize("time_filtering", [True, False])
+def test_directory_is_the_probe_chain_cell_by_cell(time_filtering):
+    cfg = shim_io.config()
+    nm = shim_io.neural_points(cfg)
+    view, keep, d = _directory(nm, time_filtering)
+    assert d["valid"] == 1 and cfg.buffer_size == 100003
+    (ox, oy, oz), (nx, ny, nz) = d["o"], d["n"]
+    pts = nm.local_neural_points.cpu().numpy()
+    cell = np.floor(pts / np.float32(cfg.voxel_size_m)).astype(np.int64)
+    assert (cell.min(0) - 4 == np.array([ox, oy, oz])).all() and (cell.max(0) + 5 == np.array([ox + nx, oy + ny, oz + nz])).all()
+    gx, gy, gz = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    cells = np.stack((gx + ox, gy + oy, gz + oz), -1).reshape(-1, 3).astype(np.int64)
+    want = _chain(nm, cells, time_filtering).reshape(nx, ny, nz)
+    # bits
+    bits = d["w"][:, 0].reshape(nx, ny, d["nzw"])
+    got = np.zeros((nx, ny, d["nzw"] * 32), dtype=bool)
+    for b in range(32):
+        got[:, :, b::32] = ((bits >> np.uint32(b)) & 1).astype(bool)
+    assert not got[:, :, nz:].any()
+    assert (got[:, :, :nz] == (want >= 0)).all()
+    # foreign collisions are really present in this fixture: occupied cells that hold no point of their own
+    own = np.zeros((nx, ny, nz), dtype=bool)
+    own[cell[:, 0] - ox, cell[:, 1] - oy, cell[:, 2] - oz] = True
+    assert ((want >= 0) & ~own).sum() > 10
+    # ranks: exclusive prefix of the popcounts in word order; rows: the chain's point, in cell order
+    pop = np.array([bin(int(v)).count("1") for v in d["w"][:, 0]])
+    rank = d["w"][:, 1] & 0xFFFFFF
+    assert (rank == np.concatenate(([0], np.cumsum(pop)[:-1]))).all() and int(pop.sum()) == d["n_hits"]
+    nxt = d["w"][:, 1] >> 24
+    w0 = d["w"][:, 0]
+    same_col = (np.arange(d["words"]) + 1) % d["nzw"] != 0
+    assert (nxt[:-1][same_col[:-1]] == (w0[1:][same_col[:-1]] & 0xFF)).all() and (nxt[~same_col] == 0).all()
+    ids = want[want >= 0]  # C order of (x, y, z) == word order then bit order
+    assert (d["pos"][:, 3].copy().view(np.int32) == ids).all()
+    assert (d["pos"][:, :3] == pts[ids]).all()
+
+
+def _records(nm, mp, idx, bs, decim, flags):
+    from clid_slam_amd import _lib
+
+    lib = _lib.load()
+    view, keep = nm._map_view(True)
+    cfg = nm.config
+    ta = _lib.TrainArgs()
+    ta.pool_coord, ta.pool_label = mp.global_coord_pool.data_ptr(), mp.sdf_label_pool.data_ptr()
+    ta.pool_ts, ta.pool_weight = mp.time_pool.data_ptr(), mp.weight_pool.data_ptr()
+    ta.bs, ta.decimation, ta.batch_offset, ta.eikonal_mode, ta.loss_weight_on = bs, decim, 0, 1, 1
+    ta.fd_eps = float(cfg.voxel_size_m * cfg.num_grad_step_ratio)
+    iters = idx.shape[0]
+    n = int(lib.clid_train_search_floats(bs, 0, decim, 1, iters))
+    n_tasks = int(lib.clid_train_search_tasks(bs, 0, decim, 1))
+    ta.debug_flags = flags
+    rec = torch.zeros(n, device="cuda")
+    _lib.check(lib.clid_train_search(C.byref(view), C.byref(ta), iters, idx.data_ptr(), bs, rec.data_ptr(), _lib.stream()), "clid_train_search")
+    torch.cuda.synchronize()
+    per = rec.numel() // iters
+    return shim_io.task_records(rec, iters, n_tasks).reshape(-1, 48, 4).cpu(), rec.view(iters, per)[:, n_tasks * 192:].cpu(), view
+
+
+def _same(a, b):
+    assert torch.equal(a[0].contiguous().view(torch.int32), b[0].contiguous().view(torch.int32))  # records, bit patterns
+    assert torch.equal(a[1].contiguous().view(torch.int32), b[1].contiguous().view(torch.int32))  # tile number blocks
+
+
+@pytest.mark.parametrize("nnc,alpha", [(2, 0.5), (1, 1.0), (2, 0.2)])
+def test_records_from_the_directory_equal_probing_on_the_collision_fixture(nnc, alpha):
+    """Golden map (B = 100003): batch samples, their finite-difference copies, plus samples pushed to the rim of and far
+    outside the directory's box (those tasks fall back to probing: a foreign collision can answer there)."""
+    cfg = shim_io.config(num_nei_cells=nnc, search_alpha=alpha)
+    nm = shim_io.neural_points(cfg)
+    nm.set_search_neighborhood(num_nei_cells=nnc, search_alpha=alpha)
+    dec = shim_io.decoder(cfg)
+    mp, p = shim_io.mapper(cfg, nm, dec)
+    view, keep, d = _directory(nm)
+    S = mp.global_coord_pool.shape[0]
+    # append outliers to the pool: at the box faces (+- a few cells) and far away
+    g = torch.Generator().manual_seed(5)
+    lo = torch.tensor(d["o"], dtype=torch.float32) * cfg.voxel_size_m
+    hi = lo + torch.tensor(d["n"], dtype=torch.float32) * cfg.voxel_size_m
+    rim = lo + (hi - lo) * torch.rand((400, 3), generator=g)
+    face = torch.randint(0, 3, (400,), generator=g)
+    side = torch.randint(0, 2, (400,), generator=g).bool()
+    off = (torch.rand(400, generator=g) - 0.5) * 8 * cfg.voxel_size_m
+    rim[torch.arange(400), face] = torch.where(side, hi[face], lo[face]) + off
+    far = (torch.rand((100, 3), generator=g) - 0.5) * 4000.0
+    extra = torch.cat((rim, far))
+    mp.set_pool(torch.cat((mp.global_coord_pool.cpu(), extra)), torch.cat((mp.sdf_label_pool.cpu(), torch.zeros(500))),
+                torch.cat((mp.weight_pool.cpu(), torch.ones(500))), torch.cat((mp.time_pool.cpu(), torch.zeros(500, dtype=torch.int32))))
+    bs, decim, iters = 2048, 5, 2
+    idx = torch.randint(0, S, (iters, bs), generator=g)
+    idx[:, ::7] = S + torch.randint(0, 500, (iters, len(range(0, bs, 7))), generator=g)
+    idx = idx.cuda()
+    a = _records(nm, mp, idx, bs, decim, 0)
+    b = _records(nm, mp, idx, bs, decim, 8)
+    assert a[2].cdir_hdr and a[2].stencil_rows
+    _same(a, b)
+    ids = a[0][:, 16:].reshape(-1, 8, 8, 2)[:, :, :6, 1].contiguous().view(torch.int32)
+    assert float((ids >= 0).float().mean()) > 0.1  # (the comparison is not vacuous)
+
+
+def test_records_from_the_directory_equal_probing_at_full_size():
+    """bench scene, buffer_size 5e7, 16 384 samples x 3 iterations (tiles numbered by the search launch) and a 65 536-sample
+    iteration (per-task kernel)."""
+    import bench
+    from clid_slam_amd import HotPathConfig
+
+    cfg = HotPathConfig()
+    cfg.device = "cuda:0"
+    nm, dec, mp, scene = bench.build_scene(cfg, "cuda:0")
+    view, keep, d = _directory(nm)
+    assert d["valid"] == 1 and d["n_hits"] >= nm.local_count() * 0.9
+    for bs, iters in ((16384, 3), (65536, 1)):
+        idx = torch.randint(0, mp.pool_sample_count, (iters, bs), device="cuda", generator=torch.Generator("cuda").manual_seed(3 + bs))
+        a = _records(nm, mp, idx, bs, cfg.gradient_decimation, 0)
+        b = _records(nm, mp, idx, bs, cfg.gradient_decimation, 8)
+        _same(a, b)
+
+
+def test_window_beyond_the_capacity_falls_back_to_probing():
+    """A directory whose box exceeds the word capacity is marked invalid on the device; the search launch notices and
+    probes the table (same records)."""
+    from clid_slam_amd import _lib
+
+    cfg = shim_io.config()
+    nm = shim_io.neural_points(cfg)
+    dec = shim_io.decoder(cfg)
+    mp, p = shim_io.mapper(cfg, nm, dec)
+    bs, decim = 1024, 10
+    idx = torch.randint(0, mp.global_coord_pool.shape[0], (1, bs), generator=torch.Generator().manual_seed(9)).cuda()
+    a = _records(nm, mp, idx, bs, decim, 0)
+    view, keep = nm._map_view(True)
+    (tab, tab_pos, filt, log2filter), pos4, log2cap = nm._table(True, True)
+    cdir = keep[8]
+    scratch = torch.zeros(64, device="cuda", dtype=torch.int32)
+    _lib.check(_lib.load().clid_cdir_build(pos4.data_ptr(), pos4.shape[0], tab.data_ptr(), tab_pos.data_ptr(), log2cap, filt.data_ptr(),
+                                           log2filter, int(nm.buffer_size), float(nm.resolution), cdir[0].data_ptr(), cdir[1].data_ptr(),
+                                           256, cdir[2].data_ptr(), cdir[2].shape[0], scratch.data_ptr(), _lib.stream()), "clid_cdir_build")
+    torch.cuda.synchronize()
+    assert int(cdir[0][8]) == 0
+    b = _records(nm, mp, idx, bs, decim, 0)
+    _same(a, b)
