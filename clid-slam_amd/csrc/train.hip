@@ -244,6 +244,12 @@ __device__ __forceinline__ bool search8(const clid_map_view& mv, const DeltaLds&
 // so hit number g of a query is its g-th valid probe.  Lane l of the query's 8 lanes takes rows [4 l, 4 l + 4), the lanes
 // agree on the hits' numbering with one 8-lane scan, expand their rows' rank ranges into an LDS list, and then every lane
 // takes an equal share of the hits (l, l + 8, ...): one position load + distance + insert per hit instead of per probe.
+#ifndef CLID_CD_WAVES_TASKS
+#define CLID_CD_WAVES_TASKS 8  // waves per SIMD the directory-search instantiations are compiled for (64 VGPRs without the
+#endif                         // probing code: 8 waves hide the words -> list -> position chain better than 6)
+#ifndef CLID_CD_WAVES_TILES
+#define CLID_CD_WAVES_TILES 6
+#endif
 constexpr int kCdRows = 32;  // staged stencil rows: (2 nc + 1)^2 <= 25 for nc <= 2, the rest empty
 constexpr int kCdHits = 88;  // list entries per query slot (>= 81 probes)
 struct CellLds {
@@ -680,7 +686,10 @@ struct TileNumLds {
 };
 
 // one wave task: pool gathers, 81-cell search of its 8 query slots, IDW weights / blended offsets -> record in `hd`
-__device__ __forceinline__ void search_task(const clid_map_view& mv, const clid_train_args& ta, const TaskMap& tmap,
+// CD: the cell-directory search (returns true = a query point lies outside the directory's box: nothing was written, the task
+// is left to the probing kernels); else search8 (returns false).
+template <bool CD>
+__device__ __forceinline__ bool search_task(const clid_map_view& mv, const clid_train_args& ta, const TaskMap& tmap,
                                             const DeltaLds& dl, const long long* __restrict__ index, int task, int it, int use_filter,
                                             const unsigned* __restrict__ filt_lds, WaveHead& hd, const CellLds& cl) {
   const int lane = threadIdx.x & 63, lane8 = lane & 7, slot8 = lane >> 3;
@@ -705,25 +714,27 @@ __device__ __forceinline__ void search_task(const clid_map_view& mv, const clid_
     hd.qdesc[slot8] = make_float4(__int_as_float(qd.p), __int_as_float(code), label, wt);
   }
   asm volatile("" ::"v"(px), "v"(py), "v"(pz));
-  bool redo;
-  if (use_filter == 3) {
-    // the window's cell directory: (use_filter == 3 lends the dynamic LDS to the hit lists, see the kernels)
+  if constexpr (CD) {
+    // the window's cell directory (the dynamic LDS holds the hit lists)
     const int nc = cl.nc;
     const int rx = (int)floorf(fdiv(px, mv.resolution)) - cl.ox, ry = (int)floorf(fdiv(py, mv.resolution)) - cl.oy;
     const int rz0 = (int)floorf(fdiv(pz, mv.resolution)) - cl.oz - nc;
-    // all 2 nc + 1 cells per axis inside the box?  (outside it a probe can only meet a foreign collision: search8 handles it)
+    // all 2 nc + 1 cells per axis inside the box?  Outside it a probe can only meet a foreign collision: the probing kernels
+    // answer that exactly (padding slots search the coordinates of sample 0 like they do: identical records).  A window
+    // beyond the directory's capacity (cl.valid == 0) defers every task.
     const bool inside = (unsigned)(rx - nc) < (unsigned)(cl.nx - 2 * nc) && (unsigned)(ry - nc) < (unsigned)(cl.ny - 2 * nc) &&
                         (unsigned)rz0 < (unsigned)(cl.nz - 2 * nc);
-    redo = !inside;  // (padding slots search the coordinates of sample 0 like the probing kernels: identical records)
-    if (!__any(redo)) {
-      int* list = const_cast<int*>(reinterpret_cast<const int*>(filt_lds)) + ((threadIdx.x >> 6) * 8 + slot8) * kCdHits;
-      search_cells(mv, cl, list, px, py, pz, rx, ry, rz0, lane8, lane & 56, hd.win[slot8], (ta.debug_flags & 4) != 0);
-    }
-  } else if (use_filter == 1) redo = search8<true, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], filt_lds);
-  else if (use_filter == 2) redo = search8<true, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], mv.filter);
-  else redo = search8<false, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
-  if (__any(redo) || ((ta.debug_flags & 4) && use_filter != 3))  // rare (debug bit 2 forces it: tests compare the two paths)
-    search8<false, CLID_K>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
+    if (__any(!inside) || !cl.valid) return true;
+    int* list = const_cast<int*>(reinterpret_cast<const int*>(filt_lds)) + ((threadIdx.x >> 6) * 8 + slot8) * kCdHits;
+    search_cells(mv, cl, list, px, py, pz, rx, ry, rz0, lane8, lane & 56, hd.win[slot8], (ta.debug_flags & 4) != 0);
+  } else {
+    bool redo;
+    if (use_filter == 1) redo = search8<true, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], filt_lds);
+    else if (use_filter == 2) redo = search8<true, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], mv.filter);
+    else redo = search8<false, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
+    if (__any(redo) || (ta.debug_flags & 4))  // rare (debug bit 2 forces it: tests compare the two paths)
+      search8<false, CLID_K>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8]);
+  }
   // (d2, id) -> (IDW weight, id) + blended offset (np.py:653-706), lane8 = k
   wave_lds_fence();
   const float2 wn = hd.win[slot8][lane8 < CLID_K ? lane8 : 0];
@@ -740,6 +751,7 @@ __device__ __forceinline__ void search_task(const clid_map_view& mv, const clid_
   wave_lds_fence();
   hd.win[slot8][lane8] = lane8 < CLID_K ? make_float2(w, wn.y) : (lane8 == CLID_K ? make_float2(rx, ry) : make_float2(rz, 0.f));
   wave_lds_fence();
+  return false;
 }
 
 // The tile's pairs numbered per distinct map row: lane = (q = lane & 15, g = lane >> 4) as in k_decode_tile, lane (q, g)
@@ -804,40 +816,48 @@ __device__ __noinline__ void number_tile(const WaveHead& h0, const WaveHead& h1,
   wave_lds_fence();
 }
 
-template <bool XMAP>
-__global__ void __launch_bounds__(kFusedBlock, CLID_SEARCH_WAVES)
+// MODE 0: probing (search8) over every tile of the launch.  MODE 1: the cell-directory search over every tile; a tile with a query
+// point outside the directory's box goes on its iteration's deferred list (train_common.hpp).  MODE 2: probing over the
+// deferred lists (grid.y = iteration; almost always empty: the block leaves before it stages anything).
+template <bool XMAP, int MODE>
+__global__ void __launch_bounds__(kFusedBlock, MODE == 1 ? CLID_CD_WAVES_TILES : CLID_SEARCH_WAVES)
 k_search_tiles(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __restrict__ rec, int n_iter, long long index_stride,
                int use_filter) {
   __shared__ DeltaLds dl;
   __shared__ CellLds cl;
   __shared__ WaveHead heads[kFusedBlock / 64][2];
   __shared__ TileNumLds nums[kFusedBlock / 64];
-  extern __shared__ unsigned filt_lds[];  // with a prefilter of <= 32 KB: 2^log2filter bits (dynamic LDS); use_filter == 3: hit lists
-  stage_delta(dl, mv);
-  stage_cells(cl, mv, use_filter == 3);
-  if (use_filter == 1)
+  extern __shared__ unsigned filt_lds[];  // MODE 0 / 2 with a prefilter of <= 32 KB: 2^log2filter bits; MODE 1: the hit lists
+  const size_t iter_f4 = rec_floats_per_iter(tmap.n_tasks) / 4;
+  const size_t def_off = rec_deferred_offset(tmap.n_tasks);
+  if (MODE == 2 && reinterpret_cast<const int*>(rec + (size_t)blockIdx.y * iter_f4)[def_off] == 0) return;
+  if (MODE != 1) stage_delta(dl, mv);
+  stage_cells(cl, mv, MODE == 1);
+  if (MODE != 1 && use_filter == 1)
     for (int i = threadIdx.x; i < (1 << mv.log2filter) / 32; i += kFusedBlock) filt_lds[i] = mv.filter[i];
   __syncthreads();
-  if (use_filter == 3 && !cl.valid) use_filter = 0;  // the window did not fit the directory's capacity: probe the table
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves_per_block = kFusedBlock / 64;
   const int n_tiles = (tmap.n_tasks + 1) / 2;
-  const size_t iter_f4 = rec_floats_per_iter(tmap.n_tasks) / 4;
-  // XCD-aware tile mapping for maps beyond one L2 (the launcher's use_filter == 2): block b runs on XCD b % 8 (observed
-  // dispatch order; a speed matter only) and every XCD has its own 4 MB L2.  On batches in Morton order consecutive tasks are
-  // neighbours in space, so XCD x takes the x-th eighth of the bundle tiles and of the plain tiles of EVERY iteration: its
-  // L2 then serves one eighth of the map (M = 243 k: search 18.9 -> 17.5 us per iteration; at M = 23 k it costs 0.2 us)
+  // XCD-aware tile mapping for maps beyond one L2: block b runs on XCD b % 8 (observed dispatch order; a speed matter only)
+  // and every XCD has its own 4 MB L2.  On batches in Morton order consecutive tasks are neighbours in space, so XCD x takes
+  // the x-th eighth of the bundle tiles and of the plain tiles of EVERY iteration: its L2 then serves one eighth of the map
+  // (M = 243 k: search 18.9 -> 17.5 us per iteration; at M = 23 k it costs 0.2 us)
   const int xcd = blockIdx.x & 7, xb = blockIdx.x >> 3, xnb = ((int)gridDim.x + 7 - xcd) >> 3;
   const int nb_t = (tmap.n_fd + 1) / 2, n_rest = n_tiles - nb_t;
   const int xb0 = (int)((long long)nb_t * xcd / 8), xb1 = (int)((long long)nb_t * (xcd + 1) / 8);
   const int xr0 = (int)((long long)n_rest * xcd / 8), xr1 = (int)((long long)n_rest * (xcd + 1) / 8);
   const int xlen = (xb1 - xb0) + (xr1 - xr0);
-  constexpr bool xmap = XMAP;  // (its own instantiation: the mapping's scalars cost the small-map kernel registers it has to spill)
+  constexpr bool xmap = XMAP && MODE != 2;  // (its own instantiation: the mapping's scalars cost the small-map kernel registers it has to spill)
   const int w_first = xmap ? xb * waves_per_block + wave : blockIdx.x * waves_per_block + wave;
   const int w_step = xmap ? xnb * waves_per_block : gridDim.x * waves_per_block;
-  const int w_total = xmap ? xlen * n_iter : n_tiles * n_iter;
+  const int* dlist = reinterpret_cast<const int*>(rec + (size_t)blockIdx.y * iter_f4) + def_off;  // (MODE 2)
+  const int w_total = MODE == 2 ? dlist[0] : (xmap ? xlen * n_iter : n_tiles * n_iter);
   for (int w = w_first; w < w_total; w += w_step) {
     int it, tile;
-    if (xmap) {
+    if (MODE == 2) {
+      it = blockIdx.y;
+      tile = dlist[4 + w];
+    } else if (xmap) {
       it = w / xlen;
       const int u = w - it * xlen;
       tile = u < xb1 - xb0 ? xb0 + u : nb_t + xr0 + (u - (xb1 - xb0));
@@ -847,12 +867,22 @@ k_search_tiles(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
     }
     const long long* index = reinterpret_cast<const long long*>(ta.index) + (long long)it * index_stride;
     float4* __restrict__ out = rec + (size_t)it * iter_f4;
+    bool deferred = false;
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
       const int task = 2 * tile + half;
       if (task >= tmap.n_tasks) break;
-      search_task(mv, ta, tmap, dl, index, task, it, use_filter, filt_lds, heads[wave][half], cl);
+      deferred = search_task<MODE == 1>(mv, ta, tmap, dl, index, task, it, use_filter, filt_lds, heads[wave][half], cl);
+      if (deferred) break;
       if (lane < kRecFloat4) out[(size_t)task * kRecFloat4 + lane] = reinterpret_cast<const float4*>(&heads[wave][half])[lane];
+    }
+    if (deferred) {
+      if (lane == 0) {
+        int* dl_out = reinterpret_cast<int*>(out) + def_off;
+        dl_out[4 + atomicAdd(dl_out, 1)] = tile;
+      }
+      wave_lds_fence();
+      continue;
     }
     number_tile(heads[wave][0], heads[wave][1], nums[wave],
                 reinterpret_cast<int*>(out + (size_t)tmap.n_tasks * kRecFloat4) + (size_t)tile * kTileNumWords,
@@ -862,36 +892,41 @@ k_search_tiles(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
 
 // The same search per TASK, without numbering: iterations of more than kTileLargeFrom tiles (65 536 samples and up), whose
 // decode launch numbers its tiles in place.  (Pairing the tasks costs the search 5-8 % by itself, the numbering another
-// 13 %: 105 -> 113 -> 126 us per iteration at 262 144 samples.)
-template <bool XMAP>
-__global__ void __launch_bounds__(kFusedBlock, CLID_SEARCH_WAVES)
+// 13 %: 105 -> 113 -> 126 us per iteration at 262 144 samples.)  MODE as in k_search_tiles.
+template <bool XMAP, int MODE>
+__global__ void __launch_bounds__(kFusedBlock, MODE == 1 ? CLID_CD_WAVES_TASKS : CLID_SEARCH_WAVES)
 k_search_tasks(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __restrict__ rec, int n_iter, long long index_stride,
                int use_filter) {
   __shared__ DeltaLds dl;
   __shared__ CellLds cl;
   __shared__ WaveHead heads[kFusedBlock / 64];
   extern __shared__ unsigned filt_lds[];
-  stage_delta(dl, mv);
-  stage_cells(cl, mv, use_filter == 3);
-  if (use_filter == 1)
+  const size_t iter_f4 = rec_floats_per_iter(tmap.n_tasks) / 4;
+  const size_t def_off = rec_deferred_offset(tmap.n_tasks);
+  if (MODE == 2 && reinterpret_cast<const int*>(rec + (size_t)blockIdx.y * iter_f4)[def_off] == 0) return;
+  if (MODE != 1) stage_delta(dl, mv);
+  stage_cells(cl, mv, MODE == 1);
+  if (MODE != 1 && use_filter == 1)
     for (int i = threadIdx.x; i < (1 << mv.log2filter) / 32; i += kFusedBlock) filt_lds[i] = mv.filter[i];
   __syncthreads();
-  if (use_filter == 3 && !cl.valid) use_filter = 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves_per_block = kFusedBlock / 64;
-  const size_t iter_f4 = rec_floats_per_iter(tmap.n_tasks) / 4;
   // XCD x takes the x-th eighth of the bundle tasks and of the plain tasks of every iteration (see k_search_tiles)
   const int xcd = blockIdx.x & 7, xb = blockIdx.x >> 3, xnb = ((int)gridDim.x + 7 - xcd) >> 3;
   const int n_rest = tmap.n_tasks - tmap.n_fd;
   const int xb0 = (int)((long long)tmap.n_fd * xcd / 8), xb1 = (int)((long long)tmap.n_fd * (xcd + 1) / 8);
   const int xr0 = (int)((long long)n_rest * xcd / 8), xr1 = (int)((long long)n_rest * (xcd + 1) / 8);
   const int xlen = (xb1 - xb0) + (xr1 - xr0);
-  constexpr bool xmap = XMAP;
+  constexpr bool xmap = XMAP && MODE != 2;
   const int w_first = xmap ? xb * waves_per_block + wave : blockIdx.x * waves_per_block + wave;
   const int w_step = xmap ? xnb * waves_per_block : gridDim.x * waves_per_block;
-  const int w_total = xmap ? xlen * n_iter : tmap.n_tasks * n_iter;
+  const int* dlist = reinterpret_cast<const int*>(rec + (size_t)blockIdx.y * iter_f4) + def_off;  // (MODE 2)
+  const int w_total = MODE == 2 ? dlist[0] : (xmap ? xlen * n_iter : tmap.n_tasks * n_iter);
   for (int w = w_first; w < w_total; w += w_step) {
     int it, task;
-    if (xmap) {
+    if (MODE == 2) {
+      it = blockIdx.y;
+      task = dlist[4 + w];
+    } else if (xmap) {
       it = w / xlen;
       const int u = w - it * xlen;
       task = u < xb1 - xb0 ? xb0 + u : tmap.n_fd + xr0 + (u - (xb1 - xb0));
@@ -900,9 +935,14 @@ k_search_tasks(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
       task = w - it * tmap.n_tasks;
     }
     const long long* index = reinterpret_cast<const long long*>(ta.index) + (long long)it * index_stride;
-    search_task(mv, ta, tmap, dl, index, task, it, use_filter, filt_lds, heads[wave], cl);
-    if (lane < kRecFloat4)
+    if (search_task<MODE == 1>(mv, ta, tmap, dl, index, task, it, use_filter, filt_lds, heads[wave], cl)) {
+      if (lane == 0) {
+        int* dl_out = reinterpret_cast<int*>(rec + (size_t)it * iter_f4) + def_off;
+        dl_out[4 + atomicAdd(dl_out, 1)] = task;
+      }
+    } else if (lane < kRecFloat4) {
       rec[(size_t)it * iter_f4 + (size_t)task * kRecFloat4 + lane] = reinterpret_cast<const float4*>(&heads[wave])[lane];
+    }
     wave_lds_fence();
   }
 }
@@ -1343,17 +1383,17 @@ static int n_queries(const clid_train_args* a, int* n_fd, int* first) {
 // Grid of the hoisted search launch (grid-stride over chunk x tasks): exactly the blocks that are resident at once
 // (CUs x 4 SIMDs x CLID_SEARCH_WAVES / waves per block = 768 on MI355X), so every block stages the 32 KB prefilter into
 // LDS once per launch.  A 2048-block grid re-staged it 2.7 times: 42.5 -> 39.2 us per iteration in the mapping(10) regime.
-static int search_blocks() {
-  static thread_local int dev_cached = -1, blocks = 0;  // (a cache of a device attribute, not state of the loop)
+static int search_blocks(int waves_per_simd = CLID_SEARCH_WAVES) {
+  static thread_local int dev_cached = -1, cus_cached = 0;  // (a cache of a device attribute, not state of the loop)
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 768;
+  if (hipGetDevice(&dev) != hipSuccess) return 128 * waves_per_simd;
   if (dev != dev_cached) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    blocks = cus * 4 * CLID_SEARCH_WAVES / (kFusedBlock / 64);
+    cus_cached = cus;
     dev_cached = dev;
   }
-  return blocks;
+  return cus_cached * 4 * waves_per_simd / (kFusedBlock / 64);
 }
 
 static int fused_blocks(int n_tasks, int block = kFusedBlock) {
@@ -1675,22 +1715,43 @@ extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args*
   if (mv->cdir_hdr && mv->cdir_words && mv->cdir_pos && mv->stencil_rows && mv->stencil_nc >= 1 && mv->stencil_nc <= 2 &&
       !(a->debug_flags & 8))
     use_filter = 3;
-  const size_t dyn = use_filter == 1 ? ((size_t)1 << mv->log2filter) / 8
-                                     : (use_filter == 3 ? (size_t)(kFusedBlock / 64) * 8 * kCdHits * sizeof(int) : 0);
+  const bool cdir = use_filter == 3;
+  if (cdir) use_filter = big_map ? 2 : (mv->filter && mv->log2filter >= 10 && mv->log2filter <= 18 && filter_enabled() ? 1 : 0);
+  const size_t dyn_probe = use_filter == 1 ? ((size_t)1 << mv->log2filter) / 8 : 0;
+  const size_t dyn_cells = (size_t)(kFusedBlock / 64) * 8 * kCdHits * sizeof(int);
   // iterations of at most kTileLargeFrom tiles: tasks in pairs, the tile's pairs numbered for the decode launch (one tile
   // per wave there); larger ones: per task, the decode kernel numbers in place (train_common.hpp tiles_prenumbered)
   const bool num = clid_tiles_prenumbered(tmap.n_tasks, mv);
   long long sb = num ? ((long long)((tmap.n_tasks + 1) / 2) * n_iter + kFusedBlock / 64 - 1) / (kFusedBlock / 64)
                      : ((long long)tmap.n_tasks * n_iter + kFusedBlock / 64 - 1) / (kFusedBlock / 64);
-  if (sb > search_blocks()) sb = search_blocks();
+  const int resident = search_blocks(cdir ? (num ? CLID_CD_WAVES_TILES : CLID_CD_WAVES_TASKS) : CLID_SEARCH_WAVES);
+  if (sb > resident) sb = resident;
   const bool xm = CLID_XCD_MAP && big_map && sb >= 8;
-#define CLID_SEARCH_LAUNCH(K)                                                                                    \
-  CLID_KLAUNCH(a->prof, 1, K, dim3((unsigned)sb), dim3(kFusedBlock), dyn, s, *mv, t2, tmap,                     \
-               reinterpret_cast<float4*>(rec_out), n_iter, (long long)index_stride, use_filter)
-  if (num && xm) CLID_SEARCH_LAUNCH(k_search_tiles<true>);
-  else if (num) CLID_SEARCH_LAUNCH(k_search_tiles<false>);
-  else if (xm) CLID_SEARCH_LAUNCH(k_search_tasks<true>);
-  else CLID_SEARCH_LAUNCH(k_search_tasks<false>);
+  const size_t per_iter_f = rec_floats_per_iter(tmap.n_tasks);
+#define CLID_SEARCH_LAUNCH(K, GRID, DYN)                                                                                   \
+  CLID_KLAUNCH(a->prof, 1, K, GRID, dim3(kFusedBlock), DYN, s, *mv, t2, tmap, reinterpret_cast<float4*>(rec_out), n_iter, \
+               (long long)index_stride, use_filter)
+  if (cdir) {
+    // the deferred lists start empty; the directory launch fills them, the probing launch behind it walks them
+    if (hipMemset2DAsync(rec_out + rec_deferred_offset(tmap.n_tasks), per_iter_f * sizeof(float), 0, sizeof(int), (size_t)n_iter, s) !=
+        hipSuccess) {
+      clid_set_error("clid_train_search: list reset failed");
+      return CLID_E_HIP;
+    }
+    const dim3 g1((unsigned)sb), g2(16, (unsigned)n_iter);
+    if (num && xm) CLID_SEARCH_LAUNCH((k_search_tiles<true, 1>), g1, dyn_cells);
+    else if (num) CLID_SEARCH_LAUNCH((k_search_tiles<false, 1>), g1, dyn_cells);
+    else if (xm) CLID_SEARCH_LAUNCH((k_search_tasks<true, 1>), g1, dyn_cells);
+    else CLID_SEARCH_LAUNCH((k_search_tasks<false, 1>), g1, dyn_cells);
+    if (num) CLID_SEARCH_LAUNCH((k_search_tiles<false, 2>), g2, dyn_probe);
+    else CLID_SEARCH_LAUNCH((k_search_tasks<false, 2>), g2, dyn_probe);
+  } else {
+    const dim3 g1((unsigned)sb);
+    if (num && xm) CLID_SEARCH_LAUNCH((k_search_tiles<true, 0>), g1, dyn_probe);
+    else if (num) CLID_SEARCH_LAUNCH((k_search_tiles<false, 0>), g1, dyn_probe);
+    else if (xm) CLID_SEARCH_LAUNCH((k_search_tasks<true, 0>), g1, dyn_probe);
+    else CLID_SEARCH_LAUNCH((k_search_tasks<false, 0>), g1, dyn_probe);
+  }
 #undef CLID_SEARCH_LAUNCH
   CLID_CHECK_LAUNCH();
   return CLID_OK;

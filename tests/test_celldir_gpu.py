@@ -103,7 +103,10 @@ def _records(nm, mp, idx, bs, decim, flags):
     _lib.check(lib.clid_train_search(C.byref(view), C.byref(ta), iters, idx.data_ptr(), bs, rec.data_ptr(), _lib.stream()), "clid_train_search")
     torch.cuda.synchronize()
     per = rec.numel() // iters
-    return shim_io.task_records(rec, iters, n_tasks).reshape(-1, 48, 4).cpu(), rec.view(iters, per)[:, n_tasks * 192:].cpu(), view
+    tail = ((n_tasks + 4) + 3) & ~3  # behind the records and number blocks: the iteration's deferred list (count | tasks / tiles)
+    deferred = int(rec.view(iters, per)[:, per - tail].contiguous().view(torch.int32).sum())
+    return (shim_io.task_records(rec, iters, n_tasks).reshape(-1, 48, 4).cpu(), rec.view(iters, per)[:, n_tasks * 192:per - tail].cpu(), view,
+            deferred)
 
 
 def _same(a, b):
@@ -143,6 +146,7 @@ def test_records_from_the_directory_equal_probing_on_the_collision_fixture(nnc, 
     b = _records(nm, mp, idx, bs, decim, 8)
     assert a[2].cdir_hdr and a[2].stencil_rows
     _same(a, b)
+    assert a[3] > 0 and b[3] == 0  # tasks with a query point outside the box went through the deferred list
     ids = a[0][:, 16:].reshape(-1, 8, 8, 2)[:, :, :6, 1].contiguous().view(torch.int32)
     assert float((ids >= 0).float().mean()) > 0.1  # (the comparison is not vacuous)
 
@@ -188,3 +192,4 @@ def test_window_beyond_the_capacity_falls_back_to_probing():
     assert int(cdir[0][8]) == 0
     b = _records(nm, mp, idx, bs, decim, 0)
     _same(a, b)
+    assert b[3] > a[3] and b[3] >= 64  # every tile of the launch was deferred to the probing kernels
