@@ -90,7 +90,8 @@ def _check_tile_number_blocks(rec, n_it, n_tasks, ids, live):
     bijection onto the tile's distinct ids, 255 marks pairs without a neighbour (or of a padding slot)."""
     n_tiles = (n_tasks + 1) // 2
     per = rec.numel() // n_it
-    blocks = rec.view(n_it, per)[:, n_tasks * 192:].contiguous().view(torch.int32).cpu().numpy().reshape(n_it, n_tiles, 128)
+    # (behind the number blocks: the iteration's deferred list of the directory search, train_common.hpp)
+    blocks = rec.view(n_it, per)[:, n_tasks * 192:n_tasks * 192 + n_tiles * 128].contiguous().view(torch.int32).cpu().numpy().reshape(n_it, n_tiles, 128)
     for it in range(n_it):
         for tile in range(0, n_tiles, 7):
             b = blocks[it, tile]
