@@ -140,12 +140,14 @@ def kernel_report(lib, mp, steps, bs_local, decim, M, decode_variant):
     iters = max(n.value, 1)
     Q = bs_local + 6 * ((bs_local + decim - 1) // decim)
     hoisted = out[1] > 0.0
+    n_tasks_est = int(lib.clid_train_search_tasks(bs_local, 0, decim, 1))  # <= 2048 tiles: the launch that also numbers the tiles
     dname = {0: "k_train_fused8<2> (decode, 16 lanes/query)", 1: "k_decode_tile<fp32 MFMA>", 2: "k_decode_tile<bf16 MFMA>"}[decode_variant]
     rows = [
         (dname if hoisted else "k_train_fused8<0> (search+decode)", out[0] / iters,
          Q * (B_DECODE_FWD_Q + B_BWD_Q) if hoisted else Q * (B_SEARCH_Q + B_DECODE_FWD_Q + B_BWD_Q) + bs_local * B_POOL_SAMPLE,
          "752 B/query (316 fwd after the search + 436 bwd) x %d query points" % Q if hoisted else "1440 B/query + 24 B/sample"),
-        ("k_search_tiles (search + tile numbering, per iteration of a <=32-iteration launch)", out[1] / iters,
+        (("k_search_tiles (cell-directory search + tile numbering" if (n_tasks_est + 1) // 2 <= 2048 else
+          "k_search_tasks (cell-directory search") + ", per iteration of a <=32-iteration launch)", out[1] / iters,
          Q * B_SEARCH_Q + bs_local * B_POOL_SAMPLE, "688 B/query x %d + 24 B x %d samples" % (Q, bs_local)),
         ("k_reduce_partials (+ pack of the touched rows)", out[2] / iters, 0.0, ""),
         ("k_touch_bits + k_touch_scan (per iteration of a chunk)", out[5] / iters, 0.0, ""),
@@ -354,7 +356,7 @@ def main():
         dom = max(kernels, key=lambda k: k["avg_us"])
         traffic = None  # HBM bytes per launch from the committed PMC passes (same workload and kernel only)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")))
             wk = tj["workload"]
             if wk["bs_per_gpu"] == bs_local and wk["decimation"] == decim and dom["kernel"] in tj:
                 traffic = tj[dom["kernel"]]["traffic_bytes"]
@@ -368,9 +370,9 @@ def main():
             "avg_launch_us": dom["avg_us"], "kernels": kernels, "profiled_steps": n_prof,
             "step_bytes": step_bytes, "step_frac_of_peak": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
             "note": "avg_launch_us = mean dispatch begin->end of the kernel (hipExtLaunchKernelGGL start/stop events on the "
-                    "launch stream, the clock rocprofv3 --kernel-trace reports; committed trace: profiles/r03_*_kernel_stats.csv); "
+                    "launch stream, the clock rocprofv3 --kernel-trace reports; committed trace: profiles/r04_*_kernel_stats.csv); "
                     "achieved = SURVEY section 8(d) algorithmic bytes of the launch / that duration; traffic = offline PMC passes "
-                    "(profiles/r03_hbm_traffic.json, 2 x FETCH_SIZE + WRITE_SIZE); the loop is bound by dependent-launch latency "
+                    "(profiles/r04_hbm_traffic.json, FETCH_SIZE / WRITE_SIZE as the guide corrects them); the loop is bound by dependent-launch latency "
                     "and the memory-side atomic rate at this batch size, not by HBM bandwidth (DESIGN.md section 6)",
         }
     sync()

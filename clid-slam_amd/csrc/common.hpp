@@ -162,6 +162,45 @@ struct TopK {  // replicated across the group
   int nn;         // valid probes over all P (np.py:600-602)
 };
 
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// candidates of the searches: local id (< 2^22) | probe / hit index (< 384 = kMaxProbes) << 22 -- equal distances resolve by index
+constexpr int kProbeShift = 22;
+
+// ---- cell directory of the window (csrc/celldir.hip), block-staged part ---------------------------------------------------
+constexpr int kCdRows = 32;  // staged stencil rows: (2 nc + 1)^2 <= 25 for nc <= 2, the rest empty
+constexpr int kCdHits = 88;  // list entries per query slot (>= 81 probes)
+struct CellLds {
+  int4 row[kCdRows];  // per (dx, dy) row: word offset (dx ny + dy) nzw | stencil bits along z | bits below the first stencil bit | -
+  int ox, oy, oz, nx, ny, nz, nzw, valid, nc;
+};
+__device__ __forceinline__ void stage_cells(CellLds& cl, const clid_map_view& mv, bool want) {
+  const bool have = want && mv.cdir_hdr && mv.cdir_words && mv.cdir_pos && mv.stencil_rows && mv.stencil_nc >= 1 && mv.stencil_nc <= 2;
+  const int nc = have ? mv.stencil_nc : 1, S = 2 * nc + 1;
+  if (threadIdx.x < kCdRows) {
+    const int r = threadIdx.x;
+    int4 e = make_int4(0, 0, 0, 0);
+    if (have && r < S * S) {
+      const int dx = r / S - nc, dy = r % S - nc;
+      const unsigned zm = mv.stencil_rows[r];
+      e.x = (dx * mv.cdir_hdr[4] + dy) * mv.cdir_hdr[6];
+      e.y = (int)zm;
+      e.z = (int)((zm & (0u - zm)) - 1u);
+    }
+    cl.row[r] = e;
+  }
+  if (threadIdx.x == 0) {
+    cl.ox = have ? mv.cdir_hdr[0] : 0; cl.oy = have ? mv.cdir_hdr[1] : 0; cl.oz = have ? mv.cdir_hdr[2] : 0;
+    cl.nx = have ? mv.cdir_hdr[3] : 0; cl.ny = have ? mv.cdir_hdr[4] : 0; cl.nz = have ? mv.cdir_hdr[5] : 0;
+    cl.nzw = have ? mv.cdir_hdr[6] : 0;
+    cl.valid = have ? mv.cdir_hdr[8] : 0;
+    cl.nc = nc;
+  }
+}
+
 // Per-offset slot deltas staged in LDS, padded with zeros to a multiple of kProbeChunk
 constexpr int kProbesPerLane = 6;
 constexpr int kProbeChunk = CLID_G * kProbesPerLane;  // 96 >= 81
@@ -175,11 +214,53 @@ __device__ __forceinline__ void stage_delta(DeltaLds& s, const clid_map_view& mv
   for (int i = threadIdx.x; i < padded; i += blockDim.x) s.d[i] = i < mv.P ? mv.delta[i] : 0;
 }
 
+// ---- 16-lane searches of the inference / autograd kernels ------------------------------------------------------------------
+// what a kernel stages for them: the probe deltas, and -- for the walk over the window's cell directory -- the directory's
+// block-staged part and one hit list per query group of the block
+struct SearchLds : DeltaLds {
+  CellLds cl;
+  int list[CLID_QPB][kCdHits];
+};
+__device__ __forceinline__ void stage_delta(SearchLds& s, const clid_map_view& mv) {
+  stage_delta(static_cast<DeltaLds&>(s), mv);
+  stage_cells(s.cl, mv, true);
+}
+
+// K winners of the group's sorted per-lane lists, replicated over the group.  Candidates carry their probe / hit index above the
+// id (kProbeShift); of several lanes holding the same distance the lowest index wins: the order of a STABLE sort of the
+// reference's dist2 row (np.py:607-609, whose torch.sort leaves the order of equal distances undefined).
+__device__ __forceinline__ void select_topk16(Cand& c, int lane16, int gbase, TopK& out) {
+#pragma unroll
+  for (int k = 0; k < CLID_K; ++k) {
+    const float head = c.d[0];
+    const float m = group_min(head);
+    const bool mine = (head == m) && (c.j[0] >= 0);
+    const unsigned long long b = __ballot(mine);
+    const unsigned gb = (unsigned)(b >> gbase) & 0xFFFFu;
+    int owner = gb ? (__ffs(gb) - 1) : 0;
+    if (__any((gb & (gb - 1u)) != 0u)) {  // rare: the same distance on several lanes
+      int key = mine ? (c.j[0] >> kProbeShift) : 0x7fffffff;
+      int kmin = key;
+      kmin = min(kmin, __builtin_amdgcn_update_dpp(0x7fffffff, kmin, 0x128, 0xF, 0xF, false));
+      kmin = min(kmin, __builtin_amdgcn_update_dpp(0x7fffffff, kmin, 0x124, 0xF, 0xF, false));
+      kmin = min(kmin, __builtin_amdgcn_update_dpp(0x7fffffff, kmin, 0x122, 0xF, 0xF, false));
+      kmin = min(kmin, __builtin_amdgcn_update_dpp(0x7fffffff, kmin, 0x121, 0xF, 0xF, false));
+      const unsigned long long b2 = __ballot(mine && key == kmin);
+      const unsigned g2 = (unsigned)(b2 >> gbase) & 0xFFFFu;
+      owner = g2 ? (__ffs(g2) - 1) : 0;
+    }
+    const int wj = __shfl(c.j[0], gbase + owner, 64);
+    out.d2[k] = gb ? m : 9e3f;  // np.py:606
+    out.j[k] = gb ? (wj & ((1 << kProbeShift) - 1)) : -1;
+    if (gb && lane16 == owner) c.pop();
+  }
+}
+
 // Search the P probe cells of one query (x,y,z) with the 16 lanes of a group and select the K
 // nearest valid neighbours, ascending (np.py:971-1030 + 595-612).  All probe loads of a chunk are
 // issued before any is consumed (the dependent chain is bucket -> position, not 6x that).
-__device__ __forceinline__ void search_topk(const clid_map_view& mv, const DeltaLds& dl, float x, float y,
-                                            float z, int lane16, int gbase, TopK& out, int tm = -100) {
+__device__ __forceinline__ void search_topk_probe(const clid_map_view& mv, const DeltaLds& dl, float x, float y,
+                                                  float z, int lane16, int gbase, TopK& out, int tm = -100) {
   const int4* __restrict__ tab = reinterpret_cast<const int4*>(mv.tab);
   const int B = mv.buffer_size;
   const int r0 = base_slot(x, y, z, mv.resolution, B);
@@ -187,22 +268,16 @@ __device__ __forceinline__ void search_topk(const clid_map_view& mv, const Delta
   c.init();
   int nvalid = 0;
   const float4* __restrict__ tpos = reinterpret_cast<const float4*>(mv.tab_pos);
-  // lane l owns the contiguous probes [R l, R (l + 1)), R = ceil(P / 16), in ascending order: with the strict < of the insert
-  // and the lowest lane winning ties in the selection below, equal distances are resolved by probe index -- a stable sort
-  // of the reference's dist2 row (np.py:607-609, whose torch.sort leaves the order of equal distances undefined)
-  const int R = (mv.P + CLID_G - 1) / CLID_G;
-  const int obase = R * lane16;
-  for (int o0 = 0; o0 < R; o0 += kProbesPerLane) {
+  for (int o0 = 0; o0 < mv.P; o0 += kProbeChunk) {
     int slot[kProbesPerLane];
     unsigned home[kProbesPerLane];
     int4 bk[kProbesPerLane];
 #pragma unroll
     for (int t = 0; t < kProbesPerLane; ++t) {
-      const int o = obase + o0 + t;
-      const bool in = (o0 + t < R) && (o < mv.P);
-      int sl = r0 + dl.d[in ? o : 0];
+      const int o = o0 + t * CLID_G + lane16;
+      int sl = r0 + dl.d[o];
       if (sl >= B) sl -= B;
-      slot[t] = in ? sl : -2;  // -2 never matches a key
+      slot[t] = (o < mv.P) ? sl : -2;  // -2 never matches a key
       home[t] = tab_home(sl, mv.log2cap);
       bk[t] = tab[slot[t] != -2 ? home[t] : 0];
     }
@@ -229,26 +304,106 @@ __device__ __forceinline__ void search_topk(const clid_map_view& mv, const Delta
       const float ax = fsub(pp[t].x, x), ay = fsub(pp[t].y, y), az = fsub(pp[t].z, z);
       const float d2 = fadd(fadd(fmul(ax, ax), fmul(ay, ay)), fmul(az, az));
       if (cell[t] >= 0 && !(d2 > mv.max_valid_dist2)) {  // np.py:1016-1020
-        c.insert(d2, __float_as_int(pp[t].w));
+        c.insert(d2, __float_as_int(pp[t].w) | ((o0 + t * CLID_G + lane16) << kProbeShift));
         ++nvalid;
       }
     }
   }
   out.nn = group_sum_i(nvalid);
   CLID_STAMP(tm + 3);
+  select_topk16(c, lane16, gbase, out);
+}
+
+// The same over the window's cell directory (csrc/celldir.hip; the 8-lane form with the commentary: csrc/train.hip
+// search_cells): lane l takes the stencil rows 2 l, 2 l + 1 -- one 8-byte load per row --, the group numbers the hits in probe
+// order with one 16-lane scan, expands the rows' rank ranges into its LDS list, and every lane takes the hits l, l + 16, ...:
+// one position load + distance + insert per HIT.  (rx, ry) = cell - origin, rz0 = cell_z - origin_z - nc, in range.
+__device__ __forceinline__ void search_topk_cells(const clid_map_view& mv, const CellLds& cl, int* __restrict__ list, float x, float y,
+                                                  float z, int rx, int ry, int rz0, int lane16, int gbase, TopK& out) {
+  const uint2* __restrict__ words = reinterpret_cast<const uint2*>(mv.cdir_words);
+  const float4* __restrict__ cpos = reinterpret_cast<const float4*>(mv.cdir_pos);
+  const int sh = rz0 & 31;
+  const int qbase = (rx * cl.ny + ry) * cl.nzw + (rz0 >> 5);
+  const unsigned low = (1u << sh) - 1u;
+  int4 rw[2];
+  uint2 e[2];
 #pragma unroll
-  for (int k = 0; k < CLID_K; ++k) {
-    const float head = c.d[0];
-    const float m = group_min(head);
-    const bool mine = (head == m) && (c.j[0] >= 0);
-    const unsigned long long b = __ballot(mine);
-    const unsigned gb = (unsigned)(b >> gbase) & 0xFFFFu;
-    int owner = gb ? (__ffs(gb) - 1) : 0;
-    const int wj = __shfl(c.j[0], gbase + owner, 64);
-    out.d2[k] = gb ? m : 9e3f;  // np.py:606
-    out.j[k] = gb ? wj : -1;
-    if (gb && lane16 == owner) c.pop();
+  for (int t = 0; t < 2; ++t) {
+    rw[t] = cl.row[2 * lane16 + t];
+    e[t] = make_uint2(0u, 0u);
+    if (rw[t].y) e[t] = words[qbase + rw[t].x];
   }
+  int rf[2], cnt[2], n_l = 0;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const unsigned a = __builtin_amdgcn_alignbit(e[t].y >> 24, e[t].x, (unsigned)sh);
+    cnt[t] = __popc(a & (unsigned)rw[t].y);
+    rf[t] = (int)(e[t].y & 0xFFFFFFu) + __popc(e[t].x & low) + __popc(a & (unsigned)rw[t].z);
+    n_l += cnt[t];
+  }
+  int incl = n_l;  // inclusive sum over the lanes 0 .. lane16 of the group (a DPP row: row_shr shifts zeros in)
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);
+  const int H = group_sum_i(n_l);
+  int p = incl - n_l;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+      if (k < cnt[t]) list[p + k] = rf[t] + k;
+    p += cnt[t];
+  }
+  wave_lds_fence();
+  int hmax = max(H, __shfl_xor(H, 16, 64));
+  hmax = max(hmax, __shfl_xor(hmax, 32, 64));
+  const int trips = (__builtin_amdgcn_readfirstlane(hmax) + 31) >> 5;  // two hits per lane and trip
+  Cand c;
+  c.init();
+  int nvalid = 0;
+  for (int i0 = 0; i0 < trips; ++i0) {
+    float4 pp[2];
+    int g[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      g[t] = lane16 + 16 * (2 * i0 + t);
+      const bool ok = g[t] < H;
+      pp[t] = cpos[ok ? list[ok ? g[t] : 0] : 0];
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float ax = fsub(pp[t].x, x), ay = fsub(pp[t].y, y), az = fsub(pp[t].z, z);
+      const float d2 = fadd(fadd(fmul(ax, ax), fmul(ay, ay)), fmul(az, az));
+      if (g[t] < H && !(d2 > mv.max_valid_dist2)) {  // np.py:1016-1020
+        c.insert(d2, __float_as_int(pp[t].w) | (g[t] << kProbeShift));
+        ++nvalid;
+      }
+    }
+  }
+  out.nn = group_sum_i(nvalid);
+  select_topk16(c, lane16, gbase, out);
+  wave_lds_fence();  // (the list is free again)
+}
+
+__device__ __forceinline__ void search_topk(const clid_map_view& mv, const DeltaLds& dl, float x, float y, float z, int lane16,
+                                            int gbase, TopK& out, int tm = -100) {
+  search_topk_probe(mv, dl, x, y, z, lane16, gbase, out, tm);
+}
+// with the directory staged: walk it when the whole wave's query points lie inside its box (outside it a probe can only
+// meet a foreign collision: the probing search answers that exactly)
+__device__ __forceinline__ void search_topk(const clid_map_view& mv, SearchLds& sl, float x, float y, float z, int lane16,
+                                            int gbase, TopK& out, int tm = -100) {
+  const CellLds& cl = sl.cl;
+  const int nc = cl.nc;
+  const int rx = (int)floorf(fdiv(x, mv.resolution)) - cl.ox, ry = (int)floorf(fdiv(y, mv.resolution)) - cl.oy;
+  const int rz0 = (int)floorf(fdiv(z, mv.resolution)) - cl.oz - nc;
+  const bool inside = (unsigned)(rx - nc) < (unsigned)(cl.nx - 2 * nc) && (unsigned)(ry - nc) < (unsigned)(cl.ny - 2 * nc) &&
+                      (unsigned)rz0 < (unsigned)(cl.nz - 2 * nc);
+  if (cl.valid && !__any(!inside))
+    search_topk_cells(mv, cl, sl.list[(threadIdx.x >> 4) % CLID_QPB], x, y, z, rx, ry, rz0, lane16, gbase, out);
+  else
+    search_topk_probe(mv, sl, x, y, z, lane16, gbase, out, tm);
 }
 
 // IDW weights (np.py:688-706): w_k = valid_k/(d2_k+eps) normalised; all zero when no neighbour.
@@ -318,7 +473,8 @@ __device__ __forceinline__ void stage_mlp(MlpLds& s, const float* W1, const floa
   __syncthreads();
 }
 // weights + probe deltas with ONE barrier
-__device__ __forceinline__ void stage_mlp_and_delta(MlpLds& s, DeltaLds& dl, const clid_map_view& mv,
+template <class SearchState>
+__device__ __forceinline__ void stage_mlp_and_delta(MlpLds& s, SearchState& dl, const clid_map_view& mv,
                                                     const float* W1, const float* b1, const float* W2,
                                                     const float* b2) {
   stage_delta(dl, mv);

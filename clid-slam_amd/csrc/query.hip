@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(CLID_BLOCK)
 k_query_fwd(clid_map_view mv, const float* __restrict__ x, int N, int weighted_first,
             float* __restrict__ feat_out, float* __restrict__ w_out, int* __restrict__ idx_out,
             int* __restrict__ nn_out, float* __restrict__ cert_out) {
-  __shared__ DeltaLds dl;
+  __shared__ SearchLds dl;
   stage_delta(dl, mv);
   __syncthreads();
   const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48;
@@ -237,7 +237,7 @@ struct PointEval {  // replicated across the 16 lanes of the group
   int nn;
 };
 // query (training_mode=False) -> Decoder.sdf -> analytic d sdf / d x of ONE point per 16-lane group
-__device__ __forceinline__ PointEval eval_point(const clid_map_view& mv, const MlpLds& mlp, const DeltaLds& dl,
+__device__ __forceinline__ PointEval eval_point(const clid_map_view& mv, const MlpLds& mlp, SearchLds& dl,
                                                 float scale, float px, float py, float pz, int lane16, int gbase) {
   TopK t;
   search_topk(mv, dl, px, py, pz, lane16, gbase, t);
@@ -316,7 +316,7 @@ __device__ __forceinline__ PointEval eval_point(const clid_map_view& mv, const M
 //   d sdf / d x = sum_k [ w_k d sdf_k / d x + sdf_k d w_k / d x ],  d sdf_k / d x = u_k[F:F+3] (the input's last 3 columns are
 //   x - p_k), u_k = scale (W2 .* act_k) W1,  d w_k / d x = w_k (abar - alpha_k) with alpha_k = 2 r_k omega_k.
 // Six decoder evaluations per point instead of one; no shipped config uses it.
-__device__ __forceinline__ PointEval eval_point_nf(const clid_map_view& mv, const MlpLds& mlp, const DeltaLds& dl,
+__device__ __forceinline__ PointEval eval_point_nf(const clid_map_view& mv, const MlpLds& mlp, SearchLds& dl,
                                                    float scale, float px, float py, float pz, int lane16, int gbase,
                                                    float* sdf_std) {
   TopK t;
@@ -383,7 +383,7 @@ k_sdf_grad_x(clid_map_view mv, const float* W1, const float* b1, const float* W2
              float scale, const float* __restrict__ x, int N, float* __restrict__ sdf_out,
              float* __restrict__ grad_out, int* __restrict__ nn_out, float* __restrict__ cert_out) {
   __shared__ MlpLds mlp;
-  __shared__ DeltaLds dl;
+  __shared__ SearchLds dl;
   stage_mlp_and_delta(mlp, dl, mv, W1, b1, W2, b2);
   const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48;
   const int q_raw = blockIdx.x * CLID_QPB + (threadIdx.x >> 4);
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(CLID_BLOCK)
 k_sdf_query(clid_map_view mv, const float* W1, const float* b1, const float* W2, const float* b2, float scale,
             const float* __restrict__ x, int N, float* __restrict__ sdf_out, int* __restrict__ nn_out) {
   __shared__ MlpLds mlp;
-  __shared__ DeltaLds dl;
+  __shared__ SearchLds dl;
   stage_mlp_and_delta(mlp, dl, mv, W1, b1, W2, b2);
   const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48;
   const int my_k = lane16 >> 1;
@@ -491,7 +491,7 @@ k_track_model(clid_map_view mv, const float* W1, const float* b1, const float* W
               const float* __restrict__ pc_imu, int N, float* __restrict__ sdf_out, float* __restrict__ grad_out,
               float* __restrict__ pmap_out, int* __restrict__ valid_out, double* __restrict__ normal_eq /* 28 */) {
   __shared__ MlpLds mlp;
-  __shared__ DeltaLds dl;
+  __shared__ SearchLds dl;
   __shared__ double red[CLID_QPB][28];
   stage_mlp_and_delta(mlp, dl, mv, W1, b1, W2, b2);
   const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48, grp_in_block = threadIdx.x >> 4;

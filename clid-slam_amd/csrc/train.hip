@@ -21,11 +21,6 @@ namespace clid {
 // All six finite-difference SDFs of a bundle therefore live in one wave, so the eikonal term, its
 // backward, the BCE term and the decoder / feature gradients are produced without a grid-wide hand-off
 // and without writing per-query state to HBM.
-__device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 #ifndef CLID_FUSED_WAVES
 #define CLID_FUSED_WAVES 4
@@ -93,7 +88,6 @@ __device__ __forceinline__ int match_base(const WaveLds& wl, int j) {
 #define CLID_PROBE_ROWS 6
 #endif
 constexpr int kProbeRows8 = CLID_PROBE_ROWS;  // probes per lane per chunk; chunk = 8 * rows slots
-constexpr int kProbeShift = 22;  // search8's candidates: local id (< 2^22) | probe index (< 384 = kMaxProbes) << 22
 
 // Per-lane sorted candidate list of DEPTH entries.  The 81 probes of a query are spread over 8 lanes, so a lane
 // almost never owns more than 3 of the 6 winners: the throughput (search-only) kernel runs with DEPTH = 3 -- half
@@ -250,35 +244,6 @@ __device__ __forceinline__ bool search8(const clid_map_view& mv, const DeltaLds&
 #ifndef CLID_CD_WAVES_TILES
 #define CLID_CD_WAVES_TILES 6
 #endif
-constexpr int kCdRows = 32;  // staged stencil rows: (2 nc + 1)^2 <= 25 for nc <= 2, the rest empty
-constexpr int kCdHits = 88;  // list entries per query slot (>= 81 probes)
-struct CellLds {
-  int4 row[kCdRows];  // per (dx, dy) row: word offset (dx ny + dy) nzw | stencil bits along z | bits below the first stencil bit | -
-  int ox, oy, oz, nx, ny, nz, nzw, valid, nc;
-};
-__device__ __forceinline__ void stage_cells(CellLds& cl, const clid_map_view& mv, bool want) {
-  const bool have = want && mv.cdir_hdr && mv.cdir_words && mv.cdir_pos && mv.stencil_rows && mv.stencil_nc >= 1 && mv.stencil_nc <= 2;
-  const int nc = have ? mv.stencil_nc : 1, S = 2 * nc + 1;
-  if (threadIdx.x < kCdRows) {
-    const int r = threadIdx.x;
-    int4 e = make_int4(0, 0, 0, 0);
-    if (have && r < S * S) {
-      const int dx = r / S - nc, dy = r % S - nc;
-      const unsigned zm = mv.stencil_rows[r];
-      e.x = (dx * mv.cdir_hdr[4] + dy) * mv.cdir_hdr[6];
-      e.y = (int)zm;
-      e.z = (int)((zm & (0u - zm)) - 1u);
-    }
-    cl.row[r] = e;
-  }
-  if (threadIdx.x == 0) {
-    cl.ox = have ? mv.cdir_hdr[0] : 0; cl.oy = have ? mv.cdir_hdr[1] : 0; cl.oz = have ? mv.cdir_hdr[2] : 0;
-    cl.nx = have ? mv.cdir_hdr[3] : 0; cl.ny = have ? mv.cdir_hdr[4] : 0; cl.nz = have ? mv.cdir_hdr[5] : 0;
-    cl.nzw = have ? mv.cdir_hdr[6] : 0;
-    cl.valid = have ? mv.cdir_hdr[8] : 0;
-    cl.nc = nc;
-  }
-}
 // inclusive sum over the lanes 0 .. lane8 of an 8-lane group (row_shr never reaches across the group: guarded by lane8)
 __device__ __forceinline__ int group8_scan_i(int v, int lane8) {
   int t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);

@@ -765,6 +765,9 @@ class NeuralPoints(nn.Module):
             n = ids.shape[0]
         else:
             ids, n = None, self.count()
+        if n >= (1 << 22):
+            raise NotImplementedError(f"{n} points in one table: the searches address at most 2^22 (their candidates carry the "
+                                      "probe index next to the id)")
         log2cap = max(5, int(math.ceil(math.log2(max(2 * n, 32)))))  # 4-key buckets, <= 0.5 keys per bucket
         tab = torch.empty((1 << log2cap, 4), device=pts.device, dtype=torch.int32)
         tab_pos = torch.zeros((1 << log2cap, 4, 4), device=pts.device, dtype=torch.float32)
@@ -786,7 +789,7 @@ class NeuralPoints(nn.Module):
             "clid_table_build",
         )
         cdir = None
-        if locally and os.environ.get("CLID_CELLDIR", "1") != "0":
+        if n > 0 and os.environ.get("CLID_CELLDIR", "1") != "0":  # (the global map too: dense inference for meshing walks it)
             # cell directory of the window (csrc/celldir.hip): occupancy bits + ranks over the bounding box of its points,
             # sized on the device against these capacities (no read-back); cached buffers, they grow with the window
             words_cap = max(1 << 18, 16 * n)

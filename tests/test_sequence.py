@@ -112,7 +112,10 @@ def test_subt_sequence_harness_first_frames_vs_oracle(freeze_after):
     assert [c["frozen"] for c in checks] == ([False, True, True] if freeze_after == 1 else [False] * 3)
     for c in checks:
         assert c["teacher_forced_iters"] >= min(10, c["iters"]), c
-        assert c["max_dloss"] <= 2e-5 and c["max_probe_dloss"] <= 2e-5, c
+        # losses: teacher-forced (same parameters on both sides) at the strict bar; the free-running trajectory's losses are a
+        # secondary report like its parameters -- eps = 1e-15 sign chaos moves single entries by +-lr per step
+        assert c["max_probe_dloss"] <= 2e-5, (c["frame"], c["max_probe_dloss"])
+        assert c["max_dloss"] <= 2e-4, (c["frame"], c["max_dloss"], c.get("max_dtheta"), c.get("n_dtheta_gt_1e4"), c.get("max_ddecoder"))
         for t, r in enumerate(c["teacher_forced"]):
             # every gradient entry of every iteration at the 1e-4 relative bar (no eps = 1e-15 amplification in a
             # gradient); rows the oracle leaves at exactly zero are zero here too, up to a handful of gathered rows whose
