@@ -770,7 +770,7 @@ class NeuralPoints(nn.Module):
                                       "probe index next to the id)")
         log2cap = max(5, int(math.ceil(math.log2(max(2 * n, 32)))))  # 4-key buckets, <= 0.5 keys per bucket
         tab = torch.empty((1 << log2cap, 4), device=pts.device, dtype=torch.int32)
-        tab_pos = torch.zeros((1 << log2cap, 4, 4), device=pts.device, dtype=torch.float32)
+        tab_pos = torch.empty((1 << log2cap, 4, 4), device=pts.device, dtype=torch.float32)  # (only the rows of stored keys are ever used)
         pos4 = torch.empty((max(n, 1), 4), device=pts.device, dtype=torch.float32)
         # probe prefilter (one-hash Bloom filter over the stored slots), 8 bits per key: up to 2^18 bits (32 KB) the chunked
         # search kernel keeps it in LDS next to its other state; larger local maps get a filter of up to 2^24 bits (2 MB)
@@ -800,7 +800,7 @@ class NeuralPoints(nn.Module):
                 wc, hc = int(words_cap * 1.5), int(hits_cap * 1.5)
                 bufs = pool[slot] = (wc, hc, torch.empty((wc + 1, 2), device=pts.device, dtype=torch.int32),
                                      torch.empty((hc, 4), device=pts.device, dtype=torch.float32),
-                                     torch.empty((wc // 256 + 2,), device=pts.device, dtype=torch.int32))
+                                     torch.empty((wc // 32 + 2,), device=pts.device, dtype=torch.int32))
             hdr = torch.empty((16,), device=pts.device, dtype=torch.int32)  # (per table: a cached table keeps its own header)
             _lib.check(
                 lib.clid_cdir_build(_lib.ptr(pos4), n, _lib.ptr(tab), _lib.ptr(tab_pos), log2cap, _lib.ptr(filt), log2filter,

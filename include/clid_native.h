@@ -95,7 +95,7 @@ typedef struct clid_map_view {
  * A probe of cell c in the reference is buffer_pt_index[hash(c) mod B] -> travel-distance filter -> global2local
  * (model/neural_points.py:984-1009, 595-598), 81 times per query, and 3 of 4 probes find nothing.  Which cells yield a
  * local point does not depend on the query, so it is resolved once per table: over the bounding box of the window's points
- * (+ 4 cells) one bit per voxel = "the reference's chain for this cell's slot yields a local id >= 0" -- evaluated by
+ * (+ a margin) one bit per voxel = "the reference's chain for this cell's slot yields a local id >= 0" -- evaluated by
  * looking the cell's slot up in the compact table, so a point returned by a foreign colliding cell, a point shadowed in its
  * slot and the same point returned by two cells are all reproduced exactly -- plus, per 32 z-adjacent cells, the rank of the
  * word's first hit in `cdir_pos`, the (x, y, z, id) rows of all hits in cell order (x-major, then y, then z: the probe order
@@ -105,10 +105,10 @@ typedef struct clid_map_view {
  * says whether the window fitted; the searches fall back to probing the table itself when it did not, and for query points
  * farther than nc cells outside the box (whose probes can only meet foreign collisions).
  *   hdr_out    [CLID_CDIR_HDR_INTS] i32, words_out [words_cap + 1][2] u32, pos_out [hits_cap][4] f32,
- *   scratch    [words_cap / 256 + 2] i32 (block sums of the rank scan)
+ *   scratch    [words_cap / 32 + 2] i32 (hit counts per 32 words: the rank scan)
  *   pos4 / n   the window's points (clid_table_build's pos4_out), tab / tab_pos / filter: its table */
 #define CLID_CDIR_HDR_INTS 16
-#define CLID_CDIR_MARGIN 4
+#define CLID_CDIR_MARGIN_XY 8  /* cells around the points' box along x and y (along z: >= 2, whatever the column's words leave) */
 int clid_cdir_build(const float* pos4, int32_t n, const int32_t* tab, const float* tab_pos, int32_t log2cap,
                     const uint32_t* filter, int32_t log2filter, int64_t buffer_size, float resolution, int32_t* hdr_out,
                     uint32_t* words_out, int64_t words_cap, float* pos_out, int64_t hits_cap, int32_t* scratch, void* stream);

@@ -56,7 +56,9 @@ def test_directory_is_the_probe_chain_cell_by_cell(time_filtering):
     (ox, oy, oz), (nx, ny, nz) = d["o"], d["n"]
     pts = nm.local_neural_points.cpu().numpy()
     cell = np.floor(pts / np.float32(cfg.voxel_size_m)).astype(np.int64)
-    assert (cell.min(0) - 4 == np.array([ox, oy, oz])).all() and (cell.max(0) + 5 == np.array([ox + nx, oy + ny, oz + nz])).all()
+    lo, hi = cell.min(0), cell.max(0)
+    assert ox == lo[0] - 8 and oy == lo[1] - 8 and ox + nx == hi[0] + 9 and oy + ny == hi[1] + 9  # margins: 8 cells in x / y,
+    assert nz % 32 == 0 and oz <= lo[2] - 2 and oz + nz >= hi[2] + 3                             # >= 2 in z (whole words)
     gx, gy, gz = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
     cells = np.stack((gx + ox, gy + oy, gz + oz), -1).reshape(-1, 3).astype(np.int64)
     want = _chain(nm, cells, time_filtering).reshape(nx, ny, nz)
@@ -184,7 +186,7 @@ def test_window_beyond_the_capacity_falls_back_to_probing():
     view, keep = nm._map_view(True)
     (tab, tab_pos, filt, log2filter), pos4, log2cap = nm._table(True, True)
     cdir = keep[8]
-    scratch = torch.zeros(64, device="cuda", dtype=torch.int32)
+    scratch = torch.zeros(64, device="cuda", dtype=torch.int32)  # (words_cap / 32 + 2 entries)
     _lib.check(_lib.load().clid_cdir_build(pos4.data_ptr(), pos4.shape[0], tab.data_ptr(), tab_pos.data_ptr(), log2cap, filt.data_ptr(),
                                            log2filter, int(nm.buffer_size), float(nm.resolution), cdir[0].data_ptr(), cdir[1].data_ptr(),
                                            256, cdir[2].data_ptr(), cdir[2].shape[0], scratch.data_ptr(), _lib.stream()), "clid_cdir_build")

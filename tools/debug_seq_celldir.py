@@ -28,3 +28,13 @@ for t in bad[:4].tolist():
             print(" task", t, "slot", sl, "x", x, "cell", c, "H", sum(v >= 0 for v in ch), "\n   dir ", wa[:6, 0].tolist(), wa[:6, 1].contiguous().view(torch.int32).tolist(),
                   "\n   prob", wb[:6, 0].tolist(), wb[:6, 1].contiguous().view(torch.int32).tolist())
             break
+# which query points fall outside the box (they defer their task to the probing launch)?
+S = mp.pool_sample_count
+q = mp.global_coord_pool[torch.randint(0, S, (200000,), device="cuda")].cpu().numpy()
+cell = np.floor(q / np.float32(cfg.voxel_size_m)).astype(np.int64)
+o, n = np.array(d["o"]), np.array(d["n"])
+rel = cell - o
+for margin_extra in (0, 4, 8, 12):
+    lo = 2 - margin_extra
+    out = (rel < lo) | (rel >= n - 2 + margin_extra)
+    print("extra margin", margin_extra, "fraction of samples outside", out.any(1).mean(), "per axis", out.mean(0))
