@@ -123,7 +123,7 @@ def cpu_baseline(cfg, nm, dec, mp, bs, budget_s=15.0, max_iters=400):
     }
 
 
-def kernel_report(lib, mp, steps, bs_local, decim, M, decode_variant):
+def kernel_report(lib, mp, steps, bs_local, decim, M, decode_variant, analytic=False):
     """Profiled pass: average dispatch duration per kernel + roofline fraction on the section-8(d) bytes."""
     from clid_slam_amd import _lib
 
@@ -142,7 +142,12 @@ def kernel_report(lib, mp, steps, bs_local, decim, M, decode_variant):
     hoisted = out[1] > 0.0
     n_tasks_est = int(lib.clid_train_search_tasks(bs_local, 0, decim, 1))  # <= 2048 tiles: the launch that also numbers the tiles
     dname = {0: "k_train_fused8<2> (decode, 16 lanes/query)", 1: "k_decode_tile<fp32 MFMA>", 2: "k_decode_tile<bf16 MFMA>"}[decode_variant]
-    rows = [
+    if analytic:  # loss.numerical_grad_on: False -- one launch per iteration: search + decode + analytic d sdf / d x + backward through it
+        rows = [("k_train_analytic (search + decode + analytic eikonal, 16 lanes/query)", out[0] / iters, bs_local * 1860.0,
+                 "1860 B/sample (SURVEY 8d: 1440 per query fwd+bwd + 24 pool gather + 12 gradient write + 384 second-order feature-gradient pass) x %d samples" % bs_local),
+                ("k_adam_all", out[3] / iters, B_ADAM_ROW * (M + 1) + 833 * B_ADAM_PARAM, "256 B/row x %d rows + 28 B x 833" % (M + 1))]
+    else:
+      rows = [
         (dname if hoisted else "k_train_fused8<0> (search+decode)", out[0] / iters,
          Q * (B_DECODE_FWD_Q + B_BWD_Q) if hoisted else Q * (B_SEARCH_Q + B_DECODE_FWD_Q + B_BWD_Q) + bs_local * B_POOL_SAMPLE,
          "752 B/query (316 fwd after the search + 436 bwd) x %d query points" % Q if hoisted else "1440 B/query + 24 B/sample"),
@@ -174,6 +179,8 @@ def main():
     ap.add_argument("--decode", type=int, default=None, choices=(0, 1, 2), help="override the decode kernel (clid_train_args.decode_variant)")
     ap.add_argument("--frame-calls", type=int, default=100, help="repetitions of mapping(10) for the per-frame regime (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--analytic", action="store_true",
+                    help="loss.numerical_grad_on: False (utils/mapper.py:695-696): analytic d sdf / d x on EVERY sample, backward through it")
     ap.add_argument("--layer-norm", action="store_true", help="layer_norm_on: True (run_SubT_MRS.yaml:27) instead of the ncd128 default")
     ap.add_argument("--freeze-decoder", action="store_true",
                     help="steady-state variant: decoder frozen (freeze_model, slam.py:193-196); not the headline config")
@@ -225,6 +232,8 @@ def main():
 
     cfg = HotPathConfig()  # == config/run_ncd128.yaml resolved values (SURVEY.md section 8 header)
     cfg.layer_norm_on = bool(args.layer_norm)
+    if args.analytic:
+        cfg.numerical_grad, cfg.gradient_decimation = False, 1
     cfg.device = device
     if wl["scaling"] == "strong":
         if wl["bs"] % world:
@@ -349,7 +358,7 @@ def main():
     kernels, roof = None, None
     prof_steps = min(args.steps, 100)
     if rank == 0:
-        kernels, n_prof = kernel_report(lib, mp, prof_steps, bs_local, decim, M, wl["decode"])
+        kernels, n_prof = kernel_report(lib, mp, prof_steps, bs_local, decim, M, wl["decode"], analytic=args.analytic)
     else:
         mp.mapping(prof_steps)  # every rank takes part (the loop contains collectives when world > 1)
     if rank == 0:
@@ -389,7 +398,7 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": wl["scaling"], "vs_baseline": None,
             "dtype": wl["dtype"], "data": "synthetic",
             "config": {
-                "workload": f"{args.config}: {wl['what']}; numerical eikonal (decimation {decim}), Adam; synthetic box-room "
+                "workload": f"{args.config}: {wl['what']}; {'analytic eikonal on every sample' if args.analytic else f'numerical eikonal (decimation {decim})'}, Adam; synthetic box-room "
                             "Ouster-128 scan",
                 "bs_per_gpu": bs_local, "global_batch": bs_global, "decoder_frozen": bool(args.freeze_decoder), "layer_norm_on": bool(args.layer_norm),
                 "decode_kernel": wl["decode"], "query_points_per_step_per_gpu": bs_local + 6 * ((bs_local + decim - 1) // decim),

@@ -19,7 +19,7 @@ namespace clid {
 __global__ void __launch_bounds__(CLID_BLOCK, 3)
 k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, int n_rounds) {
   __shared__ MlpLds mlp;
-  __shared__ DeltaLds dl;
+  __shared__ SearchLds dl;  // (+ the window's cell directory: the search walks it, common.hpp search_topk)
   __shared__ float red[(CLID_BLOCK / 64) * kRedFloats];
   stage_mlp_and_delta(mlp, dl, mv, ta.W1, ta.b1, ta.W2, ta.b2);
   const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48, grp = lane >> 4;
