@@ -43,6 +43,23 @@ def timed(fn, reps, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
+def timed_device(fn, reps, warm=3):
+    """Seconds of DEVICE time per call: the launches queue up behind a spin kernel, so the span between the two events is the
+    kernels back to back -- what a caller that iterates the model (5-20 evaluations per scan) sees once its host side keeps up,
+    and what `timed` hides when the Python glue of one call (view, ctypes, a 28-double fill) is longer than the kernel."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(int(2.0e7))  # ~10 ms of spinning: time to enqueue everything below
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
 def sampler_row(cfg, args):
     """N2: one Ouster-128-like scan (box room) through the raw-point map update, the fused sampler launch and
     the whole Mapper.process_frame."""
@@ -149,18 +166,22 @@ def main():
     n1 = pc_imu.shape[0]
     t1a = timed(lambda: tracking._launch(nm, dec, cfg, rot, sensor, pc_imu, False, True), 200, warm=50)
     t1b = timed(lambda: tracking._launch(nm, dec, cfg, rot, sensor, pc_imu, True, False), 200, warm=10)
+    rot_d, pos_d = rot.to(dev), sensor.to(dev)  # the filter's state as device tensors (utils/error_state_iekf.py:176-186)
+    t1c = timed_device(lambda: tracking._launch(nm, dec, cfg, rot_d, pos_d, pc_imu, False, True), 100, warm=10)
+    t1d = timed_device(lambda: tracking._launch(nm, dec, cfg, rot_d, pos_d, pc_imu, True, False), 100, warm=10)
     S, b, n_valid = tracking.normal_equations(nm, dec, cfg, rot, sensor, pc_imu)
     alg1 = n1 * (12.0 + BYTES_SEARCH + BYTES_FEAT + 4.0)
     line1 = {
         "row": "N1", "metric": "tracking measurement-model points/sec (IEKFOM.h_model, fused normal equations)",
         "value": n1 / t1a, "unit": "points/s", "n_gpus": 1, "us_per_call_normal_equations": 1e6 * t1a,
-        "us_per_call_per_point_outputs": 1e6 * t1b, "dtype": "f32 (f64 reduction)", "data": "synthetic",
+        "us_per_call_per_point_outputs": 1e6 * t1b, "us_per_call_device": 1e6 * t1c, "us_per_call_device_per_point_outputs": 1e6 * t1d, "dtype": "f32 (f64 reduction)", "data": "synthetic",
         "config": {"workload": "box-room map of bench.py, local map view, one IEKF iteration", "points": n1,
                    "valid_points": n_valid},
         "roofline": {"bound": "hbm", "kernel": "k_track_model", "achieved": alg1 / t1a / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": alg1 / t1a / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "note": "a few-thousand-point launch is latency-bound (one wave-latency long); host time per "
-                             "call includes the 9+3 float pose upload by value"},
+                     "note": "value / frac: wall clock per Python call (view + ctypes + a 28-double fill + the launch: host-bound); "
+                             "us_per_call_device: the launches back to back on the device, pose read from device tensors "
+                             "(clid_track_model_dev; incl. the two 12-float conversions and the fill)"},
     }
 
     # ---- N3: dense inference over points scattered through the mapped volume

@@ -103,6 +103,8 @@ _SIGS = {
     "clid_sdf_query": (C.c_int, [C.POINTER(MapView), _vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _vp, _vp]),
     "clid_track_model": (C.c_int, [C.POINTER(MapView), _vp, _vp, _vp, _vp, _f32, C.POINTER(_f32), C.POINTER(_f32), _i32,
                          _f32, _f32, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clid_track_model_dev": (C.c_int, [C.POINTER(MapView), _vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32,
+                         _f32, _f32, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clid_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _f32, _i32, _vp, _i32, _f32, _vp, _vp, _vp, _vp]),
     "clid_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _i32, _vp]),
     "clid_train_workspace_floats": (_i64, [_i32, _i32, _i32]),

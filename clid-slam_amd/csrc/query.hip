@@ -489,11 +489,18 @@ struct TrackParams {
 __global__ void __launch_bounds__(CLID_BLOCK)
 k_track_model(clid_map_view mv, const float* W1, const float* b1, const float* W2, const float* b2, TrackParams tp,
               const float* __restrict__ pc_imu, int N, float* __restrict__ sdf_out, float* __restrict__ grad_out,
-              float* __restrict__ pmap_out, int* __restrict__ valid_out, double* __restrict__ normal_eq /* 28 */) {
+              float* __restrict__ pmap_out, int* __restrict__ valid_out, double* __restrict__ normal_eq /* 28 */,
+              const float* __restrict__ rot_dev, const float* __restrict__ pos_dev) {
   __shared__ MlpLds mlp;
   __shared__ SearchLds dl;
   __shared__ double red[CLID_QPB][28];
   stage_mlp_and_delta(mlp, dl, mv, W1, b1, W2, b2);
+  if (rot_dev) {  // the pose read on the device (uniform loads): no host round trip in front of the launch
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tp.R[i] = rot_dev[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tp.t[i] = pos_dev[i];
+  }
   const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48, grp_in_block = threadIdx.x >> 4;
   const int q_raw = blockIdx.x * CLID_QPB + grp_in_block;
   const bool live = q_raw < N;
@@ -537,7 +544,9 @@ k_track_model(clid_map_view mv, const float* W1, const float* b1, const float* W
     double s = 0.0;
 #pragma unroll
     for (int g = 0; g < CLID_QPB; ++g) s += red[g][threadIdx.x];
-    if (s != 0.0) atomicAdd(&normal_eq[threadIdx.x], s);
+    // CLID_TRACK_COPIES line-separated copies of the 28 sums, block b adds to copy b mod 16: atomics on one cache line retire
+    // one after the other (512 blocks x 28 adds on two lines were 8 of the launch's 19 us); the caller adds the copies up
+    if (s != 0.0) atomicAdd(&normal_eq[(blockIdx.x % CLID_TRACK_COPIES) * 32 + threadIdx.x], s);
   }
 }
 
@@ -624,20 +633,20 @@ extern "C" int clid_sdf_grad_x(const clid_map_view* mv, const float* W1, const f
   return CLID_OK;
 }
 
-extern "C" int clid_track_model(const clid_map_view* mv, const float* W1, const float* b1, const float* W2,
-                                const float* b2, float sdf_scale, const float* rot_host, const float* pos_host,
-                                int32_t min_nn, float min_grad_norm, float max_grad_norm, float max_sdf_std,
-                                const float* pc_imu, int32_t N, float* sdf_out, float* grad_out, float* pmap_out, int32_t* valid_out,
-                                double* normal_eq, void* stream) {
+static int track_model_launch(const clid_map_view* mv, const float* W1, const float* b1, const float* W2, const float* b2,
+                              float sdf_scale, const float* rot_host, const float* pos_host, const float* rot_dev,
+                              const float* pos_dev, int32_t min_nn, float min_grad_norm, float max_grad_norm, float max_sdf_std,
+                              const float* pc_imu, int32_t N, float* sdf_out, float* grad_out, float* pmap_out, int32_t* valid_out,
+                              double* normal_eq, void* stream) {
   if (int e = check_view(mv, "clid_track_model")) return e;
-  if (!rot_host || !pos_host || !pc_imu || N < 0) {
+  if (!((rot_host && pos_host) || (rot_dev && pos_dev)) || !pc_imu || N < 0) {
     clid_set_error("clid_track_model: bad argument");
     return CLID_E_ARG;
   }
   if (N == 0) return CLID_OK;
   clid::TrackParams tp;
-  for (int i = 0; i < 9; ++i) tp.R[i] = rot_host[i];
-  for (int i = 0; i < 3; ++i) tp.t[i] = pos_host[i];
+  for (int i = 0; i < 9; ++i) tp.R[i] = rot_host ? rot_host[i] : 0.f;
+  for (int i = 0; i < 3; ++i) tp.t[i] = pos_host ? pos_host[i] : 0.f;
   tp.scale = sdf_scale;
   tp.min_grad_norm = min_grad_norm;
   tp.max_grad_norm = max_grad_norm;
@@ -645,9 +654,29 @@ extern "C" int clid_track_model(const clid_map_view* mv, const float* W1, const 
   tp.max_sdf_std = max_sdf_std;
   hipLaunchKernelGGL(clid::k_track_model, dim3((N + CLID_QPB - 1) / CLID_QPB), dim3(CLID_BLOCK), 0,
                      (hipStream_t)stream, *mv, W1, b1, W2, b2, tp, pc_imu, N, sdf_out, grad_out, pmap_out, valid_out,
-                     normal_eq);
+                     normal_eq, rot_dev, pos_dev);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
+}
+
+extern "C" int clid_track_model(const clid_map_view* mv, const float* W1, const float* b1, const float* W2,
+                                const float* b2, float sdf_scale, const float* rot_host, const float* pos_host,
+                                int32_t min_nn, float min_grad_norm, float max_grad_norm, float max_sdf_std,
+                                const float* pc_imu, int32_t N, float* sdf_out, float* grad_out, float* pmap_out, int32_t* valid_out,
+                                double* normal_eq, void* stream) {
+  return track_model_launch(mv, W1, b1, W2, b2, sdf_scale, rot_host, pos_host, nullptr, nullptr, min_nn, min_grad_norm, max_grad_norm,
+                            max_sdf_std, pc_imu, N, sdf_out, grad_out, pmap_out, valid_out, normal_eq, stream);
+}
+
+// the same with the pose in DEVICE memory (rot_dev [9] row-major fp32, pos_dev [3]): the reference's filter keeps its state
+// in device tensors (utils/error_state_iekf.py:176-186), so iterating the update needs no host round trip per evaluation
+extern "C" int clid_track_model_dev(const clid_map_view* mv, const float* W1, const float* b1, const float* W2,
+                                    const float* b2, float sdf_scale, const float* rot_dev, const float* pos_dev,
+                                    int32_t min_nn, float min_grad_norm, float max_grad_norm, float max_sdf_std,
+                                    const float* pc_imu, int32_t N, float* sdf_out, float* grad_out, float* pmap_out,
+                                    int32_t* valid_out, double* normal_eq, void* stream) {
+  return track_model_launch(mv, W1, b1, W2, b2, sdf_scale, nullptr, nullptr, rot_dev, pos_dev, min_nn, min_grad_norm, max_grad_norm,
+                            max_sdf_std, pc_imu, N, sdf_out, grad_out, pmap_out, valid_out, normal_eq, stream);
 }
 
 extern "C" int clid_sdf_query(const clid_map_view* mv, const float* W1, const float* b1, const float* W2,

@@ -26,9 +26,16 @@ def _launch(neural_points, geo_decoder, config, rot, pos, pc_imu, per_point: boo
     dev = x.device
     view, keep = neural_points._map_view(True)
     W1, b1, W2, b2 = geo_decoder.flat_params()
-    # (the state lives on the device in the reference's filter: 12 numbers through the pinned landing buffer)
-    r = (C.c_float * 9)(*_lib.small_to_host(torch.as_tensor(rot).contiguous()).to(torch.float32).reshape(-1).tolist())
-    t = (C.c_float * 3)(*_lib.small_to_host(torch.as_tensor(pos).contiguous()).to(torch.float32).reshape(-1).tolist())
+    # the state lives on the device in the reference's filter (utils/error_state_iekf.py:176-186): the kernel reads the 12
+    # numbers there (clid_track_model_dev) -- two tiny conversions, no host round trip per evaluation; a host pose goes by value
+    rot, pos = torch.as_tensor(rot), torch.as_tensor(pos)
+    on_dev = rot.is_cuda and pos.is_cuda
+    if on_dev:
+        r = rot.detach().to(torch.float32).contiguous()
+        t = pos.detach().to(torch.float32).contiguous()
+    else:
+        r = (C.c_float * 9)(*rot.detach().to(torch.float32).reshape(-1).tolist())
+        t = (C.c_float * 3)(*pos.detach().to(torch.float32).reshape(-1).tolist())
     out = {}
     if per_point:
         # raw per-point outputs: a cached scratch set per (n, device) -- everything handed to the caller below is derived
@@ -41,10 +48,11 @@ def _launch(neural_points, geo_decoder, config, rot, pos, pc_imu, per_point: boo
             out = cache[(n, str(dev))] = {
                 "sdf": torch.empty(n, device=dev, dtype=torch.float32), "grad": torch.empty((n, 3), device=dev, dtype=torch.float32),
                 "pmap": torch.empty((n, 3), device=dev, dtype=torch.float32), "valid": torch.empty(n, device=dev, dtype=torch.int32)}
-    ne = torch.zeros(28, device=dev, dtype=torch.float64) if reduce else None
+    ne = torch.zeros((16, 32), device=dev, dtype=torch.float64) if reduce else None  # CLID_TRACK_COPIES partial copies of the 28 sums
+    fn = lib.clid_track_model_dev if on_dev else lib.clid_track_model
     _lib.check(
-        lib.clid_track_model(C.byref(view), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
-                             float(geo_decoder.sdf_scale), r, t, int(config.track_mask_query_nn_k),
+        fn(C.byref(view), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
+                             float(geo_decoder.sdf_scale), _lib.ptr(r) if on_dev else r, _lib.ptr(t) if on_dev else t, int(config.track_mask_query_nn_k),
                              float(config.reg_min_grad_norm), float(config.reg_max_grad_norm),
                              float(config.surface_sample_range_m * getattr(config, "max_sdf_std_ratio", 1.0)), _lib.ptr(x), n,
                              _lib.ptr(out.get("sdf")), _lib.ptr(out.get("grad")), _lib.ptr(out.get("pmap")),
@@ -76,6 +84,7 @@ def h_model(neural_points, geo_decoder, config, rot, pos, pc_imu):
 def normal_equations(neural_points, geo_decoder, config, rot, pos, pc_imu):
     """(S [18,18] f64 = H^T R_inv H, HtRz [18] f64 = H^T R_inv z, n_valid) in one launch."""
     x, _, ne = _launch(neural_points, geo_decoder, config, rot, pos, pc_imu, False, True)
+    ne = ne.sum(0)  # the kernel spreads its float64 atomics over 16 line-separated copies
     S = torch.zeros((18, 18), device=x.device, dtype=torch.float64)
     iu = torch.triu_indices(6, 6, device=x.device)
     S[iu[0], iu[1]] = ne[:21]

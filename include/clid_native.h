@@ -107,6 +107,7 @@ typedef struct clid_map_view {
  *   hdr_out    [CLID_CDIR_HDR_INTS] i32, words_out [words_cap + 1][2] u32, pos_out [hits_cap][4] f32,
  *   scratch    [words_cap / 32 + 2] i32 (hit counts per 32 words: the rank scan)
  *   pos4 / n   the window's points (clid_table_build's pos4_out), tab / tab_pos / filter: its table */
+#define CLID_TRACK_COPIES 16
 #define CLID_CDIR_HDR_INTS 16
 #define CLID_CDIR_MARGIN_XY 8  /* cells around the points' box along x and y (along z: >= 2, whatever the column's words leave) */
 int clid_cdir_build(const float* pos4, int32_t n, const int32_t* tab, const float* tab_pos, int32_t log2cap,
@@ -185,12 +186,20 @@ int clid_sdf_query(const clid_map_view* mv, const float* W1, const float* b1, co
  * p_map = R p_imu + t, sdf + analytic gradient at p_map, validity mask (nn >= min_nn, min < |g| < max, and -- with
  * mv->weighted_first == 0 -- std of the neighbours' SDFs < max_sdf_std, :217-225 / :236-241),
  * and -- when normal_eq != NULL -- the float64 sums update_iterated (:299-305) needs instead of the N x 18 H:
- *   normal_eq[0..20]  upper triangle (row-major) of the 6x6 block of S = H^T R_inv H   (+=, zero it first)
- *   normal_eq[21..26] H^T R_inv z,   normal_eq[27] number of valid points
+ *   normal_eq [CLID_TRACK_COPIES][32] float64 (+=, zero it first): 16 partial copies (one per 256 bytes; a block adds to copy
+ *   block mod 16, so the atomics do not queue on one cache line) whose SUM over the copies is
+ *     [0..20]  upper triangle (row-major) of the 6x6 block of S = H^T R_inv H,  [21..26] H^T R_inv z,  [27] number of valid points
  * rot_host [9] row-major / pos_host [3]: HOST floats (the filter state lives on the host).
  * Per-point outputs (any may be NULL): sdf [N], grad [N][3], pmap [N][3], valid [N] int32. */
 int clid_track_model(const clid_map_view* mv, const float* W1, const float* b1, const float* W2,
                      const float* b2, float sdf_scale, const float* rot_host, const float* pos_host,
+                     int32_t min_nn, float min_grad_norm, float max_grad_norm, float max_sdf_std, const float* pc_imu,
+                     int32_t N, float* sdf_out, float* grad_out, float* pmap_out, int32_t* valid_out,
+                     double* normal_eq, void* stream);
+/* the same with the pose in DEVICE memory (rot_dev [9] row-major fp32, pos_dev [3] fp32): the reference's filter keeps
+ * x.rot / x.pos in device tensors (utils/error_state_iekf.py:176-186); no host round trip in front of the launch */
+int clid_track_model_dev(const clid_map_view* mv, const float* W1, const float* b1, const float* W2,
+                     const float* b2, float sdf_scale, const float* rot_dev, const float* pos_dev,
                      int32_t min_nn, float min_grad_norm, float max_grad_norm, float max_sdf_std, const float* pc_imu,
                      int32_t N, float* sdf_out, float* grad_out, float* pmap_out, int32_t* valid_out,
                      double* normal_eq, void* stream);
