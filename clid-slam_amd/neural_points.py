@@ -184,7 +184,7 @@ class NeuralPoints(nn.Module):
         st = dict(st)
         st["_tables"] = {}
         st.pop("_replica_gens", None)  # torch.Generator objects do not pickle
-        for k in ("_sensor_pos_host", "_win_ws", "_win_counts", "_ins_ws", "_ins_count", "_ins_win_counts", "_gbuf", "_stencils", "_presampled", "_track_scratch", "_cdir_bufs", "_stencil_rows"):
+        for k in ("_sensor_pos_host", "_win_ws", "_win_counts", "_ins_ws", "_ins_count", "_ins_win_counts", "_gbuf", "_stencils", "_presampled", "_track_scratch", "_track_ne", "_cdir_bufs", "_stencil_rows"):
             st.pop(k, None)
         # views of capacity / upper-bound buffers would drag the whole buffers into the pickle: the global arrays (capacity
         # buffers of the in-place insert) and the local arrays, mask and index map (outputs of the window selection, allocated

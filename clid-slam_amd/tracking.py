@@ -48,7 +48,14 @@ def _launch(neural_points, geo_decoder, config, rot, pos, pc_imu, per_point: boo
             out = cache[(n, str(dev))] = {
                 "sdf": torch.empty(n, device=dev, dtype=torch.float32), "grad": torch.empty((n, 3), device=dev, dtype=torch.float32),
                 "pmap": torch.empty((n, 3), device=dev, dtype=torch.float32), "valid": torch.empty(n, device=dev, dtype=torch.int32)}
-    ne = torch.zeros((16, 32), device=dev, dtype=torch.float64) if reduce else None  # CLID_TRACK_COPIES partial copies of the 28 sums
+    ne = None
+    if reduce:  # CLID_TRACK_COPIES partial copies of the 28 sums; two buffers alternate so a caller may still hold the last result
+        ring = neural_points.__dict__.setdefault("_track_ne", {})
+        pair = ring.get(str(dev))
+        if pair is None:
+            pair = ring[str(dev)] = [torch.empty((16, 32), device=dev, dtype=torch.float64) for _ in range(2)] + [0]
+        pair[2] ^= 1
+        ne = pair[pair[2]].zero_()
     fn = lib.clid_track_model_dev if on_dev else lib.clid_track_model
     _lib.check(
         fn(C.byref(view), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
