@@ -30,6 +30,17 @@ BYTES_SEARCH = 688.0
 BYTES_FEAT = 216.0
 
 
+def pmc_traffic(kernel, default_workload: bool):
+    """HBM bytes per launch of `kernel` from the committed counter passes (tools/next_rows_traffic.sh; default workload only)."""
+    if not default_workload:
+        return None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_next_rows_traffic.json")))
+        return next(v["traffic_bytes"] for k, v in tj.items() if isinstance(v, dict) and kernel in k)
+    except (OSError, StopIteration, KeyError, ValueError):
+        return None
+
+
 def timed(fn, reps, warm=3):
     for _ in range(warm):
         fn()
@@ -109,7 +120,7 @@ def sampler_row(cfg, args):
                    "samples_per_ray": n_all, "raw_map_points": int(lpm.local_point_cloud_map.shape[0]),
                    "pool_after_frame": int(mp.pool_sample_count), "neural_points": int(mp.neural_points.count())},
         "roofline": {"bound": "hbm", "kernel": "k_sample_frame", "achieved": alg / t_kernel / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": alg / t_kernel / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": alg / t_kernel / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("k_sample_frame", True),
                      "algorithmic_bytes_per_launch": alg},
     }
     if not args.no_cpu_baseline:
@@ -178,7 +189,7 @@ def main():
         "config": {"workload": "box-room map of bench.py, local map view, one IEKF iteration", "points": n1,
                    "valid_points": n_valid},
         "roofline": {"bound": "hbm", "kernel": "k_track_model", "achieved": alg1 / t1a / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": alg1 / t1a / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": alg1 / t1a / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("k_track_model", args.track_points == 8192),
                      "note": "value / frac: wall clock per Python call (view + ctypes + a 28-double fill + the launch: host-bound); "
                              "us_per_call_device: the launches back to back on the device, pose read from device tensors "
                              "(clid_track_model_dev; incl. the two 12-float conversions and the fill)"},
@@ -199,7 +210,7 @@ def main():
                    "points": args.points, "neural_points": int(nm.neural_points.shape[0]),
                    "mask_fraction": float(mask3.mean().item())},
         "roofline": {"bound": "hbm", "kernel": "k_sdf_query", "achieved": alg3 / t3 / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": alg3 / t3 / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": alg3 / t3 / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("k_sdf_query", args.points == 4194304),
                      "algorithmic_bytes_per_launch": alg3 * min(cfg.infer_bs, args.points) / args.points},
     }
 
