@@ -246,7 +246,7 @@ def _grad_row(probe, rec, frozen):
         kink[rec["ambiguous_rows"]] = True
     d = (gh - g0).abs().max(1).values
     row = {"grad_theta_max": gmax, "dgrad_theta_rel": float(d[~kink].max()) / gmax,
-           "kink_rows": int(kink.sum()), "kink_queries": int(rec.get("ambiguous_queries", 0)),
+           "rows": int(g0.shape[0]), "kink_rows": int(kink.sum()), "kink_queries": int(rec.get("ambiguous_queries", 0)),
            "dgrad_theta_rel_kink_rows": (float(d[kink].max()) / gmax) if bool(kink.any()) else 0.0,
            "dgrad_theta_rel_all_rows": float(d.max()) / gmax,
            # rows the oracle never gathers get exactly zero here too (anything else would become a +-lr step); a gathered

@@ -781,6 +781,25 @@ __device__ __noinline__ void number_tile(const WaveHead& h0, const WaveHead& h1,
   wave_lds_fence();
 }
 
+// MODE 2: the deferred FLAGS of an iteration (one word per task / tile, written by every unit of the directory launch: no reset
+// needed) are shared out in slices of kDeferSlice units per block (grid.x = ceil(units / kDeferSlice)); a block compacts the
+// set flags of its slice into `found` and returns whether there is anything to do.  Block-uniform.
+constexpr int kDeferSlice = 512;
+static_assert(kDeferSlice == kFusedBlock, "one unit of the slice per thread");
+__device__ __forceinline__ bool gather_deferred(const int* __restrict__ flags, int n_units, int* found, int& count) {
+  if (threadIdx.x == 0) count = 0;
+  __syncthreads();
+  const int u = blockIdx.x * kDeferSlice + threadIdx.x;  // (kDeferSlice == kFusedBlock: one unit per thread)
+  const bool set = u < n_units && flags[u] != 0;
+  const unsigned long long b = __ballot(set);
+  int base = 0;
+  if ((threadIdx.x & 63) == 0 && b) base = atomicAdd(&count, __popcll(b));
+  base = __shfl(base, 0, 64);
+  if (set) found[base + __popcll(b & ((1ull << (threadIdx.x & 63)) - 1ull))] = u;
+  __syncthreads();
+  return count > 0;
+}
+
 // MODE 0: probing (search8) over every tile of the launch.  MODE 1: the cell-directory search over every tile; a tile with a query
 // point outside the directory's box goes on its iteration's deferred list (train_common.hpp).  MODE 2: probing over the
 // deferred lists (grid.y = iteration; almost always empty: the block leaves before it stages anything).
@@ -795,14 +814,17 @@ k_search_tiles(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
   extern __shared__ unsigned filt_lds[];  // MODE 0 / 2 with a prefilter of <= 32 KB: 2^log2filter bits; MODE 1: the hit lists
   const size_t iter_f4 = rec_floats_per_iter(tmap.n_tasks) / 4;
   const size_t def_off = rec_deferred_offset(tmap.n_tasks);
-  if (MODE == 2 && reinterpret_cast<const int*>(rec + (size_t)blockIdx.y * iter_f4)[def_off] == 0) return;
+  const int n_tiles = (tmap.n_tasks + 1) / 2;
+  __shared__ int dfound[kDeferSlice], dcount;
+  if (MODE == 2) {  // this block's slice of the iteration's deferred flags -> its work list (usually empty: leave at once)
+    if (!gather_deferred(reinterpret_cast<const int*>(rec + (size_t)blockIdx.y * iter_f4) + def_off, n_tiles, dfound, dcount)) return;
+  }
   if (MODE != 1) stage_delta(dl, mv);
   stage_cells(cl, mv, MODE == 1);
   if (MODE != 1 && use_filter == 1)
     for (int i = threadIdx.x; i < (1 << mv.log2filter) / 32; i += kFusedBlock) filt_lds[i] = mv.filter[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves_per_block = kFusedBlock / 64;
-  const int n_tiles = (tmap.n_tasks + 1) / 2;
   // XCD-aware tile mapping for maps beyond one L2: block b runs on XCD b % 8 (observed dispatch order; a speed matter only)
   // and every XCD has its own 4 MB L2.  On batches in Morton order consecutive tasks are neighbours in space, so XCD x takes
   // the x-th eighth of the bundle tiles and of the plain tiles of EVERY iteration: its L2 then serves one eighth of the map
@@ -813,15 +835,14 @@ k_search_tiles(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
   const int xr0 = (int)((long long)n_rest * xcd / 8), xr1 = (int)((long long)n_rest * (xcd + 1) / 8);
   const int xlen = (xb1 - xb0) + (xr1 - xr0);
   constexpr bool xmap = XMAP && MODE != 2;  // (its own instantiation: the mapping's scalars cost the small-map kernel registers it has to spill)
-  const int w_first = xmap ? xb * waves_per_block + wave : blockIdx.x * waves_per_block + wave;
-  const int w_step = xmap ? xnb * waves_per_block : gridDim.x * waves_per_block;
-  const int* dlist = reinterpret_cast<const int*>(rec + (size_t)blockIdx.y * iter_f4) + def_off;  // (MODE 2)
-  const int w_total = MODE == 2 ? dlist[0] : (xmap ? xlen * n_iter : n_tiles * n_iter);
+  const int w_first = MODE == 2 ? wave : (xmap ? xb * waves_per_block + wave : blockIdx.x * waves_per_block + wave);
+  const int w_step = MODE == 2 ? waves_per_block : (xmap ? xnb * waves_per_block : gridDim.x * waves_per_block);
+  const int w_total = MODE == 2 ? dcount : (xmap ? xlen * n_iter : n_tiles * n_iter);
   for (int w = w_first; w < w_total; w += w_step) {
     int it, tile;
     if (MODE == 2) {
       it = blockIdx.y;
-      tile = dlist[4 + w];
+      tile = dfound[w];
     } else if (xmap) {
       it = w / xlen;
       const int u = w - it * xlen;
@@ -841,11 +862,8 @@ k_search_tiles(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
       if (deferred) break;
       if (lane < kRecFloat4) out[(size_t)task * kRecFloat4 + lane] = reinterpret_cast<const float4*>(&heads[wave][half])[lane];
     }
+    if (MODE == 1 && lane == 0) reinterpret_cast<int*>(out)[def_off + tile] = deferred ? 1 : 0;  // (every tile writes its flag)
     if (deferred) {
-      if (lane == 0) {
-        int* dl_out = reinterpret_cast<int*>(out) + def_off;
-        dl_out[4 + atomicAdd(dl_out, 1)] = tile;
-      }
       wave_lds_fence();
       continue;
     }
@@ -868,7 +886,10 @@ k_search_tasks(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
   extern __shared__ unsigned filt_lds[];
   const size_t iter_f4 = rec_floats_per_iter(tmap.n_tasks) / 4;
   const size_t def_off = rec_deferred_offset(tmap.n_tasks);
-  if (MODE == 2 && reinterpret_cast<const int*>(rec + (size_t)blockIdx.y * iter_f4)[def_off] == 0) return;
+  __shared__ int dfound[kDeferSlice], dcount;
+  if (MODE == 2) {
+    if (!gather_deferred(reinterpret_cast<const int*>(rec + (size_t)blockIdx.y * iter_f4) + def_off, tmap.n_tasks, dfound, dcount)) return;
+  }
   if (MODE != 1) stage_delta(dl, mv);
   stage_cells(cl, mv, MODE == 1);
   if (MODE != 1 && use_filter == 1)
@@ -882,15 +903,14 @@ k_search_tasks(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
   const int xr0 = (int)((long long)n_rest * xcd / 8), xr1 = (int)((long long)n_rest * (xcd + 1) / 8);
   const int xlen = (xb1 - xb0) + (xr1 - xr0);
   constexpr bool xmap = XMAP && MODE != 2;
-  const int w_first = xmap ? xb * waves_per_block + wave : blockIdx.x * waves_per_block + wave;
-  const int w_step = xmap ? xnb * waves_per_block : gridDim.x * waves_per_block;
-  const int* dlist = reinterpret_cast<const int*>(rec + (size_t)blockIdx.y * iter_f4) + def_off;  // (MODE 2)
-  const int w_total = MODE == 2 ? dlist[0] : (xmap ? xlen * n_iter : tmap.n_tasks * n_iter);
+  const int w_first = MODE == 2 ? wave : (xmap ? xb * waves_per_block + wave : blockIdx.x * waves_per_block + wave);
+  const int w_step = MODE == 2 ? waves_per_block : (xmap ? xnb * waves_per_block : gridDim.x * waves_per_block);
+  const int w_total = MODE == 2 ? dcount : (xmap ? xlen * n_iter : tmap.n_tasks * n_iter);
   for (int w = w_first; w < w_total; w += w_step) {
     int it, task;
     if (MODE == 2) {
       it = blockIdx.y;
-      task = dlist[4 + w];
+      task = dfound[w];
     } else if (xmap) {
       it = w / xlen;
       const int u = w - it * xlen;
@@ -900,11 +920,9 @@ k_search_tasks(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
       task = w - it * tmap.n_tasks;
     }
     const long long* index = reinterpret_cast<const long long*>(ta.index) + (long long)it * index_stride;
-    if (search_task<MODE == 1>(mv, ta, tmap, dl, index, task, it, use_filter, filt_lds, heads[wave], cl)) {
-      if (lane == 0) {
-        int* dl_out = reinterpret_cast<int*>(rec + (size_t)it * iter_f4) + def_off;
-        dl_out[4 + atomicAdd(dl_out, 1)] = task;
-      }
+    const bool deferred = search_task<MODE == 1>(mv, ta, tmap, dl, index, task, it, use_filter, filt_lds, heads[wave], cl);
+    if (MODE == 1 && lane == 0) reinterpret_cast<int*>(rec + (size_t)it * iter_f4)[def_off + task] = deferred ? 1 : 0;
+    if (deferred) {
     } else if (lane < kRecFloat4) {
       rec[(size_t)it * iter_f4 + (size_t)task * kRecFloat4 + lane] = reinterpret_cast<const float4*>(&heads[wave])[lane];
     }
@@ -1692,18 +1710,13 @@ extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args*
   const int resident = search_blocks(cdir ? (num ? CLID_CD_WAVES_TILES : CLID_CD_WAVES_TASKS) : CLID_SEARCH_WAVES);
   if (sb > resident) sb = resident;
   const bool xm = CLID_XCD_MAP && big_map && sb >= 8;
-  const size_t per_iter_f = rec_floats_per_iter(tmap.n_tasks);
 #define CLID_SEARCH_LAUNCH(K, GRID, DYN)                                                                                   \
   CLID_KLAUNCH(a->prof, 1, K, GRID, dim3(kFusedBlock), DYN, s, *mv, t2, tmap, reinterpret_cast<float4*>(rec_out), n_iter, \
                (long long)index_stride, use_filter)
   if (cdir) {
-    // the deferred lists start empty; the directory launch fills them, the probing launch behind it walks them
-    if (hipMemset2DAsync(rec_out + rec_deferred_offset(tmap.n_tasks), per_iter_f * sizeof(float), 0, sizeof(int), (size_t)n_iter, s) !=
-        hipSuccess) {
-      clid_set_error("clid_train_search: list reset failed");
-      return CLID_E_HIP;
-    }
-    const dim3 g1((unsigned)sb), g2(16, (unsigned)n_iter);
+    // every unit of the directory launch writes its deferred flag; the probing launch behind it shares the flags out
+    const int units = num ? (tmap.n_tasks + 1) / 2 : tmap.n_tasks;
+    const dim3 g1((unsigned)sb), g2((unsigned)((units + kDeferSlice - 1) / kDeferSlice), (unsigned)n_iter);
     if (num && xm) CLID_SEARCH_LAUNCH((k_search_tiles<true, 1>), g1, dyn_cells);
     else if (num) CLID_SEARCH_LAUNCH((k_search_tiles<false, 1>), g1, dyn_cells);
     else if (xm) CLID_SEARCH_LAUNCH((k_search_tasks<true, 1>), g1, dyn_cells);

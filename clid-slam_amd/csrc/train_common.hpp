@@ -28,9 +28,9 @@ constexpr int kTileNumWords = 128, kTileNumCount = 96, kTileNumBytes = 100;
 #endif
 constexpr int kTileLargeFrom = CLID_TILE_LARGE_FROM;  // tiles
 __host__ __device__ inline bool tiles_prenumbered(int n_tasks) { return (n_tasks + 1) / 2 <= kTileLargeFrom; }
-// ... and behind those the iteration's DEFERRED list (32-bit words): [0] count, [4 ..) the tasks (tiles, when the iteration is
-// pre-numbered) the cell-directory search launch leaves to the probing kernels -- a query point outside the directory's box
-// (csrc/train.hip search_task); the launch that follows walks the lists.
+// ... and behind those the iteration's DEFERRED flags (one 32-bit word per task; per tile when the iteration is pre-numbered):
+// 1 = the cell-directory search launch leaves the unit to the probing kernels -- a query point outside the directory's box
+// (csrc/train.hip search_task); the launch that follows gathers the set flags.  Every unit writes its word: nothing to reset.
 __host__ __device__ inline size_t rec_deferred_offset(int n_tasks) {
   return (size_t)n_tasks * kRecFloatsPerTask + (tiles_prenumbered(n_tasks) ? (size_t)((n_tasks + 1) / 2) * kTileNumWords : 0);
 }

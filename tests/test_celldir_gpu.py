@@ -105,8 +105,8 @@ def _records(nm, mp, idx, bs, decim, flags):
     _lib.check(lib.clid_train_search(C.byref(view), C.byref(ta), iters, idx.data_ptr(), bs, rec.data_ptr(), _lib.stream()), "clid_train_search")
     torch.cuda.synchronize()
     per = rec.numel() // iters
-    tail = ((n_tasks + 4) + 3) & ~3  # behind the records and number blocks: the iteration's deferred list (count | tasks / tiles)
-    deferred = int(rec.view(iters, per)[:, per - tail].contiguous().view(torch.int32).sum())
+    tail = ((n_tasks + 4) + 3) & ~3  # behind the records and number blocks: the iteration's deferred flags (one word per task / tile)
+    deferred = int(rec.view(iters, per)[:, per - tail:].contiguous().view(torch.int32).sum())
     return (shim_io.task_records(rec, iters, n_tasks).reshape(-1, 48, 4).cpu(), rec.view(iters, per)[:, n_tasks * 192:per - tail].cpu(), view,
             deferred)
 
