@@ -178,7 +178,8 @@ struct CellLds {
   int ox, oy, oz, nx, ny, nz, nzw, valid, nc;
 };
 __device__ __forceinline__ void stage_cells(CellLds& cl, const clid_map_view& mv, bool want) {
-  const bool have = want && mv.cdir_hdr && mv.cdir_words && mv.cdir_pos && mv.stencil_rows && mv.stencil_nc >= 1 && mv.stencil_nc <= 2;
+  const bool have = want && mv.cdir_hdr && mv.cdir_words && mv.cdir_pos && mv.stencil_rows && mv.stencil_nc >= 1 && mv.stencil_nc <= 2 &&
+                    mv.P <= kCdHits;  // (the hit lists hold one entry per probe: a full 5 x 5 x 5 stencil probes the table instead)
   const int nc = have ? mv.stencil_nc : 1, S = 2 * nc + 1;
   if (threadIdx.x < kCdRows) {
     const int r = threadIdx.x;

@@ -1696,7 +1696,7 @@ extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args*
   // instead of 2 nc + 1 probes; debug bit 3 keeps the probe kernels (A/B, tests)
   const bool big_map = use_filter == 2;
   if (mv->cdir_hdr && mv->cdir_words && mv->cdir_pos && mv->stencil_rows && mv->stencil_nc >= 1 && mv->stencil_nc <= 2 &&
-      !(a->debug_flags & 8))
+      mv->P <= kCdHits && !(a->debug_flags & 8))
     use_filter = 3;
   const bool cdir = use_filter == 3;
   if (cdir) use_filter = big_map ? 2 : (mv->filter && mv->log2filter >= 10 && mv->log2filter <= 18 && filter_enabled() ? 1 : 0);

@@ -442,6 +442,9 @@ class Mapper:
                 dist.all_reduce(nm.local_point_ts_update, op=dist.ReduceOp.MAX)
                 dist.all_reduce(losses)
             self._mapping_calls = getattr(self, "_mapping_calls", 0) + 1
+            # every call: the sizes the exchange depends on (cheap, asynchronous, verified at the next call's end); every
+            # `replica_check_every`-th call: the content sums too
+            self._queue_size_check(dist, M_local, iter_count)
             if (self._mapping_calls - 1) % max(int(getattr(self, "replica_check_every", 16)), 1) == 0:
                 self._check_replicas(dist)
         self.last_losses = losses
@@ -573,6 +576,26 @@ class Mapper:
             if int(bad.item()):
                 raise _lib.P2pTimeout("clid_p2p: a rank of the group gave up waiting at an exchange; the call's sums are invalid")
         return moved
+
+    def _queue_size_check(self, dist, M_local: int, iter_count: int):
+        """with each rank drawing only its own shard, nothing cross-checked the replicas between two full checks.
+        Every sharded call now MIN-all-reduces [x, -x] over (local map size, pool size, new-sample count, iterations, draw
+        counter) -- one tiny asynchronous collective -- and the PREVIOUS call's result is examined here, when it has long
+        arrived (no stall): different sizes mean different row lists and exchange lengths, i.e. garbage sums."""
+        wire = self.neural_points.local_geo_features.device if dist.get_backend() == "nccl" else torch.device("cpu")
+        prev = self.__dict__.pop("_size_check", None)
+        if prev is not None:
+            work, t, mine = prev
+            work.wait()
+            got = t.tolist()
+            n = len(mine)
+            if got[:n] != mine or [-v for v in got[n:]] != mine:
+                raise RuntimeError(f"data-parallel replicas diverged: this rank had (M_local, pool, new samples, iterations, draws) = {mine}, "
+                                   f"the group's min / max are {got[:n]} / {[-v for v in got[n:]]}")
+        mine = [int(M_local), int(self.pool_sample_count), int(0 if self.new_idx is None else self.new_idx.shape[0]), int(iter_count),
+                int(getattr(self, "_draw_calls", 0))]
+        t = torch.tensor(mine + [-v for v in mine], dtype=torch.int64, device=wire)
+        self._size_check = (dist.all_reduce(t, op=dist.ReduceOp.MIN, async_op=True), t, mine)
 
     def _check_replicas(self, dist):
         """Data parallelism here relies on every rank holding a bit-identical replica of the map and the pool (same
@@ -737,8 +760,13 @@ class Mapper:
             self.local_point_cloud_map._sensor_pos_host = (origin, tuple(float(v) for v in cur_pose_torch[:3, 3].tolist()))
             # the raw-point map's new size is needed by nobody before the frame's last read-back: it lands in the frame's
             # count block and is read there (the sampler's kernels take the upper bound meanwhile)
+            # ... only where the fused sampler + compaction path, which reads the size on the device, is certain to follow
+            # (with the dynamic filter or the un-fused sampler a row-wise consumer would have seen the upper bound's
+            # uninitialised tail)
+            fused_follows = (not filter_dynamic and pts.is_cuda and hasattr(self.sampler, "_run") and getattr(cfg, "from_sample_points", True)
+                             and not getattr(cfg, "from_all_samples", False) and os.environ.get("CLID_FUSED_COMPACT", "1") != "0")
             self.local_point_cloud_map._defer_counts = (
-                self._frame_count_block(pts.device)[4:6] if pts.is_cuda and os.environ.get("CLID_DEFER_CLOUD_COUNT", "1") != "0" else None)
+                self._frame_count_block(pts.device)[4:6] if fused_follows and os.environ.get("CLID_DEFER_CLOUD_COUNT", "1") != "0" else None)
             self.local_point_cloud_map.update_map(origin, transform_torch(pts, cur_pose_torch))
         self.static_mask = torch.ones(pts.shape[0], dtype=torch.bool, device=pts.device)
         if filter_dynamic:  # :189-204
@@ -843,6 +871,7 @@ class Mapper:
         self.determine_used_pose()
         new_pending = None
         if overlap:
+            map_ready = main.record_event() if os.environ.get("CLID_TABLE_PREFETCH_EARLY", "1") != "0" else None
             main.wait_stream(side)
             if cfg.bs_new_sample > 0:
                 # the new-sample selection (below) launched on the pool arrays still in flight: it reads the two pool counts on
@@ -854,7 +883,12 @@ class Mapper:
                 third = getattr(self, "_third_stream", None)
                 if third is None or third.device != coord.device:
                     third = self._third_stream = torch.cuda.Stream(device=coord.device)
-                third.wait_stream(main)
+                # (it waits for the map update only -- not, through `main`, for the pool's compaction on the side stream: the
+                # table + directory build, ~70 us of small launches, then runs NEXT TO that bandwidth-bound copy)
+                if map_ready is not None:
+                    third.wait_event(map_ready)
+                else:
+                    third.wait_stream(main)
                 nm.prefetch_local_table(third)
             self._pool_filter_finish(with_tail=new_pending is not None)
         elif fused_pool:

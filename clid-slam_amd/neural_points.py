@@ -792,7 +792,7 @@ class NeuralPoints(nn.Module):
         if n > 0 and os.environ.get("CLID_CELLDIR", "1") != "0":  # (the global map too: dense inference for meshing walks it)
             # cell directory of the window (csrc/celldir.hip): occupancy bits + ranks over the bounding box of its points,
             # sized on the device against these capacities (no read-back); cached buffers, they grow with the window
-            words_cap = max(1 << 18, 16 * n)
+            words_cap = max(1 << 21, 16 * n)  # (2^21 words = a 560 m x 560 m x 12.8 m box of 0.4 m cells: sparse early maps fit too)
             hits_cap = 4 * n + 4096
             pool = self.__dict__.setdefault("_cdir_bufs", {})  # per table slot: two cached tables never share a directory
             bufs = pool.get(slot)

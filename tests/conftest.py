@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+# a flag wait of the peer-mapped exchange polls for 600 s by default before the call falls back to the collective; in the tests
+# (several ranks time-sliced on ONE device) a stall should cost a minute, not ten (inherited by the spawned ranks)
+os.environ.setdefault("CLID_P2P_TIMEOUT_S", "60")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

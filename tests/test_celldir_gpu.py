@@ -116,7 +116,7 @@ def _same(a, b):
     assert torch.equal(a[1].contiguous().view(torch.int32), b[1].contiguous().view(torch.int32))  # tile number blocks
 
 
-@pytest.mark.parametrize("nnc,alpha", [(2, 0.5), (1, 1.0), (2, 0.2)])
+@pytest.mark.parametrize("nnc,alpha", [(2, 0.5), (1, 1.0), (2, 0.2), (2, 1.6)])  # (2, 1.6): all 125 cells -- more probes than a hit list holds: probing
 def test_records_from_the_directory_equal_probing_on_the_collision_fixture(nnc, alpha):
     """Golden map (B = 100003): batch samples, their finite-difference copies, plus samples pushed to the rim of and far
     outside the directory's box (those tasks fall back to probing: a foreign collision can answer there)."""
@@ -148,7 +148,7 @@ def test_records_from_the_directory_equal_probing_on_the_collision_fixture(nnc, 
     b = _records(nm, mp, idx, bs, decim, 8)
     assert a[2].cdir_hdr and a[2].stencil_rows
     _same(a, b)
-    assert a[3] > 0 and b[3] == 0  # tasks with a query point outside the box went through the deferred list
+    assert (a[3] > 0 or nm.neighbor_K > 88) and b[3] == 0  # tasks with a query point outside the box went through the deferred list
     ids = a[0][:, 16:].reshape(-1, 8, 8, 2)[:, :, :6, 1].contiguous().view(torch.int32)
     assert float((ids >= 0).float().mean()) > 0.1  # (the comparison is not vacuous)
 

@@ -109,3 +109,43 @@ def test_p2p_timeout_falls_back_to_the_collective_on_every_rank(tmp_path):
     assert np.abs(a["theta"] - b["theta"]).max() <= 2e-5 and np.abs(a["W1"] - b["W1"]).max() <= 2e-5
     assert np.abs(a["cert"] - b["cert"]).max() <= 2e-3 and np.array_equal(a["ts"], b["ts"])
     assert int(b["exchange"][2]) == 0  # the repeated call did not use the peer-mapped buffers
+
+
+def _run_size_check(rank, world, port):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_io as gio
+    import shim_io
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["CLID_P2P"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    p = gio.load("pool.npz")
+    g = gio.load("g6_loop_numerical_train_ln0.npz")
+    cfg = shim_io.config(bs=2048)
+    nm = shim_io.neural_points(cfg, base=p)
+    dec = shim_io.decoder(cfg, g, "init_")
+    mpr, _ = shim_io.mapper(cfg, nm, dec)
+    mpr.replica_check_every = 1000  # (only the first call runs the full content check)
+    idx = torch.randint(0, p["coord"].shape[0], (2, 2048), generator=torch.Generator().manual_seed(3)).cuda()
+    mpr.mapping(2, index_seq=idx)
+    mpr.mapping(2, index_seq=idx)  # verifies call 1's sizes (equal)
+    if rank == 1:
+        mpr._draw_calls = 12345    # a replica that has drawn a different number of batches
+    mpr.mapping(2, index_seq=idx)  # queues the differing signature
+    try:
+        mpr.mapping(2, index_seq=idx)
+        raised = False
+    except RuntimeError as e:
+        raised = "replicas diverged" in str(e)
+    assert raised, rank  # EVERY rank notices (MIN / MAX over the group), one call late and without a stall
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sizes_are_cross_checked_on_every_call():
+    """between two full replica checks nothing compared the ranks' sizes any more; every sharded call now carries a
+    tiny asynchronous MIN / MAX of (local map size, pool size, new samples, iterations, draw counter)."""
+    mp.spawn(_run_size_check, args=(2, 29950 + (os.getpid() % 40)), nprocs=2, join=True)
