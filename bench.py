@@ -143,8 +143,11 @@ def kernel_report(lib, mp, steps, bs_local, decim, M, decode_variant, analytic=F
     n_tasks_est = int(lib.clid_train_search_tasks(bs_local, 0, decim, 1))  # <= 2048 tiles: the launch that also numbers the tiles
     dname = {0: "k_train_fused8<2> (decode, 16 lanes/query)", 1: "k_decode_tile<fp32 MFMA>", 2: "k_decode_tile<bf16 MFMA>"}[decode_variant]
     if analytic:  # loss.numerical_grad_on: False -- one launch per iteration: search + decode + analytic d sdf / d x + backward through it
-        rows = [("k_train_analytic (search + decode + analytic eikonal, 16 lanes/query)", out[0] / iters, bs_local * 1860.0,
+        rows = [("k_train_analytic (decode + analytic eikonal + backward through it, 16 lanes/query%s)" % ("" if hoisted else "; search inside"),
+                 out[0] / iters, bs_local * (1860.0 - (B_SEARCH_Q if hoisted else 0.0)),
                  "1860 B/sample (SURVEY 8d: 1440 per query fwd+bwd + 24 pool gather + 12 gradient write + 384 second-order feature-gradient pass) x %d samples" % bs_local),
+                ("k_search_tiles / k_search_tasks (cell-directory search of the plain tasks, per iteration of a <=32-iteration launch)",
+                 out[1] / iters, bs_local * (B_SEARCH_Q + B_POOL_SAMPLE), "688 B/query + 24 B/sample x %d samples" % bs_local),
                 ("k_adam_all", out[3] / iters, B_ADAM_ROW * (M + 1) + 833 * B_ADAM_PARAM, "256 B/row x %d rows + 28 B x 833" % (M + 1))]
     else:
       rows = [

@@ -1394,7 +1394,7 @@ static int decode_variant_for(const clid_train_args* a) {
 extern "C" int clid_train_decode_kernel(const clid_map_view* mv, const clid_train_args* a) {
   return (mv && a) ? decode_variant_for(a) : CLID_E_ARG;
 }
-static bool hoisted(const clid_train_args* a) { return a->eikonal_mode != 2 && a->pipeline != 0; }
+static bool hoisted(const clid_train_args* a) { return a->pipeline != 0; }  // (analytic mode too since round 4: records of plain tasks)
 // Rows of per-block partials the forward/backward launch of an iteration leaves in the workspace -- a function of the
 // arguments alone (ABI 2 handed it from clid_train_decode to clid_train_adam through a thread_local): the analytic kernel,
 // the tile kernels (hoisted schedule) and the 16-lane kernel each have their own grid rule.
@@ -1426,19 +1426,19 @@ extern "C" int64_t clid_touch_workspace_bytes(int32_t M, int32_t chunk_iters) {
 }
 extern "C" int64_t clid_train_search_floats(int32_t bs, int64_t batch_offset, int32_t decimation,
                                             int32_t eikonal_mode, int32_t n_iter) {
-  if (bs <= 0 || decimation <= 0 || n_iter < 0 || eikonal_mode == 2) return -1;
+  if (bs <= 0 || decimation <= 0 || n_iter < 0) return -1;
   const int first = fd_first(batch_offset, decimation);
   const int n_fd = eikonal_mode == 1 ? fd_count(bs, batch_offset, decimation) : 0;
   return (int64_t)rec_floats_per_iter(make_task_map(bs, n_fd, first, decimation).n_tasks) * n_iter;
 }
 extern "C" int32_t clid_train_search_tasks(int32_t bs, int64_t batch_offset, int32_t decimation, int32_t eikonal_mode) {
-  if (bs <= 0 || decimation <= 0 || eikonal_mode == 2) return -1;
+  if (bs <= 0 || decimation <= 0) return -1;
   const int first = fd_first(batch_offset, decimation);
   const int n_fd = eikonal_mode == 1 ? fd_count(bs, batch_offset, decimation) : 0;
   return make_task_map(bs, n_fd, first, decimation).n_tasks;
 }
 extern "C" int32_t clid_train_chunk_iters(const clid_train_args* a) {
-  if (!a || a->bs <= 0 || a->decimation <= 0 || a->eikonal_mode == 2) return 0;
+  if (!a || a->bs <= 0 || a->decimation <= 0) return 0;
   int n_fd, first;
   const int Q = n_queries(a, &n_fd, &first);
   const size_t per_iter = (size_t)clid_train_search_floats(a->bs, a->batch_offset, a->decimation, a->eikonal_mode, 1);
@@ -1535,7 +1535,7 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
   fa.pipeline = 0;  // this entry IS the fused schedule (partial_rows / touched-row bookkeeping follow it)
   const int nb = partial_rows(&fa);
   if (a->eikonal_mode == 2) {  // loss.numerical_grad_on: False (utils/mapper.py:57-69, 660-661, 695-696)
-    if (int e = clid_launch_train_analytic(mv, a, ws.partial, s)) return e;
+    if (int e = clid_launch_train_analytic(mv, a, ws.partial, nullptr, s)) return e;
   } else {
     CLID_KLAUNCH(a->prof, 0, k_train_fused8<0>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap, (float4*)nullptr);
     CLID_CHECK_LAUNCH();
@@ -1655,7 +1655,7 @@ static int check_train_args(const clid_map_view* mv, const clid_train_args* a, c
     clid_set_error("%s: neighbourhood of %d cells exceeds the supported %d", who, mv->P, kMaxProbes);
     return CLID_E_SHAPE;
   }
-  if (a->bs <= 0 || a->decimation <= 0 || a->eikonal_mode == 2) {
+  if (a->bs <= 0 || a->decimation <= 0 || (a->eikonal_mode == 2 && a->decimation != 1)) {
     clid_set_error("%s: bs=%d decimation=%d eikonal_mode=%d", who, a->bs, a->decimation, a->eikonal_mode);
     return CLID_E_ARG;
   }
@@ -1751,7 +1751,9 @@ extern "C" int clid_train_decode(const clid_map_view* mv, const clid_train_args*
   da.pipeline = 1;  // this entry IS the hoisted schedule
   const int variant = decode_variant_for(&da);
   const int nb = partial_rows(&da);
-  if (variant) {
+  if (a->eikonal_mode == 2) {  // loss.numerical_grad_on: False: the analytic iteration from the records (csrc/train_analytic.hip)
+    if (int e = clid_launch_train_analytic(mv, a, ws.partial, rec, s)) return e;
+  } else if (variant) {
     if (int e = clid_launch_decode_tile(mv, a, ws.partial, tmap, rec, variant == 2 ? 1 : 0, s)) return e;
   } else {
     CLID_KLAUNCH(a->prof, 0, k_train_fused8<2>, dim3(nb), dim3(kFusedBlock), 0, s, *mv, *a, ws.partial, tmap,

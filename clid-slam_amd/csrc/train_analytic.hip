@@ -9,6 +9,8 @@
 //   dW1[h,:] += s W2[h] a[h] t,  dW2[h] += s a[h] (W1[h,:] . t),  d feat_k += (w_k delta + s_k) u[0:8]
 // One round = 4 queries per wave, forward and backward back to back in registers (no shifted copies, so
 // no cross-query dependency).  Lane layout of the gather as in train.hip: lane16 = 2k + half.
+#include <type_traits>
+
 #include "train_common.hpp"
 
 namespace clid {
@@ -16,12 +18,17 @@ namespace clid {
 #define CLID_BFLY(x) x += dpp_mov<0x128>(x); x += dpp_mov<0x124>(x); x += dpp_mov<0x122>(x);
 #define CLID_SWAP(x) dpp_mov<0xB1>(x)  // quad_perm [1,0,3,2]: the other lane of the pair
 
+// HOISTED: neighbours and IDW weights come from the records of the chunk's search launch (clid_train_search: plain tasks of 8
+// samples, task = position / 8) -- positions only, nothing the training writes -- instead of a search inside the iteration's
+// dependent chain; omega_k is recomputed from x - p_k with the search's own operation order (bit-identical).
+template <bool HOISTED>
 __global__ void __launch_bounds__(CLID_BLOCK, 3)
-k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, int n_rounds) {
+k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, int n_rounds, const float4* __restrict__ rec) {
   __shared__ MlpLds mlp;
-  __shared__ SearchLds dl;  // (+ the window's cell directory: the search walks it, common.hpp search_topk)
+  __shared__ typename std::conditional<HOISTED, DeltaLds, SearchLds>::type dl;  // (in-kernel search: + the window's cell directory)
   __shared__ float red[(CLID_BLOCK / 64) * kRedFloats];
-  stage_mlp_and_delta(mlp, dl, mv, ta.W1, ta.b1, ta.W2, ta.b2);
+  if (HOISTED) stage_mlp(mlp, ta.W1, ta.b1, ta.W2, ta.b2);
+  else stage_mlp_and_delta(mlp, dl, mv, ta.W1, ta.b1, ta.W2, ta.b2);
   const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48, grp = lane >> 4;
   const int wave = threadIdx.x >> 6, waves_per_block = CLID_BLOCK / 64;
   const int my_k = lane16 >> 1;
@@ -37,20 +44,38 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
 
   for (int rd = blockIdx.x * waves_per_block + wave; rd < n_rounds; rd += gridDim.x * waves_per_block) {
     const int p_raw = rd * 4 + grp;
-    const bool live = p_raw < ta.bs;
-    const long long s = ta.index[live ? p_raw : 0];
-    const float px = ta.pool_coord[s * 3 + 0], py = ta.pool_coord[s * 3 + 1], pz = ta.pool_coord[s * 3 + 2];
-    TopK t;
-    search_topk(mv, dl, px, py, pz, lane16, gbase, t);
-    float w[CLID_K], omega[CLID_K];
-    idw_weights(t, w, omega);
+    bool live = p_raw < ta.bs;
+    long long s = 0;
+    float px, py, pz, rec_label = 0.f, rec_wt = 1.f;
+    int rec_ts = 0;
     int my_j = -1;
     float my_w = 0.f, my_om = 0.f;
+    if constexpr (HOISTED) {
+      const float4* r = rec + (size_t)(p_raw >> 3) * 48;  // qinfo[8] | qdesc[8] | win[8][8] float2
+      const int slot = p_raw & 7;
+      const float4 qi = r[live ? slot : 0], qd = r[8 + (live ? slot : 0)];
+      live = live && __float_as_int(qd.x) >= 0;
+      px = qi.x; py = qi.y; pz = qi.z;
+      rec_ts = __float_as_int(qi.w);
+      rec_label = qd.z; rec_wt = qd.w;
+      const float2 wn = reinterpret_cast<const float2*>(r + 16)[(live ? slot : 0) * 8 + (my_k < CLID_K ? my_k : 0)];
+      if (my_k < CLID_K) {
+        my_w = wn.x;
+        my_j = __float_as_int(wn.y);
+      }
+    } else {
+      s = ta.index[live ? p_raw : 0];
+      px = ta.pool_coord[s * 3 + 0]; py = ta.pool_coord[s * 3 + 1]; pz = ta.pool_coord[s * 3 + 2];
+      TopK t;
+      search_topk(mv, dl, px, py, pz, lane16, gbase, t);
+      float w[CLID_K], omega[CLID_K];
+      idw_weights(t, w, omega);
 #pragma unroll
-    for (int k = 0; k < CLID_K; ++k) {
-      my_j = (my_k == k) ? t.j[k] : my_j;
-      my_w = (my_k == k) ? w[k] : my_w;
-      my_om = (my_k == k) ? omega[k] : my_om;
+      for (int k = 0; k < CLID_K; ++k) {
+        my_j = (my_k == k) ? t.j[k] : my_j;
+        my_w = (my_k == k) ? w[k] : my_w;
+        my_om = (my_k == k) ? omega[k] : my_om;
+      }
     }
     if (!live) my_j = -1;
     const bool valid = my_j >= 0;
@@ -71,6 +96,8 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
       v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
     }
     const float rx = valid ? fsub(px, pj.x) : 0.f, ry = valid ? fsub(py, pj.y) : 0.f, rz = valid ? fsub(pz, pj.z) : 0.f;
+    if constexpr (HOISTED)  // np.py:688-693 on dist2 = |p_k - x|^2 in the search's operation order
+      my_om = valid ? fdiv(1.0f, fadd(fadd(fadd(fmul(rx, rx), fmul(ry, ry)), fmul(rz, rz)), 1e-15f)) : 0.f;
 
     // ---- blended decoder input f (replicated)
     float f[CLID_D];
@@ -115,14 +142,14 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
     // ---- training_mode side effects (np.py:708-733)
     if (valid && !odd && lane16 < 2 * CLID_K) {
       atomicAdd(&mv.cert[my_j], my_w);
-      if (mv.ts_update) atomicMax(&mv.ts_update[my_j], ta.pool_ts[s]);
+      if (mv.ts_update) atomicMax(&mv.ts_update[my_j], HOISTED ? rec_ts : ta.pool_ts[s]);
     }
 
     // ---- losses and their derivatives
     float delta = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
     if (live) {
-      const float label = ta.pool_label[s];
-      const float wt = ta.loss_weight_on ? fabsf(ta.pool_weight[s]) : 1.0f;  // mapper.py:747-749
+      const float label = HOISTED ? rec_label : ta.pool_label[s];
+      const float wt = HOISTED ? rec_wt : (ta.loss_weight_on ? fabsf(ta.pool_weight[s]) : 1.0f);  // mapper.py:747-749
       const float z = sdf * inv_sigma;
       const float tgt = __frcp_rn(1.0f + __expf(-label * inv_sigma));         // loss.py:60
       const float ez = __expf(-fabsf(z));
@@ -208,15 +235,19 @@ int clid_train_analytic_blocks(int bs) {
   return nb > clid::kMaxBwdBlocks ? clid::kMaxBwdBlocks : (nb < 1 ? 1 : nb);
 }
 
-int clid_launch_train_analytic(const clid_map_view* mv, const clid_train_args* a, float* partial, hipStream_t s) {
+int clid_launch_train_analytic(const clid_map_view* mv, const clid_train_args* a, float* partial, const float* rec, hipStream_t s) {
   if (a->decimation != 1) {
     clid_set_error("clid_train_fwd_bwd: analytic eikonal mode expects gradient_decimation == 1 (utils/config.py:645-646), got %d",
                    a->decimation);
     return CLID_E_ARG;
   }
   const int rounds = (a->bs + 3) / 4;
-  CLID_KLAUNCH(a->prof, 0, clid::k_train_analytic, dim3(clid_train_analytic_blocks(a->bs)), dim3(CLID_BLOCK), 0, s, *mv, *a,
-                     partial, rounds);
+  if (rec)
+    CLID_KLAUNCH(a->prof, 0, clid::k_train_analytic<true>, dim3(clid_train_analytic_blocks(a->bs)), dim3(CLID_BLOCK), 0, s, *mv, *a,
+                 partial, rounds, reinterpret_cast<const float4*>(rec));
+  else
+    CLID_KLAUNCH(a->prof, 0, clid::k_train_analytic<false>, dim3(clid_train_analytic_blocks(a->bs)), dim3(CLID_BLOCK), 0, s, *mv, *a,
+                 partial, rounds, static_cast<const float4*>(nullptr));
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

@@ -319,7 +319,7 @@ class Mapper:
         sdf_dbg = getattr(self, "_sdf_dbg", None)   # test aid: SDF per record slot (tile kernels)
         ta.sdf_dbg = None if sdf_dbg is None else sdf_dbg.data_ptr()
         ta.prof = getattr(self, "_prof", None)      # measurement aid: clid_profile_create() object
-        hoist = eik_mode != 2 and ta.pipeline == 1
+        hoist = ta.pipeline == 1  # (the analytic-eikonal iteration reads the hoisted search's records too)
         tile = hoist and lib.clid_train_decode_kernel(C.byref(view), C.byref(ta)) > 0
 
         aa = _lib.AdamArgs()
