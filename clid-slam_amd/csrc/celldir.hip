@@ -3,11 +3,11 @@
 // (model/neural_points.py:984-1009, 595-598) -- as one bit per cell over the bounding box of the window's points, a rank
 // per 32 cells and the (x, y, z, id) rows of the hits in cell order.  Built from the compact probe table (csrc/table.hip),
 // which already IS that chain keyed by slot number, so collisions of the big table are reproduced bit for bit:
-//   k_cdir_box    cell bounding box of the window's points; the block that finishes last derives origin = min - margin, dims,
-//                 word count and validity
-//   k_cdir_bits   8 lanes per 32 z-adjacent cells: the cells' slot numbers by one exact hash + modular additions, prefilter
-//                 bit, bucket compare on the 12 % that pass; occupancy word + hit count per 32 words; the block that finishes
-//                 last scans the counts
+//   k_cdir_box    cell bounding box of the window's points (biased non-negative extremes over a zeroed header)
+//   k_cdir_bits   every block derives origin = min - margin, dims and word count from the extremes (block 0 stores them); 8 lanes
+//                 per 32 z-adjacent cells: the cells' slot numbers by one exact hash + modular additions, prefilter bit, bucket
+//                 compare on the 12 % that pass; occupancy word + hit count per 32 words
+//   k_cdir_scan   exclusive scan of those counts (one block), hit total, validity against the row capacity
 //   k_cdir_rows   rank of every word's first hit, the hits' rows copied from the table in cell order, the next word's low
 //                 bits packed next to the rank (a stencil row that straddles two words is still one 8-byte load)
 // No launch depends on a host read-back: the arrays have capacities, the header carries the sizes and a validity word.
