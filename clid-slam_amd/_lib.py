@@ -54,7 +54,7 @@ class TrainArgs(C.Structure):
         # per-call switches and aids (ABI 3: no process-global state in the library)
         ("decode_variant", _i32), ("pipeline", _i32), ("sdf_dbg", _vp), ("prof", _vp),
         # touched-row bookkeeping of the hoisted-search loop (NULL = dense exchange / dense Adam sweep)
-        ("touch_ws", _vp), ("touch_stride", _i64), ("touch_iter", _i32), ("touch_all", _i32), ("cbuf", _vp), ("p2p", _vp),
+        ("touch_ws", _vp), ("touch_stride", _i64), ("touch_iter", _i32), ("touch_all", _i32), ("cbuf", _vp), ("p2p", _vp), ("decode_each_neighbour", _i32),
     ]
 
 
@@ -216,7 +216,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.clid_abi_version() != 4:
+    if lib.clid_abi_version() != 5:
         raise RuntimeError("libclid_native.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

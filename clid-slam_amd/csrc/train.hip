@@ -1388,7 +1388,7 @@ static int fused_blocks(int n_tasks, int block = kFusedBlock) {
 // 16-lanes-per-query kernel
 static int decode_variant_for(const clid_train_args* a) {
   const int v = a->decode_variant < 0 ? 0 : (a->decode_variant > 2 ? 2 : a->decode_variant);
-  if (v == 0 || a->eikonal_mode == 2 || a->grad_stride != CLID_GRAD_ROW16) return 0;
+  if (v == 0 || a->eikonal_mode == 2 || a->decode_each_neighbour || a->grad_stride != CLID_GRAD_ROW16) return 0;
   return v;
 }
 extern "C" int clid_train_decode_kernel(const clid_map_view* mv, const clid_train_args* a) {
@@ -1403,6 +1403,7 @@ static int partial_rows(const clid_train_args* a) {
   int n_fd, first;
   n_queries(a, &n_fd, &first);
   const TaskMap tmap = make_task_map(a->bs, n_fd, first, a->decimation);
+  if (a->decode_each_neighbour) return clid_train_wf0_rows(tmap.n_tasks, n_fd);
   if (hoisted(a) && decode_variant_for(a)) return clid_decode_tile_blocks(tmap.n_tasks);
   return fused_blocks(tmap.n_tasks);
 }
@@ -1524,6 +1525,10 @@ extern "C" int clid_train_fwd_bwd(const clid_map_view* mv, const clid_train_args
   }
   if (a->bs <= 0 || a->decimation <= 0) {
     clid_set_error("clid_train_fwd_bwd: bs=%d decimation=%d", a->bs, a->decimation);
+    return CLID_E_ARG;
+  }
+  if (a->decode_each_neighbour) {
+    clid_set_error("clid_train_fwd_bwd: decode_each_neighbour (weighted_first: False) runs on the hoisted schedule only");
     return CLID_E_ARG;
   }
   hipStream_t s = (hipStream_t)stream;
@@ -1659,6 +1664,10 @@ static int check_train_args(const clid_map_view* mv, const clid_train_args* a, c
     clid_set_error("%s: bs=%d decimation=%d eikonal_mode=%d", who, a->bs, a->decimation, a->eikonal_mode);
     return CLID_E_ARG;
   }
+  if (a->decode_each_neighbour && (a->eikonal_mode == 2 || a->cbuf)) {
+    clid_set_error("%s: decode_each_neighbour (weighted_first: False) needs the hoisted schedule, eikonal mode 0 or 1 and the plain exchange", who);
+    return CLID_E_ARG;
+  }
   return check_touch(a, mv->M, who);
 }
 
@@ -1753,6 +1762,8 @@ extern "C" int clid_train_decode(const clid_map_view* mv, const clid_train_args*
   const int nb = partial_rows(&da);
   if (a->eikonal_mode == 2) {  // loss.numerical_grad_on: False: the analytic iteration from the records (csrc/train_analytic.hip)
     if (int e = clid_launch_train_analytic(mv, a, ws.partial, rec, s)) return e;
+  } else if (a->decode_each_neighbour) {  // neuralpoints.weighted_first: False (csrc/train_wf0.hip)
+    if (int e = clid_launch_train_wf0(mv, a, ws.partial, tmap, rec, s)) return e;
   } else if (variant) {
     if (int e = clid_launch_decode_tile(mv, a, ws.partial, tmap, rec, variant == 2 ? 1 : 0, s)) return e;
   } else {

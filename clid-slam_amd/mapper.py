@@ -250,7 +250,10 @@ class Mapper:
         lib = _lib.load()
         self._check_fused_config()
         cfg, nm = self.config, self.neural_points
-        if not cfg.weighted_first:
+        pipeline = int(_lib.PIPELINE if getattr(self, "pipeline", None) is None else self.pipeline)
+        if not cfg.weighted_first and (pipeline != 1 or (cfg.ekional_loss_on and cfg.weight_e > 0 and not cfg.numerical_grad)):
+            # per-neighbour decoding is fused on the hoisted schedule with the numerical (or no) eikonal term
+            # (csrc/train_wf0.hip); the analytic term would need a second derivative through six decoder evaluations
             return self._mapping_unfused(iter_count, index_seq)
         iter_count = max(1, iter_count + self.adaptive_iter_offset)
         dist = _dist()
@@ -315,7 +318,8 @@ class Mapper:
         ta.grad_stride = gstride
         # per-call switches: ONE place decides the schedule and the kernel for Python and C alike
         ta.decode_variant = int(_lib.DECODE_VARIANT if getattr(self, "decode_variant", None) is None else self.decode_variant)
-        ta.pipeline = int(_lib.PIPELINE if getattr(self, "pipeline", None) is None else self.pipeline)
+        ta.pipeline = pipeline
+        ta.decode_each_neighbour = 0 if cfg.weighted_first else 1
         sdf_dbg = getattr(self, "_sdf_dbg", None)   # test aid: SDF per record slot (tile kernels)
         ta.sdf_dbg = None if sdf_dbg is None else sdf_dbg.data_ptr()
         ta.prof = getattr(self, "_prof", None)      # measurement aid: clid_profile_create() object

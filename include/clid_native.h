@@ -289,6 +289,11 @@ typedef struct clid_train_args {
    * rank instead of an RCCL ring; NULL, a rank count other than the communicator's, or a capacity below
    * 848 + 9 (M + 1) floats keep RCCL for the call. */
   struct clid_p2p* p2p;
+  /* 1 = `neuralpoints.weighted_first: False` (utils/mapper.py:679-680): every neighbour's own decoder input is decoded and
+   * the K SDFs are blended with the IDW weights, for the samples and the shifted copies alike (csrc/train_wf0.hip).
+   * Hoisted schedule (clid_train_search / clid_train_decode / clid_mapping_run*), eikonal modes 0 and 1, plain exchange;
+   * 0 (the reference's default, every shipped config) = decode the blended input. */
+  int32_t decode_each_neighbour;
 } clid_train_args;
 
 /* Touched-row workspace (see clid_train_args.touch_ws).  clid_train_touch_scan turns the chunk's flags (after the

@@ -442,32 +442,44 @@ def test_mapping_loop_vs_oracle_free_batches(env, mode, ln):
     assert maxerr(nm.local_point_certainties, recs[-1]["certainties"]) <= 2e-3
 
 
-def test_mapping_weighted_first_false_vs_oracle(env):
-    """`weighted_first: False`: the un-fused loop over the HIP autograd ops against the oracle."""
+@pytest.mark.parametrize("pipeline,ln,eik,train", [(1, 0, True, True), (1, 1, True, True), (1, 0, False, True), (1, 1, True, False),
+                                                   (0, 0, True, True)])
+def test_mapping_weighted_first_false_vs_oracle(env, pipeline, ln, eik, train):
+    """`weighted_first: False` (every neighbour decoded, SDFs blended; utils/mapper.py:679-680) against the oracle: the
+    fused iteration of csrc/train_wf0.hip on the hoisted schedule (pipeline 1: numerical / no eikonal term, layer norm,
+    frozen decoder) and the un-fused loop over the HIP autograd ops it replaced (pipeline 0)."""
     p = gio.load("pool.npz")
-    g = gio.load("g6_loop_numerical_train_ln0.npz")
-    bs, iters = 2048, 2
-    cfg = env.config(weighted_first=False, bs=bs)
+    g = gio.load(f"g6_loop_numerical_train_ln{ln}.npz")
+    bs, iters = 2048, 3
+    cfg = env.config(weighted_first=False, layer_norm_on=bool(ln), bs=bs, ekional_loss_on=eik)
     gen = torch.Generator().manual_seed(9)
     idx = torch.randint(0, p["coord"].shape[0], (iters, bs), generator=gen)
     nm = env.neural_points(cfg, base=p)
     dec = env.decoder(cfg, g, "init_")
+    if not train:
+        for q in dec.parameters():
+            q.requires_grad_(False)
     mp, _ = env.mapper(cfg, nm, dec)
+    mp.pipeline = pipeline
     mp.mapping(iters, index_seq=idx.cuda())
-    st = gio.map_state(weighted_first=False)
+    st = gio.map_state(weighted_first=False, layer_norm_on=bool(ln))
     m = gio.T(g["local_mask"])
     st.local_geo_features = gio.T(p["base_geo_features"])[m].clone()
     st.local_point_certainties = gio.T(p["base_point_certainties"])[m[:-1]].clone()
     st.local_point_ts_update = gio.T(p["base_point_ts_update"])[m[:-1]].clone()
     pool, _ = gio.sample_pool()
     od = gio.decoder(g, "init_")
-    recs = O.mapping_iters(st, od, pool, idx, O.LoopConfig(), record=True)
+    recs = O.mapping_iters(st, od, pool, idx, O.LoopConfig(ekional_loss_on=eik, train_decoder=train), record=True)
     got = mp.last_losses.cpu()
     for it, r in enumerate(recs):
-        assert abs(float(got[it, 0]) - float(r["loss"])) <= 1e-5
+        assert abs(float(got[it, 0]) - float(r["loss"])) <= 1e-5, (it, got[it], r["loss"])
+        if eik:
+            assert abs(float(got[it, 2]) - float(r["eikonal_loss"])) <= 1e-5
     assert maxerr(nm.local_geo_features, recs[-1]["theta"]) <= 1e-4
     for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
-        assert maxerr(t, o) <= 1e-4
+        assert maxerr(t, o) <= (1e-4 if train else 0.0)
+    assert maxerr(nm.local_point_certainties, recs[-1]["certainties"]) <= 2e-3
+    assert torch.equal(nm.local_point_ts_update.cpu(), st.local_point_ts_update)
 
 
 def test_default_buffer_size_scene_vs_oracle(env):
