@@ -1763,7 +1763,7 @@ extern "C" int clid_train_decode(const clid_map_view* mv, const clid_train_args*
   if (a->eikonal_mode == 2) {  // loss.numerical_grad_on: False: the analytic iteration from the records (csrc/train_analytic.hip)
     if (int e = clid_launch_train_analytic(mv, a, ws.partial, rec, s)) return e;
   } else if (a->decode_each_neighbour) {  // neuralpoints.weighted_first: False (csrc/train_wf0.hip)
-    if (int e = clid_launch_train_wf0(mv, a, ws.partial, tmap, rec, s)) return e;
+    if (int e = clid_launch_train_wf0(mv, a, ws.partial, tmap, const_cast<float*>(rec), s)) return e;
   } else if (variant) {
     if (int e = clid_launch_decode_tile(mv, a, ws.partial, tmap, rec, variant == 2 ? 1 : 0, s)) return e;
   } else {

@@ -306,6 +306,6 @@ int clid_decode_tile_blocks(int n_tasks);
 bool clid_tiles_prenumbered(int n_tasks, const clid_map_view* mv);  // does the decode launch read the search launch's number blocks?
 // host-side launchers of the analytic-eikonal iteration (train_analytic.hip)
 int clid_train_wf0_rows(int n_tasks, int n_fd);  // csrc/train_wf0.hip (`weighted_first: False`)
-int clid_launch_train_wf0(const clid_map_view* mv, const clid_train_args* a, float* partial, const clid::TaskMap& tmap, const float* rec, hipStream_t s);
+int clid_launch_train_wf0(const clid_map_view* mv, const clid_train_args* a, float* partial, const clid::TaskMap& tmap, float* rec, hipStream_t s);  // rec: the copies' label / weight fields are scratch
 int clid_launch_train_analytic(const clid_map_view* mv, const clid_train_args* a, float* partial, const float* rec, hipStream_t s);  // rec: the hoisted search's records, or NULL (search inside)
 int clid_train_analytic_blocks(int bs);

@@ -8,10 +8,12 @@
 //
 // Six decoder evaluations per query point instead of one, so the finite-difference coupling is resolved BETWEEN launches
 // instead of inside a wave (three launches per iteration, 16 lanes per query as csrc/train_analytic.hip):
-//   pass 0  shifted copies, forward only           -> sdf_fd [6][n_fd]
-//   pass 1  batch samples: forward, BCE; on the decimation lattice the eikonal term from sdf_fd and its upstream gradients
-//           -> dsdf_fd [6][n_fd]; backward of the sample
-//   pass 2  shifted copies again: forward, backward with the upstream of dsdf_fd
+//   pass 0  shifted copies, forward only: SDF -> the copy's record slot
+//   pass 1  batch samples: forward, BCE; a decimated sample also reads its six copies' SDFs (same task record), adds the
+//           eikonal term and leaves the copies' upstream gradients in their slots; backward of the sample
+//   pass 2  shifted copies again: forward, backward with that upstream gradient
+// The two scratch values of a shifted copy live in the label / loss-weight fields of ITS OWN record slot (qdesc.z / .w, which
+// mean nothing for a copy): no side buffer, no capacity bound, and a record can be decoded again (pass 0 rewrites them).
 // Per neighbour k the backward is the single-query decoder backward (train_common.hpp mlp_backward) with dz = s w_k dL/dsdf;
 // the rows' gradients go through the layer-norm backward on the two lanes that loaded the row and out as 4-float atomics.
 #include "train_common.hpp"
@@ -19,8 +21,11 @@
 namespace clid {
 
 constexpr int kWf0Block = 256, kWf0Groups = kWf0Block / CLID_G;  // 16 query points per block and round
-constexpr int kWf0MaxBlocks = 256;    // partial rows per gradient pass
-constexpr int kWf0ScratchRow = 512;   // sdf_fd / dsdf_fd live in the partial-row buffer from this row on
+#ifndef CLID_WF0_BLOCKS
+#define CLID_WF0_BLOCKS 512
+#endif
+constexpr int kWf0MaxBlocks = CLID_WF0_BLOCKS;  // per pass; passes 1 and 2 leave one partial row per block
+static_assert(2 * kWf0MaxBlocks <= kMaxBwdBlocks, "partial rows");
 
 struct Wf0Lds {
   float v[kWf0Groups][CLID_K][12];  // per query group and neighbour: the decoder input (11) | 1 (the bias column of dW1)
@@ -28,8 +33,7 @@ struct Wf0Lds {
 
 template <int PASS>
 __global__ void __launch_bounds__(kWf0Block)
-k_train_wf0(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, int row_base, TaskMap tmap, const float4* __restrict__ rec,
-            float* __restrict__ sdf_fd, float* __restrict__ dsdf_fd) {
+k_train_wf0(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, int row_base, TaskMap tmap, float4* __restrict__ rec) {
   __shared__ MlpLds mlp;
   __shared__ Wf0Lds wl;
   __shared__ float red[(kWf0Block / 64) * kRedFloats];
@@ -47,20 +51,22 @@ k_train_wf0(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, i
   const float inv_two_eps = fdiv(1.0f, 2.0f * ta.fd_eps);
   const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
   const float sc = ta.sdf_scale;
-  const int n_slots = tmap.n_tasks * 8, n_fd = tmap.n_fd;
+  const int n_fd = tmap.n_fd;
+  const int n_slots = (PASS == 1 ? tmap.n_tasks : n_fd) * 8;  // the shifted copies live in the bundle tasks 0 .. n_fd-1 (train_common.hpp TaskMap)
   const bool train = ta.train_decoder != 0;
 
   for (int u0 = blockIdx.x * kWf0Groups; u0 < n_slots; u0 += gridDim.x * kWf0Groups) {
     const int u = u0 + gib;
     const bool inr = u < n_slots;
-    const float4* r = rec + (size_t)((inr ? u : 0) >> 3) * 48;  // qinfo[8] | qdesc[8] | win[8][8] float2
-    const int slot = (inr ? u : 0) & 7;
+    const int task = (inr ? u : 0) >> 3, slot = (inr ? u : 0) & 7;
+    float4* r = rec + (size_t)task * 48;  // qinfo[8] | qdesc[8] | win[8][8] float2
     const float4 qi = r[slot], qd = r[8 + slot];
     const int p = __float_as_int(qd.x), code = __float_as_int(qd.y);
     const bool act = inr && p >= 0 && (PASS == 1 ? code < 0 : code >= 0);
-    const int lat = p - tmap.first;  // position on the decimation lattice
-    const int jfd = (lat >= 0 && n_fd > 0) ? lat / tmap.decim : 0;
-    const bool on_lattice = n_fd > 0 && lat >= 0 && lat - jfd * tmap.decim == 0 && jfd < n_fd;
+    // bundle task j < n_fd (train_common.hpp task_query): slots 0..5 = the copies x+ x- y+ y- z+ z- (code = slot ^ 1),
+    // slot 6 = the decimated sample itself, slot 7 = the sample in front of it
+    const bool on_lattice = task < n_fd && slot == 6;
+    float* scratch = reinterpret_cast<float*>(r + 8);  // qdesc[s] = scratch[4 s ..]: .z = SDF of copy s, .w = its upstream gradient
     const float2* win = reinterpret_cast<const float2*>(r + 16) + slot * 8;
     float w6[CLID_K];
     float my_w = 0.f;
@@ -126,7 +132,7 @@ k_train_wf0(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, i
     }
 
     if (PASS == 0) {
-      if (act && lane16 == 0) sdf_fd[(size_t)code * n_fd + jfd] = sdf;
+      if (act && lane16 == 0) scratch[4 * slot + 2] = sdf;
       wave_lds_fence();
       continue;
     }
@@ -144,20 +150,20 @@ k_train_wf0(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, i
         if (lane16 == 0) bce_acc += wt * li;
         dsdf = wt * (sg - tgt) * inv_sigma * ta.inv_n_main;
         if (on_lattice && ta.weight_e > 0.f) {  // numerical eikonal term of this sample (mapper.py:1011-1013, 795-797)
-          const float gx = (sdf_fd[(size_t)1 * n_fd + jfd] - sdf_fd[(size_t)0 * n_fd + jfd]) * inv_two_eps;
-          const float gy = (sdf_fd[(size_t)3 * n_fd + jfd] - sdf_fd[(size_t)2 * n_fd + jfd]) * inv_two_eps;
-          const float gz = (sdf_fd[(size_t)5 * n_fd + jfd] - sdf_fd[(size_t)4 * n_fd + jfd]) * inv_two_eps;
+          const float gx = (scratch[4 * 0 + 2] - scratch[4 * 1 + 2]) * inv_two_eps;
+          const float gy = (scratch[4 * 2 + 2] - scratch[4 * 3 + 2]) * inv_two_eps;
+          const float gz = (scratch[4 * 4 + 2] - scratch[4 * 5 + 2]) * inv_two_eps;
           const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
           if (lane16 == 0) eik_acc += (nrm - 1.f) * (nrm - 1.f);
           const float ecoef = nrm > 0.f ? ta.weight_e * 2.f * (nrm - 1.f) * ta.inv_n_eik * inv_two_eps / nrm : 0.f;
-          if (lane16 < 6) {  // code = 2 axis + (sign > 0)
+          if (lane16 < 6) {  // slot s: axis s >> 1, the + copy on the even slot
             const float ga = lane16 < 2 ? gx : (lane16 < 4 ? gy : gz);
-            dsdf_fd[(size_t)lane16 * n_fd + jfd] = ((lane16 & 1) ? 1.f : -1.f) * ecoef * ga;
+            scratch[4 * lane16 + 3] = ((lane16 & 1) ? -1.f : 1.f) * ecoef * ga;
           }
         }
       }
     } else {
-      dsdf = act ? dsdf_fd[(size_t)code * n_fd + jfd] : 0.f;
+      dsdf = act ? scratch[4 * slot + 3] : 0.f;
     }
 
     // ================= training_mode side effects (np.py:708-733): batch samples and shifted copies alike
@@ -228,23 +234,15 @@ static int wf0_blocks(int n_tasks) {
   return nb > kWf0MaxBlocks ? kWf0MaxBlocks : (nb < 1 ? 1 : nb);
 }
 // partial rows an iteration leaves for clid_train_adam: one set per gradient pass
-int clid_train_wf0_rows(int n_tasks, int n_fd) { return wf0_blocks(n_tasks) * (n_fd > 0 ? 2 : 1); }
+int clid_train_wf0_rows(int n_tasks, int n_fd) { return wf0_blocks(n_tasks) + (n_fd > 0 ? wf0_blocks(n_fd) : 0); }
 
-int clid_launch_train_wf0(const clid_map_view* mv, const clid_train_args* a, float* partial, const TaskMap& tmap, const float* rec,
+int clid_launch_train_wf0(const clid_map_view* mv, const clid_train_args* a, float* partial, const TaskMap& tmap, float* rec,
                           hipStream_t s) {
-  if ((long long)12 * tmap.n_fd > (long long)(kMaxBwdBlocks - kWf0ScratchRow) * kPartialStride || kWf0ScratchRow < 2 * kWf0MaxBlocks) {
-    clid_set_error("clid_train_decode (weighted_first = False): %d decimated samples exceed the workspace", tmap.n_fd);
-    return CLID_E_SHAPE;
-  }
-  const int nb = wf0_blocks(tmap.n_tasks);
-  float* sdf_fd = partial + (size_t)kWf0ScratchRow * kPartialStride;
-  float* dsdf_fd = sdf_fd + (size_t)6 * tmap.n_fd;
-  const float4* r4 = reinterpret_cast<const float4*>(rec);
-  if (tmap.n_fd > 0)
-    CLID_KLAUNCH(a->prof, 0, k_train_wf0<0>, dim3(nb), dim3(kWf0Block), 0, s, *mv, *a, partial, 0, tmap, r4, sdf_fd, dsdf_fd);
-  CLID_KLAUNCH(a->prof, 0, k_train_wf0<1>, dim3(nb), dim3(kWf0Block), 0, s, *mv, *a, partial, 0, tmap, r4, sdf_fd, dsdf_fd);
-  if (tmap.n_fd > 0)
-    CLID_KLAUNCH(a->prof, 0, k_train_wf0<2>, dim3(nb), dim3(kWf0Block), 0, s, *mv, *a, partial, nb, tmap, r4, sdf_fd, dsdf_fd);
+  const int nb = wf0_blocks(tmap.n_tasks), nb_fd = wf0_blocks(tmap.n_fd);
+  float4* r4 = reinterpret_cast<float4*>(rec);
+  if (tmap.n_fd > 0) CLID_KLAUNCH(a->prof, 0, k_train_wf0<0>, dim3(nb_fd), dim3(kWf0Block), 0, s, *mv, *a, partial, 0, tmap, r4);
+  CLID_KLAUNCH(a->prof, 0, k_train_wf0<1>, dim3(nb), dim3(kWf0Block), 0, s, *mv, *a, partial, 0, tmap, r4);
+  if (tmap.n_fd > 0) CLID_KLAUNCH(a->prof, 0, k_train_wf0<2>, dim3(nb_fd), dim3(kWf0Block), 0, s, *mv, *a, partial, nb, tmap, r4);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

@@ -292,7 +292,9 @@ typedef struct clid_train_args {
   /* 1 = `neuralpoints.weighted_first: False` (utils/mapper.py:679-680): every neighbour's own decoder input is decoded and
    * the K SDFs are blended with the IDW weights, for the samples and the shifted copies alike (csrc/train_wf0.hip).
    * Hoisted schedule (clid_train_search / clid_train_decode / clid_mapping_run*), eikonal modes 0 and 1, plain exchange;
-   * 0 (the reference's default, every shipped config) = decode the blended input. */
+   * 0 (the reference's default, every shipped config) = decode the blended input.  clid_train_decode then keeps two
+   * intermediate values per shifted copy in the copy's own record slot (the label / weight fields, unused for a copy): the
+   * one case in which it writes to `rec`. */
   int32_t decode_each_neighbour;
 } clid_train_args;
 
