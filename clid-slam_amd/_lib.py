@@ -120,6 +120,7 @@ _SIGS = {
     "clid_voxel_down_sample": (C.c_int, [_vp, _i32, _f32, _vp, _vp, _vp]),
     "clid_voxel_down_sample_launch": (C.c_int, [_vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "clid_voxel_down_sample_finish": (C.c_int, [_i32, _vp, _vp, _vp]),
+    "clid_voxel_down_sample_async": (C.c_int, [_vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "clid_voxel_down_sample_min_value": (C.c_int, [_vp, _i32, _f32, _vp, _vp, _vp, _vp]),
     "clid_map_rehash": (C.c_int, [_vp, _vp, _i32, _f32, _vp, _i64, _vp]),
     "clid_map_gather": (C.c_int, [_vp, _i32, _i64] + [_vp] * 13),
@@ -129,9 +130,9 @@ _SIGS = {
     "clid_pool_filter": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(C.c_double), C.c_double,
                                    _i64, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clid_cloud_workspace_bytes": (_i64, [_i64]),
-    "clid_cloud_update": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _f32, C.POINTER(C.c_double), C.c_double, _i32, _vp, _vp, _vp, _vp]),
+    "clid_cloud_update": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _f32, C.POINTER(C.c_double), C.c_double, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clid_map_insert_workspace_bytes": (_i64, [_i32]),
-    "clid_map_insert": (C.c_int, [_vp, _i32, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp]),
+    "clid_map_insert": (C.c_int, [_vp, _i32, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clid_local_window_workspace_bytes": (_i64, [_i64]),
     "clid_local_window": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _i32, C.POINTER(C.c_double), C.c_double, _i32,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),

@@ -26,7 +26,7 @@ struct VoxStats {
   unsigned count;    // number of occupied voxels (filled by the compaction)
   long long stride;  // v = max over axes of (cell - offset), the reference's linearisation stride
   unsigned overflow; // the bucketed ordering gave up (a bucket beyond its capacity): the caller orders with the library
-  unsigned pad;
+  unsigned spilled;  // ... or, without a host in the loop (clid_voxel_down_sample_async), entries parked in the spill list
 };
 
 __device__ __forceinline__ int ordered(float f) {
@@ -123,6 +123,7 @@ __global__ void k_vox_init(VoxStats* st, int* box) {
     st->count = 0u;
     st->stride = 0;
     st->overflow = 0u;
+    st->spilled = 0u;
   }
 }
 
@@ -281,7 +282,8 @@ __global__ void __launch_bounds__(kVbThreads) k_vox_splitters(const float* __res
 __global__ void __launch_bounds__(256) k_vox_partition(const long long* __restrict__ keys, const unsigned long long* __restrict__ vals,
                                                        int log2cap, VoxStats* st, const long long* __restrict__ split,
                                                        unsigned* __restrict__ bucket_cnt, long long* __restrict__ bkeys,
-                                                       long long* __restrict__ bidx) {
+                                                       long long* __restrict__ bidx, long long* __restrict__ spill_keys,
+                                                       long long* __restrict__ spill_idx) {
   __shared__ long long sp[kVbBuckets];
   for (int i = threadIdx.x; i < kVbBuckets - 1; i += blockDim.x) sp[i] = split[i];
   __syncthreads();
@@ -294,7 +296,13 @@ __global__ void __launch_bounds__(256) k_vox_partition(const long long* __restri
     if (b + step <= kVbBuckets - 1 && sp[b + step - 1] <= k) b += step;
   const unsigned pos = atomicAdd(&bucket_cnt[b * kVbCntStride], 1u);
   if (pos >= (unsigned)kVbCap) {
-    st->overflow = 1u;
+    if (spill_keys) {  // no host in the loop: parked for k_vox_bucket_big
+      const unsigned q = atomicAdd(&st->spilled, 1u);
+      spill_keys[q] = k;
+      spill_idx[q] = (long long)(vals[h] & 0xffffffffULL);
+    } else {
+      st->overflow = 1u;
+    }
     return;
   }
   bkeys[(size_t)b * kVbCap + pos] = k;
@@ -341,12 +349,66 @@ __global__ void __launch_bounds__(kVbThreads) k_vox_bucket_sort(const unsigned* 
     if (tid == 0) st->count = (unsigned)below;
     below -= c;
   }
-  if (st->overflow || c == 0) return;  // (block-uniform)
+  if (st->overflow || c == 0 || c > kVbCap) return;  // (block-uniform; c > capacity only without a host in the loop: k_vox_bucket_big)
   const long long* bk = bkeys + (size_t)b * kVbCap;
   const long long* bi = bidx + (size_t)b * kVbCap;
   if (c <= kVbThreads) vb_emit<1>(c, below, bk, bi, sval, out);
   else if (c <= 2 * kVbThreads) vb_emit<2>(c, below, bk, bi, sval, out);
   else vb_emit<4>(c, below, bk, bi, sval, out);
+}
+
+// Without a host in the loop (clid_voxel_down_sample_async) a bucket beyond its capacity cannot fall back to the library's
+// sort, which needs the count on the host.  Its entries -- kVbCap stored, the rest in the spill list shared by all buckets --
+// are ranked by counting instead (ids are unique): quadratic, but correct for any input, and it never runs on LiDAR frames
+// (a bucket holds 1/512 of the voxels on average; beyond capacity = 35 x that at 6e4 voxels).  Always launched: block 0 also
+// publishes [number of voxels | ids too wide for the packed sort values] where the consumers' kernels read them.
+__global__ void __launch_bounds__(kVbThreads) k_vox_bucket_big(const unsigned* __restrict__ bucket_cnt, const long long* __restrict__ bkeys,
+                                                               const long long* __restrict__ bidx, const long long* __restrict__ spill_keys,
+                                                               const long long* __restrict__ spill_idx, const long long* __restrict__ split,
+                                                               const VoxStats* __restrict__ st, long long* __restrict__ out,
+                                                               long long* __restrict__ count_out) {
+  __shared__ long long skey[kVbCap];
+  __shared__ unsigned wsum[kVbThreads / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b == 0 && tid == 0) {
+    const unsigned long long sd = (unsigned long long)st->stride;
+    const unsigned long long top = sd * (1ULL + sd + sd * sd);
+    int bits = 1;
+    while (bits < 63 && (top >> bits)) ++bits;
+    count_out[0] = (long long)st->count;
+    count_out[1] = bits <= 64 - kVbPosBits - 1 ? 0 : 1;
+  }
+  const int c = (int)bucket_cnt[b * kVbCntStride];
+  if (c <= kVbCap) return;  // (block-uniform)
+  unsigned mine = tid < b ? bucket_cnt[tid * kVbCntStride] : 0u;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if ((tid & 63) == 0) wsum[tid >> 6] = mine;
+  for (int i = tid; i < kVbCap; i += kVbThreads) skey[i] = bkeys[(size_t)b * kVbCap + i];
+  __syncthreads();
+  long long below = 0;
+  for (int w = 0; w < kVbThreads / 64; ++w) below += wsum[w];
+  const bool has_lo = b > 0, has_hi = b < kVbBuckets - 1;
+  const long long lo = has_lo ? split[b - 1] : 0, hi = has_hi ? split[b] : 0;  // bucket b: split[b-1] <= id < split[b]
+  const int S = (int)st->spilled;
+  for (int e = tid; e < kVbCap + S; e += kVbThreads) {
+    long long k, src;
+    if (e < kVbCap) {
+      k = skey[e];
+      src = bidx[(size_t)b * kVbCap + e];
+    } else {
+      k = spill_keys[e - kVbCap];
+      if ((has_lo && k < lo) || (has_hi && k >= hi)) continue;  // another bucket's
+      src = spill_idx[e - kVbCap];
+    }
+    long long rank = 0;
+    for (int i = 0; i < kVbCap; ++i) rank += skey[i] < k ? 1 : 0;
+    for (int i = 0; i < S; ++i) {
+      const long long o = spill_keys[i];
+      rank += (o < k && !(has_lo && o < lo)) ? 1 : 0;  // (o < k < hi already)
+    }
+    out[below + rank] = src;
+  }
 }
 
 struct Pose12 {
@@ -615,9 +677,12 @@ __global__ void __launch_bounds__(256) k_window_gather(WindowArgs a, const int* 
 // naming one slot the LAST one wins, whether it was taken or not) and the append of positions / orientations / stamps /
 // certainties -- ~45 torch ops incl. an argsort in the reference-style chain, four launches + a scan here.
 struct InsertArgs {
-  const float* samples; int n;            // voxel-down-sampled points [n][3]
+  const float* samples; int n;            // voxel-down-sampled points [n][3] ...
+  const long long* s_idx;                 // ... or, with a list: sample i = row s_idx[i] of `samples`,
+  const long long* n_dev;                 //     i < *n_dev (n is then the upper bound the grids are sized for)
   long long* table; int buffer_size;      // buffer_pt_index
   float* points; float* orient; int* ts_create; int* ts_update; float* cert;  // global arrays with room for n more rows
+  float4* feat;                           // optional: feature rows of the added points and the padding row behind them <- 0
   const float* travel;                    // travel_dist or NULL
   long long base;                         // points in the map before the insert
   int test_on;                            // 0: empty map / reboot frame -> every sample is taken (:370-371)
@@ -630,7 +695,12 @@ __global__ void __launch_bounds__(256) k_insert_probe(InsertArgs a, int* __restr
                                                       int* __restrict__ flag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
-  const float x = a.samples[i * 3 + 0], y = a.samples[i * 3 + 1], z = a.samples[i * 3 + 2];
+  if (a.n_dev && i >= *a.n_dev) {  // beyond the device-side count: takes part in the scan as "not taken"
+    flag[i] = 0;
+    return;
+  }
+  const long long r = a.s_idx ? a.s_idx[i] : (long long)i;
+  const float x = a.samples[r * 3 + 0], y = a.samples[r * 3 + 1], z = a.samples[r * 3 + 2];
   const int slot = base_slot(x, y, z, a.res, a.buffer_size);  // == fmod(sum cell*prime, B) taken non-negative (:355-361)
   const long long h = a.table[slot];
   bool take = true;
@@ -648,7 +718,7 @@ __global__ void __launch_bounds__(256) k_insert_probe(InsertArgs a, int* __restr
 }
 __global__ void __launch_bounds__(256) k_insert_claim(InsertArgs a, const int* __restrict__ phys) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
+  if (i >= a.n || (a.n_dev && i >= *a.n_dev)) return;
   atomicMax(reinterpret_cast<long long*>(&a.table[phys[i]]), kClaimBase + i);
 }
 __global__ void __launch_bounds__(256) k_insert_commit(InsertArgs a, const int* __restrict__ phys, const long long* __restrict__ held,
@@ -656,16 +726,29 @@ __global__ void __launch_bounds__(256) k_insert_commit(InsertArgs a, const int* 
                                                        long long* __restrict__ counts) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
-  if (i == a.n - 1) counts[0] = pos[i] + flag[i];
+  if (i == a.n - 1) {
+    counts[0] = pos[i] + flag[i];
+    if (a.feat) {  // the padding row moves behind the last added point (zero-initialised features: geo_feature_std == 0)
+      const long long pad = a.base + pos[i] + flag[i];
+      a.feat[pad * 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+      a.feat[pad * 2 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (a.n_dev && i >= *a.n_dev) return;
   const bool take = flag[i] != 0;
   const long long dst = a.base + pos[i];
   if (a.table[phys[i]] == kClaimBase + i) a.table[phys[i]] = take ? dst : held[i];  // the last sample naming this slot decides it
   if (!take) return;
-  a.points[dst * 3 + 0] = a.samples[i * 3 + 0]; a.points[dst * 3 + 1] = a.samples[i * 3 + 1]; a.points[dst * 3 + 2] = a.samples[i * 3 + 2];
+  const long long r = a.s_idx ? a.s_idx[i] : (long long)i;
+  a.points[dst * 3 + 0] = a.samples[r * 3 + 0]; a.points[dst * 3 + 1] = a.samples[r * 3 + 1]; a.points[dst * 3 + 2] = a.samples[r * 3 + 2];
   reinterpret_cast<float4*>(a.orient)[dst] = make_float4(1.f, 0.f, 0.f, 0.f);
   a.ts_create[dst] = a.cur_ts;
   a.ts_update[dst] = a.cur_ts;
   a.cert[dst] = 0.f;
+  if (a.feat) {
+    a.feat[dst * 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    a.feat[dst * 2 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 }
 
 // ---- raw-point map maintenance (model/local_point_cloud_map.py:43-72) -------------------------------------------------
@@ -684,7 +767,9 @@ __device__ __forceinline__ int cloud_slot(float x, float y, float z, float res, 
 }
 struct CloudArgs {
   const float* old_pts; long long n_a;   // map before the update
-  const float* samples; long long n_s;   // voxel-down-sampled scan points (world frame)
+  const float* samples; long long n_s;   // voxel-down-sampled scan points (world frame) ...
+  const long long* s_idx;                // ... or, with a list: sample i = row s_idx[i] of `samples`,
+  const long long* n_s_dev;              //     i < *n_s_dev (n_s is then the upper bound the grids are sized for)
   const long long* table_old; long long* table_new; int buffer_size;
   float res;
   double sx, sy, sz, map_size;
@@ -705,8 +790,9 @@ __global__ void __launch_bounds__(256) k_cloud_flags(CloudArgs a, int* __restric
     bool fresh = false, keep = false;
     if (i < a.n_a) {
       keep = cloud_near(a, a.old_pts + i * 3);
-    } else {
-      const float* p = a.samples + (i - a.n_a) * 3;
+    } else if (!a.n_s_dev || i - a.n_a < *a.n_s_dev) {
+      const long long r = i - a.n_a;
+      const float* p = a.samples + (a.s_idx ? a.s_idx[r] : r) * 3;
       fresh = a.table_old[cloud_slot(p[0], p[1], p[2], a.res, a.buffer_size)] == -1;  // :49-56: slot still empty
       keep = fresh && cloud_near(a, p);
     }
@@ -730,7 +816,7 @@ __global__ void __launch_bounds__(256) k_cloud_scatter(CloudArgs a, const int* _
   if (i >= n) return;
   if (i == n - 1) counts[0] = pos[i] + flag[i];
   if (!flag[i]) return;
-  const float* p = i < a.n_a ? a.old_pts + i * 3 : a.samples + (i - a.n_a) * 3;
+  const float* p = i < a.n_a ? a.old_pts + i * 3 : a.samples + (a.s_idx ? a.s_idx[i - a.n_a] : i - a.n_a) * 3;
   const long long j = pos[i];
   out[j * 3 + 0] = p[0]; out[j * 3 + 1] = p[1]; out[j * 3 + 2] = p[2];
   // the rebuilt table: several points may share a slot, the largest index stays (:69-71, amax == last writer)
@@ -844,7 +930,7 @@ extern "C" int64_t clid_voxel_workspace_bytes(int32_t n) {
 }
 
 static int vox_launch(const float* points, int32_t n, float voxel_size, const float* value, void* workspace,
-                      int64_t* idx_out, void* stream, const int64_t* n_dev_in = nullptr) {
+                      int64_t* idx_out, void* stream, const int64_t* n_dev_in = nullptr, int64_t* count_out_dev = nullptr) {
   const long long* n_dev = reinterpret_cast<const long long*>(n_dev_in);
   if (n < 0 || !(voxel_size > 0.f) || (n > 0 && (!points || !workspace || !idx_out))) {
     clid_set_error("clid_voxel_down_sample: bad argument");
@@ -880,9 +966,14 @@ static int vox_launch(const float* points, int32_t n, float voxel_size, const fl
   const bool bucketed = n <= (1 << 21);  // beyond: the buckets would overflow anyway
   if (bucketed) {
     hipLaunchKernelGGL(k_vox_splitters, dim3(1), dim3(kVbThreads), 0, s, points, n, voxel_size, box, split, bcnt, n_dev);
-    hipLaunchKernelGGL(k_vox_partition, dim3(table_blocks1k * 4), dim3(256), 0, s, keys, vals, log2cap, st, split, bcnt, bkeys, bidx);
+    // count_out_dev: nobody will come back for the count (or for an overflowing bucket): spill list + k_vox_bucket_big
+    hipLaunchKernelGGL(k_vox_partition, dim3(table_blocks1k * 4), dim3(256), 0, s, keys, vals, log2cap, st, split, bcnt, bkeys, bidx,
+                       count_out_dev ? flat_a : nullptr, count_out_dev ? idx_a : nullptr);
     hipLaunchKernelGGL(k_vox_bucket_sort, dim3(kVbBuckets), dim3(kVbThreads), 0, s, bcnt, bkeys, bidx, st,
                        reinterpret_cast<long long*>(idx_out));
+    if (count_out_dev)
+      hipLaunchKernelGGL(k_vox_bucket_big, dim3(kVbBuckets), dim3(kVbThreads), 0, s, bcnt, bkeys, bidx, flat_a, idx_a, split, st,
+                         reinterpret_cast<long long*>(idx_out), reinterpret_cast<long long*>(count_out_dev));
   } else {
     hipLaunchKernelGGL(k_vox_compact, dim3(table_blocks1k), dim3(1024), 0, s, keys, vals, log2cap, st, flat_a, idx_a);
   }
@@ -951,6 +1042,17 @@ extern "C" int clid_voxel_down_sample_launch(const float* points, int32_t n, flo
 }
 extern "C" int clid_voxel_down_sample_finish(int32_t n, void* workspace, int64_t* idx_out, void* stream) {
   return vox_finish(n, workspace, idx_out, stream);
+}
+// The whole pass without a host round trip: count_out (device int64[2]) receives [number of voxels m | 1 if the voxel ids
+// were too wide for the device-side ordering (then idx_out is not ordered: the caller treats the frame as failed)] and
+// idx_out[0..m) the indices; consumers take both on the device (clid_cloud_update / clid_map_insert with sample_idx).
+extern "C" int clid_voxel_down_sample_async(const float* points, int32_t n, float voxel_size, const int64_t* n_dev, void* workspace,
+                                            int64_t* idx_out, int64_t* count_out, void* stream) {
+  if (n <= 0 || n > (1 << 21) || !count_out) {
+    clid_set_error("clid_voxel_down_sample_async: 1 .. 2^21 points and a count block");
+    return CLID_E_ARG;
+  }
+  return vox_launch(points, n, voxel_size, nullptr, workspace, idx_out, stream, n_dev, count_out);
 }
 
 extern "C" int clid_voxel_down_sample(const float* points, int32_t n, float voxel_size, void* workspace,
@@ -1651,7 +1753,7 @@ extern "C" int clid_map_insert(const float* samples, int32_t n, int64_t* buffer_
                                float* neural_points, float* point_orientations, int32_t* ts_create, int32_t* ts_update,
                                float* certainties, int64_t base, const float* travel_dist, int32_t cur_ts, int32_t test_on,
                                int32_t temporal, float far_dist2, float diff_travel, int64_t* count_out, void* workspace,
-                               void* stream) {
+                               const int64_t* sample_idx, const int64_t* n_dev, float* features_zero, void* stream) {
   if (n < 0 || !buffer_pt_index || buffer_size <= 0 || buffer_size >= (1LL << 30) || !count_out || !workspace || base < 0 ||
       (n > 0 && (!samples || !neural_points || !point_orientations || !ts_create || !ts_update || !certainties)) ||
       (test_on && temporal && !travel_dist)) {
@@ -1668,8 +1770,9 @@ extern "C" int clid_map_insert(const float* samples, int32_t n, int64_t* buffer_
   long long* held = reinterpret_cast<long long*>(ws + 3 * align256((size_t)n * 4));
   void* cub = ws + 3 * align256((size_t)n * 4) + align256((size_t)n * 8);
   size_t cub_bytes = pool_scan_bytes(n);
-  InsertArgs a{samples, n, reinterpret_cast<long long*>(buffer_pt_index), (int)buffer_size, neural_points, point_orientations,
-               ts_create, ts_update, certainties, travel_dist, (long long)base, test_on, temporal, cur_ts, resolution, far_dist2,
+  InsertArgs a{samples, n, reinterpret_cast<const long long*>(sample_idx), reinterpret_cast<const long long*>(n_dev),
+               reinterpret_cast<long long*>(buffer_pt_index), (int)buffer_size, neural_points, point_orientations,
+               ts_create, ts_update, certainties, reinterpret_cast<float4*>(features_zero), travel_dist, (long long)base, test_on, temporal, cur_ts, resolution, far_dist2,
                diff_travel};
   const unsigned blocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_insert_probe, dim3(blocks), dim3(256), 0, s, a, phys, held, flag);
@@ -1692,7 +1795,8 @@ extern "C" int64_t clid_cloud_workspace_bytes(int64_t n_total) {
 extern "C" int clid_cloud_update(const float* map_points, int64_t n_map, const float* samples, int64_t n_samples,
                                  const int64_t* table_old, int64_t* table_new, int64_t buffer_size, float resolution,
                                  const double* sensor_pos_host, double map_size, int32_t pos_is_f64, float* points_out,
-                                 int64_t* counts_out, void* workspace, void* stream) {
+                                 int64_t* counts_out, void* workspace, const int64_t* sample_idx, const int64_t* n_samples_dev,
+                                 void* stream) {
   const long long n = n_map + n_samples;
   if (n_map < 0 || n_samples < 0 || n >= (1LL << 31) || !table_old || !table_new || table_old == table_new || buffer_size <= 0 ||
       buffer_size >= (1LL << 30) || !sensor_pos_host || !counts_out || !workspace || (n_map > 0 && !map_points) ||
@@ -1713,7 +1817,8 @@ extern "C" int clid_cloud_update(const float* map_points, int64_t n_map, const f
   int* pos = reinterpret_cast<int*>(ws + align256((size_t)n * 4));
   void* cub = ws + 2 * align256((size_t)n * 4);
   size_t cub_bytes = pool_scan_bytes(n);
-  CloudArgs a{map_points, n_map, samples, n_samples, reinterpret_cast<const long long*>(table_old),
+  CloudArgs a{map_points, n_map, samples, n_samples, reinterpret_cast<const long long*>(sample_idx),
+              reinterpret_cast<const long long*>(n_samples_dev), reinterpret_cast<const long long*>(table_old),
               reinterpret_cast<long long*>(table_new), (int)buffer_size, resolution, sensor_pos_host[0], sensor_pos_host[1],
               sensor_pos_host[2], map_size, pos_is_f64};
   const unsigned blocks = (unsigned)((n + 255) / 256);

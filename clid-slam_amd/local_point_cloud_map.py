@@ -13,7 +13,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .tools import voxel_down_sample_torch
+from .tools import voxel_down_sample_async, voxel_down_sample_torch
 
 
 class LocalPointCloudMap:
@@ -79,7 +79,19 @@ class LocalPointCloudMap:
         dev = points.device
         if getattr(self, "_count_pending", False):
             self._finish_count()
-        samples = points[voxel_down_sample_torch(points, self.resolution)].contiguous()
+        defer = getattr(self, "_defer_counts", None)
+        self._defer_counts = None
+        vox = self.__dict__.pop("_defer_vox", None)  # device int64[2] left by Mapper.process_frame: [voxel count | ordering failed]
+        s_idx = n_s_dev = None
+        if defer is not None and vox is not None:
+            # nothing on the host needs the scan's voxel count: the down-sampling stays in flight, the update takes its index
+            # list and count on the device (sized for every scan point), the caller reads the block with the frame's last read-back
+            scan = points.contiguous()
+            s_idx = voxel_down_sample_async(scan, self.resolution, vox)
+        if s_idx is not None:
+            samples, n_s_dev = scan, vox[0:1]
+        else:
+            samples = points[voxel_down_sample_torch(points, self.resolution)].contiguous()
         old = self.local_point_cloud_map.contiguous()
         n_a, n_s = int(old.shape[0]), int(samples.shape[0])
         n = n_a + n_s
@@ -101,30 +113,34 @@ class LocalPointCloudMap:
         if getattr(self, "_cloud_ws", None) is None or self._cloud_ws.numel() < need or self._cloud_ws.device != dev:
             self._cloud_ws = torch.empty(int(need * 1.5) + 1024, device=dev, dtype=torch.uint8)
             self._cloud_counts = torch.zeros(2, device=dev, dtype=torch.int64)
-        defer = getattr(self, "_defer_counts", None)
-        self._defer_counts = None
         counts = defer if defer is not None else self._cloud_counts
         _lib.check(lib.clid_cloud_update(
             old.data_ptr(), n_a, samples.data_ptr(), n_s, self.buffer_pt_index.data_ptr(), out_tab.data_ptr(), self.buffer_size,
             float(self.resolution), (C.c_double * 3)(*sp), float(self.map_size), int(sensor_position.dtype == torch.float64),
-            out_pts.data_ptr(), counts.data_ptr(), self._cloud_ws.data_ptr(), _lib.stream()), "clid_cloud_update")
+            out_pts.data_ptr(), counts.data_ptr(), self._cloud_ws.data_ptr(), _lib.ptr(s_idx), _lib.ptr(n_s_dev), _lib.stream()),
+            "clid_cloud_update")
         state["side"] = side
         self.buffer_pt_index = out_tab
         if defer is not None:
             # the caller reads the count later (Mapper.process_frame: with the frame's last read-back); until then the map is
             # its first n rows -- an upper bound: rows beyond the true count are referenced by no slot of the table
             self.local_point_cloud_map = out_pts[:n]
-            self._count_pending, self._pending = True, (out_pts, defer)
+            self._count_pending, self._pending = True, (out_pts, defer, vox if s_idx is not None else None)
             return True
         kept = _lib.read_counts(self._cloud_counts, 1)[0]  # the one host round trip (sizes the map)
         self.local_point_cloud_map = out_pts[:kept]
         return True
 
-    def _finish_count(self, kept=None):
-        """Settle a deferred update_map: `kept` as read by the caller, or one read-back here."""
-        out_pts, counts = self._pending
+    def _finish_count(self, kept=None, vox_failed=None):
+        """Settle a deferred update_map: `kept` (and the failure flag of the scan's voxel pass, when that stayed in flight) as
+        read by the caller, or read back here."""
+        out_pts, counts, vox = self._pending
         if kept is None:
             kept = _lib.read_counts(counts, 1)[0]
+            vox_failed = None if vox is None else _lib.read_counts(vox, 2)[1]
+        if vox is not None and vox_failed:
+            raise RuntimeError("voxel down-sampling of the scan: voxel ids too wide for the device-side ordering (a bounding box "
+                               "beyond 2^17 voxels per axis); CLID_ASYNC_VOXEL=0 takes the path with the library sort")
         self.local_point_cloud_map = out_pts[:int(kept)]
         self._count_pending, self._pending = False, None
 

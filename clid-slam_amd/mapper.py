@@ -17,6 +17,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -728,7 +729,25 @@ class Mapper:
             poses = self.dataset.gt_poses
         else:
             return
-        self.used_poses = torch.as_tensor(poses[: cur + 1], device=self.device, dtype=torch.float64)
+        src = poses[: cur + 1]
+        if isinstance(src, np.ndarray):
+            # uploaded when somebody reads `used_poses` (the un-fused pool path): a pageable host-to-device copy per frame
+            # synchronises the stream, and nothing on the fused path reads the tensor.  Copied now, as the reference's
+            # torch.tensor() copies now (odometry poses are updated in place later).
+            self._used_poses, self._used_poses_src = None, src.copy()
+        else:
+            self.used_poses = torch.as_tensor(src, device=self.device, dtype=torch.float64)
+
+    @property
+    def used_poses(self):
+        src = self.__dict__.get("_used_poses_src")
+        if src is not None:
+            self._used_poses, self._used_poses_src = torch.as_tensor(src, device=self.device, dtype=torch.float64), None
+        return self.__dict__.get("_used_poses")
+
+    @used_poses.setter
+    def used_poses(self, value):
+        self._used_poses, self._used_poses_src = value, None
 
     def dynamic_filter(self, points_torch, type_2_on: bool = True):
         """utils/mapper.py:99-136: static = not (certainly free space), and the SDF gradient looks sane."""
@@ -760,6 +779,7 @@ class Mapper:
             # the sampler's draws do not depend on the raw-point map: enqueued now, they are generated while the host waits
             # for the map update's round trips (same generator, same order as at their old place: nothing in between draws)
             self.sampler.predraw(pts.shape[0], pts.device)
+        async_vox = os.environ.get("CLID_ASYNC_VOXEL", "1") != "0"  # voxel passes whose counts nobody reads on their own
         if not use_pin:  # :178-183
             self.local_point_cloud_map._sensor_pos_host = (origin, tuple(float(v) for v in cur_pose_torch[:3, 3].tolist()))
             # the raw-point map's new size is needed by nobody before the frame's last read-back: it lands in the frame's
@@ -771,6 +791,8 @@ class Mapper:
                              and not getattr(cfg, "from_all_samples", False) and os.environ.get("CLID_FUSED_COMPACT", "1") != "0")
             self.local_point_cloud_map._defer_counts = (
                 self._frame_count_block(pts.device)[4:6] if fused_follows and os.environ.get("CLID_DEFER_CLOUD_COUNT", "1") != "0" else None)
+            if self.local_point_cloud_map._defer_counts is not None and async_vox:
+                self.local_point_cloud_map._defer_vox = self._frame_counts[8:10]
             self.local_point_cloud_map.update_map(origin, transform_torch(pts, cur_pose_torch))
         self.static_mask = torch.ones(pts.shape[0], dtype=torch.bool, device=pts.device)
         if filter_dynamic:  # :189-204
@@ -803,8 +825,9 @@ class Mapper:
                          and cur_pose_torch.dtype == torch.float64 and self.coord_pool.shape[0] + 8 * pts.shape[0] < (1 << 31)
                          and os.environ.get("CLID_FUSED_POOL", "1") != "0" and os.environ.get("CLID_POOL_OVERLAP", "1") != "0"
                          and os.environ.get("CLID_DEFER_COMPACT_COUNT", "1") != "0" and pts.shape[0] > 0)
-            coord, gcoord, sdf_label, weight, stamp, update_points = self._sample_compact_fused(pts, cur_pose_torch, frame_id,
-                                                                                               defer_counts=defer_cmp)
+            async_upd = defer_cmp and async_vox and nm.update_is_fused()
+            coord, gcoord, sdf_label, weight, stamp, update_points = self._sample_compact_fused(
+                pts, cur_pose_torch, frame_id, defer_counts=defer_cmp, counts=nm.update_counts(pts.device)[5:7] if async_upd else None)
         else:  # :240-245, the region-specific SDF estimation
             coord, sdf_label, weight = self.sampler.sample(pts, self.local_point_cloud_map, cur_pose_torch)
         n_cur = coord.shape[0]
@@ -837,18 +860,24 @@ class Mapper:
         # frame's largest, bandwidth-bound at a full pool) go to a side stream and run under NeuralPoints.update, whose
         # launches are small and separated by its read-backs; joined before anything reads the pool.
         overlap = fused_pool and gcoord is not None and os.environ.get("CLID_POOL_OVERLAP", "1") != "0"
+        vox_idx = None
         if overlap:
             # the map growth starts with a voxel down-sampling whose kernels starve next to the pool's 230-us five-array
             # compaction (k_vox_compact: 15 -> 187 us): it runs first, alone, and the pool work is forked behind it, next to
             # the insert / window launches that are small and separated by read-backs
             # Its launches go out first; the pool's launches (a side stream that waits for them) are prepared on the host
             # while they execute, and only then the down-sampling's round trip is made.
-            from .tools import voxel_down_sample_finish, voxel_down_sample_launch, voxel_down_sample_torch
+            from .tools import voxel_down_sample_async, voxel_down_sample_finish, voxel_down_sample_launch, voxel_down_sample_torch
 
             two_phase = update_points.is_cuda and update_points.shape[0] > 0
             cmp_dev = self._cmp_counts if defer_cmp else None  # [kept rows, near-surface rows] of the compaction, on the device
+            # The map growth's voxel pass stays in flight where the insert + window that follow take its list and count on the
+            # device: its count, the compaction's two and the insert / window counts then come back in ONE read-back
+            # (NeuralPoints.update); the two-phase path (a round trip of its own for the voxel count) otherwise.
+            if two_phase and defer_cmp and async_upd:
+                vox_idx = voxel_down_sample_async(update_points, nm.resolution, nm.update_counts(coord.device)[3:5], n_dev=cmp_dev[1:2])
             pending_vox = (voxel_down_sample_launch(update_points, nm.resolution, n_dev=None if cmp_dev is None else cmp_dev[1:2])
-                           if two_phase else None)
+                           if two_phase and vox_idx is None else None)
             main = torch.cuda.current_stream(coord.device)
             side = getattr(self, "_side_stream", None)
             if side is None or side.device != coord.device:
@@ -857,48 +886,64 @@ class Mapper:
             with torch.cuda.stream(side):
                 self._pool_append_filter_fused(coord, gcoord, sdf_label, weight, stamp, cur_pose_torch, frame_id, defer=True,
                                                n_b_dev=None if cmp_dev is None else cmp_dev[0:1])
-            keep_idx = voxel_down_sample_finish(pending_vox) if two_phase else voxel_down_sample_torch(update_points, nm.resolution)
-            if defer_cmp:  # (the stream has just been drained by the voxel count's round trip: this one finds its data ready)
+            if vox_idx is not None:
+                keep_idx = None
+            else:
+                keep_idx = voxel_down_sample_finish(pending_vox) if two_phase else voxel_down_sample_torch(update_points, nm.resolution)
+            if defer_cmp and vox_idx is None:  # (the stream has just been drained by the voxel count's round trip: this one finds its data ready)
                 kept, n_near = _lib.read_counts(self._cmp_counts, 2)
                 coord, gcoord, sdf_label, weight, stamp = coord[:kept], gcoord[:kept], sdf_label[:kept], weight[:kept], stamp[:kept]
                 update_points = update_points[:n_near]
                 n_cur = self.cur_sample_count = kept
                 defer_cmp = False
-            nm._presampled = (update_points, update_points[keep_idx])
-        if defer_cmp:  # (not reached with the conditions above; kept for safety: settle the counts before anything uses the rows)
+            nm._presampled = (update_points, (vox_idx, nm.update_counts(coord.device)[3:5]) if vox_idx is not None else update_points[keep_idx])
+        if defer_cmp and vox_idx is None:  # (not reached with the conditions above; kept for safety: settle the counts before anything uses the rows)
             kept, n_near = _lib.read_counts(self._cmp_counts, 2)
             coord, gcoord, sdf_label, weight, stamp = coord[:kept], gcoord[:kept], sdf_label[:kept], weight[:kept], stamp[:kept]
             update_points = update_points[:n_near]
             n_cur = self.cur_sample_count = kept
+            defer_cmp = False
         self.cur_new_point_ratio = nm.update(update_points, origin, orientation, frame_id)
+        if defer_cmp:  # the compaction's counts came back with the insert / window counts
+            kept, n_near = nm._last_update_counts[5:7]
+            coord, gcoord, sdf_label, weight, stamp = coord[:kept], gcoord[:kept], sdf_label[:kept], weight[:kept], stamp[:kept]
+            update_points = update_points[:n_near]
+            n_cur = self.cur_sample_count = kept
+            defer_cmp = False
 
-        self.determine_used_pose()
         new_pending = None
         if overlap:
-            map_ready = main.record_event() if os.environ.get("CLID_TABLE_PREFETCH_EARLY", "1") != "0" else None
-            main.wait_stream(side)
+            # Tail of the frame, in the order that keeps the device busy: the local probe table + cell directory of the mapping()
+            # call that follows (csrc/table.hip, csrc/celldir.hip: ~100 us of small launches at 250 k local points) depend on
+            # the map only -- enqueued first, on a third stream that waits for the map update alone (not, through `main`, for
+            # the pool's compaction on the side stream); the new-sample selection, which needs the pool arrays, next to it on
+            # `main`; the host-only bookkeeping while both run; then the frame's last read-back.
+            if os.environ.get("CLID_TABLE_PREFETCH", "1") != "0":
+                third = getattr(self, "_third_stream", None)
+                if third is None or third.device != coord.device:
+                    third = self._third_stream = torch.cuda.Stream(device=coord.device)
+                if os.environ.get("CLID_TABLE_PREFETCH_EARLY", "1") != "0":
+                    third.wait_event(main.record_event())
+                    nm.prefetch_local_table(third)
+                    main.wait_stream(side)
+                else:
+                    main.wait_stream(side)
+                    third.wait_stream(main)
+                    nm.prefetch_local_table(third)
+            else:
+                main.wait_stream(side)
             if cfg.bs_new_sample > 0:
                 # the new-sample selection (below) launched on the pool arrays still in flight: it reads the two pool counts on
                 # the device, so ONE read-back serves the pool maintenance and the selection
                 new_pending = self._new_sample_launch_pending(coord.shape[0])
-            if os.environ.get("CLID_TABLE_PREFETCH", "1") != "0":
-                # the local probe table of the mapping() call that follows (csrc/table.hip, ~30 us at 250 k local points) depends on
-                # the map only: built now on a third stream, next to the pool's compaction, instead of in front of the searches
-                third = getattr(self, "_third_stream", None)
-                if third is None or third.device != coord.device:
-                    third = self._third_stream = torch.cuda.Stream(device=coord.device)
-                # (it waits for the map update only -- not, through `main`, for the pool's compaction on the side stream: the
-                # table + directory build, ~70 us of small launches, then runs NEXT TO that bandwidth-bound copy)
-                if map_ready is not None:
-                    third.wait_event(map_ready)
-                else:
-                    third.wait_stream(main)
-                nm.prefetch_local_table(third)
+            self.determine_used_pose()
             self._pool_filter_finish(with_tail=new_pending is not None)
         elif fused_pool:
+            self.determine_used_pose()
             self._pool_append_filter_fused(coord, gcoord if gcoord is not None else transform_torch(coord, cur_pose_torch),
                                            sdf_label, weight, stamp, cur_pose_torch, frame_id)
         else:
+            self.determine_used_pose()
             self._pool_append_filter_torch(coord, sdf_label, weight, stamp, sem_label, color_label, normal_label,
                                            cur_pose_torch, origin, frame_id, n_cur)
 
@@ -934,7 +979,7 @@ class Mapper:
                     if frame_id > cfg.freeze_after_frame and ratio > getattr(cfg, "new_sample_ratio_restart", 0.3):
                         self.adaptive_iter_offset = 10
 
-    def _sample_compact_fused(self, pts, cur_pose_torch, frame_id, defer_counts=False):
+    def _sample_compact_fused(self, pts, cur_pose_torch, frame_id, defer_counts=False, counts=None):
         """Sampler launch + `clid_sample_compact`: (coord, gcoord, sdf_label, weight, stamp, update_points) of this frame
         as utils/mapper.py:240-283 / :297-310 produce them (kept rows in order; update_points = world-frame rows with
         |sdf| < surface_sample_range_m * map_surface_ratio)."""
@@ -945,7 +990,9 @@ class Mapper:
         need = int(lib.clid_sample_compact_workspace_bytes(n))
         if getattr(self, "_cmp_ws", None) is None or self._cmp_ws.numel() < need or self._cmp_ws.device != dev:
             self._cmp_ws = torch.empty(int(need * 1.3) + 256, device=dev, dtype=torch.uint8)
-            self._cmp_counts = torch.zeros(2, device=dev, dtype=torch.int64)
+            self._cmp_own_counts = torch.zeros(2, device=dev, dtype=torch.int64)
+        # [kept rows | near-surface rows]: in the caller's block when it reads them with other counts in one read-back
+        self._cmp_counts = counts if counts is not None else self._cmp_own_counts
         out3 = torch.empty((3, max(n, 1), 3), device=dev, dtype=torch.float32)   # coord | gcoord | update_points
         out1 = torch.empty((2, max(n, 1)), device=dev, dtype=torch.float32)      # label | weight
         stamp = torch.empty(max(n, 1), device=dev, dtype=torch.int32)
@@ -1127,7 +1174,7 @@ class Mapper:
         raw-point map (whose count nothing needs before the end of process_frame)."""
         fc = getattr(self, "_frame_counts", None)
         if fc is None or fc.device != torch.device(dev):
-            fc = self._frame_counts = torch.zeros(8, device=dev, dtype=torch.int64)
+            fc = self._frame_counts = torch.zeros(16, device=dev, dtype=torch.int64)  # [8:10]: the scan's voxel pass [count | failed]
             self._pool_counts, self._new_count = fc[0:3], fc[3:4]
         return fc
 
@@ -1135,12 +1182,12 @@ class Mapper:
         side, out, _ = self._pool_pending
         self._pool_pending = None
         if with_tail:  # the new-sample selection was launched on the pool arrays in flight; the raw-point map's count rides along
-            got = _lib.read_counts(self._frame_counts, 5)
+            got = _lib.read_counts(self._frame_counts, 10)
             kept, kept_cur = got[0], got[1]
             self._new_count_host = got[3]
             lpm = self.local_point_cloud_map
             if getattr(lpm, "_count_pending", False):
-                lpm._finish_count(got[4])
+                lpm._finish_count(got[4], got[9])
         else:
             kept, kept_cur = _lib.read_counts(self._pool_counts, 2)  # the one host round trip of the pool maintenance
         self._pool_side = side

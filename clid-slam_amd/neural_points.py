@@ -245,6 +245,10 @@ class NeuralPoints(nn.Module):
         """Insert new neural points for `points` [N,3] (model/neural_points.py:324-437)."""
         res = self.resolution
         pre = self.__dict__.pop("_presampled", None)  # (points tensor, its voxel-down-sampled rows) left by Mapper.process_frame
+        if pre is not None and pre[0] is points and isinstance(pre[1], tuple):
+            # (index list, device count) of a voxel down-sampling still in flight (tools.voxel_down_sample_async): the fused
+            # insert takes both on the device, nothing waits for the pass on the host
+            return self._update_fused(points, sensor_position, sensor_orientation, cur_ts, sample_idx=pre[1][0], vox_counts=pre[1][1])
         if pre is not None and pre[0] is points:
             sample_points = pre[1]
         else:
@@ -326,9 +330,26 @@ class NeuralPoints(nn.Module):
         self._gbuf = buf
         return buf
 
-    def _update_fused(self, sample_points, sensor_position, sensor_orientation, cur_ts: int):
+    def update_is_fused(self) -> bool:
+        """True when `update` will run the insert and the window selection as one enqueue with one read-back (every shipped
+        configuration on the GPU): only then may the voxel pass in front of it stay in flight."""
+        return (self.color_features is None and self.buffer_pt_index is not None and self.buffer_pt_index.is_cuda
+                and int(self.buffer_size) < (1 << 30) and self.geo_features.shape[1] == _lib.F and self.point_ts_create.dtype == torch.int32
+                and self.geo_feature_std == 0 and os.environ.get("CLID_FUSED_INSERT_WINDOW", "1") != "0")
+
+    def update_counts(self, dev):
+        """Device block [points added | in the time window, local points | voxels of the update's down-sampling, its failure
+        flag]: ONE read-back for the insert, the window and the down-sampling in front of them."""
+        blk = getattr(self, "_ins_win_counts", None)
+        if blk is None or blk.device != torch.device(dev) or blk.shape[0] != 8:
+            blk = self._ins_win_counts = torch.zeros(8, device=dev, dtype=torch.int64)  # ([5:7]: the caller's, Mapper.process_frame)
+            self._ins_count, self._win_counts = blk[:1], blk[1:3]
+        return blk
+
+    def _update_fused(self, sample_points, sensor_position, sensor_orientation, cur_ts: int, sample_idx=None, vox_counts=None):
         """The insert of `update` in one enqueue (csrc/mapops.hip clid_map_insert) + ONE count read-back, appending in
-        place into the capacity buffers."""
+        place into the capacity buffers.  sample_idx / vox_counts: the samples are rows sample_idx[i], i < vox_counts[0] (device),
+        of `sample_points`; the number of rows is the bound everything is sized for."""
         lib = _lib.load()
         n, base = int(sample_points.shape[0]), int(self.count())
         dev = sample_points.device
@@ -339,27 +360,31 @@ class NeuralPoints(nn.Module):
         need = int(lib.clid_map_insert_workspace_bytes(n))
         if getattr(self, "_ins_ws", None) is None or self._ins_ws.numel() < need or self._ins_ws.device != dev:
             self._ins_ws = torch.empty(int(need * 1.5) + 1024, device=dev, dtype=torch.uint8)
-        if getattr(self, "_ins_win_counts", None) is None or self._ins_win_counts.device != dev:
-            self._ins_win_counts = torch.zeros(3, device=dev, dtype=torch.int64)  # [added | in the time window, local points]
-            self._ins_count, self._win_counts = self._ins_win_counts[:1], self._ins_win_counts[1:]
+        self.update_counts(dev)
         res = float(self.resolution)
+        feat = buf["geo_features"]
+        fused_window = self.geo_feature_std == 0 and os.environ.get("CLID_FUSED_INSERT_WINDOW", "1") != "0"
         _lib.check(lib.clid_map_insert(
             sample_points.data_ptr(), n, self.buffer_pt_index.data_ptr(), int(self.buffer_size), res,
             buf["neural_points"].data_ptr(), buf["point_orientations"].data_ptr(), buf["point_ts_create"].data_ptr(),
             buf["point_ts_update"].data_ptr(), buf["point_certainties"].data_ptr(), base, _lib.ptr(travel), int(cur_ts), test_on,
             temporal, float(3 * res**2), float(self.diff_travel_dist_local), self._ins_count.data_ptr(), self._ins_ws.data_ptr(),
-            _lib.stream()), "clid_map_insert")
-        feat = buf["geo_features"]
-        if self.geo_feature_std == 0 and os.environ.get("CLID_FUSED_INSERT_WINDOW", "1") != "0":
+            _lib.ptr(sample_idx), None if vox_counts is None else vox_counts[0:1].data_ptr(),
+            feat.data_ptr() if fused_window else None, _lib.stream()), "clid_map_insert")
+        if fused_window:
             # zero-initialised features (every shipped config): nothing between the insert and the window selection needs
             # the number of added points on the host, so the window is enqueued on the insert's device-side count and the
-            # two share ONE read-back (model/neural_points.py:324-437 + :439-536)
-            feat[base:base + n + 1].zero_()
+            # two share ONE read-back (model/neural_points.py:324-437 + :439-536); the insert zeroes the new feature rows itself
             got = self._reset_local_map_fused(sensor_position, sensor_orientation, cur_ts, True, 50, True,
-                                              pending=(buf, base, n, self._ins_count))
+                                              pending=(buf, base, n, self._ins_count, vox_counts is not None))
             if got is not None:
-                return got / max(n, 1)
+                return got[0] / max(got[1], 1)
         n_new = _lib.read_counts(self._ins_count, 1)[0]  # the one host round trip of the insert (sizes the views)
+        if vox_counts is not None:
+            n, bad = _lib.read_counts(vox_counts, 2)
+            if bad:
+                raise RuntimeError("voxel down-sampling of the map update: voxel ids too wide for the device-side ordering "
+                                   "(a bounding box beyond 2^17 voxels per axis); CLID_ASYNC_VOXEL=0 takes the path with the library sort")
         total = base + n_new
         if self.geo_feature_std != 0:
             gen = _lib.replica_generator(self, self.config, self.device, 2)  # None = global RNG unless data-parallel
@@ -442,7 +467,7 @@ class NeuralPoints(nn.Module):
         here and the number of inserted points is returned (None: not applicable, nothing was enqueued)."""
         pts = self.neural_points
         if pending is not None:
-            buf, base, n_add, ins_count = pending
+            buf, base, n_add, ins_count, with_vox = pending
             if not (self.color_features is None and base + n_add > 0):
                 return None
             self.cur_ts = cur_ts
@@ -464,9 +489,7 @@ class NeuralPoints(nn.Module):
         need = int(lib.clid_local_window_workspace_bytes(n))
         if getattr(self, "_win_ws", None) is None or self._win_ws.numel() < need or self._win_ws.device != dev:
             self._win_ws = torch.empty(int(need * 1.3) + 1024, device=dev, dtype=torch.uint8)
-        if getattr(self, "_ins_win_counts", None) is None or self._ins_win_counts.device != dev:
-            self._ins_win_counts = torch.zeros(3, device=dev, dtype=torch.int64)
-            self._ins_count, self._win_counts = self._ins_win_counts[:1], self._ins_win_counts[1:]
+        self.update_counts(dev)
         if pending is None:
             for name in ("point_orientations", "point_certainties", "geo_features", "point_ts_update", "point_ts_create"):
                 _lib.require_cuda(getattr(self, name), name)
@@ -503,7 +526,15 @@ class NeuralPoints(nn.Module):
                 m = _lib.read_counts(self._win_counts, 2)[1]  # the one host round trip: sizes the local arrays
             else:
                 # ONE read-back for the insert and the window: the window's count pair sits next to the insert's count
-                n_new, _, m = _lib.read_counts(self._ins_win_counts, 3)
+                if with_vox:  # ... and the voxel pass in front of the insert: [voxels | ordering failed]
+                    got = self._last_update_counts = _lib.read_counts(self._ins_win_counts, 7)
+                    n_new, _, m, n_vox, bad = got[:5]
+                    if bad:
+                        raise RuntimeError("voxel down-sampling of the map update: voxel ids too wide for the device-side ordering "
+                                           "(a bounding box beyond 2^17 voxels per axis); CLID_ASYNC_VOXEL=0 takes the path with the library sort")
+                else:
+                    n_new, _, m = _lib.read_counts(self._ins_win_counts, 3)
+                    n_vox = n_add
             if m <= cap:
                 break
             cap = n  # (grew by more than a quarter since the last frame: once more with room for everything)
@@ -522,7 +553,7 @@ class NeuralPoints(nn.Module):
         self._local_ids_pad = None
         self.local_orientation = sensor_orientation
         self._map_version += 1
-        return True if pending is None else n_new
+        return True if pending is None else (n_new, n_vox)
 
     def assign_local_to_global(self):
         """model/neural_points.py:538-549."""

@@ -92,6 +92,27 @@ def voxel_down_sample_launch(points: torch.Tensor, voxel_size: float, value: tor
     return (pts, val, ws, out, n)
 
 
+def voxel_down_sample_async(points: torch.Tensor, voxel_size: float, count_out: torch.Tensor, n_dev: torch.Tensor = None):
+    """The voxel down-sampling without a host round trip (`clid_voxel_down_sample_async`): returns the index tensor [n] whose
+    first count_out[0] entries (device int64; count_out[1] != 0: ordering failed, see include/clid_native.h) are the result.
+    The consumers take list and count on the device (LocalPointCloudMap.update_map / NeuralPoints.update).  None: not
+    applicable (more than 2^21 points) -- the caller takes the two-phase path."""
+    from . import _lib
+
+    n = points.shape[0]
+    if not (0 < n <= (1 << 21)) or points.dtype != torch.float32 or not points.is_contiguous():
+        return None
+    lib = _lib.load()
+    need = int(lib.clid_voxel_workspace_bytes(n))
+    ws = _VOX_WS.get(points.device)
+    if ws is None or ws.numel() < need:
+        ws = _VOX_WS[points.device] = torch.empty(int(need * 1.25) + 256, device=points.device, dtype=torch.uint8)
+    out = torch.empty(n, device=points.device, dtype=torch.int64)
+    _lib.check(lib.clid_voxel_down_sample_async(points.data_ptr(), n, float(voxel_size), _lib.ptr(n_dev), ws.data_ptr(), out.data_ptr(),
+                                                count_out.data_ptr(), _lib.stream()), "clid_voxel_down_sample_async")
+    return out
+
+
 def voxel_down_sample_finish(handle):
     """Second half: the one host round trip; returns the indices (ascending linear voxel id)."""
     from . import _lib

@@ -504,6 +504,13 @@ int clid_voxel_down_sample(const float* points, int32_t n, float voxel_size, voi
 int clid_voxel_down_sample_launch(const float* points, int32_t n, float voxel_size, const float* value, const int64_t* n_dev,
                                   void* workspace, int64_t* idx_out, void* stream);
 int clid_voxel_down_sample_finish(int32_t n, void* workspace, int64_t* idx_out, void* stream);
+/* The whole pass without a host round trip (1 <= n <= 2^21 points): count_out (device int64[2]) receives [number of occupied
+ * voxels m | 1 if the voxel ids were too wide for the device-side ordering -- a bounding box beyond 2^17 voxels per axis; idx_out
+ * is then unordered and the caller must treat the call as failed when it reads the block], idx_out[0..m) the indices in
+ * ascending voxel id.  A bucket of the device-side ordering beyond its capacity is ranked by counting on the device (slow,
+ * exact) instead of by the library sort of _finish, which needs m on the host. */
+int clid_voxel_down_sample_async(const float* points, int32_t n, float voxel_size, const int64_t* n_dev, void* workspace,
+                                 int64_t* idx_out, int64_t* count_out, void* stream);
 /* voxel_down_sample_min_value_torch (utils/tools.py:685-724): as above, but the point of a voxel with the smallest
  * `value` [n] (>= 0; quantised to 1000 levels of its maximum, lowest index among equals) is taken -- the selection
  * NeuralPoints.recreate_hash makes with |ts - cur_ts| or (max certainty - certainty) (model/neural_points.py:864-882).
@@ -554,7 +561,10 @@ int clid_pool_filter(const float* coord_a, const float* gcoord_a, const float* l
 int64_t clid_cloud_workspace_bytes(int64_t n_total);
 int clid_cloud_update(const float* map_points, int64_t n_map, const float* samples, int64_t n_samples, const int64_t* table_old,
                       int64_t* table_new, int64_t buffer_size, float resolution, const double* sensor_pos_host, double map_size,
-                      int32_t pos_is_f64, float* points_out, int64_t* counts_out, void* workspace, void* stream);
+                      int32_t pos_is_f64, float* points_out, int64_t* counts_out, void* workspace, const int64_t* sample_idx,
+                      const int64_t* n_samples_dev, void* stream);
+/* sample_idx / n_samples_dev != NULL (device; the idx_out / count_out of a clid_voxel_down_sample_async still in flight):
+ * sample i is row sample_idx[i] of `samples`, i < *n_samples_dev <= n_samples (the bound the grids are sized for). */
 
 /* The insert of NeuralPoints.update (model/neural_points.py:346-437) for the voxel-down-sampled `samples` [n][3]: slot of
  * each sample's voxel in buffer_pt_index, take test (empty | held point farther than sqrt(far_dist2) | held point stale
@@ -566,7 +576,12 @@ int64_t clid_map_insert_workspace_bytes(int32_t n);
 int clid_map_insert(const float* samples, int32_t n, int64_t* buffer_pt_index, int64_t buffer_size, float resolution,
                     float* neural_points, float* point_orientations, int32_t* ts_create, int32_t* ts_update, float* certainties,
                     int64_t base, const float* travel_dist, int32_t cur_ts, int32_t test_on, int32_t temporal, float far_dist2,
-                    float diff_travel, int64_t* count_out, void* workspace, void* stream);
+                    float diff_travel, int64_t* count_out, void* workspace, const int64_t* sample_idx, const int64_t* n_dev,
+                    float* features_zero, void* stream);
+/* sample_idx / n_dev != NULL (device): sample i is row sample_idx[i] of `samples`, i < *n_dev <= n -- the voxel down-sampling
+ * in front of the insert is then still in flight (clid_voxel_down_sample_async) and nothing waits for it on the host.
+ * features_zero != NULL ([rows + 1][8] floats, the global feature array): the rows of the added points and the padding row
+ * behind the last of them are zeroed (geo_feature_std == 0) -- the caller cannot size a fill without the count. */
 
 /* NeuralPoints.reset_local_map (model/neural_points.py:439-536): the local window = points whose creation (or mid)
  * stamp lies within `diff_travel` of travelled distance (or `diff_ts_local` frames) of cur_ts -- dropped when it holds

@@ -26,6 +26,45 @@ def test_voxel_down_sample_kernel_matches_the_reference_rule(n, voxel, seed):
     assert torch.equal(got.cpu(), want)
 
 
+def _voxel_async(pts, voxel, n_live=None):
+    from clid_slam_amd.tools import voxel_down_sample_async
+
+    counts = torch.full((2,), -7, dtype=torch.int64, device="cuda")
+    n_dev = None if n_live is None else torch.tensor([n_live], dtype=torch.int64, device="cuda")
+    idx = voxel_down_sample_async(pts, voxel, counts, n_dev=n_dev)
+    m, bad = counts.tolist()
+    return idx[:m].cpu(), m, bad
+
+
+@pytest.mark.parametrize("n,voxel,seed", [(1, 0.2, 0), (7, 0.4, 1), (5000, 0.2, 2), (200000, 0.4, 3), (450000, 0.1, 4), (1_500_000, 0.08, 5)])
+def test_voxel_down_sample_without_a_round_trip(n, voxel, seed):
+    """clid_voxel_down_sample_async (index list + count left on the device; buckets beyond their capacity ranked by counting
+    on the device instead of by the library sort, which needs the count on the host -- the last case has ~1e6 voxels in 512
+    buckets of 4096) == the oracle's rule; and on a prefix given by a device-side count."""
+    g = torch.Generator().manual_seed(seed)
+    pts = (torch.rand((n, 3), generator=g) - 0.3) * torch.tensor([40.0, 25.0, 6.0])
+    if n > 10:
+        pts[n // 2] = pts[n // 3]
+    got, m, bad = _voxel_async(pts.cuda(), voxel)
+    assert bad == 0 and torch.equal(got, R.voxel_down_sample(pts, voxel))
+    if 10 < n <= 450000:
+        live = (2 * n) // 3
+        got, m, bad = _voxel_async(pts.cuda(), voxel, n_live=live)
+        assert bad == 0 and torch.equal(got, R.voxel_down_sample(pts[:live], voxel))
+
+
+def test_voxel_down_sample_without_a_round_trip_skewed_buckets():
+    """Every sampled point (the splitters come from 1024 evenly spaced inputs) in ONE voxel, 30000 other voxels beyond it: the
+    last bucket receives all of them (capacity 4096), the rest goes through the spill list and the counting ranks."""
+    n = 40960
+    g = torch.Generator().manual_seed(11)
+    pts = torch.rand((n, 3), generator=g) * torch.tensor([60.0, 50.0, 10.0]) + torch.tensor([5.0, 5.0, 5.0])
+    pts[torch.arange(0, n, n // 1024)] = torch.tensor([0.05, 0.05, 0.05])
+    got, m, bad = _voxel_async(pts.cuda(), 0.5)
+    want = R.voxel_down_sample(pts, 0.5)
+    assert bad == 0 and m == want.numel() and m > 20000 and torch.equal(got, want)
+
+
 def test_voxel_down_sample_kernel_on_a_scan():
     from clid_slam_amd.synth import box_room_scan
     from clid_slam_amd.tools import voxel_down_sample_torch

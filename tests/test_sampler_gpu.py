@@ -250,3 +250,36 @@ def test_process_frame_fused_glue_equals_the_op_chain(monkeypatch):
             else:
                 assert x == y
     assert runs[1][-1][5].numel() > 0 and runs[1][-1][0].shape[0] > 100_000
+
+
+def test_process_frame_without_voxel_round_trips_equals_the_two_phase_path(monkeypatch):
+    """The two voxel passes of a frame left in flight (CLID_ASYNC_VOXEL, default: their index lists and counts are consumed
+    on the device by the raw-point map update and by the insert + window; counts come back with the reads that follow)
+    against the paths that read each voxel count back: identical raw-point maps, pools, neural-point maps, windows and
+    selections on six frames of the sequence workload."""
+    import bench_sequence as BS
+    from clid_slam_amd import _lib
+
+    runs, reads = [], []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CLID_ASYNC_VOXEL", mode)
+        torch.manual_seed(0)
+        snaps, n_reads = [], [0]
+        orig = _lib.load().clid_read_back
+
+        def grab(mp, nm):
+            lpm = mp.local_point_cloud_map
+            snaps.append((mp.coord_pool.clone(), mp.global_coord_pool.clone(), mp.sdf_label_pool.clone(), mp.weight_pool.clone(),
+                          mp.time_pool.clone(), mp.new_idx.clone(), mp.adaptive_iter_offset, mp.cur_sample_count, mp.cur_new_point_ratio,
+                          nm.neural_points.clone(), nm.local_neural_points.clone(), nm.buffer_pt_index.clone(), nm.global2local.clone(),
+                          nm.local_mask.clone(), lpm.local_point_cloud_map.clone(), lpm.buffer_pt_index.clone()))
+
+        cfg, rows, checks, objs = BS.run(6, "cuda:0", quiet=True, after_process=grab)
+        runs.append(snaps)
+    assert len(runs[0]) == len(runs[1]) == 6
+    for a, b in zip(*runs):
+        for x, y in zip(a, b):
+            if isinstance(x, torch.Tensor):
+                assert x.shape == y.shape and torch.equal(x, y)
+            else:
+                assert x == y
