@@ -37,6 +37,10 @@ class DataSampler:
         if noise is None and pre is not None and pre[0] == (R, str(dev)):
             z_s, u_f, u_b = pre[1]
         elif noise is None:  # utils/data_sampler.py:47, :72, :93 (this order)
+            if pre is not None:
+                # a predraw for another ray count / device: the generator goes back to where it was before it, so the
+                # stream of random numbers stays the reference's (and the same on every rank of a data-parallel group)
+                self._restore_generator(pre[2])
             z_s, u_f, u_b = self._draw(R, dev)
         else:
             z_s, u_f, u_b = (t.to(dev, torch.float32).contiguous() for t in noise)
@@ -75,7 +79,20 @@ class DataSampler:
     def predraw(self, n_rays: int, dev) -> None:
         """The next `_run`'s random draws for `n_rays` rays, enqueued ahead of time (Mapper.process_frame: before the raw-point
         map update, whose round trips they then overlap); consumed by the next `_run` with that ray count, dropped otherwise."""
-        self._predrawn = ((int(n_rays), str(torch.device(dev) if not isinstance(dev, torch.device) else dev)), self._draw(int(n_rays), dev))
+        dev = torch.device(dev) if not isinstance(dev, torch.device) else dev
+        gen = _lib.replica_generator(self, self.config, dev, 1)
+        state = (gen, gen.get_state()) if gen is not None else (None, torch.cuda.get_rng_state(dev) if dev.type == "cuda" else torch.get_rng_state())
+        self._predrawn = ((int(n_rays), str(dev)), self._draw(int(n_rays), dev), (dev, state))
+
+    @staticmethod
+    def _restore_generator(saved) -> None:
+        dev, (gen, state) = saved
+        if gen is not None:
+            gen.set_state(state)
+        elif dev.type == "cuda":
+            torch.cuda.set_rng_state(state, dev)
+        else:
+            torch.set_rng_state(state)
 
     def sample(self, points_torch, local_point_cloud_map, cur_pose_torch, noise=None):
         """utils/data_sampler.py:260-402: (coord [S,3] sensor frame, sdf_label [S], weight [S]); near-surface

@@ -155,6 +155,29 @@ def test_device_rng_contract():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[5], b[5])
 
 
+def test_dropped_predraw_does_not_shift_the_random_stream():
+    """A predraw for another ray count is dropped AND the generator goes back to where it was: the draws that follow are
+    the ones a run without the predraw makes (the reference's stream; identical on every rank of a data-parallel group)."""
+    from clid_slam_amd import DataSampler
+
+    g = gio.load("g9_sampler.npz")
+    cfg = _cfg(g)
+    pts = gio.T(g["f0_points"]).cuda()
+    torch.manual_seed(5)
+    a = DataSampler(cfg).sample_pin(pts)
+    after_a = torch.rand(4, device="cuda")
+    torch.manual_seed(5)
+    smp = DataSampler(cfg)
+    smp.predraw(pts.shape[0] + 17, pts.device)
+    b = smp.sample_pin(pts)
+    after_b = torch.rand(4, device="cuda")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[5], b[5]) and torch.equal(after_a, after_b)
+    torch.manual_seed(5)
+    smp.predraw(pts.shape[0], pts.device)  # the matching predraw is consumed as it is
+    c = smp.sample_pin(pts)
+    assert torch.equal(a[0], c[0]) and torch.equal(after_a, torch.rand(4, device="cuda"))
+
+
 def test_process_frame_g10():
     """Mapper.process_frame over the three G10 frames: pool sizes, per-frame membership, label / coordinate
     sums, the new-sample selection and the neural-point map growth against the reference's own run."""
