@@ -25,6 +25,7 @@ struct CloudView {
   const float* pts;
   const int* nb;
   long long B;
+  double inv_B;  // 1 / B: the slot arithmetic below
   int n_pts, P;
   float res, max_range, eta, thr;
 };
@@ -68,6 +69,22 @@ __device__ __forceinline__ void jacobi_4x3(float a[3][4], float v[3][3]) {
   }
 }
 
+// h mod B, non-negative -- what `fmod` with the sign of h followed by python-style indexing of a negative slot amounts to
+// (lpcm.py:38-41, 112-116).  A 64-bit remainder by a run-time divisor is a ~100-instruction software routine and every
+// sample takes P = 7 of them: for |h| < 2^52 (cells within +-1e6 of the origin) the quotient comes from one fp64 multiply,
+// off by at most one, and the remainder is corrected in integers -- exact.
+__device__ __forceinline__ long long cloud_slot_of(long long h, long long B, double inv_B) {
+  if (h > -(1LL << 52) && h < (1LL << 52)) {
+    const long long q = (long long)floor((double)h * inv_B);
+    long long r = h - q * B;
+    if (r < 0) r += B;
+    if (r >= B) r -= B;
+    return r;
+  }
+  long long s = h % B;
+  return s < 0 ? s + B : s;
+}
+
 // |SDF| estimate of one world-frame sample; returns the surface flag (at least one raw point around it)
 __device__ __forceinline__ bool region_estimate(const CloudView& cv, float x, float y, float z, float* sdf_abs) {
   const long long cx = (long long)floorf(fdiv(x, cv.res)), cy = (long long)floorf(fdiv(y, cv.res)),
@@ -87,8 +104,7 @@ __device__ __forceinline__ bool region_estimate(const CloudView& cv, float x, fl
       const int oo = in ? o : 0;
       const long long h = (cx + cv.nb[3 * oo]) * kCloudPrime0 + (cy + cv.nb[3 * oo + 1]) * kCloudPrime1 +
                           (cz + cv.nb[3 * oo + 2]) * kCloudPrime2;
-      long long s = h % cv.B;  // fmod keeps the sign; the table is then indexed python-style (lpcm.py:38-41,112-116)
-      if (s < 0) s += cv.B;
+      const long long s = cloud_slot_of(h, cv.B, cv.inv_B);  // fmod keeps the sign; the table is then indexed python-style (lpcm.py:38-41,112-116)
       id[t] = in ? cv.table[s] : -1;
     }
     float px[kCloudChunk], py[kCloudChunk], pz[kCloudChunk];
@@ -163,16 +179,31 @@ struct SampleParams {
   float T[12];
 };
 
-// thread = (ray, sample slot k): k = 0 exact hit | 1..ns near-surface | then nf in front | then nb behind
+// thread = (ray, sample slot k): k = 0 exact hit | 1..ns near-surface | then nf in front | then nb behind.
+// Thread order: first the n_rays * ns near-surface pairs, slot-major (their region estimate -- 7 table probes, a 4 x 3
+// Jacobi SVD -- is ~20 x the work of the other slots: in ray-major order half the lanes of every wave sat out that path),
+// then the light slots; consecutive lanes = consecutive rays, so the draws and the scan points are read coalesced.  The
+// outputs keep the ray-major order the reference produces.
 __global__ void __launch_bounds__(256) k_sample_frame(CloudView cv, SampleParams sp, const float* __restrict__ pts,
                                                       int n_rays, const float* __restrict__ z_s,
                                                       const float* __restrict__ u_f, const float* __restrict__ u_b,
                                                       float* __restrict__ coord, float* __restrict__ label,
                                                       float* __restrict__ weight, unsigned char* __restrict__ keep) {
   const int n_all = 1 + sp.ns + sp.nf + sp.nb;
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)n_rays * n_all) return;
-  const int ray = (int)(t / n_all), k = (int)(t - (long long)ray * n_all);
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (long long)n_rays * n_all) return;
+  const long long heavy = (long long)n_rays * sp.ns;
+  int ray, k;
+  if (tid < heavy) {
+    k = 1 + (int)(tid / n_rays);
+    ray = (int)(tid - (long long)(k - 1) * n_rays);
+  } else {
+    const long long u = tid - heavy;
+    const int j = (int)(u / n_rays);  // 0: the measured point, then the free-space slots
+    ray = (int)(u - (long long)j * n_rays);
+    k = j == 0 ? 0 : sp.ns + j;
+  }
+  const long long t = (long long)ray * n_all + k;  // output row
   const float x = pts[ray * 3 + 0], y = pts[ray * 3 + 1], z = pts[ray * 3 + 2];
   const float dist = sqrtf(fadd(fadd(fmul(x, x), fmul(y, y)), fmul(z, z)));  // ds.py:37-39
   const float two_sigma = 2.0f * sp.sigma;
@@ -237,6 +268,7 @@ static int cloud_view_from(const clid_cloud_view* c, CloudView* out, const char*
   out->pts = c->points;
   out->nb = c->neighbor_idx;
   out->B = c->buffer_size;
+  out->inv_B = 1.0 / (double)c->buffer_size;
   out->n_pts = c->n_points;
   out->P = c->P;
   out->res = c->resolution;
