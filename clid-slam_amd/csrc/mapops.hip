@@ -132,6 +132,17 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long k) {
   return k;
 }
 
+// With a device-side count below the bound the table was sized (and cleared) for, only its first 2^l slots are used, l by
+// the host's rule on the live count: the near-surface rows of a frame are a third of the sampler rows the host knows about
+// (an 8 MB region of a 32 MB table: the atomics and the partition pass stay closer to the caches).
+__device__ __forceinline__ int vox_eff_log2cap(int log2cap, int n_bound, const long long* __restrict__ n_dev) {
+  if (!n_dev) return log2cap;
+  const int n = vox_n(n_bound, n_dev);
+  int l = 10;
+  while ((1LL << l) < 2LL * n) ++l;
+  return l < log2cap ? l : log2cap;
+}
+
 __global__ void __launch_bounds__(256) k_vox_insert(const float* __restrict__ pts, int n_bound, float v, VoxStats* st,
                                                     long long* keys, unsigned long long* vals, int log2cap,
                                                     const float* __restrict__ value, const int* __restrict__ box,
@@ -157,7 +168,7 @@ __global__ void __launch_bounds__(256) k_vox_insert(const float* __restrict__ pt
   const long long gx = (long long)cx - off[0], gy = (long long)cy - off[1], gz = (long long)cz - off[2];
   const long long flat = gx + gy * stride + gz * stride * stride;
   const unsigned long long pack = ((unsigned long long)q << 32) | (unsigned)i;  // min == (smallest q, then smallest index)
-  const unsigned long long mask = (1ULL << log2cap) - 1ULL;
+  const unsigned long long mask = (1ULL << vox_eff_log2cap(log2cap, n_bound, n_dev)) - 1ULL;
   unsigned long long h = mix64((unsigned long long)flat) & mask;
   for (;;) {
     const long long prev = (long long)atomicCAS(reinterpret_cast<unsigned long long*>(&keys[h]), ~0ULL, (unsigned long long)flat);
@@ -283,8 +294,10 @@ __global__ void __launch_bounds__(256) k_vox_partition(const long long* __restri
                                                        int log2cap, VoxStats* st, const long long* __restrict__ split,
                                                        unsigned* __restrict__ bucket_cnt, long long* __restrict__ bkeys,
                                                        long long* __restrict__ bidx, long long* __restrict__ spill_keys,
-                                                       long long* __restrict__ spill_idx) {
+                                                       long long* __restrict__ spill_idx, int n_bound,
+                                                       const long long* __restrict__ n_dev) {
   __shared__ long long sp[kVbBuckets];
+  if ((long long)blockIdx.x * blockDim.x >= (1LL << vox_eff_log2cap(log2cap, n_bound, n_dev))) return;  // (block-uniform)
   for (int i = threadIdx.x; i < kVbBuckets - 1; i += blockDim.x) sp[i] = split[i];
   __syncthreads();
   const long long h = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -968,7 +981,7 @@ static int vox_launch(const float* points, int32_t n, float voxel_size, const fl
     hipLaunchKernelGGL(k_vox_splitters, dim3(1), dim3(kVbThreads), 0, s, points, n, voxel_size, box, split, bcnt, n_dev);
     // count_out_dev: nobody will come back for the count (or for an overflowing bucket): spill list + k_vox_bucket_big
     hipLaunchKernelGGL(k_vox_partition, dim3(table_blocks1k * 4), dim3(256), 0, s, keys, vals, log2cap, st, split, bcnt, bkeys, bidx,
-                       count_out_dev ? flat_a : nullptr, count_out_dev ? idx_a : nullptr);
+                       count_out_dev ? flat_a : nullptr, count_out_dev ? idx_a : nullptr, n, n_dev);
     hipLaunchKernelGGL(k_vox_bucket_sort, dim3(kVbBuckets), dim3(kVbThreads), 0, s, bcnt, bkeys, bidx, st,
                        reinterpret_cast<long long*>(idx_out));
     if (count_out_dev)

@@ -50,6 +50,12 @@ timeout 900 python bench_sequence.py --frames 200 --check-frames 3 --profile-las
 timeout 900 python bench_sequence.py --frames 60 --quiet --gpus 2 --backend gloo > $out/sequence_60_gloo2.json 2>> $out/log.txt
 timeout 600 python bench.py --gpus 2 --backend gloo --steps 20 --warmup 5 --no-cpu-baseline --frame-calls 0 > $out/bench_cfg2_gloo2.json 2>> $out/log.txt
 timeout 600 python bench_next.py > $out/next_rows.jsonl 2>> $out/log.txt
+# 6. weighted_first: False (fused three-launch iteration vs the autograd loop), the long sequence, process_frame's device time line
+timeout 600 python tools/time_wf0.py 20 2>> $out/log.txt | tail -1 > $out/wf0_iteration.json
+timeout 900 python bench_sequence.py --frames 800 --quiet > $out/sequence_800.json 2>> $out/log.txt
+for m in 0 1 0 1; do CLID_ASYNC_VOXEL=$m timeout 600 python bench_sequence.py --frames 120 --quiet 2>> $out/log.txt | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'CLID_ASYNC_VOXEL': $m, **d['steady_state']}))"; done > $out/process_frame_async_ab.jsonl
+timeout 600 rocprofv3 --kernel-trace --memory-copy-trace -d $out/ft -o ft --output-format csv -- python bench_sequence.py --frames 60 --quiet > /dev/null 2>> $out/log.txt
+python tools/frame_trace.py $out/ft > $out/frame_trace.txt; rm -rf $out/ft
 for t in trace_cfg2 trace_cfg3; do f=$(find $out/$t -name 'stats_kernel_stats.csv' | head -1); cp "$f" $out/${t}_kernel_stats.csv; done
 rm -rf $out/trace_cfg2 $out/trace_cfg3 $out/pmc_cfg2 $out/pmc_cfg3
 ls -la $out | head -40; tail -5 $out/log.txt
