@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) k_vox_insert(const float* __restrict__ pt
                                                     const float* __restrict__ value, const int* __restrict__ box,
                                                     const long long* __restrict__ n_dev) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= vox_n(n_bound, n_dev)) return;
+  const bool live = i < vox_n(n_bound, n_dev);
   // tools.py:653, :661-663: offset = floor(min / v); stride = max(cell - offset) over ALL axes (not max + 1: voxels
   // whose coordinate equals the stride alias another voxel, reproduced on purpose -- it decides which points exist)
   long long off[3], stride = 0;
@@ -159,15 +159,52 @@ __global__ void __launch_bounds__(256) k_vox_insert(const float* __restrict__ pt
     stride = top > stride ? top : stride;
   }
   if (i == 0) st->stride = stride;
-  const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
-  float cx, cy, cz;
-  float d = centre_dist(x, y, z, v, &cx, &cy, &cz);
-  if (value) d = value[i];
-  const float dmax = __int_as_float(box[6 * kBoxStride]);
-  const long long q = dmax > 0.f ? (long long)fmul(fdiv(d, dmax), 999.0f) : 0;  // :657-659
-  const long long gx = (long long)cx - off[0], gy = (long long)cy - off[1], gz = (long long)cz - off[2];
-  const long long flat = gx + gy * stride + gz * stride * stride;
-  const unsigned long long pack = ((unsigned long long)q << 32) | (unsigned)i;  // min == (smallest q, then smallest index)
+  long long flat = -1;
+  unsigned long long pack = ~0ULL;
+  if (live) {
+    const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+    float cx, cy, cz;
+    float d = centre_dist(x, y, z, v, &cx, &cy, &cz);
+    if (value) d = value[i];
+    const float dmax = __int_as_float(box[6 * kBoxStride]);
+    const long long q = dmax > 0.f ? (long long)fmul(fdiv(d, dmax), 999.0f) : 0;  // :657-659
+    const long long gx = (long long)cx - off[0], gy = (long long)cy - off[1], gz = (long long)cz - off[2];
+    flat = gx + gy * stride + gz * stride * stride;
+    pack = ((unsigned long long)q << 32) | (unsigned)i;  // min == (smallest q, then smallest index)
+  }
+  // Neighbouring inputs fall into the same voxel (the samples of one ray around its end point; ~10 inputs per voxel on
+  // the map growth's pass) and the table's atomics are what the launch waits for: the lanes of a wave that share a voxel
+  // first agree on their minimum, ONE of them goes to the table.  No memory operation inside the loop.
+  const int lane = threadIdx.x & 63;
+  bool todo = live, rep = false;
+  // (worth it only where neighbours do share: a wave with fewer than 16 lanes equal to their successor goes as it is)
+  if (__popcll(__ballot(live && flat == __shfl_down(flat, 1, 64) && lane < 63)) < 16) {
+    rep = live;
+    todo = false;
+  }
+  for (int round = 0;; ++round) {
+    const unsigned long long m = __ballot(todo);
+    if (!m) break;
+    if (round == 16) {  // a wave of (mostly) distinct voxels: the rest goes as it is, the table's atomicMin sorts it out
+      rep = rep || todo;
+      break;
+    }
+    const int leader = __ffsll((long long)m) - 1;
+    const long long lk = __shfl(flat, leader, 64);
+    const bool same = todo && flat == lk;
+    unsigned long long p = same ? pack : ~0ULL;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const unsigned long long q2 = __shfl_xor(p, o, 64);
+      p = q2 < p ? q2 : p;
+    }
+    if (lane == leader) {
+      rep = true;
+      pack = p;
+    }
+    todo = todo && !same;
+  }
+  if (!rep) return;
   const unsigned long long mask = (1ULL << vox_eff_log2cap(log2cap, n_bound, n_dev)) - 1ULL;
   unsigned long long h = mix64((unsigned long long)flat) & mask;
   for (;;) {
