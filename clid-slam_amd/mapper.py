@@ -951,24 +951,25 @@ class Mapper:
             self.local_point_cloud_map._finish_count()
         # newly observed region: samples of this frame whose neighbourhood is still uncertain (:400-462)
         if cfg.bs_new_sample > 0:
-            cur = self.global_coord_pool[self.global_coord_pool.shape[0] - self.cur_sample_count:]
-            cur_label = self.sdf_label_pool[self.sdf_label_pool.shape[0] - self.cur_sample_count:]
-            nm.set_search_neighborhood(num_nei_cells=1, search_alpha=0.0)
-            try:
-                if new_pending is not None:
-                    self.new_idx = new_pending[: self._new_count_host]  # (read with the pool counts)
-                elif self._new_sample_fused_ok(cur, cur_label):
-                    self.new_idx = self._new_sample_select_fused(cur, cur_label)
-                else:
-                    certainty = torch.zeros(cur.shape[0], device=cur.device)
-                    for head in range(0, cur.shape[0], cfg.infer_bs):
-                        certainty[head:head + cfg.infer_bs] = nm.query_certainty(cur[head:head + cfg.infer_bs, :])
-                    self.new_idx = torch.where(
-                        (certainty < getattr(cfg, "new_certainty_thre", 1.0)) & (torch.abs(cur_label) < cfg.surface_sample_range_m * 3.0)
-                    )[0]
-                    self.new_idx += self.pool_sample_count - self.cur_sample_count
-            finally:
-                nm.set_search_neighborhood(num_nei_cells=cfg.num_nei_cells, search_alpha=cfg.search_alpha)
+            if new_pending is not None:
+                self.new_idx = new_pending[: self._new_count_host]  # (launched above, read with the pool counts)
+            else:
+                cur = self.global_coord_pool[self.global_coord_pool.shape[0] - self.cur_sample_count:]
+                cur_label = self.sdf_label_pool[self.sdf_label_pool.shape[0] - self.cur_sample_count:]
+                nm.set_search_neighborhood(num_nei_cells=1, search_alpha=0.0)
+                try:
+                    if self._new_sample_fused_ok(cur, cur_label):
+                        self.new_idx = self._new_sample_select_fused(cur, cur_label)
+                    else:
+                        certainty = torch.zeros(cur.shape[0], device=cur.device)
+                        for head in range(0, cur.shape[0], cfg.infer_bs):
+                            certainty[head:head + cfg.infer_bs] = nm.query_certainty(cur[head:head + cfg.infer_bs, :])
+                        self.new_idx = torch.where(
+                            (certainty < getattr(cfg, "new_certainty_thre", 1.0)) & (torch.abs(cur_label) < cfg.surface_sample_range_m * 3.0)
+                        )[0]
+                        self.new_idx += self.pool_sample_count - self.cur_sample_count
+                finally:
+                    nm.set_search_neighborhood(num_nei_cells=cfg.num_nei_cells, search_alpha=cfg.search_alpha)
             self.adaptive_iter_offset = 0
             ratio = self.new_idx.shape[0] / max(self.cur_sample_count, 1)
             if cfg.adaptive_iters:

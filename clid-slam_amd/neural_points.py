@@ -184,7 +184,7 @@ class NeuralPoints(nn.Module):
         st = dict(st)
         st["_tables"] = {}
         st.pop("_replica_gens", None)  # torch.Generator objects do not pickle
-        for k in ("_sensor_pos_host", "_win_ws", "_win_counts", "_ins_ws", "_ins_count", "_ins_win_counts", "_gbuf", "_stencils", "_presampled", "_track_scratch", "_track_ne", "_cdir_bufs", "_stencil_rows"):
+        for k in ("_sensor_pos_host", "_win_ws", "_win_counts", "_ins_ws", "_ins_count", "_ins_win_counts", "_gbuf", "_stencils", "_presampled", "_track_scratch", "_track_ne", "_cdir_bufs", "_stencil_rows", "_travel32_cache", "_last_update_counts"):
             st.pop(k, None)
         # views of capacity / upper-bound buffers would drag the whole buffers into the pickle: the global arrays (capacity
         # buffers of the in-place insert) and the local arrays, mask and index map (outputs of the window selection, allocated
@@ -330,6 +330,16 @@ class NeuralPoints(nn.Module):
         self._gbuf = buf
         return buf
 
+    def _travel32(self) -> torch.Tensor:
+        """`travel_dist` as the float32 array the kernels read (the insert, the window and the table build of one frame share
+        ONE conversion; the cache follows the tensor's identity and version counter)."""
+        t = self.travel_dist
+        key = (t.data_ptr(), t._version, t.shape[0], t.dtype, t.device)
+        hit = self.__dict__.get("_travel32_cache")
+        if hit is None or hit[0] != key:
+            hit = self._travel32_cache = (key, t.to(torch.float32).contiguous(), t)  # (keeps `t` alive: the pointer stays its)
+        return hit[1]
+
     def update_is_fused(self) -> bool:
         """True when `update` will run the insert and the window selection as one enqueue with one read-back (every shipped
         configuration on the GPU): only then may the voxel pass in front of it stay in flight."""
@@ -356,7 +366,7 @@ class NeuralPoints(nn.Module):
         buf = self._ensure_global_capacity(n)
         test_on = int((not self.is_empty()) and (cur_ts != self.reboot_ts))
         temporal = int(bool(self.temporal_local_map_on))
-        travel = self.travel_dist.to(torch.float32).contiguous() if (test_on and temporal) else None
+        travel = self._travel32() if (test_on and temporal) else None
         need = int(lib.clid_map_insert_workspace_bytes(n))
         if getattr(self, "_ins_ws", None) is None or self._ins_ws.numel() < need or self._ins_ws.device != dev:
             self._ins_ws = torch.empty(int(need * 1.5) + 1024, device=dev, dtype=torch.uint8)
@@ -485,7 +495,7 @@ class NeuralPoints(nn.Module):
             sp = [float(v) for v in sensor_position.detach().reshape(-1)[:3].tolist()]
         f64 = int(sensor_position.dtype == torch.float64)
         temporal = int(bool(self.temporal_local_map_on))
-        travel = self.travel_dist.to(torch.float32).contiguous() if (temporal and use_travel_dist) else None
+        travel = self._travel32() if (temporal and use_travel_dist) else None
         need = int(lib.clid_local_window_workspace_bytes(n))
         if getattr(self, "_win_ws", None) is None or self._win_ws.numel() < need or self._win_ws.device != dev:
             self._win_ws = torch.empty(int(need * 1.3) + 1024, device=dev, dtype=torch.uint8)
@@ -810,7 +820,7 @@ class NeuralPoints(nn.Module):
         log2filter = min(18, log2filter) if n <= (1 << 17) else min(24, log2filter)
         filt = torch.empty(((1 << log2filter) // 32,), device=pts.device, dtype=torch.int32)
         tsc = self.point_ts_create if time_filtering else None
-        trv = self.travel_dist.to(torch.float32).contiguous() if time_filtering else None
+        trv = self._travel32() if time_filtering else None
         _lib.check(
             lib.clid_table_build(_lib.ptr(ids), n, _lib.ptr(pts), _lib.ptr(big), int(self.buffer_size),
                                  float(self.resolution), _lib.ptr(tsc), _lib.ptr(trv), int(self.cur_ts),
