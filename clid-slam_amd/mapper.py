@@ -874,18 +874,29 @@ class Mapper:
             # The map growth's voxel pass stays in flight where the insert + window that follow take its list and count on the
             # device: its count, the compaction's two and the insert / window counts then come back in ONE read-back
             # (NeuralPoints.update); the two-phase path (a round trip of its own for the voxel count) otherwise.
-            if two_phase and defer_cmp and async_upd:
-                vox_idx = voxel_down_sample_async(update_points, nm.resolution, nm.update_counts(coord.device)[3:5], n_dev=cmp_dev[1:2])
-            pending_vox = (voxel_down_sample_launch(update_points, nm.resolution, n_dev=None if cmp_dev is None else cmp_dev[1:2])
-                           if two_phase and vox_idx is None else None)
             main = torch.cuda.current_stream(coord.device)
             side = getattr(self, "_side_stream", None)
             if side is None or side.device != coord.device:
                 side = self._side_stream = torch.cuda.Stream(device=coord.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                self._pool_append_filter_fused(coord, gcoord, sdf_label, weight, stamp, cur_pose_torch, frame_id, defer=True,
-                                               n_b_dev=None if cmp_dev is None else cmp_dev[0:1])
+
+            def fork_pool():
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._pool_append_filter_fused(coord, gcoord, sdf_label, weight, stamp, cur_pose_torch, frame_id, defer=True,
+                                                   n_b_dev=None if cmp_dev is None else cmp_dev[0:1])
+
+            pool_first = two_phase and defer_cmp and async_upd and os.environ.get("CLID_POOL_FORK_EARLY", "1") != "0"
+            if pool_first:
+                # Nothing waits for the voxel pass on the host, and the frame's critical path runs through the pool (flags, list,
+                # capacity drop, count, 220 us of compaction = 330 us, then the new-sample selection on its output): it is
+                # forked right behind the sampler's compaction, its bandwidth-bound prelude next to the voxel pass
+                fork_pool()
+            if two_phase and defer_cmp and async_upd:
+                vox_idx = voxel_down_sample_async(update_points, nm.resolution, nm.update_counts(coord.device)[3:5], n_dev=cmp_dev[1:2])
+            pending_vox = (voxel_down_sample_launch(update_points, nm.resolution, n_dev=None if cmp_dev is None else cmp_dev[1:2])
+                           if two_phase and vox_idx is None else None)
+            if not pool_first:
+                fork_pool()
             if vox_idx is not None:
                 keep_idx = None
             else:
