@@ -24,8 +24,11 @@ constexpr int kPairStride = 12;             // floats per pair in LDS: 8 gradien
 // HOISTED: neighbours and IDW weights come from the records of the chunk's search launch (clid_train_search: plain tasks of 8
 // samples, task = position / 8) -- positions only, nothing the training writes -- instead of a search inside the iteration's
 // dependent chain; omega_k is recomputed from x - p_k with the search's own operation order (bit-identical).
+#ifndef CLID_ANALYTIC_WAVES
+#define CLID_ANALYTIC_WAVES 3
+#endif
 template <bool HOISTED>
-__global__ void __launch_bounds__(CLID_BLOCK, 3)
+__global__ void __launch_bounds__(CLID_BLOCK, CLID_ANALYTIC_WAVES)
 k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, int n_rounds, const float4* __restrict__ rec) {
   __shared__ MlpLds mlp;
   __shared__ typename std::conditional<HOISTED, DeltaLds, SearchLds>::type dl;  // (in-kernel search: + the window's cell directory)
@@ -266,10 +269,13 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
 
 }  // namespace clid
 
+#ifndef CLID_ANALYTIC_MAX_BLOCKS
+#define CLID_ANALYTIC_MAX_BLOCKS 512  // two rounds per wave, two blocks per CU: 20.3 -> 17.0 us, and k_adam_all sums 512 partial rows (7.8 -> 5.2 us)
+#endif
 int clid_train_analytic_blocks(int bs) {
   const int rounds = (bs + 3) / 4;
   int nb = (rounds + CLID_BLOCK / 64 - 1) / (CLID_BLOCK / 64);
-  return nb > clid::kMaxBwdBlocks ? clid::kMaxBwdBlocks : (nb < 1 ? 1 : nb);
+  return nb > CLID_ANALYTIC_MAX_BLOCKS ? CLID_ANALYTIC_MAX_BLOCKS : (nb < 1 ? 1 : nb);
 }
 
 int clid_launch_train_analytic(const clid_map_view* mv, const clid_train_args* a, float* partial, const float* rec, hipStream_t s) {

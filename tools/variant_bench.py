@@ -7,8 +7,21 @@ flags = sys.argv[1].split()
 csrc = os.path.join(ROOT, "clid-slam_amd", "csrc")
 out = "/tmp/libclid_variant.so"
 srcs = [os.path.join(csrc, f) for f in ("api.hip", "comm.hip", "p2p.hip", "table.hip", "celldir.hip", "query.hip", "train.hip", "train_analytic.hip", "train_wf0.hip", "train_tile.hip", "mlp.hip", "sampler.hip", "mapops.hip")]
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=on",
-                       "-Wno-unused-value", "-Wno-unused-result", "-w", *flags, "-shared", *srcs, "-ldl", "-o", out])
+only = os.environ.get("VARIANT_SRCS", "").split()  # recompile just these sources, link the rest from the committed build's objects
+CC = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=on", "-Wno-unused-value", "-Wno-unused-result", "-w"]
+if only:
+    objdir = os.path.join(ROOT, "clid-slam_amd", "lib", "obj")
+    objs = []
+    for f in srcs:
+        b = os.path.basename(f)
+        o = os.path.join(objdir, b.replace(".hip", ".o"))
+        if b in only:
+            o = "/tmp/variant_" + b.replace(".hip", ".o")
+            subprocess.check_call(CC + flags + ["-c", f, "-o", o])
+        objs.append(o)
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", out])
+else:
+    subprocess.check_call(CC + flags + ["-shared", *srcs, "-ldl", "-o", out])
 import clid_slam_amd  # noqa
 from clid_slam_amd import _lib
 _lib.LIB_PATH = out
