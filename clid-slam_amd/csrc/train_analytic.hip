@@ -15,8 +15,6 @@
 
 namespace clid {
 
-constexpr int kPairsPerRound = 4 * CLID_K;  // (query, neighbour) pairs of one wave round
-constexpr int kPairStride = 12;             // floats per pair in LDS: 8 gradients | certainty increment | pad
 
 #define CLID_BFLY(x) x += dpp_mov<0x128>(x); x += dpp_mov<0x124>(x); x += dpp_mov<0x122>(x);
 #define CLID_SWAP(x) dpp_mov<0xB1>(x)  // quad_perm [1,0,3,2]: the other lane of the pair
@@ -33,11 +31,7 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
   __shared__ MlpLds mlp;
   __shared__ typename std::conditional<HOISTED, DeltaLds, SearchLds>::type dl;  // (in-kernel search: + the window's cell directory)
   __shared__ float red[(CLID_BLOCK / 64) * kRedFloats];
-  // 16-float accumulation rows: the 24 (query, neighbour) pairs of a round leave through LDS, so that 9 consecutive lanes
-  // add one pair's [8 feature gradients | certainty increment] = ONE 64-byte request at the memory-side atomic units per
-  // pair instead of 8 + 1 (the launch is bound by their ~17 G requests/s: 30 requests per sample were 29 of its 32 us)
-  __shared__ float pair_val[CLID_BLOCK / 64][kPairsPerRound * kPairStride];
-  __shared__ int pair_row[CLID_BLOCK / 64][kPairsPerRound + 4];
+  __shared__ PairLds pairs[CLID_BLOCK / 64];  // merged scatter on 16-float accumulation rows (train_common.hpp)
   if (HOISTED) stage_mlp(mlp, ta.W1, ta.b1, ta.W2, ta.b2);
   else stage_mlp_and_delta(mlp, dl, mv, ta.W1, ta.b1, ta.W2, ta.b2);
   const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48, grp = lane >> 4;
@@ -234,27 +228,7 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
         d2 = rstd * (d2 - m1 - v.z * m2); d3 = rstd * (d3 - m1 - v.w * m2);
       }
       if (merged) {
-        float* pv = pair_val[wave];
-        int* pr = pair_row[wave];
-        if (lane16 < 2 * CLID_K) {
-          const int pair = grp * CLID_K + my_k;
-          *reinterpret_cast<float4*>(&pv[pair * kPairStride + (odd ? 4 : 0)]) = make_float4(d0, d1, d2, d3);
-          if (!odd) {
-            pv[pair * kPairStride + CLID_F] = valid ? my_w : 0.f;  // np.py:714, merged by k_adam_all (column 8 of the row)
-            pr[pair] = valid ? my_j : -1;
-          }
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int pass = 0; pass < (kPairsPerRound + 6) / 7; ++pass) {  // 7 pairs x 9 columns per instruction
-          const int pl = lane / 9, col = lane - pl * 9, pair = pass * 7 + pl;
-          if (lane < 63 && pair < kPairsPerRound) {
-            const int row = pr[pair];
-            const float val = pv[pair * kPairStride + col];
-            if (row >= 0) atomicAdd(g_theta + (size_t)row * CLID_GRAD_ROW16 + col, val);
-          }
-        }
-        wave_lds_fence();
+        scatter_pairs_rows16(pairs[wave], lane, grp, my_k, odd, valid ? my_j : -1, d0, d1, d2, d3, valid ? my_w : 0.f, g_theta);
       } else if (valid && lane16 < 2 * CLID_K && ck != 0.f) {
         float* dst = g_theta + (size_t)my_j * gstride + (odd ? 4 : 0);
         atomicAdd(dst + 0, d0); atomicAdd(dst + 1, d1); atomicAdd(dst + 2, d2); atomicAdd(dst + 3, d3);

@@ -253,6 +253,40 @@ __device__ __forceinline__ void mlp_backward(const MlpLds& s, const float (&f)[C
   }
 }
 
+// 16-lane kernels (lane16 = 2 k + half, 4 query points per wave and round) on 16-float accumulation rows: the round's 24
+// (query, neighbour) pairs leave through LDS, so that 9 consecutive lanes add one pair's [8 feature gradients | certainty
+// increment] = ONE 64-byte request at the memory-side atomic units instead of 8 + 1 (those units retire ~17 G requests/s
+// whatever the width, tools/ubench_atomic.hip; 30 requests per sample were 29 of the analytic iteration's 32 us).  The
+// certainty increment (np.py:714) rides in column 8 and is merged by k_adam_all.
+constexpr int kPairsPerRound = 4 * CLID_K;  // (query, neighbour) pairs of one wave round
+constexpr int kPairStride = 12;             // floats per pair in LDS: 8 gradients | certainty increment | pad
+struct PairLds {
+  float val[kPairsPerRound * kPairStride];
+  int row[kPairsPerRound + 4];
+};
+__device__ __forceinline__ void scatter_pairs_rows16(PairLds& pl, int lane, int grp, int my_k, bool odd, int row, float d0, float d1,
+                                                     float d2, float d3, float cert_inc, float* __restrict__ rows16) {
+  if (my_k < CLID_K) {
+    const int pair = grp * CLID_K + my_k;
+    *reinterpret_cast<float4*>(&pl.val[pair * kPairStride + (odd ? 4 : 0)]) = make_float4(d0, d1, d2, d3);
+    if (!odd) {
+      pl.val[pair * kPairStride + CLID_F] = cert_inc;
+      pl.row[pair] = row;  // -1: nothing to add for this pair
+    }
+  }
+  wave_lds_fence();
+#pragma unroll
+  for (int pass = 0; pass < (kPairsPerRound + 6) / 7; ++pass) {  // 7 pairs x 9 columns per instruction
+    const int pi = lane / 9, col = lane - pi * 9, pair = pass * 7 + pi;
+    if (lane < 63 && pair < kPairsPerRound) {
+      const int r = pl.row[pair];
+      const float val = pl.val[pair * kPairStride + col];
+      if (r >= 0) atomicAdd(rows16 + (size_t)r * CLID_GRAD_ROW16 + col, val);
+    }
+  }
+  wave_lds_fence();
+}
+
 }  // namespace clid
 
 // ---- launches under the optional per-kernel timing (clid_train_args.prof, train.hip) ------------------------------------

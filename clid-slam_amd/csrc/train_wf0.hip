@@ -15,7 +15,8 @@
 // The two scratch values of a shifted copy live in the label / loss-weight fields of ITS OWN record slot (qdesc.z / .w, which
 // mean nothing for a copy): no side buffer, no capacity bound, and a record can be decoded again (pass 0 rewrites them).
 // Per neighbour k the backward is the single-query decoder backward (train_common.hpp mlp_backward) with dz = s w_k dL/dsdf;
-// the rows' gradients go through the layer-norm backward on the two lanes that loaded the row and out as 4-float atomics.
+// the rows' gradients go through the layer-norm backward on the two lanes that loaded the row and out as ONE request per
+// (query, neighbour) pair (scatter_pairs_rows16, train_common.hpp).
 #include "train_common.hpp"
 
 namespace clid {
@@ -37,6 +38,7 @@ k_train_wf0(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, i
   __shared__ MlpLds mlp;
   __shared__ Wf0Lds wl;
   __shared__ float red[(kWf0Block / 64) * kRedFloats];
+  __shared__ PairLds pairs[kWf0Block / 64];  // merged scatter on 16-float accumulation rows (train_common.hpp)
   stage_mlp(mlp, ta.W1, ta.b1, ta.W2, ta.b2);
   const int lane = threadIdx.x & 63, lane16 = lane & 15, gib = threadIdx.x >> 4;
   const int my_k = lane16 >> 1;
@@ -47,6 +49,7 @@ k_train_wf0(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, i
   float bce_acc = 0.f, eik_acc = 0.f;
   const int gstride = ta.grad_stride == CLID_GRAD_ROW16 ? CLID_GRAD_ROW16 : CLID_F;
   float* g_theta = ta.grad + CLID_GRAD_OFFSET(gstride);
+  const bool merged = gstride == CLID_GRAD_ROW16;
   const float inv_sigma = fdiv(1.0f, ta.sigma);
   const float inv_two_eps = fdiv(1.0f, 2.0f * ta.fd_eps);
   const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
@@ -168,9 +171,9 @@ k_train_wf0(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, i
 
     // ================= training_mode side effects (np.py:708-733): batch samples and shifted copies alike
     if (valid && !odd) {
-      atomicAdd(&mv.cert[my_j], my_w);
-      const int ts = __float_as_int(qi.w);
-      if (PASS == 1 && mv.ts_update && ta.pool_ts) atomicMax(&mv.ts_update[my_j], ts);
+      if (!merged) atomicAdd(&mv.cert[my_j], my_w);
+      const int ts = __float_as_int(qi.w);  // amax is idempotent: only a newer stamp needs the atomic
+      if (PASS == 1 && mv.ts_update && ta.pool_ts && mv.ts_update[my_j] < ts) atomicMax(&mv.ts_update[my_j], ts);
     }
 
     // ================= backward, neighbour by neighbour
@@ -215,7 +218,10 @@ k_train_wf0(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, i
       d0 = rstd * (d0 - m1 - v.x * m2); d1 = rstd * (d1 - m1 - v.y * m2);
       d2 = rstd * (d2 - m1 - v.z * m2); d3 = rstd * (d3 - m1 - v.w * m2);
     }
-    if (valid && dsdf != 0.f) {
+    if (merged) {
+      scatter_pairs_rows16(pairs[threadIdx.x >> 6], lane, lane >> 4, my_k, odd, valid ? my_j : -1, d0, d1, d2, d3,
+                           valid ? my_w : 0.f, g_theta);
+    } else if (valid && dsdf != 0.f) {
       float* dst = g_theta + (size_t)my_j * gstride + (odd ? 4 : 0);
       atomicAdd(dst + 0, d0); atomicAdd(dst + 1, d1); atomicAdd(dst + 2, d2); atomicAdd(dst + 3, d3);
     }

@@ -389,9 +389,9 @@ class Mapper:
                 # the neighbour searches do not depend on the training state: one launch per chunk of iterations
                 # resolves this rank's shard of every batch, then decode/backward -> all-reduce -> Adam per iteration.
                 # With the tile kernels the certainty increments ride in the all-reduced accumulation rows (every rank's
-                # Adam launch applies the global sum), and so they do in the analytic-eikonal iteration (its pairs leave as
+                # Adam launch applies the global sum), and so they do in the analytic-eikonal and weighted_first: False iterations (their pairs leave as
                 # whole rows); the other 16-lane kernels add this rank's share to the array directly
-                cert_in_rows = tile or eik_mode == 2
+                cert_in_rows = tile or eik_mode == 2 or bool(ta.decode_each_neighbour)
                 cert0 = None if cert_in_rows else nm.local_point_certainties.clone()
                 comm = _lib.rccl_comm(dist)
                 if cbuf is not None and hoist and want_p2p:
