@@ -952,25 +952,36 @@ __device__ __forceinline__ float* mlp_param_ptr(float* W1, float* b1, float* W2,
   return b2;
 }
 
-// sum of column p over the nb partial rows by ONE WAVE: lane l takes rows l, l + 64, ... with all of its loads in
-// flight at once (7 at nb = 410), then a wave reduction -- one memory round trip instead of a chain of them
-__device__ __forceinline__ float column_sum_wave(const float* __restrict__ partial, int nb, int p) {
-  const int lane = threadIdx.x & 63;
-  float a[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = 0.f;
-  float s1 = 0.f;
-  if (p < CLID_MLP_PARAMS + 2) {
-    int b = lane;
-#pragma unroll
-    for (int i = 0; i < 8; ++i, b += 64)
-      if (b < nb) a[i] = partial[(size_t)b * kPartialStride + p];
-    for (; b < nb; b += 64) s1 += partial[(size_t)b * kPartialStride + p];
-  }
-  return wave_sum((((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + s1);
-}
-constexpr int kColsPerBlock = 4;  // 256 threads = 4 waves = 4 columns of the partial rows
+// sums of the 16 columns p0 .. p0+15 over the nb partial rows by ONE BLOCK of 256 threads: thread (c = t & 15, rg = t >> 4)
+// takes column p0 + c of rows rg, rg + 16, ... with up to 32 loads in flight, so a load instruction of a wave reads 4 rows x
+// 64 contiguous bytes (one wave per column read 64 different lines per instruction: 835 x nb lines = 22 MB through L2 at
+// nb = 410 for 1.4 MB of partial rows, and k_adam_all's time followed nb: 4.35 / 5.2 / 7.8 us at 256 / 512 / 1024 rows).
+// The row groups are folded by two lane exchanges and one trip through LDS; the sums arrive on threads 0..15.
+constexpr int kColsPerBlock = 16;
 constexpr int kColBlocks = (CLID_MLP_PARAMS + 2 + kColsPerBlock - 1) / kColsPerBlock;
+__device__ __forceinline__ float column_sum_block16(const float* __restrict__ partial, int nb, int p0, float* red /* LDS [64] */) {
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p0 + c < kPartialStride) {  // (the last block's columns beyond the row's pad would run into the next row)
+    const float* __restrict__ src = partial + p0 + c;
+    for (int b0 = rg; b0 < nb; b0 += 16 * 32) {
+      float a[32];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const int b = b0 + 16 * i;
+        a[i] = b < nb ? src[(size_t)b * kPartialStride] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 32; ++i) acc[i & 3] += a[i];
+    }
+  }
+  float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  if ((threadIdx.x & 63) < 16) red[(threadIdx.x >> 6) * 16 + c] = s;
+  __syncthreads();
+  return threadIdx.x < 16 ? (red[c] + red[16 + c]) + (red[32 + c] + red[48 + c]) : 0.f;
+}
 
 __device__ __forceinline__ void finish_loss(int p, float tot, float* loss_out, float inv_n_main, float inv_n_eik,
                                             float weight_e) {
@@ -1104,13 +1115,16 @@ k_reduce_partials(const float* __restrict__ partial, int nb, float* __restrict__
     }
     return;
   }
-  const int p = blockIdx.x * kColsPerBlock + (threadIdx.x >> 6);
-  if (p >= CLID_MLP_PARAMS + 2) return;
-  if (!train_decoder && p < CLID_MLP_PARAMS) return;  // frozen decoder: only the loss columns carry data
-  const float tot = column_sum_wave(partial, nb, p);
-  if ((threadIdx.x & 63) != 0) return;
-  if (p < CLID_MLP_PARAMS) dst[p] = tot;
-  else finish_loss(p, tot, loss_out, inv_n_main, inv_n_eik, weight_e);
+  __shared__ float red[64];
+  const int p0 = (int)blockIdx.x * kColsPerBlock, p = p0 + (int)(threadIdx.x & 15);
+  if (!train_decoder && p0 + kColsPerBlock <= CLID_MLP_PARAMS) return;  // frozen decoder: only the loss columns carry data
+  const float tot = column_sum_block16(partial, nb, p0, red);
+  if (threadIdx.x >= 16 || p >= CLID_MLP_PARAMS + 2) return;
+  if (p < CLID_MLP_PARAMS) {
+    if (train_decoder) dst[p] = tot;
+  } else {
+    finish_loss(p, tot, loss_out, inv_n_main, inv_n_eik, weight_e);
+  }
 }
 
 struct AdamLaunch {
@@ -1126,7 +1140,7 @@ struct AdamLaunch {
   const float* cbuf;       // non-null (with ti): gradients / certainty increments / decoder gradients from the compact buffer
 };
 
-// blocks [0, kColBlocks): 4 decoder parameters / loss columns each (reduce partial rows or read grad), Adam
+// blocks [0, kColBlocks): 16 decoder parameters / loss columns each (reduce partial rows or read grad), Adam
 // blocks [kColBlocks, +n_feat_blocks): dense Adam over the feature table (float4), gradient zeroed in the same pass
 __global__ void __launch_bounds__(256) k_adam_all(AdamLaunch a) {
   // the column blocks carry the longer chain (7 loads -> wave sum -> Adam -> store): they are dispatched first
@@ -1232,19 +1246,20 @@ __global__ void __launch_bounds__(256) k_adam_all(AdamLaunch a) {
     }
     return;
   }
-  const int p = (int)blockIdx.x * kColsPerBlock + (threadIdx.x >> 6);
-  if (p >= CLID_MLP_PARAMS + 2) return;
-  if (!a.train_decoder && p < CLID_MLP_PARAMS) return;  // frozen decoder: no decoder gradients were produced
+  __shared__ float red[64];
+  const int p0 = (int)blockIdx.x * kColsPerBlock, p = p0 + (int)(threadIdx.x & 15);
+  if (!a.train_decoder && p0 + kColsPerBlock <= CLID_MLP_PARAMS) return;  // frozen decoder: no decoder gradients were produced
+  const bool owner = threadIdx.x < 16 && p < CLID_MLP_PARAMS + 2;
   float* dst = nullptr;
   float P = 0.f, M = 0.f, V = 0.f;
-  if (p < CLID_MLP_PARAMS && a.train_decoder) {  // parameter and state requested before the column sum, not after it
+  if (owner && p < CLID_MLP_PARAMS && a.train_decoder) {  // parameter and state requested before the column sum, not after it
     dst = mlp_param_ptr(a.W1, a.b1, a.W2, a.b2, p);
     P = *dst; M = a.m_mlp[p]; V = a.v_mlp[p];
   }
   float gsum;
-  if (a.partial) gsum = column_sum_wave(a.partial, a.nb, p);
-  else gsum = (p < CLID_MLP_PARAMS) ? (a.cbuf ? a.cbuf[p] : a.grad[p]) : 0.f;
-  if ((threadIdx.x & 63) != 0) return;
+  if (a.partial) gsum = column_sum_block16(a.partial, a.nb, p0, red);
+  else gsum = (owner && p < CLID_MLP_PARAMS) ? (a.cbuf ? a.cbuf[p] : a.grad[p]) : 0.f;
+  if (!owner) return;
   if (p < CLID_MLP_PARAMS) {
     if (a.train_decoder) {
       adam_update(P, gsum, M, V, a.k, 0.f);

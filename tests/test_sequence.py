@@ -128,7 +128,9 @@ def test_subt_sequence_harness_first_frames_vs_oracle(freeze_after):
             # zero-feature rows on the list -- 1 898 of 61 k rows were seen once; the list must stay a small minority)
             assert r["kink_rows"] <= max(256, r["rows"] // 10) and r["dgrad_theta_rel_kink_rows"] <= 5e-3, (c["frame"], t, r)
             assert r.get("dgrad_decoder_rel", 0.0) <= 1e-4, (c["frame"], t, r)
-            assert r["rows_nonzero_only_in_hip"] <= 4 and r["rows_nonzero_only_in_oracle"] <= 4 and r["residue_rel"] <= 1e-6, (c["frame"], t, r)
+            # (the COUNT of such rows moves with the state -- 0 to 6 of ~60 k rows were seen over boxes and summation orders of
+            # the decoder's column sums --; what gates is that they hold nothing but residue: <= 1e-6 of the largest entry)
+            assert r["rows_nonzero_only_in_hip"] <= 16 and r["rows_nonzero_only_in_oracle"] <= 16 and r["residue_rel"] <= 1e-6, (c["frame"], t, r)
         if "max_dtheta" in c:
             # free-running parameters after the call: Adam with eps = 1e-15 moves an entry whose gradient is cancellation
             # residue by up to lr * iters differently in ANY two correct summation orders, so only that hard bound gates;
