@@ -679,6 +679,10 @@ extern "C" int clid_track_model_dev(const clid_map_view* mv, const float* W1, co
                             max_sdf_std, pc_imu, N, sdf_out, grad_out, pmap_out, valid_out, normal_eq, stream);
 }
 
+bool clid_sdf_query_tile_ok(const clid_map_view* mv);
+int clid_launch_sdf_query_tile(const clid_map_view* mv, const float* W1, const float* b1, const float* W2, const float* b2,
+                               float sdf_scale, const float* x, int N, float* sdf_out, int* nn_out, hipStream_t s);
+
 extern "C" int clid_sdf_query(const clid_map_view* mv, const float* W1, const float* b1, const float* W2,
                               const float* b2, float sdf_scale, const float* x, int32_t N, float* sdf_out,
                               int32_t* nn_out, void* stream) {
@@ -688,6 +692,12 @@ extern "C" int clid_sdf_query(const clid_map_view* mv, const float* W1, const fl
     return CLID_E_ARG;
   }
   if (N == 0) return CLID_OK;
+  // weighted_first: True: the tile kernel (csrc/query_tile.hip: 8-lane search + decoder on the matrix cores);
+  // CLID_SDF_TILE=0 keeps the 16-lane kernel (A/B, tests compare the two)
+  const char* tile_env = getenv("CLID_SDF_TILE");
+  const bool tile_on = !(tile_env && tile_env[0] == '0');
+  if (tile_on && clid_sdf_query_tile_ok(mv))
+    return clid_launch_sdf_query_tile(mv, W1, b1, W2, b2, sdf_scale, x, N, sdf_out, nn_out, (hipStream_t)stream);
   int nb = (N + CLID_QPB - 1) / CLID_QPB;
   if (nb > 8192) nb = 8192;
   hipLaunchKernelGGL(clid::k_sdf_query, dim3(nb), dim3(CLID_BLOCK), 0, (hipStream_t)stream, *mv, W1, b1, W2, b2,

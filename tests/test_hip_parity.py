@@ -621,6 +621,32 @@ def test_dense_sdf_query_vs_oracle(env, ln, loc):
     assert (nn == 0).any() and (nn >= 4).any()
 
 
+@pytest.mark.parametrize("ln,loc", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_sdf_query_tile_kernel_equals_the_16_lane_kernel(env, ln, loc, monkeypatch):
+    """Row N3: the matrix-core tile kernel (csrc/query_tile.hip: 8-lane search of the training launches + MFMA decoder) against
+    the 16-lane VALU kernel it replaces, on points inside the map, around it (outside the cell directory's box: probing
+    search) and far away; ragged sizes.  Neighbour counts bit-exact, SDF within fp32 summation-order noise."""
+    from clid_slam_amd import mesher
+
+    g = gio.load("g2_query.npz")
+    cfg = env.config(layer_norm_on=bool(ln))
+    nm = env.neural_points(cfg)
+    dec = env.decoder(cfg)
+    gen = torch.Generator().manual_seed(3)
+    base = gio.T(g["x"])
+    x = torch.cat([base, base + 0.3 * torch.randn(base.shape, generator=gen), base + 6.0 * torch.randn(base.shape, generator=gen),
+                   base[:37] * 50.0]).cuda()
+    for n in (x.shape[0], 1, 15, 17, 1000 + 13):
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("CLID_SDF_TILE", mode)
+            sdf, _, _, mask = mesher.query_points(nm, dec, cfg, x[:n], bs=1 << 20, query_locally=bool(loc), mask_min_nn_count=4)
+            out[mode] = (sdf.clone(), mask.clone())
+        assert torch.equal(out["0"][1], out["1"][1]), n
+        assert maxerr(out["0"][0], out["1"][0]) <= 1e-6, n
+    assert out["1"][1].any() and not out["1"][1].all()
+
+
 @pytest.mark.parametrize("ln,loc,wf", [(0, 0, 1), (0, 1, 1), (1, 0, 1), (1, 1, 1), (0, 0, 0), (0, 1, 0), (1, 0, 0), (1, 1, 0)])
 def test_mesher_query_points_vs_reference_g12(env, ln, loc, wf):
     """Row N3 against the reference's own `Mesher.query_points` output (fixture G12), through the `Mesher` drop-in, for both
