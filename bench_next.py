@@ -209,7 +209,7 @@ def main():
         "config": {"workload": "box-room map of bench.py, global map view, infer_bs = %d" % cfg.infer_bs,
                    "points": args.points, "neural_points": int(nm.neural_points.shape[0]),
                    "mask_fraction": float(mask3.mean().item())},
-        "roofline": {"bound": "hbm", "kernel": "k_sdf_query", "achieved": alg3 / t3 / 1e9, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_sdf_query_tile", "achieved": alg3 / t3 / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": alg3 / t3 / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("k_sdf_query", args.points == 4194304),
                      "algorithmic_bytes_per_launch": alg3 * min(cfg.infer_bs, args.points) / args.points},
     }

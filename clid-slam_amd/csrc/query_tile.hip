@@ -16,7 +16,7 @@ namespace clid {
 
 constexpr int kQtBlock = 256, kQtWaves = kQtBlock / 64;
 #ifndef CLID_QT_WAVES
-#define CLID_QT_WAVES 6  // waves per SIMD the kernel is compiled for
+#define CLID_QT_WAVES 4  // waves per SIMD the kernel is compiled for (128 VGPRs; measured 2 / 3 / 4 / 5 / 6 / 8: 1.20 / 0.96 / 0.88 / 1.04 / 1.15 / 1.00 ms per 4.2 M points)
 #endif
 
 struct QtHead {

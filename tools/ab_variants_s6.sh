@@ -1,7 +1,6 @@
-# developer tool (GPU box): A/B of compile-time variants through tools/variant_bench.py (only the named source is recompiled)
+# developer tool (GPU box): A/B of compile-time variants (only the named source is recompiled)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/s6; o=gpurun_out/s6/variants.txt; : > $o
-export VARIANT_SRCS=train_tile.hip
-for f in "-DCLID_TILE_WAVES_SMALL=4" "-DCLID_TILE_WAVES_SMALL=2" "-DCLID_TILE_WAVES_SMALL=8" "-DCLID_TILE_WAVES_SMALL=4" "-DCLID_TILE_WAVES_SMALL=2" "-DCLID_TILE_WAVES_SMALL=8"; do
-  python tools/variant_bench.py "$f" --steps 200 --warmup 20 --frame-calls 0 >> $o 2>> gpurun_out/s6/variants.err
+for f in "-DCLID_QT_WAVES=4" "-DCLID_QT_WAVES=3" "-DCLID_QT_WAVES=2" "-DCLID_QT_WAVES=4" "-DCLID_QT_WAVES=3"; do
+  python tools/time_sdf_query.py "$f" >> $o 2>> gpurun_out/s6/variants.err
 done
 cat $o
