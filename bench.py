@@ -279,6 +279,8 @@ def main():
         returns (seconds = max over the ranks, split of the region on this rank)."""
         for _ in range(args.warmup):  # W untimed steps, one per call: the GPU's clocks ramp over several hundred us of work
             mp.mapping(1)             # (a single 5-iteration call leaves the first timed call 14 % slow: tools/warm_clocks.py)
+            torch.cuda.synchronize()  # each step complete before the next is enqueued: five calls queued back to back leave
+                                      # the first timed call 15-20 us (3 %) slow (tools/warm_clocks.py five / fivesync)
         sync()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()

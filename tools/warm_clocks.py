@@ -14,6 +14,29 @@ elif mode == "same": mp.mapping(20)
 elif mode == "sleep": mp.mapping(5); torch.cuda.synchronize(); time.sleep(0.5)
 elif mode == "five":
     for _ in range(5): mp.mapping(1)
+elif mode == "fivesync":
+    for _ in range(5): mp.mapping(1); torch.cuda.synchronize()
+elif mode == "fivehot":  # the loop itself first (everything resident), then the driver's warm-up shape
+    for _ in range(50): mp.mapping(20)
+    torch.cuda.synchronize()
+    for _ in range(5): mp.mapping(1)
+elif mode == "fivehotsync":
+    for _ in range(50): mp.mapping(20)
+    torch.cuda.synchronize()
+    for _ in range(5): mp.mapping(1); torch.cuda.synchronize()
+elif mode == "busy":  # ~100 ms of matrix products, then the driver's warm-up shape
+    a = torch.randn(4096, 4096, device="cuda:0")
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.1:
+        a @ a
+    torch.cuda.synchronize()
+    for _ in range(5): mp.mapping(1)
+elif mode == "loop":  # ~100 ms of the loop itself
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.1:
+        mp.mapping(20)
+    torch.cuda.synchronize()
+    for _ in range(5): mp.mapping(1)
 torch.cuda.synchronize()
 for r in range(4):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
