@@ -1292,6 +1292,7 @@ __device__ __forceinline__ void sort_pairs(unsigned (&key)[ITEMS], unsigned (&po
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) digit[r] = key[r] & 0xFFu;
   counting_pass<ITEMS>(digit, dest, tab, scan_tmp);
+  CLID_STAMP(7);
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) seq[dest[r]] = ((key[r] >> 8) << 14) | pos[r];
   __syncthreads();
@@ -1301,6 +1302,7 @@ __device__ __forceinline__ void sort_pairs(unsigned (&key)[ITEMS], unsigned (&po
     digit[r] = (s[r] >> 14) & 0xFFu;
   }
   counting_pass<ITEMS>(digit, dest, tab, scan_tmp);  // (its barriers also cover the reads of seq above)
+  CLID_STAMP(8);
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) seq[dest[r]] = ((s[r] >> 22) << 14) | (s[r] & 0x3FFFu);
   __syncthreads();
@@ -1353,29 +1355,46 @@ k_batch_sort_bucket(const long long* __restrict__ draws, const unsigned* __restr
   __shared__ unsigned tab[kSortBins * kSortWaves];
   __shared__ unsigned seq[CAP];
   __shared__ unsigned sel_key[CAP], sel_pos[CAP];
-  __shared__ unsigned samp[256], sorted[256], wcnt[kSortWaves], wlow[kSortWaves];
+  __shared__ __attribute__((aligned(16))) unsigned samp[256];
+  __shared__ unsigned sorted[256], prank[kSortThreads / 256][256], wcnt[kSortWaves], wlow[kSortWaves];
   __shared__ typename BinScan::TempStorage scan_tmp;
   const int bk = blockIdx.x % kSortBuckets;
   const int sg = blockIdx.x / kSortBuckets;
   const int it = sg / full_segs, seg = seg0 + (sg - it * full_segs);
   const long long e0 = (long long)it * bs + (long long)seg * kSortSeg;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // ---- splitters: the 256 keys at positions 0, 64, 128, ... ranked by (key, sample number)
-  if (threadIdx.x < 256) samp[threadIdx.x] = keys[e0 + 64 * threadIdx.x];
+  // ---- splitters: the 256 keys at positions 0, 64, 128, ... ranked by (key, sample number).  All threads take part: thread
+  // (sample i, part p) counts the samples of quarter p below sample i, 4 per LDS read (256 sequential reads per thread were a
+  // quarter of the launch: 15.9 k of 63 k cycles, tools/sort_timing.py)
+  CLID_STAMP(0);
+  if (threadIdx.x < 256) samp[threadIdx.x] = (keys[e0 + 64 * threadIdx.x] << 8) | threadIdx.x;  // (24-bit code, sample number): distinct
   __syncthreads();
-  if (threadIdx.x < 256) {
-    const unsigned c = samp[threadIdx.x];
+  CLID_STAMP(1);
+  {
+    constexpr int kParts = kSortThreads / 256, kPer4 = 64 / kParts;  // uint4 reads per thread
+    const int i = threadIdx.x & 255, part = threadIdx.x >> 8;
+    const unsigned c = samp[i];
+    const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(samp) + part * kPer4;
     unsigned rank = 0;
-    for (int j = 0; j < 256; ++j) {
-      const unsigned o = samp[j];
-      rank += (o < c || (o == c && j < (int)threadIdx.x)) ? 1u : 0u;
+#pragma unroll
+    for (int jj = 0; jj < kPer4; ++jj) {
+      const uint4 o = s4[jj];
+      rank += (o.x < c ? 1u : 0u) + (o.y < c ? 1u : 0u) + (o.z < c ? 1u : 0u) + (o.w < c ? 1u : 0u);
     }
-    sorted[rank] = c;
+    prank[part][i] = rank;
   }
   __syncthreads();
-  unsigned split[kSortBuckets - 1];
+  if (threadIdx.x < 256) {
+    unsigned rank = 0;
 #pragma unroll
-  for (int k = 1; k < kSortBuckets; ++k) split[k - 1] = sorted[k * (256 / kSortBuckets)];
+    for (int p2 = 0; p2 < kSortThreads / 256; ++p2) rank += prank[p2][threadIdx.x];
+    sorted[rank] = samp[threadIdx.x] >> 8;
+  }
+  __syncthreads();
+  CLID_STAMP(2);
+  // this block's key range [lo, hi): splitter k = the sample of rank k * 256 / kSortBuckets
+  const unsigned lo = bk > 0 ? sorted[bk * (256 / kSortBuckets)] : 0u;
+  const unsigned hi = bk + 1 < kSortBuckets ? sorted[(bk + 1) * (256 / kSortBuckets)] : 0xFFFFFFFFu;  // (keys are 24-bit codes)
   // ---- scan of the segment in wave-blocked order: count, then keep this block's key range in position order
   unsigned key[SCAN];
   unsigned cm = 0, cl = 0;
@@ -1384,12 +1403,10 @@ k_batch_sort_bucket(const long long* __restrict__ draws, const unsigned* __restr
   for (int r = 0; r < SCAN; ++r) {
     const int p = wave * (SCAN * 64) + r * 64 + lane;
     key[r] = keys[e0 + p];
-    int b = 0;
-#pragma unroll
-    for (int k = 0; k < kSortBuckets - 1; ++k) b += key[r] >= split[k] ? 1 : 0;
-    const bool mine = b == bk;
+    const bool below = key[r] < lo;  // (bucket b = number of splitters <= key: b < bk <=> key < split[bk - 1])
+    const bool mine = !below && key[r] < hi;
     cm += (unsigned)__popcll(__ballot(mine));
-    cl += (unsigned)__popcll(__ballot(b < bk));
+    cl += (unsigned)__popcll(__ballot(below));
     mine_bits |= mine ? (1ULL << r) : 0ULL;
   }
   if (lane == 0) {
@@ -1397,6 +1414,7 @@ k_batch_sort_bucket(const long long* __restrict__ draws, const unsigned* __restr
     wlow[wave] = cl;
   }
   __syncthreads();
+  CLID_STAMP(3);
   unsigned wbase = 0, m = 0, lower = 0;
 #pragma unroll
   for (int w = 0; w < kSortWaves; ++w) {
@@ -1424,6 +1442,7 @@ k_batch_sort_bucket(const long long* __restrict__ draws, const unsigned* __restr
   }
   if (overflow) return;
   __syncthreads();
+  CLID_STAMP(4);
   unsigned k4[ITEMS], pos[ITEMS], dest[ITEMS];
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
@@ -1432,10 +1451,17 @@ k_batch_sort_bucket(const long long* __restrict__ draws, const unsigned* __restr
     pos[r] = i < m ? sel_pos[i] : 0x3FFFu;
   }
   sort_pairs<ITEMS>(k4, pos, dest, tab, seq, scan_tmp);
+  CLID_STAMP(5);
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r)
     if (dest[r] < m) index_out[e0 + lower + dest[r]] = draws[e0 + pos[r]];
+  CLID_STAMP(6);
 }
+#ifdef CLID_TIMING
+extern "C" int clid_debug_read_stamps_mapops(long long* out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(clid::clid_stamps), sizeof(long long) * 256 * 32) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int64_t clid_mapping_prep_workspace_bytes(int32_t iters, int32_t bs) {
   const long long n = (long long)iters * bs;
