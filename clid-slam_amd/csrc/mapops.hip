@@ -1214,11 +1214,11 @@ k_mapping_prep(float4* __restrict__ zero4, long long n_zero4, long long* __restr
 // axis: wraps every 256 voxels) and sorts (key, position) in LDS with a stable block radix sort, so the order is a function
 // of the draws alone: identical on every rank.  The zero fill is shared by all blocks.
 constexpr int kSortSeg = 16384, kSortThreads = 1024, kSortBins = 256, kSortWaves = kSortThreads / 64;
-#ifndef CLID_SORT_BUCKETS
-#define CLID_SORT_BUCKETS 8
-#endif
-constexpr int kSortBuckets = CLID_SORT_BUCKETS;        // blocks (= CUs) that share one full segment
-constexpr int kSortBucketItems = 32 / kSortBuckets;  // capacity of a bucket block = twice the mean
+// blocks (= CUs) that share one full segment: 8 with a capacity of twice the mean bucket (4 elements per thread), or -- while
+// the call's blocks still find a CU each (iterations x segments <= 16: the per-frame calls of slam.py) -- 16 with three times
+// the mean (3 per thread): the counting passes are bound by the VALU rate of the block's ONE CU
+constexpr int kSortBucketsFew = 8, kSortBucketsMany = 16;
+__host__ __device__ constexpr int sort_bucket_items(int buckets) { return buckets == kSortBucketsMany ? 3 : 32 / buckets; }
 using BinScan = hipcub::BlockScan<unsigned, kSortThreads>;
 
 // lanes of the wave that hold the same 8-bit digit as this lane (an OR-mask row in LDS per wave does the same with two LDS
@@ -1344,14 +1344,16 @@ k_batch_sort_tail(const long long* __restrict__ draws, const unsigned* __restric
     if ((int)dest[r] < n) index_out[e0 + dest[r]] = draws[e0 + pos[r]];
 }
 
-// k_batch_sort_bucket: a FULL segment is shared by kSortBuckets blocks (sorting in LDS is bound by one CU's LDS rate: 54 us
+// k_batch_sort_bucket: a FULL segment is shared by BUCKETS blocks (sorting in LDS is bound by one CU's LDS rate: 54 us
 // for 16 384 elements in one block).  Every block derives the same 7 splitters from the same 256 sample keys, scans the
 // segment's keys (64 KB, coalesced), keeps the elements of ITS key range in position order, sorts them and writes them
 // behind the smaller ranges.  No communication between the blocks.
+template <int BUCKETS>
 __global__ void __launch_bounds__(kSortThreads)
 k_batch_sort_bucket(const long long* __restrict__ draws, const unsigned* __restrict__ keys, long long* __restrict__ index_out,
                     int bs, int full_segs, int seg0) {
-  constexpr int ITEMS = kSortBucketItems, CAP = ITEMS * kSortThreads, SCAN = kSortSeg / kSortThreads;
+  constexpr int kSortBuckets = BUCKETS;
+  constexpr int ITEMS = sort_bucket_items(BUCKETS), CAP = ITEMS * kSortThreads, SCAN = kSortSeg / kSortThreads;
   __shared__ unsigned tab[kSortBins * kSortWaves];
   __shared__ unsigned seq[CAP];
   __shared__ unsigned sel_key[CAP], sel_pos[CAP];
@@ -1503,6 +1505,8 @@ extern "C" int clid_mapping_prep(float* zero_base, int64_t zero_floats, int64_t*
   const int full_segs = seg_full_end > seg0 ? seg_full_end - seg0 : 0;
   const int tail_base = seg_full_end * kSortSeg;           // a shorter last segment exists iff the window reaches bs
   const int tail = (c0 + nc) - tail_base;                  // > 0 only then (c0 + nc == bs, bs no multiple of the segment)
+  const int kSortBuckets = (long long)iters * ((bs + kSortSeg - 1) / kSortSeg) <= 16 ? kSortBucketsMany : kSortBucketsFew;  // (by the
+  // CALL's shape, not the shard's: every rank of a data-parallel run takes the same path)
   const long long sort_blocks = (long long)iters * full_segs * kSortBuckets;
   const bool sorted = want_sort && n_index > 0 && sort_blocks < (1LL << 31);
   char* ws = static_cast<char*>(sort_workspace);
@@ -1516,8 +1520,14 @@ extern "C" int clid_mapping_prep(float* zero_base, int64_t zero_floats, int64_t*
                      reinterpret_cast<const long long*>(new_idx), (unsigned long long)n_new, (unsigned long long)seed,
                      (unsigned long long)counter, pool_coord, resolution, keys, c0, nc > 0 ? nc : 1);
   if (sorted && full_segs > 0)
-    hipLaunchKernelGGL(k_batch_sort_bucket, dim3((unsigned)sort_blocks), dim3(kSortThreads), 0, s, draws, keys,
-                       reinterpret_cast<long long*>(index_out), bs, full_segs, seg0);
+  {
+    if (kSortBuckets == kSortBucketsMany)
+      hipLaunchKernelGGL(k_batch_sort_bucket<kSortBucketsMany>, dim3((unsigned)sort_blocks), dim3(kSortThreads), 0, s, draws, keys,
+                         reinterpret_cast<long long*>(index_out), bs, full_segs, seg0);
+    else
+      hipLaunchKernelGGL(k_batch_sort_bucket<kSortBucketsFew>, dim3((unsigned)sort_blocks), dim3(kSortThreads), 0, s, draws, keys,
+                         reinterpret_cast<long long*>(index_out), bs, full_segs, seg0);
+  }
   if (sorted && tail > 0)
     hipLaunchKernelGGL(k_batch_sort_tail, dim3((unsigned)iters), dim3(kSortThreads), 0, s, draws, keys,
                        reinterpret_cast<long long*>(index_out), bs, tail_base);
