@@ -22,8 +22,13 @@ namespace clid {
 // HOISTED: neighbours and IDW weights come from the records of the chunk's search launch (clid_train_search: plain tasks of 8
 // samples, task = position / 8) -- positions only, nothing the training writes -- instead of a search inside the iteration's
 // dependent chain; omega_k is recomputed from x - p_k with the search's own operation order (bit-identical).
+// This lane's share of the decoder lives in registers (52 floats) and the kernel is compiled for 2 waves per SIMD -- what a launch
+// of <= 512 blocks puts there anyway: 16.2 -> 14.6 us against the weights in LDS at 3 waves (with 3 waves it spills: 23 us)
 #ifndef CLID_ANALYTIC_WAVES
-#define CLID_ANALYTIC_WAVES 3
+#define CLID_ANALYTIC_WAVES 2
+#endif
+#ifndef CLID_ANALYTIC_REGW
+#define CLID_ANALYTIC_REGW 1
 #endif
 template <bool HOISTED>
 __global__ void __launch_bounds__(CLID_BLOCK, CLID_ANALYTIC_WAVES)
@@ -41,6 +46,20 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
   MlpAcc acc;
   acc.zero();
   float bce_acc = 0.f, eik_acc = 0.f;
+#if CLID_ANALYTIC_REGW
+  // this lane's share of the decoder (hidden units lane16 + 16 u) in registers: the forward pass, u = s (W2 .* a) W1 and
+  // W1 t each walk it once per round -- three LDS reads per weight and round otherwise
+  float w1r[CLID_HPL][CLID_D], b1r[CLID_HPL], w2r[CLID_HPL];
+#pragma unroll
+  for (int uu = 0; uu < CLID_HPL; ++uu) {
+    const int h = lane16 + CLID_G * uu;
+#pragma unroll
+    for (int c = 0; c < CLID_D; ++c) w1r[uu][c] = mlp.w[h * CLID_D + c];
+    b1r[uu] = mlp.w[CLID_H * CLID_D + h];
+    w2r[uu] = mlp.w[CLID_H * CLID_D + CLID_H + h];
+  }
+  const float b2r = mlp.w[CLID_MLP_PARAMS - 1];
+#endif
   const int gstride = ta.grad_stride == CLID_GRAD_ROW16 ? CLID_GRAD_ROW16 : CLID_F;
   const bool merged = gstride == CLID_GRAD_ROW16;
   float* g_theta = ta.grad + CLID_GRAD_OFFSET(gstride);
@@ -119,19 +138,44 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
       f[8] = r0; f[9] = r1; f[10] = r2;
     }
     float pre[CLID_HPL];
+#if CLID_ANALYTIC_REGW
+    float sdf;
+    {
+      float part = 0.f;
+#pragma unroll
+      for (int uu = 0; uu < CLID_HPL; ++uu) {
+        float a = b1r[uu];
+#pragma unroll
+        for (int c = 0; c < CLID_D; ++c) a = fmaf(w1r[uu][c], f[c], a);
+        pre[uu] = a;
+        part = fmaf(w2r[uu], fmaxf(a, 0.f), part);
+      }
+      sdf = sc * (group_sum(part) + b2r);
+    }
+    const int l16 = lane16;
+#else
     const float sdf = mlp_forward(mlp, f, lane16, sc, pre);
     const int l16 = lane16 + opaque_zero();
+#endif
     // ---- u = s (W2 .* a) W1   (replicated)
     float u[CLID_D];
     float e[CLID_HPL];
 #pragma unroll
     for (int uu = 0; uu < CLID_HPL; ++uu)
+#if CLID_ANALYTIC_REGW
+      e[uu] = pre[uu] > 0.f ? sc * w2r[uu] : 0.f;
+#else
       e[uu] = pre[uu] > 0.f ? sc * mlp.w[CLID_H * CLID_D + CLID_H + l16 + CLID_G * uu] : 0.f;
+#endif
 #pragma unroll
     for (int c = 0; c < CLID_D; ++c) {
       float part = 0.f;
 #pragma unroll
+#if CLID_ANALYTIC_REGW
+      for (int uu = 0; uu < CLID_HPL; ++uu) part = fmaf(w1r[uu][c], e[uu], part);
+#else
       for (int uu = 0; uu < CLID_HPL; ++uu) part = fmaf(mlp.w[(l16 + CLID_G * uu) * CLID_D + c], e[uu], part);
+#endif
       u[c] = group_sum(part);
     }
     // ---- d w_k / d x and g = d sdf / d x
@@ -202,10 +246,17 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
       for (int uu = 0; uu < CLID_HPL; ++uu) {
         const int h = l16 + CLID_G * uu;
         const bool on = pre[uu] > 0.f;
+#if CLID_ANALYTIC_REGW
+        const float dh = on ? dz * w2r[uu] : 0.f;
+        float w1t = 0.f;
+#pragma unroll
+        for (int c = 0; c < CLID_D; ++c) w1t = fmaf(w1r[uu][c], tv[c], w1t);
+#else
         const float dh = on ? dz * mlp.w[CLID_H * CLID_D + CLID_H + h] : 0.f;
         float w1t = 0.f;
 #pragma unroll
         for (int c = 0; c < CLID_D; ++c) w1t = fmaf(mlp.w[h * CLID_D + c], tv[c], w1t);
+#endif
         acc.dW2[uu] += on ? (dz * pre[uu] + sc * w1t) : 0.f;
         acc.dW1[uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh, fb, acc.dW1[uu], 0, 0, 0);
         acc.dW1[uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[uu], tb, acc.dW1[uu], 0, 0, 0);
