@@ -33,7 +33,7 @@ struct Wf0Lds {
 };
 
 template <int PASS>
-__global__ void __launch_bounds__(kWf0Block)
+__global__ void __launch_bounds__(kWf0Block, 2)  // (2 waves per SIMD: what <= 512 blocks put there)
 k_train_wf0(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, int row_base, TaskMap tmap, float4* __restrict__ rec) {
   __shared__ MlpLds mlp;
   __shared__ Wf0Lds wl;
@@ -43,7 +43,30 @@ k_train_wf0(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, i
   const int lane = threadIdx.x & 63, lane16 = lane & 15, gib = threadIdx.x >> 4;
   const int my_k = lane16 >> 1;
   const bool odd = lane16 & 1;
+#ifndef CLID_WF0_REGW
+#define CLID_WF0_REGW 1
+#endif
+#if CLID_WF0_REGW
+  // this lane's share of the decoder (hidden units lane16 + 16 u) in registers: six forward and six backward walks per query point
+  const int l16 = lane16;
+  float w1r[CLID_HPL][CLID_D], b1r[CLID_HPL], w2r[CLID_HPL];
+#pragma unroll
+  for (int uu = 0; uu < CLID_HPL; ++uu) {
+    const int h = lane16 + CLID_G * uu;
+#pragma unroll
+    for (int c = 0; c < CLID_D; ++c) w1r[uu][c] = mlp.w[h * CLID_D + c];
+    b1r[uu] = mlp.w[CLID_H * CLID_D + h];
+    w2r[uu] = mlp.w[CLID_H * CLID_D + CLID_H + h];
+  }
+#define WF0_W1(uu, h, c) w1r[uu][c]
+#define WF0_B1(uu, h) b1r[uu]
+#define WF0_W2(uu, h) w2r[uu]
+#else
   const int l16 = lane16 + opaque_zero();  // (keeps the decoder weights in LDS, common.hpp)
+#define WF0_W1(uu, h, c) mlp.w[(h) * CLID_D + (c)]
+#define WF0_B1(uu, h) mlp.w[CLID_H * CLID_D + (h)]
+#define WF0_W2(uu, h) mlp.w[CLID_H * CLID_D + CLID_H + (h)]
+#endif
   MlpAcc acc;
   acc.zero();
   float bce_acc = 0.f, eik_acc = 0.f;
@@ -124,11 +147,11 @@ k_train_wf0(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, i
 #pragma unroll
       for (int uu = 0; uu < CLID_HPL; ++uu) {
         const int h = l16 + CLID_G * uu;
-        float a = mlp.w[CLID_H * CLID_D + h];
+        float a = WF0_B1(uu, h);
 #pragma unroll
-        for (int c = 0; c < CLID_D; ++c) a = fmaf(mlp.w[h * CLID_D + c], vk[c], a);
+        for (int c = 0; c < CLID_D; ++c) a = fmaf(WF0_W1(uu, h, c), vk[c], a);
         pre[k][uu] = a;
-        part = fmaf(mlp.w[CLID_H * CLID_D + CLID_H + h], fmaxf(a, 0.f), part);
+        part = fmaf(WF0_W2(uu, h), fmaxf(a, 0.f), part);
       }
       const float sdf_k = sc * (group_sum(part) + mlp.w[CLID_MLP_PARAMS - 1]);
       sdf = fadd(sdf, fmul(sdf_k, w6[k]));  // utils/mapper.py:679-680 (a neighbour slot without a point has weight 0)
@@ -186,7 +209,7 @@ k_train_wf0(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, i
       for (int uu = 0; uu < CLID_HPL; ++uu) {
         const int h = l16 + CLID_G * uu;
         const bool on = pre[k][uu] > 0.f;
-        dh[uu] = on ? dz * mlp.w[CLID_H * CLID_D + CLID_H + h] : 0.f;
+        dh[uu] = on ? dz * WF0_W2(uu, h) : 0.f;
         if (train) acc.dW2[uu] += on ? dz * pre[k][uu] : 0.f;
       }
       if (train) {
@@ -201,7 +224,7 @@ k_train_wf0(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, i
       for (int c = 0; c < CLID_F; ++c) {
         float part = 0.f;
 #pragma unroll
-        for (int uu = 0; uu < CLID_HPL; ++uu) part = fmaf(mlp.w[(l16 + CLID_G * uu) * CLID_D + c], dh[uu], part);
+        for (int uu = 0; uu < CLID_HPL; ++uu) part = fmaf(WF0_W1(uu, l16 + CLID_G * uu, c), dh[uu], part);
         dv[c] = group_sum(part);
       }
       if (my_k == k) {
