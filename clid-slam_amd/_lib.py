@@ -428,3 +428,24 @@ def require_cuda(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
     if not t.is_contiguous():
         raise RuntimeError(f"{name} must be contiguous")
     return t
+
+
+def low_priority_stream(device):
+    """A side stream of the LOWEST priority the device offers: the frame's large pool compaction (200 us of bandwidth-bound
+    launches) runs on it next to the map growth's chain of small dependent launches on the caller's stream -- at equal priority
+    those starve behind the big launch's waves (k_vox_splitters: 12 -> 138 us, profiles/r04_frame_trace.txt).  CLID_POOL_PRIO=0
+    keeps a stream of default priority (A/B)."""
+    import os
+    import torch
+
+    if os.environ.get("CLID_POOL_PRIO", "1") == "0":
+        return torch.cuda.Stream(device=device)
+    hip = C.CDLL("libamdhip64.so")
+    least, greatest = C.c_int(0), C.c_int(0)
+    with torch.cuda.device(device):
+        if hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) != 0 or least.value == greatest.value:
+            return torch.cuda.Stream(device=device)
+        handle = C.c_void_p()
+        if hip.hipStreamCreateWithPriority(C.byref(handle), C.c_uint(1), C.c_int(least.value)) != 0:  # 1 = hipStreamNonBlocking
+            return torch.cuda.Stream(device=device)
+    return torch.cuda.ExternalStream(handle.value, device=device)

@@ -878,7 +878,7 @@ class Mapper:
             main = torch.cuda.current_stream(coord.device)
             side = getattr(self, "_side_stream", None)
             if side is None or side.device != coord.device:
-                side = self._side_stream = torch.cuda.Stream(device=coord.device)
+                side = self._side_stream = _lib.low_priority_stream(coord.device)
 
             def fork_pool():
                 side.wait_stream(main)
