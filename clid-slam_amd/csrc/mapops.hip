@@ -312,18 +312,34 @@ __device__ __forceinline__ long long vox_flat(const float* __restrict__ pts, int
   return gx + gy * stride + gz * stride * stride;
 }
 
-// splitters[k] = sample of rank kVbPerBucket (k + 1), k = 0 .. kVbBuckets - 2, among the ids of 1024 evenly spaced input points
-__global__ void __launch_bounds__(kVbThreads) k_vox_splitters(const float* __restrict__ pts, int n_bound, float v, const int* __restrict__ box,
+// splitters[k] = sample of rank kVbPerBucket (k + 1), k = 0 .. kVbBuckets - 2, among the ids of 1024 evenly spaced input points.
+// Ranks by counting on (id, sample number) composites, 256 samples per block of 256 threads: one 1024-thread block (a bitonic
+// network, 11.8 us) needs a whole CU's wave slots at once and starved next to the pool's compaction on the side stream
+// (138 us, profiles/r04_frame_trace.txt); small blocks fit wherever one of that launch's blocks leaves.
+constexpr int kVsThreads = 256, kVsShift = 10;
+static_assert(kVbSamples == (1 << kVsShift) && kVbSamples % kVsThreads == 0, "sample number in the composite's low bits");
+__global__ void __launch_bounds__(kVsThreads) k_vox_splitters(const float* __restrict__ pts, int n_bound, float v, const int* __restrict__ box,
                                                               long long* __restrict__ split, unsigned* __restrict__ bucket_cnt,
                                                               const long long* __restrict__ n_dev) {
-  __shared__ unsigned long long sval[kVbSamples];
+  __shared__ __attribute__((aligned(16))) unsigned long long sval[kVbSamples];
   const int tid = threadIdx.x;
   const int n = vox_n(n_bound, n_dev);
-  if (tid < kVbBuckets) bucket_cnt[tid * kVbCntStride] = 0u;
-  unsigned long long sk[1];
-  sk[0] = n > 0 ? (unsigned long long)vox_flat(pts, (int)((long long)tid * n / kVbSamples), v, box) : 0ULL;
-  vb_bitonic<1>(sk, sval, kVbSamples);
-  if (tid % kVbPerBucket == 0 && tid > 0) split[tid / kVbPerBucket - 1] = (long long)sk[0];
+  if (blockIdx.x == 0)
+    for (int i = tid; i < kVbBuckets; i += kVsThreads) bucket_cnt[i * kVbCntStride] = 0u;
+  for (int sidx = tid; sidx < kVbSamples; sidx += kVsThreads) {
+    const unsigned long long id = n > 0 ? (unsigned long long)vox_flat(pts, (int)((long long)sidx * n / kVbSamples), v, box) : 0ULL;
+    sval[sidx] = (id << kVsShift) | (unsigned)sidx;  // (ids beyond 51 bits take the library path / raise: mapops vox_finish)
+  }
+  __syncthreads();
+  const unsigned long long c = sval[blockIdx.x * kVsThreads + tid];
+  const ulonglong2* __restrict__ s2 = reinterpret_cast<const ulonglong2*>(sval);
+  int rank = 0;
+#pragma unroll 8
+  for (int j = 0; j < kVbSamples / 2; ++j) {
+    const ulonglong2 o = s2[j];
+    rank += (o.x < c ? 1 : 0) + (o.y < c ? 1 : 0);
+  }
+  if (rank % kVbPerBucket == 0 && rank > 0) split[rank / kVbPerBucket - 1] = (long long)(c >> kVsShift);
 }
 
 // occupied slots of the hash table -> bucket lists
@@ -593,34 +609,40 @@ k_pool_drop(unsigned char* __restrict__ flag, const int* __restrict__ kept_list,
 struct PoolDst {
   float* coord; float* gcoord; float* label; float* weight; int* time;
 };
+// One block per 256 consecutive samples.  (A bounded, grid-stride launch -- 2 / 4 / 6 blocks per CU, to leave wave slots to the
+// map growth's small launches on the main stream -- was measured: process_frame 1.10-1.17 / 1.01-1.08 / 0.95-0.96 ms against
+// 0.94-0.95: this launch is bandwidth-bound, wants every slot, and the pool chain it ends is the frame's critical path.)
 __global__ void __launch_bounds__(256)
 k_pool_scatter(PoolSrc a, PoolSrc b, const unsigned char* __restrict__ flag, const int* __restrict__ block_off,
                const int* __restrict__ block_cnt, PoolDst d, long long* __restrict__ counts) {
-  const long long n = a.n + b.n;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool f = i < n && flag[i];
-  const long long j = (long long)block_off[blockIdx.x] + block_prefix256(f, nullptr);
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-    const long long kept = (long long)block_off[blockIdx.x] + block_cnt[blockIdx.x];
-    counts[0] = kept;  // samples kept in total
-    // ... of which from this frame (the tail): kept minus what survived of the old pool (positions < a.n)
-    long long kept_old = 0;
-    if (a.n > 0) {
-      const long long ba = a.n / 256;
-      kept_old = ba < (long long)gridDim.x ? (long long)block_off[ba] : kept;
-      for (long long q = ba * 256; q < a.n && ba < (long long)gridDim.x; ++q) kept_old += flag[q];
+  const long long n = a.n + b.n, n_vblocks = gridDim.x;
+  {
+    const long long vb = blockIdx.x;
+    const long long i = vb * blockDim.x + threadIdx.x;
+    const bool f = i < n && flag[i];
+    const long long j = (long long)block_off[vb] + block_prefix256(f, nullptr);
+    if (vb == n_vblocks - 1 && threadIdx.x == 0) {
+      const long long kept = (long long)block_off[vb] + block_cnt[vb];
+      counts[0] = kept;  // samples kept in total
+      // ... of which from this frame (the tail): kept minus what survived of the old pool (positions < a.n)
+      long long kept_old = 0;
+      if (a.n > 0) {
+        const long long ba = a.n / 256;
+        kept_old = ba < n_vblocks ? (long long)block_off[ba] : kept;
+        for (long long q = ba * 256; q < a.n && ba < n_vblocks; ++q) kept_old += flag[q];
+      }
+      counts[1] = kept - kept_old;
     }
-    counts[1] = kept - kept_old;
+    if (!f) return;
+    const bool old = i < a.n;
+    const PoolSrc& s = old ? a : b;
+    const long long k = old ? i : i - a.n;
+    d.coord[j * 3 + 0] = s.coord[k * 3 + 0]; d.coord[j * 3 + 1] = s.coord[k * 3 + 1]; d.coord[j * 3 + 2] = s.coord[k * 3 + 2];
+    d.gcoord[j * 3 + 0] = s.gcoord[k * 3 + 0]; d.gcoord[j * 3 + 1] = s.gcoord[k * 3 + 1]; d.gcoord[j * 3 + 2] = s.gcoord[k * 3 + 2];
+    d.label[j] = s.label[k];
+    d.weight[j] = s.weight[k];
+    d.time[j] = s.time[k];
   }
-  if (!f) return;
-  const bool old = i < a.n;
-  const PoolSrc& s = old ? a : b;
-  const long long k = old ? i : i - a.n;
-  d.coord[j * 3 + 0] = s.coord[k * 3 + 0]; d.coord[j * 3 + 1] = s.coord[k * 3 + 1]; d.coord[j * 3 + 2] = s.coord[k * 3 + 2];
-  d.gcoord[j * 3 + 0] = s.gcoord[k * 3 + 0]; d.gcoord[j * 3 + 1] = s.gcoord[k * 3 + 1]; d.gcoord[j * 3 + 2] = s.gcoord[k * 3 + 2];
-  d.label[j] = s.label[k];
-  d.weight[j] = s.weight[k];
-  d.time[j] = s.time[k];
 }
 
 // ---- local-window selection (model/neural_points.py:439-536) -------------------------------------------------------
@@ -1015,7 +1037,7 @@ static int vox_launch(const float* points, int32_t n, float voxel_size, const fl
   const unsigned table_blocks1k = (unsigned)((((size_t)1 << log2cap) + 1023) / 1024);
   const bool bucketed = n <= (1 << 21);  // beyond: the buckets would overflow anyway
   if (bucketed) {
-    hipLaunchKernelGGL(k_vox_splitters, dim3(1), dim3(kVbThreads), 0, s, points, n, voxel_size, box, split, bcnt, n_dev);
+    hipLaunchKernelGGL(k_vox_splitters, dim3(kVbSamples / kVsThreads), dim3(kVsThreads), 0, s, points, n, voxel_size, box, split, bcnt, n_dev);
     // count_out_dev: nobody will come back for the count (or for an overflowing bucket): spill list + k_vox_bucket_big
     hipLaunchKernelGGL(k_vox_partition, dim3(table_blocks1k * 4), dim3(256), 0, s, keys, vals, log2cap, st, split, bcnt, bkeys, bidx,
                        count_out_dev ? flat_a : nullptr, count_out_dev ? idx_a : nullptr, n, n_dev);
