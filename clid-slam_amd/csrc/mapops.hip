@@ -633,6 +633,45 @@ k_pool_scatter(PoolSrc a, PoolSrc b, const unsigned char* __restrict__ flag, con
       }
       counts[1] = kept - kept_old;
     }
+    // coordinates: 3 floats per sample.  A block whose 256 samples come from ONE source at a 16-byte aligned offset stages the
+    // two 3 KB tiles through LDS -- contiguous 16-byte loads in, the kept samples' floats compacted, contiguous stores out --
+    // instead of six stride-12 loads and six stride-12 stores per thread
+    __shared__ __attribute__((aligned(16))) float tile[2][768];
+    __shared__ float packed[2][768];
+    const long long i0 = vb * blockDim.x;
+    const bool one_src = i0 + 256 <= a.n || i0 >= a.n;
+    const PoolSrc& sb = i0 < a.n ? a : b;
+    const long long k0 = i0 < a.n ? i0 : i0 - a.n;
+    const bool full = i0 + 256 <= n;
+    const bool fast = one_src && full && (((uintptr_t)(sb.coord + 3 * k0) | (uintptr_t)(sb.gcoord + 3 * k0)) & 15) == 0;  // (block-uniform)
+    if (fast) {
+      if (threadIdx.x < 192) {
+        reinterpret_cast<float4*>(tile[0])[threadIdx.x] = reinterpret_cast<const float4*>(sb.coord + 3 * k0)[threadIdx.x];
+        reinterpret_cast<float4*>(tile[1])[threadIdx.x] = reinterpret_cast<const float4*>(sb.gcoord + 3 * k0)[threadIdx.x];
+      }
+      __syncthreads();
+      const int jl = (int)(j - block_off[vb]);  // position among the block's kept samples
+      if (f) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          packed[0][3 * jl + c] = tile[0][3 * threadIdx.x + c];
+          packed[1][3 * jl + c] = tile[1][3 * threadIdx.x + c];
+        }
+      }
+      __syncthreads();
+      const int n3 = 3 * block_cnt[vb];
+      float* __restrict__ oc = d.coord + 3 * (long long)block_off[vb];
+      float* __restrict__ og = d.gcoord + 3 * (long long)block_off[vb];
+      for (int x = threadIdx.x; x < n3; x += 256) {
+        oc[x] = packed[0][x];
+        og[x] = packed[1][x];
+      }
+      if (!f) return;
+      d.label[j] = sb.label[k0 + threadIdx.x];
+      d.weight[j] = sb.weight[k0 + threadIdx.x];
+      d.time[j] = sb.time[k0 + threadIdx.x];
+      return;
+    }
     if (!f) return;
     const bool old = i < a.n;
     const PoolSrc& s = old ? a : b;
