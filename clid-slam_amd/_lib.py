@@ -440,12 +440,16 @@ def low_priority_stream(device):
 
     if os.environ.get("CLID_POOL_PRIO", "1") == "0":
         return torch.cuda.Stream(device=device)
-    hip = C.CDLL("libamdhip64.so")
+    hip = load()  # the HIP runtime the native library is linked against (dlsym walks its dependencies): the one its launches use
     least, greatest = C.c_int(0), C.c_int(0)
     with torch.cuda.device(device):
-        if hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) != 0 or least.value == greatest.value:
+        try:
+            get_range, create = hip.hipDeviceGetStreamPriorityRange, hip.hipStreamCreateWithPriority
+        except AttributeError:
+            return torch.cuda.Stream(device=device)
+        if get_range(C.byref(least), C.byref(greatest)) != 0 or least.value == greatest.value:
             return torch.cuda.Stream(device=device)
         handle = C.c_void_p()
-        if hip.hipStreamCreateWithPriority(C.byref(handle), C.c_uint(1), C.c_int(least.value)) != 0:  # 1 = hipStreamNonBlocking
+        if create(C.byref(handle), C.c_uint(1), C.c_int(least.value)) != 0:  # 1 = hipStreamNonBlocking
             return torch.cuda.Stream(device=device)
     return torch.cuda.ExternalStream(handle.value, device=device)
