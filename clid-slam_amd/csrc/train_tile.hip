@@ -566,10 +566,11 @@ extern "C" int clid_debug_read_stamps_tile(long long* out_host) {
 // do the tiles of a launch over n_tasks tasks read their row numbers from the search launch's number blocks?
 bool clid_tiles_prenumbered(int n_tasks, const clid_map_view* mv) {
   // (i) at most kTileLargeFrom tiles: the decode launch then runs one tile per wave and is one tile's dependent chain long
-  // (14.5 -> 12.6 us at 16 384 samples for +1.0 us per iteration in the search launch); (ii) a local map whose probe table
-  // still sits in one L2 (the launcher's LDS-prefilter regime, M <= 2^17): at M = 243 k the search pays 4.5 us per
-  // iteration for the numbering and the decode gains 4.4 -- no gain, and the call's searches come first.
-  return tiles_prenumbered(n_tasks) && !(mv->filter && mv->log2filter > 18);
+  // (14.5 -> 12.6 us at 16 384 samples for +1.0 us per iteration in the search launch); (ii) with the PROBING search, a local map
+  // whose probe table still sits in one L2 (the launcher's LDS-prefilter regime, M <= 2^17): at M = 243 k that search paid 4.5 us
+  // per iteration for the numbering and the decode gained 4.4.  The cell-directory search pays 1.9 us there and the decode gains
+  // 4.2 (19.5 -> 15.3 us at M = 231 k, layer norm, frozen decoder): with a directory in the view every small launch pre-numbers.
+  return tiles_prenumbered(n_tasks) && (mv->cdir_hdr != nullptr || !(mv->filter && mv->log2filter > 18));
 }
 
 int clid_decode_tile_blocks(int n_tasks) {
