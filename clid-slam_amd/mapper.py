@@ -915,7 +915,25 @@ class Mapper:
             update_points = update_points[:n_near]
             n_cur = self.cur_sample_count = kept
             defer_cmp = False
+        prefetched = [False]
+        if (overlap and os.environ.get("CLID_TABLE_PREFETCH", "1") != "0" and os.environ.get("CLID_TABLE_PREFETCH_EARLY", "1") != "0"
+                and os.environ.get("CLID_TABLE_PREFETCH_HOOK", "1") != "0"):
+            # the table + cell directory of the mapping() call that follows depend on the new window only: their build goes out
+            # from INSIDE NeuralPoints.update, right behind the window's count read-back (the device idles there until the host
+            # has something for it), on the third stream ordered behind the window's launches
+            third = getattr(self, "_third_stream", None)
+            if third is None or third.device != coord.device:
+                third = self._third_stream = torch.cuda.Stream(device=coord.device)
+            main_s = torch.cuda.current_stream(coord.device)
+
+            def _prefetch_now():
+                third.wait_event(main_s.record_event())
+                nm.prefetch_local_table(third)
+                prefetched[0] = True
+
+            nm._on_window_ready = _prefetch_now
         self.cur_new_point_ratio = nm.update(update_points, origin, orientation, frame_id)
+        nm.__dict__.pop("_on_window_ready", None)  # (a path that never reached the fused window selection)
         if defer_cmp:  # the compaction's counts came back with the insert / window counts
             kept, n_near = nm._last_update_counts[5:7]
             coord, gcoord, sdf_label, weight, stamp = coord[:kept], gcoord[:kept], sdf_label[:kept], weight[:kept], stamp[:kept]
@@ -934,7 +952,9 @@ class Mapper:
                 third = getattr(self, "_third_stream", None)
                 if third is None or third.device != coord.device:
                     third = self._third_stream = torch.cuda.Stream(device=coord.device)
-                if os.environ.get("CLID_TABLE_PREFETCH_EARLY", "1") != "0":
+                if prefetched[0]:  # (went out from inside NeuralPoints.update)
+                    main.wait_stream(side)
+                elif os.environ.get("CLID_TABLE_PREFETCH_EARLY", "1") != "0":
                     third.wait_event(main.record_event())
                     nm.prefetch_local_table(third)
                     main.wait_stream(side)

@@ -549,20 +549,28 @@ class NeuralPoints(nn.Module):
                 break
             cap = n  # (grew by more than a quarter since the last frame: once more with room for everything)
         self._last_local_m = int(m)
+        # First what the probe table of the new window is keyed on and built from (_table): a caller that wants the table + cell
+        # directory build in flight at once (Mapper.process_frame: `_on_window_ready`) gets its turn before the other dozen
+        # views are cut -- the device idles behind this read-back until that build is enqueued
         if pending is not None:
             total = base + n_new
-            self.neural_points, self.point_orientations = buf["neural_points"][:total], buf["point_orientations"][:total]
-            self.point_ts_create, self.point_ts_update = buf["point_ts_create"][:total], buf["point_ts_update"][:total]
+            self.neural_points, self.point_ts_create = buf["neural_points"][:total], buf["point_ts_create"][:total]
+            g2l = g2l[:total + 1]
+        self.local_neural_points, self.global2local, self._local_ids = l_pts[:m], g2l, ids[:m]
+        self._map_version += 1
+        hook = self.__dict__.pop("_on_window_ready", None)
+        if hook is not None:
+            hook()
+        if pending is not None:
+            self.point_orientations, self.point_ts_update = buf["point_orientations"][:total], buf["point_ts_update"][:total]
             self.point_certainties, self.geo_features = buf["point_certainties"][:total], buf["geo_features"][:total + 1]
-            mask, g2l = mask[:total + 1], g2l[:total + 1]
-        self.local_neural_points, self.local_point_orientations = l_pts[:m], l_ori[:m]
+            mask = mask[:total + 1]
+        self.local_point_orientations = l_ori[:m]
         self.local_point_certainties, self.local_point_ts_update = l_cert[:m], l_ts[:m]
-        self.local_mask, self.global2local = mask, g2l
+        self.local_mask = mask
         self.local_geo_features = nn.Parameter(l_feat[:m + 1])
-        self._local_ids = ids[:m]
         self._local_ids_pad = None
         self.local_orientation = sensor_orientation
-        self._map_version += 1
         return True if pending is None else (n_new, n_vox)
 
     def assign_local_to_global(self):
@@ -810,15 +818,28 @@ class NeuralPoints(nn.Module):
             raise NotImplementedError(f"{n} points in one table: the searches address at most 2^22 (their candidates carry the "
                                       "probe index next to the id)")
         log2cap = max(5, int(math.ceil(math.log2(max(2 * n, 32)))))  # 4-key buckets, <= 0.5 keys per bucket
-        tab = torch.empty((1 << log2cap, 4), device=pts.device, dtype=torch.int32)
-        tab_pos = torch.empty((1 << log2cap, 4, 4), device=pts.device, dtype=torch.float32)  # (only the rows of stored keys are ever used)
-        pos4 = torch.empty((max(n, 1), 4), device=pts.device, dtype=torch.float32)
+        # (the log2filter of the table is needed for the buffers: computed here, used below)
+        log2filter = max(13, int(math.ceil(math.log2(max(8 * n, 32)))))
+        log2filter = min(18, log2filter) if n <= (1 << 17) else min(24, log2filter)
+        # Buffers cached per table slot and only re-allocated to grow (the kernels take pointers and sizes: nobody reads these
+        # tensors' shapes).  A rebuild overwrites the slot's previous table in place: it runs on the stream that used it, or --
+        # Mapper.process_frame's prefetch -- on a stream ordered behind everything the caller's stream has enqueued so far.
+        tcache = self.__dict__.setdefault("_table_bufs", {})
+        tb = tcache.get(slot)
+        need = (1 << log2cap, max(n, 1), (1 << log2filter) // 32)
+        if tb is None or tb[0] < need[0] or tb[1] < need[1] or tb[2] < need[2] or tb[3].device != pts.device:
+            c0, c1, c2 = need[0], int(need[1] * 1.25) + 1024, need[2]
+            if tb is not None and tb[3].device == pts.device:
+                c0, c2 = max(c0, tb[0]), max(c2, tb[2])
+            tb = tcache[slot] = (c0, c1, c2, torch.empty((c0, 4), device=pts.device, dtype=torch.int32),
+                                 torch.empty((c0, 4, 4), device=pts.device, dtype=torch.float32),  # (only the rows of stored keys are ever used)
+                                 torch.empty((c1, 4), device=pts.device, dtype=torch.float32),
+                                 torch.empty((c2,), device=pts.device, dtype=torch.int32),
+                                 torch.empty((16,), device=pts.device, dtype=torch.int32))
+        tab, tab_pos, pos4, filt, hdr = tb[3], tb[4], tb[5], tb[6], tb[7]
         # probe prefilter (one-hash Bloom filter over the stored slots), 8 bits per key: up to 2^18 bits (32 KB) the chunked
         # search kernel keeps it in LDS next to its other state; larger local maps get a filter of up to 2^24 bits (2 MB)
         # that the kernel reads from global memory (it stays L2-resident, unlike the key table it guards)
-        log2filter = max(13, int(math.ceil(math.log2(max(8 * n, 32)))))
-        log2filter = min(18, log2filter) if n <= (1 << 17) else min(24, log2filter)
-        filt = torch.empty(((1 << log2filter) // 32,), device=pts.device, dtype=torch.int32)
         tsc = self.point_ts_create if time_filtering else None
         trv = self._travel32() if time_filtering else None
         _lib.check(
@@ -842,7 +863,6 @@ class NeuralPoints(nn.Module):
                 bufs = pool[slot] = (wc, hc, torch.empty((wc + 1, 2), device=pts.device, dtype=torch.int32),
                                      torch.empty((hc, 4), device=pts.device, dtype=torch.float32),
                                      torch.empty((wc // 32 + 2,), device=pts.device, dtype=torch.int32))
-            hdr = torch.empty((16,), device=pts.device, dtype=torch.int32)  # (per table: a cached table keeps its own header)
             _lib.check(
                 lib.clid_cdir_build(_lib.ptr(pos4), n, _lib.ptr(tab), _lib.ptr(tab_pos), log2cap, _lib.ptr(filt), log2filter,
                                     int(self.buffer_size), float(self.resolution), _lib.ptr(hdr), _lib.ptr(bufs[2]), bufs[0],
