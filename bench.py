@@ -34,7 +34,21 @@ sys.path.insert(0, ROOT)
 # Completion waits by polling instead of interrupts: the timed region is ~0.7 ms and ends in a host wait; an interrupt-driven
 # wake-up was measured to arrive 30-60 ms late in about 1 run of 20 (GPU events 0.64 ms, wall clock 58.7 ms:
 # `timed_region_split` in the output line).  Must be set before the HSA runtime starts, i.e. before importing torch.
-os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+# Single-GPU runs only (or CLID_BENCH_POLL=1): N ranks busy-polling next to RCCL's proxy threads on a host whose core count is not
+# known in advance is a first-run risk the multi-GPU line does not need -- its timed region ends in a collective anyway.
+def _multi_rank_argv():
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return True
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            return sys.argv[i + 1] not in ("0", "1")
+        if a.startswith("--gpus="):
+            return a.split("=", 1)[1] not in ("0", "1")
+    return False
+
+
+if os.environ.get("CLID_BENCH_POLL", "auto") == "1" or (os.environ.get("CLID_BENCH_POLL", "auto") != "0" and not _multi_rank_argv()):
+    os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
 # the peer-mapped A/B leg of a multi-GPU run: a flag wait gives up after 20 s here (library default 600 s) and the call is
 # repeated over RCCL, so a transport that does not work on this node costs seconds, not the run
 os.environ.setdefault("CLID_P2P_TIMEOUT_S", "20")
@@ -410,6 +424,7 @@ def main():
                 "neural_points_local": M, "pool_samples": int(mp.pool_sample_count), "buffer_size": cfg.buffer_size,
                 "parallelism": f"dp{world} (batch sharded, RCCL all-reduce of [decoder|feature] grads)" if world > 1 else "single GPU",
                 "rccl_ranks_in_c_abi": rccl_ranks,
+                "host_cores": os.cpu_count(), "completion_wait": "poll" if os.environ.get("HSA_ENABLE_INTERRUPT") == "0" else "interrupt",
                 "gradient_exchange": legs,
             },
             "final_loss": {"total": losses[0], "bce": losses[1], "eikonal": losses[2]},

@@ -55,6 +55,10 @@ class TrainArgs(C.Structure):
         ("decode_variant", _i32), ("pipeline", _i32), ("sdf_dbg", _vp), ("prof", _vp),
         # touched-row bookkeeping of the hoisted-search loop (NULL = dense exchange / dense Adam sweep)
         ("touch_ws", _vp), ("touch_stride", _i64), ("touch_iter", _i32), ("touch_all", _i32), ("cbuf", _vp), ("p2p", _vp), ("decode_each_neighbour", _i32),
+        # overlapped search schedule (ABI 6): clid_sched_create() object, iterations per side launch, block cap of a side launch
+        ("sched", _vp), ("side_group", _i32), ("side_blocks", _i32),
+        # config.ekional_add_to: 0 all / 1 surface / 2 freespace, |label| threshold, 1 / subset size per iteration (device floats)
+        ("eik_mask", _i32), ("eik_mask_range", _f32), ("eik_inv_n", _vp),
     ]
 
 
@@ -179,6 +183,9 @@ _SIGS = {
     "clid_train_search_tasks": (_i32, [_i32, _i64, _i32, _i32]),
     "clid_train_search": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), _i32, _vp, _i64, _vp, _vp]),
     "clid_train_decode": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), _vp, _vp]),
+    "clid_sched_create": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
+    "clid_sched_destroy": (None, [_vp]),
+    "clid_debug_cu_census": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     "clid_profile_create": (_vp, []),
     "clid_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int), _vp]),
     "clid_profile_destroy": (None, [_vp]),
@@ -200,6 +207,8 @@ def _env_int(name: str, default: int, lo: int, hi: int) -> int:
 # its attributes of the same names.  They were process-global setters inside the library in ABI 2.
 DECODE_VARIANT = _env_int("CLID_DECODE", 1, 0, 2)   # 0 VALU kernel, 1 tile kernel fp32 MFMA, 2 tile kernel bf16 MFMA
 PIPELINE = _env_int("CLID_PIPELINE", 1, 0, 1)       # 1 hoisted searches, 0 one fused search+decode launch per iteration
+# overlapped search schedule (clid_train_args.sched): defaults of CLID_SIDE / CLID_SIDE_CUS / CLID_SIDE_GROUP / CLID_SIDE_BLOCKS
+SIDE_DEFAULT, SIDE_CUS_DEFAULT, SIDE_GROUP_DEFAULT, SIDE_BLOCKS_DEFAULT = "0", "", 1, 0
 
 
 def load():
@@ -217,7 +226,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.clid_abi_version() != 5:
+    if lib.clid_abi_version() != 6:
         raise RuntimeError("libclid_native.so ABI version mismatch; rebuild")
     _lib = lib
     return lib
@@ -371,6 +380,63 @@ def p2p_likely(dist, wanted=None) -> bool:
     the payload the object carries."""
     wanted = p2p_default() if wanted is None else bool(wanted)
     return wanted and _p2p is not False and dist.get_world_size() <= 8
+
+
+_sched = {}  # device index -> (clid_sched pointer or None, side_group, side_blocks)
+
+
+def cu_mask_words(spec: str, n_cus: int = 256, n_xcd: int = 8):
+    """uint32 words of a CU mask for hipExtStreamCreateWithCUMask.  Bit i of the mask = compute unit i in the driver's
+    numbering, which walks the XCDs first (bit i -> XCD i % 8, measured: tools/cu_mask_census.py).  `spec`:
+      "percu:N"  N compute units of every XCD (bits 0 .. 8 N - 1);   "xcd:K"  every compute unit of XCDs 0 .. K - 1;
+      "hex:..."  the mask itself, most significant word first;       "" / "none"  no mask (None)."""
+    spec = (spec or "").strip().lower()
+    if spec in ("", "none", "0"):
+        return None
+    bits = [0] * n_cus
+    kind, _, val = spec.partition(":")
+    if kind == "percu":
+        for i in range(min(int(val) * n_xcd, n_cus)):
+            bits[i] = 1
+    elif kind == "xcd":
+        for i in range(n_cus):
+            bits[i] = 1 if (i % n_xcd) < int(val) else 0
+    elif kind == "hex":
+        v = int(val, 16)
+        for i in range(n_cus):
+            bits[i] = (v >> i) & 1
+    else:
+        raise ValueError(f"CU mask spec {spec!r}")
+    if not any(bits):
+        return None
+    words = [sum(bits[32 * w + b] << b for b in range(32)) for w in range(n_cus // 32)]
+    return words
+
+
+def sched(device=None):
+    """The process-wide schedule object of the overlapped search schedule for `device` (clid_train_args.sched): a side
+    stream -- confined to the compute units of CLID_SIDE_CUS when set -- and its events, created on first use.  Returns
+    (pointer or None, side_group, side_blocks).  CLID_SIDE = 0 / 1 switches the schedule off / on (default: see below),
+    CLID_SIDE_GROUP = iterations per side launch (0 = growing groups), CLID_SIDE_BLOCKS = block cap of a side launch,
+    CLID_SIDE_PRIO = -1 / 0 / 1."""
+    dev = None if device is None else torch.device(device).index
+    if dev is None:
+        dev = torch.cuda.current_device()
+    hit = _sched.get(dev)
+    if hit is not None:
+        return hit
+    out = (None, 0, 0)
+    if os.environ.get("CLID_SIDE", SIDE_DEFAULT) == "1":
+        lib = load()
+        words = cu_mask_words(os.environ.get("CLID_SIDE_CUS", SIDE_CUS_DEFAULT))
+        obj = _vp()
+        with torch.cuda.device(dev):
+            arr = (C.c_uint32 * len(words))(*words) if words else None
+            check(lib.clid_sched_create(arr, len(words) if words else 0, _env_int("CLID_SIDE_PRIO", 0, -1, 1), C.byref(obj)),
+                  "clid_sched_create")
+        out = (obj, _env_int("CLID_SIDE_GROUP", SIDE_GROUP_DEFAULT, 0, 32), _env_int("CLID_SIDE_BLOCKS", SIDE_BLOCKS_DEFAULT, 0, 1 << 16))
+    _sched[dev] = out
+    return out
 
 
 def check(rc: int, what: str) -> None:

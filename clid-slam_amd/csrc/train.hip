@@ -717,6 +717,10 @@ __device__ __forceinline__ float column_sum_block16(const float* __restrict__ pa
   return threadIdx.x < 16 ? (red[c] + red[16 + c]) + (red[32 + c] + red[48 + c]) : 0.f;
 }
 
+// eik_inv_n != NULL (config.ekional_add_to "surface" / "freespace"): the eikonal mean runs over that many decimated samples
+__device__ __forceinline__ float eik_normaliser(const float* eik_inv_n, float inv_n_eik) {
+  return eik_inv_n ? *eik_inv_n : inv_n_eik;
+}
 __device__ __forceinline__ void finish_loss(int p, float tot, float* loss_out, float inv_n_main, float inv_n_eik,
                                             float weight_e) {
   if (p == CLID_MLP_PARAMS) {
@@ -832,7 +836,8 @@ __device__ __forceinline__ int touch_pos(const TouchIter& ti, long long row) {  
 __global__ void __launch_bounds__(256)
 k_reduce_partials(const float* __restrict__ partial, int nb, float* __restrict__ dst,
                   float* __restrict__ loss_out, float inv_n_main, float inv_n_eik, float weight_e,
-                  int train_decoder, TouchIter ti, float* __restrict__ rows, float* __restrict__ cbuf, long long n_rows) {
+                  int train_decoder, TouchIter ti, float* __restrict__ rows, float* __restrict__ cbuf, long long n_rows,
+                  const float* __restrict__ eik_inv_n) {
   if ((int)blockIdx.x >= kColBlocks) {
     const long long idx = (long long)((int)blockIdx.x - kColBlocks) * 256 + threadIdx.x;
     const long long row = idx >> 1;
@@ -857,7 +862,29 @@ k_reduce_partials(const float* __restrict__ partial, int nb, float* __restrict__
   if (p < CLID_MLP_PARAMS) {
     if (train_decoder) dst[p] = tot;
   } else {
-    finish_loss(p, tot, loss_out, inv_n_main, inv_n_eik, weight_e);
+    finish_loss(p, tot, loss_out, inv_n_main, eik_normaliser(eik_inv_n, inv_n_eik), weight_e);
+  }
+}
+
+// config.ekional_add_to "surface" / "freespace" (utils/mapper.py:779-789): size of the iteration's eikonal subset = decimated
+// samples (positions first, first + decimation, ...) whose |sdf_label| is below / not below the surface range.  One block per
+// iteration of the chunk.
+__global__ void __launch_bounds__(256)
+k_eik_mask_count(const long long* __restrict__ index, long long index_stride, const float* __restrict__ pool_label, int first,
+                 int decimation, int n_fd, int mode, float range, float* __restrict__ inv_count) {
+  const long long* idx = index + (long long)blockIdx.x * index_stride;
+  int c = 0;
+  for (int k = threadIdx.x; k < n_fd; k += 256) {
+    const float lab = pool_label[idx[first + (long long)k * decimation]];
+    c += ((fabsf(lab) < range) == (mode == 1)) ? 1 : 0;
+  }
+  __shared__ int red[4];
+  c = (int)wave_sum((float)c);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int n = red[0] + red[1] + red[2] + red[3];
+    inv_count[blockIdx.x] = n > 0 ? fdiv(1.0f, (float)n) : 0.f;  // (an empty subset contributes nothing)
   }
 }
 
@@ -872,6 +899,7 @@ struct AdamLaunch {
   AdamK k;
   TouchIter ti;            // ti.bits != NULL: only rows touched so far in the call are visited (16-float rows only)
   const float* cbuf;       // non-null (with ti): gradients / certainty increments / decoder gradients from the compact buffer
+  const float* eik_inv_n;  // non-null: 1 / size of this iteration's eikonal subset (config.ekional_add_to != "all")
 };
 
 // blocks [0, kColBlocks): 16 decoder parameters / loss columns each (reduce partial rows or read grad), Adam
@@ -1001,7 +1029,7 @@ __global__ void __launch_bounds__(256) k_adam_all(AdamLaunch a) {
     }
     if (!a.cbuf) a.grad[p] = 0.f;  // (the compact buffer is rewritten by the next iteration's pack)
   } else if (a.partial) {
-    finish_loss(p, gsum, a.loss_out, a.inv_n_main, a.inv_n_eik, a.weight_e);
+    finish_loss(p, gsum, a.loss_out, a.inv_n_main, eik_normaliser(a.eik_inv_n, a.inv_n_eik), a.weight_e);
   }
 }
 
@@ -1254,7 +1282,8 @@ static int launch_reduce(const clid_map_view* mv, const clid_train_args* a, cons
   const unsigned row_blocks = pack ? (unsigned)((n_rows * 2 + 255) / 256) : 0u;
   CLID_KLAUNCH(a->prof, 2, k_reduce_partials, dim3(kColBlocks + row_blocks), dim3(256), 0, s, partial, nb,
                pack ? a->cbuf : a->grad, a->loss_out, a->inv_n_main, a->inv_n_eik, eik_weight(a, n_fd), a->train_decoder, ti,
-               a->grad + CLID_GRAD_FEAT_OFFSET16, a->cbuf, n_rows);
+               a->grad + CLID_GRAD_FEAT_OFFSET16, a->cbuf, n_rows,
+               (const float*)((a->eik_mask && a->eik_inv_n) ? a->eik_inv_n + a->touch_iter : nullptr));
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }
@@ -1345,6 +1374,7 @@ extern "C" int clid_train_adam(const clid_adam_args* a, const clid_train_args* t
   L.partial = nullptr; L.nb = 0; L.loss_out = nullptr; L.inv_n_main = L.inv_n_eik = L.weight_e = 0.f;
   L.ti = TouchIter{nullptr, nullptr, nullptr, nullptr};
   L.cbuf = nullptr;
+  L.eik_inv_n = (t && t->eik_mask && t->eik_inv_n) ? t->eik_inv_n + t->touch_iter : nullptr;
   if (t && t->defer_reduce) {  // single-GPU: fold the partial reduction of the forward/backward launch of `t` into this one
     int n_fd, first;
     const int Q = n_queries(t, &n_fd, &first);
@@ -1417,11 +1447,46 @@ static int check_train_args(const clid_map_view* mv, const clid_train_args* a, c
     clid_set_error("%s: decode_each_neighbour (weighted_first: False) needs the hoisted schedule, eikonal mode 0 or 1 and the plain exchange", who);
     return CLID_E_ARG;
   }
+  if (a->eik_mask) {
+    if (a->eik_mask < 0 || a->eik_mask > 2 || !a->eik_inv_n || a->eikonal_mode != 1 || a->decode_each_neighbour ||
+        !hoisted(a) || !decode_variant_for(a) || a->cbuf || a->touch_iter < 0 || a->touch_iter >= kMaxChunkIters) {
+      clid_set_error("%s: eik_mask (config.ekional_add_to surface / freespace) needs eik_inv_n, the numerical eikonal term, the "
+                     "hoisted schedule, a tile decode kernel and one rank", who);
+      return CLID_E_ARG;
+    }
+  }
   return check_touch(a, mv->M, who);
 }
 
+// sizes of the chunk's eikonal subsets (config.ekional_add_to != "all"): eik_inv_n[it_rel0 + i], i < n_iter
+static int launch_eik_inv_n(const clid_train_args* a, int n_iter, const int64_t* index_base, int64_t index_stride, int it_rel0,
+                            hipStream_t s) {
+  if (!a->eik_mask) return CLID_OK;
+  if (it_rel0 < 0 || it_rel0 + n_iter > kMaxChunkIters) {
+    clid_set_error("clid_train_search: eik_inv_n holds %d iterations", kMaxChunkIters);
+    return CLID_E_ARG;
+  }
+  int n_fd, first;
+  n_queries(a, &n_fd, &first);
+  hipLaunchKernelGGL(k_eik_mask_count, dim3((unsigned)n_iter), dim3(256), 0, s, reinterpret_cast<const long long*>(index_base),
+                     (long long)index_stride, a->pool_label, first, a->decimation, n_fd, a->eik_mask, a->eik_mask_range,
+                     a->eik_inv_n + it_rel0);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+static int train_search_impl(const clid_map_view* mv, const clid_train_args* a, int32_t n_iter, const int64_t* index_base,
+                             int64_t index_stride, float* rec_out, void* stream, int grid_cap);
 extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args* a, int32_t n_iter,
                                  const int64_t* index_base, int64_t index_stride, float* rec_out, void* stream) {
+  if (int e = check_train_args(mv, a, "clid_train_search")) return e;
+  if (n_iter > 0 && index_base && a->pool_label)
+    if (int e = launch_eik_inv_n(a, n_iter, index_base, index_stride, 0, (hipStream_t)stream)) return e;
+  return train_search_impl(mv, a, n_iter, index_base, index_stride, rec_out, stream, 0);
+}
+// grid_cap > 0: at most that many blocks (the side launches of the overlapped schedule leave wave slots to the chain)
+static int train_search_impl(const clid_map_view* mv, const clid_train_args* a, int32_t n_iter, const int64_t* index_base,
+                             int64_t index_stride, float* rec_out, void* stream, int grid_cap) {
   if (int e = check_train_args(mv, a, "clid_train_search")) return e;
   if (n_iter <= 0 || !index_base || !rec_out || !a->pool_coord) {
     clid_set_error("clid_train_search: bad argument");
@@ -1467,6 +1532,7 @@ extern "C" int clid_train_search(const clid_map_view* mv, const clid_train_args*
                      : ((long long)tmap.n_tasks * n_iter + kFusedBlock / 64 - 1) / (kFusedBlock / 64);
   const int resident = search_blocks(cdir ? (num ? CLID_CD_WAVES_TILES : CLID_CD_WAVES_TASKS) : CLID_SEARCH_WAVES);
   if (sb > resident) sb = resident;
+  if (grid_cap > 0 && sb > grid_cap) sb = grid_cap;
   const bool xm = CLID_XCD_MAP && big_map && sb >= 8;
 #define CLID_SEARCH_LAUNCH(K, GRID, DYN)                                                                                   \
   CLID_KLAUNCH(a->prof, 1, K, GRID, dim3(kFusedBlock), DYN, s, *mv, t2, tmap, reinterpret_cast<float4*>(rec_out), n_iter, \
@@ -1530,6 +1596,125 @@ extern "C" int clid_train_decode(const clid_map_view* mv, const clid_train_args*
   return CLID_OK;
 }
 
+// ---- schedule object of the overlapped search schedule (clid_train_args.sched) ------------------------------------------
+struct clid_sched {
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr;
+  hipEvent_t done[kMaxChunkIters] = {};
+  int device = -1;
+};
+extern "C" int clid_sched_create(const uint32_t* cu_mask, int32_t mask_words, int32_t priority, clid_sched** out) {
+  if (!out || mask_words < 0 || (mask_words > 0 && !cu_mask)) {
+    clid_set_error("clid_sched_create: bad argument");
+    return CLID_E_ARG;
+  }
+  *out = nullptr;
+  clid_sched* s = new clid_sched();
+  bool ok = hipGetDevice(&s->device) == hipSuccess;
+  if (ok && mask_words > 0) {
+    ok = hipExtStreamCreateWithCUMask(&s->side, (uint32_t)mask_words, cu_mask) == hipSuccess;
+  } else if (ok) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const int prio = priority < 0 ? least : (priority > 0 ? greatest : 0);
+    ok = hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, prio) == hipSuccess;
+  }
+  ok = ok && hipEventCreateWithFlags(&s->fork, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; ok && i < kMaxChunkIters; ++i) ok = hipEventCreateWithFlags(&s->done[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    clid_set_error("clid_sched_create: %s", hipGetErrorString(hipGetLastError()));
+    clid_sched_destroy(s);
+    return CLID_E_HIP;
+  }
+  *out = s;
+  return CLID_OK;
+}
+extern "C" void clid_sched_destroy(clid_sched* s) {
+  if (!s) return;
+  if (s->side) {
+    (void)hipStreamSynchronize(s->side);
+    (void)hipStreamDestroy(s->side);
+  }
+  if (s->fork) (void)hipEventDestroy(s->fork);
+  for (int i = 0; i < kMaxChunkIters; ++i)
+    if (s->done[i]) (void)hipEventDestroy(s->done[i]);
+  delete s;
+}
+
+__global__ void __launch_bounds__(64) k_cu_census(int* __restrict__ out, long long hold) {
+  unsigned hw = 0, xcc = 0;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const long long t0 = __builtin_readcyclecounter();
+  while ((long long)__builtin_readcyclecounter() - t0 < hold) __builtin_amdgcn_s_sleep(8);
+  if (threadIdx.x == 0) out[blockIdx.x] = (int)(((xcc & 0xf) << 16) | (hw & 0xffff));
+}
+extern "C" int clid_debug_cu_census(clid_sched* sc, int32_t* out_host, int32_t n_blocks, int32_t hold_cycles, void* stream) {
+  if (!out_host || n_blocks < 1 || n_blocks > (1 << 20)) {
+    clid_set_error("clid_debug_cu_census: bad argument");
+    return CLID_E_ARG;
+  }
+  hipStream_t s = sc ? sc->side : (hipStream_t)stream;
+  int* dev = nullptr;
+  if (hipMalloc(&dev, sizeof(int) * (size_t)n_blocks) != hipSuccess) return CLID_E_HIP;
+  hipLaunchKernelGGL(k_cu_census, dim3((unsigned)n_blocks), dim3(64), 0, s, dev, (long long)hold_cycles);
+  const bool ok = hipStreamSynchronize(s) == hipSuccess &&
+                  hipMemcpy(out_host, dev, sizeof(int) * (size_t)n_blocks, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(dev);
+  if (!ok) {
+    clid_set_error("clid_debug_cu_census: %s", hipGetErrorString(hipGetLastError()));
+    return CLID_E_HIP;
+  }
+  return CLID_OK;
+}
+
+// The chunk with its searches BESIDE the chain (clid_train_args.sched): iteration it0's search in front of the first decode
+// on the launch stream; the searches of the chunk's other iterations on the object's side stream in groups, each followed by
+// an event the decode of the group's first iteration waits for.  The side stream starts behind `fork` = everything the launch
+// stream has queued so far (the batch draw / ordering of this call, the previous chunk's decodes that still read the record
+// buffer).  Every group's event is waited for before the chunk ends: nothing of the call is left on the side stream.
+static int chunk_overlapped(const clid_map_view* mv, clid_train_args& ta, clid_adam_args& aa, int it0, int n_it,
+                            const int64_t* index_base, int64_t index_stride, float* loss_base, float* rec, size_t per_iter,
+                            hipStream_t main) {
+  clid_sched* sc = ta.sched;
+  if (hipEventRecord(sc->fork, main) != hipSuccess || hipStreamWaitEvent(sc->side, sc->fork, 0) != hipSuccess) {
+    clid_set_error("clid_mapping_run: fork of the side stream failed: %s", hipGetErrorString(hipGetLastError()));
+    return CLID_E_HIP;
+  }
+  if (int e = train_search_impl(mv, &ta, 1, index_base + (int64_t)it0 * index_stride, index_stride, rec, main, 0)) return e;
+  int group_of[kMaxChunkIters];  // iteration (relative) -> event to wait for in front of its decode, -1 none
+  for (int i = 0; i < n_it; ++i) group_of[i] = -1;
+  int n_groups = 0;
+  for (int i = 1, g = 1; i < n_it; ++n_groups) {
+    const int want = ta.side_group > 0 ? ta.side_group : g;
+    const int n = (n_it - i) < want ? (n_it - i) : want;
+    if (int e = train_search_impl(mv, &ta, n, index_base + (int64_t)(it0 + i) * index_stride, index_stride,
+                                  rec + (size_t)i * per_iter, sc->side, ta.side_blocks))
+      return e;
+    if (hipEventRecord(sc->done[n_groups], sc->side) != hipSuccess) {
+      clid_set_error("clid_mapping_run: event record failed: %s", hipGetErrorString(hipGetLastError()));
+      return CLID_E_HIP;
+    }
+    group_of[i] = n_groups;
+    i += n;
+    g *= 2;
+  }
+  for (int i = 0; i < n_it; ++i) {
+    const int it = it0 + i;
+    if (group_of[i] >= 0 && hipStreamWaitEvent(main, sc->done[group_of[i]], 0) != hipSuccess) {
+      clid_set_error("clid_mapping_run: event wait failed: %s", hipGetErrorString(hipGetLastError()));
+      return CLID_E_HIP;
+    }
+    ta.index = index_base + (int64_t)it * index_stride;
+    ta.loss_out = loss_base + (size_t)it * 4;
+    ta.touch_iter = i;
+    if (int e = clid_train_decode(mv, &ta, rec + (size_t)i * per_iter, main)) return e;
+    aa.step = it + 1;
+    if (int e = clid_train_adam(&aa, &ta, main)) return e;
+  }
+  return CLID_OK;
+}
+
 static int mapping_run_hoisted(const clid_map_view* mv, clid_train_args& ta, clid_adam_args& aa, int iters,
                                const int64_t* index_base, int64_t index_stride, float* loss_base, void* stream) {
   int n_fd, first;
@@ -1543,8 +1728,18 @@ static int mapping_run_hoisted(const clid_map_view* mv, clid_train_args& ta, cli
   }
   for (int it0 = 0; it0 < iters; it0 += chunk) {
     const int n_it = (iters - it0) < chunk ? (iters - it0) : chunk;
-    if (int e = clid_train_search(mv, &ta, n_it, index_base + (int64_t)it0 * index_stride, index_stride, ws.rec,
-                                  stream))
+    if (int e = launch_eik_inv_n(&ta, n_it, index_base + (int64_t)it0 * index_stride, index_stride, 0, (hipStream_t)stream)) return e;
+    if (ta.sched && !ta.touch_ws && n_it >= 2) {
+      int dev = -1;
+      if (hipGetDevice(&dev) != hipSuccess || dev != ta.sched->device) {
+        clid_set_error("clid_mapping_run: the schedule object belongs to device %d, the current device is %d", ta.sched->device, dev);
+        return CLID_E_ARG;
+      }
+      if (int e = chunk_overlapped(mv, ta, aa, it0, n_it, index_base, index_stride, loss_base, ws.rec, per_iter, (hipStream_t)stream))
+        return e;
+      continue;
+    }
+    if (int e = train_search_impl(mv, &ta, n_it, index_base + (int64_t)it0 * index_stride, index_stride, ws.rec, stream, 0))
       return e;
     if (ta.touch_ws)
       if (int e = clid_train_touch_scan(&ta, mv->M, n_it, it0, nullptr, stream)) return e;

@@ -55,15 +55,22 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kHash = 128;      // LDS hash slots for the <= 96 distinct map rows of a tile
 constexpr int kMaxRows = 96;
 struct alignas(16) TileLds {
-  float dh[16 * kDhStride];  // [q][h]
+  union {                      // the numbering's hash is dead before dh is staged (both per wave; a fence in between)
+    float dh[16 * kDhStride];  // [q][h]
+    struct {
+      int hkey[kHash];         // (in-kernel numbering only) hash slot -> map row id, -1 empty
+      int hrow[kHash];         // (in-kernel numbering only) hash slot -> row number inside the tile
+    };
+  };
   float f[16 * kFStride];    // [q][c], c = 0..15 (11 = the bias input 1, 12..15 = 0)
   float wm[kMaxRows * 16];   // [row][q]: weight of query q on the tile's distinct map row `row`
-  int hkey[kHash];           // (in-kernel numbering only) hash slot -> map row id, -1 empty
-  int hrow[kHash];           // (in-kernel numbering only) hash slot -> row number inside the tile
   int rowid[kMaxRows];       // row number -> map row id
   int count;                 // (in-kernel numbering only) distinct rows of the tile
   int pad_[3];
 };
+// 13 200 bytes per wave: three 4-wave blocks (52 800 B) or six 2-wave blocks (26 400 B) fit a CU's 160 KB of LDS, i.e. LDS
+// admits 3 waves per SIMD (with the hash in its own 1 KB the 4-wave block was 56 896 B: two per CU)
+static_assert(sizeof(TileLds) * 12 <= 160 * 1024, "LDS plan: 12 tile waves per CU");
 
 // layer-norm variants: what F.layer_norm's backward needs of every distinct row, saved by the forward pass
 struct alignas(16) TileLnLds {
@@ -95,12 +102,17 @@ __device__ __forceinline__ void tile_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// WPS = waves per SIMD the instantiation is compiled for (launch bounds): 0 = the default -- layer norm pins 2 (VGPRs + AGPRs
+// <= 256; it lands on 1 otherwise), the others ask for 1 and get 2 --, 3 = the large-launch instantiation at <= 168 registers
+// (65 536 samples and up: many tiles per SIMD, the launch is bound by resident waves, not by one tile's chain)
 #ifndef CLID_TILE_WAVES
-#define CLID_TILE_WAVES (LN ? 2 : 1)  // layer norm: pin 2 waves per SIMD (VGPRs + AGPRs <= 256; it lands on 1 otherwise)
+#define CLID_TILE_WAVES (WPS ? WPS : ((LN || EM) ? 2 : 1))
 #endif
 // PRE: the tiles' row numbers come from the search launch's number blocks (small launches on maps within one L2: see
 // clid_tiles_prenumbered); otherwise the kernel numbers in place
-template <int PREC, bool LN, int TW, bool PRE>
+// EM: config.ekional_add_to "surface" / "freespace" (its own instantiations: the default ones are register-tight, three more
+// live values put the headline kernel at 226 + 32 > 256 registers = one wave per SIMD)
+template <int PREC, bool LN, int TW, bool PRE, int WPS = 0, bool EM = false>
 __global__ void __launch_bounds__(TW * 64, CLID_TILE_WAVES)
 k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap,
               const float4* __restrict__ rec, const int* __restrict__ tnum, int n_tiles, float* __restrict__ sdf_dbg) {
@@ -115,6 +127,9 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
   const float sc = ta.sdf_scale;
   const float inv_sigma = fdiv(1.0f, ta.sigma);
   const float inv_two_eps = fdiv(1.0f, 2.0f * ta.fd_eps);
+  // config.ekional_add_to (utils/mapper.py:779-789): "surface" / "freespace" restrict the eikonal mean to the decimated samples
+  // with |label| below / not below the surface range; the subset's size was counted by the search launch
+  const float inv_n_eik = EM ? ta.eik_inv_n[ta.touch_iter] : ta.inv_n_eik;  // (uniform: a scalar load)
   float* __restrict__ rows = ta.grad + CLID_GRAD_FEAT_OFFSET16;
   const float4* __restrict__ feat4 = reinterpret_cast<const float4*>(mv.feat);
   const float4* __restrict__ pos4 = reinterpret_cast<const float4*>(mv.pos4);
@@ -383,8 +398,13 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
         gy = (s2 - s3) * inv_two_eps;
         gz = (s4 - s5) * inv_two_eps;
         const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
-        if (slot == 6 && g == 0) eik_acc += (nrm - 1.f) * (nrm - 1.f);
-        ecoef = nrm > 0.f ? ta.weight_e * 2.f * (nrm - 1.f) * ta.inv_n_eik * inv_two_eps / nrm : 0.f;
+        bool inmask = true;
+        if constexpr (EM) {  // the decimated sample (slot 6 of the bundle) decides for its six copies
+          const float lab6 = __shfl(qq.z, b8 + 6, 64);
+          inmask = (fabsf(lab6) < ta.eik_mask_range) == (ta.eik_mask == 1);
+        }
+        if (slot == 6 && g == 0 && inmask) eik_acc += (nrm - 1.f) * (nrm - 1.f);
+        ecoef = (nrm > 0.f && inmask) ? ta.weight_e * 2.f * (nrm - 1.f) * inv_n_eik * inv_two_eps / nrm : 0.f;
       }
       if (p >= 0) {
         if (code < 0) {
@@ -595,17 +615,23 @@ int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, f
   const float4* r4 = reinterpret_cast<const float4*>(rec);
   const int* tn = reinterpret_cast<const int*>(rec + (size_t)tmap.n_tasks * kRecFloatsPerTask);  // (rec_floats_per_iter layout)
   const bool pre = clid_tiles_prenumbered(tmap.n_tasks, mv);
+#define CLID_TILE_LAUNCH_K(K, TWV)                                                                                    \
+  CLID_KLAUNCH(a->prof, 0, K, dim3(nb), dim3((TWV) * 64), 0, s, *mv, *a, partial, tmap, r4, tn, n_tiles, a->sdf_dbg)
 #define CLID_TILE_LAUNCH(P, L)                                                                                        \
   do {                                                                                                                \
-    if (tile_waves_for(n_tiles) == kTileWavesSmall && pre)                                                            \
-      CLID_KLAUNCH(a->prof, 0, (k_decode_tile<P, L, kTileWavesSmall, true>), dim3(nb), dim3(kTileWavesSmall * 64), 0, s, *mv,  \
-                   *a, partial, tmap, r4, tn, n_tiles, a->sdf_dbg);                                                   \
-    else if (tile_waves_for(n_tiles) == kTileWavesSmall)                                                              \
-      CLID_KLAUNCH(a->prof, 0, (k_decode_tile<P, L, kTileWavesSmall, false>), dim3(nb), dim3(kTileWavesSmall * 64), 0, s, *mv, \
-                   *a, partial, tmap, r4, tn, n_tiles, a->sdf_dbg);                                                   \
+    const bool small = tile_waves_for(n_tiles) == kTileWavesSmall;                                                    \
+    if (a->eik_mask) { /* config.ekional_add_to surface / freespace: the masked instantiations */                     \
+      if (small && pre) CLID_TILE_LAUNCH_K((k_decode_tile<P, L, kTileWavesSmall, true, 0, true>), kTileWavesSmall);   \
+      else if (small) CLID_TILE_LAUNCH_K((k_decode_tile<P, L, kTileWavesSmall, false, 0, true>), kTileWavesSmall);    \
+      else CLID_TILE_LAUNCH_K((k_decode_tile<P, L, kTileWavesLarge, false, 0, true>), kTileWavesLarge);               \
+    } else if (small && pre)                                                                                          \
+      CLID_TILE_LAUNCH_K((k_decode_tile<P, L, kTileWavesSmall, true>), kTileWavesSmall);                              \
+    else if (small)                                                                                                   \
+      CLID_TILE_LAUNCH_K((k_decode_tile<P, L, kTileWavesSmall, false>), kTileWavesSmall);                             \
+    else if (!L && (a->debug_flags & 16)) /* debug bit 4: the 3-waves-per-SIMD instantiation (A/B: it spills, 43 vs 29 us) */ \
+      CLID_TILE_LAUNCH_K((k_decode_tile<P, L, kTileWavesLarge, false, L ? 0 : 3>), kTileWavesLarge);                  \
     else                                                                                                              \
-      CLID_KLAUNCH(a->prof, 0, (k_decode_tile<P, L, kTileWavesLarge, false>), dim3(nb), dim3(kTileWavesLarge * 64), 0, s, *mv, \
-                   *a, partial, tmap, r4, tn, n_tiles, a->sdf_dbg);                                                   \
+      CLID_TILE_LAUNCH_K((k_decode_tile<P, L, kTileWavesLarge, false>), kTileWavesLarge);                             \
   } while (0)
   if (prec == 1) {
     if (mv->layer_norm) CLID_TILE_LAUNCH(1, true);
@@ -614,6 +640,7 @@ int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, f
     if (mv->layer_norm) CLID_TILE_LAUNCH(0, true);
     else CLID_TILE_LAUNCH(0, false);
   }
+#undef CLID_TILE_LAUNCH_K
 #undef CLID_TILE_LAUNCH
   CLID_CHECK_LAUNCH();
   return CLID_OK;

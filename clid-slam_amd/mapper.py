@@ -237,8 +237,9 @@ class Mapper:
             bad.append(f"main_loss_type={c.main_loss_type}")
         if self.ba_done_flag:
             bad.append("ba_done_flag")
-        if c.ekional_loss_on and getattr(c, "ekional_add_to", "all") != "all":
-            bad.append(f"ekional_add_to={c.ekional_add_to}")
+        add_to = getattr(c, "ekional_add_to", "all")
+        if c.ekional_loss_on and add_to not in ("all", "surface", "freespace"):
+            bad.append(f"ekional_add_to={add_to}")
         if not getattr(c, "opt_adam", True):
             bad.append("opt_adam=False")
         if bad:
@@ -324,6 +325,21 @@ class Mapper:
         sdf_dbg = getattr(self, "_sdf_dbg", None)   # test aid: SDF per record slot (tile kernels)
         ta.sdf_dbg = None if sdf_dbg is None else sdf_dbg.data_ptr()
         ta.prof = getattr(self, "_prof", None)      # measurement aid: clid_profile_create() object
+        if not dist:  # searches of iterations >= 1 beside the decode -> Adam chain (include/clid_native.h clid_train_args.sched)
+            ta.sched, ta.side_group, ta.side_blocks = _lib.sched(dev)
+        add_to = getattr(cfg, "ekional_add_to", "all")
+        if eik_mode and add_to in ("surface", "freespace"):
+            # utils/mapper.py:779-789: the eikonal mean over the decimated samples near / away from the surface only.  The
+            # subset's size is data: counted per iteration by the search launch, used by the tile decode kernels and Adam
+            if (eik_mode != 1 or dist or not cfg.weighted_first or ta.pipeline != 1
+                    or not lib.clid_train_decode_kernel(C.byref(view), C.byref(ta)) > 0):
+                raise NotImplementedError(f"fused mapping loop: ekional_add_to={add_to} runs on the tile decode kernels with the "
+                                          "numerical eikonal term on one GPU (no shipped config sets it)")
+            inv = getattr(self, "_eik_inv_n", None)
+            if inv is None or inv.device != dev:
+                inv = self._eik_inv_n = torch.zeros(64, device=dev, dtype=torch.float32)
+            ta.eik_mask = 1 if add_to == "surface" else 2
+            ta.eik_mask_range, ta.eik_inv_n = float(cfg.surface_sample_range_m), inv.data_ptr()
         hoist = ta.pipeline == 1  # (the analytic-eikonal iteration reads the hoisted search's records too)
         tile = hoist and lib.clid_train_decode_kernel(C.byref(view), C.byref(ta)) > 0
 

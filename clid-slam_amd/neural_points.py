@@ -184,8 +184,8 @@ class NeuralPoints(nn.Module):
         st = dict(st)
         st["_tables"] = {}
         st.pop("_replica_gens", None)  # torch.Generator objects do not pickle
-        for k in ("_sensor_pos_host", "_win_ws", "_win_counts", "_ins_ws", "_ins_count", "_ins_win_counts", "_gbuf", "_stencils", "_presampled", "_track_scratch", "_track_ne", "_cdir_bufs", "_stencil_rows", "_travel32_cache", "_last_update_counts"):
-            st.pop(k, None)
+        for k in ("_sensor_pos_host", "_win_ws", "_win_counts", "_ins_ws", "_ins_count", "_ins_win_counts", "_gbuf", "_stencils", "_presampled", "_track_scratch", "_track_ne", "_cdir_bufs", "_table_bufs", "_table_event", "_travel32_cache", "_last_update_counts"):
+            st.pop(k, None)  # (`_stencil_rows`, 25 ints, stays: a restored map walks its cell directory like a fresh one)
         # views of capacity / upper-bound buffers would drag the whole buffers into the pickle: the global arrays (capacity
         # buffers of the in-place insert) and the local arrays, mask and index map (outputs of the window selection, allocated
         # at the size of the global map)
@@ -805,6 +805,12 @@ class NeuralPoints(nn.Module):
         lib = _lib.load()
         _lib.require_cuda(big, "buffer_pt_index", torch.int64)
         pts = _lib.require_cuda(self.neural_points, "neural_points", torch.float32)
+        ev = self.__dict__.get("_table_event")
+        if ev is not None and ev[0] == slot:
+            # the key moved on while a build of this slot, enqueued ahead on another stream (prefetch_local_table), may still
+            # be writing the slot's cached buffers: the rebuild below goes behind it
+            torch.cuda.current_stream(pts.device).wait_event(ev[1])
+            self.__dict__["_table_event"] = None
         if int(self.buffer_size) >= (1 << 30):
             raise NotImplementedError("buffer_size >= 2^30 is not supported by the int32 slot arithmetic")
         if locally:

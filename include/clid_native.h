@@ -296,7 +296,38 @@ typedef struct clid_train_args {
    * intermediate values per shifted copy in the copy's own record slot (the label / weight fields, unused for a copy): the
    * one case in which it writes to `rec`. */
   int32_t decode_each_neighbour;
+  /* ---- overlapped search schedule of clid_mapping_run (ABI 6; NULL = every search of a chunk runs in front of the chunk's
+   * decode -> Adam chain).  With a schedule object (clid_sched_create: a side stream, optionally confined to a CU mask, and a
+   * ring of events) only iteration 0's search stays in front of the first decode; the searches of iterations 1 .. n-1 --
+   * which read nothing training writes (positions, directory, sample indices) -- go out on the side stream in launches of
+   * `side_group` iterations (0 = growing groups 1, 2, 4, 8, ...) on grids of at most `side_blocks` blocks (0 = the resident
+   * grid), beside the chain; the decode of the first iteration of a group waits for the group's event.  Same records, same
+   * results.  Single GPU, dense Adam sweep (touch_ws == NULL) only; otherwise the field is ignored. */
+  struct clid_sched* sched;
+  int32_t side_group;
+  int32_t side_blocks;
+  /* ---- config.ekional_add_to (utils/mapper.py:779-789; ABI 6): 0 = "all" (every shipped config), 1 = "surface", 2 =
+   * "freespace": the eikonal term is the mean over the decimated samples with |sdf_label| < eik_mask_range
+   * (config.surface_sample_range_m) / over the others.  The size of that subset is data: clid_train_search (and
+   * clid_mapping_run per chunk) counts it per iteration and leaves 1 / size in eik_inv_n [>= 32] floats (device), position =
+   * touch_iter; the decode / Adam launches normalise by it (an empty subset: 0 -- the reference's mean of an empty tensor is NaN).
+   * Tile decode kernels (decode_variant 1 / 2), numerical eikonal term, one rank; other combinations are rejected. */
+  int32_t eik_mask;
+  float eik_mask_range;
+  float* eik_inv_n;
 } clid_train_args;
+
+/* Schedule object for clid_train_args.sched.  cu_mask / mask_words as hipExtStreamCreateWithCUMask takes them (bit i set =
+ * the side stream's kernels may use compute unit i in the driver's numbering: on an 8-XCD part consecutive bits walk the
+ * XCDs first, tools/cu_mask_census.py); NULL / 0 = an ordinary non-blocking stream.  priority: 0 default, -1 the device's
+ * lowest, +1 its highest.  The object belongs to one host thread and one device. */
+typedef struct clid_sched clid_sched;
+int clid_sched_create(const uint32_t* cu_mask, int32_t mask_words, int32_t priority, clid_sched** out);
+void clid_sched_destroy(clid_sched* s);
+/* measurement aid: one word per block of a launch of n_blocks x 64 threads on the object's side stream (sched NULL: on
+ * `stream`) = (XCC id << 16) | the low 16 bits of HW_ID (CU, shader array and engine ids); every block holds its CU for
+ * hold_cycles so the dispatcher spreads the grid.  Synchronises. */
+int clid_debug_cu_census(clid_sched* s, int32_t* out_host, int32_t n_blocks, int32_t hold_cycles, void* stream);
 
 /* Touched-row workspace (see clid_train_args.touch_ws).  clid_train_touch_scan turns the chunk's flags (after the
  * cross-rank MAX when sharded) into per-iteration bit sets + prefix sums + counts and the per-row first-touch iteration

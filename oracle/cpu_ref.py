@@ -329,6 +329,8 @@ class LoopConfig:
     train_decoder: bool = True  # False after `freeze_model` (utils/tools.py:314, slam.py:193-196)
     loss_scale_counts: Optional[tuple] = None  # (N_global, N'_global) for sharded runs; None = local
     fd_first: int = 0  # sharded runs: local position of the first decimated sample
+    ekional_add_to: str = "all"  # utils/mapper.py:779-789: "all" | "surface" | "freespace"
+    surface_sample_range_m: float = 0.25  # config: the |sdf_label| threshold of the surface mask (utils/mapper.py:692-694)
 
 
 def draw_batch_index(pool_count: int, new_idx: Optional[torch.Tensor], bs: int, bs_new_sample: int, gen=None):
@@ -370,7 +372,11 @@ def loss_and_grads(st: MapState, dec: DecoderParams, pool: SamplePool, index: to
     total = l_bce
     l_eik = torch.zeros(())
     if lc.ekional_loss_on and lc.weight_e > 0 and g is not None:
-        l_eik = eikonal_loss(g)
+        g_used = g
+        if lc.ekional_add_to != "all":  # utils/mapper.py:779-789 (mask on the decimated subset)
+            surface = (label.abs() < lc.surface_sample_range_m)[lc.fd_first :: (lc.gradient_decimation if lc.numerical_grad else 1)]
+            g_used = g[surface] if lc.ekional_add_to == "surface" else g[~surface]
+        l_eik = eikonal_loss(g_used)
         total = total + lc.weight_e * l_eik
     if lc.loss_scale_counts is not None:  # sharded: normalise by the global counts
         n_glob, ng_glob = lc.loss_scale_counts
@@ -395,24 +401,37 @@ def loss_and_grads(st: MapState, dec: DecoderParams, pool: SamplePool, index: to
     return out
 
 
-def relu_ambiguous_rows(st: MapState, dec: DecoderParams, pool: SamplePool, index: torch.Tensor, lc: LoopConfig, tau: float):
+def relu_ambiguous_rows(st: MapState, dec: DecoderParams, pool: SamplePool, index: torch.Tensor, lc: LoopConfig, tau: float,
+                        with_slack: bool = False):
     """Checker aid (no reference counterpart): the map rows whose gradient of this iteration is NOT a continuous function of
     the fp32 rounding -- rows gathered by a query point (batch sample or finite-difference copy, utils/mapper.py:697-704)
     that has a hidden pre-activation of the decoder (model/decoder.py:58-82) within `tau` of the ReLU kink.  Two correct
     fp32 evaluations of such a query (different summation orders in W1 f + b1) may open / close that unit, which moves the
-    gradient of the query's <= K neighbour rows by one hidden unit's whole contribution.  Returns (rows int64, queries)."""
+    gradient of the query's <= K neighbour rows by one hidden unit's whole contribution.  Returns (rows int64, queries).
+
+    `with_slack`: also a per-row BOUND on that movement, [M + 1] floats (0 for rows no such query gathers): for every
+    (query q, unit h) on the kink and every neighbour row j of q
+        w_qj * |dL/dsdf_q| * sdf_scale * |W2[h]| * ||W1[h, :F]||_2 * (layer norm: 1 / sqrt(var_j + 1e-5))
+    summed per row -- what opening or closing unit h for query q adds to / removes from the gradient of row j (the L2 norm
+    of the 8-vector; the layer-norm Jacobian rstd (I - 11^T / F - xh xh^T / F) has norm <= rstd).  dL/dsdf comes from the
+    loss of utils/mapper.py:746-798 restated on the SDFs of all bs + 6 n_fd points as leaves.  A checker then holds a listed
+    row to strict tolerance + this bound instead of a blanket looser bar.  None where the bound is not derived
+    (`weighted_first: False`, analytic eikonal, sharded normalisers).  Fourth value: bool [M + 1], the rows ANY query point of
+    the iteration gathers (a row outside it must receive an exactly-zero gradient from any correct implementation)."""
     with torch.no_grad():
         coord = pool.global_coord[index]
         pts = [coord]
+        n_fd = 0
         if lc.ekional_loss_on and lc.numerical_grad:
             x = coord[lc.fd_first :: lc.gradient_decimation]
+            n_fd = x.shape[0]
             for a in range(3):
                 e = torch.zeros(3, dtype=x.dtype)
                 e[a] = lc.fd_eps
                 pts += [x + e, x - e]
         allp = torch.cat(pts, dim=0)
         cert = st.local_point_certainties.clone()
-        f, _, _, _, idx = query_feature(st, allp, None, training_mode=False)
+        f, w, _, _, idx = query_feature(st, allp, None, training_mode=False)
         st.local_point_certainties.copy_(cert)
         if not st.weighted_first:
             f = f.reshape(-1, f.shape[-1])
@@ -420,9 +439,39 @@ def relu_ambiguous_rows(st: MapState, dec: DecoderParams, pool: SamplePool, inde
         else:
             idx_q = idx
         pre = F.linear(f, dec.W1, dec.b1)
-        amb = pre.abs().min(dim=1).values < tau
+        amb_u = pre.abs() < tau
+        amb = amb_u.any(dim=1)
         rows = idx_q[amb].reshape(-1)
-        return torch.unique(rows[rows >= 0]), int(amb.sum())
+        rows_u, n_q = torch.unique(rows[rows >= 0]), int(amb.sum())
+        gathered = torch.zeros(st.local_geo_features.shape[0], dtype=torch.bool)
+        gathered[idx_q[idx_q >= 0]] = True   # rows some query point of the iteration gathers at all
+    if not with_slack:
+        return rows_u, n_q
+    derivable = (st.weighted_first and lc.loss_scale_counts is None and (lc.numerical_grad or not lc.ekional_loss_on))
+    if not derivable:
+        return rows_u, n_q, None, gathered
+    bs = coord.shape[0]
+    sdf = mlp_sdf(dec, f).detach().requires_grad_(True)
+    weight = pool.weight[index].abs()
+    total = sdf_bce_loss(sdf[:bs], pool.sdf_label[index], lc.sigma, weight, lc.loss_weight_on)
+    if n_fd > 0 and lc.weight_e > 0:
+        s = sdf[bs:].unsqueeze(-1)
+        g = torch.cat([(s[2 * a * n_fd:(2 * a + 1) * n_fd] - s[(2 * a + 1) * n_fd:(2 * a + 2) * n_fd]) / (2 * lc.fd_eps)
+                       for a in range(3)], dim=1)
+        total = total + lc.weight_e * eikonal_loss(g)
+    (dsdf,) = torch.autograd.grad(total, sdf)
+    with torch.no_grad():
+        Fdim = st.local_geo_features.shape[1]
+        unit = dec.W2.reshape(-1).abs() * dec.W1[:, :Fdim].norm(dim=1)           # [H]
+        per_q = dsdf.abs() * abs(float(dec.sdf_scale)) * (amb_u.to(unit.dtype) * unit).sum(dim=1)   # [Q]
+        contrib = (w.reshape(w.shape[0], -1) * per_q[:, None])                     # [Q, K]
+        slack = torch.zeros(st.local_geo_features.shape[0], dtype=contrib.dtype)
+        ok = (idx_q >= 0) & amb[:, None]
+        slack.index_add_(0, idx_q[ok], contrib[ok])
+        if st.layer_norm_on:
+            var = st.local_geo_features.detach().var(dim=1, unbiased=False)
+            slack = slack / torch.sqrt(var + 1e-5)
+    return rows_u, n_q, slack, gathered
 
 
 def mapping_iters(st: MapState, dec: DecoderParams, pool: SamplePool, index_seq, lc: LoopConfig, record=False,
@@ -437,10 +486,10 @@ def mapping_iters(st: MapState, dec: DecoderParams, pool: SamplePool, index_seq,
     ad_dec = [AdamState(torch.zeros_like(t), torch.zeros_like(t)) for t in dec.tensors()]
     recs = []
     for it in range(len(index_seq)):
-        amb = relu_ambiguous_rows(st, dec, pool, index_seq[it], lc, ambiguity_tau) if (record and ambiguity_tau) else None
+        amb = relu_ambiguous_rows(st, dec, pool, index_seq[it], lc, ambiguity_tau, with_slack=True) if (record and ambiguity_tau) else None
         out = loss_and_grads(st, dec, pool, index_seq[it], lc)
         if amb is not None:
-            out["ambiguous_rows"], out["ambiguous_queries"] = amb
+            out["ambiguous_rows"], out["ambiguous_queries"], out["ambiguous_row_slack"], out["gathered_rows"] = amb
         with torch.no_grad():
             if lc.train_decoder:
                 for name, t, s in zip(("W1", "b1", "W2", "b2"), dec.tensors(), ad_dec):

@@ -259,12 +259,18 @@ def main():
     )
     sensor = torch.tensor([9.0, 3.0, 1.6])
     g6_common = {}
-    for mode in ("numerical", "analytic"):
-        for frozen in (False, True):
-            for ln in ((False, True) if (mode == "numerical" and not frozen) else (False,)):
-                tag = f"{mode}_{'frozen' if frozen else 'train'}_ln{int(ln)}"
+    cases = [(mode, frozen, ln, "all") for mode in ("numerical", "analytic") for frozen in (False, True)
+             for ln in ((False, True) if (mode == "numerical" and not frozen) else (False,))]
+    # config.ekional_add_to "surface" / "freespace" (utils/mapper.py:779-789; after the five cases above, whose files stay as
+    # they were: every case seeds its own draws)
+    cases += [("numerical", False, False, "surface"), ("numerical", False, False, "freespace")]
+    for mode, frozen, ln, add_to in cases:
+        for _once in (0,):
+            for _once2 in (0,):
+                tag = f"{mode}_{'frozen' if frozen else 'train'}_ln{int(ln)}" + ("" if add_to == "all" else f"_eik{add_to}")
                 cfg6 = ref_config(ref, bs=BS, bs_new_sample=200)
                 cfg6.layer_norm_on = ln
+                cfg6.ekional_add_to = add_to
                 if mode == "analytic":
                     cfg6.numerical_grad = False
                     cfg6.gradient_decimation = 1

@@ -142,6 +142,60 @@ def region_sdf(lc: LocalCloud, points: torch.Tensor):
     return sdf_abs, surface
 
 
+def region_sdf_ambiguity(lc: LocalCloud, points: torch.Tensor, coord_tol: float = 2e-5, eta_tol: float = 2e-3,
+                         resid_tol: float = 2e-4, tie_tol: float = 1e-5, label_tol: float = 5e-5, noise: float = 6e-6):
+    """Checker aid (no reference counterpart): the samples whose label / surface mask from `region_sdf`
+    (model/local_point_cloud_map.py:98-201) is NOT a continuous function of fp32 rounding, so that two correct
+    implementations -- different summation orders in the rigid transform, the centring and the 4 x 3 SVD, on world coordinates
+    of tens of metres -- may legitimately disagree by more than rounding.  Returns a dict of bool masks [n]:
+      cell       a coordinate within `coord_tol` of a voxel boundary (floor(p / r) may differ: another neighbourhood)
+      range      the nearest or the 4th-nearest distance within `coord_tol` of the "no neighbour" range (mask / fit validity)
+      tie        4th and 5th nearest neighbour within `tie_tol` of each other (another set of 4 points -> another plane)
+      eta        eta = s_min / (s_mid + 1e-6) within `eta_tol` of its threshold 0.2 (plane accepted by one side only)
+      resid      largest point-to-plane residual within `resid_tol` of its threshold 0.1 (likewise)
+      illcond    accepted plane whose normal is badly conditioned: the label's sensitivity to `noise` metres of centring
+                 error, |p - c| * noise / (s_mid - s_min), exceeds `label_tol` (nearly collinear points of one scan line)
+      any        the union.
+    A checker holds every sample OUTSIDE `any` to the strict label tolerance and an exact surface mask."""
+    n = points.shape[0]
+    out = {k: torch.zeros(n, dtype=torch.bool) for k in ("cell", "range", "tie", "eta", "resid", "illcond")}
+    step = 262144
+    for a in range(0, n, step):
+        p = points[a:a + step]
+        sl = slice(a, a + p.shape[0])
+        u = p / lc.resolution
+        out["cell"][sl] = ((u - torch.round(u)).abs() * lc.resolution < coord_tol).any(dim=1)
+        cells = torch.floor(u).long()[:, None, :] + lc.neighbor_idx
+        idx = lc.buffer_pt_index[cloud_hash(lc, cells)]
+        nb = lc.points[idx]
+        d = torch.norm(nb - p[:, None, :], dim=-1)
+        d = torch.where(idx == -1, torch.tensor(lc.max_valid_range, dtype=d.dtype), d)
+        kk = min(5, d.shape[1])
+        d5, i5 = torch.topk(d, kk, largest=False, dim=1)
+        real_near = (idx != -1) & ((d - lc.max_valid_range).abs() < coord_tol)   # a REAL distance at the sentinel's value
+        out["range"][sl] = real_near.any(dim=1)
+        four = d5[:, 3] < lc.max_valid_range
+        if kk == 5:
+            out["tie"][sl] = four & ((d5[:, 4] - d5[:, 3]) < tie_tol)
+        knn = torch.gather(nb, 1, i5[:, :4].unsqueeze(-1).expand(-1, -1, 3))[four]
+        c = knn.mean(dim=1, keepdim=True)
+        _, sv, vh = torch.linalg.svd(knn - c, full_matrices=False)
+        eta = sv[:, -1] / (sv[:, 1] + 1e-6)
+        flat = eta <= 0.2
+        normal = vh[:, -1, :]
+        offset = -1.0 * torch.sum(normal * c.squeeze(1), dim=1)
+        resid = torch.abs(torch.bmm(knn, normal.unsqueeze(-1)).squeeze(-1) + offset.unsqueeze(-1)).max(dim=1).values
+        lever = torch.norm(p[four] - c.squeeze(1), dim=1)
+        sens = lever * noise / (sv[:, 1] - sv[:, -1]).clamp_min(1e-12)
+        ok = flat & (resid <= 0.1)
+        fi = torch.nonzero(four).flatten() + a
+        out["eta"][fi] = (eta - 0.2).abs() < eta_tol
+        out["resid"][fi] = flat & ((resid - 0.1).abs() < resid_tol)
+        out["illcond"][fi] = ok & (sens > label_tol)
+    out["any"] = out["cell"] | out["range"] | out["tie"] | out["eta"] | out["resid"] | out["illcond"]
+    return out
+
+
 def transform(points: torch.Tensor, pose: torch.Tensor) -> torch.Tensor:
     """utils/tools.py:590-609 (homogeneous row-vector product in the points' dtype)."""
     homo = torch.cat([points, torch.ones(points.shape[0], 1).to(points)], dim=1)

@@ -179,14 +179,24 @@ def test_adam_kernel_vs_torch(env):
 G6 = [("numerical", False, 0), ("numerical", False, 1), ("numerical", True, 0), ("analytic", False, 0), ("analytic", True, 0)]
 
 
+@pytest.mark.parametrize("add_to", ["surface", "freespace"])
+def test_mapping_loop_g6_ekional_add_to(env, add_to):
+    """config.ekional_add_to "surface" / "freespace" (utils/mapper.py:779-789) against the reference's own loop: the eikonal
+    mean runs over the decimated samples with |sdf_label| below / not below config.surface_sample_range_m."""
+    g_all = gio.load("g6_loop_numerical_train_ln0.npz")
+    g = gio.load(f"g6_loop_numerical_train_ln0_eik{add_to}.npz")
+    assert abs(float(g["loss_total"][0]) - float(g_all["loss_total"][0])) > 1e-4  # (the fixture really differs from "all")
+    test_mapping_loop_g6(env, "numerical", False, 0, add_to)
+
+
 @pytest.mark.parametrize("mode,frozen,ln", G6)
-def test_mapping_loop_g6(env, mode, frozen, ln):
+def test_mapping_loop_g6(env, mode, frozen, ln, add_to="all"):
     from clid_slam_amd.tools import freeze_model
 
-    tag = f"{mode}_{'frozen' if frozen else 'train'}_ln{ln}"
+    tag = f"{mode}_{'frozen' if frozen else 'train'}_ln{ln}" + ("" if add_to == "all" else f"_eik{add_to}")
     g = gio.load(f"g6_loop_{tag}.npz")
     p = gio.load("pool.npz")
-    cfg = env.config(layer_norm_on=bool(ln), bs=int(g["index_seq"].shape[1]), bs_new_sample=200)
+    cfg = env.config(layer_norm_on=bool(ln), bs=int(g["index_seq"].shape[1]), bs_new_sample=200, ekional_add_to=add_to)
     if mode == "analytic":
         cfg.numerical_grad, cfg.gradient_decimation = False, 1
     nm = env.neural_points(cfg, base=p)
@@ -995,6 +1005,58 @@ def test_mapping_with_internal_draws_replays_on_the_oracle(layer_norm, monkeypat
         ga = r["grad_theta"].abs()
         noise |= (ga < 1e-10) & (ga.max(dim=1, keepdim=True).values > 0)
     err = (nm.local_geo_features.detach().cpu() - recs[-1]["theta"]).abs()
-    assert float(err[~noise].max()) <= 1e-4 and int((err > 1e-4).sum()) <= 8
+    assert float(err[~noise].max()) <= 1e-4 and float(err.max()) <= cfg.lr * 3 * 1.01  # (only entries the oracle's mask names may differ)
     for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
         assert float((t.detach().cpu() - o).abs().max()) <= 1e-4
+
+
+def test_pickle_after_gpu_calls_carries_no_device_mirror(env, tmp_path):
+    """utils/tools.py:347-367 pickles the whole NeuralPoints module (`pin_map.pth`).  After the GPU calls that build the
+    mirrors -- mapping() (local probe table + cell directory, cached per slot) and a query of the global map (global table) --
+    the pickle must hold the reference's arrays only: no probe table, no directory, no cached buffers, no event."""
+    import io
+    import pickle
+
+    g = gio.load("g6_loop_numerical_train_ln0.npz")
+    p = gio.load("pool.npz")
+    idx = gio.T(g["index_seq"]).to(torch.int64)[:2]
+    cfg = env.config(bs=int(idx.shape[1]))
+    nm = env.neural_points(cfg, base=p)
+    dec = env.decoder(cfg, g, "init_")
+    mp, _ = env.mapper(cfg, nm, dec)
+    mp.mapping(2, index_seq=idx.cuda())
+    nm.radius_neighborhood_search(gio.T(gio.load("g1_search.npz")["x"]).cuda())
+    nm.prefetch_local_table(torch.cuda.Stream())
+    torch.cuda.synchronize()
+    assert nm._tables and nm.__dict__.get("_table_bufs") and nm.__dict__.get("_cdir_bufs")
+    st = nm.__getstate__()
+    for k in ("_table_bufs", "_cdir_bufs", "_table_event", "_travel32_cache", "_stencils", "_gbuf"):
+        assert k not in st, k
+    assert st["_tables"] == {}
+    # what the pickle may weigh: the tensors of the reference's attribute list (+ the stencil constants)
+    def nbytes(o, seen):
+        if isinstance(o, torch.Tensor):
+            key = o.untyped_storage().data_ptr()
+            if key in seen:
+                return 0
+            seen.add(key)
+            return o.untyped_storage().nbytes()
+        if isinstance(o, dict):
+            return sum(nbytes(v, seen) for v in o.values())
+        if isinstance(o, (list, tuple)):
+            return sum(nbytes(v, seen) for v in o)
+        return 0
+    expected = nbytes(st, set())
+    path = tmp_path / "m.pth"
+    torch.save(nm, path)
+    size = path.stat().st_size
+    mirrors = nbytes(nm.__dict__.get("_table_bufs"), set()) + nbytes(nm.__dict__.get("_cdir_bufs"), set())
+    assert mirrors > (1 << 20)                       # (they exist and are large: the test means something)
+    assert size < expected + (1 << 16), (size, expected, mirrors)
+    nm2 = torch.load(path, weights_only=False)
+    assert nm2._tables == {} and "_table_bufs" not in nm2.__dict__
+    # a restored map answers the same search (mirrors rebuilt on demand, directory walk included)
+    x = gio.T(gio.load("g1_search.npz")["x"]).cuda()
+    d2a, ia = nm.radius_neighborhood_search(x)
+    d2b, ib = nm2.radius_neighborhood_search(x)
+    assert torch.equal(ia, ib) and torch.equal(d2a, d2b)

@@ -107,18 +107,21 @@ def test_adam_matches_torch_optim():
         assert torch.equal(p, p_ref.detach())
 
 
-G6 = [("numerical", False, 0), ("numerical", False, 1), ("numerical", True, 0), ("analytic", False, 0), ("analytic", True, 0)]
+G6 = [("numerical", False, 0, "all"), ("numerical", False, 1, "all"), ("numerical", True, 0, "all"), ("analytic", False, 0, "all"),
+      ("analytic", True, 0, "all"),
+      # config.ekional_add_to (utils/mapper.py:779-789): the eikonal mean over the near-surface / the free-space decimated samples
+      ("numerical", False, 0, "surface"), ("numerical", False, 0, "freespace")]
 
 
-@pytest.mark.parametrize("mode,frozen,ln", G6)
-def test_g6_mapping_loop(mode, frozen, ln):
-    tag = f"{mode}_{'frozen' if frozen else 'train'}_ln{ln}"
+@pytest.mark.parametrize("mode,frozen,ln,add_to", G6)
+def test_g6_mapping_loop(mode, frozen, ln, add_to):
+    tag = f"{mode}_{'frozen' if frozen else 'train'}_ln{ln}" + ("" if add_to == "all" else f"_eik{add_to}")
     g = gio.load(f"g6_loop_{tag}.npz")
     st = gio.map_state(layer_norm_on=bool(ln))
     pool, praw = gio.sample_pool()
     dec = gio.decoder(g, "init_")
     lc = O.LoopConfig(numerical_grad=(mode == "numerical"), gradient_decimation=10 if mode == "numerical" else 1,
-                      train_decoder=not frozen)
+                      train_decoder=not frozen, ekional_add_to=add_to)
     index_seq = gio.T(g["index_seq"]).to(torch.int64)
     # a1: the batch composition rule reproduces the reference's batch from its recorded draws
     idx0 = torch.cat((gio.T(g["draw_hist0"]), gio.T(g["new_idx"])[gio.T(g["draw_pick0"])]))
@@ -225,3 +228,50 @@ def test_relu_ambiguous_rows_is_a_pure_checker_aid(ln):
     assert set(recs[0]["ambiguous_rows"].tolist()) <= set(touched.tolist()) | {int(st.local_geo_features.shape[0]) - 1}
     assert torch.equal(recs[0]["ambiguous_rows"], r2)
     close(recs[1]["loss"], g["loss_total"][1], 2e-6, "records unchanged by the ambiguity pass")
+
+
+@pytest.mark.parametrize("ln", [0, 1])
+@pytest.mark.parametrize("tau", [1e-5, 3e-5])
+def test_relu_kink_row_bound_holds_for_forced_gates(ln, tau, monkeypatch):
+    """The per-row bound `relu_ambiguous_rows(..., with_slack=True)` hands to the GPU checks (a listed row may differ from the
+    oracle's gradient by at most strict tolerance + 1.25 x its bound; every other row is strict): checked oracle against
+    oracle.  The decoder's ReLU gates of every (query, unit) inside the tau band are FORCED open, forced closed, or flipped at
+    random -- the evaluations two correct fp32 implementations may disagree on -- and the gradient of the iteration
+    (utils/mapper.py:642-836) is recomputed: rows outside the list do not move (<= 1e-6 of the largest entry), listed rows
+    move by less than their bound, and rows nobody gathers stay exactly zero."""
+    import torch.nn.functional as F
+
+    g = gio.load(f"g6_loop_numerical_train_ln{ln}.npz")
+    pool, _ = gio.sample_pool()
+    dec = gio.decoder(g, "init_")
+    lc = O.LoopConfig()
+    idx = gio.T(g["index_seq"]).to(torch.int64)[0]
+    st = gio.map_state(layer_norm_on=bool(ln))
+    rows, nq, slack, gathered = O.relu_ambiguous_rows(st, dec, pool, idx, lc, tau, with_slack=True)
+    assert nq > 0 and slack is not None and float(slack[rows].min()) >= 0.0 and float(slack.sum()) > 0.0
+    kink = torch.zeros(slack.shape[0], dtype=torch.bool)
+    kink[rows] = True
+    assert float(slack[~kink].abs().max()) == 0.0 and bool(gathered[rows].all())
+    base = O.loss_and_grads(st, dec, pool, idx, lc)["grad_theta"]
+    assert not bool((base != 0).any(1)[~gathered].any())
+    gmax = float(base.abs().max())
+    moved = 0.0
+    for mode in (True, False, None):
+        gen = torch.Generator().manual_seed(7)
+
+        def forced(d, f, mode=mode):
+            pre = F.linear(f, d.W1, d.b1)
+            amb = pre.detach().abs() < tau
+            m = torch.full_like(amb, bool(mode)) if mode is not None else (torch.rand(amb.shape, generator=gen) < 0.5)
+            gate = torch.where(amb, m, pre.detach() > 0).to(pre.dtype)
+            return F.linear(pre * gate, d.W2, d.b2).squeeze(1) * d.sdf_scale
+
+        monkeypatch.setattr(O, "mlp_sdf", forced)
+        other = O.loss_and_grads(gio.map_state(layer_norm_on=bool(ln)), dec, pool, idx, lc)["grad_theta"]
+        monkeypatch.undo()
+        d = (other - base).abs().max(1).values
+        assert float(d[~kink].max()) <= 1e-6 * gmax
+        assert float((d - 1.25 * slack).max()) <= 1e-5 * gmax
+        assert not bool((other != 0).any(1)[~gathered].any())
+        moved = max(moved, float(d[kink].max()) / gmax)
+    assert moved > 1e-4  # the forced gates really moved listed rows beyond the strict bar (the bound is doing work)

@@ -6,7 +6,8 @@ Tolerances: sample coordinates and weights follow the reference's fp32 op order 
 labels from the plane fit are |n.p + d| with world coordinates of tens of metres in fp32, so two correct
 implementations of the 4x3 SVD differ by ~1e-5 m there: 1e-4 m is asserted, nearest-point and projective labels
 to 2e-6.  A sample within rounding of a voxel boundary or of a validity threshold can legitimately fall on the
-other side; such flips are counted and bounded (<= 0.1 %)."""
+other side, and a badly conditioned plane fit moves by more than rounding: the ORACLE names those samples
+(oracle.sampler_ref.region_sdf_ambiguity, <= 1 %); every sample it does not name is held to the strict bars."""
 import numpy as np
 import pytest
 import torch
@@ -41,22 +42,41 @@ def _cloud_at(g, fid, cfg):
     return lpm
 
 
+def _oracle_cloud(lpm, cfg):
+    lc = R.LocalCloud.empty(resolution=0.2, buffer_size=cfg.local_buffer_size, map_size=cfg.local_map_size)
+    lc.buffer_pt_index = lpm.buffer_pt_index.cpu()
+    lc.points = lpm.local_point_cloud_map.cpu()
+    return lc
+
+
 @pytest.mark.parametrize("fid", [0, 1, 2])
 def test_region_sdf_kernel_g9(fid):
+    """model/local_point_cloud_map.py:98-201 against the reference's own outputs.  The surface mask is exact (identical inputs
+    => identical cells).  Labels: strict (1e-4 m) on every sample the oracle does not NAME as discontinuous in fp32 rounding
+    (oracle.sampler_ref.region_sdf_ambiguity: a plane fit on the eta / residual threshold, a 4th / 5th neighbour tie, a
+    badly conditioned normal); the named ones are few and bounded by the label range."""
     g = gio.load("g9_sampler.npz")
-    lpm = _cloud_at(g, fid, _cfg(g))
-    d, ok = lpm.region_specific_sdf_estimation(gio.T(g[f"f{fid}_q"]).cuda())
+    cfg = _cfg(g)
+    lpm = _cloud_at(g, fid, cfg)
+    q = gio.T(g[f"f{fid}_q"])
+    d, ok = lpm.region_specific_sdf_estimation(q.cuda())
     ok, d = ok.cpu().numpy(), d.cpu().numpy()
     assert np.array_equal(ok, g[f"f{fid}_q_ok"])  # identical inputs => identical cells and masks
+    amb = R.region_sdf_ambiguity(_oracle_cloud(lpm, cfg), q)
+    named = (amb["any"] & ~amb["cell"]).numpy()   # (the cells are given here: same inputs on both sides)
     err = np.abs(d - g[f"f{fid}_q_sdf"])
-    flips = err > 1e-4   # plane accepted by one side only (eta / residual within rounding of its threshold)
-    assert flips.mean() <= 1e-3, flips.sum()
-    assert err[~flips].max() <= 1e-4
+    assert named.mean() <= 1e-2, named.sum()
+    assert err[~named].max() <= 1e-4, (int((err[~named] > 1e-4).sum()), float(err[~named].max()))
+    assert err[named].max() <= 0.4 if named.any() else True   # (plane vs nearest-point label: bounded by the neighbourhood)
     assert np.median(err) <= 2e-6
 
 
 @pytest.mark.parametrize("fid", [0, 2])
 def test_sampler_kernel_g9(fid):
+    """utils/data_sampler.py:260-402 against the reference's own (compacted) outputs, row by row: the rows are aligned through
+    the dense (ray, sample) index -- the oracle's keep mask reproduces the reference's compaction (checked: same count) -- and
+    compared on the intersection of the two keep masks; a row kept by one side only must be one the oracle names (a sample within
+    rounding of a voxel boundary / of the neighbourhood's range)."""
     from clid_slam_amd import DataSampler
 
     g = gio.load("g9_sampler.npz")
@@ -64,18 +84,35 @@ def test_sampler_kernel_g9(fid):
     lpm = _cloud_at(g, fid, cfg)
     pts, pose = gio.T(g[f"f{fid}_points"]), gio.T(g[f"f{fid}_pose"])
     noise = gio.sampler_noise(gio.S(g[f"f{fid}_seed"]), pts.shape[0])
-    coord, label, weight = DataSampler(cfg).sample(pts.cuda(), lpm, pose, noise=noise)
     want_c, want_l, want_w = g[f"f{fid}_coord"], g[f"f{fid}_label"], g[f"f{fid}_weight"]
-    if coord.shape[0] != want_c.shape[0]:
-        # a near-surface sample within rounding of a voxel boundary changed its mask: rows no longer align, the
-        # row-by-row comparison is the dense test below; here only the count is bounded
-        assert abs(coord.shape[0] - want_c.shape[0]) <= 1e-3 * want_c.shape[0]
-        return
-    assert np.abs(coord.cpu().numpy() - want_c).max() <= 2e-6 * 60
-    assert np.abs(weight.cpu().numpy() - want_w).max() <= 1e-6
-    err = np.abs(label.cpu().numpy() - want_l)
-    assert (err > 1e-4).mean() <= 1e-3
-    assert np.median(err) <= 2e-6
+    coord, label, weight, keep, n_all = DataSampler(cfg)._run(pts.cuda(), lpm, pose, noise)
+    coord, label, weight, k = coord.cpu().numpy(), label.cpu().numpy(), weight.cpu().numpy(), keep.bool().cpu().numpy()
+    # the oracle's dense keep mask and ambiguity list (ray-major, like the kernel's dense outputs)
+    lc = _oracle_cloud(lpm, cfg)
+    sc = R.SamplerConfig()
+    xyz, disp, ratio, depth, disp_s, n_all_o = R._ray_samples(sc, pts, noise)
+    Rn = pts.shape[0]
+    n_surface = Rn * (sc.surface_sample_n + 1)
+    world = R.transform(xyz[Rn:n_surface], pose)
+    _, ok = R.region_sdf(lc, world)
+    amb = R.region_sdf_ambiguity(lc, world)
+    kp = torch.ones(Rn * n_all_o, dtype=torch.bool)
+    kp[Rn:n_surface] = ok
+    named = torch.zeros(Rn * n_all_o, dtype=torch.bool)
+    named[Rn:n_surface] = amb["any"]
+    want_k, named = R._ray_major(kp, n_all_o).numpy(), R._ray_major(named, n_all_o).numpy()
+    assert n_all == n_all_o and int(want_k.sum()) == want_c.shape[0]   # the oracle's mask IS the reference's compaction
+    pos = np.cumsum(want_k) - 1                                          # dense index -> row of the golden arrays
+    assert not ((k != want_k) & ~named).any(), int(((k != want_k) & ~named).sum())
+    assert (k != want_k).mean() <= 1e-3
+    both = k & want_k
+    rows = pos[both]
+    assert np.abs(coord[both] - want_c[rows]).max() <= 2e-6 * 60
+    assert np.abs(weight[both] - want_w[rows]).max() <= 1e-6
+    err = np.abs(label[both] - want_l[rows])
+    strict = ~named[both]
+    assert err[strict].max() <= 1e-4, (int((err[strict] > 1e-4).sum()), float(err[strict].max()))
+    assert named.mean() <= 1e-2 and np.median(err) <= 2e-6
 
 
 @pytest.mark.parametrize("fid", [0, 1, 2])
@@ -110,11 +147,15 @@ def test_sampler_kernel_dense_vs_oracle(fid):
     assert np.abs(coord.cpu().numpy() - want_c).max() <= 1e-4
     assert np.abs(weight.cpu().numpy() - want_w).max() <= 1e-6
     k = keep.bool().cpu().numpy()
-    assert (k != want_k).mean() <= 1e-3
+    amb = R.region_sdf_ambiguity(lc, R.transform(xyz[Rn:n_surface], pose))
+    nm_ = torch.zeros(Rn * n_all, dtype=torch.bool)
+    nm_[Rn:n_surface] = amb["any"]
+    named = R._ray_major(nm_, n_all).numpy()
+    assert not ((k != want_k) & ~named).any() and (k != want_k).mean() <= 1e-3   # masks differ only where the oracle names the sample
     both = k & want_k
-    err = np.abs(label.cpu().numpy() - want_l)[both]
-    assert (err > 1e-4).mean() <= 2e-3, (err > 1e-4).sum()
-    assert np.median(err) <= 2e-6
+    err = np.abs(label.cpu().numpy() - want_l)
+    assert err[both & ~named].max() <= 1e-4, (int((err[both & ~named] > 1e-4).sum()), float(err[both & ~named].max()))
+    assert named.mean() <= 1e-2 and np.median(err[both]) <= 2e-6
     assert (~k).sum() > 0 and k.sum() > 0
 
 

@@ -84,7 +84,7 @@ def test_multi_frame_mapping_tracks_the_oracle(layer_norm):
             noise |= (ga < 1e-10) & (ga.max(dim=1, keepdim=True).values > 0)
         err = (nm.local_geo_features.detach().cpu() - recs[-1]["theta"]).abs()
         assert float(err[~noise].max()) <= 1e-4, fid
-        assert float(err.max()) <= cfg.lr * iters * 1.01 and int((err > 1e-4).sum()) <= 8, (fid, int((err > 1e-4).sum()))
+        assert float(err.max()) <= cfg.lr * iters * 1.01, (fid, float(err.max()))  # (entries the oracle's mask names: bounded by lr * iters)
         for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
             assert float((t.detach().cpu() - o).abs().max()) <= 1e-4
         assert float((nm.local_point_certainties.cpu() - recs[-1]["certainties"]).abs().max()) <= 2e-3
@@ -122,15 +122,18 @@ def test_subt_sequence_harness_first_frames_vs_oracle(freeze_after):
             # eight sums cancel exactly in one summation order only -- and those hold nothing but rounding residue
             assert r["dgrad_theta_rel"] <= 1e-4, (c["frame"], t, r)
             # rows gathered by a query whose decoder pre-activation sits on the ReLU kink in the oracle (|pre| < 4e-6): two
-            # correct fp32 evaluations may gate that unit differently and the rows' gradients jump by one hidden unit's
-            # contribution of one query.  Few rows (different ones every iteration), bounded, reported
-            # (their number depends on the state: a hidden unit whose bias sits near zero puts every query that sees only
-            # zero-feature rows on the list -- 1 898 of 61 k rows were seen once; the list must stay a small minority)
-            assert r["kink_rows"] <= max(256, r["rows"] // 10) and r["dgrad_theta_rel_kink_rows"] <= 5e-3, (c["frame"], t, r)
+            # correct fp32 evaluations may gate that unit differently and the rows' gradients move by one hidden unit's
+            # contribution of one query.  The oracle names those rows AND bounds each one's movement
+            # (oracle.cpu_ref.relu_ambiguous_rows, `ambiguous_row_slack`; the bound itself is checked oracle-vs-oracle with forced
+            # gates in tests/test_oracle_golden.py): every row -- listed or not -- must be within the strict bar + 1.25 x its own
+            # bound (0 for rows not listed).  No allowance by count: a defect on any row the bound does not explain fails here.
+            assert r["dgrad_theta_rel_beyond_slack"] <= 1e-4, (c["frame"], t, r)
+            assert r["kink_rows"] <= 6 * r["kink_queries"], (c["frame"], t, r)   # (a query gathers at most K = 6 rows)
             assert r.get("dgrad_decoder_rel", 0.0) <= 1e-4, (c["frame"], t, r)
             # (the COUNT of such rows moves with the state -- 0 to 6 of ~60 k rows were seen over boxes and summation orders of
             # the decoder's column sums --; what gates is that they hold nothing but residue: <= 1e-6 of the largest entry)
-            assert r["rows_nonzero_only_in_hip"] <= 16 and r["rows_nonzero_only_in_oracle"] <= 16 and r["residue_rel"] <= 1e-6, (c["frame"], t, r)
+            # rows no query point gathers (the oracle's list of gathered rows) are exactly zero, no exception
+            assert r["residue_rel"] <= 1e-6 and r["ungathered_rows_nonzero"] == 0, (c["frame"], t, r)
         if "max_dtheta" in c:
             # free-running parameters after the call: Adam with eps = 1e-15 moves an entry whose gradient is cancellation
             # residue by up to lr * iters differently in ANY two correct summation orders, so only that hard bound gates;
@@ -215,7 +218,7 @@ def test_large_local_map_tracks_the_oracle(layer_norm):
         ga = r["grad_theta"].abs()
         noise |= (ga < 1e-10) & (ga.max(dim=1, keepdim=True).values > 0)
     err = (nm.local_geo_features.detach().cpu() - recs[-1]["theta"]).abs()
-    assert float(err[~noise].max()) <= 1e-4 and int((err > 1e-4).sum()) <= 8
+    assert float(err[~noise].max()) <= 1e-4 and float(err.max()) <= cfg.lr * iters * 1.01  # (only entries the oracle's mask names may differ)
     for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
         assert float((t.detach().cpu() - o).abs().max()) <= 1e-4
     assert float((nm.local_point_certainties.cpu() - recs[-1]["certainties"]).abs().max()) <= 2e-3
