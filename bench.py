@@ -382,18 +382,47 @@ def main():
         mp.mapping(prof_steps)  # every rank takes part (the loop contains collectives when world > 1)
     if rank == 0:
         dom = max(kernels, key=lambda k: k["avg_us"])
-        traffic = None  # HBM bytes per launch from the committed PMC passes (same workload and kernel only)
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")))
-            wk = tj["workload"]
-            if wk["bs_per_gpu"] == bs_local and wk["decimation"] == decim and dom["kernel"] in tj:
-                traffic = tj[dom["kernel"]]["traffic_bytes"]
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, second, stamp = None, None, None  # from the committed PMC passes (same workload and kernel only)
+        for fn in ("r05_hbm_traffic.json", "r04_hbm_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            except (OSError, ValueError):
+                continue
+            stamp = dict(tj.get("source", {}), file="profiles/" + fn)
+            wk = tj.get("workload", {})
+            ent = tj.get(dom["kernel"]) if (wk.get("bs_per_gpu") == bs_local and wk.get("decimation") == decim) else None
+            if ent is None and bs_local == 65536:
+                ent = tj.get("cfg3", {}).get(dom["kernel"])
+            if ent:
+                traffic = ent.get("traffic_bytes")
+                iss, res = ent.get("issue"), ent.get("resources")
+                if iss and iss.get("valu_port_cycles"):
+                    # the roof that binds at these sizes is not HBM: VALU / matrix-port occupancy of the launch and the waves a
+                    # SIMD can keep resident (MI355X_MICROARCH.md: wave64 VALU = 2 cycles on a SIMD-32, fp32 16x16x4 MFMA 32
+                    # cycles per SIMD; 256 CUs x 4 SIMDs, 2.4 GHz)
+                    simds, clock = 1024, 2.4e9
+                    frac = iss["valu_port_cycles"] / (simds * clock * dom["avg_us"] * 1e-6)
+                    wait = (iss["wait_any"] / iss["wave_cycles"]) if iss.get("wave_cycles") else None
+                    second = {"issue_frac": round(frac, 4), "valu_port_cycles_per_launch": iss["valu_port_cycles"],
+                              "valu_insts": iss["valu_insts"], "mfma_busy_cycles": iss["mfma_busy_cycles"], "salu_insts": iss.get("salu_insts"),
+                              "lds_insts": iss.get("lds_insts"), "vmem_insts": iss.get("vmem_insts"), "waves": iss.get("waves"),
+                              "wait_any_over_wave_cycles": wait and round(wait, 3),
+                              "occupancy_waves_per_simd": res and res.get("occupancy_waves_per_simd"), "resources": res,
+                              "rule": "issue_frac = (2 x (VALU - MFMA instructions) + MFMA busy cycles) / (1024 SIMDs x 2.4 GHz x the "
+                                      "launch duration measured in THIS run); instruction counts from the offline PMC pass"}
+            break
         step_bytes = sum(k["algorithmic_bytes"] for k in kernels)
         roof = {
             "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dom["frac_of_hbm_peak"], "traffic": traffic,
+            # what actually binds the dominant launch: the nominal HBM figures above stay as the contract's
+            # roofline; `binds` / `issue` say which roof the numbers point at
+            "binds": (None if second is None else
+                      ("latency: %s waves per SIMD resident (register / LDS limited), VALU + matrix port busy %.0f %% of the launch, "
+                       "waves parked %.0f %% of their cycles" % (second["occupancy_waves_per_simd"], 100 * second["issue_frac"],
+                                                                 100 * (second["wait_any_over_wave_cycles"] or 0.0)))
+                      if second["issue_frac"] < 0.6 else "VALU / matrix issue"),
+            "issue": second, "counters_from": stamp,
             "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "bytes_rule": dom["bytes_rule"],
             "avg_launch_us": dom["avg_us"], "kernels": kernels, "profiled_steps": n_prof,
             "step_bytes": step_bytes, "step_frac_of_peak": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,

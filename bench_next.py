@@ -180,19 +180,45 @@ def main():
     rot_d, pos_d = rot.to(dev), sensor.to(dev)  # the filter's state as device tensors (utils/error_state_iekf.py:176-186)
     t1c = timed_device(lambda: tracking._launch(nm, dec, cfg, rot_d, pos_d, pc_imu, False, True), 100, warm=10)
     t1d = timed_device(lambda: tracking._launch(nm, dec, cfg, rot_d, pos_d, pc_imu, True, False), 100, warm=10)
+    bound = tracking.bind(nm, dec, cfg, pc_imu)   # what the cached binding holds: one argument block per scan
+    t1e = timed(lambda: bound.launch(rot, sensor, False, True), 200, warm=50)
     S, b, n_valid = tracking.normal_equations(nm, dec, cfg, rot, sensor, pc_imu)
+
+    def full_ne():
+        tracking.normal_equations(nm, dec, cfg, rot, sensor, pc_imu, host=True)
+    for _ in range(20):
+        full_ne()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        full_ne()
+    t1f = (time.perf_counter() - t0) / 200
+    def time_h_model(fused):  # the drop-in call the reference's update_iterated makes (host-synchronous: its outputs are sized by data)
+        tracking._FUSED_ROWS = fused
+        for _ in range(10):
+            tracking.h_model(nm, dec, cfg, rot, sensor, pc_imu)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            tracking.h_model(nm, dec, cfg, rot, sensor, pc_imu)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 100
+    t1h_torch, t1h = time_h_model(False), time_h_model(True)
     alg1 = n1 * (12.0 + BYTES_SEARCH + BYTES_FEAT + 4.0)
     line1 = {
         "row": "N1", "metric": "tracking measurement-model points/sec (IEKFOM.h_model, fused normal equations)",
         "value": n1 / t1a, "unit": "points/s", "n_gpus": 1, "us_per_call_normal_equations": 1e6 * t1a,
+        "us_h_model_call": 1e6 * t1h, "us_h_model_call_torch_glue": 1e6 * t1h_torch,
+        "us_per_call_bound_object": 1e6 * t1e, "us_normal_equations_round_trip_host_result": 1e6 * t1f,
         "us_per_call_per_point_outputs": 1e6 * t1b, "us_per_call_device": 1e6 * t1c, "us_per_call_device_per_point_outputs": 1e6 * t1d, "dtype": "f32 (f64 reduction)", "data": "synthetic",
         "config": {"workload": "box-room map of bench.py, local map view, one IEKF iteration", "points": n1,
                    "valid_points": n_valid},
         "roofline": {"bound": "hbm", "kernel": "k_track_model", "achieved": alg1 / t1a / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": alg1 / t1a / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("k_track_model", args.track_points == 8192),
-                     "note": "value / frac: wall clock per Python call (view + ctypes + a 28-double fill + the launch: host-bound); "
-                             "us_per_call_device: the launches back to back on the device, pose read from device tensors "
-                             "(clid_track_model_dev; incl. the two 12-float conversions and the fill)"},
+                     "note": "value / frac: wall clock per Python call through the cached binding (key check + pose + one ctypes call: "
+                             "host-bound; the launch clears the next call's reduction buffer itself); us_per_call_bound_object: the "
+                             "same without the cache lookup; us_normal_equations_round_trip_host_result: launch + one-block finish "
+                             "launch + poll of the pinned result block, per call, host-synchronous; us_per_call_device: the launches "
+                             "back to back on the device, pose read from device tensors"},
     }
 
     # ---- N3: dense inference over points scattered through the mapped volume

@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libclid_native.so")
+# (CLID_NATIVE_LIB: a variant build of the same sources, `python clid-slam_amd/build.py --variant NAME -D...` -- A/B of compile-time switches)
+LIB_PATH = os.environ.get("CLID_NATIVE_LIB") or os.path.join(_HERE, "lib", "libclid_native.so")
 
 F, D, H, K = 8, 11, 64, 6
 MLP_PARAMS = H * D + H + H + 1  # 833
@@ -59,6 +60,16 @@ class TrainArgs(C.Structure):
         ("sched", _vp), ("side_group", _i32), ("side_blocks", _i32),
         # config.ekional_add_to: 0 all / 1 surface / 2 freespace, |label| threshold, 1 / subset size per iteration (device floats)
         ("eik_mask", _i32), ("eik_mask_range", _f32), ("eik_inv_n", _vp),
+    ]
+
+
+class TrackCall(C.Structure):
+    """clid_track_call: what stays fixed over the iterations of the measurement model on one scan."""
+    _fields_ = [
+        ("mv", MapView),
+        ("W1", _vp), ("b1", _vp), ("W2", _vp), ("b2", _vp),
+        ("sdf_scale", _f32), ("min_nn", _i32), ("min_grad_norm", _f32), ("max_grad_norm", _f32), ("max_sdf_std", _f32), ("N", _i32),
+        ("pc_imu", _vp), ("sdf_out", _vp), ("grad_out", _vp), ("pmap_out", _vp), ("valid_out", _vp),
     ]
 
 
@@ -183,6 +194,11 @@ _SIGS = {
     "clid_train_search_tasks": (_i32, [_i32, _i64, _i32, _i32]),
     "clid_train_search": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), _i32, _vp, _i64, _vp, _vp]),
     "clid_train_decode": (C.c_int, [C.POINTER(MapView), C.POINTER(TrainArgs), _vp, _vp]),
+    "clid_track_model_call": (C.c_int, [C.POINTER(TrackCall), _vp, _vp, _i32, _vp, _vp, _vp, C.c_double, _vp]),
+    "clid_track_valid_count": (C.c_int, [_vp, _i32, _vp, _vp, C.c_double, _vp]),
+    "clid_track_rows": (C.c_int, [C.POINTER(TrackCall), _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clid_pinned_alloc": (C.c_int, [_i64, C.POINTER(_vp), C.POINTER(_vp)]),
+    "clid_pinned_free": (None, [_vp]),
     "clid_sched_create": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
     "clid_sched_destroy": (None, [_vp]),
     "clid_debug_cu_census": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),

@@ -41,6 +41,25 @@ def _stamp() -> str:
     return h.hexdigest()
 
 
+def build_variant(name: str, extra_flags) -> str:
+    """Developer aid (A/B of compile-time switches): the library built with `extra_flags` as lib/libclid_native_<name>.so; run
+    with CLID_NATIVE_LIB=<that path> (clid-slam_amd/_lib.py)."""
+    objdir = os.path.join(LIBDIR, "obj_" + name)
+    os.makedirs(objdir, exist_ok=True)
+    out = os.path.join(LIBDIR, f"libclid_native_{name}.so")
+    hipcc = _hipcc()
+
+    def one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        subprocess.run([hipcc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj], check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(one, SOURCES))
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", out], check=True)
+    return out
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     stamp_file = LIB + ".stamp"
@@ -76,4 +95,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--variant" in sys.argv:  # python build.py --variant NAME -DFLAG=0 ...
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        build(force="--force" in sys.argv)

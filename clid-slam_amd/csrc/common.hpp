@@ -167,8 +167,13 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// candidates of the searches: local id (< 2^22) | probe / hit index (< 384 = kMaxProbes) << 22 -- equal distances resolve by index
+// candidates of the searches: point id | probe / hit index << shift -- equal distances resolve by index.  The training searches
+// (local window) use the constant: ids < 2^22, indices < 384 = kMaxProbes.  The inference searches, which also walk GLOBAL tables
+// (dense meshing queries), take the shift from the view: neighbourhoods of at most 128 cells (num_nei_cells <= 2: every shipped
+// config) leave 24 bits for the id -- 16.7 M points per table; larger stencils keep 22.
 constexpr int kProbeShift = 22;
+constexpr int kProbeShiftWide = 24;
+__host__ __device__ inline int probe_shift_of(int P) { return P <= 128 ? kProbeShiftWide : kProbeShift; }
 
 // ---- cell directory of the window (csrc/celldir.hip), block-staged part ---------------------------------------------------
 constexpr int kCdRows = 32;  // staged stencil rows: (2 nc + 1)^2 <= 25 for nc <= 2, the rest empty
@@ -230,7 +235,7 @@ __device__ __forceinline__ void stage_delta(SearchLds& s, const clid_map_view& m
 // K winners of the group's sorted per-lane lists, replicated over the group.  Candidates carry their probe / hit index above the
 // id (kProbeShift); of several lanes holding the same distance the lowest index wins: the order of a STABLE sort of the
 // reference's dist2 row (np.py:607-609, whose torch.sort leaves the order of equal distances undefined).
-__device__ __forceinline__ void select_topk16(Cand& c, int lane16, int gbase, TopK& out) {
+__device__ __forceinline__ void select_topk16(Cand& c, int lane16, int gbase, TopK& out, int sh) {
 #pragma unroll
   for (int k = 0; k < CLID_K; ++k) {
     const float head = c.d[0];
@@ -240,7 +245,7 @@ __device__ __forceinline__ void select_topk16(Cand& c, int lane16, int gbase, To
     const unsigned gb = (unsigned)(b >> gbase) & 0xFFFFu;
     int owner = gb ? (__ffs(gb) - 1) : 0;
     if (__any((gb & (gb - 1u)) != 0u)) {  // rare: the same distance on several lanes
-      int key = mine ? (c.j[0] >> kProbeShift) : 0x7fffffff;
+      int key = mine ? (c.j[0] >> sh) : 0x7fffffff;
       int kmin = key;
       kmin = min(kmin, __builtin_amdgcn_update_dpp(0x7fffffff, kmin, 0x128, 0xF, 0xF, false));
       kmin = min(kmin, __builtin_amdgcn_update_dpp(0x7fffffff, kmin, 0x124, 0xF, 0xF, false));
@@ -252,7 +257,7 @@ __device__ __forceinline__ void select_topk16(Cand& c, int lane16, int gbase, To
     }
     const int wj = __shfl(c.j[0], gbase + owner, 64);
     out.d2[k] = gb ? m : 9e3f;  // np.py:606
-    out.j[k] = gb ? (wj & ((1 << kProbeShift) - 1)) : -1;
+    out.j[k] = gb ? (wj & ((1 << sh) - 1)) : -1;
     if (gb && lane16 == owner) c.pop();
   }
 }
@@ -265,6 +270,7 @@ __device__ __forceinline__ void search_topk_probe(const clid_map_view& mv, const
   const int4* __restrict__ tab = reinterpret_cast<const int4*>(mv.tab);
   const int B = mv.buffer_size;
   const int r0 = base_slot(x, y, z, mv.resolution, B);
+  const int sh = probe_shift_of(mv.P);
   Cand c;
   c.init();
   int nvalid = 0;
@@ -305,14 +311,14 @@ __device__ __forceinline__ void search_topk_probe(const clid_map_view& mv, const
       const float ax = fsub(pp[t].x, x), ay = fsub(pp[t].y, y), az = fsub(pp[t].z, z);
       const float d2 = fadd(fadd(fmul(ax, ax), fmul(ay, ay)), fmul(az, az));
       if (cell[t] >= 0 && !(d2 > mv.max_valid_dist2)) {  // np.py:1016-1020
-        c.insert(d2, __float_as_int(pp[t].w) | ((o0 + t * CLID_G + lane16) << kProbeShift));
+        c.insert(d2, __float_as_int(pp[t].w) | ((o0 + t * CLID_G + lane16) << sh));
         ++nvalid;
       }
     }
   }
   out.nn = group_sum_i(nvalid);
   CLID_STAMP(tm + 3);
-  select_topk16(c, lane16, gbase, out);
+  select_topk16(c, lane16, gbase, out, sh);
 }
 
 // The same over the window's cell directory (csrc/celldir.hip; the 8-lane form with the commentary: csrc/train.hip
@@ -360,6 +366,7 @@ __device__ __forceinline__ void search_topk_cells(const clid_map_view& mv, const
   int hmax = max(H, __shfl_xor(H, 16, 64));
   hmax = max(hmax, __shfl_xor(hmax, 32, 64));
   const int trips = (__builtin_amdgcn_readfirstlane(hmax) + 31) >> 5;  // two hits per lane and trip
+  const int psh = probe_shift_of(mv.P);
   Cand c;
   c.init();
   int nvalid = 0;
@@ -377,13 +384,13 @@ __device__ __forceinline__ void search_topk_cells(const clid_map_view& mv, const
       const float ax = fsub(pp[t].x, x), ay = fsub(pp[t].y, y), az = fsub(pp[t].z, z);
       const float d2 = fadd(fadd(fmul(ax, ax), fmul(ay, ay)), fmul(az, az));
       if (g[t] < H && !(d2 > mv.max_valid_dist2)) {  // np.py:1016-1020
-        c.insert(d2, __float_as_int(pp[t].w) | (g[t] << kProbeShift));
+        c.insert(d2, __float_as_int(pp[t].w) | (g[t] << psh));
         ++nvalid;
       }
     }
   }
   out.nn = group_sum_i(nvalid);
-  select_topk16(c, lane16, gbase, out);
+  select_topk16(c, lane16, gbase, out, psh);
   wave_lds_fence();  // (the list is free again)
 }
 

@@ -441,8 +441,12 @@ __global__ void __launch_bounds__(kVbThreads) k_vox_bucket_big(const unsigned* _
     const unsigned long long top = sd * (1ULL + sd + sd * sd);
     int bits = 1;
     while (bits < 63 && (top >> bits)) ++bits;
-    count_out[0] = (long long)st->count;
-    count_out[1] = bits <= 64 - kVbPosBits - 1 ? 0 : 1;
+    // ids too wide for the packed sort values: the index list is unordered.  The consumers size their work by count_out[0] on the
+    // device (clid_map_insert / clid_cloud_update: n_dev), so a failed pass publishes ZERO voxels -- nothing is inserted from an
+    // unordered list -- and the flag; the host sees it at its next read-back and repeats the step through the library sort
+    const bool bad = !(bits <= 64 - kVbPosBits - 1);
+    count_out[0] = bad ? 0LL : (long long)st->count;
+    count_out[1] = bad ? 1 : 0;
   }
   const int c = (int)bucket_cnt[b * kVbCntStride];
   if (c <= kVbCap) return;  // (block-uniform)

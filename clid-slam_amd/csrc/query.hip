@@ -2,6 +2,8 @@
 // NeuralPoints.query_feature and its autograd backward; model/neural_points.py:553-769, 971-1030)
 // and the fused inference kernel query -> Decoder.sdf -> analytic d sdf/d x
 // (utils/tools.py:298-311 as used by utils/error_state_iekf.py:209-227).
+#include <string.h>
+
 #include "common.hpp"
 
 namespace clid {
@@ -490,7 +492,10 @@ __global__ void __launch_bounds__(CLID_BLOCK)
 k_track_model(clid_map_view mv, const float* W1, const float* b1, const float* W2, const float* b2, TrackParams tp,
               const float* __restrict__ pc_imu, int N, float* __restrict__ sdf_out, float* __restrict__ grad_out,
               float* __restrict__ pmap_out, int* __restrict__ valid_out, double* __restrict__ normal_eq /* 28 */,
-              const float* __restrict__ rot_dev, const float* __restrict__ pos_dev) {
+              const float* __restrict__ rot_dev, const float* __restrict__ pos_dev, double* __restrict__ zero_next = nullptr) {
+  // (clid_track_model_call) block 0 clears the NEXT call's reduction buffer: 16 x 32 doubles, two per thread
+  if (zero_next && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < CLID_TRACK_COPIES * 32; i += CLID_BLOCK) zero_next[i] = 0.0;
   __shared__ MlpLds mlp;
   __shared__ SearchLds dl;
   __shared__ double red[CLID_QPB][28];
@@ -550,6 +555,104 @@ k_track_model(clid_map_view mv, const float* W1, const float* b1, const float* W
   }
 }
 
+// one block behind k_track_model: the 16 line-separated copies added up in a fixed order, the 28 sums written to pinned
+// host-mapped memory, then -- behind a system-scope fence -- the epoch the host polls for
+__global__ void __launch_bounds__(64) k_track_finish(const double* __restrict__ normal_eq, double* __restrict__ result, double epoch) {
+  if (threadIdx.x < 28) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < CLID_TRACK_COPIES; ++c) s += normal_eq[c * 32 + threadIdx.x];
+    result[threadIdx.x] = s;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&result[31], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// ---- IEKFOM.h_model's outputs from the per-point outputs (clid_track_valid_count / clid_track_rows) -----------------------
+__global__ void __launch_bounds__(256) k_track_count(const int* __restrict__ valid, int N, int* __restrict__ block_count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool v = i < N && valid[i] != 0;
+  const unsigned long long b = __ballot(v);
+  __shared__ int wc[4];
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) block_count[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+// one block: block counts -> exclusive prefix in place (+ total behind it), total and epoch to the pinned block
+__global__ void __launch_bounds__(1024) k_track_scan(int* __restrict__ block_count, int nb, double* __restrict__ result, double epoch) {
+  __shared__ int part[1024];
+  const int per = (nb + 1023) / 1024, b0 = threadIdx.x * per;
+  int s = 0;
+  for (int i = 0; i < per; ++i)
+    if (b0 + i < nb) s += block_count[b0 + i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan of the per-thread sums
+    const int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - s;
+  for (int i = 0; i < per; ++i)
+    if (b0 + i < nb) {
+      const int c = block_count[b0 + i];
+      block_count[b0 + i] = run;
+      run += c;
+    }
+  if (threadIdx.x == 1023) {
+    block_count[nb] = part[1023];
+    result[29] = (double)part[1023];
+    __threadfence_system();
+    __hip_atomic_store(&result[31], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+__global__ void __launch_bounds__(256)
+k_track_rows(const float* __restrict__ pc_imu, const float* __restrict__ sdf, const float* __restrict__ grad, const float* __restrict__ pmap,
+             const int* __restrict__ valid, int N, TrackParams tp, const float* __restrict__ rot_dev, const int* __restrict__ block_prefix,
+             double* __restrict__ z_out, double* __restrict__ H_out, float* __restrict__ vp_out, double* __restrict__ rinv_out) {
+  if (rot_dev) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tp.R[i] = rot_dev[i];
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool v = i < N && valid[i] != 0;
+  const unsigned long long b = __ballot(v);
+  __shared__ int wc[4];
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  int base = block_prefix[blockIdx.x];
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wc[w];
+  if (!v) return;
+  const long long r = base + __popcll(b & ((1ull << (threadIdx.x & 63)) - 1ull));
+  const float gx = grad[i * 3 + 0], gy = grad[i * 3 + 1], gz = grad[i * 3 + 2];
+  const float ix = pc_imu[i * 3 + 0], iy = pc_imu[i * 3 + 1], iz = pc_imu[i * 3 + 2];
+  // q = R^T g, h = [p_imu x q | g] in fp32 (utils/error_state_iekf.py:246-251 builds them with fp32 bmm's), stored as float64
+  const float qx = tp.R[0] * gx + tp.R[3] * gy + tp.R[6] * gz;
+  const float qy = tp.R[1] * gx + tp.R[4] * gy + tp.R[7] * gz;
+  const float qz = tp.R[2] * gx + tp.R[5] * gy + tp.R[8] * gz;
+  double* H = H_out + r * 18;
+  H[0] = (double)(iy * qz - iz * qy);
+  H[1] = (double)(iz * qx - ix * qz);
+  H[2] = (double)(ix * qy - iy * qx);
+  H[3] = (double)gx;
+  H[4] = (double)gy;
+  H[5] = (double)gz;
+#pragma unroll
+  for (int k = 6; k < 18; ++k) H[k] = 0.0;
+  const double z = (double)sdf[i];
+  const float gn = sqrtf(gx * gx + gy * gy + gz * gz);
+  const double ga = (double)(gn - 1.0f);   // (grad_norm - 1.0 in fp32, then widened: :256)
+  z_out[r] = z;
+  rinv_out[r] = 1.0 / (1.0 + ga * ga) * (0.4 / (0.4 + z * z)) * 1000.0;
+  vp_out[r * 3 + 0] = pmap[i * 3 + 0];
+  vp_out[r * 3 + 1] = pmap[i * 3 + 1];
+  vp_out[r * 3 + 2] = pmap[i * 3 + 2];
+}
+
 }  // namespace clid
 
 static int check_view(const clid_map_view* mv, const char* who) {
@@ -557,6 +660,11 @@ static int check_view(const clid_map_view* mv, const char* who) {
       mv->log2cap < 4 || mv->buffer_size <= 0) {
     clid_set_error("%s: incomplete map view", who);
     return CLID_E_ARG;
+  }
+  if (mv->M >= (1 << clid::probe_shift_of(mv->P))) {
+    clid_set_error("%s: a table of %d points exceeds the 2^%d the searches' candidates address with %d-cell neighbourhoods", who, mv->M,
+                   clid::probe_shift_of(mv->P), mv->P);
+    return CLID_E_SHAPE;
   }
   return CLID_OK;
 }
@@ -677,6 +785,91 @@ extern "C" int clid_track_model_dev(const clid_map_view* mv, const float* W1, co
                                     int32_t* valid_out, double* normal_eq, void* stream) {
   return track_model_launch(mv, W1, b1, W2, b2, sdf_scale, nullptr, nullptr, rot_dev, pos_dev, min_nn, min_grad_norm, max_grad_norm,
                             max_sdf_std, pc_imu, N, sdf_out, grad_out, pmap_out, valid_out, normal_eq, stream);
+}
+
+extern "C" int clid_track_model_call(const clid_track_call* c, const float* rot, const float* pos, int32_t pose_on_device,
+                                     double* normal_eq, double* zero_next, double* result, double epoch, void* stream) {
+  if (!c || !rot || !pos || !c->pc_imu || c->N < 0 || (result && !normal_eq)) {
+    clid_set_error("clid_track_model_call: bad argument");
+    return CLID_E_ARG;
+  }
+  if (int e = check_view(&c->mv, "clid_track_model_call")) return e;
+  if (c->N == 0) return CLID_OK;
+  clid::TrackParams tp;
+  for (int i = 0; i < 9; ++i) tp.R[i] = pose_on_device ? 0.f : rot[i];
+  for (int i = 0; i < 3; ++i) tp.t[i] = pose_on_device ? 0.f : pos[i];
+  tp.scale = c->sdf_scale;
+  tp.min_grad_norm = c->min_grad_norm;
+  tp.max_grad_norm = c->max_grad_norm;
+  tp.min_nn = c->min_nn;
+  tp.max_sdf_std = c->max_sdf_std;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(clid::k_track_model, dim3((c->N + CLID_QPB - 1) / CLID_QPB), dim3(CLID_BLOCK), 0, s, c->mv, c->W1, c->b1, c->W2,
+                     c->b2, tp, c->pc_imu, c->N, c->sdf_out, c->grad_out, c->pmap_out, c->valid_out, normal_eq,
+                     pose_on_device ? rot : nullptr, pose_on_device ? pos : nullptr, zero_next);
+  if (result) hipLaunchKernelGGL(clid::k_track_finish, dim3(1), dim3(64), 0, s, normal_eq, result, epoch);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+extern "C" int clid_track_valid_count(const int32_t* valid, int32_t N, int32_t* block_prefix, double* result, double epoch,
+                                      void* stream) {
+  if (!valid || N <= 0 || !block_prefix || !result || N > (1 << 24)) {
+    clid_set_error("clid_track_valid_count: bad argument");
+    return CLID_E_ARG;
+  }
+  const int nb = (N + 255) / 256;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(clid::k_track_count, dim3(nb), dim3(256), 0, s, valid, N, block_prefix);
+  hipLaunchKernelGGL(clid::k_track_scan, dim3(1), dim3(1024), 0, s, block_prefix, nb, result, epoch);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+extern "C" int clid_track_rows(const clid_track_call* c, const float* rot, const float* pos, int32_t pose_on_device,
+                               const int32_t* block_prefix, double* z_out, double* H_out, float* valid_points_out, double* r_inv_out,
+                               void* stream) {
+  if (!c || !rot || !c->pc_imu || !c->sdf_out || !c->grad_out || !c->pmap_out || !c->valid_out || c->N <= 0 || !block_prefix ||
+      !z_out || !H_out || !valid_points_out || !r_inv_out) {
+    clid_set_error("clid_track_rows: bad argument (needs the per-point outputs of the bound call)");
+    return CLID_E_ARG;
+  }
+  (void)pos;
+  clid::TrackParams tp;
+  for (int i = 0; i < 9; ++i) tp.R[i] = pose_on_device ? 0.f : rot[i];
+  for (int i = 0; i < 3; ++i) tp.t[i] = 0.f;
+  tp.scale = c->sdf_scale;
+  tp.min_grad_norm = c->min_grad_norm;
+  tp.max_grad_norm = c->max_grad_norm;
+  tp.min_nn = c->min_nn;
+  tp.max_sdf_std = c->max_sdf_std;
+  hipLaunchKernelGGL(clid::k_track_rows, dim3((c->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->pc_imu, c->sdf_out, c->grad_out,
+                     c->pmap_out, c->valid_out, c->N, tp, pose_on_device ? rot : nullptr, block_prefix, z_out, H_out, valid_points_out,
+                     r_inv_out);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
+extern "C" int clid_pinned_alloc(int64_t bytes, void** host_out, void** dev_out) {
+  if (bytes <= 0 || !host_out || !dev_out) {
+    clid_set_error("clid_pinned_alloc: bad argument");
+    return CLID_E_ARG;
+  }
+  void* h = nullptr;
+  void* d = nullptr;
+  if (hipHostMalloc(&h, (size_t)bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+    clid_set_error("clid_pinned_alloc: %s", hipGetErrorString(hipGetLastError()));
+    if (h) (void)hipHostFree(h);
+    return CLID_E_HIP;
+  }
+  memset(h, 0, (size_t)bytes);
+  *host_out = h;
+  *dev_out = d;
+  return CLID_OK;
+}
+extern "C" void clid_pinned_free(void* host_ptr) {
+  if (host_ptr) (void)hipHostFree(host_ptr);
 }
 
 bool clid_sdf_query_tile_ok(const clid_map_view* mv);

@@ -32,6 +32,8 @@ __device__ __forceinline__ float qt_xsum32(float v) {  // v[lane] + v[lane ^ 32]
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// PSH: the id's width in the search's candidates (search8.hpp): 22 bits, or 24 for tables beyond 2^22 points with <= 128-cell stencils
+template <int PSH>
 __global__ void __launch_bounds__(kQtBlock, CLID_QT_WAVES)
 k_sdf_query_tile(clid_map_view mv, const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
                  const float* __restrict__ b2p, float sc, const float* __restrict__ x, int N, float* __restrict__ sdf_out,
@@ -88,9 +90,9 @@ k_sdf_query_tile(clid_map_view mv, const float* __restrict__ W1, const float* __
                           (unsigned)rz0 < (unsigned)(cl.nz - 2 * nc);
       int nvalid = 0;
       if (cl.valid && !__any(!inside))
-        search_cells<true>(mv, cl, lists + (wave * 8 + slot8) * kCdHits, px, py, pz, rx, ry, rz0, lane8, lane & 56, win, false, &nvalid);
+        search_cells<true, PSH>(mv, cl, lists + (wave * 8 + slot8) * kCdHits, px, py, pz, rx, ry, rz0, lane8, lane & 56, win, false, &nvalid);
       else
-        search8<false, CLID_K, true>(mv, dl, px, py, pz, lane8, lane & 56, win, nullptr, &nvalid);
+        search8<false, CLID_K, true, PSH>(mv, dl, px, py, pz, lane8, lane & 56, win, nullptr, &nvalid);
       nvalid = group8_sum_i(nvalid);
       // (d2, id) -> (IDW weight, id) + blended offset (np.py:653-706), lane8 = k
       wave_lds_fence();
@@ -172,7 +174,9 @@ k_sdf_query_tile(clid_map_view mv, const float* __restrict__ W1, const float* __
 }  // namespace clid
 
 // launcher for clid_sdf_query (csrc/query.hip): the configurations this kernel covers
-bool clid_sdf_query_tile_ok(const clid_map_view* mv) { return mv->weighted_first != 0 && mv->P <= clid::kMaxProbes; }
+bool clid_sdf_query_tile_ok(const clid_map_view* mv) {
+  return mv->weighted_first != 0 && mv->P <= clid::kMaxProbes && mv->M < (1 << clid::probe_shift_of(mv->P));
+}
 
 static int qt_resident_blocks() {
   static thread_local int dev_cached = -1, cus_cached = 0;  // (a cache of a device attribute)
@@ -193,8 +197,12 @@ int clid_launch_sdf_query_tile(const clid_map_view* mv, const float* W1, const f
   int nb = (n_tiles + clid::kQtWaves - 1) / clid::kQtWaves;
   const int resident = qt_resident_blocks();
   if (nb > resident) nb = resident;
-  hipLaunchKernelGGL(clid::k_sdf_query_tile, dim3(nb), dim3(clid::kQtBlock), 0, s, *mv, W1, b1, W2, b2, sdf_scale, x, N, sdf_out,
-                     nn_out);
+  if (mv->M >= (1 << clid::kProbeShift))  // (only reached with <= 128-cell stencils: clid_sdf_query_tile_ok)
+    hipLaunchKernelGGL(clid::k_sdf_query_tile<clid::kProbeShiftWide>, dim3(nb), dim3(clid::kQtBlock), 0, s, *mv, W1, b1, W2, b2,
+                       sdf_scale, x, N, sdf_out, nn_out);
+  else
+    hipLaunchKernelGGL(clid::k_sdf_query_tile<clid::kProbeShift>, dim3(nb), dim3(clid::kQtBlock), 0, s, *mv, W1, b1, W2, b2, sdf_scale,
+                       x, N, sdf_out, nn_out);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

@@ -75,7 +75,9 @@ struct CandN {
 // The K winners of the group's sorted per-lane lists -> win[0..K), ascending distance.  Candidates carry their probe index
 // above their id (kProbeShift): when several lanes hold the same distance the lowest index wins -- a stable sort of the
 // reference's dist2 row (np.py:607-609).  Returns the distance of the K-th winner (inf when fewer were found).
-template <int DEPTH>
+// PSH (here and below): the id's width in a candidate -- kProbeShift for the training searches (local window), kProbeShiftWide for
+// inference over global tables (common.hpp)
+template <int DEPTH, int PSH = kProbeShift>
 __device__ __forceinline__ float select_packed(CandN<DEPTH>& c, int lane8, int gshift, float2* __restrict__ win) {
   float m = 0.f;
 #pragma unroll
@@ -87,14 +89,14 @@ __device__ __forceinline__ float select_packed(CandN<DEPTH>& c, int lane8, int g
     const unsigned gb = (unsigned)(b >> gshift) & 0xFFu;
     bool take = gb && lane8 == (int)(__ffs(gb) - 1);
     if (__any((gb & (gb - 1u)) != 0u)) {  // rare: several lanes hold the same distance
-      const int key = mine ? (c.j[0] >> kProbeShift) : 0x7fffffff;
+      const int key = mine ? (c.j[0] >> PSH) : 0x7fffffff;
       int kmin = min(key, __builtin_amdgcn_update_dpp(0x7fffffff, key, 0xB1, 0xF, 0xF, false));
       kmin = min(kmin, __builtin_amdgcn_update_dpp(0x7fffffff, kmin, 0x4E, 0xF, 0xF, false));
       kmin = min(kmin, __builtin_amdgcn_update_dpp(0x7fffffff, kmin, 0x141, 0xF, 0xF, false));
       take = mine && key == kmin;
     }
     if (take) {
-      win[k] = make_float2(m, __int_as_float(c.j[0] & ((1 << kProbeShift) - 1)));
+      win[k] = make_float2(m, __int_as_float(c.j[0] & ((1 << PSH) - 1)));
       c.pop();
     }
   }
@@ -105,7 +107,7 @@ __device__ __forceinline__ float select_packed(CandN<DEPTH>& c, int lane8, int g
 // list may have lost a winner (the caller then repeats with DEPTH = K).
 // `filt` (optional, LDS): bit per stored slot; a probe whose bit is clear cannot match and is not loaded
 // COUNT: *nvalid += this lane's probes that hit a point within max_valid_dist2 (np.py:600-602; the dense SDF query's mask)
-template <bool FILTER, int DEPTH, bool COUNT = false>
+template <bool FILTER, int DEPTH, bool COUNT = false, int PSH = kProbeShift>
 __device__ __forceinline__ bool search8(const clid_map_view& mv, const DeltaLds& dl, float x, float y, float z,
                                         int lane8, int gshift, float2* __restrict__ win,
                                         const unsigned* __restrict__ filt = nullptr, int* nvalid = nullptr) {
@@ -164,13 +166,13 @@ __device__ __forceinline__ bool search8(const clid_map_view& mv, const DeltaLds&
       const float ax = fsub(pp[t].x, x), ay = fsub(pp[t].y, y), az = fsub(pp[t].z, z);
       const float d2 = fadd(fadd(fmul(ax, ax), fmul(ay, ay)), fmul(az, az));
       if (cell[t] >= 0 && !(d2 > mv.max_valid_dist2)) {  // np.py:1016-1020
-        c.insert(d2, __float_as_int(pp[t].w) | ((o0 + 8 * t + lane8) << kProbeShift));
+        c.insert(d2, __float_as_int(pp[t].w) | ((o0 + 8 * t + lane8) << PSH));
         if constexpr (COUNT) ++*nvalid;
       }
     }
   }
   CLID_STAMP(2);
-  const float m = select_packed(c, lane8, gshift, win);
+  const float m = select_packed<DEPTH, PSH>(c, lane8, gshift, win);
   // m = distance of the 6th winner (inf when fewer were found): anything pushed out at or below it is suspect
   return DEPTH < CLID_K && c.dropped <= m && c.dropped < __builtin_inff();
 }
@@ -203,7 +205,7 @@ __device__ __forceinline__ int group8_scan_i(int v, int lane8) {
 // probes: the winners spread over the lanes), kCdBatch position loads in flight per lane and trip; candidates carry their hit
 // number above the id, ties resolve as in search8.  `trips` is the wave's maximum (uniform).  Returns search8's "repeat at full depth".
 constexpr int kCdBatch = 3;
-template <int DEPTH, bool COUNT = false>
+template <int DEPTH, bool COUNT = false, int PSH = kProbeShift>
 __device__ __forceinline__ bool consume_hits(const clid_map_view& mv, const int* __restrict__ list, int H, int trips, float x, float y,
                                              float z, int lane8, int gshift, float2* __restrict__ win, int* nvalid = nullptr) {
   const float4* __restrict__ cpos = reinterpret_cast<const float4*>(mv.cdir_pos);
@@ -223,17 +225,17 @@ __device__ __forceinline__ bool consume_hits(const clid_map_view& mv, const int*
       const float ax = fsub(pp[t].x, x), ay = fsub(pp[t].y, y), az = fsub(pp[t].z, z);
       const float d2 = fadd(fadd(fmul(ax, ax), fmul(ay, ay)), fmul(az, az));
       if (g[t] < H && !(d2 > mv.max_valid_dist2)) {  // np.py:1016-1020
-        c.insert(d2, __float_as_int(pp[t].w) | (g[t] << kProbeShift));
+        c.insert(d2, __float_as_int(pp[t].w) | (g[t] << PSH));
         if constexpr (COUNT) ++*nvalid;
       }
     }
   }
-  const float m = select_packed(c, lane8, gshift, win);
+  const float m = select_packed<DEPTH, PSH>(c, lane8, gshift, win);
   return DEPTH < CLID_K && c.dropped <= m && c.dropped < __builtin_inff();
 }
 // One query of the task: (rx, ry) = cell - origin, rz0 = cell_z - origin_z - nc (all in range: the caller checked).  `list`:
 // this query slot's kCdHits ints in LDS.
-template <bool COUNT = false>
+template <bool COUNT = false, int PSH = kProbeShift>
 __device__ __forceinline__ void search_cells(const clid_map_view& mv, const CellLds& cl, int* __restrict__ list, float x, float y,
                                              float z, int rx, int ry, int rz0, int lane8, int gshift, float2* __restrict__ win,
                                              bool full_depth, int* nvalid = nullptr) {
@@ -275,11 +277,11 @@ __device__ __forceinline__ void search_cells(const clid_map_view& mv, const Cell
   const int trips = (__builtin_amdgcn_readfirstlane(hmax) + 8 * kCdBatch - 1) / (8 * kCdBatch);
   if (lane8 < CLID_K) win[lane8] = make_float2(9e3f, __int_as_float(-1));  // np.py:606
   bool redo = full_depth;
-  if (!full_depth) redo = consume_hits<3, COUNT>(mv, list, H, trips, x, y, z, lane8, gshift, win, nvalid);
+  if (!full_depth) redo = consume_hits<3, COUNT, PSH>(mv, list, H, trips, x, y, z, lane8, gshift, win, nvalid);
   if (__any(redo)) {  // a 3-deep list may have pushed a winner out (or debug bit 2): once more at full depth, from the same list
     if (lane8 < CLID_K) win[lane8] = make_float2(9e3f, __int_as_float(-1));
-    if (full_depth) consume_hits<CLID_K, COUNT>(mv, list, H, trips, x, y, z, lane8, gshift, win, nvalid);
-    else consume_hits<CLID_K>(mv, list, H, trips, x, y, z, lane8, gshift, win);  // (counted by the first pass)
+    if (full_depth) consume_hits<CLID_K, COUNT, PSH>(mv, list, H, trips, x, y, z, lane8, gshift, win, nvalid);
+    else consume_hits<CLID_K, false, PSH>(mv, list, H, trips, x, y, z, lane8, gshift, win);  // (counted by the first pass)
   }
 }
 

@@ -32,6 +32,8 @@
 //            through LDS to put them on the K axis (skipped when the decoder is frozen).
 // PREC = 1 runs the three contractions on v_mfma_f32_16x16x32_bf16 (bf16 operands, fp32 accumulation,
 // BASELINE.json configs[2]); everything outside the MFMAs is unchanged fp32.
+#include <type_traits>
+
 #include "train_common.hpp"
 
 namespace clid {
@@ -42,6 +44,12 @@ namespace clid {
 #define CLID_TILE_WAVES_SMALL 4
 #endif
 constexpr int kTileWavesSmall = CLID_TILE_WAVES_SMALL, kTileWavesLarge = 2;
+#ifndef CLID_TILE_EARLY_REC
+#define CLID_TILE_EARLY_REC 0  // (A/B) the one-tile-per-wave kernels request their record before the weight staging
+#endif
+#ifndef CLID_TILE_BLK
+#define CLID_TILE_BLK 1  // block-level dW1 flush of the one-tile-per-wave launches (0: the per-wave form, A/B)
+#endif
 __host__ inline int tile_waves_for(int n_tiles) { return n_tiles > kTileLargeFrom ? kTileWavesLarge : kTileWavesSmall; }
 constexpr int kRecF4 = 48;       // float4 per search record (== kRecFloat4 of train.hip)
 constexpr int kDhStride = 84;    // floats per query row of the dh transposition buffer (conflict-free b128 stores)
@@ -67,6 +75,32 @@ struct alignas(16) TileLds {
   int rowid[kMaxRows];       // row number -> map row id
   int count;                 // (in-kernel numbering only) distinct rows of the tile
   int pad_[3];
+};
+// The <= 168-register instantiation (WPS == 3) keeps the decoder's MFMA operands in LDS instead of 48 registers per lane, which
+// costs 5.4 KB per block; its tile buffers give that back: the 16 x 16 staging rows of f live in the padding of dh's rows
+// (columns 64..79 of the 84-float rows), so a tile wave needs 11 920 bytes and a 4-wave block 47 680 + 5 392 = 53 072 (three per CU).
+struct alignas(16) TileLdsC {
+  union {
+    float dh[16 * kDhStride];  // [q][0..63] = dh, [q][64..79] = f (c = 0..15)
+    struct {
+      int hkey[kHash];
+      int hrow[kHash];
+    };
+  };
+  float wm[kMaxRows * 16];
+  int rowid[kMaxRows];
+  int count;
+  int pad_[3];
+};
+constexpr int kWStride = 20;                       // floats per hidden unit of the LDS weight table: W1[h][0..10] | b1[h] | 0 0 0 0 | pad
+constexpr int kWOffW2 = CLID_H * kWStride;         // then W2[64], then b2
+constexpr int kWFloats = kWOffW2 + CLID_H + 4;
+template <class TL> struct tile_f;                 // where the f staging rows live
+template <> struct tile_f<TileLds> {
+  static __device__ __forceinline__ float* at(TileLds& tl, int row) { return &tl.f[row * kFStride]; }
+};
+template <> struct tile_f<TileLdsC> {
+  static __device__ __forceinline__ float* at(TileLdsC& tl, int row) { return &tl.dh[row * kDhStride + 64]; }
 };
 // 13 200 bytes per wave: three 4-wave blocks (52 800 B) or six 2-wave blocks (26 400 B) fit a CU's 160 KB of LDS, i.e. LDS
 // admits 3 waves per SIMD (with the hash in its own 1 KB the 4-wave block was 56 896 B: two per CU)
@@ -116,12 +150,21 @@ template <int PREC, bool LN, int TW, bool PRE, int WPS = 0, bool EM = false>
 __global__ void __launch_bounds__(TW * 64, CLID_TILE_WAVES)
 k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap,
               const float4* __restrict__ rec, const int* __restrict__ tnum, int n_tiles, float* __restrict__ sdf_dbg) {
-  __shared__ TileLds tls[TW];
+  constexpr bool LW = WPS == 3;  // decoder operands read from LDS per use (the <= 168-register instantiation)
+  // BLK (launches of one tile per wave: the pre-numbered instantiation): dW1 / db1 are contracted once per BLOCK behind the
+  // block's barrier -- wave w takes hidden units 16 w .. 16 w + 15 over the 64 queries whose dh / f rows the four waves staged
+  // in LDS anyway -- and leave straight from the accumulator registers; only dW2 / db2 / the two loss sums (67 numbers per wave)
+  // still cross the waves through LDS.  The per-wave form wrote 835 floats per wave to LDS and summed them behind a second barrier.
+  constexpr bool BLK = CLID_TILE_BLK && PRE && TW == 4 && !LW && PREC == 0;
+  using TL = typename std::conditional<LW, TileLdsC, TileLds>::type;
+  __shared__ TL tls[TW];
   __shared__ TileLnLds lns[LN ? TW : 1];
-  static_assert(sizeof(TileLds) % 16 == 0 && sizeof(TileLds) * TW >= TW * kRedFloats * sizeof(float), "LDS plan");
+  __shared__ float wq[LW ? kWFloats : 4];
+  static_assert(sizeof(TL) % 16 == 0 && sizeof(TL) * TW >= TW * kRedFloats * sizeof(float), "LDS plan");
+  static_assert(!LW || (sizeof(TileLdsC) * TW + kWFloats * 4) * (12 / TW) <= 160 * 1024, "LDS plan: 3 waves per SIMD");
   float* red = reinterpret_cast<float*>(tls);  // the block flush reuses the tile buffers (after a barrier)
   const int lane = threadIdx.x & 63, q = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
-  TileLds& tl = tls[wave];
+  TL& tl = tls[wave];
   TileLnLds& ln = lns[LN ? wave : 0];
   const bool train = ta.train_decoder != 0;
   const float sc = ta.sdf_scale;
@@ -134,11 +177,68 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
   const float4* __restrict__ feat4 = reinterpret_cast<const float4*>(mv.feat);
   const float4* __restrict__ pos4 = reinterpret_cast<const float4*>(mv.pos4);
 
+  // the lane's slice of a tile's search record (+ its number block): 31 registers
+  struct TileRec {
+    float4 qi, qq, w01, w23, w45, wf;
+    int4 rid4;
+    int n_rows, rnum0, rnum1;
+  };
+  auto load_rec = [&](int tile) -> TileRec {
+    TileRec rc;
+    const int task = 2 * tile + (q >> 3), slot = q & 7;
+    const float4* r = rec + (size_t)(task < tmap.n_tasks ? task : 0) * kRecF4;
+    rc.qi = r[slot];
+    rc.qq = r[8 + slot];
+    rc.w01 = r[16 + slot * 4];
+    rc.w23 = r[16 + slot * 4 + 1];
+    rc.w45 = r[16 + slot * 4 + 2];
+    rc.wf = r[16 + slot * 4 + 3];  // (fx, fy | fz, -): blended offset, decoder inputs 8..10
+    rc.rid4 = make_int4(0, 0, 0, 0);
+    rc.n_rows = 0;
+    rc.rnum0 = rc.rnum1 = 255;
+    if constexpr (PRE) {
+      // PRE (launches of one tile per wave): the tile's pairs were numbered per distinct map row by the search launch
+      // (k_search_tiles, train.hip) -- the number block sits behind the iteration's task records
+      const int* __restrict__ tn = tnum + (size_t)tile * kTileNumWords;
+      if (lane < kMaxRows / 4) rc.rid4 = *reinterpret_cast<const int4*>(tn + 4 * lane);
+      rc.n_rows = tn[kTileNumCount];
+      const unsigned char* __restrict__ rbytes = reinterpret_cast<const unsigned char*>(tn + kTileNumBytes);
+      rc.rnum0 = rbytes[q * CLID_K + g];
+      if (g < 2) rc.rnum1 = rbytes[q * CLID_K + g + 4];
+    }
+    return rc;
+  };
+  // EARLY (one tile per wave): the wave's record is requested BEFORE the decoder weights are staged -- its ~1 us of latency runs
+  // under the staging's two barriers.  (Round 4 measured this on the 224 + 32-register kernel: 31 more live registers put it
+  // at one wave per SIMD; the block-level dW1 flush freed them.)
+  constexpr bool EARLY = CLID_TILE_EARLY_REC && BLK;
+  TileRec early;
+  if constexpr (EARLY) {
+    const int t0 = blockIdx.x * TW + wave;
+    early = load_rec(t0 < n_tiles ? t0 : 0);
+  }
+
   // ---- constant MFMA operands: the decoder weights (3.3 KB) are staged through LDS with one coalesced load per
   // thread (48 strided global loads per lane cost ~1.5 us of address-unit time at the start of every wave)
   //   A1[u][s] = W1e[16u + q][4g + s]     (W1e = [W1 | b1 | 0 0 0 0])            layer 1, A[i = lane & 15][k = lane >> 4]
   //   W2r[u][r] = W2[16u + 4g + r]                                                 layer 2 / dh, accumulator layout
   //   A2[u][r] = W1[16u + 4g + r][q], q < 8                                        d f, B[k = lane >> 4][j = lane & 15]
+  float A1[4][4], W2r[4][4], A2[4][4];
+  float b2;
+  if constexpr (LW) {
+    // the operand table stays in LDS for the whole launch: W1e rows padded to 20 floats (conflict-free 16-byte reads of
+    // A1 = W1e[16u + q][4g ..], column reads of A2 = W1[16u + 4g + r][q]), bf16 variants pre-rounded like the register path
+    for (int i = threadIdx.x; i < CLID_H * 16; i += (TW * 64)) {
+      const int h = i >> 4, c = i & 15;
+      float a = c < CLID_D ? ta.W1[h * CLID_D + c] : (c == CLID_D ? ta.b1[h] : 0.f);
+      if (PREC == 1 && c != CLID_D) a = bf16_round(a);
+      wq[h * kWStride + c] = a;
+    }
+    if (threadIdx.x < CLID_H) wq[kWOffW2 + threadIdx.x] = ta.W2[threadIdx.x];
+    if (threadIdx.x == 0) wq[kWOffW2 + CLID_H] = ta.b2[0];
+    __syncthreads();
+    b2 = wq[kWOffW2 + CLID_H];
+  } else {
   {
     float* wl = reinterpret_cast<float*>(tls);  // [W1 704 | b1 64 | W2 64 | b2 1]; overwritten by the first tile's fences later
     for (int i = threadIdx.x; i < CLID_H * CLID_D; i += (TW * 64)) wl[i] = ta.W1[i];
@@ -149,8 +249,6 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
     if (threadIdx.x == 0) wl[CLID_MLP_PARAMS - 1] = ta.b2[0];
   }
   __syncthreads();
-  float A1[4][4], W2r[4][4], A2[4][4];
-  float b2;
   {
     const float* wl = reinterpret_cast<const float*>(tls);
 #pragma unroll
@@ -175,8 +273,22 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
     b2 = wl[CLID_MLP_PARAMS - 1];
   }
   __syncthreads();  // the tile buffers may be written from here on
+  }
+  // operand access: registers, or (LW) the LDS table
+  auto ldA1 = [&](int u) -> float4 {
+    if constexpr (LW) return *reinterpret_cast<const float4*>(&wq[(16 * u + q) * kWStride + 4 * g]);
+    else return make_float4(A1[u][0], A1[u][1], A1[u][2], A1[u][3]);
+  };
+  auto ldW2 = [&](int u) -> float4 {
+    if constexpr (LW) return *reinterpret_cast<const float4*>(&wq[kWOffW2 + 16 * u + 4 * g]);
+    else return make_float4(W2r[u][0], W2r[u][1], W2r[u][2], W2r[u][3]);
+  };
+  auto ldA2 = [&](int u, int rr) -> float {
+    if constexpr (LW) return q < CLID_F ? wq[(16 * u + 4 * g + rr) * kWStride + q] : 0.f;
+    else return A2[u][rr];
+  };
   CLID_STAMP(0);
-  asm volatile("" ::"v"(A1[3][3]), "v"(W2r[3][3]), "v"(A2[3][3]));
+  if constexpr (!LW) asm volatile("" ::"v"(A1[3][3]), "v"(W2r[3][3]), "v"(A2[3][3]));
   CLID_STAMP(1);
 
   f32x4 dW1a[4];
@@ -193,26 +305,15 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
     // ================= record of this lane's query slot
     const int task = 2 * tile + (q >> 3), slot = q & 7;
     const bool tlive = task < tmap.n_tasks;
-    const float4* r = rec + (size_t)(tlive ? task : 0) * kRecF4;
-    const float4 qi = r[slot];
-    const float4 qq = r[8 + slot];
-    const float4 w01 = r[16 + slot * 4], w23 = r[16 + slot * 4 + 1], w45 = r[16 + slot * 4 + 2];
-    const float4 wf = r[16 + slot * 4 + 3];              // (fx, fy | fz, -): blended offset, decoder inputs 8..10
+    TileRec rc;
+    if constexpr (EARLY) rc = early;
+    else rc = load_rec(tile);
+    const float4 qi = rc.qi, qq = rc.qq, w01 = rc.w01, w23 = rc.w23, w45 = rc.w45, wf = rc.wf;
     const int sidx = tlive ? __float_as_int(qi.w) : -1;  // time stamp of the sample, -1 = padding slot
     const bool bundle = tlive && task < tmap.n_fd;
-    // PRE (launches of one tile per wave): the tile's pairs were numbered per distinct map row by the search launch
-    // (k_search_tiles, train.hip) -- the number block sits behind the iteration's task records
-    int4 rid4 = make_int4(0, 0, 0, 0);
-    int n_rows = 0;
-    int rnum[2] = {255, 255};
-    if constexpr (PRE) {
-      const int* __restrict__ tn = tnum + (size_t)tile * kTileNumWords;
-      if (lane < kMaxRows / 4) rid4 = *reinterpret_cast<const int4*>(tn + 4 * lane);
-      n_rows = tn[kTileNumCount];
-      const unsigned char* __restrict__ rbytes = reinterpret_cast<const unsigned char*>(tn + kTileNumBytes);
-      rnum[0] = rbytes[q * CLID_K + g];
-      if (g < 2) rnum[1] = rbytes[q * CLID_K + g + 4];
-    }
+    const int4 rid4 = rc.rid4;
+    int n_rows = rc.n_rows;
+    const int rnum[2] = {rc.rnum0, rc.rnum1};
     // IDW weights and neighbour ids come from the search record (np.py:688-706)
     float w[CLID_K] = {w01.x, w01.z, w23.x, w23.z, w45.x, w45.z};
     int j[CLID_K] = {__float_as_int(w01.y), __float_as_int(w01.w), __float_as_int(w23.y),
@@ -360,8 +461,11 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         D[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) D[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[u][s], pc[s], D[u], 0, 0, 0);
+        const float4 a = ldA1(u);
+        D[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, pc[0], D[u], 0, 0, 0);
+        D[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, pc[1], D[u], 0, 0, 0);
+        D[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, pc[2], D[u], 0, 0, 0);
+        D[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, pc[3], D[u], 0, 0, 0);
       }
     } else {
       // K = 32: lane (q, g) owns K slots 8g .. 8g+7 = its 4 columns (bf16) | 4 spare slots; the spare slots of the
@@ -369,8 +473,9 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
       const bf16x8 bq = bf16_frag(pack_bf16(pc[0], pc[1]), pack_bf16(pc[2], pc[3]), g == 2 ? pack_bf16(1.0f, 0.f) : 0u, 0u);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float blo = A1[u][3] - bf16_round(A1[u][3]);  // g == 2: the bias' low part
-        const bf16x8 aq = bf16_frag(pack_bf16(A1[u][0], A1[u][1]), pack_bf16(A1[u][2], A1[u][3]),
+        const float4 a = ldA1(u);
+        const float blo = a.w - bf16_round(a.w);  // g == 2: the bias' low part
+        const bf16x8 aq = bf16_frag(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w),
                                     g == 2 ? pack_bf16(blo, 0.f) : 0u, 0u);
         D[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bq, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       }
@@ -378,9 +483,13 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
     // ================= layer 2 (decoder.py:76-82)
     float part = 0.f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) part = fmaf(W2r[u][rr], fmaxf(D[u][rr], 0.f), part);
+    for (int u = 0; u < 4; ++u) {
+      const float4 w2 = ldW2(u);
+      part = fmaf(w2.x, fmaxf(D[u][0], 0.f), part);
+      part = fmaf(w2.y, fmaxf(D[u][1], 0.f), part);
+      part = fmaf(w2.z, fmaxf(D[u][2], 0.f), part);
+      part = fmaf(w2.w, fmaxf(D[u][3], 0.f), part);
+    }
     const float sdf = sc * (xsum32(xsum16(part)) + b2);
     if (sdf_dbg && g == 0 && tlive) sdf_dbg[(size_t)task * 8 + slot] = sdf;  // tests: SDF per record slot
     CLID_STAMP(5);
@@ -428,13 +537,16 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
     const float dz = sc * delta;
     float dh[4][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 4; ++u) {
+      const float4 w2v = ldW2(u);
+      const float w2[4] = {w2v.x, w2v.y, w2v.z, w2v.w};
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const bool on = D[u][rr] > 0.f;
-        dh[u][rr] = on ? dz * W2r[u][rr] : 0.f;
+        dh[u][rr] = on ? dz * w2[rr] : 0.f;
         if (train) dW2a[u][rr] += on ? dz * D[u][rr] : 0.f;
       }
+    }
     if (train && g == 0) db2a += dz;
     // d f, operands swapped: Df[rr] of lane (c = lane & 15, G = lane >> 4) = d f[c] of query slot 4G + rr
     f32x4 Df = {0.f, 0.f, 0.f, 0.f};
@@ -444,8 +556,8 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
       for (int u = 0; u < 4; u += 2)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          Df = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[u][rr], A2[u][rr], Df, 0, 0, 0);
-          Df2 = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[u + 1][rr], A2[u + 1][rr], Df2, 0, 0, 0);
+          Df = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[u][rr], ldA2(u, rr), Df, 0, 0, 0);
+          Df2 = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[u + 1][rr], ldA2(u + 1, rr), Df2, 0, 0, 0);
         }
       Df += Df2;
     } else {
@@ -453,8 +565,8 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
       for (int t = 0; t < 2; ++t) {  // K slot 8g + e <-> hidden 16(2t + e/4) + 4g + e%4
         const bf16x8 aq = bf16_frag(pack_bf16(dh[2 * t][0], dh[2 * t][1]), pack_bf16(dh[2 * t][2], dh[2 * t][3]),
                                     pack_bf16(dh[2 * t + 1][0], dh[2 * t + 1][1]), pack_bf16(dh[2 * t + 1][2], dh[2 * t + 1][3]));
-        const bf16x8 bq = bf16_frag(pack_bf16(A2[2 * t][0], A2[2 * t][1]), pack_bf16(A2[2 * t][2], A2[2 * t][3]),
-                                    pack_bf16(A2[2 * t + 1][0], A2[2 * t + 1][1]), pack_bf16(A2[2 * t + 1][2], A2[2 * t + 1][3]));
+        const bf16x8 bq = bf16_frag(pack_bf16(ldA2(2 * t, 0), ldA2(2 * t, 1)), pack_bf16(ldA2(2 * t, 2), ldA2(2 * t, 3)),
+                                    pack_bf16(ldA2(2 * t + 1, 0), ldA2(2 * t + 1, 1)), pack_bf16(ldA2(2 * t + 1, 2), ldA2(2 * t + 1, 3)));
         Df = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bq, Df, 0, 0, 0);
       }
     }
@@ -464,7 +576,7 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         *reinterpret_cast<float4*>(&tl.dh[q * kDhStride + 16 * u + 4 * g]) = make_float4(dh[u][0], dh[u][1], dh[u][2], dh[u][3]);
-      *reinterpret_cast<float4*>(&tl.f[q * kFStride + 4 * g]) = make_float4(pc[0], pc[1], pc[2], pc[3]);
+      *reinterpret_cast<float4*>(tile_f<TL>::at(tl, q) + 4 * g) = make_float4(pc[0], pc[1], pc[2], pc[3]);
       tile_lds_fence();
     }
     {
@@ -511,11 +623,11 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
     }
     CLID_STAMP(10);
     // ================= dW1 (+ db1 through the bias column) on the matrix cores
-    if (train) {
+    if (train && !BLK) {
       if (PREC == 0) {
         float bt[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bt[s] = tl.f[(4 * s + g) * kFStride + q];
+        for (int s = 0; s < 4; ++s) bt[s] = tile_f<TL>::at(tl, 4 * s + g)[q];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -524,7 +636,7 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
       } else {  // K slot 8g + e <-> query 8g + e (g < 2), zero above
         float fq[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) fq[e] = g < 2 ? tl.f[(8 * g + e) * kFStride + q] : 0.f;
+        for (int e = 0; e < 8; ++e) fq[e] = g < 2 ? tile_f<TL>::at(tl, 8 * g + e)[q] : 0.f;
         const bf16x8 bq = bf16_frag(pack_bf16(fq[0], fq[1]), pack_bf16(fq[2], fq[3]), pack_bf16(fq[4], fq[5]), pack_bf16(fq[6], fq[7]));
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -541,6 +653,55 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
   }
 
   CLID_STAMP(12);
+  float* out = partial + (size_t)blockIdx.x * kPartialStride;
+  if constexpr (BLK) {
+    __shared__ float aux[TW][72];  // per wave: dW2 [64] | db2 | bce sum | eikonal sum
+    const float bce_w = wave_sum(bce_acc), eik_w = wave_sum(eik_acc);
+    if (train) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float s2 = group_sum(dW2a[u][rr]);
+          if (q == 0) aux[wave][16 * u + 4 * g + rr] = s2;
+        }
+      const float db2_w = wave_sum(db2a);
+      if (lane == 0) aux[wave][CLID_H] = db2_w;
+    }
+    if (lane == 0) {
+      aux[wave][CLID_H + 1] = bce_w;
+      aux[wave][CLID_H + 2] = eik_w;
+    }
+    __syncthreads();  // every wave's tile is done: its dh / f rows are complete
+    if (train) {
+      // dW1[16 wave + i][c] = sum over the block's (up to) 64 queries of dh[query][16 wave + i] f[query][c]: A[i = q][k] = dh of
+      // query k, B[k][j = q] = f of query k; lane (q, g) ends with rows 16 wave + 4 g + r of column q (column 11 = db1)
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sw = 0; sw < TW; ++sw) {
+        if (blockIdx.x * TW + sw >= n_tiles) break;  // (uniform: the block's trailing waves had no tile, their buffers are stale)
+        TL& ts = tls[sw];
+#pragma unroll
+        for (int sq = 0; sq < 4; sq += 2) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ts.dh[(4 * sq + g) * kDhStride + 16 * wave + q], tile_f<TL>::at(ts, 4 * sq + g)[q], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ts.dh[(4 * sq + 4 + g) * kDhStride + 16 * wave + q], tile_f<TL>::at(ts, 4 * sq + 4 + g)[q], acc1, 0, 0, 0);
+        }
+      }
+      acc0 += acc1;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int h = 16 * wave + 4 * g + rr;
+        if (q < CLID_D) out[h * CLID_D + q] = acc0[rr];
+        else if (q == CLID_D) out[CLID_H * CLID_D + h] = acc0[rr];
+      }
+    }
+    if (threadIdx.x < CLID_H + 3 && (train || threadIdx.x > CLID_H)) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < TW; ++wv) sacc += aux[wv][threadIdx.x];
+      out[CLID_H * CLID_D + CLID_H + threadIdx.x] = sacc;  // W2 [64] | b2 | bce | eik: consecutive in the partial row
+    }
+  } else {
   __syncthreads();
   // ---- block flush: one partial row [833 decoder gradients | bce | eik] per block
   float* mine = red + wave * kRedFloats;
@@ -564,12 +725,12 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
     mine[CLID_MLP_PARAMS + 1] = eik_w;
   }
   __syncthreads();
-  float* out = partial + (size_t)blockIdx.x * kPartialStride;
   for (int i = train ? threadIdx.x : CLID_MLP_PARAMS + threadIdx.x; i < CLID_MLP_PARAMS + 2; i += (TW * 64)) {
     float s = 0.f;
 #pragma unroll
     for (int wv = 0; wv < TW; ++wv) s += red[wv * kRedFloats + i];
     out[i] = s;
+  }
   }
   CLID_STAMP(13);
 }
@@ -615,6 +776,8 @@ int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, f
   const float4* r4 = reinterpret_cast<const float4*>(rec);
   const int* tn = reinterpret_cast<const int*>(rec + (size_t)tmap.n_tasks * kRecFloatsPerTask);  // (rec_floats_per_iter layout)
   const bool pre = clid_tiles_prenumbered(tmap.n_tasks, mv);
+  int nb3 = (n_tiles + 3) / 4;  // (the 4-wave blocks of the 3-waves-per-SIMD instantiation: never more partial rows than `nb`)
+  if (nb3 > nb) nb3 = nb;
 #define CLID_TILE_LAUNCH_K(K, TWV)                                                                                    \
   CLID_KLAUNCH(a->prof, 0, K, dim3(nb), dim3((TWV) * 64), 0, s, *mv, *a, partial, tmap, r4, tn, n_tiles, a->sdf_dbg)
 #define CLID_TILE_LAUNCH(P, L)                                                                                        \
@@ -628,8 +791,9 @@ int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, f
       CLID_TILE_LAUNCH_K((k_decode_tile<P, L, kTileWavesSmall, true>), kTileWavesSmall);                              \
     else if (small)                                                                                                   \
       CLID_TILE_LAUNCH_K((k_decode_tile<P, L, kTileWavesSmall, false>), kTileWavesSmall);                             \
-    else if (!L && (a->debug_flags & 16)) /* debug bit 4: the 3-waves-per-SIMD instantiation (A/B: it spills, 43 vs 29 us) */ \
-      CLID_TILE_LAUNCH_K((k_decode_tile<P, L, kTileWavesLarge, false, L ? 0 : 3>), kTileWavesLarge);                  \
+    else if (!L && (a->debug_flags & 16)) /* debug bit 4: the 3-waves-per-SIMD instantiation (operands from LDS; 4-wave blocks) */ \
+      CLID_KLAUNCH(a->prof, 0, (k_decode_tile<P, L, 4, false, L ? 0 : 3>), dim3(nb3), dim3(256), 0, s, *mv, *a, partial, tmap, r4, tn, \
+                   n_tiles, a->sdf_dbg);                                                                               \
     else                                                                                                              \
       CLID_TILE_LAUNCH_K((k_decode_tile<P, L, kTileWavesLarge, false>), kTileWavesLarge);                             \
   } while (0)

@@ -125,7 +125,8 @@ class LocalPointCloudMap:
             # the caller reads the count later (Mapper.process_frame: with the frame's last read-back); until then the map is
             # its first n rows -- an upper bound: rows beyond the true count are referenced by no slot of the table
             self.local_point_cloud_map = out_pts[:n]
-            self._count_pending, self._pending = True, (out_pts, defer, vox if s_idx is not None else None)
+            self._count_pending, self._pending = True, (out_pts, defer, vox if s_idx is not None else None,
+                                                        (sensor_position, points) if s_idx is not None else None)
             return True
         kept = _lib.read_counts(self._cloud_counts, 1)[0]  # the one host round trip (sizes the map)
         self.local_point_cloud_map = out_pts[:kept]
@@ -134,15 +135,20 @@ class LocalPointCloudMap:
     def _finish_count(self, kept=None, vox_failed=None):
         """Settle a deferred update_map: `kept` (and the failure flag of the scan's voxel pass, when that stayed in flight) as
         read by the caller, or read back here."""
-        out_pts, counts, vox = self._pending
+        out_pts, counts, vox, redo = self._pending
         if kept is None:
             kept = _lib.read_counts(counts, 1)[0]
             vox_failed = None if vox is None else _lib.read_counts(vox, 2)[1]
-        if vox is not None and vox_failed:
-            raise RuntimeError("voxel down-sampling of the scan: voxel ids too wide for the device-side ordering (a bounding box "
-                               "beyond 2^17 voxels per axis); CLID_ASYNC_VOXEL=0 takes the path with the library sort")
         self.local_point_cloud_map = out_pts[:int(kept)]
         self._count_pending, self._pending = False, None
+        if vox is not None and vox_failed:
+            # the scan's voxel ids were too wide for the device-side ordering (a bounding box beyond 2^17 voxels per axis: an
+            # outlier point).  That pass published zero voxels, so the update above inserted nothing (crop + table rebuild only);
+            # the same scan goes in again through the pass with the library sort (one extra round trip, this frame only)
+            self.vox_fallbacks = getattr(self, "vox_fallbacks", 0) + 1
+            self._defer_counts = None
+            self.__dict__.pop("_defer_vox", None)
+            self.update_map(redo[0], redo[1])
 
     def set_search_neighborhood(self, num_nei_cells: int = 1, search_alpha: float = 0.2) -> None:
         """:74-96: the cells within (num_nei_cells + search_alpha) of the centre cell (7 by default)."""

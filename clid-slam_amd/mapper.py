@@ -924,7 +924,8 @@ class Mapper:
                 update_points = update_points[:n_near]
                 n_cur = self.cur_sample_count = kept
                 defer_cmp = False
-            nm._presampled = (update_points, (vox_idx, nm.update_counts(coord.device)[3:5]) if vox_idx is not None else update_points[keep_idx])
+            nm._presampled = (update_points, (vox_idx, nm.update_counts(coord.device)[3:5], None if cmp_dev is None else cmp_dev[1:2])
+                              if vox_idx is not None else update_points[keep_idx])
         if defer_cmp and vox_idx is None:  # (not reached with the conditions above; kept for safety: settle the counts before anything uses the rows)
             kept, n_near = _lib.read_counts(self._cmp_counts, 2)
             coord, gcoord, sdf_label, weight, stamp = coord[:kept], gcoord[:kept], sdf_label[:kept], weight[:kept], stamp[:kept]

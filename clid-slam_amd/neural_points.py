@@ -241,6 +241,17 @@ class NeuralPoints(nn.Module):
         cache[key] = (self.neighbor_dx, self.neighbor_K, self.max_valid_dist2, self._delta, self._stencil_rows, self._stencil_nc)
 
     # ------------------------------------------------------------------ map maintenance (host logic)
+    def _update_after_failed_voxel_pass(self, points, sensor_position, sensor_orientation, cur_ts, n_valid_dev=None):
+        """The device-side voxel ordering in front of the insert gave up (voxel ids too wide: a bounding box beyond 2^17 voxels
+        per axis, i.e. an outlier point).  It published ZERO voxels, so the insert that sized itself by that count on the device
+        added nothing and the map is as it was: the same points go through `update` again, this time down-sampled by the pass
+        with the library sort (one extra host round trip, this frame only)."""
+        self.vox_fallbacks = getattr(self, "vox_fallbacks", 0) + 1
+        self.__dict__.pop("_presampled", None)
+        if n_valid_dev is not None:  # only the first *n_valid_dev rows of `points` count (a compaction still in flight sized them)
+            points = points[: _lib.read_counts(n_valid_dev, 1)[0]]
+        return self.update(points, sensor_position, sensor_orientation, cur_ts)
+
     def update(self, points: torch.Tensor, sensor_position: torch.Tensor, sensor_orientation: torch.Tensor, cur_ts: int):
         """Insert new neural points for `points` [N,3] (model/neural_points.py:324-437)."""
         res = self.resolution
@@ -248,7 +259,8 @@ class NeuralPoints(nn.Module):
         if pre is not None and pre[0] is points and isinstance(pre[1], tuple):
             # (index list, device count) of a voxel down-sampling still in flight (tools.voxel_down_sample_async): the fused
             # insert takes both on the device, nothing waits for the pass on the host
-            return self._update_fused(points, sensor_position, sensor_orientation, cur_ts, sample_idx=pre[1][0], vox_counts=pre[1][1])
+            return self._update_fused(points, sensor_position, sensor_orientation, cur_ts, sample_idx=pre[1][0], vox_counts=pre[1][1],
+                                      n_valid_dev=pre[1][2] if len(pre[1]) > 2 else None)
         if pre is not None and pre[0] is points:
             sample_points = pre[1]
         else:
@@ -356,7 +368,8 @@ class NeuralPoints(nn.Module):
             self._ins_count, self._win_counts = blk[:1], blk[1:3]
         return blk
 
-    def _update_fused(self, sample_points, sensor_position, sensor_orientation, cur_ts: int, sample_idx=None, vox_counts=None):
+    def _update_fused(self, sample_points, sensor_position, sensor_orientation, cur_ts: int, sample_idx=None, vox_counts=None,
+                      n_valid_dev=None):
         """The insert of `update` in one enqueue (csrc/mapops.hip clid_map_insert) + ONE count read-back, appending in
         place into the capacity buffers.  sample_idx / vox_counts: the samples are rows sample_idx[i], i < vox_counts[0] (device),
         of `sample_points`; the number of rows is the bound everything is sized for."""
@@ -387,14 +400,15 @@ class NeuralPoints(nn.Module):
             # two share ONE read-back (model/neural_points.py:324-437 + :439-536); the insert zeroes the new feature rows itself
             got = self._reset_local_map_fused(sensor_position, sensor_orientation, cur_ts, True, 50, True,
                                               pending=(buf, base, n, self._ins_count, vox_counts is not None))
+            if got == "vox_failed":
+                return self._update_after_failed_voxel_pass(sample_points, sensor_position, sensor_orientation, cur_ts, n_valid_dev)
             if got is not None:
                 return got[0] / max(got[1], 1)
         n_new = _lib.read_counts(self._ins_count, 1)[0]  # the one host round trip of the insert (sizes the views)
         if vox_counts is not None:
             n, bad = _lib.read_counts(vox_counts, 2)
             if bad:
-                raise RuntimeError("voxel down-sampling of the map update: voxel ids too wide for the device-side ordering "
-                                   "(a bounding box beyond 2^17 voxels per axis); CLID_ASYNC_VOXEL=0 takes the path with the library sort")
+                return self._update_after_failed_voxel_pass(sample_points, sensor_position, sensor_orientation, cur_ts, n_valid_dev)
         total = base + n_new
         if self.geo_feature_std != 0:
             gen = _lib.replica_generator(self, self.config, self.device, 2)  # None = global RNG unless data-parallel
@@ -539,9 +553,8 @@ class NeuralPoints(nn.Module):
                 if with_vox:  # ... and the voxel pass in front of the insert: [voxels | ordering failed]
                     got = self._last_update_counts = _lib.read_counts(self._ins_win_counts, 7)
                     n_new, _, m, n_vox, bad = got[:5]
-                    if bad:
-                        raise RuntimeError("voxel down-sampling of the map update: voxel ids too wide for the device-side ordering "
-                                           "(a bounding box beyond 2^17 voxels per axis); CLID_ASYNC_VOXEL=0 takes the path with the library sort")
+                    if bad:  # (the pass published zero voxels: nothing was inserted, no array was re-pointed yet)
+                        return "vox_failed"
                 else:
                     n_new, _, m = _lib.read_counts(self._ins_win_counts, 3)
                     n_vox = n_add
@@ -820,9 +833,13 @@ class NeuralPoints(nn.Module):
             n = ids.shape[0]
         else:
             ids, n = None, self.count()
-        if n >= (1 << 22):
-            raise NotImplementedError(f"{n} points in one table: the searches address at most 2^22 (their candidates carry the "
-                                      "probe index next to the id)")
+        # the searches' candidates carry the probe index next to the id: 22 bits of id in the training kernels (local window),
+        # 24 in the inference kernels for neighbourhoods of <= 128 cells (csrc/common.hpp probe_shift_of) -- a GLOBAL table
+        # (meshing, dense SDF queries) may therefore hold 16.7 M points
+        id_bits = 22 if (locally or int(self.neighbor_K) > 128) else 24
+        if n >= (1 << id_bits):
+            raise NotImplementedError(f"{n} points in one {'local' if locally else 'global'} table: the searches address at most "
+                                      f"2^{id_bits} (their candidates carry the probe index next to the id)")
         log2cap = max(5, int(math.ceil(math.log2(max(2 * n, 32)))))  # 4-key buckets, <= 0.5 keys per bucket
         # (the log2filter of the table is needed for the buffers: computed here, used below)
         log2filter = max(13, int(math.ceil(math.log2(max(8 * n, 32)))))

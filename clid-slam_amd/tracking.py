@@ -9,71 +9,183 @@ d SDF / d x inference path, `IEKFOM.h_model` (utils/error_state_iekf.py:176-264)
 S = H^T R_inv H (18 x 18, float64, non-zero 6 x 6 block) and H^T R_inv z, reduced on the GPU without
 materialising H.  The 18-state filter itself (predict / boxplus / covariance) is host-side 18 x 18 math and
 stays with the reference (out of scope).
+
+The filter iterates the model up to `max_iteration` times per scan (utils/error_state_iekf.py:286-305) with the SAME points
+and map -- only the pose moves.  Everything that stays fixed is therefore bound ONCE per scan (`bind` / the cached binding the
+module-level functions use): the map view, the decoder pointers, the thresholds, the point tensor and the scratch outputs sit in
+one `clid_track_call` argument block; an evaluation passes the pose and the reduction buffers only (`clid_track_model_call`).
+The reduction buffers form a ring of three -- the launch accumulates into one, clears the next one itself, the previous result
+stays readable -- and the 28 sums of `normal_equations` come back through pinned, host-mapped memory that a one-block launch
+fills (no fill launch, no torch reductions, no copy, no stream synchronisation per evaluation).
 """
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
+import numpy as np
 import torch
 
 from . import _lib
 
 
+class BoundTrackModel:
+    """The measurement model bound to (map state, decoder, thresholds, scan points): see the module docstring."""
+
+    def __init__(self, neural_points, geo_decoder, config, pc_imu):
+        lib = _lib.load()
+        self._lib = lib
+        x = _lib.require_cuda(pc_imu.detach().to(torch.float32).contiguous(), "pc_imu", torch.float32)
+        self.x, self.n, self.dev = x, int(x.shape[0]), x.device
+        view, keep = neural_points._map_view(True)
+        W1, b1, W2, b2 = geo_decoder.flat_params()
+        self._keep = (keep, W1, b1, W2, b2, x)
+        c = self.call = _lib.TrackCall()
+        c.mv = view
+        c.W1, c.b1, c.W2, c.b2 = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr()
+        c.sdf_scale, c.min_nn = float(geo_decoder.sdf_scale), int(config.track_mask_query_nn_k)
+        c.min_grad_norm, c.max_grad_norm = float(config.reg_min_grad_norm), float(config.reg_max_grad_norm)
+        c.max_sdf_std = float(config.surface_sample_range_m * getattr(config, "max_sdf_std_ratio", 1.0))
+        c.N, c.pc_imu = self.n, x.data_ptr()
+        self._call_ref = C.byref(c)
+        self.out = None          # per-point outputs (allocated on first use)
+        # process-wide per device: the ring of reduction buffers (all zero between calls: every launch clears the next one) and
+        # the pinned result block
+        shared = _SHARED.get(str(self.dev))
+        if shared is None:
+            ring = torch.zeros((3, 16, 32), device=self.dev, dtype=torch.float64)
+            host, devp = C.c_void_p(), C.c_void_p()
+            _lib.check(lib.clid_pinned_alloc(32 * 8, C.byref(host), C.byref(devp)), "clid_pinned_alloc")
+            res = np.ctypeslib.as_array(C.cast(host, C.POINTER(C.c_double)), shape=(32,))
+            shared = _SHARED[str(self.dev)] = {"ring": ring, "ptr": [ring[i].data_ptr() for i in range(3)], "cur": 0,
+                                               "res": res, "res_dev": devp.value, "epoch": 0.0}
+        self._shared = shared
+        self._pose = torch.empty(12, device=self.dev, dtype=torch.float32)  # device staging for a device-resident pose
+        self._pose_ptr = (self._pose.data_ptr(), self._pose.data_ptr() + 36)
+        self._host_pose = (C.c_float * 12)()
+
+    # -- the pose: host numbers by value, device tensors through one staging copy (no host round trip)
+    def _pose_args(self, rot, pos):
+        rot, pos = torch.as_tensor(rot), torch.as_tensor(pos)
+        if rot.is_cuda and pos.is_cuda:
+            if rot.dtype == torch.float32 and pos.dtype == torch.float32 and rot.is_contiguous() and pos.is_contiguous():
+                return rot.data_ptr(), pos.data_ptr(), 1  # (read in place)
+            self._pose[:9].copy_(rot.detach().reshape(-1))
+            self._pose[9:].copy_(pos.detach().reshape(-1))
+            return self._pose_ptr[0], self._pose_ptr[1], 1
+        hp = self._host_pose
+        hp[:9] = rot.detach().to(torch.float32).reshape(-1).tolist()
+        hp[9:] = pos.detach().to(torch.float32).reshape(-1).tolist()
+        base = C.addressof(hp)
+        return base, base + 36, 0
+
+    def _per_point(self, on: bool):
+        c = self.call
+        if on and self.out is None:
+            n, dev = self.n, self.dev
+            self.out = {"sdf": torch.empty(n, device=dev, dtype=torch.float32), "grad": torch.empty((n, 3), device=dev, dtype=torch.float32),
+                        "pmap": torch.empty((n, 3), device=dev, dtype=torch.float32), "valid": torch.empty(n, device=dev, dtype=torch.int32)}
+        o = self.out if on else None
+        c.sdf_out = o["sdf"].data_ptr() if o else None
+        c.grad_out = o["grad"].data_ptr() if o else None
+        c.pmap_out = o["pmap"].data_ptr() if o else None
+        c.valid_out = o["valid"].data_ptr() if o else None
+
+    def launch(self, rot, pos, per_point: bool, reduce: bool, result: bool = False):
+        """Enqueue one evaluation.  reduce: accumulate the 28 sums (returns the [16, 32] buffer of partial copies); result:
+        also have them added up into the pinned block (`wait_result`)."""
+        r, t, on_dev = self._pose_args(rot, pos)
+        self._per_point(per_point)
+        sh = self._shared
+        ne = nxt = res = None
+        epoch = 0.0
+        if reduce:
+            cur = sh["cur"]
+            sh["cur"] = (cur + 1) % 3
+            ne, nxt = sh["ptr"][cur], sh["ptr"][(cur + 1) % 3]
+            if result:
+                sh["epoch"] = epoch = sh["epoch"] + 1.0
+                res = sh["res_dev"]
+        _lib.check(self._lib.clid_track_model_call(self._call_ref, r, t, on_dev, ne, nxt, res, epoch, _lib.stream()),
+                   "clid_track_model_call")
+        return sh["ring"][(sh["cur"] + 2) % 3] if reduce else None
+
+    def rows(self, rot, pos, tdt=torch.float64):
+        """IEKFOM.h_model's outputs for the pose, compacted on the device in point order: the model launch with per-point outputs,
+        a count + scan of the valid flags whose total comes back through the pinned block (the one host wait: the outputs are
+        sized by it, as the reference's own boolean indexing is), then one launch that writes z, H, valid_points and R_inv."""
+        lib, sh = self._lib, self._shared
+        r, t, on_dev = self._pose_args(rot, pos)
+        self._per_point(True)
+        _lib.check(lib.clid_track_model_call(self._call_ref, r, t, on_dev, None, None, None, 0.0, _lib.stream()), "clid_track_model_call")
+        if getattr(self, "_blk", None) is None:
+            self._blk = torch.empty((self.n + 255) // 256 + 1, device=self.dev, dtype=torch.int32)
+        sh["epoch"] = epoch = sh["epoch"] + 1.0
+        _lib.check(lib.clid_track_valid_count(self.out["valid"].data_ptr(), self.n, self._blk.data_ptr(), sh["res_dev"], epoch, _lib.stream()),
+                   "clid_track_valid_count")
+        res = sh["res"]
+        while res[31] != epoch:
+            pass
+        nv = int(res[29])
+        dev = self.dev
+        z = torch.empty(nv, device=dev, dtype=torch.float64)
+        H = torch.empty((nv, 18), device=dev, dtype=torch.float64)
+        vp = torch.empty((nv, 3), device=dev, dtype=torch.float32)
+        rinv = torch.empty(nv, device=dev, dtype=torch.float64)
+        if nv:
+            _lib.check(lib.clid_track_rows(self._call_ref, r, t, on_dev, self._blk.data_ptr(), z.data_ptr(), H.data_ptr(), vp.data_ptr(),
+                                           rinv.data_ptr(), _lib.stream()), "clid_track_rows")
+        if tdt != torch.float64:
+            z, H, rinv = z.to(tdt), H.to(tdt), rinv.to(tdt)
+        return z, H, vp, rinv
+
+    def wait_result(self):
+        """The 28 sums of the last `launch(..., reduce=True, result=True)` as a float64 numpy array (polls the pinned block)."""
+        sh = self._shared
+        res, epoch = sh["res"], sh["epoch"]
+        while res[31] != epoch:
+            pass
+        return res[:28].copy()
+
+
+import os as _os
+
+_FUSED_ROWS = _os.environ.get("CLID_TRACK_ROWS", "1") != "0"  # h_model's outputs compacted on the device (0: the torch glue, A/B)
+_SHARED = {}   # per device: reduction ring + pinned result block
+_BOUND = {}    # per NeuralPoints object: (key, weakref to the point tensor, BoundTrackModel)
+
+
+def bind(neural_points, geo_decoder, config, pc_imu) -> BoundTrackModel:
+    """The binding for this (map state, decoder, scan): cached per NeuralPoints object and reused while the SAME point tensor
+    is evaluated against an unchanged map -- the iterations of one `update_iterated` call."""
+    theta = neural_points.local_geo_features
+    key = (id(pc_imu), pc_imu.data_ptr(), pc_imu._version, tuple(pc_imu.shape), neural_points._map_version, int(neural_points.cur_ts),
+           id(neural_points.travel_dist), theta.data_ptr(), id(geo_decoder), id(neural_points.global2local),
+           float(config.reg_min_grad_norm), float(config.reg_max_grad_norm), int(config.track_mask_query_nn_k))
+    hit = _BOUND.get(id(neural_points))
+    if hit is not None and hit[0] == key and hit[1]() is pc_imu and hit[3]() is neural_points:
+        return hit[2]
+    b = BoundTrackModel(neural_points, geo_decoder, config, pc_imu)
+    if len(_BOUND) >= 8:
+        _BOUND.clear()
+    _BOUND[id(neural_points)] = (key, weakref.ref(pc_imu), b, weakref.ref(neural_points))
+    return b
+
+
 def _launch(neural_points, geo_decoder, config, rot, pos, pc_imu, per_point: bool, reduce: bool):
-    lib = _lib.load()
-    x = _lib.require_cuda(pc_imu.detach().to(torch.float32).contiguous(), "pc_imu", torch.float32)
-    n = x.shape[0]
-    dev = x.device
-    view, keep = neural_points._map_view(True)
-    W1, b1, W2, b2 = geo_decoder.flat_params()
-    # the state lives on the device in the reference's filter (utils/error_state_iekf.py:176-186): the kernel reads the 12
-    # numbers there (clid_track_model_dev) -- two tiny conversions, no host round trip per evaluation; a host pose goes by value
-    rot, pos = torch.as_tensor(rot), torch.as_tensor(pos)
-    on_dev = rot.is_cuda and pos.is_cuda
-    if on_dev:
-        r = rot.detach().to(torch.float32).contiguous()
-        t = pos.detach().to(torch.float32).contiguous()
-    else:
-        r = (C.c_float * 9)(*rot.detach().to(torch.float32).reshape(-1).tolist())
-        t = (C.c_float * 3)(*pos.detach().to(torch.float32).reshape(-1).tolist())
-    out = {}
-    if per_point:
-        # raw per-point outputs: a cached scratch set per (n, device) -- everything handed to the caller below is derived
-        # by masked indexing, i.e. copied (the filter calls this 5-20 times per scan)
-        cache = neural_points.__dict__.setdefault("_track_scratch", {})
-        out = cache.get((n, str(dev)))
-        if out is None:
-            if len(cache) >= 4:
-                cache.clear()
-            out = cache[(n, str(dev))] = {
-                "sdf": torch.empty(n, device=dev, dtype=torch.float32), "grad": torch.empty((n, 3), device=dev, dtype=torch.float32),
-                "pmap": torch.empty((n, 3), device=dev, dtype=torch.float32), "valid": torch.empty(n, device=dev, dtype=torch.int32)}
-    ne = None
-    if reduce:  # CLID_TRACK_COPIES partial copies of the 28 sums; two buffers alternate so a caller may still hold the last result
-        ring = neural_points.__dict__.setdefault("_track_ne", {})
-        pair = ring.get(str(dev))
-        if pair is None:
-            pair = ring[str(dev)] = [torch.empty((16, 32), device=dev, dtype=torch.float64) for _ in range(2)] + [0]
-        pair[2] ^= 1
-        ne = pair[pair[2]].zero_()
-    fn = lib.clid_track_model_dev if on_dev else lib.clid_track_model
-    _lib.check(
-        fn(C.byref(view), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
-                             float(geo_decoder.sdf_scale), _lib.ptr(r) if on_dev else r, _lib.ptr(t) if on_dev else t, int(config.track_mask_query_nn_k),
-                             float(config.reg_min_grad_norm), float(config.reg_max_grad_norm),
-                             float(config.surface_sample_range_m * getattr(config, "max_sdf_std_ratio", 1.0)), _lib.ptr(x), n,
-                             _lib.ptr(out.get("sdf")), _lib.ptr(out.get("grad")), _lib.ptr(out.get("pmap")),
-                             _lib.ptr(out.get("valid")), _lib.ptr(ne), _lib.stream()),
-        "clid_track_model",
-    )
-    return x, out, ne
+    """One evaluation through the cached binding: (points, per-point outputs or {}, [16, 32] partial sums or None)."""
+    b = bind(neural_points, geo_decoder, config, pc_imu)
+    ne = b.launch(rot, pos, per_point, reduce)
+    return b.x, (b.out if per_point else {}), ne
 
 
 def h_model(neural_points, geo_decoder, config, rot, pos, pc_imu):
     """(sdf_residual [Nv] f64, H [Nv,18] f64, valid_points [Nv,3], R_inv [Nv] f64) as
     utils/error_state_iekf.py:176-264 computes them for the state (rot, pos)."""
-    x, out, _ = _launch(neural_points, geo_decoder, config, rot, pos, pc_imu, True, False)
     tdt = getattr(config, "tran_dtype", torch.float64)
+    if pc_imu.shape[0] > 0 and _FUSED_ROWS:
+        return bind(neural_points, geo_decoder, config, pc_imu).rows(rot, pos, tdt)
+    x, out, _ = _launch(neural_points, geo_decoder, config, rot, pos, pc_imu, True, False)
     valid = out["valid"].bool()
     g = out["grad"][valid]
     p = x[valid]
@@ -88,17 +200,22 @@ def h_model(neural_points, geo_decoder, config, rot, pos, pc_imu):
     return z, H, out["pmap"][valid], r_inv
 
 
-def normal_equations(neural_points, geo_decoder, config, rot, pos, pc_imu):
-    """(S [18,18] f64 = H^T R_inv H, HtRz [18] f64 = H^T R_inv z, n_valid) in one launch."""
-    x, _, ne = _launch(neural_points, geo_decoder, config, rot, pos, pc_imu, False, True)
-    ne = ne.sum(0)  # the kernel spreads its float64 atomics over 16 line-separated copies
-    S = torch.zeros((18, 18), device=x.device, dtype=torch.float64)
-    iu = torch.triu_indices(6, 6, device=x.device)
-    S[iu[0], iu[1]] = ne[:21]
-    S[iu[1], iu[0]] = ne[:21]
-    b = torch.zeros(18, device=x.device, dtype=torch.float64)
-    b[:6] = ne[21:27]
-    return S, b, int(ne[27].item())  # (the caller solves the 6 x 6 system on the host next: this read-back is its input)
+def normal_equations(neural_points, geo_decoder, config, rot, pos, pc_imu, host: bool = False):
+    """(S [18,18] f64 = H^T R_inv H, HtRz [18] f64 = H^T R_inv z, n_valid) in one launch (+ a one-block finish launch).  The 28
+    sums arrive through pinned host memory; `host=True` returns S and HtRz as CPU tensors (the 6 x 6 solve the caller does next
+    is host-sized work), otherwise they are uploaded in ONE 18 x 19 copy."""
+    b = bind(neural_points, geo_decoder, config, pc_imu)
+    b.launch(rot, pos, False, True, result=True)
+    ne = b.wait_result()
+    SB = np.zeros((18, 19), dtype=np.float64)
+    iu = np.triu_indices(6)
+    SB[iu[0], iu[1]] = ne[:21]
+    SB[iu[1], iu[0]] = ne[:21]
+    SB[:6, 18] = ne[21:27]
+    t = torch.from_numpy(SB)
+    if not host:
+        t = t.to(b.dev)
+    return t[:, :18], t[:, 18], int(ne[27])
 
 
 class IEKFOMMeasurement:

@@ -204,6 +204,41 @@ int clid_track_model_dev(const clid_map_view* mv, const float* W1, const float* 
                      int32_t N, float* sdf_out, float* grad_out, float* pmap_out, int32_t* valid_out,
                      double* normal_eq, void* stream);
 
+/* The measurement model iterated (utils/error_state_iekf.py:286-305 calls h_model up to max_iteration times per scan with the
+ * SAME points and map; only the pose moves): everything of a clid_track_model call that stays fixed over those iterations, built
+ * once per scan by the host (ABI 6).  clid_track_model_call then takes the pose and the reduction buffers only:
+ *   normal_eq   [CLID_TRACK_COPIES][32] float64, ALREADY ZERO (may be NULL: per-point outputs only);
+ *   zero_next   NULL or another [CLID_TRACK_COPIES][32] buffer the launch clears for the next call (a ring of three: accumulate
+ *               into one, clear the next, the previous result stays readable) -- no fill launch per evaluation;
+ *   result      NULL or the DEVICE address of 32 float64 in pinned, host-mapped memory (clid_pinned_alloc): a one-block launch
+ *               behind the model adds the copies up, writes sums [0..27] there and then `epoch` (as a double) into [31]; the
+ *               host polls [31] -- no copy, no stream synchronisation, no torch launches for the 28 numbers. */
+typedef struct clid_track_call {
+  clid_map_view mv;
+  const float* W1; const float* b1; const float* W2; const float* b2;
+  float sdf_scale;
+  int32_t min_nn;
+  float min_grad_norm, max_grad_norm, max_sdf_std;
+  int32_t N;
+  const float* pc_imu;
+  float* sdf_out; float* grad_out; float* pmap_out; int32_t* valid_out;   /* per-point outputs, any may be NULL */
+} clid_track_call;
+int clid_track_model_call(const clid_track_call* c, const float* rot, const float* pos, int32_t pose_on_device,
+                          double* normal_eq, double* zero_next, double* result, double epoch, void* stream);
+/* The outputs of IEKFOM.h_model (utils/error_state_iekf.py:243-262) from the per-point outputs of a clid_track_model call, on
+ * the device: clid_track_valid_count counts the valid points per block of 256 (block_prefix [ceil(N / 256) + 1] int32 receives
+ * the EXCLUSIVE prefix, the total last) and writes the total as a double into result[29], then `epoch` into result[31] (pinned,
+ * host-mapped: the host polls, allocates the four outputs and calls) clid_track_rows, which compacts in point order:
+ *   z [Nv] f64 = sdf,  H [Nv][18] f64 = [p_imu x (R^T g) | g | 0 ... 0] (fp32 products, like the reference's fp32 bmm's),
+ *   valid_points [Nv][3] f32 (map frame),  r_inv [Nv] f64 = 1 / (1 + (|g| - 1)^2) * 0.4 / (0.4 + z^2) * 1000. */
+int clid_track_valid_count(const int32_t* valid, int32_t N, int32_t* block_prefix, double* result, double epoch, void* stream);
+int clid_track_rows(const clid_track_call* c, const float* rot, const float* pos, int32_t pose_on_device,
+                    const int32_t* block_prefix, double* z_out, double* H_out, float* valid_points_out, double* r_inv_out,
+                    void* stream);
+/* `bytes` of pinned host memory mapped into the device's address space: *host_out for the CPU, *dev_out for kernels */
+int clid_pinned_alloc(int64_t bytes, void** host_out, void** dev_out);
+void clid_pinned_free(void* host_ptr);
+
 /* utils/loss.py:44-62 sdf_bce_loss (weighted, mean) + eikonal term (utils/mapper.py:779-798):
  * loss_out[0..2] = total, bce, eikonal (+=, zero it first); d_pred_out [N]; d_g_out [Ng][3]. */
 int clid_loss_fwd_bwd(const float* pred, const float* label, const float* weight, int32_t N,

@@ -35,10 +35,11 @@ def test_struct_layout_matches_the_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "%s"\n'
-        "int main(){printf(\"%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n\", sizeof(clid_map_view),"
+        "int main(){printf(\"%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n\", sizeof(clid_map_view),"
         " sizeof(clid_train_args), sizeof(clid_adam_args), offsetof(clid_map_view, log2cap),"
         " offsetof(clid_train_args, grad), offsetof(clid_adam_args, n_feat), sizeof(clid_cloud_view),"
-        " sizeof(clid_sampler_params), offsetof(clid_cloud_view, resolution), offsetof(clid_sampler_params, pose));"
+        " sizeof(clid_sampler_params), offsetof(clid_cloud_view, resolution), offsetof(clid_sampler_params, pose),"
+        " sizeof(clid_track_call), offsetof(clid_track_call, pc_imu), offsetof(clid_train_args, sched), offsetof(clid_train_args, eik_inv_n));"
         " return 0;}\n" % HEADER
     )
     exe = tmp_path / "sz"
@@ -46,7 +47,8 @@ def test_struct_layout_matches_the_header(tmp_path):
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(_lib.MapView), C.sizeof(_lib.TrainArgs), C.sizeof(_lib.AdamArgs), _lib.MapView.log2cap.offset,
             _lib.TrainArgs.grad.offset, _lib.AdamArgs.n_feat.offset, C.sizeof(_lib.CloudView),
-            C.sizeof(_lib.SamplerParams), _lib.CloudView.resolution.offset, _lib.SamplerParams.pose.offset]
+            C.sizeof(_lib.SamplerParams), _lib.CloudView.resolution.offset, _lib.SamplerParams.pose.offset,
+            C.sizeof(_lib.TrackCall), _lib.TrackCall.pc_imu.offset, _lib.TrainArgs.sched.offset, _lib.TrainArgs.eik_inv_n.offset]
     assert got == want
 
 

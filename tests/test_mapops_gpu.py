@@ -250,3 +250,56 @@ def test_pool_filter_window_capacity_and_order(n_a, n_b, capacity):
         assert capacity <= kept < len(win)
     for got, src in zip(out, (coord, gcoord, label, weight, stamp)):
         assert torch.equal(got[:kept].cpu(), src[want])
+
+
+def test_an_outlier_that_defeats_the_device_side_voxel_ordering_is_recovered_from():
+    """a scan with one point far outside (a bounding box beyond 2^17 voxels per axis) makes the device-side voxel
+    ordering give up.  The pass then publishes ZERO voxels, so the consumers that size themselves by that count on the device
+    (the raw-point map update, the neural-point insert) change nothing, and the host repeats the step through the pass with the
+    library sort at its next read-back: the maps end up exactly as on the path that never left the voxel pass in flight."""
+    from clid_slam_amd import HotPathConfig, LocalPointCloudMap, NeuralPoints
+    from clid_slam_amd.synth import box_room_scan
+    from clid_slam_amd.tools import voxel_down_sample_async
+
+    dev = "cuda:0"
+    cfg = HotPathConfig()
+    cfg.device = dev
+    pts = box_room_scan(n_elev=32, n_azim=512, seed=3).to(dev)
+    pts = torch.cat((pts[:, :3].float(), torch.tensor([[60000.0, -3.0, 1.0]], device=dev))).contiguous()
+    sensor = torch.zeros(3, device=dev, dtype=torch.float64)
+
+    # ---- raw-point map: deferred counts + voxel pass in flight (what Mapper.process_frame arms) vs the plain path
+    maps = []
+    for armed in (False, True):
+        lpm = LocalPointCloudMap(cfg)
+        lpm.update_map(sensor, pts[:2000])        # a first frame through the plain path
+        if armed:
+            lpm._defer_counts = torch.zeros(2, device=dev, dtype=torch.int64)
+            lpm._defer_vox = torch.zeros(2, device=dev, dtype=torch.int64)
+        lpm.update_map(sensor, pts)
+        if armed:
+            assert lpm._count_pending
+            lpm._finish_count()
+            assert getattr(lpm, "vox_fallbacks", 0) == 1
+        maps.append((lpm.local_point_cloud_map.clone(), lpm.buffer_pt_index.clone()))
+    assert maps[0][0].shape == maps[1][0].shape and torch.equal(maps[0][0], maps[1][0]) and torch.equal(maps[0][1], maps[1][1])
+
+    # ---- neural-point map: insert + window on the voxel pass' device-side list vs the plain path
+    res = []
+    for armed in (False, True):
+        torch.manual_seed(0)
+        nm = NeuralPoints(cfg)
+        nm.travel_dist = torch.zeros(4, device=dev)
+        nm.update(pts[:3000], torch.zeros(3, device=dev), torch.eye(3, device=dev), 0)
+        assert nm.update_is_fused()
+        if armed:
+            counts = nm.update_counts(dev)
+            idx = voxel_down_sample_async(pts, nm.resolution, counts[3:5])
+            nm._presampled = (pts, (idx, counts[3:5], None))
+        ratio = nm.update(pts, torch.zeros(3, device=dev), torch.eye(3, device=dev), 1)
+        if armed:
+            assert getattr(nm, "vox_fallbacks", 0) == 1
+        res.append((ratio, nm.neural_points.clone(), nm.buffer_pt_index.clone(), nm.local_neural_points.clone(), nm.global2local.clone()))
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert a.shape == b.shape and torch.equal(a, b)
