@@ -204,6 +204,9 @@ def main():
     ap.add_argument("--diag", action="store_true", help="extra host time stamps around the timed region (start latency of the "
                     "first launch, poll vs synchronize); adds two event polls to the region: measurement aid only")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for single-GPU dry runs)")
+    ap.add_argument("--exchange-ab", default=os.environ.get("CLID_BENCH_EXCHANGE_AB", "rccl"), choices=("none", "rccl", "all"),
+                    help="multi-GPU: extra timed legs in the same processes -- none; rccl = dense and compact payload over RCCL "
+                         "(default); all = also the peer-mapped transport (csrc/p2p.hip: never run across devices yet, opt-in)")
     args = ap.parse_args()
     wl = dict(CONFIGS[args.config])
     if args.bs:
@@ -340,6 +343,7 @@ def main():
         headline = exchange_report(dt)
         legs = {}
         plan = (("rccl_dense", "dense", "rccl"), ("rccl_compact", "compact", "rccl"), ("p2p_compact", "compact", "p2p"))
+        plan = tuple(p for p in plan if args.exchange_ab == "all" or (args.exchange_ab == "rccl" and p[2] == "rccl"))
         for name, mode, transport in plan:
             if headline["mode"] == mode and transport == "rccl":
                 legs[name] = dict(headline, headline=True)

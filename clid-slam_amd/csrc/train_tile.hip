@@ -45,7 +45,7 @@ namespace clid {
 #endif
 constexpr int kTileWavesSmall = CLID_TILE_WAVES_SMALL, kTileWavesLarge = 2;
 #ifndef CLID_TILE_EARLY_REC
-#define CLID_TILE_EARLY_REC 0  // (A/B) the one-tile-per-wave kernels request their record before the weight staging
+#define CLID_TILE_EARLY_REC 1  // the one-tile-per-wave fp32 kernels request their record before the weight staging (0: A/B)
 #endif
 #ifndef CLID_TILE_BLK
 #define CLID_TILE_BLK 1  // block-level dW1 flush of the one-tile-per-wave launches (0: the per-wave form, A/B)
@@ -208,9 +208,12 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
     }
     return rc;
   };
-  // EARLY (one tile per wave): the wave's record is requested BEFORE the decoder weights are staged -- its ~1 us of latency runs
-  // under the staging's two barriers.  (Round 4 measured this on the 224 + 32-register kernel: 31 more live registers put it
-  // at one wave per SIMD; the block-level dW1 flush freed them.)
+  // EARLY (one tile per wave, fp32): the wave's record is requested BEFORE the decoder weights are staged -- its ~1 us of latency
+  // runs under the staging's two barriers (decode 11.93 -> 11.65 us, three alternating runs).  (Round 4 measured this on the
+  // 224 + 32-register kernel: 31 more live registers put it at one wave per SIMD; the block-level dW1 flush freed them.)
+  // Measured and NOT kept on top of it (profiles/r05_decode_chain_experiments.jsonl): the block flush with all 32 operands requested
+  // from LDS in front of four independent product chains, and the merge's 16-row product chains issued in pairs -- together
+  // 11.65 -> 12.0 us: the compiler's own interleaving of LDS reads and products was the better schedule.
   constexpr bool EARLY = CLID_TILE_EARLY_REC && BLK;
   TileRec early;
   if constexpr (EARLY) {

@@ -272,13 +272,14 @@ def test_bench_spawns_its_ranks(tmp_path):
 
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(T.__file__.rsplit("/tests/", 1)[0], "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--frame-calls", "0", "--no-cpu-baseline", "--bs", "2048"]
+           "--frame-calls", "0", "--no-cpu-baseline", "--bs", "2048", "--exchange-ab", "all"]
     out = subprocess.run(cmd + ["--backend", "gloo"], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4096 and line["config"]["bs_per_gpu"] == 2048
     # one run = the A/B of the gradient exchange: the headline on the default (collective, dense at this map size), the
-    # compact payload over the collective, and the compact payload over the peer-mapped buffers, ms per step each
+    # compact payload over the collective, and (--exchange-ab all: opt-in since round 5, the transport has never run across
+    # devices) the compact payload over the peer-mapped buffers, ms per step each
     legs = line["config"]["gradient_exchange"]
     assert set(legs) >= {"rccl_dense", "rccl_compact", "p2p_compact"}
     assert legs["rccl_dense"].get("headline") and abs(legs["rccl_dense"]["ms_per_step"] - line["ms_per_step"]) < 1e-9
