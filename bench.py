@@ -431,9 +431,9 @@ def main():
             "avg_launch_us": dom["avg_us"], "kernels": kernels, "profiled_steps": n_prof,
             "step_bytes": step_bytes, "step_frac_of_peak": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
             "note": "avg_launch_us = mean dispatch begin->end of the kernel (hipExtLaunchKernelGGL start/stop events on the "
-                    "launch stream, the clock rocprofv3 --kernel-trace reports; committed trace: profiles/r04_*_kernel_stats.csv); "
+                    "launch stream, the clock rocprofv3 --kernel-trace reports; committed trace: profiles/r05_*_kernel_stats.csv); "
                     "achieved = SURVEY section 8(d) algorithmic bytes of the launch / that duration; traffic = offline PMC passes "
-                    "(profiles/r04_hbm_traffic.json, FETCH_SIZE / WRITE_SIZE as the guide corrects them); the loop is bound by dependent-launch latency "
+                    "(the file `counters_from` names, FETCH_SIZE / WRITE_SIZE as the guide corrects them); the loop is bound by dependent-launch latency "
                     "and the memory-side atomic rate at this batch size, not by HBM bandwidth (DESIGN.md section 6)",
         }
     sync()

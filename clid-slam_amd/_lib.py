@@ -60,6 +60,8 @@ class TrainArgs(C.Structure):
         ("sched", _vp), ("side_group", _i32), ("side_blocks", _i32),
         # config.ekional_add_to: 0 all / 1 surface / 2 freespace, |label| threshold, 1 / subset size per iteration (device floats)
         ("eik_mask", _i32), ("eik_mask_range", _f32), ("eik_inv_n", _vp),
+        # ABI 7: config.main_loss_type (0 bce / 1 sdf_l1 / 2 sdf_l2 / 3 zhong); ba_done_flag: per-frame poses [n_pose][12] fp32
+        ("main_loss_type", _i32), ("n_pose", _i32), ("pool_pose", _vp),
     ]
 
 
@@ -242,7 +244,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.clid_abi_version() != 6:
+    if lib.clid_abi_version() != 7:
         raise RuntimeError("libclid_native.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -397,6 +397,18 @@ __device__ __forceinline__ bool search_task(const clid_map_view& mv, const clid_
   const bool live = qd.p >= 0;
   const long long s = index[live ? qd.p : 0];
   float px = ta.pool_coord[s * 3 + 0], py = ta.pool_coord[s * 3 + 1], pz = ta.pool_coord[s * 3 + 2];
+  if (ta.pool_pose) {
+    // Mapper.ba_done_flag (mapper.py:646-658): the pool is in the samples' sensor frames; bmm(R, p) + t of
+    // utils/tools.py:612-636 with the pose of the sample's frame, products and sums unfused in that order
+    int fr = ta.pool_ts[s];
+    fr = fr < 0 ? 0 : (fr >= ta.n_pose ? ta.n_pose - 1 : fr);
+    const float4* T = reinterpret_cast<const float4*>(ta.pool_pose) + (size_t)fr * 3;
+    const float4 r0 = T[0], r1 = T[1], r2 = T[2];
+    const float x = px, y = py, z = pz;
+    px = fadd(fadd(fadd(fmul(r0.x, x), fmul(r0.y, y)), fmul(r0.z, z)), r0.w);
+    py = fadd(fadd(fadd(fmul(r1.x, x), fmul(r1.y, y)), fmul(r1.z, z)), r1.w);
+    pz = fadd(fadd(fadd(fmul(r2.x, x), fmul(r2.y, y)), fmul(r2.z, z)), r2.w);
+  }
   if (qd.axis == 0) px = fadd(px, qd.sign * ta.fd_eps);  // x + [eps,0,0] in fp32 (mapper.py:988-999)
   if (qd.axis == 1) py = fadd(py, qd.sign * ta.fd_eps);
   if (qd.axis == 2) pz = fadd(pz, qd.sign * ta.fd_eps);
@@ -1446,6 +1458,21 @@ static int check_train_args(const clid_map_view* mv, const clid_train_args* a, c
   if (a->decode_each_neighbour && (a->eikonal_mode == 2 || a->cbuf)) {
     clid_set_error("%s: decode_each_neighbour (weighted_first: False) needs the hoisted schedule, eikonal mode 0 or 1 and the plain exchange", who);
     return CLID_E_ARG;
+  }
+  if (a->main_loss_type) {
+    if (a->main_loss_type < 0 || a->main_loss_type > 3 || a->eikonal_mode == 2 || a->decode_each_neighbour || !hoisted(a) ||
+        !decode_variant_for(a)) {
+      clid_set_error("%s: main_loss_type %d (config.main_loss_type sdf_l1 / sdf_l2 / zhong) needs the hoisted schedule, a tile "
+                     "decode kernel, eikonal mode 0 or 1 and weighted_first", who, a->main_loss_type);
+      return CLID_E_ARG;
+    }
+  }
+  if (a->pool_pose) {
+    if (!a->pool_ts || a->n_pose <= 0 || !hoisted(a) || ((uintptr_t)a->pool_pose & 15) != 0) {
+      clid_set_error("%s: pool_pose (Mapper.ba_done_flag) needs pool_ts, n_pose > 0, 16-byte alignment and the hoisted schedule "
+                     "(the poses are applied by clid_train_search)", who);
+      return CLID_E_ARG;
+    }
   }
   if (a->eik_mask) {
     if (a->eik_mask < 0 || a->eik_mask > 2 || !a->eik_inv_n || a->eikonal_mode != 1 || a->decode_each_neighbour ||

@@ -144,8 +144,9 @@ __device__ __forceinline__ void tile_lds_fence() {
 #endif
 // PRE: the tiles' row numbers come from the search launch's number blocks (small launches on maps within one L2: see
 // clid_tiles_prenumbered); otherwise the kernel numbers in place
-// EM: config.ekional_add_to "surface" / "freespace" (its own instantiations: the default ones are register-tight, three more
-// live values put the headline kernel at 226 + 32 > 256 registers = one wave per SIMD)
+// EM: the reference's non-default loop branches -- config.ekional_add_to "surface" / "freespace" and config.main_loss_type
+// "sdf_l1" / "sdf_l2" / "zhong" (their own instantiations: the default ones are register-tight, three more live values put the
+// headline kernel at 226 + 32 > 256 registers = one wave per SIMD)
 template <int PREC, bool LN, int TW, bool PRE, int WPS = 0, bool EM = false>
 __global__ void __launch_bounds__(TW * 64, CLID_TILE_WAVES)
 k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap,
@@ -172,7 +173,7 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
   const float inv_two_eps = fdiv(1.0f, 2.0f * ta.fd_eps);
   // config.ekional_add_to (utils/mapper.py:779-789): "surface" / "freespace" restrict the eikonal mean to the decimated samples
   // with |label| below / not below the surface range; the subset's size was counted by the search launch
-  const float inv_n_eik = EM ? ta.eik_inv_n[ta.touch_iter] : ta.inv_n_eik;  // (uniform: a scalar load)
+  const float inv_n_eik = (EM && ta.eik_mask) ? ta.eik_inv_n[ta.touch_iter] : ta.inv_n_eik;  // (uniform: a scalar load)
   float* __restrict__ rows = ta.grad + CLID_GRAD_FEAT_OFFSET16;
   const float4* __restrict__ feat4 = reinterpret_cast<const float4*>(mv.feat);
   const float4* __restrict__ pos4 = reinterpret_cast<const float4*>(mv.pos4);
@@ -513,7 +514,7 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
         bool inmask = true;
         if constexpr (EM) {  // the decimated sample (slot 6 of the bundle) decides for its six copies
           const float lab6 = __shfl(qq.z, b8 + 6, 64);
-          inmask = (fabsf(lab6) < ta.eik_mask_range) == (ta.eik_mask == 1);
+          if (ta.eik_mask) inmask = (fabsf(lab6) < ta.eik_mask_range) == (ta.eik_mask == 1);
         }
         if (slot == 6 && g == 0 && inmask) eik_acc += (nrm - 1.f) * (nrm - 1.f);
         ecoef = (nrm > 0.f && inmask) ? ta.weight_e * 2.f * (nrm - 1.f) * inv_n_eik * inv_two_eps / nrm : 0.f;
@@ -521,13 +522,27 @@ k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial,
       if (p >= 0) {
         if (code < 0) {
           const float label = qq.z, wt = qq.w;
-          const float z = sdf * inv_sigma;
-          const float tgt = __frcp_rn(1.0f + __expf(-label * inv_sigma));  // loss.py:60
-          const float ez = __expf(-fabsf(z));
-          const float sg = (z >= 0.f ? 1.0f : ez) * __frcp_rn(1.0f + ez);
-          const float li = fmaxf(z, 0.f) - z * tgt + __logf(1.0f + ez);    // BCEWithLogits
-          if (g == 0) bce_acc += wt * li;
-          delta = wt * (sg - tgt) * inv_sigma * ta.inv_n_main;
+          if (!EM || ta.main_loss_type == 0) {
+            const float z = sdf * inv_sigma;
+            const float tgt = __frcp_rn(1.0f + __expf(-label * inv_sigma));  // loss.py:60
+            const float ez = __expf(-fabsf(z));
+            const float sg = (z >= 0.f ? 1.0f : ez) * __frcp_rn(1.0f + ez);
+            const float li = fmaxf(z, 0.f) - z * tgt + __logf(1.0f + ez);    // BCEWithLogits
+            if (g == 0) bce_acc += wt * li;
+            delta = wt * (sg - tgt) * inv_sigma * ta.inv_n_main;
+          } else if (ta.main_loss_type == 3) {
+            // sdf_zhong_loss (loss.py:66-84, trunc_dist None): |pred - label / 2| - |label / 2| where positive, else 0
+            const float mid = label * 0.5f, sh = sdf - mid;
+            const bool on = fabsf(sh) > fabsf(mid);
+            if (g == 0 && on) bce_acc += wt * (fabsf(sh) - fabsf(mid));
+            delta = on ? wt * (sh > 0.f ? 1.0f : (sh < 0.f ? -1.0f : 0.f)) * ta.inv_n_main : 0.f;
+          } else {
+            // sdf_diff_loss (loss.py:9-17, scale 1): weight * diff^2 ("sdf_l2") or weight * |diff| ("sdf_l1"), summed / count
+            const float diff = sdf - label;
+            const bool l2 = ta.main_loss_type == 2;
+            if (g == 0) bce_acc += wt * (l2 ? diff * diff : fabsf(diff));
+            delta = wt * (l2 ? 2.0f * diff : (diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.f))) * ta.inv_n_main;
+          }
         } else {
           const int axis = code >> 1;
           const float ga = axis == 0 ? gx : (axis == 1 ? gy : gz);
@@ -786,7 +801,7 @@ int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, f
 #define CLID_TILE_LAUNCH(P, L)                                                                                        \
   do {                                                                                                                \
     const bool small = tile_waves_for(n_tiles) == kTileWavesSmall;                                                    \
-    if (a->eik_mask) { /* config.ekional_add_to surface / freespace: the masked instantiations */                     \
+    if (a->eik_mask || a->main_loss_type) { /* config.ekional_add_to surface / freespace, main_loss_type != bce */     \
       if (small && pre) CLID_TILE_LAUNCH_K((k_decode_tile<P, L, kTileWavesSmall, true, 0, true>), kTileWavesSmall);   \
       else if (small) CLID_TILE_LAUNCH_K((k_decode_tile<P, L, kTileWavesSmall, false, 0, true>), kTileWavesSmall);    \
       else CLID_TILE_LAUNCH_K((k_decode_tile<P, L, kTileWavesLarge, false, 0, true>), kTileWavesLarge);               \

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import torch
@@ -230,6 +231,9 @@ class Mapper:
         nrm = self.normal_label_pool[index, :] if self.normal_label_pool is not None else None
         return coord, self.sdf_label_pool[index], self.time_pool[index], nrm, sem, col, self.weight_pool[index]
 
+    # config.main_loss_type -> clid_train_args.main_loss_type (utils/mapper.py:751-767)
+    MAIN_LOSS_TYPES = {"bce": 0, "sdf_l1": 1, "sdf_l2": 2, "zhong": 3}
+
     # ------------------------------------------------------------------ a11
     def _check_fused_config(self):
         c = self.config
@@ -242,10 +246,8 @@ class Mapper:
             bad.append("consistency_loss_on")
         if getattr(c, "proj_correction_on", False):
             bad.append("proj_correction_on")
-        if c.main_loss_type != "bce":
-            bad.append(f"main_loss_type={c.main_loss_type}")
-        if self.ba_done_flag:
-            bad.append("ba_done_flag")
+        if c.main_loss_type not in self.MAIN_LOSS_TYPES:
+            sys.exit("Please choose a valid loss type")  # utils/mapper.py:766-767
         add_to = getattr(c, "ekional_add_to", "all")
         if c.ekional_loss_on and add_to not in ("all", "surface", "freespace"):
             bad.append(f"ekional_add_to={add_to}")
@@ -317,6 +319,17 @@ class Mapper:
         pool_w = _lib.require_cuda(self.weight_pool, "weight_pool", torch.float32)
 
         ta = _lib.TrainArgs()
+        if self.ba_done_flag:
+            # utils/mapper.py:646-658: the poses of old frames moved (bundle adjustment) and global_coord_pool is stale until the
+            # next process_frame re-projects it: get_batch hands out the sensor-frame coordinates and every sample is moved by
+            # the pose of ITS frame -- here inside the search launch's gather (clid_train_args.pool_pose)
+            pool_coord = _lib.require_cuda(self.coord_pool, "coord_pool", torch.float32)
+            poses = self.used_poses
+            if poses is None or poses.dim() != 3 or pipeline != 1:
+                raise NotImplementedError("fused mapping loop: ba_done_flag needs used_poses [frames, 4, 4] and the hoisted schedule")
+            pose34 = poses[:, :3, :].to(device=dev, dtype=torch.float32).contiguous()  # (`.to(points)` of utils/tools.py:624-625)
+            keep = (keep, pose34)
+            ta.pool_pose, ta.n_pose = pose34.data_ptr(), int(pose34.shape[0])
         ta.pool_coord, ta.pool_label, ta.pool_ts, ta.pool_weight = (
             pool_coord.data_ptr(), pool_label.data_ptr(), pool_ts.data_ptr(), pool_w.data_ptr())
         ta.bs, ta.decimation, ta.batch_offset = bs_local, decim, batch_offset
@@ -324,6 +337,9 @@ class Mapper:
         ta.inv_n_main, ta.inv_n_eik = 1.0 / bs_global, 1.0 / n_eik_global
         ta.sigma, ta.weight_e = float(self.sdf_scale), float(cfg.weight_e)
         ta.loss_weight_on, ta.eikonal_mode, ta.train_decoder = int(bool(cfg.loss_weight_on)), eik_mode, int(train_decoder)
+        ta.main_loss_type = self.MAIN_LOSS_TYPES[cfg.main_loss_type]
+        if ta.main_loss_type in (1, 2):
+            ta.loss_weight_on = 1  # sdf_diff_loss applies the sample weight whatever config.loss_weight_on says (utils/loss.py:9-17)
         ta.W1, ta.b1, ta.W2, ta.b2 = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr()
         ta.sdf_scale = float(self.geo_mlp.sdf_scale)
         ta.grad, ta.ws = grad.data_ptr(), self._ws.data_ptr()

@@ -350,6 +350,19 @@ typedef struct clid_train_args {
   int32_t eik_mask;
   float eik_mask_range;
   float* eik_inv_n;
+  /* ---- ABI 7: two more branches of the reference's loop body.
+   * main_loss_type = config.main_loss_type (utils/mapper.py:751-767): 0 "bce" (utils/loss.py:44-62; every shipped config),
+   * 1 "sdf_l1", 2 "sdf_l2" (sdf_diff_loss, utils/loss.py:9-17: the sample weight is ALWAYS applied -- the caller sets
+   * loss_weight_on = 1 so that the search records carry it), 3 "zhong" (sdf_zhong_loss, utils/loss.py:66-84, trunc_dist None).
+   * Non-zero values run on the tile decode kernels of the hoisted schedule (eikonal modes 0 / 1, weighted_first); loss_out[1]
+   * is then that loss.
+   * pool_pose != NULL = Mapper.ba_done_flag (utils/mapper.py:646-658): `pool_coord` holds the samples in their SENSOR frames
+   * (Mapper.coord_pool) and a sample drawn from frame ts = pool_ts[s] is moved to the world frame by row ts of
+   * pool_pose [n_pose][12] (fp32, the upper 3 x 4 block of used_poses[ts], row-major) as utils/tools.py:612-636 does:
+   * ((r0 x + r1 y) + r2 z) + t per coordinate, unfused.  Needs pool_ts; ts is clamped to [0, n_pose). */
+  int32_t main_loss_type;
+  int32_t n_pose;
+  const float* pool_pose;
 } clid_train_args;
 
 /* Schedule object for clid_train_args.sched.  cu_mask / mask_words as hipExtStreamCreateWithCUMask takes them (bit i set =

@@ -273,6 +273,41 @@ def sdf_bce_loss(pred, label, sigma, weight, weighted=False, bce_reduction="mean
     )
 
 
+def sdf_diff_loss(pred, label, weight, scale=1.0, l2_loss=True):
+    """utils/loss.py:9-17 (`main_loss_type` "sdf_l2" / "sdf_l1"; the weight is always applied)."""
+    diff_m = (pred - label) / scale
+    return (weight * (diff_m**2 if l2_loss else diff_m.abs())).sum() / pred.shape[0]
+
+
+def sdf_zhong_loss(pred, label, trunc_dist=None, weight=None, weighted=False):
+    """utils/loss.py:66-84 (`main_loss_type` "zhong"): L1 distance to the segment between 0 and the label."""
+    mid = label / 2.0
+    shift_abs = (pred - mid).abs()
+    mask = shift_abs > mid.abs()
+    loss = torch.where(mask, shift_abs - mid.abs(), torch.zeros_like(label))
+    if trunc_dist is not None:
+        loss = torch.where(label.abs() < trunc_dist, (pred - label).abs(), loss)
+    return (loss * (weight if weighted else 1.0)).mean()
+
+
+def main_loss(lc, pred, label, weight):
+    """The `main_loss_type` switch of utils/mapper.py:751-767."""
+    if lc.main_loss_type == "bce":
+        return sdf_bce_loss(pred, label, lc.sigma, weight, lc.loss_weight_on)
+    if lc.main_loss_type == "zhong":
+        return sdf_zhong_loss(pred, label, None, weight, lc.loss_weight_on)
+    if lc.main_loss_type in ("sdf_l1", "sdf_l2"):
+        return sdf_diff_loss(pred, label, weight, l2_loss=lc.main_loss_type == "sdf_l2")
+    raise SystemExit("Please choose a valid loss type")
+
+
+def transform_batch(points: torch.Tensor, transformation: torch.Tensor) -> torch.Tensor:
+    """utils/tools.py:612-636: bmm(R, p) + t with the poses cast to the points' dtype."""
+    rot = transformation[:, :3, :3].to(points)
+    trans = transformation[:, :3, 3:].to(points)
+    return (torch.bmm(rot, points.unsqueeze(-1)) + trans).squeeze(-1)
+
+
 def eikonal_loss(g: torch.Tensor) -> torch.Tensor:
     """utils/mapper.py:795-797 (`ekional_add_to == "all"`)."""
     return ((g.norm(2, dim=-1) - 1.0) ** 2).mean()
@@ -312,6 +347,15 @@ class SamplePool:
     sdf_label: torch.Tensor  # [S]
     time: torch.Tensor  # [S] int32
     weight: torch.Tensor  # [S]
+    # Mapper.ba_done_flag (utils/mapper.py:646-658): sensor-frame coordinates + used_poses [frames,4,4]; None = global_coord is current
+    local_coord: Optional[torch.Tensor] = None
+    used_poses: Optional[torch.Tensor] = None
+
+    def coord_of(self, index):
+        """What the loop body trains on: utils/mapper.py:646-658."""
+        if self.used_poses is None:
+            return self.global_coord[index]
+        return transform_batch(self.local_coord[index], self.used_poses[self.time[index].long()])
 
 
 @dataclass
@@ -331,6 +375,7 @@ class LoopConfig:
     fd_first: int = 0  # sharded runs: local position of the first decimated sample
     ekional_add_to: str = "all"  # utils/mapper.py:779-789: "all" | "surface" | "freespace"
     surface_sample_range_m: float = 0.25  # config: the |sdf_label| threshold of the surface mask (utils/mapper.py:692-694)
+    main_loss_type: str = "bce"  # utils/mapper.py:751-767: "bce" | "zhong" | "sdf_l1" | "sdf_l2"
 
 
 def draw_batch_index(pool_count: int, new_idx: Optional[torch.Tensor], bs: int, bs_new_sample: int, gen=None):
@@ -346,7 +391,7 @@ def draw_batch_index(pool_count: int, new_idx: Optional[torch.Tensor], bs: int, 
 def loss_and_grads(st: MapState, dec: DecoderParams, pool: SamplePool, index: torch.Tensor, lc: LoopConfig):
     """One iteration body of utils/mapper.py:642-835 up to `backward()`; returns a dict with the
     loss triple, sdf_pred and the gradients of the feature table and decoder tensors."""
-    coord = pool.global_coord[index]
+    coord = pool.coord_of(index)
     label = pool.sdf_label[index]
     ts = pool.time[index]
     weight = pool.weight[index].abs()
@@ -368,7 +413,7 @@ def loss_and_grads(st: MapState, dec: DecoderParams, pool: SamplePool, index: to
     elif lc.ekional_loss_on and lc.numerical_grad:
         g = numerical_gradient(st, dec, coord[lc.fd_first :: lc.gradient_decimation], lc.fd_eps)
     n_main = sdf_pred.shape[0]
-    l_bce = sdf_bce_loss(sdf_pred, label, lc.sigma, weight, lc.loss_weight_on)
+    l_bce = main_loss(lc, sdf_pred, label, weight)  # (named after the default; utils/mapper.py:751-767)
     total = l_bce
     l_eik = torch.zeros(())
     if lc.ekional_loss_on and lc.weight_e > 0 and g is not None:
@@ -417,9 +462,12 @@ def relu_ambiguous_rows(st: MapState, dec: DecoderParams, pool: SamplePool, inde
     loss of utils/mapper.py:746-798 restated on the SDFs of all bs + 6 n_fd points as leaves.  A checker then holds a listed
     row to strict tolerance + this bound instead of a blanket looser bar.  None where the bound is not derived
     (`weighted_first: False`, analytic eikonal, sharded normalisers).  Fourth value: bool [M + 1], the rows ANY query point of
-    the iteration gathers (a row outside it must receive an exactly-zero gradient from any correct implementation)."""
+    the iteration gathers (a row outside it must receive an exactly-zero gradient from any correct implementation).  Fifth
+    value: the same bound for the DECODER's gradient, [H D + 2 H + 1] floats in the order W1 | b1 | W2 | b2: opening or closing
+    unit h for query q moves dW1[h, c] by |dL/dsdf_q| sdf_scale |W2[h]| |f_q[c]|, db1[h] by the same without f, and dW2[h]
+    by at most |dL/dsdf_q| sdf_scale tau (the unit's activation is inside the band); None where not derived."""
     with torch.no_grad():
-        coord = pool.global_coord[index]
+        coord = pool.coord_of(index)
         pts = [coord]
         n_fd = 0
         if lc.ekional_loss_on and lc.numerical_grad:
@@ -449,11 +497,11 @@ def relu_ambiguous_rows(st: MapState, dec: DecoderParams, pool: SamplePool, inde
         return rows_u, n_q
     derivable = (st.weighted_first and lc.loss_scale_counts is None and (lc.numerical_grad or not lc.ekional_loss_on))
     if not derivable:
-        return rows_u, n_q, None, gathered
+        return rows_u, n_q, None, gathered, None
     bs = coord.shape[0]
     sdf = mlp_sdf(dec, f).detach().requires_grad_(True)
     weight = pool.weight[index].abs()
-    total = sdf_bce_loss(sdf[:bs], pool.sdf_label[index], lc.sigma, weight, lc.loss_weight_on)
+    total = main_loss(lc, sdf[:bs], pool.sdf_label[index], weight)
     if n_fd > 0 and lc.weight_e > 0:
         s = sdf[bs:].unsqueeze(-1)
         g = torch.cat([(s[2 * a * n_fd:(2 * a + 1) * n_fd] - s[(2 * a + 1) * n_fd:(2 * a + 2) * n_fd]) / (2 * lc.fd_eps)
@@ -471,7 +519,11 @@ def relu_ambiguous_rows(st: MapState, dec: DecoderParams, pool: SamplePool, inde
         if st.layer_norm_on:
             var = st.local_geo_features.detach().var(dim=1, unbiased=False)
             slack = slack / torch.sqrt(var + 1e-5)
-    return rows_u, n_q, slack, gathered
+        dz = dsdf.abs() * abs(float(dec.sdf_scale))                                  # [Q]
+        gate = amb_u.to(unit.dtype) * dz[:, None]                                  # [Q, H]
+        gw = gate * dec.W2.reshape(-1).abs()[None, :]
+        dec_slack = torch.cat(((gw.t() @ f.abs()).reshape(-1), gw.sum(dim=0), gate.sum(dim=0) * tau, torch.zeros(1, dtype=unit.dtype)))
+    return rows_u, n_q, slack, gathered, dec_slack
 
 
 def mapping_iters(st: MapState, dec: DecoderParams, pool: SamplePool, index_seq, lc: LoopConfig, record=False,
@@ -489,7 +541,8 @@ def mapping_iters(st: MapState, dec: DecoderParams, pool: SamplePool, index_seq,
         amb = relu_ambiguous_rows(st, dec, pool, index_seq[it], lc, ambiguity_tau, with_slack=True) if (record and ambiguity_tau) else None
         out = loss_and_grads(st, dec, pool, index_seq[it], lc)
         if amb is not None:
-            out["ambiguous_rows"], out["ambiguous_queries"], out["ambiguous_row_slack"], out["gathered_rows"] = amb
+            (out["ambiguous_rows"], out["ambiguous_queries"], out["ambiguous_row_slack"], out["gathered_rows"],
+             out["ambiguous_decoder_slack"]) = amb
         with torch.no_grad():
             if lc.train_decoder:
                 for name, t, s in zip(("W1", "b1", "W2", "b2"), dec.tensors(), ad_dec):

@@ -264,13 +264,20 @@ def main():
     # config.ekional_add_to "surface" / "freespace" (utils/mapper.py:779-789; after the five cases above, whose files stay as
     # they were: every case seeds its own draws)
     cases += [("numerical", False, False, "surface"), ("numerical", False, False, "freespace")]
-    for mode, frozen, ln, add_to in cases:
+    cases = [c + ("bce", False) for c in cases]
+    # config.main_loss_type "sdf_l1" / "sdf_l2" / "zhong" (utils/mapper.py:751-767) and Mapper.ba_done_flag (:646-658: the pool in
+    # the samples' sensor frames, moved by used_poses[ts] inside the loop) -- appended, so the files above stay as they were
+    cases += [("numerical", False, False, "all", lt, False) for lt in ("sdf_l1", "sdf_l2", "zhong")]
+    cases += [("numerical", False, False, "all", "bce", True)]
+    for mode, frozen, ln, add_to, loss_type, ba in cases:
         for _once in (0,):
             for _once2 in (0,):
-                tag = f"{mode}_{'frozen' if frozen else 'train'}_ln{int(ln)}" + ("" if add_to == "all" else f"_eik{add_to}")
+                tag = (f"{mode}_{'frozen' if frozen else 'train'}_ln{int(ln)}" + ("" if add_to == "all" else f"_eik{add_to}")
+                       + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else ""))
                 cfg6 = ref_config(ref, bs=BS, bs_new_sample=200)
                 cfg6.layer_norm_on = ln
                 cfg6.ekional_add_to = add_to
+                cfg6.main_loss_type = loss_type
                 if mode == "analytic":
                     cfg6.numerical_grad = False
                     cfg6.gradient_decimation = 1
@@ -294,6 +301,25 @@ def main():
                 mp.pool_sample_count = pool["coord"].shape[0]
                 mp.cur_sample_count = int((pool["time"] == 2).sum())
                 mp.used_poses = torch.eye(4, dtype=torch.float64)[None].repeat(3, 1, 1)
+                if ba:
+                    # three non-trivial frame poses; the sensor-frame pool is what maps onto the scene through them (fp32
+                    # rounding apart), the world-frame pool is stale (as after a bundle adjustment) and must not be read
+                    gp = torch.Generator().manual_seed(23)
+                    ang = (torch.rand(3, 3, generator=gp, dtype=torch.float64) - 0.5) * 0.6
+                    poses = torch.eye(4, dtype=torch.float64)[None].repeat(3, 1, 1)
+                    for fi in range(3):
+                        ax, ay, az = [float(v) for v in ang[fi]]
+                        Rx = torch.tensor([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]], dtype=torch.float64)
+                        Ry = torch.tensor([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]], dtype=torch.float64)
+                        Rz = torch.tensor([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]], dtype=torch.float64)
+                        poses[fi, :3, :3] = Rz @ Ry @ Rx
+                        poses[fi, :3, 3] = (torch.rand(3, generator=gp, dtype=torch.float64) - 0.5) * 8.0
+                    P = poses[pool["time"].long()]
+                    local = torch.bmm(P[:, :3, :3].transpose(1, 2), (pool["coord"].double() - P[:, :3, 3]).unsqueeze(-1)).squeeze(-1)
+                    mp.coord_pool = local.to(torch.float32)
+                    mp.global_coord_pool = pool["coord"] + 0.37  # stale
+                    mp.used_poses = poses
+                    mp.ba_done_flag = True
                 mp.adaptive_iter_offset = 0
                 new_start = mp.pool_sample_count - mp.cur_sample_count
                 gnew = torch.Generator().manual_seed(11)
@@ -358,8 +384,21 @@ def main():
                     losses["total"].append(float(self))
                     return real_backward(self, *a, **k)
 
+                real_diff, real_zhong = ref_mapper_mod.sdf_diff_loss, ref_mapper_mod.sdf_zhong_loss
+
+                def rec_diff(*a, **k):
+                    v = real_diff(*a, **k)
+                    losses["bce"].append(float(v))  # (the main loss, whatever its type)
+                    return v
+
+                def rec_zhong(*a, **k):
+                    v = real_zhong(*a, **k)
+                    losses["bce"].append(float(v))
+                    return v
+
                 ref_mapper_mod.setup_optimizer = hooked_setup
                 ref_mapper_mod.sdf_bce_loss = rec_bce
+                ref_mapper_mod.sdf_diff_loss, ref_mapper_mod.sdf_zhong_loss = rec_diff, rec_zhong
                 torch.Tensor.backward = rec_backward
                 torch.randint = rec_randint
                 torch.manual_seed(1234)
@@ -370,13 +409,14 @@ def main():
                     torch.Tensor.backward = real_backward
                     ref_mapper_mod.setup_optimizer = real_setup
                     ref_mapper_mod.sdf_bce_loss = real_bce
+                    ref_mapper_mod.sdf_diff_loss, ref_mapper_mod.sdf_zhong_loss = real_diff, real_zhong
 
                 assert len(per_iter) == ITERS and len(draws) == 2 * ITERS, (len(per_iter), len(draws))
                 index_seq = []
                 for it in range(ITERS):
                     hist, pick = draws[2 * it], draws[2 * it + 1]
                     index = torch.cat((hist, mp.new_idx[pick]), 0)
-                    assert torch.equal(pool["coord"][index], batches[it][0])
+                    assert torch.equal((mp.coord_pool if ba else pool["coord"])[index], batches[it][0])
                     index_seq.append(index)
                 out = {
                     "index_seq": torch.stack(index_seq).to(torch.int32).numpy(),
@@ -385,6 +425,9 @@ def main():
                     "loss_bce": np.array(losses["bce"]), "loss_total": np.array(losses["total"]),
                     "W1_init": None,
                 }
+                if ba:
+                    out["ba_coord_pool"] = mp.coord_pool.numpy()
+                    out["ba_used_poses"] = mp.used_poses.numpy()
                 torch.manual_seed(42)
                 dec_init = ref.Decoder(cfg6, cfg6.geo_mlp_hidden_dim, cfg6.geo_mlp_level, 1)
                 out.pop("W1_init")

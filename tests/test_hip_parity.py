@@ -189,14 +189,33 @@ def test_mapping_loop_g6_ekional_add_to(env, add_to):
     test_mapping_loop_g6(env, "numerical", False, 0, add_to)
 
 
+@pytest.mark.parametrize("loss_type", ["sdf_l1", "sdf_l2", "zhong"])
+def test_mapping_loop_g6_main_loss_type(env, loss_type):
+    """config.main_loss_type "sdf_l1" / "sdf_l2" / "zhong" (utils/mapper.py:751-767, utils/loss.py:9-17, 66-84) against the
+    reference's own loop, on the tile decode kernels."""
+    g_bce = gio.load("g6_loop_numerical_train_ln0.npz")
+    g = gio.load(f"g6_loop_numerical_train_ln0_{loss_type}.npz")
+    assert abs(float(g["loss_total"][0]) - float(g_bce["loss_total"][0])) > 1e-3  # (the fixture really is another loss)
+    test_mapping_loop_g6(env, "numerical", False, 0, "all", loss_type)
+
+
+def test_mapping_loop_g6_ba_done_flag(env):
+    """Mapper.ba_done_flag (utils/mapper.py:646-658): the batch comes from the sensor-frame pool and every sample is moved by the
+    pose of its own frame (utils/tools.py:612-636) -- inside the search launch's gather here; the (stale) world-frame pool is not
+    read by the loop."""
+    test_mapping_loop_g6(env, "numerical", False, 0, "all", "bce", True)
+
+
 @pytest.mark.parametrize("mode,frozen,ln", G6)
-def test_mapping_loop_g6(env, mode, frozen, ln, add_to="all"):
+def test_mapping_loop_g6(env, mode, frozen, ln, add_to="all", loss_type="bce", ba=False):
     from clid_slam_amd.tools import freeze_model
 
-    tag = f"{mode}_{'frozen' if frozen else 'train'}_ln{ln}" + ("" if add_to == "all" else f"_eik{add_to}")
+    tag = (f"{mode}_{'frozen' if frozen else 'train'}_ln{ln}" + ("" if add_to == "all" else f"_eik{add_to}")
+           + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else ""))
     g = gio.load(f"g6_loop_{tag}.npz")
     p = gio.load("pool.npz")
-    cfg = env.config(layer_norm_on=bool(ln), bs=int(g["index_seq"].shape[1]), bs_new_sample=200, ekional_add_to=add_to)
+    cfg = env.config(layer_norm_on=bool(ln), bs=int(g["index_seq"].shape[1]), bs_new_sample=200, ekional_add_to=add_to,
+                     main_loss_type=loss_type)
     if mode == "analytic":
         cfg.numerical_grad, cfg.gradient_decimation = False, 1
     nm = env.neural_points(cfg, base=p)
@@ -204,6 +223,11 @@ def test_mapping_loop_g6(env, mode, frozen, ln, add_to="all"):
     if frozen:
         freeze_model(dec)
     mp, _ = env.mapper(cfg, nm, dec)
+    if ba:
+        mp.coord_pool = gio.T(g["ba_coord_pool"]).cuda()
+        mp.used_poses = gio.T(g["ba_used_poses"]).cuda()
+        mp.global_coord_pool = mp.global_coord_pool + 0.37  # stale, as after a bundle adjustment: only the batch ordering may look at it
+        mp.ba_done_flag = True
     idx = gio.T(g["index_seq"]).to(torch.int64).cuda()
     iters = idx.shape[0]
     mp.mapping(iters, index_seq=idx)

@@ -110,18 +110,30 @@ def test_adam_matches_torch_optim():
 G6 = [("numerical", False, 0, "all"), ("numerical", False, 1, "all"), ("numerical", True, 0, "all"), ("analytic", False, 0, "all"),
       ("analytic", True, 0, "all"),
       # config.ekional_add_to (utils/mapper.py:779-789): the eikonal mean over the near-surface / the free-space decimated samples
-      ("numerical", False, 0, "surface"), ("numerical", False, 0, "freespace")]
+      ("numerical", False, 0, "surface"), ("numerical", False, 0, "freespace"),
+      # config.main_loss_type (utils/mapper.py:751-767) and Mapper.ba_done_flag (utils/mapper.py:646-658)
+      ("numerical", False, 0, "all", "sdf_l1"), ("numerical", False, 0, "all", "sdf_l2"), ("numerical", False, 0, "all", "zhong"),
+      ("numerical", False, 0, "all", "bce", True)]
 
 
-@pytest.mark.parametrize("mode,frozen,ln,add_to", G6)
-def test_g6_mapping_loop(mode, frozen, ln, add_to):
-    tag = f"{mode}_{'frozen' if frozen else 'train'}_ln{ln}" + ("" if add_to == "all" else f"_eik{add_to}")
+@pytest.mark.parametrize("case", G6, ids=lambda c: "-".join(str(x) for x in c))
+def test_g6_mapping_loop(case):
+    mode, frozen, ln, add_to, loss_type, ba = tuple(case) + ("all", "bce", False)[len(case) - 3:]
+    tag = (f"{mode}_{'frozen' if frozen else 'train'}_ln{ln}" + ("" if add_to == "all" else f"_eik{add_to}")
+           + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else ""))
     g = gio.load(f"g6_loop_{tag}.npz")
     st = gio.map_state(layer_norm_on=bool(ln))
     pool, praw = gio.sample_pool()
+    if ba:  # the pool in the samples' sensor frames + the frames' poses; the world-frame pool is stale and must not be read
+        pool.local_coord, pool.used_poses = gio.T(g["ba_coord_pool"]), gio.T(g["ba_used_poses"])
+        pool.global_coord = pool.global_coord + 0.37
+        moved = O.transform_batch(pool.local_coord, pool.used_poses[pool.time.long()])
+        assert 0 < float((moved - gio.T(praw["coord"])).abs().max()) < 1e-5  # (the poses map the sensor frames back onto the scene)
     dec = gio.decoder(g, "init_")
+    if loss_type != "bce":
+        dec.sdf_scale = 1.0  # model/decoder.py:51-53: the decoder's output scale is the logistic sigma only for the BCE loss
     lc = O.LoopConfig(numerical_grad=(mode == "numerical"), gradient_decimation=10 if mode == "numerical" else 1,
-                      train_decoder=not frozen, ekional_add_to=add_to)
+                      train_decoder=not frozen, ekional_add_to=add_to, main_loss_type=loss_type)
     index_seq = gio.T(g["index_seq"]).to(torch.int64)
     # a1: the batch composition rule reproduces the reference's batch from its recorded draws
     idx0 = torch.cat((gio.T(g["draw_hist0"]), gio.T(g["new_idx"])[gio.T(g["draw_pick0"])]))
@@ -247,15 +259,18 @@ def test_relu_kink_row_bound_holds_for_forced_gates(ln, tau, monkeypatch):
     lc = O.LoopConfig()
     idx = gio.T(g["index_seq"]).to(torch.int64)[0]
     st = gio.map_state(layer_norm_on=bool(ln))
-    rows, nq, slack, gathered = O.relu_ambiguous_rows(st, dec, pool, idx, lc, tau, with_slack=True)
+    rows, nq, slack, gathered, dec_slack = O.relu_ambiguous_rows(st, dec, pool, idx, lc, tau, with_slack=True)
     assert nq > 0 and slack is not None and float(slack[rows].min()) >= 0.0 and float(slack.sum()) > 0.0
+    assert dec_slack.shape[0] == dec.W1.numel() + 2 * dec.W1.shape[0] + 1 and float(dec_slack.min()) >= 0.0
     kink = torch.zeros(slack.shape[0], dtype=torch.bool)
     kink[rows] = True
     assert float(slack[~kink].abs().max()) == 0.0 and bool(gathered[rows].all())
-    base = O.loss_and_grads(st, dec, pool, idx, lc)["grad_theta"]
+    base_all = O.loss_and_grads(st, dec, pool, idx, lc)
+    base = base_all["grad_theta"]
+    base_dec = torch.cat([base_all["grad_" + n].reshape(-1) for n in ("W1", "b1", "W2", "b2")])
     assert not bool((base != 0).any(1)[~gathered].any())
-    gmax = float(base.abs().max())
-    moved = 0.0
+    gmax, dmax = float(base.abs().max()), float(base_dec.abs().max())
+    moved = moved_dec = 0.0
     for mode in (True, False, None):
         gen = torch.Generator().manual_seed(7)
 
@@ -267,11 +282,18 @@ def test_relu_kink_row_bound_holds_for_forced_gates(ln, tau, monkeypatch):
             return F.linear(pre * gate, d.W2, d.b2).squeeze(1) * d.sdf_scale
 
         monkeypatch.setattr(O, "mlp_sdf", forced)
-        other = O.loss_and_grads(gio.map_state(layer_norm_on=bool(ln)), dec, pool, idx, lc)["grad_theta"]
+        other_all = O.loss_and_grads(gio.map_state(layer_norm_on=bool(ln)), dec, pool, idx, lc)
         monkeypatch.undo()
+        other = other_all["grad_theta"]
+        dd = (torch.cat([other_all["grad_" + n].reshape(-1) for n in ("W1", "b1", "W2", "b2")]) - base_dec).abs()
+        # the decoder's gradient: entries of units nobody holds on the kink do not move, the others by less than their bound
+        assert float(dd[dec_slack == 0].max()) <= 1e-6 * dmax
+        assert float((dd - 1.25 * dec_slack).max()) <= 1e-5 * dmax
+        moved_dec = max(moved_dec, float(dd.max()) / dmax)
         d = (other - base).abs().max(1).values
         assert float(d[~kink].max()) <= 1e-6 * gmax
         assert float((d - 1.25 * slack).max()) <= 1e-5 * gmax
         assert not bool((other != 0).any(1)[~gathered].any())
         moved = max(moved, float(d[kink].max()) / gmax)
     assert moved > 1e-4  # the forced gates really moved listed rows beyond the strict bar (the bound is doing work)
+    assert moved_dec > 1e-5

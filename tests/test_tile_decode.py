@@ -235,7 +235,7 @@ def test_tile_vs_oracle_at_262144_samples(env, variant, ln):
     dec = gio.decoder(g, "init_")
     idx64 = index.to(torch.int64)
     lc = O.LoopConfig()
-    rows, nq, slack, gathered = O.relu_ambiguous_rows(st, dec, pool, idx64, lc, 4e-6, with_slack=True)
+    rows, nq, slack, gathered, dec_slack = O.relu_ambiguous_rows(st, dec, pool, idx64, lc, 4e-6, with_slack=True)
     o = O.loss_and_grads(st, dec, pool, idx64, lc)
     dl = abs(float(loss[0]) - float(o["loss"]))
     gt = grad[_lib.GRAD_FEAT_OFFSET:].view(-1, 8)
@@ -252,7 +252,8 @@ def test_tile_vs_oracle_at_262144_samples(env, variant, ln):
     st64.local_geo_features = st.local_geo_features.detach().double()
     o64 = O.loss_and_grads(st64, gio.as_double(gio.decoder(g, "init_")), gio.as_double(gio.sample_pool()[0]), idx64, lc)
     gd = torch.cat([o64["grad_" + n].reshape(-1) for n in ("W1", "b1", "W2", "b2")])
-    ddec = float((grad[: H * D + 2 * H + 1].double() - gd).abs().max()) / float(gd.abs().max())
+    # (entries of hidden units that some query holds on the ReLU kink may move by the oracle's own bound, like the listed rows)
+    ddec = float(((grad[: H * D + 2 * H + 1].double() - gd).abs() - 1.25 * dec_slack.double()).max()) / float(gd.abs().max())
     gd32 = torch.cat([o["grad_" + n].reshape(-1) for n in ("W1", "b1", "W2", "b2")])
     print(f"[decoder gradient, largest entry {float(gd.abs().max()):.3e}] HIP vs float64 oracle {ddec:.2e}; fp32 oracle vs float64 "
           f"oracle {float((gd32.double() - gd).abs().max()) / float(gd.abs().max()):.2e}")
