@@ -146,6 +146,8 @@ _SIGS = {
     "clid_pool_workspace_bytes": (_i64, [_i64]),
     "clid_pool_filter": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(C.c_double), C.c_double,
                                    _i64, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clid_pool_filter_after": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(C.c_double), C.c_double,
+                                         _i64, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clid_cloud_workspace_bytes": (_i64, [_i64]),
     "clid_cloud_update": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _f32, C.POINTER(C.c_double), C.c_double, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clid_map_insert_workspace_bytes": (_i64, [_i32]),

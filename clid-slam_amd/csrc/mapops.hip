@@ -1619,12 +1619,33 @@ extern "C" int64_t clid_pool_workspace_bytes(int64_t n_total) {
                    align256(pool_scan_bytes((long long)nblk)) + 256);
 }
 
+extern "C" int clid_pool_filter_after(const float* coord_a, const float* gcoord_a, const float* label_a, const float* weight_a,
+                                      const int32_t* time_a, int64_t n_a, const float* coord_b, const float* gcoord_b,
+                                      const float* label_b, const float* weight_b, const int32_t* time_b, int64_t n_b,
+                                      const double* origin_host, double radius2, int64_t capacity, uint64_t seed, float* coord_out,
+                                      float* gcoord_out, float* label_out, float* weight_out, int32_t* time_out,
+                                      int64_t* counts_out, void* workspace, const int64_t* n_b_dev, void* stream,
+                                      void* scatter_after_event);
 extern "C" int clid_pool_filter(const float* coord_a, const float* gcoord_a, const float* label_a, const float* weight_a,
                                 const int32_t* time_a, int64_t n_a, const float* coord_b, const float* gcoord_b,
                                 const float* label_b, const float* weight_b, const int32_t* time_b, int64_t n_b,
                                 const double* origin_host, double radius2, int64_t capacity, uint64_t seed, float* coord_out,
                                 float* gcoord_out, float* label_out, float* weight_out, int32_t* time_out,
                                 int64_t* counts_out, void* workspace, const int64_t* n_b_dev, void* stream) {
+  return clid_pool_filter_after(coord_a, gcoord_a, label_a, weight_a, time_a, n_a, coord_b, gcoord_b, label_b, weight_b, time_b, n_b,
+                                origin_host, radius2, capacity, seed, coord_out, gcoord_out, label_out, weight_out, time_out,
+                                counts_out, workspace, n_b_dev, stream, nullptr);
+}
+// scatter_after_event != NULL (a recorded hipEvent_t): the five-array compaction -- the frame's one bandwidth-bound launch, which
+// takes every wave slot of the chip for its duration -- is held back until that event; the flag / list / drop passes in front of it
+// are not.  (process_frame records it behind the map growth's voxel pass, whose small dependent launches starve next to it.)
+extern "C" int clid_pool_filter_after(const float* coord_a, const float* gcoord_a, const float* label_a, const float* weight_a,
+                                      const int32_t* time_a, int64_t n_a, const float* coord_b, const float* gcoord_b,
+                                      const float* label_b, const float* weight_b, const int32_t* time_b, int64_t n_b,
+                                      const double* origin_host, double radius2, int64_t capacity, uint64_t seed, float* coord_out,
+                                      float* gcoord_out, float* label_out, float* weight_out, int32_t* time_out,
+                                      int64_t* counts_out, void* workspace, const int64_t* n_b_dev, void* stream,
+                                      void* scatter_after_event) {
   const long long n = n_a + n_b;
   if (n_a < 0 || n_b < 0 || n >= (1LL << 31) || !origin_host || !counts_out || !workspace || capacity < 0 ||
       (n_a > 0 && (!coord_a || !gcoord_a || !label_a || !weight_a || !time_a)) ||
@@ -1664,6 +1685,10 @@ extern "C" int clid_pool_filter(const float* coord_a, const float* gcoord_a, con
     }
   }
   const PoolDst d{coord_out, gcoord_out, label_out, weight_out, time_out};
+  if (scatter_after_event && hipStreamWaitEvent(s, (hipEvent_t)scatter_after_event, 0) != hipSuccess) {
+    clid_set_error("clid_pool_filter_after: event wait failed: %s", hipGetErrorString(hipGetLastError()));
+    return CLID_E_HIP;
+  }
   hipLaunchKernelGGL(k_pool_scatter, dim3(blocks), dim3(256), 0, s, a, b, flag, block_off, block_cnt, d, counts);
   CLID_CHECK_LAUNCH();
   return CLID_OK;

@@ -1455,8 +1455,8 @@ static int check_train_args(const clid_map_view* mv, const clid_train_args* a, c
     clid_set_error("%s: bs=%d decimation=%d eikonal_mode=%d", who, a->bs, a->decimation, a->eikonal_mode);
     return CLID_E_ARG;
   }
-  if (a->decode_each_neighbour && (a->eikonal_mode == 2 || a->cbuf)) {
-    clid_set_error("%s: decode_each_neighbour (weighted_first: False) needs the hoisted schedule, eikonal mode 0 or 1 and the plain exchange", who);
+  if (a->decode_each_neighbour && (a->cbuf || (a->eikonal_mode == 2 && !hoisted(a)))) {
+    clid_set_error("%s: decode_each_neighbour (weighted_first: False) needs the hoisted schedule and the plain exchange", who);
     return CLID_E_ARG;
   }
   if (a->main_loss_type) {

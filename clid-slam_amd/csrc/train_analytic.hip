@@ -289,6 +289,215 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
   flush_mlp_acc(acc, bce_acc, eik_acc, red, partial + (size_t)blockIdx.x * kPartialStride, ta.train_decoder != 0);
 }
 
+
+// ---- `neuralpoints.weighted_first: False` with the analytic eikonal term (utils/mapper.py:676-680, 695-696) ---------------
+// Every neighbour's own input in_k = [feat_k | x - p_k] is decoded and the K SDFs are blended: sdf = sum_k w_k s_k, so
+//   g = d sdf / d x = sum_k (dw_k s_k + w_k u_k[8:11]),      u_k = s (W2 .* a_k) W1  (the decoder's d s_k / d in_k)
+// and with delta = dL/dsdf, c = dL/dg the backward THROUGH g has first-order form per neighbour (a_k is piecewise constant):
+//   dL/ds_k = w_k delta + c . dw_k =: ck_k,        dL/du_k = [0_8 ; w_k c] =: t_k
+//   dW1[h,:] += ck_k s W2[h] a_k[h] [in_k | 1] + s W2[h] a_k[h] t_k,   dW2[h] += ck_k s relu(pre_k[h]) + s a_k[h] (W1[h,:] . t_k)
+//   db2 += ck_k s,     d feat_k = ck_k u_k[0:8]  (then the row's layer-norm backward)
+// Hoisted schedule only (records of plain tasks).  Layout as k_train_analytic: 4 queries per wave round, lane16 = 2 k + half;
+// the decoder is evaluated once per neighbour with in_k broadcast over the query's 16 lanes (pass 1: s_k, u_k -> g, losses;
+// pass 2: the same evaluation again for the gradients -- recomputing 44 FMAs per lane beats keeping 6 x 4 pre-activations).
+__global__ void __launch_bounds__(CLID_BLOCK, 1)  // (208 B of scratch per lane when held to 256 registers)
+k_train_analytic_wf0(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, int n_rounds, const float4* __restrict__ rec) {
+  __shared__ MlpLds mlp;
+  __shared__ float red[(CLID_BLOCK / 64) * kRedFloats];
+  __shared__ PairLds pairs[CLID_BLOCK / 64];
+  stage_mlp(mlp, ta.W1, ta.b1, ta.W2, ta.b2);
+  const int lane = threadIdx.x & 63, lane16 = lane & 15, gbase = lane & 48, grp = lane >> 4;
+  const int wave = threadIdx.x >> 6, waves_per_block = CLID_BLOCK / 64;
+  const int my_k = lane16 >> 1;
+  const bool odd = lane16 & 1;
+  MlpAcc acc;
+  acc.zero();
+  float bce_acc = 0.f, eik_acc = 0.f;
+  float w1r[CLID_HPL][CLID_D], b1r[CLID_HPL], w2r[CLID_HPL];
+#pragma unroll
+  for (int uu = 0; uu < CLID_HPL; ++uu) {
+    const int h = lane16 + CLID_G * uu;
+#pragma unroll
+    for (int c = 0; c < CLID_D; ++c) w1r[uu][c] = mlp.w[h * CLID_D + c];
+    b1r[uu] = mlp.w[CLID_H * CLID_D + h];
+    w2r[uu] = mlp.w[CLID_H * CLID_D + CLID_H + h];
+  }
+  const float b2r = mlp.w[CLID_MLP_PARAMS - 1];
+  const int gstride = ta.grad_stride == CLID_GRAD_ROW16 ? CLID_GRAD_ROW16 : CLID_F;
+  const bool merged = gstride == CLID_GRAD_ROW16;
+  float* g_theta = ta.grad + CLID_GRAD_OFFSET(gstride);
+  const float inv_sigma = fdiv(1.0f, ta.sigma);
+  const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
+  const float sc = ta.sdf_scale;
+
+  for (int rd = blockIdx.x * waves_per_block + wave; rd < n_rounds; rd += gridDim.x * waves_per_block) {
+    const int p_raw = rd * 4 + grp;
+    bool live = p_raw < ta.bs;
+    const float4* r = rec + (size_t)(p_raw >> 3) * 48;  // qinfo[8] | qdesc[8] | win[8][8] float2
+    const int slot = p_raw & 7;
+    const float4 qi = r[live ? slot : 0], qd = r[8 + (live ? slot : 0)];
+    live = live && __float_as_int(qd.x) >= 0;
+    const float px = qi.x, py = qi.y, pz = qi.z;
+    const int rec_ts = __float_as_int(qi.w);
+    const float rec_label = qd.z, rec_wt = qd.w;
+    const float2 wn = reinterpret_cast<const float2*>(r + 16)[(live ? slot : 0) * 8 + (my_k < CLID_K ? my_k : 0)];
+    float my_w = 0.f;
+    int my_j = -1;
+    if (my_k < CLID_K) {
+      my_w = wn.x;
+      my_j = __float_as_int(wn.y);
+    }
+    if (!live) my_j = -1;
+    const bool valid = my_j >= 0;
+    if (!valid) my_w = 0.f;
+    const int jc = valid ? my_j : 0;
+    float4 v = reinterpret_cast<const float4*>(mv.feat)[(size_t)jc * 2 + (odd ? 1 : 0)];
+    const float4 pj = pos4[jc];
+    const int ts_old = (valid && !odd && mv.ts_update) ? mv.ts_update[jc] : 0x7fffffff;
+    if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float rstd = 1.f;
+    if (mv.layer_norm) {  // np.py:632-633; an all-zero (invalid) row stays zero
+      float s1 = (v.x + v.y) + (v.z + v.w);
+      s1 += CLID_SWAP(s1);
+      const float mu = s1 * (1.0f / CLID_F);
+      v.x -= mu; v.y -= mu; v.z -= mu; v.w -= mu;
+      float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      s2 += CLID_SWAP(s2);
+      rstd = 1.0f / sqrtf(s2 * (1.0f / CLID_F) + 1e-5f);
+      v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
+    }
+    const float rx = valid ? fsub(px, pj.x) : 0.f, ry = valid ? fsub(py, pj.y) : 0.f, rz = valid ? fsub(pz, pj.z) : 0.f;
+    const float my_om = valid ? fdiv(1.0f, fadd(fadd(fadd(fmul(rx, rx), fmul(ry, ry)), fmul(rz, rz)), 1e-15f)) : 0.f;
+    // d w_k / d x
+    const float alx = 2.f * rx * my_om, aly = 2.f * ry * my_om, alz = 2.f * rz * my_om;
+    float abx = my_w * alx, aby = my_w * aly, abz = my_w * alz;
+    CLID_BFLY(abx) CLID_BFLY(aby) CLID_BFLY(abz)
+    const float dwx = my_w * (abx - alx), dwy = my_w * (aby - aly), dwz = my_w * (abz - alz);
+
+    // the decoder on neighbour k's input, broadcast from its lane pair: pre-activations of this lane's hidden units
+    auto load_in = [&](int k, float (&fk)[CLID_D]) {
+      const int l0 = gbase + 2 * k;
+      fk[0] = __shfl(v.x, l0, 64); fk[1] = __shfl(v.y, l0, 64); fk[2] = __shfl(v.z, l0, 64); fk[3] = __shfl(v.w, l0, 64);
+      fk[4] = __shfl(v.x, l0 + 1, 64); fk[5] = __shfl(v.y, l0 + 1, 64); fk[6] = __shfl(v.z, l0 + 1, 64); fk[7] = __shfl(v.w, l0 + 1, 64);
+      fk[8] = __shfl(rx, l0, 64); fk[9] = __shfl(ry, l0, 64); fk[10] = __shfl(rz, l0, 64);
+    };
+    auto eval = [&](const float (&fk)[CLID_D], float (&pre)[CLID_HPL]) -> float {
+      float part = 0.f;
+#pragma unroll
+      for (int uu = 0; uu < CLID_HPL; ++uu) {
+        float a = b1r[uu];
+#pragma unroll
+        for (int c = 0; c < CLID_D; ++c) a = fmaf(w1r[uu][c], fk[c], a);
+        pre[uu] = a;
+        part = fmaf(w2r[uu], fmaxf(a, 0.f), part);
+      }
+      return sc * (group_sum(part) + b2r);
+    };
+
+    // ---- pass 1: s_k and u_k of every neighbour; this lane keeps those of ITS neighbour
+    float s_mine = 0.f, us0 = 0.f, us1 = 0.f, us2 = 0.f, us3 = 0.f, u8 = 0.f, u9 = 0.f, u10 = 0.f;
+#pragma unroll
+    for (int k = 0; k < CLID_K; ++k) {
+      float fk[CLID_D], pre[CLID_HPL], e[CLID_HPL], u[CLID_D];
+      load_in(k, fk);
+      const float sk_val = eval(fk, pre);
+#pragma unroll
+      for (int uu = 0; uu < CLID_HPL; ++uu) e[uu] = pre[uu] > 0.f ? sc * w2r[uu] : 0.f;
+#pragma unroll
+      for (int c = 0; c < CLID_D; ++c) {
+        float part = 0.f;
+#pragma unroll
+        for (int uu = 0; uu < CLID_HPL; ++uu) part = fmaf(w1r[uu][c], e[uu], part);
+        u[c] = group_sum(part);
+      }
+      if (my_k == k) {
+        s_mine = sk_val;
+        us0 = odd ? u[4] : u[0]; us1 = odd ? u[5] : u[1]; us2 = odd ? u[6] : u[2]; us3 = odd ? u[7] : u[3];
+        u8 = u[8]; u9 = u[9]; u10 = u[10];
+      }
+    }
+    // blended SDF and g (the sums run over one parity class = the K neighbours; both classes carry the same value)
+    float sdf = my_w * s_mine;
+    float gx = s_mine * dwx + my_w * u8, gy = s_mine * dwy + my_w * u9, gz = s_mine * dwz + my_w * u10;
+    CLID_BFLY(sdf) CLID_BFLY(gx) CLID_BFLY(gy) CLID_BFLY(gz)
+
+    // ---- training_mode side effects (np.py:708-733)
+    if (valid && !odd && lane16 < 2 * CLID_K) {
+      if (!merged) atomicAdd(&mv.cert[my_j], my_w);
+      if (ts_old < rec_ts) atomicMax(&mv.ts_update[my_j], rec_ts);
+    }
+
+    // ---- losses and their derivatives
+    float delta = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
+    if (live) {
+      const float z = sdf * inv_sigma;
+      const float tgt = __frcp_rn(1.0f + __expf(-rec_label * inv_sigma));     // loss.py:60
+      const float ez = __expf(-fabsf(z));
+      const float sg = (z >= 0.f ? 1.0f : ez) * __frcp_rn(1.0f + ez);
+      const float li = fmaxf(z, 0.f) - z * tgt + __logf(1.0f + ez);           // BCEWithLogits
+      if (lane16 == 0) bce_acc += rec_wt * li;
+      delta = rec_wt * (sg - tgt) * inv_sigma * ta.inv_n_main;
+      if (ta.weight_e > 0.f) {
+        const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
+        if (lane16 == 0) eik_acc += (nrm - 1.f) * (nrm - 1.f);
+        const float coef = nrm > 0.f ? ta.weight_e * 2.f * (nrm - 1.f) * ta.inv_n_eik / nrm : 0.f;
+        cx = coef * gx; cy = coef * gy; cz = coef * gz;
+      }
+    }
+    const float ck = my_w * delta + (cx * dwx + cy * dwy + cz * dwz);  // dL/ds_k of this lane's neighbour
+
+    // ---- pass 2: decoder gradients, neighbour by neighbour
+    if (ta.train_decoder) {
+#pragma unroll
+      for (int k = 0; k < CLID_K; ++k) {
+        float fk[CLID_D], pre[CLID_HPL];
+        load_in(k, fk);
+        (void)eval(fk, pre);
+        const float ck_k = __shfl(ck, gbase + 2 * k, 64), w_k = __shfl(my_w, gbase + 2 * k, 64);
+        const float dz = sc * ck_k;
+        const float tq0 = w_k * cx, tq1 = w_k * cy, tq2 = w_k * cz;  // dL/du_k[8:11]
+        float fb = (lane16 == CLID_D) ? 1.0f : 0.f, tb = 0.f;
+#pragma unroll
+        for (int c = 0; c < CLID_D; ++c) fb = (lane16 == c) ? fk[c] : fb;
+        tb = lane16 == 8 ? tq0 : (lane16 == 9 ? tq1 : (lane16 == 10 ? tq2 : 0.f));
+#pragma unroll
+        for (int uu = 0; uu < CLID_HPL; ++uu) {
+          const bool on = pre[uu] > 0.f;
+          const float e = on ? sc * w2r[uu] : 0.f;
+          const float dh = on ? dz * w2r[uu] : 0.f;
+          const float w1t = fmaf(w1r[uu][8], tq0, fmaf(w1r[uu][9], tq1, w1r[uu][10] * tq2));
+          acc.dW2[uu] += on ? (dz * pre[uu] + sc * w1t) : 0.f;
+          acc.dW1[uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh, fb, acc.dW1[uu], 0, 0, 0);
+          acc.dW1[uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(e, tb, acc.dW1[uu], 0, 0, 0);
+        }
+        if (lane16 == 0) acc.db2 += dz;
+      }
+    }
+
+    // ---- feature gradients: d feat_k = ck_k u_k[0:8] on the (normalised) row of neighbour k
+    {
+      float d0 = ck * us0, d1 = ck * us1, d2 = ck * us2, d3 = ck * us3;
+      if (mv.layer_norm) {
+        float m1 = (d0 + d1) + (d2 + d3);
+        float m2 = (d0 * v.x + d1 * v.y) + (d2 * v.z + d3 * v.w);
+        m1 += CLID_SWAP(m1);
+        m2 += CLID_SWAP(m2);
+        m1 *= (1.0f / CLID_F);
+        m2 *= (1.0f / CLID_F);
+        d0 = rstd * (d0 - m1 - v.x * m2); d1 = rstd * (d1 - m1 - v.y * m2);
+        d2 = rstd * (d2 - m1 - v.z * m2); d3 = rstd * (d3 - m1 - v.w * m2);
+      }
+      if (merged) {
+        scatter_pairs_rows16(pairs[wave], lane, grp, my_k, odd, valid ? my_j : -1, d0, d1, d2, d3, valid ? my_w : 0.f, g_theta);
+      } else if (valid && lane16 < 2 * CLID_K && ck != 0.f) {
+        float* dst = g_theta + (size_t)my_j * gstride + (odd ? 4 : 0);
+        atomicAdd(dst + 0, d0); atomicAdd(dst + 1, d1); atomicAdd(dst + 2, d2); atomicAdd(dst + 3, d3);
+      }
+    }
+  }
+  flush_mlp_acc(acc, bce_acc, eik_acc, red, partial + (size_t)blockIdx.x * kPartialStride, ta.train_decoder != 0);
+}
+
 #undef CLID_BFLY
 #undef CLID_SWAP
 
@@ -310,6 +519,16 @@ int clid_launch_train_analytic(const clid_map_view* mv, const clid_train_args* a
     return CLID_E_ARG;
   }
   const int rounds = (a->bs + 3) / 4;
+  if (a->decode_each_neighbour) {  // neuralpoints.weighted_first: False
+    if (!rec) {
+      clid_set_error("clid_train_fwd_bwd: decode_each_neighbour with the analytic eikonal term runs on the hoisted schedule only");
+      return CLID_E_ARG;
+    }
+    CLID_KLAUNCH(a->prof, 0, clid::k_train_analytic_wf0, dim3(clid_train_analytic_blocks(a->bs)), dim3(CLID_BLOCK), 0, s, *mv, *a,
+                 partial, rounds, reinterpret_cast<const float4*>(rec));
+    CLID_CHECK_LAUNCH();
+    return CLID_OK;
+  }
   if (rec)
     CLID_KLAUNCH(a->prof, 0, clid::k_train_analytic<true>, dim3(clid_train_analytic_blocks(a->bs)), dim3(CLID_BLOCK), 0, s, *mv, *a,
                  partial, rounds, reinterpret_cast<const float4*>(rec));

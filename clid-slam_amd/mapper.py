@@ -23,6 +23,8 @@ import torch
 
 from . import _lib
 
+POOL_GATE_DEFAULT = "0"  # process_frame: hold the pool compaction back until the map growth's voxel pass is through (A/B)
+
 
 def _dist():
     import torch.distributed as dist
@@ -264,9 +266,9 @@ class Mapper:
         self._check_fused_config()
         cfg, nm = self.config, self.neural_points
         pipeline = int(_lib.PIPELINE if getattr(self, "pipeline", None) is None else self.pipeline)
-        if not cfg.weighted_first and (pipeline != 1 or (cfg.ekional_loss_on and cfg.weight_e > 0 and not cfg.numerical_grad)):
-            # per-neighbour decoding is fused on the hoisted schedule with the numerical (or no) eikonal term
-            # (csrc/train_wf0.hip); the analytic term would need a second derivative through six decoder evaluations
+        if not cfg.weighted_first and pipeline != 1:
+            # per-neighbour decoding is fused on the hoisted schedule: csrc/train_wf0.hip (numerical or no eikonal term),
+            # k_train_analytic_wf0 (analytic term: the backward through six decoder evaluations per sample in closed form)
             return self._mapping_unfused(iter_count, index_seq)
         iter_count = max(1, iter_count + self.adaptive_iter_offset)
         dist = _dist()
@@ -924,20 +926,32 @@ class Mapper:
             if side is None or side.device != coord.device:
                 side = self._side_stream = _lib.low_priority_stream(coord.device)
 
-            def fork_pool():
+            def fork_pool(scatter_after=None):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     self._pool_append_filter_fused(coord, gcoord, sdf_label, weight, stamp, cur_pose_torch, frame_id, defer=True,
-                                                   n_b_dev=None if cmp_dev is None else cmp_dev[0:1])
+                                                   n_b_dev=None if cmp_dev is None else cmp_dev[0:1], scatter_after=scatter_after)
 
             pool_first = two_phase and defer_cmp and async_upd and os.environ.get("CLID_POOL_FORK_EARLY", "1") != "0"
-            if pool_first:
+            # CLID_POOL_GATE=1: the pool's flag / list / drop passes beside the voxel pass, its compaction (which takes every wave
+            # slot: k_vox_bucket_sort 15 -> 120 us beside it) only behind the voxel pass, beside the insert / window launches
+            gate = pool_first and os.environ.get("CLID_POOL_GATE", POOL_GATE_DEFAULT) == "1"
+            if pool_first and not gate:
                 # Nothing waits for the voxel pass on the host, and the frame's critical path runs through the pool (flags, list,
                 # capacity drop, count, 220 us of compaction = 330 us, then the new-sample selection on its output): it is
                 # forked right behind the sampler's compaction, its bandwidth-bound prelude next to the voxel pass
                 fork_pool()
             if two_phase and defer_cmp and async_upd:
+                if gate:
+                    fork_at = main.record_event()  # (the side stream must not wait for the voxel pass: fork where the pool's inputs are ready)
                 vox_idx = voxel_down_sample_async(update_points, nm.resolution, nm.update_counts(coord.device)[3:5], n_dev=cmp_dev[1:2])
+                if gate:
+                    vox_done = torch.cuda.Event()
+                    vox_done.record(main)
+                    side.wait_event(fork_at)
+                    with torch.cuda.stream(side):
+                        self._pool_append_filter_fused(coord, gcoord, sdf_label, weight, stamp, cur_pose_torch, frame_id, defer=True,
+                                                       n_b_dev=None if cmp_dev is None else cmp_dev[0:1], scatter_after=vox_done)
             pending_vox = (voxel_down_sample_launch(update_points, nm.resolution, n_dev=None if cmp_dev is None else cmp_dev[1:2])
                            if two_phase and vox_idx is None else None)
             if not pool_first:
@@ -1101,7 +1115,7 @@ class Mapper:
         their last counts[1] rows, read on the device); returns the index buffer, or None when the fused path does not apply.
         The count is read after the pool's (`process_frame`)."""
         cfg, nm = self.config, self.neural_points
-        _, out, _ = self._pool_pending
+        out = self._pool_pending[1]
         if not self._new_sample_fused_ok(out["gcoord"], out["label"]) or n_upper <= 0:
             return None
         lib = _lib.load()
@@ -1204,7 +1218,7 @@ class Mapper:
 
 
     def _pool_append_filter_fused(self, coord, gcoord, sdf_label, weight, stamp, cur_pose_torch, frame_id, defer=False,
-                                  n_b_dev=None):
+                                  n_b_dev=None, scatter_after=None):
         """utils/mapper.py:297-392 in one enqueue (csrc/mapops.hip clid_pool_filter): append this frame's samples, window
         test in float64, random drop above `pool_capacity`, stable compaction of the five arrays into the other half of a
         ping-pong buffer; ONE small read-back for the two counts the host needs (pool size for the batch draws, number
@@ -1236,13 +1250,15 @@ class Mapper:
         b = [t.contiguous() for t in (coord.float(), gcoord.float(), sdf_label.float(), weight.float(), stamp.to(torch.int32))]
         origin = (C.c_double * 3)(*[float(v) for v in cur_pose_torch[:3, 3].tolist()])  # the pose is already on the host
         self._pool_drop_seed = (getattr(self, "_pool_drop_seed", int(getattr(cfg, "seed", 42)) * 7919) * 6364136223846793005 + 1442695040888963407) % (1 << 64)
-        _lib.check(lib.clid_pool_filter(
+        # scatter_after: a recorded torch.cuda.Event the compaction launch waits for (the passes in front of it do not)
+        _lib.check(lib.clid_pool_filter_after(
             a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), a[4].data_ptr(), n_a,
             b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), b[3].data_ptr(), b[4].data_ptr(), n_b,
             origin, float(cfg.window_radius) ** 2, int(cfg.pool_capacity), self._pool_drop_seed,
             out["coord"].data_ptr(), out["gcoord"].data_ptr(), out["label"].data_ptr(), out["weight"].data_ptr(),
-            out["time"].data_ptr(), self._pool_counts.data_ptr(), self._pool_ws.data_ptr(), _lib.ptr(n_b_dev), _lib.stream()), "clid_pool_filter")
-        self._pool_pending = (side, out, (a, b))  # (inputs stay referenced until the launches have been joined)
+            out["time"].data_ptr(), self._pool_counts.data_ptr(), self._pool_ws.data_ptr(), _lib.ptr(n_b_dev), _lib.stream(),
+            None if scatter_after is None else scatter_after.cuda_event), "clid_pool_filter_after")
+        self._pool_pending = (side, out, (a, b), scatter_after)  # (inputs stay referenced until the launches have been joined)
         if not defer:
             self._pool_filter_finish()
 
@@ -1257,7 +1273,7 @@ class Mapper:
         return fc
 
     def _pool_filter_finish(self, with_tail: bool = False):
-        side, out, _ = self._pool_pending
+        side, out = self._pool_pending[:2]
         self._pool_pending = None
         if with_tail:  # the new-sample selection was launched on the pool arrays in flight; the raw-point map's count rides along
             got = _lib.read_counts(self._frame_counts, 10)

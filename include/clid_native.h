@@ -631,6 +631,16 @@ int clid_pool_filter(const float* coord_a, const float* gcoord_a, const float* l
                      int64_t capacity, uint64_t seed, float* coord_out, float* gcoord_out, float* label_out,
                      float* weight_out, int32_t* time_out, int64_t* counts_out, void* workspace, const int64_t* n_b_dev,
                      void* stream); /* n_b_dev != NULL (device int64): only the first min(*n_b_dev, n_b) samples of `b` exist */
+/* The same with a gate: scatter_after_event != NULL (a recorded hipEvent_t) holds the five-array compaction -- the one launch of
+ * the frame that fills every wave slot of the chip -- back until the event; the flag / list / drop passes in front of it run at
+ * once.  Mapper.process_frame records the event behind the map growth's voxel pass (small dependent launches that starve beside
+ * the compaction). */
+int clid_pool_filter_after(const float* coord_a, const float* gcoord_a, const float* label_a, const float* weight_a,
+                           const int32_t* time_a, int64_t n_a, const float* coord_b, const float* gcoord_b, const float* label_b,
+                           const float* weight_b, const int32_t* time_b, int64_t n_b, const double* origin_host, double radius2,
+                           int64_t capacity, uint64_t seed, float* coord_out, float* gcoord_out, float* label_out,
+                           float* weight_out, int32_t* time_out, int64_t* counts_out, void* workspace, const int64_t* n_b_dev,
+                           void* stream, void* scatter_after_event);
 
 /* LocalPointCloudMap.update_map (model/local_point_cloud_map.py:43-72) after the voxel down-sampling of the scan: the
  * `samples` whose voxel slot in table_old is still empty are appended to the map, the map is cropped to `map_size` around

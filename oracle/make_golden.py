@@ -269,15 +269,20 @@ def main():
     # the samples' sensor frames, moved by used_poses[ts] inside the loop) -- appended, so the files above stay as they were
     cases += [("numerical", False, False, "all", lt, False) for lt in ("sdf_l1", "sdf_l2", "zhong")]
     cases += [("numerical", False, False, "all", "bce", True)]
-    for mode, frozen, ln, add_to, loss_type, ba in cases:
+    cases = [c + (True,) for c in cases]
+    # neuralpoints.weighted_first: False (utils/mapper.py:679-680: every neighbour decoded, the SDFs blended) with the analytic
+    # eikonal term -- the double backward through six decoder evaluations per sample (with and without layer norm)
+    cases += [("analytic", False, False, "all", "bce", False, False), ("analytic", False, True, "all", "bce", False, False)]
+    for mode, frozen, ln, add_to, loss_type, ba, wf in cases:
         for _once in (0,):
             for _once2 in (0,):
                 tag = (f"{mode}_{'frozen' if frozen else 'train'}_ln{int(ln)}" + ("" if add_to == "all" else f"_eik{add_to}")
-                       + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else ""))
+                       + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else "") + ("" if wf else "_wf0"))
                 cfg6 = ref_config(ref, bs=BS, bs_new_sample=200)
                 cfg6.layer_norm_on = ln
                 cfg6.ekional_add_to = add_to
                 cfg6.main_loss_type = loss_type
+                cfg6.weighted_first = wf
                 if mode == "analytic":
                     cfg6.numerical_grad = False
                     cfg6.gradient_decimation = 1

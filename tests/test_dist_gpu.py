@@ -33,9 +33,9 @@ def _run(rank, world, port, out_dir, mode, sparse="0", p2p="1", every="0", fail_
     g = gio.load("g6_loop_numerical_train_ln0.npz")
     bs, iters = 4096, 3
     cfg = shim_io.config(bs=bs)
-    if mode == "analytic":
+    if mode in ("analytic", "wf0_analytic"):
         cfg.numerical_grad, cfg.gradient_decimation = False, 1
-    if mode == "wf0":  # every neighbour decoded, SDFs blended (csrc/train_wf0.hip): shards like the default iteration
+    if mode in ("wf0", "wf0_analytic"):  # every neighbour decoded, SDFs blended (csrc/train_wf0.hip): shards like the default iteration
         cfg.weighted_first = False
     nm = shim_io.neural_points(cfg, base=p)
     dec = shim_io.decoder(cfg, g, "init_")
@@ -70,10 +70,11 @@ def _run(rank, world, port, out_dir, mode, sparse="0", p2p="1", every="0", fail_
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,sparse,p2p,every", [("numerical", "0", "1", "0"), ("analytic", "0", "1", "0"), ("wf0", "0", "0", "0"), ("numerical", "1", "0", "0"),
+@pytest.mark.parametrize("mode,sparse,p2p,every", [("numerical", "0", "1", "0"), ("analytic", "0", "1", "0"), ("wf0", "0", "0", "0"), ("wf0_analytic", "0", "0", "0"),
+                                                   ("numerical", "1", "0", "0"),
                                                    ("numerical", "1", "1", "0"), ("numerical", "1", "1", "1"), ("numerical", "1", "0", "1")])
 def test_two_ranks_equal_one(tmp_path, mode, sparse, p2p, every):
-    port = 29700 + (os.getpid() % 1000) + {"numerical": 0, "analytic": 1, "wf0": 16}[mode] + 2 * int(sparse) + 4 * int(p2p) + 8 * int(every)
+    port = 29700 + (os.getpid() % 1000) + {"numerical": 0, "analytic": 1, "wf0": 16, "wf0_analytic": 17}[mode] + 2 * int(sparse) + 4 * int(p2p) + 8 * int(every)
     _run(0, 1, port, str(tmp_path), mode)
     os.environ.pop("CLID_SPARSE", None)
     mp.spawn(_run, args=(2, port, str(tmp_path), mode, sparse, p2p, every), nprocs=2, join=True)

@@ -206,16 +206,24 @@ def test_mapping_loop_g6_ba_done_flag(env):
     test_mapping_loop_g6(env, "numerical", False, 0, "all", "bce", True)
 
 
+@pytest.mark.parametrize("ln", [0, 1])
+def test_mapping_loop_g6_weighted_first_false_analytic(env, ln):
+    """`neuralpoints.weighted_first: False` with `loss.numerical_grad_on: False` (utils/mapper.py:679-680, 695-696: every
+    neighbour decoded, the SDFs blended, the eikonal term on the autograd gradient of that blend) against the reference's own
+    loop and its double backward: k_train_analytic_wf0 (csrc/train_analytic.hip)."""
+    test_mapping_loop_g6(env, "analytic", False, ln, wf=False)
+
+
 @pytest.mark.parametrize("mode,frozen,ln", G6)
-def test_mapping_loop_g6(env, mode, frozen, ln, add_to="all", loss_type="bce", ba=False):
+def test_mapping_loop_g6(env, mode, frozen, ln, add_to="all", loss_type="bce", ba=False, wf=True):
     from clid_slam_amd.tools import freeze_model
 
     tag = (f"{mode}_{'frozen' if frozen else 'train'}_ln{ln}" + ("" if add_to == "all" else f"_eik{add_to}")
-           + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else ""))
+           + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else "") + ("" if wf else "_wf0"))
     g = gio.load(f"g6_loop_{tag}.npz")
     p = gio.load("pool.npz")
     cfg = env.config(layer_norm_on=bool(ln), bs=int(g["index_seq"].shape[1]), bs_new_sample=200, ekional_add_to=add_to,
-                     main_loss_type=loss_type)
+                     main_loss_type=loss_type, weighted_first=bool(wf))
     if mode == "analytic":
         cfg.numerical_grad, cfg.gradient_decimation = False, 1
     nm = env.neural_points(cfg, base=p)

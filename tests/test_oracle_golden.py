@@ -113,16 +113,18 @@ G6 = [("numerical", False, 0, "all"), ("numerical", False, 1, "all"), ("numerica
       ("numerical", False, 0, "surface"), ("numerical", False, 0, "freespace"),
       # config.main_loss_type (utils/mapper.py:751-767) and Mapper.ba_done_flag (utils/mapper.py:646-658)
       ("numerical", False, 0, "all", "sdf_l1"), ("numerical", False, 0, "all", "sdf_l2"), ("numerical", False, 0, "all", "zhong"),
-      ("numerical", False, 0, "all", "bce", True)]
+      ("numerical", False, 0, "all", "bce", True),
+      # neuralpoints.weighted_first: False with the analytic eikonal term (utils/mapper.py:679-680, 695-696)
+      ("analytic", False, 0, "all", "bce", False, False), ("analytic", False, 1, "all", "bce", False, False)]
 
 
 @pytest.mark.parametrize("case", G6, ids=lambda c: "-".join(str(x) for x in c))
 def test_g6_mapping_loop(case):
-    mode, frozen, ln, add_to, loss_type, ba = tuple(case) + ("all", "bce", False)[len(case) - 3:]
+    mode, frozen, ln, add_to, loss_type, ba, wf = tuple(case) + ("all", "bce", False, True)[len(case) - 3:]
     tag = (f"{mode}_{'frozen' if frozen else 'train'}_ln{ln}" + ("" if add_to == "all" else f"_eik{add_to}")
-           + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else ""))
+           + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else "") + ("" if wf else "_wf0"))
     g = gio.load(f"g6_loop_{tag}.npz")
-    st = gio.map_state(layer_norm_on=bool(ln))
+    st = gio.map_state(layer_norm_on=bool(ln), weighted_first=bool(wf))
     pool, praw = gio.sample_pool()
     if ba:  # the pool in the samples' sensor frames + the frames' poses; the world-frame pool is stale and must not be read
         pool.local_coord, pool.used_poses = gio.T(g["ba_coord_pool"]), gio.T(g["ba_used_poses"])
