@@ -1380,6 +1380,53 @@ __device__ __forceinline__ void sort_pairs(unsigned (&key)[ITEMS], unsigned (&po
   counting_pass<ITEMS>(digit, dest, tab, scan_tmp);
 }
 
+// ---- class-preserving placement ------------------------------------------------------------------------------------------
+// The eikonal term of an iteration runs on coord[::decim] of its batch (utils/mapper.py:700-704): the draws at the batch
+// positions col with col % decim == 0 -- a uniform random tenth.  Ordering a batch in space must not change WHICH draws those
+// are, so the order is applied within the two classes: the lattice positions of a segment receive the segment's lattice draws
+// in (Morton code, position) order, the other positions the other draws in that order.  The eikonal subset -- and with it every
+// loss term -- is then the reference's on the unordered batch, sample for sample; only the order of the work changes.
+// (decim == 1: every position is a lattice position and the rule is the plain order.)
+struct Lattice {
+  int decim;  // config.gradient_decimation when the numerical eikonal term is on, else 1
+  int off;    // position inside the segment of its first lattice column
+};
+__device__ __forceinline__ Lattice lattice_of(long long seg_col0, int decim) {
+  return Lattice{decim, (int)((decim - (int)(seg_col0 % decim)) % decim)};
+}
+__device__ __forceinline__ bool lattice_has(const Lattice& L, unsigned p) { return L.decim == 1 || ((int)p - L.off + L.decim) % L.decim == 0; }
+// position of the r-th lattice (cls) / the r-th other position of the segment
+__device__ __forceinline__ unsigned lattice_pos(const Lattice& L, bool cls, unsigned r) {
+  if (cls) return (unsigned)L.off + r * (unsigned)L.decim;
+  if (r < (unsigned)L.off) return r;
+  const unsigned r2 = r - (unsigned)L.off, d1 = (unsigned)L.decim - 1u;
+  return (unsigned)L.off + (r2 / d1) * (unsigned)L.decim + 1u + r2 % d1;
+}
+// rD[r] = number of lattice-class elements of the block placed before element r (places `dest`, a permutation of 0 .. m-1; only
+// dest < m counts).  words / wpre: NW = ceil(m_cap / 32) unsigned each, in LDS (the radix table is free after sort_pairs).
+template <int ITEMS>
+__device__ __forceinline__ void class_ranks(const unsigned (&dest)[ITEMS], const bool (&cls)[ITEMS], unsigned m, unsigned (&rD)[ITEMS],
+                                            unsigned* words, unsigned* wpre, int NW, typename BinScan::TempStorage& scan_tmp) {
+  for (int i = threadIdx.x; i < NW; i += kSortThreads) words[i] = 0u;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r)
+    if (dest[r] < m && cls[r]) atomicOr(&words[dest[r] >> 5], 1u << (dest[r] & 31u));
+  __syncthreads();
+  {
+    const unsigned c = (int)threadIdx.x < NW ? (unsigned)__popc(words[threadIdx.x]) : 0u;
+    unsigned off;
+    BinScan(scan_tmp).ExclusiveSum(c, off);
+    if ((int)threadIdx.x < NW) wpre[threadIdx.x] = off;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    const unsigned d = dest[r] < m ? dest[r] : 0u;
+    rD[r] = wpre[d >> 5] + (unsigned)__popc(words[d >> 5] & ((1u << (d & 31u)) - 1u));
+  }
+}
+
 // Spatially ordered batches.  A segment = 16 384 consecutive samples of one iteration's batch; its draws are ordered by
 // (Morton code of the sample's voxel, draw position) -- a total order, so the result is a function of the draws alone,
 // identical on every rank.  draws / keys come from k_mapping_prep (computed by the whole chip: the 16 k random 12-byte
@@ -1388,7 +1435,7 @@ __device__ __forceinline__ void sort_pairs(unsigned (&key)[ITEMS], unsigned (&po
 // k_batch_sort_tail: one block orders a whole (short) segment: the tail of a batch that is no multiple of 16 384.
 __global__ void __launch_bounds__(kSortThreads)
 k_batch_sort_tail(const long long* __restrict__ draws, const unsigned* __restrict__ keys, long long* __restrict__ index_out, int bs,
-                  int base) {
+                  int base, int decim) {
   constexpr int ITEMS = kSortSeg / kSortThreads;
   __shared__ unsigned tab[kSortBins * kSortWaves];  // [digit][wave]
   __shared__ unsigned seq[kSortSeg];                // the sequence between passes: (remaining code << 14) | draw position
@@ -1404,6 +1451,19 @@ k_batch_sort_tail(const long long* __restrict__ draws, const unsigned* __restric
     key[r] = p < n ? keys[e0 + p] : 0xFFFFFFu;  // padding: behind every real element (largest code, larger position)
   }
   sort_pairs<ITEMS>(key, pos, dest, tab, seq, scan_tmp);
+  if (decim > 1) {  // (uniform) the order within the lattice class and within the others (see Lattice)
+    const Lattice L = lattice_of(base, decim);
+    bool cls[ITEMS];
+    unsigned rD[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) cls[r] = lattice_has(L, pos[r]);
+    static_assert(kSortSeg / 32 * 2 <= kSortBins * kSortWaves, "class_ranks' words + prefix fit the radix table");
+    class_ranks<ITEMS>(dest, cls, (unsigned)n, rD, tab, tab + kSortSeg / 32, kSortSeg / 32, scan_tmp);
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r)
+      if ((int)dest[r] < n) index_out[e0 + lattice_pos(L, cls[r], cls[r] ? rD[r] : dest[r] - rD[r])] = draws[e0 + pos[r]];
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r)
     if ((int)dest[r] < n) index_out[e0 + dest[r]] = draws[e0 + pos[r]];
@@ -1416,7 +1476,7 @@ k_batch_sort_tail(const long long* __restrict__ draws, const unsigned* __restric
 template <int BUCKETS>
 __global__ void __launch_bounds__(kSortThreads)
 k_batch_sort_bucket(const long long* __restrict__ draws, const unsigned* __restrict__ keys, long long* __restrict__ index_out,
-                    int bs, int full_segs, int seg0) {
+                    int bs, int full_segs, int seg0, int decim) {
   constexpr int kSortBuckets = BUCKETS;
   constexpr int ITEMS = sort_bucket_items(BUCKETS), CAP = ITEMS * kSortThreads, SCAN = kSortSeg / kSortThreads;
   __shared__ unsigned tab[kSortBins * kSortWaves];
@@ -1424,6 +1484,7 @@ k_batch_sort_bucket(const long long* __restrict__ draws, const unsigned* __restr
   __shared__ unsigned sel_key[CAP], sel_pos[CAP];
   __shared__ __attribute__((aligned(16))) unsigned samp[256];
   __shared__ unsigned sorted[256], prank[kSortThreads / 256][256], wcnt[kSortWaves], wlow[kSortWaves];
+  __shared__ unsigned wcntD[kSortWaves], wlowD[kSortWaves];  // (decim > 1) the lattice-class elements among them
   __shared__ typename BinScan::TempStorage scan_tmp;
   const int bk = blockIdx.x % kSortBuckets;
   const int sg = blockIdx.x / kSortBuckets;
@@ -1463,8 +1524,10 @@ k_batch_sort_bucket(const long long* __restrict__ draws, const unsigned* __restr
   const unsigned lo = bk > 0 ? sorted[bk * (256 / kSortBuckets)] : 0u;
   const unsigned hi = bk + 1 < kSortBuckets ? sorted[(bk + 1) * (256 / kSortBuckets)] : 0xFFFFFFFFu;  // (keys are 24-bit codes)
   // ---- scan of the segment in wave-blocked order: count, then keep this block's key range in position order
+  const bool classes = decim > 1;  // (uniform) order within the lattice class and within the others (see Lattice)
+  const Lattice L = lattice_of((long long)seg * kSortSeg, decim);
   unsigned key[SCAN];
-  unsigned cm = 0, cl = 0;
+  unsigned cm = 0, cl = 0, cmD = 0, clD = 0;
   unsigned long long mine_bits = 0;  // bit r: element r of this thread belongs to this block
 #pragma unroll
   for (int r = 0; r < SCAN; ++r) {
@@ -1475,37 +1538,55 @@ k_batch_sort_bucket(const long long* __restrict__ draws, const unsigned* __restr
     cm += (unsigned)__popcll(__ballot(mine));
     cl += (unsigned)__popcll(__ballot(below));
     mine_bits |= mine ? (1ULL << r) : 0ULL;
+    if (classes) {
+      const bool c = lattice_has(L, (unsigned)p);
+      cmD += (unsigned)__popcll(__ballot(mine && c));
+      clD += (unsigned)__popcll(__ballot(below && c));
+    }
   }
   if (lane == 0) {
     wcnt[wave] = cm;
     wlow[wave] = cl;
+    wcntD[wave] = cmD;
+    wlowD[wave] = clD;
   }
   __syncthreads();
   CLID_STAMP(3);
-  unsigned wbase = 0, m = 0, lower = 0;
+  unsigned wbase = 0, m = 0, lower = 0, wbaseD = 0, lowerD = 0;
 #pragma unroll
   for (int w = 0; w < kSortWaves; ++w) {
     wbase += w < wave ? wcnt[w] : 0u;
     m += wcnt[w];
     lower += wlow[w];
+    wbaseD += w < wave ? wcntD[w] : 0u;
+    lowerD += wlowD[w];
   }
   const bool overflow = m > (unsigned)CAP;  // (block-uniform) a key range more than twice the mean: keeps the draw order
-  unsigned run = wbase;
+  unsigned run = wbase, runD = wbaseD;
 #pragma unroll
   for (int r = 0; r < SCAN; ++r) {
     const bool mine = (mine_bits >> r) & 1ULL;
     const unsigned long long bal = __ballot(mine);
-    const unsigned slot = run + (unsigned)__popcll(bal & ((1ULL << lane) - 1ULL));
+    const unsigned long long below_me = (1ULL << lane) - 1ULL;
+    const unsigned slot = run + (unsigned)__popcll(bal & below_me);
     const unsigned p = (unsigned)(wave * (SCAN * 64) + r * 64 + lane);
+    const bool c = classes && lattice_has(L, p);
+    const unsigned long long balD = classes ? __ballot(mine && c) : 0ULL;
     if (mine) {
       if (overflow) {
-        index_out[e0 + lower + slot] = draws[e0 + p];
+        unsigned at = lower + slot;
+        if (classes) {
+          const unsigned before = lowerD + runD + (unsigned)__popcll(balD & below_me);  // lattice-class elements placed before this one
+          at = lattice_pos(L, c, c ? before : at - before);
+        }
+        index_out[e0 + at] = draws[e0 + p];
       } else {
         sel_key[slot] = key[r];
         sel_pos[slot] = p;
       }
     }
     run += (unsigned)__popcll(bal);
+    runD += (unsigned)__popcll(balD);
   }
   if (overflow) return;
   __syncthreads();
@@ -1519,6 +1600,22 @@ k_batch_sort_bucket(const long long* __restrict__ draws, const unsigned* __restr
   }
   sort_pairs<ITEMS>(k4, pos, dest, tab, seq, scan_tmp);
   CLID_STAMP(5);
+  if (classes) {
+    bool cls[ITEMS];
+    unsigned rD[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) cls[r] = lattice_has(L, pos[r]);
+    static_assert(CAP / 32 * 2 <= kSortBins * kSortWaves, "class_ranks' words + prefix fit the radix table");
+    class_ranks<ITEMS>(dest, cls, m, rD, tab, tab + CAP / 32, CAP / 32, scan_tmp);
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r)
+      if (dest[r] < m) {
+        const unsigned before = lowerD + rD[r];
+        index_out[e0 + lattice_pos(L, cls[r], cls[r] ? before : lower + dest[r] - before)] = draws[e0 + pos[r]];
+      }
+    CLID_STAMP(6);
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r)
     if (dest[r] < m) index_out[e0 + lower + dest[r]] = draws[e0 + pos[r]];
@@ -1539,7 +1636,11 @@ extern "C" int64_t clid_mapping_prep_workspace_bytes(int32_t iters, int32_t bs) 
 extern "C" int clid_mapping_prep(float* zero_base, int64_t zero_floats, int64_t* index_out, int32_t iters, int32_t bs,
                                  int32_t bs_new, int64_t pool_count, const int64_t* new_idx, int64_t n_new, uint64_t seed,
                                  uint64_t counter, const float* pool_coord, float resolution, void* sort_workspace,
-                                 int32_t col0, int32_t ncols, void* stream) {
+                                 int32_t col0, int32_t ncols, int32_t decimation, void* stream) {
+  if (decimation < 1) {
+    clid_set_error("clid_mapping_prep: decimation %d", decimation);
+    return CLID_E_ARG;
+  }
   if (zero_floats < 0 || (zero_floats && (!zero_base || (zero_floats & 3) || ((uintptr_t)zero_base & 15))) || iters < 0 ||
       bs < 0 || bs_new < 0 || bs_new > bs || (iters && bs && !index_out) || (index_out && iters && bs && pool_count <= 0) ||
       (bs_new > 0 && (!new_idx || n_new <= 0)) || (sort_workspace && (!pool_coord || !(resolution > 0.f))) ||
@@ -1588,14 +1689,14 @@ extern "C" int clid_mapping_prep(float* zero_base, int64_t zero_floats, int64_t*
   {
     if (kSortBuckets == kSortBucketsMany)
       hipLaunchKernelGGL(k_batch_sort_bucket<kSortBucketsMany>, dim3((unsigned)sort_blocks), dim3(kSortThreads), 0, s, draws, keys,
-                         reinterpret_cast<long long*>(index_out), bs, full_segs, seg0);
+                         reinterpret_cast<long long*>(index_out), bs, full_segs, seg0, (int)decimation);
     else
       hipLaunchKernelGGL(k_batch_sort_bucket<kSortBucketsFew>, dim3((unsigned)sort_blocks), dim3(kSortThreads), 0, s, draws, keys,
-                         reinterpret_cast<long long*>(index_out), bs, full_segs, seg0);
+                         reinterpret_cast<long long*>(index_out), bs, full_segs, seg0, (int)decimation);
   }
   if (sorted && tail > 0)
     hipLaunchKernelGGL(k_batch_sort_tail, dim3((unsigned)iters), dim3(kSortThreads), 0, s, draws, keys,
-                       reinterpret_cast<long long*>(index_out), bs, tail_base);
+                       reinterpret_cast<long long*>(index_out), bs, tail_base, (int)decimation);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

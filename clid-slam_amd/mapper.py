@@ -115,7 +115,7 @@ class Mapper:
             # first launch of the draw / ordering kernels into the reserved buffers (code-object load, LDS configuration)
             _lib.check(lib.clid_mapping_prep(None, 0, self._idx_buf.data_ptr(), iter_count, int(cfg.bs), 0,
                                              int(self.pool_sample_count), None, 0, 0, 0, self.global_coord_pool.data_ptr(),
-                                             float(nm.resolution), self._sort_ws.data_ptr(), 0, 0, _lib.stream()),
+                                             float(nm.resolution), self._sort_ws.data_ptr(), 0, 0, self._eik_decimation(), _lib.stream()),
                        "clid_mapping_prep")
 
     def _loop_buffers(self, n_rows: int, iters: int, dev, zero: bool = True):
@@ -174,6 +174,13 @@ class Mapper:
 
     SORT_BATCH_MIN_ITERS = 6
 
+    def _eik_decimation(self) -> int:
+        """The stride of the loop's eikonal subset coord[::d] (utils/mapper.py:700-704): the batch ordering keeps the draws of
+        those positions on those positions (clid_mapping_prep `decimation`); 1 when every sample / none is in the subset."""
+        cfg = self.config
+        on = cfg.ekional_loss_on and cfg.weight_e > 0 and cfg.numerical_grad and os.environ.get("CLID_ORDER_CLASSES", "1") != "0"
+        return max(int(cfg.gradient_decimation), 1) if on else 1  # (CLID_ORDER_CLASSES=0: one class, the plain order -- A/B)
+
     def _prepare_call(self, iters: int, bs: int, n_rows: int, dev, lib, col0: int = 0, ncols: int = 0):
         """Workspace reset + batch draw of one `mapping()` call in ONE launch (`clid_mapping_prep`): the composition rule
         of `_draw_index` (utils/mapper.py:473-500) with a counter-based generator keyed on (seed, call number, position),
@@ -220,7 +227,8 @@ class Mapper:
             sort_ptr = ws.data_ptr()
         _lib.check(lib.clid_mapping_prep(self._flat.data_ptr(), self._flat_used, buf.data_ptr(), iters, bs, bs_new,
                                          int(self.pool_sample_count), new_ptr, n_new, seed, self._draw_calls, coord_ptr,
-                                         float(self.neural_points.resolution), sort_ptr, int(col0), int(ncols), _lib.stream()),
+                                         float(self.neural_points.resolution), sort_ptr, int(col0), int(ncols),
+                                         self._eik_decimation(), _lib.stream()),
                    "clid_mapping_prep")
         return bufs, index_seq
 

@@ -741,8 +741,12 @@ int clid_new_sample_select(const int64_t* buffer_pt_index, int64_t buffer_size, 
  * order of the samples' voxels by a second launch (three stable 8-bit counting passes in LDS on (Morton code, draw
  * position): a function of the draws alone, identical on every rank).  The loss and gradient sums do not depend on the
  * order; neighbouring queries then share neural points, which is what the kernels' per-tile row merging and the caches
- * feed on.  The `[::decimation]` eikonal subset becomes a systematic subsample of the ordered batch (each sample still has
- * probability 1/decimation).  clid_debug_prep_draw is the host restatement of one uniform draw (tests).
+ * feed on.  `decimation` > 1 (config.gradient_decimation while the numerical eikonal term is on): the order is applied WITHIN
+ * two classes -- the positions col with col % decimation == 0 of a batch (its eikonal subset coord[::decimation],
+ * utils/mapper.py:700-704) receive the draws of those positions, the other positions the other draws, each class in (Morton
+ * code, draw position) order -- so the ordered batch has the SAME eikonal subset as the draws in their own order, sample for
+ * sample (a uniform random tenth, not a spatially stratified one); 1 = one class.  clid_debug_prep_draw is the host
+ * restatement of one uniform draw (tests).
  * [col0, col0 + ncols) (ncols <= 0: all of them) = the columns of every iteration's batch this rank needs (its shard of
  * a sharded run): only they are guaranteed to be written -- widened to whole 16 384-sample segments when ordering, because
  * a segment is ordered as a unit -- so a rank of a data-parallel group pays for its slice, not for the global batch. */
@@ -750,7 +754,7 @@ int64_t clid_mapping_prep_workspace_bytes(int32_t iters, int32_t bs);
 int clid_mapping_prep(float* zero_base, int64_t zero_floats, int64_t* index_out, int32_t iters, int32_t bs, int32_t bs_new,
                       int64_t pool_count, const int64_t* new_idx, int64_t n_new, uint64_t seed, uint64_t counter,
                       const float* pool_coord, float resolution, void* sort_workspace, int32_t col0, int32_t ncols,
-                      void* stream);
+                      int32_t decimation, void* stream);
 int64_t clid_debug_prep_draw(uint64_t seed, uint64_t counter, uint64_t e, uint64_t range);
 
 /* ---- measurement aid (bench.py roofline leg; not part of the reference's interface) -----------

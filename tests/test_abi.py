@@ -133,5 +133,5 @@ def test_batch_draw_generator_host_restatement():
     a = np.array([lib.clid_debug_prep_draw(42, 3, e, 1 << 20) for e in range(4000)], dtype=np.float64)
     b = np.array([lib.clid_debug_prep_draw(42, 4, e, 1 << 20) for e in range(4000)], dtype=np.float64)
     assert abs(np.corrcoef(a[:-1], a[1:])[0, 1]) < 0.06 and abs(np.corrcoef(a, b)[0, 1]) < 0.06
-    rc = lib.clid_mapping_prep(None, 8, None, 0, 0, 0, 0, None, 0, 0, 0, None, 0.4, None, 0, 0, None)
+    rc = lib.clid_mapping_prep(None, 8, None, 0, 0, 0, 0, None, 0, 0, 0, None, 0.4, None, 0, 0, 1, None)
     assert rc == -1 and b"clid_mapping_prep" in lib.clid_last_error()

@@ -73,7 +73,9 @@ def _run(rank, world, port, out_dir, mode, sparse="0", p2p="1", every="0", fail_
 @pytest.mark.parametrize("mode,sparse,p2p,every", [("numerical", "0", "1", "0"), ("analytic", "0", "1", "0"), ("wf0", "0", "0", "0"), ("wf0_analytic", "0", "0", "0"),
                                                    ("numerical", "1", "0", "0"),
                                                    ("numerical", "1", "1", "0"), ("numerical", "1", "1", "1"), ("numerical", "1", "0", "1")])
-def test_two_ranks_equal_one(tmp_path, mode, sparse, p2p, every):
+def test_two_ranks_equal_one(tmp_path, mode, sparse, p2p, every, monkeypatch):
+    for k in ("CLID_P2P", "CLID_TOUCH_ALL", "CLID_SPARSE"):  # (_run sets them in THIS process for the one-rank run: restored afterwards)
+        monkeypatch.setenv(k, os.environ.get(k, "0"))
     port = 29700 + (os.getpid() % 1000) + {"numerical": 0, "analytic": 1, "wf0": 16, "wf0_analytic": 17}[mode] + 2 * int(sparse) + 4 * int(p2p) + 8 * int(every)
     _run(0, 1, port, str(tmp_path), mode)
     os.environ.pop("CLID_SPARSE", None)

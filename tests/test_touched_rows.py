@@ -270,7 +270,9 @@ def test_bench_spawns_its_ranks(tmp_path):
     import subprocess
     import sys
 
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    # (no rendezvous variables of a surrounding launcher, and none of the CLID_* switches other tests of this process set)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT") and not k.startswith("CLID_")}
     cmd = [sys.executable, os.path.join(T.__file__.rsplit("/tests/", 1)[0], "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--frame-calls", "0", "--no-cpu-baseline", "--bs", "2048", "--exchange-ab", "all"]
     out = subprocess.run(cmd + ["--backend", "gloo"], capture_output=True, text=True, env=env, timeout=600)
