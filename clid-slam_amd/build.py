@@ -23,6 +23,9 @@ FLAGS = [
     "-munsafe-fp-atomics",      # global_atomic_add_f32 instead of a CAS loop
     "-ffp-contract=on",         # FMA only inside one expression; exact-order code uses __f*_rn
     "-Wno-unused-result", "-Wno-unused-value",
+    # the leading scalar / pointer arguments of a kernel arrive in SGPRs with the wave instead of through an s_load of the
+    # kernel-argument segment (decode 11.75 -> 11.5 us: the record request goes out earlier; profiles/r05_kernarg_ab.jsonl)
+    "-mllvm", "-amdgpu-kernarg-preload-count=16",
 ]
 
 

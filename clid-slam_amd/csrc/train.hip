@@ -916,7 +916,10 @@ struct AdamLaunch {
 
 // blocks [0, kColBlocks): 16 decoder parameters / loss columns each (reduce partial rows or read grad), Adam
 // blocks [kColBlocks, +n_feat_blocks): dense Adam over the feature table (float4), gradient zeroed in the same pass
-__global__ void __launch_bounds__(256) k_adam_all(AdamLaunch a) {
+// (the pointers a wave needs first lead the kernel-argument segment: they arrive in SGPRs with the wave, -amdgpu-kernarg-preload-count)
+__global__ void __launch_bounds__(256) k_adam_all(float* feat_, float* grad_, float* m_, float* v_, const float* partial_, int nb_,
+                                                  AdamLaunch a) {
+  a.feat = feat_; a.grad = grad_; a.m = m_; a.v = v_; a.partial = partial_; a.nb = nb_;
   // the column blocks carry the longer chain (7 loads -> wave sum -> Adam -> store): they are dispatched first
   if ((int)blockIdx.x >= kColBlocks) {
     const long long i4 = ((long long)((int)blockIdx.x - kColBlocks) * 256 + threadIdx.x) * 4;
@@ -1417,7 +1420,8 @@ extern "C" int clid_train_adam(const clid_adam_args* a, const clid_train_args* t
   }
   L.n_feat_blocks = (int)(((a->n_feat + 3) / 4 + 255) / 256);
   L.k = adam_scalars(a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->step);
-  CLID_KLAUNCH(t ? t->prof : nullptr, 3, k_adam_all, dim3(L.n_feat_blocks + kColBlocks), dim3(256), 0, s, L);
+  CLID_KLAUNCH(t ? t->prof : nullptr, 3, k_adam_all, dim3(L.n_feat_blocks + kColBlocks), dim3(256), 0, s, L.feat, L.grad, L.m, L.v,
+               L.partial, L.nb, L);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }

@@ -149,8 +149,10 @@ __device__ __forceinline__ void tile_lds_fence() {
 // headline kernel at 226 + 32 > 256 registers = one wave per SIMD)
 template <int PREC, bool LN, int TW, bool PRE, int WPS = 0, bool EM = false>
 __global__ void __launch_bounds__(TW * 64, CLID_TILE_WAVES)
-k_decode_tile(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, TaskMap tmap,
-              const float4* __restrict__ rec, const int* __restrict__ tnum, int n_tiles, float* __restrict__ sdf_dbg) {
+k_decode_tile(const float4* __restrict__ rec, const int* __restrict__ tnum, int n_tiles, float* __restrict__ partial,
+              float* __restrict__ sdf_dbg, TaskMap tmap, clid_map_view mv, clid_train_args ta) {
+  // (argument order: what the wave's first loads need -- the record, the number block -- leads the kernel-argument segment, ahead
+  // of the two by-value structs: with -mllvm -amdgpu-kernarg-preload-count these arrive in SGPRs with the wave)
   constexpr bool LW = WPS == 3;  // decoder operands read from LDS per use (the <= 168-register instantiation)
   // BLK (launches of one tile per wave: the pre-numbered instantiation): dW1 / db1 are contracted once per BLOCK behind the
   // block's barrier -- wave w takes hidden units 16 w .. 16 w + 15 over the 64 queries whose dh / f rows the four waves staged
@@ -797,7 +799,7 @@ int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, f
   int nb3 = (n_tiles + 3) / 4;  // (the 4-wave blocks of the 3-waves-per-SIMD instantiation: never more partial rows than `nb`)
   if (nb3 > nb) nb3 = nb;
 #define CLID_TILE_LAUNCH_K(K, TWV)                                                                                    \
-  CLID_KLAUNCH(a->prof, 0, K, dim3(nb), dim3((TWV) * 64), 0, s, *mv, *a, partial, tmap, r4, tn, n_tiles, a->sdf_dbg)
+  CLID_KLAUNCH(a->prof, 0, K, dim3(nb), dim3((TWV) * 64), 0, s, r4, tn, n_tiles, partial, a->sdf_dbg, tmap, *mv, *a)
 #define CLID_TILE_LAUNCH(P, L)                                                                                        \
   do {                                                                                                                \
     const bool small = tile_waves_for(n_tiles) == kTileWavesSmall;                                                    \
@@ -810,8 +812,8 @@ int clid_launch_decode_tile(const clid_map_view* mv, const clid_train_args* a, f
     else if (small)                                                                                                   \
       CLID_TILE_LAUNCH_K((k_decode_tile<P, L, kTileWavesSmall, false>), kTileWavesSmall);                             \
     else if (!L && (a->debug_flags & 16)) /* debug bit 4: the 3-waves-per-SIMD instantiation (operands from LDS; 4-wave blocks) */ \
-      CLID_KLAUNCH(a->prof, 0, (k_decode_tile<P, L, 4, false, L ? 0 : 3>), dim3(nb3), dim3(256), 0, s, *mv, *a, partial, tmap, r4, tn, \
-                   n_tiles, a->sdf_dbg);                                                                               \
+      CLID_KLAUNCH(a->prof, 0, (k_decode_tile<P, L, 4, false, L ? 0 : 3>), dim3(nb3), dim3(256), 0, s, r4, tn, n_tiles, partial, \
+                   a->sdf_dbg, tmap, *mv, *a);                                                                         \
     else                                                                                                              \
       CLID_TILE_LAUNCH_K((k_decode_tile<P, L, kTileWavesLarge, false>), kTileWavesLarge);                             \
   } while (0)
