@@ -51,6 +51,7 @@ if os.environ.get("CLID_BENCH_POLL", "auto") == "1" or (os.environ.get("CLID_BEN
     os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
 # the peer-mapped A/B leg of a multi-GPU run: a flag wait gives up after 20 s here (library default 600 s) and the call is
 # repeated over RCCL, so a transport that does not work on this node costs seconds, not the run
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # (this ROCm's default: kernel arguments in device memory, profiles/r05_kernarg_ab.jsonl)
 os.environ.setdefault("CLID_P2P_TIMEOUT_S", "20")
 
 import torch  # noqa: E402

@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")  # completion waits by polling, as bench.py (a frame ends in sub-ms host waits)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # (this ROCm's default: kernel arguments in device memory)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import yaml  # noqa: E402

@@ -489,10 +489,12 @@ struct TrackParams {
 };
 
 __global__ void __launch_bounds__(CLID_BLOCK)
-k_track_model(clid_map_view mv, const float* W1, const float* b1, const float* W2, const float* b2, TrackParams tp,
-              const float* __restrict__ pc_imu, int N, float* __restrict__ sdf_out, float* __restrict__ grad_out,
-              float* __restrict__ pmap_out, int* __restrict__ valid_out, double* __restrict__ normal_eq /* 28 */,
-              const float* __restrict__ rot_dev, const float* __restrict__ pos_dev, double* __restrict__ zero_next = nullptr) {
+k_track_model(const float* __restrict__ pc_imu, const float* __restrict__ rot_dev, const float* __restrict__ pos_dev, const float* W1,
+              const float* b1, const float* W2, const float* b2, int N, clid_map_view mv, TrackParams tp, float* __restrict__ sdf_out,
+              float* __restrict__ grad_out, float* __restrict__ pmap_out, int* __restrict__ valid_out,
+              double* __restrict__ normal_eq /* 28 */, double* __restrict__ zero_next = nullptr) {
+  // (argument order: the pointers of the wave's first loads -- the scan, the pose, the decoder -- lead the kernel-argument segment
+  // and arrive in SGPRs with the wave, -amdgpu-kernarg-preload-count; the by-value structs follow)
   // (clid_track_model_call) block 0 clears the NEXT call's reduction buffer: 16 x 32 doubles, two per thread
   if (zero_next && blockIdx.x == 0)
     for (int i = threadIdx.x; i < CLID_TRACK_COPIES * 32; i += CLID_BLOCK) zero_next[i] = 0.0;
@@ -761,8 +763,8 @@ static int track_model_launch(const clid_map_view* mv, const float* W1, const fl
   tp.min_nn = min_nn;
   tp.max_sdf_std = max_sdf_std;
   hipLaunchKernelGGL(clid::k_track_model, dim3((N + CLID_QPB - 1) / CLID_QPB), dim3(CLID_BLOCK), 0,
-                     (hipStream_t)stream, *mv, W1, b1, W2, b2, tp, pc_imu, N, sdf_out, grad_out, pmap_out, valid_out,
-                     normal_eq, rot_dev, pos_dev);
+                     (hipStream_t)stream, pc_imu, rot_dev, pos_dev, W1, b1, W2, b2, N, *mv, tp, sdf_out, grad_out, pmap_out, valid_out,
+                     normal_eq);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
 }
@@ -804,9 +806,9 @@ extern "C" int clid_track_model_call(const clid_track_call* c, const float* rot,
   tp.min_nn = c->min_nn;
   tp.max_sdf_std = c->max_sdf_std;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(clid::k_track_model, dim3((c->N + CLID_QPB - 1) / CLID_QPB), dim3(CLID_BLOCK), 0, s, c->mv, c->W1, c->b1, c->W2,
-                     c->b2, tp, c->pc_imu, c->N, c->sdf_out, c->grad_out, c->pmap_out, c->valid_out, normal_eq,
-                     pose_on_device ? rot : nullptr, pose_on_device ? pos : nullptr, zero_next);
+  hipLaunchKernelGGL(clid::k_track_model, dim3((c->N + CLID_QPB - 1) / CLID_QPB), dim3(CLID_BLOCK), 0, s, c->pc_imu,
+                     pose_on_device ? rot : nullptr, pose_on_device ? pos : nullptr, c->W1, c->b1, c->W2, c->b2, c->N, c->mv, tp,
+                     c->sdf_out, c->grad_out, c->pmap_out, c->valid_out, normal_eq, zero_next);
   if (result) hipLaunchKernelGGL(clid::k_track_finish, dim3(1), dim3(64), 0, s, normal_eq, result, epoch);
   CLID_CHECK_LAUNCH();
   return CLID_OK;

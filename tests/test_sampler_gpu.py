@@ -347,3 +347,30 @@ def test_process_frame_without_voxel_round_trips_equals_the_two_phase_path(monke
                 assert x.shape == y.shape and torch.equal(x, y)
             else:
                 assert x == y
+
+
+def test_process_frame_with_the_gated_pool_compaction_equals_the_default(monkeypatch):
+    """CLID_POOL_GATE=1 (clid_pool_filter_after: the five-array compaction held back behind the map growth's voxel pass by an
+    event; the passes in front of it are not) is a pure change of schedule: identical pools, maps, windows and selections."""
+    import bench_sequence as BS
+
+    runs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CLID_POOL_GATE", mode)
+        torch.manual_seed(0)
+        snaps = []
+
+        def grab(mp, nm):
+            snaps.append((mp.coord_pool.clone(), mp.global_coord_pool.clone(), mp.sdf_label_pool.clone(), mp.weight_pool.clone(),
+                          mp.time_pool.clone(), mp.new_idx.clone(), mp.adaptive_iter_offset, mp.cur_sample_count,
+                          nm.neural_points.clone(), nm.local_neural_points.clone(), nm.global2local.clone()))
+
+        BS.run(5, "cuda:0", quiet=True, after_process=grab)
+        runs.append(snaps)
+    assert len(runs[0]) == len(runs[1]) == 5
+    for a, b in zip(*runs):
+        for x, y in zip(a, b):
+            if isinstance(x, torch.Tensor):
+                assert x.shape == y.shape and torch.equal(x, y)
+            else:
+                assert x == y
