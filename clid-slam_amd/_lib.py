@@ -166,6 +166,8 @@ _SIGS = {
     "clid_mapping_prep": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i64, _vp, _i64, C.c_uint64, C.c_uint64, _vp, C.c_float,
                                     _vp, _i32, _i32, _i32, _vp]),
     "clid_debug_prep_draw": (_i64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "clid_debug_scan_scratch_bytes": (_i64, [_i64]),
+    "clid_debug_scan": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "clid_comm_unique_id": (C.c_int, [_vp]),
     "clid_comm_init": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
     "clid_comm_size": (C.c_int, [_vp]),

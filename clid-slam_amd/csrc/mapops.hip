@@ -16,6 +16,138 @@
 
 namespace clid {
 
+// ---- exclusive prefix sums (hand-written since round 5; hipcub::DeviceScan / BlockScan before) ----------------------------
+// Every compaction of this file is flags -> exclusive scan -> scatter over 1e4 .. 1e6 elements (the pool: 4e4 block counts).
+// A block of 1024 threads scans a tile of 4096 elements: 4 consecutive elements per thread, an inclusive scan of the thread
+// sums across the wave by lane shifts, the 16 wave totals through LDS.  Up to kScanOneMax elements (one tile) that is the whole
+// scan -- one launch; beyond that two launches over tiles of 1024, tile totals first, then every block adds up the totals in
+// front of its tile (<= a few hundred, cache-resident) and scans it: no look-back chain, no spin, nothing order-dependent.
+constexpr int kScanThreads = 1024, kScanTile = 4 * kScanThreads;  // the one-block form (<= kScanOneMax elements)
+constexpr int kScanThreadsM = 256, kScanTileM = 4 * kScanThreadsM;  // the two-launch form: small tiles, so that 1e5 elements
+                                                                    // already spread over ~100 CUs (both launches are latency-bound)
+constexpr long long kScanOneMax = kScanTile;  // one tile: a longer walk of one block over several tiles measured slower than the
+                                               // two-launch form (13.8 us for 10 tiles against 4.6 + 5.0 us, tracer attached)
+template <class T>
+__device__ __forceinline__ T wave_incl_scan(T v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const T o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+// exclusive prefix of one value per thread over a block of NT threads (NT / 64 wave totals in `ws`); *total = the block's sum
+template <class T, int NT>
+__device__ __forceinline__ T block_excl_scan(T v, T* ws, T* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const T incl = wave_incl_scan(v, lane);
+  if (lane == 63) ws[w] = incl;
+  __syncthreads();
+  T base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) {
+    const T x = ws[i];
+    base += i < w ? x : (T)0;
+    tot += x;
+  }
+  __syncthreads();  // (ws may be written again)
+  *total = tot;
+  return base + incl - v;
+}
+// one tile of 4 NT elements: base + 4 t .. base + 4 t + 3 of thread t; out = carry + exclusive prefix; returns carry + the tile's sum
+template <class T, int NT, bool WRITE>
+__device__ __forceinline__ T scan_tile(const T* __restrict__ in, T* __restrict__ out, long long base, long long n, T carry, T* ws) {
+  const long long i0 = base + 4LL * threadIdx.x;
+  T v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = i0 + k < n ? in[i0 + k] : (T)0;
+  T tot;
+  T ex = block_excl_scan<T, NT>((v[0] + v[1]) + (v[2] + v[3]), ws, &tot) + carry;
+  if (WRITE) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i0 + k < n) out[i0 + k] = ex;
+      ex += v[k];
+    }
+  }
+  return carry + tot;
+}
+// (all of a thread's elements are requested before the first tile is scanned: tile by tile behind the barriers of the block scan
+// every tile paid its own memory latency -- 26.8 us for the pool's 39 k block counts, 10 tiles)
+template <class T>
+__global__ void __launch_bounds__(kScanThreads) k_scan_one(const T* __restrict__ in, T* __restrict__ out, long long n) {
+  __shared__ T ws[kScanThreads / 64];
+  constexpr int kTiles = (int)(kScanOneMax / kScanTile);
+  T v[kTiles][4];
+#pragma unroll
+  for (int t = 0; t < kTiles; ++t) {
+    const long long i0 = (long long)t * kScanTile + 4LL * threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[t][k] = i0 + k < n ? in[i0 + k] : (T)0;
+  }
+  T carry = 0;
+#pragma unroll
+  for (int t = 0; t < kTiles; ++t) {
+    if ((long long)t * kScanTile >= n) break;  // (uniform)
+    const long long i0 = (long long)t * kScanTile + 4LL * threadIdx.x;
+    T tot;
+    T ex = block_excl_scan<T, kScanThreads>((v[t][0] + v[t][1]) + (v[t][2] + v[t][3]), ws, &tot) + carry;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i0 + k < n) out[i0 + k] = ex;
+      ex += v[t][k];
+    }
+    carry += tot;
+  }
+}
+template <class T>
+__global__ void __launch_bounds__(kScanThreadsM) k_scan_totals(const T* __restrict__ in, T* __restrict__ totals, long long n) {
+  __shared__ T ws[kScanThreadsM / 64];
+  const T tot = scan_tile<T, kScanThreadsM, false>(in, nullptr, (long long)blockIdx.x * kScanTileM, n, (T)0, ws);
+  if (threadIdx.x == 0) totals[blockIdx.x] = tot;
+}
+template <class T>
+__global__ void __launch_bounds__(kScanThreadsM) k_scan_apply(const T* __restrict__ in, T* __restrict__ out,
+                                                              const T* __restrict__ totals, long long n) {
+  __shared__ T ws[kScanThreadsM / 64];
+  T mine = 0;  // the totals of the tiles in front of this one, summed in a fixed order per thread, then over the block
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += kScanThreadsM) mine += totals[i];
+  T carry;
+  (void)block_excl_scan<T, kScanThreadsM>(mine, ws, &carry);
+  (void)scan_tile<T, kScanThreadsM, true>(in, out, (long long)blockIdx.x * kScanTileM, n, carry, ws);
+}
+// bytes of `scratch` scan_exclusive needs for n elements (the tile totals of the two-launch form)
+#ifndef CLID_SCAN_LIB
+#define CLID_SCAN_LIB 0  // 1: hipcub::DeviceScan (the scans of rounds 2-4; A/B)
+#endif
+static size_t scan_scratch_bytes(long long n) {
+  size_t need = ((size_t)((n + kScanTileM - 1) / kScanTileM) + 1) * 8 + 256;
+#if CLID_SCAN_LIB
+  size_t tmp = 0;
+  hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (int)n);
+  need = need > tmp + 256 ? need : tmp + 256;
+#endif
+  return need;
+}
+// out[i] = in[0] + .. + in[i - 1]; in != out; integer T (exact, order-free)
+template <class T>
+static void scan_exclusive(const T* in, T* out, long long n, void* scratch, hipStream_t s) {
+  if (n <= 0) return;
+#if CLID_SCAN_LIB
+  size_t bytes = scan_scratch_bytes(n);
+  (void)hipcub::DeviceScan::ExclusiveSum(scratch, bytes, in, out, (int)n, s);
+  return;
+#endif
+  if (n <= kScanOneMax && sizeof(T) == 4) {  // (64-bit elements would spill in the one-block form: they take the two-launch form)
+    hipLaunchKernelGGL(k_scan_one<T>, dim3(1), dim3(kScanThreads), 0, s, in, out, n);
+    return;
+  }
+  const unsigned nb = (unsigned)((n + kScanTileM - 1) / kScanTileM);
+  T* totals = static_cast<T*>(scratch);
+  hipLaunchKernelGGL(k_scan_totals<T>, dim3(nb), dim3(kScanThreadsM), 0, s, in, totals, n);
+  hipLaunchKernelGGL(k_scan_apply<T>, dim3(nb), dim3(kScanThreadsM), 0, s, in, out, (const T*)totals, n);
+}
+
 // the seven reduced values of the bounding-box pass, ONE per 128-byte line (atomics on one line retire one after the other
 // whichever word they hit): [lo x, lo y, lo z, hi x, hi y, hi z, dmax] at box[k * kBoxStride]
 constexpr int kBoxStride = 32;
@@ -1284,7 +1416,11 @@ constexpr int kSortSeg = 16384, kSortThreads = 1024, kSortBins = 256, kSortWaves
 // the mean (3 per thread): the counting passes are bound by the VALU rate of the block's ONE CU
 constexpr int kSortBucketsFew = 8, kSortBucketsMany = 16;
 __host__ __device__ constexpr int sort_bucket_items(int buckets) { return buckets == kSortBucketsMany ? 3 : 32 / buckets; }
-using BinScan = hipcub::BlockScan<unsigned, kSortThreads>;
+struct BinScan {  // LDS of block_excl_scan<unsigned, kSortThreads> (the top of this file): the block's wave totals
+  struct TempStorage {
+    unsigned w[kSortThreads / 64];
+  };
+};
 
 // lanes of the wave that hold the same 8-bit digit as this lane (an OR-mask row in LDS per wave does the same with two LDS
 // operations, but a sorting block is LDS-throughput-bound on its one CU)
@@ -1333,7 +1469,8 @@ __device__ __forceinline__ void counting_pass(const unsigned (&digit)[ITEMS], un
       sum += c[i];
     }
     unsigned off;
-    BinScan(scan_tmp).ExclusiveSum(sum, off);
+    unsigned all_;
+    off = block_excl_scan<unsigned, kSortThreads>(sum, scan_tmp.w, &all_);
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
       tab[b0 + i] = off;
@@ -1416,7 +1553,8 @@ __device__ __forceinline__ void class_ranks(const unsigned (&dest)[ITEMS], const
   {
     const unsigned c = (int)threadIdx.x < NW ? (unsigned)__popc(words[threadIdx.x]) : 0u;
     unsigned off;
-    BinScan(scan_tmp).ExclusiveSum(c, off);
+    unsigned all_;
+    off = block_excl_scan<unsigned, kSortThreads>(c, scan_tmp.w, &all_);
     if ((int)threadIdx.x < NW) wpre[threadIdx.x] = off;
   }
   __syncthreads();
@@ -1707,12 +1845,22 @@ extern "C" int64_t clid_debug_prep_draw(uint64_t seed, uint64_t counter, uint64_
   return (int64_t)(unsigned long long)(((unsigned __int128)r * range) >> 64);
 }
 
-// ---- pool maintenance --------------------------------------------------------------------------------------------
-static size_t pool_scan_bytes(long long n) {
-  size_t tmp = 0;
-  hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, (const int*)nullptr, (int*)nullptr, (int)n);
-  return tmp;
+// test entry of the hand-written exclusive scans every compaction of this file runs on: elem_bytes 4 (int32) or 8 (uint64);
+// scratch: clid_debug_scan_scratch_bytes(n) bytes
+extern "C" int64_t clid_debug_scan_scratch_bytes(int64_t n) { return (int64_t)scan_scratch_bytes(n); }
+extern "C" int clid_debug_scan(const void* in, void* out, int64_t n, int32_t elem_bytes, void* scratch, void* stream) {
+  if (n < 0 || (n > 0 && (!in || !out || !scratch || in == out)) || (elem_bytes != 4 && elem_bytes != 8)) {
+    clid_set_error("clid_debug_scan: bad argument");
+    return CLID_E_ARG;
+  }
+  if (elem_bytes == 4) scan_exclusive(static_cast<const int*>(in), static_cast<int*>(out), (long long)n, scratch, (hipStream_t)stream);
+  else scan_exclusive(static_cast<const unsigned long long*>(in), static_cast<unsigned long long*>(out), (long long)n, scratch, (hipStream_t)stream);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
 }
+
+// ---- pool maintenance --------------------------------------------------------------------------------------------
+static size_t pool_scan_bytes(long long n) { return scan_scratch_bytes(n); }
 extern "C" int64_t clid_pool_workspace_bytes(int64_t n_total) {
   if (n_total <= 0) return 256;
   const size_t nblk = ((size_t)n_total + 255) / 256;  // flags (1 B) | block counts | block offsets | kept list | scan scratch
@@ -1765,25 +1913,18 @@ extern "C" int clid_pool_filter_after(const float* coord_a, const float* gcoord_
   int* block_off = reinterpret_cast<int*>(ws + align256((size_t)n) + align256((size_t)nblk * 4));
   int* kept_list = reinterpret_cast<int*>(ws + align256((size_t)n) + 2 * align256((size_t)nblk * 4));
   void* cub = ws + align256((size_t)n) + 2 * align256((size_t)nblk * 4) + align256((size_t)n * 4);
-  size_t cub_bytes = pool_scan_bytes(nblk);
   const PoolSrc a{coord_a, gcoord_a, label_a, weight_a, time_a, n_a, nullptr},
       b{coord_b, gcoord_b, label_b, weight_b, time_b, n_b, reinterpret_cast<const long long*>(n_b_dev)};
   const unsigned blocks = (unsigned)nblk;
   hipLaunchKernelGGL(k_pool_flags, dim3(blocks), dim3(256), 0, s, a, b, origin_host[0], origin_host[1], origin_host[2], radius2,
                      flag, block_cnt);
-  if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, block_cnt, block_off, (int)nblk, s) != hipSuccess) {
-    clid_set_error("clid_pool_filter: scan failed");
-    return CLID_E_HIP;
-  }
+  scan_exclusive(block_cnt, block_off, (long long)nblk, cub, s);
   if (n > capacity) {  // only then can more than `capacity` samples survive the window test
     hipLaunchKernelGGL(k_pool_list, dim3(blocks), dim3(256), 0, s, flag, block_off, block_cnt, n, kept_list, counts);
     hipLaunchKernelGGL(k_pool_drop, dim3(1024), dim3(256), 0, s, flag, kept_list, counts, (long long)capacity,
                        (unsigned long long)seed);
     hipLaunchKernelGGL(k_pool_count, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, s, flag, n, block_cnt);
-    if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, block_cnt, block_off, (int)nblk, s) != hipSuccess) {
-      clid_set_error("clid_pool_filter: scan failed");
-      return CLID_E_HIP;
-    }
+    scan_exclusive(block_cnt, block_off, (long long)nblk, cub, s);
   }
   const PoolDst d{coord_out, gcoord_out, label_out, weight_out, time_out};
   if (scatter_after_event && hipStreamWaitEvent(s, (hipEvent_t)scatter_after_event, 0) != hipSuccess) {
@@ -1800,11 +1941,7 @@ extern "C" int clid_pool_filter_after(const float* coord_a, const float* gcoord_
 // arrays, a second mask |sdf| < surface_range * ratio, another indexed copy and two rigid transforms.  One flag pass, ONE
 // scan over packed (kept, near) 64-bit counters and one scatter: compacted coord / label / weight, the frame stamp, the
 // world-frame coordinates (pool) and the world-frame near-surface subset (NeuralPoints.update), stable order.
-static size_t scan64_bytes(long long n) {
-  size_t tmp = 0;
-  hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (int)n);
-  return tmp;
-}
+static size_t scan64_bytes(long long n) { return scan_scratch_bytes(n); }
 
 __global__ void __launch_bounds__(256)
 k_compact_flags(const unsigned char* __restrict__ keep, const float* __restrict__ label, long long n, float near_range,
@@ -1868,15 +2005,11 @@ extern "C" int clid_sample_compact(const float* coord, const float* label, const
   unsigned long long* flag = reinterpret_cast<unsigned long long*>(ws);
   unsigned long long* pos = reinterpret_cast<unsigned long long*>(ws + align256((size_t)n * 8));
   void* cub = ws + 2 * align256((size_t)n * 8);
-  size_t cub_bytes = scan64_bytes(n);
   Pose12 p;
   for (int i = 0; i < 12; ++i) p.T[i] = pose12_host[i];
   const unsigned blocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_compact_flags, dim3(blocks), dim3(256), 0, s, keep, label, (long long)n, near_range, flag);
-  if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)n, s) != hipSuccess) {
-    clid_set_error("clid_sample_compact: scan failed");
-    return CLID_E_HIP;
-  }
+  scan_exclusive(flag, pos, (long long)n, cub, s);
   hipLaunchKernelGGL(k_compact_scatter, dim3(blocks), dim3(256), 0, s, coord, label, weight, flag, pos, (long long)n, p,
                      (int)stamp, coord_out, gcoord_out, label_out, weight_out, stamp_out, update_out, counts);
   CLID_CHECK_LAUNCH();
@@ -1949,15 +2082,11 @@ extern "C" int clid_new_sample_select(const int64_t* buffer_pt_index, int64_t bu
   int* flag = reinterpret_cast<int*>(ws);
   int* pos = reinterpret_cast<int*>(ws + align256((size_t)n * 4));
   void* cub = ws + 2 * align256((size_t)n * 4);
-  size_t cub_bytes = pool_scan_bytes(n);
   const unsigned blocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_new_sample_flags, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const long long*>(buffer_pt_index),
                      (int)buffer_size, neural_points, point_certainties, delta, P, resolution, max_valid_dist2, x, sdf_label,
                      (int)n, certainty_thre, label_max, flag, reinterpret_cast<const long long*>(pool_counts));
-  if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)n, s) != hipSuccess) {
-    clid_set_error("clid_new_sample_select: scan failed");
-    return CLID_E_HIP;
-  }
+  scan_exclusive(flag, pos, (long long)n, cub, s);
   hipLaunchKernelGGL(k_new_sample_list, dim3(blocks), dim3(256), 0, s, flag, pos, (int)n, (long long)index_offset,
                      reinterpret_cast<long long*>(idx_out), count, reinterpret_cast<const long long*>(pool_counts));
   CLID_CHECK_LAUNCH();
@@ -1999,7 +2128,6 @@ extern "C" int clid_local_window(const float* neural_points, const int32_t* ts_c
   int* flag = reinterpret_cast<int*>(ws + align256((size_t)nu));
   int* pos = reinterpret_cast<int*>(ws + align256((size_t)nu) + align256((size_t)nu * 4));
   void* cub = ws + align256((size_t)nu) + 2 * align256((size_t)nu * 4);
-  size_t cub_bytes = nu > 0 ? pool_scan_bytes(nu) : 0;
   WindowArgs a{neural_points, ts_create, ts_update, travel_dist, n, reinterpret_cast<const long long*>(n_extra_dev), cur_ts,
                use_mid_ts, temporal, use_travel_dist, diff_ts_local, reboot_ts, reboot_map, diff_travel, sensor_pos_host[0],
                sensor_pos_host[1], sensor_pos_host[2], radius2, pos_is_f64};
@@ -2007,10 +2135,7 @@ extern "C" int clid_local_window(const float* neural_points, const int32_t* ts_c
     const unsigned blocks = (unsigned)((nu + 255) / 256);
     hipLaunchKernelGGL(k_window_flags, dim3(blocks < kFlagBlocks ? blocks : kFlagBlocks), dim3(256), 0, s, a, bits, counts);
     hipLaunchKernelGGL(k_window_combine, dim3(blocks), dim3(256), 0, s, a, bits, nu, counts, flag);
-    if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)nu, s) != hipSuccess) {
-      clid_set_error("clid_local_window: scan failed");
-      return CLID_E_HIP;
-    }
+    scan_exclusive(flag, pos, (long long)nu, cub, s);
   }
   WindowOut o{(long long)local_capacity, reinterpret_cast<long long*>(local_ids_out), reinterpret_cast<long long*>(global2local_out), local_mask_out,
               local_points_out, local_orient_out, local_cert_out, local_ts_out, local_feat_out, point_orientations,
@@ -2046,17 +2171,13 @@ extern "C" int clid_map_insert(const float* samples, int32_t n, int64_t* buffer_
   int* pos = reinterpret_cast<int*>(ws + 2 * align256((size_t)n * 4));
   long long* held = reinterpret_cast<long long*>(ws + 3 * align256((size_t)n * 4));
   void* cub = ws + 3 * align256((size_t)n * 4) + align256((size_t)n * 8);
-  size_t cub_bytes = pool_scan_bytes(n);
   InsertArgs a{samples, n, reinterpret_cast<const long long*>(sample_idx), reinterpret_cast<const long long*>(n_dev),
                reinterpret_cast<long long*>(buffer_pt_index), (int)buffer_size, neural_points, point_orientations,
                ts_create, ts_update, certainties, reinterpret_cast<float4*>(features_zero), travel_dist, (long long)base, test_on, temporal, cur_ts, resolution, far_dist2,
                diff_travel};
   const unsigned blocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_insert_probe, dim3(blocks), dim3(256), 0, s, a, phys, held, flag);
-  if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, n, s) != hipSuccess) {
-    clid_set_error("clid_map_insert: scan failed");
-    return CLID_E_HIP;
-  }
+  scan_exclusive(flag, pos, (long long)n, cub, s);
   hipLaunchKernelGGL(k_insert_claim, dim3(blocks), dim3(256), 0, s, a, phys);
   hipLaunchKernelGGL(k_insert_commit, dim3(blocks), dim3(256), 0, s, a, phys, held, flag, pos, counts);
   CLID_CHECK_LAUNCH();
@@ -2093,17 +2214,13 @@ extern "C" int clid_cloud_update(const float* map_points, int64_t n_map, const f
   int* flag = reinterpret_cast<int*>(ws);
   int* pos = reinterpret_cast<int*>(ws + align256((size_t)n * 4));
   void* cub = ws + 2 * align256((size_t)n * 4);
-  size_t cub_bytes = pool_scan_bytes(n);
   CloudArgs a{map_points, n_map, samples, n_samples, reinterpret_cast<const long long*>(sample_idx),
               reinterpret_cast<const long long*>(n_samples_dev), reinterpret_cast<const long long*>(table_old),
               reinterpret_cast<long long*>(table_new), (int)buffer_size, resolution, sensor_pos_host[0], sensor_pos_host[1],
               sensor_pos_host[2], map_size, pos_is_f64};
   const unsigned blocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_cloud_flags, dim3(blocks < kFlagBlocks ? blocks : kFlagBlocks), dim3(256), 0, s, a, flag, counts);
-  if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)n, s) != hipSuccess) {
-    clid_set_error("clid_cloud_update: scan failed");
-    return CLID_E_HIP;
-  }
+  scan_exclusive(flag, pos, (long long)n, cub, s);
   hipLaunchKernelGGL(k_cloud_scatter, dim3(blocks), dim3(256), 0, s, a, flag, pos, points_out, counts);
   CLID_CHECK_LAUNCH();
   return CLID_OK;
@@ -2168,14 +2285,10 @@ extern "C" int clid_map_prune_select(const int32_t* ts_update, const float* cert
   int* flag = reinterpret_cast<int*>(ws);
   int* pos = reinterpret_cast<int*>(ws + align256((size_t)n * 4));
   void* cub = ws + 2 * align256((size_t)n * 4);
-  size_t cub_bytes = pool_scan_bytes(n);
   const unsigned blocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_prune_flags, dim3(blocks), dim3(256), 0, s, ts_update, cert, (int)n, travel_dist, cur_ts, certainty_thre,
                      diff_travel_dist, global_prune, flag);
-  if (hipcub::DeviceScan::ExclusiveSum(cub, cub_bytes, flag, pos, (int)n, s) != hipSuccess) {
-    clid_set_error("clid_map_prune_select: scan failed");
-    return CLID_E_HIP;
-  }
+  scan_exclusive(flag, pos, (long long)n, cub, s);
   hipLaunchKernelGGL(k_new_sample_list, dim3(blocks), dim3(256), 0, s, flag, pos, (int)n, 0LL,
                      reinterpret_cast<long long*>(keep_idx_out), count, (const long long*)nullptr);
   CLID_CHECK_LAUNCH();

@@ -756,6 +756,11 @@ int clid_mapping_prep(float* zero_base, int64_t zero_floats, int64_t* index_out,
                       const float* pool_coord, float resolution, void* sort_workspace, int32_t col0, int32_t ncols,
                       int32_t decimation, void* stream);
 int64_t clid_debug_prep_draw(uint64_t seed, uint64_t counter, uint64_t e, uint64_t range);
+/* Test entry: the exclusive prefix sum every compaction of the map / pool maintenance runs on (hand-written: tiles of 4096
+ * elements per 1024-thread block; one launch up to 4 096 elements, two beyond), out[i] = in[0] + .. + in[i - 1], in != out;
+ * elem_bytes 4 (int32) or 8 (uint64); scratch of clid_debug_scan_scratch_bytes(n) bytes. */
+int64_t clid_debug_scan_scratch_bytes(int64_t n);
+int clid_debug_scan(const void* in, void* out, int64_t n, int32_t elem_bytes, void* scratch, void* stream);
 
 /* ---- measurement aid (bench.py roofline leg; not part of the reference's interface) -----------
  * A profiler object handed in through clid_train_args.prof: the training entry points then issue each kernel through

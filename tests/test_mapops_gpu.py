@@ -303,3 +303,28 @@ def test_an_outlier_that_defeats_the_device_side_voxel_ordering_is_recovered_fro
     assert res[0][0] == res[1][0]
     for a, b in zip(res[0][1:], res[1][1:]):
         assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("elem", [4, 8])
+def test_exclusive_scan_vs_cumsum(elem):
+    """The hand-written exclusive prefix sum behind every compaction of the map / pool maintenance (csrc/mapops.hip
+    scan_exclusive: one launch up to 4 096 elements, two beyond) against numpy on the sizes around its tile and launch
+    boundaries; flags (0 / 1) and wide values."""
+    from clid_slam_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    for n in (1, 5, 63, 64, 1023, 1024, 1025, 4095, 4096, 4097, 8192, 40959, 40960, 40961, 65536, 131072, 1_000_003, 2_500_001):
+        for wide in (False, True):
+            if elem == 4:
+                host = rng.integers(0, 800 if wide else 2, n, dtype=np.int64).astype(np.int32)
+                dev = torch.from_numpy(host).cuda()
+            else:
+                host = rng.integers(0, (1 << 40) if wide else 2, n, dtype=np.int64)
+                dev = torch.from_numpy(host).cuda()
+            out = torch.full_like(dev, -1)
+            scratch = torch.empty(int(lib.clid_debug_scan_scratch_bytes(n)), device="cuda", dtype=torch.uint8)
+            _lib.check(lib.clid_debug_scan(dev.data_ptr(), out.data_ptr(), n, elem, scratch.data_ptr(), _lib.stream()), "clid_debug_scan")
+            want = np.concatenate(([0], np.cumsum(host.astype(np.int64))[:-1]))
+            got = out.cpu().numpy().astype(np.int64)
+            assert np.array_equal(got, want), (n, wide, int((got != want).sum()))
