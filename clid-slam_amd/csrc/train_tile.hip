@@ -47,6 +47,9 @@ constexpr int kTileWavesSmall = CLID_TILE_WAVES_SMALL, kTileWavesLarge = 2;
 #ifndef CLID_TILE_EARLY_REC
 #define CLID_TILE_EARLY_REC 1  // the one-tile-per-wave fp32 kernels request their record before the weight staging (0: A/B)
 #endif
+#ifndef CLID_TILE_PF
+#define CLID_TILE_PF 1  // the multi-tile launches fetch the NEXT tile's search record straight into LDS while the current tile runs (0: A/B)
+#endif
 #ifndef CLID_TILE_BLK
 #define CLID_TILE_BLK 1  // block-level dW1 flush of the one-tile-per-wave launches (0: the per-wave form, A/B)
 #endif
@@ -165,6 +168,12 @@ k_decode_tile(const float4* __restrict__ rec, const int* __restrict__ tnum, int 
   __shared__ float wq[LW ? kWFloats : 4];
   static_assert(sizeof(TL) % 16 == 0 && sizeof(TL) * TW >= TW * kRedFloats * sizeof(float), "LDS plan");
   static_assert(!LW || (sizeof(TileLdsC) * TW + kWFloats * 4) * (12 / TW) <= 160 * 1024, "LDS plan: 3 waves per SIMD");
+  // PF (launches of several tiles per wave): the two task records of the wave's NEXT tile (96 float4) arrive by LDS-DMA
+  // (global_load_lds: no registers -- the kernel has none to spare) while the current tile runs.  The request goes out in front
+  // of the current tile's feature gathers, so the wait at their first use covers it: at the top of the next iteration the record
+  // is simply there, and that iteration no longer opens with a wait that also drains the previous tile's gradient atomics.
+  constexpr bool PF = CLID_TILE_PF && !PRE && !LW;
+  __shared__ float4 recbuf[PF ? TW : 1][PF ? 2 * kRecF4 : 1];
   float* red = reinterpret_cast<float*>(tls);  // the block flush reuses the tile buffers (after a barrier)
   const int lane = threadIdx.x & 63, q = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
   TL& tl = tls[wave];
@@ -211,6 +220,28 @@ k_decode_tile(const float4* __restrict__ rec, const int* __restrict__ tnum, int 
     }
     return rc;
   };
+  auto prefetch_rec = [&](int tile) {  // (PF) lane l brings float4 l and, l < 32, float4 64 + l of the tile's 96
+    const size_t f0 = (size_t)2 * tile * kRecF4, last = (size_t)tmap.n_tasks * kRecF4 - 1;  // (an odd task count: the tile's second half is clamped)
+    const size_t a = f0 + lane < last ? f0 + lane : last, b = f0 + 64 + lane < last ? f0 + 64 + lane : last;
+    __builtin_amdgcn_global_load_lds(rec + a, (__attribute__((address_space(3))) void*)&recbuf[PF ? wave : 0][0], 16, 0, 0);
+    if (lane < 2 * kRecF4 - 64)
+      __builtin_amdgcn_global_load_lds(rec + b, (__attribute__((address_space(3))) void*)&recbuf[PF ? wave : 0][PF ? 64 : 0], 16, 0, 0);
+  };
+  auto read_rec = [&]() -> TileRec {  // (PF) the lane's slice of the record in LDS
+    TileRec rc;
+    const float4* r = &recbuf[PF ? wave : 0][PF ? (q >> 3) * kRecF4 : 0];
+    const int slot = q & 7;
+    rc.qi = r[slot];
+    rc.qq = r[8 + slot];
+    rc.w01 = r[16 + slot * 4];
+    rc.w23 = r[16 + slot * 4 + 1];
+    rc.w45 = r[16 + slot * 4 + 2];
+    rc.wf = r[16 + slot * 4 + 3];
+    rc.rid4 = make_int4(0, 0, 0, 0);
+    rc.n_rows = 0;
+    rc.rnum0 = rc.rnum1 = 255;
+    return rc;
+  };
   // EARLY (one tile per wave, fp32): the wave's record is requested BEFORE the decoder weights are staged -- its ~1 us of latency
   // runs under the staging's two barriers (decode 11.93 -> 11.65 us, three alternating runs).  (Round 4 measured this on the
   // 224 + 32-register kernel: 31 more live registers put it at one wave per SIMD; the block-level dW1 flush freed them.)
@@ -222,6 +253,10 @@ k_decode_tile(const float4* __restrict__ rec, const int* __restrict__ tnum, int 
   if constexpr (EARLY) {
     const int t0 = blockIdx.x * TW + wave;
     early = load_rec(t0 < n_tiles ? t0 : 0);
+  }
+  if constexpr (PF) {
+    const int t0 = blockIdx.x * TW + wave;
+    if (t0 < n_tiles) prefetch_rec(t0);  // (lands under the weight staging's barriers)
   }
 
   // ---- constant MFMA operands: the decoder weights (3.3 KB) are staged through LDS with one coalesced load per
@@ -313,7 +348,14 @@ k_decode_tile(const float4* __restrict__ rec, const int* __restrict__ tnum, int 
     const bool tlive = task < tmap.n_tasks;
     TileRec rc;
     if constexpr (EARLY) rc = early;
-    else rc = load_rec(tile);
+    else if constexpr (PF) {
+      if (tile == (int)(blockIdx.x * TW + wave))  // the wave's first tile: its request is the only memory operation in flight;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every later record landed under its predecessor's gather wait
+      rc = read_rec();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the record is in registers: its LDS slot may be overwritten
+      const int nxt = tile + gridDim.x * TW;
+      if (nxt < n_tiles) prefetch_rec(nxt);
+    } else rc = load_rec(tile);
     const float4 qi = rc.qi, qq = rc.qq, w01 = rc.w01, w23 = rc.w23, w45 = rc.w45, wf = rc.wf;
     const int sidx = tlive ? __float_as_int(qi.w) : -1;  // time stamp of the sample, -1 = padding slot
     const bool bundle = tlive && task < tmap.n_fd;
