@@ -67,6 +67,32 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
   const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
   const float sc = ta.sdf_scale;
 
+  // HOISTED: the lane's slice of a round's record (10 registers; the kernel has 36 to spare at two waves per SIMD), requested one
+  // round ahead -- in front of the current round's gathers, so their wait covers it and a round does not open with a wait that
+  // also drains the previous round's gradient atomics (vmcnt is one in-order counter for loads, stores and atomics)
+#ifndef CLID_ANALYTIC_PF
+#define CLID_ANALYTIC_PF 1
+#endif
+  struct RoundRec {
+    float4 qi, qd;
+    float2 wn;
+  };
+  auto load_round = [&](int rd_) -> RoundRec {
+    const int p = rd_ * 4 + grp;
+    const bool lv = p < ta.bs;
+    const float4* r = rec + (size_t)((lv ? p : 0) >> 3) * 48;  // qinfo[8] | qdesc[8] | win[8][8] float2
+    const int sl = lv ? (p & 7) : 0;
+    RoundRec o;
+    o.qi = r[sl];
+    o.qd = r[8 + sl];
+    o.wn = reinterpret_cast<const float2*>(r + 16)[sl * 8 + (my_k < CLID_K ? my_k : 0)];
+    return o;
+  };
+  RoundRec nxt;
+  if constexpr (HOISTED && CLID_ANALYTIC_PF) {
+    const int rd0 = blockIdx.x * waves_per_block + wave;
+    if (rd0 < n_rounds) nxt = load_round(rd0);
+  }
   for (int rd = blockIdx.x * waves_per_block + wave; rd < n_rounds; rd += gridDim.x * waves_per_block) {
     const int p_raw = rd * 4 + grp;
     bool live = p_raw < ta.bs;
@@ -75,7 +101,20 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
     int rec_ts = 0;
     int my_j = -1;
     float my_w = 0.f, my_om = 0.f;
-    if constexpr (HOISTED) {
+    if constexpr (HOISTED && CLID_ANALYTIC_PF) {
+      const RoundRec cur = nxt;
+      const int rdn = rd + gridDim.x * waves_per_block;
+      if (rdn < n_rounds) nxt = load_round(rdn);
+      const float4 qi = cur.qi, qd = cur.qd;
+      live = live && __float_as_int(qd.x) >= 0;
+      px = qi.x; py = qi.y; pz = qi.z;
+      rec_ts = __float_as_int(qi.w);
+      rec_label = qd.z; rec_wt = qd.w;
+      if (my_k < CLID_K) {
+        my_w = cur.wn.x;
+        my_j = __float_as_int(cur.wn.y);
+      }
+    } else if constexpr (HOISTED) {
       const float4* r = rec + (size_t)(p_raw >> 3) * 48;  // qinfo[8] | qdesc[8] | win[8][8] float2
       const int slot = p_raw & 7;
       const float4 qi = r[live ? slot : 0], qd = r[8 + (live ? slot : 0)];
