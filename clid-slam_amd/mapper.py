@@ -934,11 +934,11 @@ class Mapper:
             if side is None or side.device != coord.device:
                 side = self._side_stream = _lib.low_priority_stream(coord.device)
 
-            def fork_pool(scatter_after=None):
+            def fork_pool():
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     self._pool_append_filter_fused(coord, gcoord, sdf_label, weight, stamp, cur_pose_torch, frame_id, defer=True,
-                                                   n_b_dev=None if cmp_dev is None else cmp_dev[0:1], scatter_after=scatter_after)
+                                                   n_b_dev=None if cmp_dev is None else cmp_dev[0:1])
 
             pool_first = two_phase and defer_cmp and async_upd and os.environ.get("CLID_POOL_FORK_EARLY", "1") != "0"
             # CLID_POOL_GATE=1: the pool's flag / list / drop passes beside the voxel pass, its compaction (which takes every wave
