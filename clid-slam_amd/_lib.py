@@ -62,6 +62,8 @@ class TrainArgs(C.Structure):
         ("eik_mask", _i32), ("eik_mask_range", _f32), ("eik_inv_n", _vp),
         # ABI 7: config.main_loss_type (0 bce / 1 sdf_l1 / 2 sdf_l2 / 3 zhong); ba_done_flag: per-frame poses [n_pose][12] fp32
         ("main_loss_type", _i32), ("n_pose", _i32), ("pool_pose", _vp),
+        # config.proj_correction_on: labels scaled by |cos(g, x - origin of the sample's frame)|; frame poses [n][12] fp32
+        ("proj_correction", _i32), ("n_frame_pose", _i32), ("frame_pose", _vp),
     ]
 
 

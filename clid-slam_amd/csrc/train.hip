@@ -1471,6 +1471,14 @@ static int check_train_args(const clid_map_view* mv, const clid_train_args* a, c
       return CLID_E_ARG;
     }
   }
+  if (a->proj_correction) {
+    if (a->eikonal_mode != 2 || !hoisted(a) || a->decode_each_neighbour || !a->frame_pose || a->n_frame_pose <= 0 ||
+        ((uintptr_t)a->frame_pose & 15) != 0 || a->main_loss_type) {
+      clid_set_error("%s: proj_correction (config.proj_correction_on) needs the analytic eikonal term on the hoisted schedule, "
+                     "weighted_first, the BCE loss and frame_pose [n_frame_pose][12] (16-byte aligned)", who);
+      return CLID_E_ARG;
+    }
+  }
   if (a->pool_pose) {
     if (!a->pool_ts || a->n_pose <= 0 || !hoisted(a) || ((uintptr_t)a->pool_pose & 15) != 0) {
       clid_set_error("%s: pool_pose (Mapper.ba_done_flag) needs pool_ts, n_pose > 0, 16-byte alignment and the hoisted schedule "

@@ -30,7 +30,9 @@ namespace clid {
 #ifndef CLID_ANALYTIC_REGW
 #define CLID_ANALYTIC_REGW 1
 #endif
-template <bool HOISTED>
+// PC: config.proj_correction_on (utils/mapper.py:712-714): label' = label |cos(g, x - origin of the sample's frame)| with g in the
+// graph, so the BCE term reaches the parameters through g as well: dL/dg gains dL/dlabel' label d|cos|/dg (its own instantiation)
+template <bool HOISTED, bool PC = false>
 __global__ void __launch_bounds__(CLID_BLOCK, CLID_ANALYTIC_WAVES)
 k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, int n_rounds, const float4* __restrict__ rec) {
   __shared__ MlpLds mlp;
@@ -243,8 +245,25 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
     // ---- losses and their derivatives
     float delta = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
     if (live) {
-      const float label = HOISTED ? rec_label : ta.pool_label[s];
+      float label = HOISTED ? rec_label : ta.pool_label[s];
       const float wt = HOISTED ? rec_wt : (ta.loss_weight_on ? fabsf(ta.pool_weight[s]) : 1.0f);  // mapper.py:747-749
+      float dcx = 0.f, dcy = 0.f, dcz = 0.f, label0 = label;  // (PC) d|cos| / dg, the unscaled label
+      if constexpr (PC) {
+        // F.cosine_similarity(g, coord - origins) (mapper.py:713): both vectors divided by max(norm, 1e-8), then the dot product
+        int fr = rec_ts;
+        fr = fr < 0 ? 0 : (fr >= ta.n_frame_pose ? ta.n_frame_pose - 1 : fr);
+        const float4* T = reinterpret_cast<const float4*>(ta.frame_pose) + (size_t)fr * 3;
+        const float dx = px - T[0].w, dy = py - T[1].w, dz = pz - T[2].w;
+        const float ng = sqrtf(gx * gx + gy * gy + gz * gz), nd = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float ig = 1.0f / fmaxf(ng, 1e-8f), id = 1.0f / fmaxf(nd, 1e-8f);
+        const float hx = gx * ig, hy = gy * ig, hz = gz * ig, ex = dx * id, ey = dy * id, ez_ = dz * id;
+        const float dot = hx * ex + hy * ey + hz * ez_;
+        const float sgn = dot > 0.f ? 1.0f : (dot < 0.f ? -1.0f : 0.f);
+        // d(dot)/dg = (e - dot h) / |g| (|g| above the clamp; below it h = g / eps is linear in g: e / eps)
+        const float k = ng > 1e-8f ? 1.0f : 0.f;
+        dcx = sgn * (ex - k * dot * hx) * ig; dcy = sgn * (ey - k * dot * hy) * ig; dcz = sgn * (ez_ - k * dot * hz) * ig;
+        label *= fabsf(dot);
+      }
       const float z = sdf * inv_sigma;
       const float tgt = __frcp_rn(1.0f + __expf(-label * inv_sigma));         // loss.py:60
       const float ez = __expf(-fabsf(z));
@@ -258,6 +277,11 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
         // d/dg of weight_e * mean((|g|-1)^2); 0 at |g| == 0 (torch norm subgradient)
         const float coef = nrm > 0.f ? ta.weight_e * 2.f * (nrm - 1.f) * ta.inv_n_eik / nrm : 0.f;
         cx = coef * gx; cy = coef * gy; cz = coef * gz;
+      }
+      if constexpr (PC) {
+        // the BCE term through the scaled label: d/dt of BCEWithLogits = -z, t = sigmoid(label' / sigma), label' = label |cos|
+        const float dcos = wt * (-z) * ta.inv_n_main * tgt * (1.0f - tgt) * inv_sigma * label0;
+        cx = fmaf(dcos, dcx, cx); cy = fmaf(dcos, dcy, cy); cz = fmaf(dcos, dcz, cz);
       }
     }
     const float sk = cx * dwx + cy * dwy + cz * dwz;  // c . dw_k
@@ -568,7 +592,10 @@ int clid_launch_train_analytic(const clid_map_view* mv, const clid_train_args* a
     CLID_CHECK_LAUNCH();
     return CLID_OK;
   }
-  if (rec)
+  if (rec && a->proj_correction)
+    CLID_KLAUNCH(a->prof, 0, (clid::k_train_analytic<true, true>), dim3(clid_train_analytic_blocks(a->bs)), dim3(CLID_BLOCK), 0, s, *mv, *a,
+                 partial, rounds, reinterpret_cast<const float4*>(rec));
+  else if (rec)
     CLID_KLAUNCH(a->prof, 0, clid::k_train_analytic<true>, dim3(clid_train_analytic_blocks(a->bs)), dim3(CLID_BLOCK), 0, s, *mv, *a,
                  partial, rounds, reinterpret_cast<const float4*>(rec));
   else

@@ -178,7 +178,8 @@ class Mapper:
         """The stride of the loop's eikonal subset coord[::d] (utils/mapper.py:700-704): the batch ordering keeps the draws of
         those positions on those positions (clid_mapping_prep `decimation`); 1 when every sample / none is in the subset."""
         cfg = self.config
-        on = cfg.ekional_loss_on and cfg.weight_e > 0 and cfg.numerical_grad and os.environ.get("CLID_ORDER_CLASSES", "1") != "0"
+        on = (cfg.ekional_loss_on and cfg.weight_e > 0 and cfg.numerical_grad and not getattr(cfg, "proj_correction_on", False)
+              and os.environ.get("CLID_ORDER_CLASSES", "1") != "0")
         return max(int(cfg.gradient_decimation), 1) if on else 1  # (CLID_ORDER_CLASSES=0: one class, the plain order -- A/B)
 
     def _prepare_call(self, iters: int, bs: int, n_rows: int, dev, lib, col0: int = 0, ncols: int = 0):
@@ -254,8 +255,9 @@ class Mapper:
             bad.append("color_on")
         if getattr(c, "consistency_loss_on", False):
             bad.append("consistency_loss_on")
-        if getattr(c, "proj_correction_on", False):
-            bad.append("proj_correction_on")
+        if getattr(c, "proj_correction_on", False) and (not c.weighted_first or c.main_loss_type != "bce"
+                                                         or getattr(c, "ekional_add_to", "all") != "all"):
+            bad.append("proj_correction_on with weighted_first: False / a loss other than bce / ekional_add_to != all")
         if c.main_loss_type not in self.MAIN_LOSS_TYPES:
             sys.exit("Please choose a valid loss type")  # utils/mapper.py:766-767
         add_to = getattr(c, "ekional_add_to", "all")
@@ -307,6 +309,15 @@ class Mapper:
         eik_mode = 0
         if cfg.ekional_loss_on and cfg.weight_e > 0:
             eik_mode = 1 if cfg.numerical_grad else 2
+        # config.proj_correction_on (utils/mapper.py:57-69, 695-696, 712-714): the labels are scaled by |cos(g, x - origin)| with
+        # the AUTOGRAD gradient g of every sample -- `require_gradient` wins over `numerical_grad`, so the eikonal term (if on)
+        # runs on that g over the whole batch too: the analytic iteration, with the eikonal weight 0 when the term is off
+        proj_corr = bool(getattr(cfg, "proj_correction_on", False))
+        weight_e = float(cfg.weight_e) if eik_mode else 0.0
+        if proj_corr:
+            if pipeline != 1:
+                raise NotImplementedError("fused mapping loop: proj_correction_on runs on the hoisted schedule")
+            eik_mode = 2
         decim = int(cfg.gradient_decimation) if eik_mode == 1 else 1
         n_eik_global = (bs_global + decim - 1) // decim
 
@@ -345,7 +356,14 @@ class Mapper:
         ta.bs, ta.decimation, ta.batch_offset = bs_local, decim, batch_offset
         ta.fd_eps = float(cfg.voxel_size_m * cfg.num_grad_step_ratio)
         ta.inv_n_main, ta.inv_n_eik = 1.0 / bs_global, 1.0 / n_eik_global
-        ta.sigma, ta.weight_e = float(self.sdf_scale), float(cfg.weight_e)
+        ta.sigma, ta.weight_e = float(self.sdf_scale), (weight_e if proj_corr else float(cfg.weight_e))
+        if proj_corr:
+            poses = self.used_poses
+            if poses is None or poses.dim() != 3:
+                raise NotImplementedError("fused mapping loop: proj_correction_on needs used_poses [frames, 4, 4] (the frames' origins)")
+            fpose = poses[:, :3, :].to(device=dev, dtype=torch.float32).contiguous()
+            keep = (keep, fpose)
+            ta.proj_correction, ta.frame_pose, ta.n_frame_pose = 1, fpose.data_ptr(), int(fpose.shape[0])
         ta.loss_weight_on, ta.eikonal_mode, ta.train_decoder = int(bool(cfg.loss_weight_on)), eik_mode, int(train_decoder)
         ta.main_loss_type = self.MAIN_LOSS_TYPES[cfg.main_loss_type]
         if ta.main_loss_type in (1, 2):

@@ -363,6 +363,13 @@ typedef struct clid_train_args {
   int32_t main_loss_type;
   int32_t n_pose;
   const float* pool_pose;
+  /* config.proj_correction_on (utils/mapper.py:712-714, "[not used]" there): the label of a sample is scaled by
+   * |cos(g, x - origin)|, g = the analytic d sdf / d x of the sample (in the autograd graph: the BCE term then also back-propagates
+   * through g), origin = the translation of frame_pose[ts] -- frame_pose [n_frame_pose][12] as pool_pose's layout (they may be the
+   * same array).  Analytic eikonal mode (eikonal_mode 2) on the hoisted schedule with weighted_first; 0 = off. */
+  int32_t proj_correction;
+  int32_t n_frame_pose;
+  const float* frame_pose;
 } clid_train_args;
 
 /* Schedule object for clid_train_args.sched.  cu_mask / mask_words as hipExtStreamCreateWithCUMask takes them (bit i set =

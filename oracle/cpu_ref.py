@@ -350,6 +350,8 @@ class SamplePool:
     # Mapper.ba_done_flag (utils/mapper.py:646-658): sensor-frame coordinates + used_poses [frames,4,4]; None = global_coord is current
     local_coord: Optional[torch.Tensor] = None
     used_poses: Optional[torch.Tensor] = None
+    # config.proj_correction_on (utils/mapper.py:652-653, 712-714): used_poses [frames,4,4] whose translations are the frames' origins
+    frame_poses: Optional[torch.Tensor] = None
 
     def coord_of(self, index):
         """What the loop body trains on: utils/mapper.py:646-658."""
@@ -376,6 +378,7 @@ class LoopConfig:
     ekional_add_to: str = "all"  # utils/mapper.py:779-789: "all" | "surface" | "freespace"
     surface_sample_range_m: float = 0.25  # config: the |sdf_label| threshold of the surface mask (utils/mapper.py:692-694)
     main_loss_type: str = "bce"  # utils/mapper.py:751-767: "bce" | "zhong" | "sdf_l1" | "sdf_l2"
+    proj_correction_on: bool = False  # utils/mapper.py:57-69, 712-714: labels scaled by |cos(g, x - origin)|, g = autograd gradient
 
 
 def draw_batch_index(pool_count: int, new_idx: Optional[torch.Tensor], bs: int, bs_new_sample: int, gen=None):
@@ -400,7 +403,7 @@ def loss_and_grads(st: MapState, dec: DecoderParams, pool: SamplePool, index: to
     for p in params:
         p.requires_grad_(True)
         p.grad = None
-    analytic = lc.ekional_loss_on and not lc.numerical_grad
+    analytic = (lc.ekional_loss_on and not lc.numerical_grad) or lc.proj_correction_on  # `require_gradient`, utils/mapper.py:57-69
     if analytic:
         coord = coord.clone().requires_grad_(True)  # :660-661
     f, w, _, _, _ = query_feature(st, coord, ts)
@@ -412,6 +415,9 @@ def loss_and_grads(st: MapState, dec: DecoderParams, pool: SamplePool, index: to
         g = autograd_gradient(coord, sdf_pred)
     elif lc.ekional_loss_on and lc.numerical_grad:
         g = numerical_gradient(st, dec, coord[lc.fd_first :: lc.gradient_decimation], lc.fd_eps)
+    if lc.proj_correction_on:  # utils/mapper.py:652-653, 712-714 (the poses are float64 there: the product promotes)
+        origins = pool.frame_poses[ts.long()][:, :3, 3]
+        label = label * torch.abs(F.cosine_similarity(g, coord - origins))
     n_main = sdf_pred.shape[0]
     l_bce = main_loss(lc, sdf_pred, label, weight)  # (named after the default; utils/mapper.py:751-767)
     total = l_bce
@@ -419,7 +425,7 @@ def loss_and_grads(st: MapState, dec: DecoderParams, pool: SamplePool, index: to
     if lc.ekional_loss_on and lc.weight_e > 0 and g is not None:
         g_used = g
         if lc.ekional_add_to != "all":  # utils/mapper.py:779-789 (mask on the decimated subset)
-            surface = (label.abs() < lc.surface_sample_range_m)[lc.fd_first :: (lc.gradient_decimation if lc.numerical_grad else 1)]
+            surface = (pool.sdf_label[index].abs() < lc.surface_sample_range_m)[lc.fd_first :: (lc.gradient_decimation if lc.numerical_grad else 1)]
             g_used = g[surface] if lc.ekional_add_to == "surface" else g[~surface]
         l_eik = eikonal_loss(g_used)
         total = total + lc.weight_e * l_eik

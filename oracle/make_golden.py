@@ -273,12 +273,18 @@ def main():
     # neuralpoints.weighted_first: False (utils/mapper.py:679-680: every neighbour decoded, the SDFs blended) with the analytic
     # eikonal term -- the double backward through six decoder evaluations per sample (with and without layer norm)
     cases += [("analytic", False, False, "all", "bce", False, False), ("analytic", False, True, "all", "bce", False, False)]
-    for mode, frozen, ln, add_to, loss_type, ba, wf in cases:
+    cases = [c + (False,) for c in cases]
+    # config.proj_correction_on (utils/mapper.py:57-69, 712-714): labels scaled by |cos(g, x - origin)| with the autograd gradient g
+    # of every sample (`require_gradient` wins over `numerical_grad`), the frames' origins = the scene's three sensor positions
+    cases += [("numerical", False, False, "all", "bce", False, True, True), ("numerical", False, True, "all", "bce", False, True, True)]
+    for mode, frozen, ln, add_to, loss_type, ba, wf, proj in cases:
         for _once in (0,):
             for _once2 in (0,):
                 tag = (f"{mode}_{'frozen' if frozen else 'train'}_ln{int(ln)}" + ("" if add_to == "all" else f"_eik{add_to}")
-                       + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else "") + ("" if wf else "_wf0"))
+                       + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else "") + ("" if wf else "_wf0")
+                       + ("_proj" if proj else ""))
                 cfg6 = ref_config(ref, bs=BS, bs_new_sample=200)
+                cfg6.proj_correction_on = proj
                 cfg6.layer_norm_on = ln
                 cfg6.ekional_add_to = add_to
                 cfg6.main_loss_type = loss_type
@@ -306,6 +312,9 @@ def main():
                 mp.pool_sample_count = pool["coord"].shape[0]
                 mp.cur_sample_count = int((pool["time"] == 2).sum())
                 mp.used_poses = torch.eye(4, dtype=torch.float64)[None].repeat(3, 1, 1)
+                if proj:
+                    for fi, spos in enumerate(((0.0, 0.0, 1.5), (6.0, 2.0, 1.5), (9.0, 3.0, 1.6))):  # build_scene's sensors
+                        mp.used_poses[fi, :3, 3] = torch.tensor(spos, dtype=torch.float64)
                 if ba:
                     # three non-trivial frame poses; the sensor-frame pool is what maps onto the scene through them (fp32
                     # rounding apart), the world-frame pool is stale (as after a bundle adjustment) and must not be read
@@ -433,6 +442,8 @@ def main():
                 if ba:
                     out["ba_coord_pool"] = mp.coord_pool.numpy()
                     out["ba_used_poses"] = mp.used_poses.numpy()
+                if proj:
+                    out["proj_used_poses"] = mp.used_poses.numpy()
                 torch.manual_seed(42)
                 dec_init = ref.Decoder(cfg6, cfg6.geo_mlp_hidden_dim, cfg6.geo_mlp_level, 1)
                 out.pop("W1_init")

@@ -214,16 +214,28 @@ def test_mapping_loop_g6_weighted_first_false_analytic(env, ln):
     test_mapping_loop_g6(env, "analytic", False, ln, wf=False)
 
 
+@pytest.mark.parametrize("ln", [0, 1])
+def test_mapping_loop_g6_proj_correction(env, ln):
+    """config.proj_correction_on (utils/mapper.py:57-69, 695-696, 712-714): every label scaled by |cos(g, x - origin of the sample's
+    frame)| with the autograd gradient g of the sample in the graph -- `require_gradient` overrides `numerical_grad`, the eikonal term
+    runs on that g over the whole batch, and the BCE term back-propagates through g too.  Against the reference's own loop."""
+    g0 = gio.load(f"g6_loop_analytic_train_ln{ln}.npz") if ln == 0 else None
+    g = gio.load(f"g6_loop_numerical_train_ln{ln}_proj.npz")
+    if g0 is not None:
+        assert abs(float(g["loss_bce"][0]) - float(g0["loss_bce"][0])) > 1e-3  # (the correction really changes the targets)
+    test_mapping_loop_g6(env, "numerical", False, ln, proj=True)
+
+
 @pytest.mark.parametrize("mode,frozen,ln", G6)
-def test_mapping_loop_g6(env, mode, frozen, ln, add_to="all", loss_type="bce", ba=False, wf=True):
+def test_mapping_loop_g6(env, mode, frozen, ln, add_to="all", loss_type="bce", ba=False, wf=True, proj=False):
     from clid_slam_amd.tools import freeze_model
 
     tag = (f"{mode}_{'frozen' if frozen else 'train'}_ln{ln}" + ("" if add_to == "all" else f"_eik{add_to}")
-           + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else "") + ("" if wf else "_wf0"))
+           + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else "") + ("" if wf else "_wf0") + ("_proj" if proj else ""))
     g = gio.load(f"g6_loop_{tag}.npz")
     p = gio.load("pool.npz")
     cfg = env.config(layer_norm_on=bool(ln), bs=int(g["index_seq"].shape[1]), bs_new_sample=200, ekional_add_to=add_to,
-                     main_loss_type=loss_type, weighted_first=bool(wf))
+                     main_loss_type=loss_type, weighted_first=bool(wf), proj_correction_on=bool(proj))
     if mode == "analytic":
         cfg.numerical_grad, cfg.gradient_decimation = False, 1
     nm = env.neural_points(cfg, base=p)
@@ -231,6 +243,8 @@ def test_mapping_loop_g6(env, mode, frozen, ln, add_to="all", loss_type="bce", b
     if frozen:
         freeze_model(dec)
     mp, _ = env.mapper(cfg, nm, dec)
+    if proj:
+        mp.used_poses = gio.T(g["proj_used_poses"]).cuda()
     if ba:
         mp.coord_pool = gio.T(g["ba_coord_pool"]).cuda()
         mp.used_poses = gio.T(g["ba_used_poses"]).cuda()

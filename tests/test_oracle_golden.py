@@ -115,14 +115,16 @@ G6 = [("numerical", False, 0, "all"), ("numerical", False, 1, "all"), ("numerica
       ("numerical", False, 0, "all", "sdf_l1"), ("numerical", False, 0, "all", "sdf_l2"), ("numerical", False, 0, "all", "zhong"),
       ("numerical", False, 0, "all", "bce", True),
       # neuralpoints.weighted_first: False with the analytic eikonal term (utils/mapper.py:679-680, 695-696)
-      ("analytic", False, 0, "all", "bce", False, False), ("analytic", False, 1, "all", "bce", False, False)]
+      ("analytic", False, 0, "all", "bce", False, False), ("analytic", False, 1, "all", "bce", False, False),
+      # config.proj_correction_on (utils/mapper.py:57-69, 712-714): labels scaled by |cos(g, x - origin)|, g in the graph
+      ("numerical", False, 0, "all", "bce", False, True, True), ("numerical", False, 1, "all", "bce", False, True, True)]
 
 
 @pytest.mark.parametrize("case", G6, ids=lambda c: "-".join(str(x) for x in c))
 def test_g6_mapping_loop(case):
-    mode, frozen, ln, add_to, loss_type, ba, wf = tuple(case) + ("all", "bce", False, True)[len(case) - 3:]
+    mode, frozen, ln, add_to, loss_type, ba, wf, proj = tuple(case) + ("all", "bce", False, True, False)[len(case) - 3:]
     tag = (f"{mode}_{'frozen' if frozen else 'train'}_ln{ln}" + ("" if add_to == "all" else f"_eik{add_to}")
-           + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else "") + ("" if wf else "_wf0"))
+           + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else "") + ("" if wf else "_wf0") + ("_proj" if proj else ""))
     g = gio.load(f"g6_loop_{tag}.npz")
     st = gio.map_state(layer_norm_on=bool(ln), weighted_first=bool(wf))
     pool, praw = gio.sample_pool()
@@ -131,11 +133,13 @@ def test_g6_mapping_loop(case):
         pool.global_coord = pool.global_coord + 0.37
         moved = O.transform_batch(pool.local_coord, pool.used_poses[pool.time.long()])
         assert 0 < float((moved - gio.T(praw["coord"])).abs().max()) < 1e-5  # (the poses map the sensor frames back onto the scene)
+    if proj:
+        pool.frame_poses = gio.T(g["proj_used_poses"])
     dec = gio.decoder(g, "init_")
     if loss_type != "bce":
         dec.sdf_scale = 1.0  # model/decoder.py:51-53: the decoder's output scale is the logistic sigma only for the BCE loss
     lc = O.LoopConfig(numerical_grad=(mode == "numerical"), gradient_decimation=10 if mode == "numerical" else 1,
-                      train_decoder=not frozen, ekional_add_to=add_to, main_loss_type=loss_type)
+                      train_decoder=not frozen, ekional_add_to=add_to, main_loss_type=loss_type, proj_correction_on=bool(proj))
     index_seq = gio.T(g["index_seq"]).to(torch.int64)
     # a1: the batch composition rule reproduces the reference's batch from its recorded draws
     idx0 = torch.cat((gio.T(g["draw_hist0"]), gio.T(g["new_idx"])[gio.T(g["draw_pick0"])]))
