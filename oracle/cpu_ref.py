@@ -379,6 +379,9 @@ class LoopConfig:
     surface_sample_range_m: float = 0.25  # config: the |sdf_label| threshold of the surface mask (utils/mapper.py:692-694)
     main_loss_type: str = "bce"  # utils/mapper.py:751-767: "bce" | "zhong" | "sdf_l1" | "sdf_l2"
     proj_correction_on: bool = False  # utils/mapper.py:57-69, 712-714: labels scaled by |cos(g, x - origin)|, g = autograd gradient
+    # utils/mapper.py:716-741, 770-776: gradient-consistency term between every drawn sample and a randomly shifted copy of it
+    consistency_loss_on: bool = False
+    weight_c: float = 0.5
 
 
 def draw_batch_index(pool_count: int, new_idx: Optional[torch.Tensor], bs: int, bs_new_sample: int, gen=None):
@@ -391,9 +394,11 @@ def draw_batch_index(pool_count: int, new_idx: Optional[torch.Tensor], bs: int, 
     return torch.randint(0, pool_count, (bs,), generator=gen)
 
 
-def loss_and_grads(st: MapState, dec: DecoderParams, pool: SamplePool, index: torch.Tensor, lc: LoopConfig):
+def loss_and_grads(st: MapState, dec: DecoderParams, pool: SamplePool, index: torch.Tensor, lc: LoopConfig, consistency=None):
     """One iteration body of utils/mapper.py:642-835 up to `backward()`; returns a dict with the
-    loss triple, sdf_pred and the gradients of the feature table and decoder tensors."""
+    loss triple, sdf_pred and the gradients of the feature table and decoder tensors.
+    `consistency` (lc.consistency_loss_on): the iteration's two random draws of utils/mapper.py:717-726 as the caller made them,
+    (near_index [n_c] int64, random_shift [N,3] in [-consistency_range, consistency_range))."""
     coord = pool.coord_of(index)
     label = pool.sdf_label[index]
     ts = pool.time[index]
@@ -403,7 +408,8 @@ def loss_and_grads(st: MapState, dec: DecoderParams, pool: SamplePool, index: to
     for p in params:
         p.requires_grad_(True)
         p.grad = None
-    analytic = (lc.ekional_loss_on and not lc.numerical_grad) or lc.proj_correction_on  # `require_gradient`, utils/mapper.py:57-69
+    analytic = ((lc.ekional_loss_on and not lc.numerical_grad) or lc.proj_correction_on
+                or lc.consistency_loss_on)  # `require_gradient`, utils/mapper.py:57-69
     if analytic:
         coord = coord.clone().requires_grad_(True)  # :660-661
     f, w, _, _, _ = query_feature(st, coord, ts)
@@ -418,9 +424,22 @@ def loss_and_grads(st: MapState, dec: DecoderParams, pool: SamplePool, index: to
     if lc.proj_correction_on:  # utils/mapper.py:652-653, 712-714 (the poses are float64 there: the product promotes)
         origins = pool.frame_poses[ts.long()][:, :3, 3]
         label = label * torch.abs(F.cosine_similarity(g, coord - origins))
+    g_near = None
+    if lc.consistency_loss_on:  # utils/mapper.py:716-741: the shifted copies, queried with the defaults (training side effects on)
+        near_index, random_shift = consistency
+        coord_near = (coord + random_shift)[near_index, :]
+        f_n, w_n, _, _, _ = query_feature(st, coord_near)
+        pred_near = mlp_sdf(dec, f_n)
+        if not st.weighted_first:
+            pred_near = (pred_near * w_n).sum(dim=1).squeeze(1)
+        g_near = autograd_gradient(coord_near, pred_near)
     n_main = sdf_pred.shape[0]
     l_bce = main_loss(lc, sdf_pred, label, weight)  # (named after the default; utils/mapper.py:751-767)
     total = l_bce
+    l_cons = torch.zeros(())
+    if g_near is not None:  # utils/mapper.py:770-776
+        l_cons = (1.0 - F.cosine_similarity(g[near_index, :], g_near)).mean()
+        total = total + lc.weight_c * l_cons
     l_eik = torch.zeros(())
     if lc.ekional_loss_on and lc.weight_e > 0 and g is not None:
         g_used = g
@@ -439,6 +458,7 @@ def loss_and_grads(st: MapState, dec: DecoderParams, pool: SamplePool, index: to
         "loss": total.detach(),
         "sdf_loss": l_bce.detach(),
         "eikonal_loss": l_eik.detach(),
+        "consistency_loss": l_cons.detach(),
         "sdf_pred": sdf_pred.detach(),
         "g": None if g is None else g.detach(),
         "grad_theta": theta.grad.detach().clone(),
@@ -533,7 +553,7 @@ def relu_ambiguous_rows(st: MapState, dec: DecoderParams, pool: SamplePool, inde
 
 
 def mapping_iters(st: MapState, dec: DecoderParams, pool: SamplePool, index_seq, lc: LoopConfig, record=False,
-                  ambiguity_tau: Optional[float] = None):
+                  ambiguity_tau: Optional[float] = None, consistency_seq=None):
     """utils/mapper.py:620-862 with a teacher-forced batch-index sequence (`index_seq` [iters,bs]).
 
     A NEW Adam state is created per call (utils/mapper.py:634).  Returns the per-iteration records
@@ -545,7 +565,7 @@ def mapping_iters(st: MapState, dec: DecoderParams, pool: SamplePool, index_seq,
     recs = []
     for it in range(len(index_seq)):
         amb = relu_ambiguous_rows(st, dec, pool, index_seq[it], lc, ambiguity_tau, with_slack=True) if (record and ambiguity_tau) else None
-        out = loss_and_grads(st, dec, pool, index_seq[it], lc)
+        out = loss_and_grads(st, dec, pool, index_seq[it], lc, None if consistency_seq is None else consistency_seq[it])
         if amb is not None:
             (out["ambiguous_rows"], out["ambiguous_queries"], out["ambiguous_row_slack"], out["gathered_rows"],
              out["ambiguous_decoder_slack"]) = amb

@@ -277,14 +277,21 @@ def main():
     # config.proj_correction_on (utils/mapper.py:57-69, 712-714): labels scaled by |cos(g, x - origin)| with the autograd gradient g
     # of every sample (`require_gradient` wins over `numerical_grad`), the frames' origins = the scene's three sensor positions
     cases += [("numerical", False, False, "all", "bce", False, True, True), ("numerical", False, True, "all", "bce", False, True, True)]
-    for mode, frozen, ln, add_to, loss_type, ba, wf, proj in cases:
+    cases = [c + (False,) for c in cases]
+    # config.consistency_loss_on (utils/mapper.py:716-741, 770-776): 1 - cos between the autograd gradient of drawn samples and of
+    # randomly shifted copies of them (a second query_feature call with the training side effects on); the reference's two extra
+    # random draws per iteration (torch.randint, torch.rand_like) are recorded
+    cases += [("numerical", False, False, "all", "bce", False, True, False, True), ("numerical", False, True, "all", "bce", False, True, False, True)]
+    for mode, frozen, ln, add_to, loss_type, ba, wf, proj, cons in cases:
         for _once in (0,):
             for _once2 in (0,):
                 tag = (f"{mode}_{'frozen' if frozen else 'train'}_ln{int(ln)}" + ("" if add_to == "all" else f"_eik{add_to}")
                        + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else "") + ("" if wf else "_wf0")
-                       + ("_proj" if proj else ""))
+                       + ("_proj" if proj else "") + ("_cons" if cons else ""))
                 cfg6 = ref_config(ref, bs=BS, bs_new_sample=200)
                 cfg6.proj_correction_on = proj
+                cfg6.consistency_loss_on = cons
+                cfg6.consistency_count = BS // 4  # (utils/config.py:904 derives it from bs at load time)
                 cfg6.layer_norm_on = ln
                 cfg6.ekional_add_to = add_to
                 cfg6.main_loss_type = loss_type
@@ -346,6 +353,14 @@ def main():
                 def rec_randint(*a, **k):
                     r = real_randint(*a, **k)
                     draws.append(r.clone())
+                    return r
+
+                shifts = []
+                real_rand_like = torch.rand_like
+
+                def rec_rand_like(*a, **k):
+                    r = real_rand_like(*a, **k)
+                    shifts.append(r.clone())
                     return r
 
                 real_get_batch = mp.get_batch
@@ -415,20 +430,23 @@ def main():
                 ref_mapper_mod.sdf_diff_loss, ref_mapper_mod.sdf_zhong_loss = rec_diff, rec_zhong
                 torch.Tensor.backward = rec_backward
                 torch.randint = rec_randint
+                torch.rand_like = rec_rand_like
                 torch.manual_seed(1234)
                 try:
                     mp.mapping(ITERS)
                 finally:
                     torch.randint = real_randint
+                    torch.rand_like = real_rand_like
                     torch.Tensor.backward = real_backward
                     ref_mapper_mod.setup_optimizer = real_setup
                     ref_mapper_mod.sdf_bce_loss = real_bce
                     ref_mapper_mod.sdf_diff_loss, ref_mapper_mod.sdf_zhong_loss = real_diff, real_zhong
 
-                assert len(per_iter) == ITERS and len(draws) == 2 * ITERS, (len(per_iter), len(draws))
+                dpi = 3 if cons else 2  # randint calls per iteration: history part, new-sample picks (, near_index)
+                assert len(per_iter) == ITERS and len(draws) == dpi * ITERS and len(shifts) == (ITERS if cons else 0), (len(per_iter), len(draws))
                 index_seq = []
                 for it in range(ITERS):
-                    hist, pick = draws[2 * it], draws[2 * it + 1]
+                    hist, pick = draws[dpi * it], draws[dpi * it + 1]
                     index = torch.cat((hist, mp.new_idx[pick]), 0)
                     assert torch.equal((mp.coord_pool if ba else pool["coord"])[index], batches[it][0])
                     index_seq.append(index)
@@ -444,6 +462,10 @@ def main():
                     out["ba_used_poses"] = mp.used_poses.numpy()
                 if proj:
                     out["proj_used_poses"] = mp.used_poses.numpy()
+                if cons:  # near_index [ITERS, n_c], random_shift = rand * 2 * range - range [ITERS, BS, 3] (utils/mapper.py:717-726)
+                    out["cons_near_index"] = torch.stack([draws[3 * it + 2] for it in range(ITERS)]).to(torch.int32).numpy()
+                    out["cons_shift"] = torch.stack([sh * 2 * cfg6.consistency_range - cfg6.consistency_range for sh in shifts]).numpy()
+                    out["cons_weight_c"] = np.float64(cfg6.weight_c)
                 torch.manual_seed(42)
                 dec_init = ref.Decoder(cfg6, cfg6.geo_mlp_hidden_dim, cfg6.geo_mlp_level, 1)
                 out.pop("W1_init")

@@ -117,14 +117,17 @@ G6 = [("numerical", False, 0, "all"), ("numerical", False, 1, "all"), ("numerica
       # neuralpoints.weighted_first: False with the analytic eikonal term (utils/mapper.py:679-680, 695-696)
       ("analytic", False, 0, "all", "bce", False, False), ("analytic", False, 1, "all", "bce", False, False),
       # config.proj_correction_on (utils/mapper.py:57-69, 712-714): labels scaled by |cos(g, x - origin)|, g in the graph
-      ("numerical", False, 0, "all", "bce", False, True, True), ("numerical", False, 1, "all", "bce", False, True, True)]
+      ("numerical", False, 0, "all", "bce", False, True, True), ("numerical", False, 1, "all", "bce", False, True, True),
+      # config.consistency_loss_on (utils/mapper.py:716-741, 770-776), with the reference's recorded draws
+      ("numerical", False, 0, "all", "bce", False, True, False, True), ("numerical", False, 1, "all", "bce", False, True, False, True)]
 
 
 @pytest.mark.parametrize("case", G6, ids=lambda c: "-".join(str(x) for x in c))
 def test_g6_mapping_loop(case):
-    mode, frozen, ln, add_to, loss_type, ba, wf, proj = tuple(case) + ("all", "bce", False, True, False)[len(case) - 3:]
+    mode, frozen, ln, add_to, loss_type, ba, wf, proj, cons = tuple(case) + ("all", "bce", False, True, False, False)[len(case) - 3:]
     tag = (f"{mode}_{'frozen' if frozen else 'train'}_ln{ln}" + ("" if add_to == "all" else f"_eik{add_to}")
-           + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else "") + ("" if wf else "_wf0") + ("_proj" if proj else ""))
+           + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else "") + ("" if wf else "_wf0") + ("_proj" if proj else "")
+           + ("_cons" if cons else ""))
     g = gio.load(f"g6_loop_{tag}.npz")
     st = gio.map_state(layer_norm_on=bool(ln), weighted_first=bool(wf))
     pool, praw = gio.sample_pool()
@@ -139,12 +142,16 @@ def test_g6_mapping_loop(case):
     if loss_type != "bce":
         dec.sdf_scale = 1.0  # model/decoder.py:51-53: the decoder's output scale is the logistic sigma only for the BCE loss
     lc = O.LoopConfig(numerical_grad=(mode == "numerical"), gradient_decimation=10 if mode == "numerical" else 1,
-                      train_decoder=not frozen, ekional_add_to=add_to, main_loss_type=loss_type, proj_correction_on=bool(proj))
+                      train_decoder=not frozen, ekional_add_to=add_to, main_loss_type=loss_type, proj_correction_on=bool(proj),
+                      consistency_loss_on=bool(cons), weight_c=float(g["cons_weight_c"]) if cons else 0.5)
+    cons_seq = None
+    if cons:
+        cons_seq = [(gio.T(g["cons_near_index"][it]).to(torch.int64), gio.T(g["cons_shift"][it])) for it in range(g["cons_shift"].shape[0])]
     index_seq = gio.T(g["index_seq"]).to(torch.int64)
     # a1: the batch composition rule reproduces the reference's batch from its recorded draws
     idx0 = torch.cat((gio.T(g["draw_hist0"]), gio.T(g["new_idx"])[gio.T(g["draw_pick0"])]))
     assert torch.equal(idx0, index_seq[0])
-    recs = O.mapping_iters(st, dec, pool, index_seq, lc, record=True)
+    recs = O.mapping_iters(st, dec, pool, index_seq, lc, record=True, consistency_seq=cons_seq)
     for it, r in enumerate(recs):
         close(r["sdf_loss"], g["loss_bce"][it], 2e-6, f"it{it} bce")
         close(r["loss"], g["loss_total"][it], 2e-6, f"it{it} total")
