@@ -64,6 +64,8 @@ class TrainArgs(C.Structure):
         ("main_loss_type", _i32), ("n_pose", _i32), ("pool_pose", _vp),
         # config.proj_correction_on: labels scaled by |cos(g, x - origin of the sample's frame)|; frame poses [n][12] fp32
         ("proj_correction", _i32), ("n_frame_pose", _i32), ("frame_pose", _vp),
+        # config.consistency_loss_on: gradient probe output, dL/dg input, partial-row placement (see the header)
+        ("g_out", _vp), ("c_extra", _vp), ("partial_row0", _i32), ("partial_rows_extra", _i32),
     ]
 
 
@@ -168,6 +170,8 @@ _SIGS = {
     "clid_mapping_prep": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i64, _vp, _i64, C.c_uint64, C.c_uint64, _vp, C.c_float,
                                     _vp, _i32, _i32, _i32, _vp]),
     "clid_debug_prep_draw": (_i64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "clid_train_partial_rows": (_i32, [_vp]),
+    "clid_consistency_couple": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.c_float, _vp, _vp, _vp, _vp]),
     "clid_debug_scan_scratch_bytes": (_i64, [_i64]),
     "clid_debug_scan": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "clid_comm_unique_id": (C.c_int, [_vp]),

@@ -97,6 +97,9 @@ class HotPathConfig:
         self.num_grad_step_ratio = 0.2
         self.proj_correction_on = False
         self.consistency_loss_on = False
+        self.weight_c = 0.5            # `utils/config.py:215-219`
+        self.consistency_count = 1000  # (derived from bs below, `utils/config.py:904`)
+        self.consistency_range = 0.05
         # continual
         self.bs_new_sample = 1000
         self.pool_capacity = int(1e7)
@@ -124,6 +127,7 @@ class HotPathConfig:
     def _derive(self) -> None:
         # `utils/config.py:903-910`
         self.infer_bs = self.bs * 64
+        self.consistency_count = int(self.bs / 4)
         self.local_map_radius = self.max_range + 2.0
         self.window_radius = max(self.max_range, 6.0)
 
@@ -184,6 +188,7 @@ class HotPathConfig:
         else:
             self.gradient_decimation = lo.get("grad_decimation", self.gradient_decimation)
             self.num_grad_step_ratio = lo.get("num_grad_step_ratio", self.num_grad_step_ratio)
+        self.consistency_loss_on = lo.get("consistency_loss_on", self.consistency_loss_on)  # `utils/config.py:654-656`
         self.from_sample_points = n.get("from_sample_points", self.from_sample_points)
         self.map_surface_ratio = n.get("map_surface_ratio", self.map_surface_ratio)
         self.prune_map_on = n.get("prune_map_on", self.prune_map_on)

@@ -1200,6 +1200,62 @@ static int partial_rows(const clid_train_args* a) {
   return fused_blocks(tmap.n_tasks);
 }
 
+extern "C" int32_t clid_train_partial_rows(const clid_train_args* t) { return t ? partial_rows(t) : 0; }
+
+// ---- config.consistency_loss_on (utils/mapper.py:770-776): 1 - cos(g[near_index[j]], g_near[j]), mean over j -------------------
+// F.cosine_similarity divides each vector by max(norm, eps) first; d cos / d a = (bh - cos ah) / |a| above the clamp, bh / eps below
+__global__ void __launch_bounds__(256)
+k_consistency_couple(const float* __restrict__ g_main, const float* __restrict__ g_near, const long long* __restrict__ near_index,
+                     int n_c, int n_main, float weight_c, float* __restrict__ c_main, float* __restrict__ c_near,
+                     float* __restrict__ loss_out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  float term = 0.f;
+  if (j < n_c) {
+    long long i = near_index[j];
+    i = i < 0 ? 0 : (i >= n_main ? n_main - 1 : i);
+    const float ax = g_main[i * 3 + 0], ay = g_main[i * 3 + 1], az = g_main[i * 3 + 2];
+    const float bx = g_near[(size_t)j * 3 + 0], by = g_near[(size_t)j * 3 + 1], bz = g_near[(size_t)j * 3 + 2];
+    const float na = sqrtf(ax * ax + ay * ay + az * az), nb = sqrtf(bx * bx + by * by + bz * bz);
+    const float ia = 1.0f / fmaxf(na, 1e-8f), ib = 1.0f / fmaxf(nb, 1e-8f);
+    const float hax = ax * ia, hay = ay * ia, haz = az * ia, hbx = bx * ib, hby = by * ib, hbz = bz * ib;
+    const float cs = hax * hbx + hay * hby + haz * hbz;
+    term = 1.0f - cs;
+    const float k = -weight_c / (float)n_c;  // dL/dcos
+    const float ka = na > 1e-8f ? cs : 0.f, kb = nb > 1e-8f ? cs : 0.f;
+    atomicAdd(&c_main[i * 3 + 0], k * (hbx - ka * hax) * ia);
+    atomicAdd(&c_main[i * 3 + 1], k * (hby - ka * hay) * ia);
+    atomicAdd(&c_main[i * 3 + 2], k * (hbz - ka * haz) * ia);
+    c_near[(size_t)j * 3 + 0] = k * (hax - kb * hbx) * ib;
+    c_near[(size_t)j * 3 + 1] = k * (hay - kb * hby) * ib;
+    c_near[(size_t)j * 3 + 2] = k * (haz - kb * hbz) * ib;
+  }
+  __shared__ float red[4];
+  term = wave_sum(term);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = term;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float m = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n_c;
+    atomicAdd(&loss_out[3], m);
+    atomicAdd(&loss_out[0], weight_c * m);
+  }
+}
+extern "C" int clid_consistency_couple(const float* g_main, const float* g_near, const int64_t* near_index, int32_t n_c, int32_t n_main,
+                                       float weight_c, float* c_main, float* c_near, float* loss_out, void* stream) {
+  if (!g_main || !g_near || !near_index || n_c <= 0 || n_main <= 0 || !c_main || !c_near || !loss_out) {
+    clid_set_error("clid_consistency_couple: bad argument");
+    return CLID_E_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(c_main, 0, sizeof(float) * 3 * (size_t)n_main, s) != hipSuccess) {
+    clid_set_error("clid_consistency_couple: %s", hipGetErrorString(hipGetLastError()));
+    return CLID_E_HIP;
+  }
+  hipLaunchKernelGGL(k_consistency_couple, dim3((unsigned)((n_c + 255) / 256)), dim3(256), 0, s, g_main, g_near,
+                     reinterpret_cast<const long long*>(near_index), (int)n_c, (int)n_main, weight_c, c_main, c_near, loss_out);
+  CLID_CHECK_LAUNCH();
+  return CLID_OK;
+}
+
 extern "C" int64_t clid_train_workspace_floats(int32_t bs, int32_t decimation, int32_t eikonal_mode) {
   if (bs <= 0 || decimation <= 0) return -1;
   const long long nfd = eikonal_mode == 1 ? (bs + decimation - 1) / decimation : 0;
@@ -1395,7 +1451,7 @@ extern "C" int clid_train_adam(const clid_adam_args* a, const clid_train_args* t
     const int Q = n_queries(t, &n_fd, &first);
     TrainWs ws = carve(t->ws, Q);
     L.partial = ws.partial;
-    L.nb = partial_rows(t);
+    L.nb = partial_rows(t) + (t->partial_rows_extra > 0 ? t->partial_rows_extra : 0);  // (+ a second batch's rows behind them)
     L.loss_out = t->loss_out;
     L.inv_n_main = t->inv_n_main;
     L.inv_n_eik = t->inv_n_eik;
@@ -1468,6 +1524,13 @@ static int check_train_args(const clid_map_view* mv, const clid_train_args* a, c
         !decode_variant_for(a)) {
       clid_set_error("%s: main_loss_type %d (config.main_loss_type sdf_l1 / sdf_l2 / zhong) needs the hoisted schedule, a tile "
                      "decode kernel, eikonal mode 0 or 1 and weighted_first", who, a->main_loss_type);
+      return CLID_E_ARG;
+    }
+  }
+  if (a->g_out || a->c_extra || a->partial_row0 || a->partial_rows_extra) {
+    if (a->eikonal_mode != 2 || !hoisted(a) || a->decode_each_neighbour || (a->g_out && a->c_extra) || a->partial_rows_extra < 0) {
+      clid_set_error("%s: g_out / c_extra / partial_row0 / partial_rows_extra (config.consistency_loss_on) belong to the analytic "
+                     "iteration on the hoisted schedule with weighted_first", who);
       return CLID_E_ARG;
     }
   }
@@ -1615,7 +1678,12 @@ extern "C" int clid_train_decode(const clid_map_view* mv, const clid_train_args*
   const int variant = decode_variant_for(&da);
   const int nb = partial_rows(&da);
   if (a->eikonal_mode == 2) {  // loss.numerical_grad_on: False: the analytic iteration from the records (csrc/train_analytic.hip)
-    if (int e = clid_launch_train_analytic(mv, a, ws.partial, rec, s)) return e;
+    if (a->partial_row0 < 0 || a->partial_row0 + nb > kMaxBwdBlocks) {
+      clid_set_error("clid_train_decode: partial_row0 %d + %d rows exceed the workspace's %d", a->partial_row0, nb, kMaxBwdBlocks);
+      return CLID_E_ARG;
+    }
+    if (int e = clid_launch_train_analytic(mv, a, ws.partial + (size_t)a->partial_row0 * kPartialStride, rec, s)) return e;
+    if (a->g_out) return CLID_OK;  // (a gradient probe: nothing to reduce)
   } else if (a->decode_each_neighbour) {  // neuralpoints.weighted_first: False (csrc/train_wf0.hip)
     if (int e = clid_launch_train_wf0(mv, a, ws.partial, tmap, const_cast<float*>(rec), s)) return e;
   } else if (variant) {

@@ -32,7 +32,8 @@ namespace clid {
 #endif
 // PC: config.proj_correction_on (utils/mapper.py:712-714): label' = label |cos(g, x - origin of the sample's frame)| with g in the
 // graph, so the BCE term reaches the parameters through g as well: dL/dg gains dL/dlabel' label d|cos|/dg (its own instantiation)
-template <bool HOISTED, bool PC = false>
+// CX: config.consistency_loss_on -- 1 = gradient probe (g of every sample to ta.g_out, nothing else), 2 = ta.c_extra added to dL/dg
+template <bool HOISTED, bool PC = false, int CX = 0>
 __global__ void __launch_bounds__(CLID_BLOCK, CLID_ANALYTIC_WAVES)
 k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ partial, int n_rounds, const float4* __restrict__ rec) {
   __shared__ MlpLds mlp;
@@ -231,6 +232,12 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
     float gx = dot * dwx, gy = dot * dwy, gz = dot * dwz;
     CLID_BFLY(gx) CLID_BFLY(gy) CLID_BFLY(gz)
     gx += wsum * u[8]; gy += wsum * u[9]; gz += wsum * u[10];
+    if constexpr (CX == 1) {  // gradient probe: g is all the caller wants of this pass
+      if (live && lane16 == 0) {
+        ta.g_out[(size_t)p_raw * 3 + 0] = gx; ta.g_out[(size_t)p_raw * 3 + 1] = gy; ta.g_out[(size_t)p_raw * 3 + 2] = gz;
+      }
+      continue;
+    }
 
     // ---- training_mode side effects (np.py:708-733)
     if (valid && !odd && lane16 < 2 * CLID_K) {
@@ -277,6 +284,9 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
         // d/dg of weight_e * mean((|g|-1)^2); 0 at |g| == 0 (torch norm subgradient)
         const float coef = nrm > 0.f ? ta.weight_e * 2.f * (nrm - 1.f) * ta.inv_n_eik / nrm : 0.f;
         cx = coef * gx; cy = coef * gy; cz = coef * gz;
+      }
+      if constexpr (CX == 2) {  // the consistency term's dL/dg of this sample (clid_consistency_couple)
+        cx += ta.c_extra[(size_t)p_raw * 3 + 0]; cy += ta.c_extra[(size_t)p_raw * 3 + 1]; cz += ta.c_extra[(size_t)p_raw * 3 + 2];
       }
       if constexpr (PC) {
         // the BCE term through the scaled label: d/dt of BCEWithLogits = -z, t = sigmoid(label' / sigma), label' = label |cos|
@@ -349,6 +359,7 @@ k_train_analytic(clid_map_view mv, clid_train_args ta, float* __restrict__ parti
       }
     }
   }
+  if constexpr (CX == 1) return;  // (a probe leaves no partial row)
   flush_mlp_acc(acc, bce_acc, eik_acc, red, partial + (size_t)blockIdx.x * kPartialStride, ta.train_decoder != 0);
 }
 
@@ -592,7 +603,13 @@ int clid_launch_train_analytic(const clid_map_view* mv, const clid_train_args* a
     CLID_CHECK_LAUNCH();
     return CLID_OK;
   }
-  if (rec && a->proj_correction)
+  if (rec && (a->g_out || a->c_extra)) {  // config.consistency_loss_on: the probe / the coupled backward
+    const dim3 grid(clid_train_analytic_blocks(a->bs)), block(CLID_BLOCK);
+    const float4* r4 = reinterpret_cast<const float4*>(rec);
+    if (a->g_out) CLID_KLAUNCH(a->prof, 0, (clid::k_train_analytic<true, false, 1>), grid, block, 0, s, *mv, *a, partial, rounds, r4);
+    else if (a->proj_correction) CLID_KLAUNCH(a->prof, 0, (clid::k_train_analytic<true, true, 2>), grid, block, 0, s, *mv, *a, partial, rounds, r4);
+    else CLID_KLAUNCH(a->prof, 0, (clid::k_train_analytic<true, false, 2>), grid, block, 0, s, *mv, *a, partial, rounds, r4);
+  } else if (rec && a->proj_correction)
     CLID_KLAUNCH(a->prof, 0, (clid::k_train_analytic<true, true>), dim3(clid_train_analytic_blocks(a->bs)), dim3(CLID_BLOCK), 0, s, *mv, *a,
                  partial, rounds, reinterpret_cast<const float4*>(rec));
   else if (rec)

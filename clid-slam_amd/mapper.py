@@ -179,7 +179,7 @@ class Mapper:
         those positions on those positions (clid_mapping_prep `decimation`); 1 when every sample / none is in the subset."""
         cfg = self.config
         on = (cfg.ekional_loss_on and cfg.weight_e > 0 and cfg.numerical_grad and not getattr(cfg, "proj_correction_on", False)
-              and os.environ.get("CLID_ORDER_CLASSES", "1") != "0")
+              and not getattr(cfg, "consistency_loss_on", False) and os.environ.get("CLID_ORDER_CLASSES", "1") != "0")
         return max(int(cfg.gradient_decimation), 1) if on else 1  # (CLID_ORDER_CLASSES=0: one class, the plain order -- A/B)
 
     def _prepare_call(self, iters: int, bs: int, n_rows: int, dev, lib, col0: int = 0, ncols: int = 0):
@@ -253,8 +253,10 @@ class Mapper:
             bad.append("semantic_on")
         if getattr(c, "color_on", False):
             bad.append("color_on")
-        if getattr(c, "consistency_loss_on", False):
-            bad.append("consistency_loss_on")
+        if getattr(c, "consistency_loss_on", False) and (not c.weighted_first or c.main_loss_type != "bce" or self.ba_done_flag
+                                                          or getattr(c, "ekional_add_to", "all") != "all" or _dist() is not None):
+            bad.append("consistency_loss_on with weighted_first: False / a loss other than bce / ekional_add_to != all / ba_done_flag "
+                       "/ several ranks")
         if getattr(c, "proj_correction_on", False) and (not c.weighted_first or c.main_loss_type != "bce"
                                                          or getattr(c, "ekional_add_to", "all") != "all"):
             bad.append("proj_correction_on with weighted_first: False / a loss other than bce / ekional_add_to != all")
@@ -313,10 +315,11 @@ class Mapper:
         # the AUTOGRAD gradient g of every sample -- `require_gradient` wins over `numerical_grad`, so the eikonal term (if on)
         # runs on that g over the whole batch too: the analytic iteration, with the eikonal weight 0 when the term is off
         proj_corr = bool(getattr(cfg, "proj_correction_on", False))
+        consistency = bool(getattr(cfg, "consistency_loss_on", False))  # utils/mapper.py:716-741: needs the autograd g as well
         weight_e = float(cfg.weight_e) if eik_mode else 0.0
-        if proj_corr:
+        if proj_corr or consistency:
             if pipeline != 1:
-                raise NotImplementedError("fused mapping loop: proj_correction_on runs on the hoisted schedule")
+                raise NotImplementedError("fused mapping loop: proj_correction_on / consistency_loss_on run on the hoisted schedule")
             eik_mode = 2
         decim = int(cfg.gradient_decimation) if eik_mode == 1 else 1
         n_eik_global = (bs_global + decim - 1) // decim
@@ -356,7 +359,7 @@ class Mapper:
         ta.bs, ta.decimation, ta.batch_offset = bs_local, decim, batch_offset
         ta.fd_eps = float(cfg.voxel_size_m * cfg.num_grad_step_ratio)
         ta.inv_n_main, ta.inv_n_eik = 1.0 / bs_global, 1.0 / n_eik_global
-        ta.sigma, ta.weight_e = float(self.sdf_scale), (weight_e if proj_corr else float(cfg.weight_e))
+        ta.sigma, ta.weight_e = float(self.sdf_scale), (weight_e if (proj_corr or consistency) else float(cfg.weight_e))
         if proj_corr:
             poses = self.used_poses
             if poses is None or poses.dim() != 3:
@@ -455,8 +458,11 @@ class Mapper:
             if not dist:
                 # single GPU: the whole loop is enqueued by one C call (hoisted searches + 2 launches per iteration)
                 ta.index, ta.loss_out = idx_base, loss_base
-                _lib.check(lib.clid_mapping_run(C.byref(view), C.byref(ta), C.byref(aa), iter_count, idx_base, bs_global,
-                                                loss_base, stream), "clid_mapping_run")
+                if consistency:
+                    self._consistency_loop(lib, view, ta, aa, iter_count, index_seq, bs_global, losses, dev, stream)
+                else:
+                    _lib.check(lib.clid_mapping_run(C.byref(view), C.byref(ta), C.byref(aa), iter_count, idx_base, bs_global,
+                                                    loss_base, stream), "clid_mapping_run")
             else:
                 # the neighbour searches do not depend on the training state: one launch per chunk of iterations
                 # resolves this rank's shard of every batch, then decode/backward -> all-reduce -> Adam per iteration.
@@ -528,6 +534,71 @@ class Mapper:
         self.last_losses = losses
         self._keep = (keep, index_seq, grad, m, v, m_mlp, v_mlp)
         nm.assign_local_to_global()
+
+    def _consistency_loop(self, lib, view, ta, aa, iter_count, index_seq, bs, losses, dev, stream):
+        """config.consistency_loss_on (utils/mapper.py:716-741, 770-776; "[not used]" there): per iteration a second batch of
+        min(consistency_count, bs) randomly shifted copies of drawn samples is searched and both batches run the analytic iteration
+        twice -- a probe that only evaluates g = d sdf / d x, `clid_consistency_couple` (the term 1 - cos(g, g_near), its value and
+        dL/dg of both batches), then the backward proper with that dL/dg added.  Host-driven (seven launches + two small torch
+        gathers per iteration): this branch is not on anybody's hot path.  The two extra draws of an iteration come from torch's
+        generator like the reference's, or from `self._consistency_draws` = [(near_index [n_c], random_shift [bs, 3])] (tests:
+        the reference's recorded draws)."""
+        cfg = self.config
+        n_c = min(int(cfg.consistency_count), bs)
+        rng, wc = float(cfg.consistency_range), float(cfg.weight_c)
+        bufs = self.__dict__.get("_cons_bufs")
+        if bufs is None or bufs["key"] != (bs, n_c, str(dev)):
+            f32 = dict(device=dev, dtype=torch.float32)
+            bufs = self._cons_bufs = {
+                "key": (bs, n_c, str(dev)),
+                "rec_main": torch.empty(int(lib.clid_train_search_floats(bs, 0, 1, 2, 1)), **f32),
+                "rec_near": torch.empty(int(lib.clid_train_search_floats(n_c, 0, 1, 2, 1)), **f32),
+                "g_main": torch.zeros((bs, 3), **f32), "g_near": torch.zeros((n_c, 3), **f32),
+                "c_main": torch.zeros((bs, 3), **f32), "c_near": torch.zeros((n_c, 3), **f32),
+                "near": torch.zeros((n_c, 3), **f32), "zeros": torch.zeros(n_c, **f32),
+                "arange": torch.arange(n_c, device=dev, dtype=torch.int64),
+            }
+        b = bufs
+        tn = _lib.TrainArgs.from_buffer_copy(ta)  # the shifted copies as a batch of their own: their coordinates are its pool,
+        tn.pool_coord, tn.pool_label, tn.pool_weight, tn.pool_ts = (  # labels / weights zero: no BCE term, no stamps (query_ts None)
+            b["near"].data_ptr(), b["zeros"].data_ptr(), b["zeros"].data_ptr(), None)
+        tn.index, tn.bs, tn.batch_offset, tn.decimation = b["arange"].data_ptr(), n_c, 0, 1
+        tn.weight_e, tn.loss_weight_on, tn.proj_correction, tn.pool_pose = 0.0, 1, 0, None
+        nb_main = int(lib.clid_train_partial_rows(C.byref(ta)))
+        nb_near = int(lib.clid_train_partial_rows(C.byref(tn)))
+        draws = getattr(self, "_consistency_draws", None)
+        pool = self.global_coord_pool
+        for it in range(iter_count):
+            index = index_seq[it]
+            loss_row = losses[it].data_ptr()
+            coord = pool.index_select(0, index)
+            if draws is not None:
+                near_index = draws[it][0].to(device=dev, dtype=torch.int64)
+                shift = draws[it][1].to(device=dev, dtype=torch.float32)
+            else:
+                near_index = torch.randint(0, bs, (n_c,), device=dev)
+                shift = torch.rand_like(coord) * 2 * rng - rng
+            near_index = near_index.contiguous()
+            b["near"].copy_((coord + shift).index_select(0, near_index))
+            ta.index, ta.loss_out, tn.loss_out = index.data_ptr(), loss_row, loss_row
+            for t_, rec_, n_ in ((ta, b["rec_main"], bs), (tn, b["rec_near"], n_c)):
+                t_.g_out, t_.c_extra, t_.partial_row0, t_.partial_rows_extra = None, None, 0, 0
+                _lib.check(lib.clid_train_search(C.byref(view), C.byref(t_), 1, t_.index, n_, rec_.data_ptr(), stream), "clid_train_search")
+            for t_, rec_, g_ in ((ta, b["rec_main"], b["g_main"]), (tn, b["rec_near"], b["g_near"])):  # the two probes
+                t_.g_out = g_.data_ptr()
+                _lib.check(lib.clid_train_decode(C.byref(view), C.byref(t_), rec_.data_ptr(), stream), "clid_train_decode")
+                t_.g_out = None
+            _lib.check(lib.clid_consistency_couple(b["g_main"].data_ptr(), b["g_near"].data_ptr(), near_index.data_ptr(), n_c, bs, wc,
+                                                   b["c_main"].data_ptr(), b["c_near"].data_ptr(), loss_row, stream),
+                       "clid_consistency_couple")
+            ta.c_extra, ta.partial_rows_extra = b["c_main"].data_ptr(), nb_near
+            tn.c_extra, tn.partial_row0 = b["c_near"].data_ptr(), nb_main
+            _lib.check(lib.clid_train_decode(C.byref(view), C.byref(ta), b["rec_main"].data_ptr(), stream), "clid_train_decode")
+            _lib.check(lib.clid_train_decode(C.byref(view), C.byref(tn), b["rec_near"].data_ptr(), stream), "clid_train_decode")
+            aa.step = it + 1
+            _lib.check(lib.clid_train_adam(C.byref(aa), C.byref(ta), stream), "clid_train_adam")
+            del near_index, shift, coord  # (their launches are enqueued on this stream: the caching allocator keeps the order)
+        ta.c_extra, ta.partial_rows_extra = None, 0
 
     def _save_trained_state(self, nm, dec_params):
         """Copies of everything a mapping() call mutates (features, decoder, certainties, update stamps) in cached

@@ -370,6 +370,18 @@ typedef struct clid_train_args {
   int32_t proj_correction;
   int32_t n_frame_pose;
   const float* frame_pose;
+  /* config.consistency_loss_on (utils/mapper.py:716-741, 770-776): 1 - cos between the analytic gradient g of drawn samples and of
+   * randomly shifted copies of them.  The copies are a second batch (own clid_train_args: their coordinates as its pool, zero
+   * weights); both batches run the analytic iteration twice per training iteration (eikonal_mode 2, hoisted records):
+   *   g_out != NULL    probe: clid_train_decode only evaluates g and stores it, [bs][3]; no side effects, no gradients;
+   *   clid_consistency_couple turns the two g arrays into the term's value and dL/dg of both batches;
+   *   c_extra != NULL  the backward proper with that dL/dg [bs][3] added to the eikonal term's (and proj_correction's) own.
+   * partial_row0: first row of the launch's per-block partials in the workspace (the second batch goes behind the first);
+   * partial_rows_extra: rows behind this batch's own that clid_train_adam also folds in. */
+  float* g_out;
+  const float* c_extra;
+  int32_t partial_row0;
+  int32_t partial_rows_extra;
 } clid_train_args;
 
 /* Schedule object for clid_train_args.sched.  cu_mask / mask_words as hipExtStreamCreateWithCUMask takes them (bit i set =
@@ -445,6 +457,14 @@ int32_t clid_train_search_tasks(int32_t bs, int64_t batch_offset, int32_t decima
 int clid_train_search(const clid_map_view* mv, const clid_train_args* t, int32_t n_iter,
                       const int64_t* index_base, int64_t index_stride, float* rec_out, void* stream);
 int clid_train_decode(const clid_map_view* mv, const clid_train_args* t, const float* rec, void* stream);
+/* rows of per-block partials the forward/backward launch of `t` leaves in the workspace (a function of the arguments alone) */
+int32_t clid_train_partial_rows(const clid_train_args* t);
+/* config.consistency_loss_on (utils/mapper.py:770-776): value and gradients of weight_c * mean_j (1 - cos(g_main[near_index[j]],
+ * g_near[j])) (F.cosine_similarity: each vector divided by max(norm, 1e-8)).  c_main [n_main][3] is zeroed and receives
+ * dL/dg_main (several copies may name one sample), c_near [n_c][3] = dL/dg_near; loss_out[3] += the mean, loss_out[0] +=
+ * weight_c * the mean. */
+int clid_consistency_couple(const float* g_main, const float* g_near, const int64_t* near_index, int32_t n_c, int32_t n_main,
+                            float weight_c, float* c_main, float* c_near, float* loss_out, void* stream);
 
 /* ---- multi-GPU: RCCL inside the C ABI (new; the reference is single-GPU, slam.py:11) ---------------------------
  * One process per GPU.  Rank 0 creates a 128-byte id (clid_comm_unique_id), the host distributes it (e.g.

@@ -226,16 +226,31 @@ def test_mapping_loop_g6_proj_correction(env, ln):
     test_mapping_loop_g6(env, "numerical", False, ln, proj=True)
 
 
+@pytest.mark.parametrize("ln", [0, 1])
+def test_mapping_loop_g6_consistency_loss(env, ln):
+    """config.consistency_loss_on (utils/mapper.py:716-741, 770-776): 1 - cos between the autograd gradient of drawn samples and of
+    randomly shifted copies of them (a second query with the training side effects on), weighted by weight_c, back-propagated
+    through both gradients -- against the reference's own loop with its recorded draws (near_index, random_shift)."""
+    g0 = gio.load(f"g6_loop_analytic_train_ln{ln}.npz") if ln == 0 else None
+    g = gio.load(f"g6_loop_numerical_train_ln{ln}_cons.npz")
+    if g0 is not None:
+        assert float(g["loss_total"][0]) - float(g0["loss_total"][0]) > 1e-3  # (the term is really there)
+    test_mapping_loop_g6(env, "numerical", False, ln, cons=True)
+
+
 @pytest.mark.parametrize("mode,frozen,ln", G6)
-def test_mapping_loop_g6(env, mode, frozen, ln, add_to="all", loss_type="bce", ba=False, wf=True, proj=False):
+def test_mapping_loop_g6(env, mode, frozen, ln, add_to="all", loss_type="bce", ba=False, wf=True, proj=False, cons=False):
     from clid_slam_amd.tools import freeze_model
 
     tag = (f"{mode}_{'frozen' if frozen else 'train'}_ln{ln}" + ("" if add_to == "all" else f"_eik{add_to}")
-           + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else "") + ("" if wf else "_wf0") + ("_proj" if proj else ""))
+           + ("" if loss_type == "bce" else f"_{loss_type}") + ("_ba" if ba else "") + ("" if wf else "_wf0") + ("_proj" if proj else "")
+           + ("_cons" if cons else ""))
     g = gio.load(f"g6_loop_{tag}.npz")
     p = gio.load("pool.npz")
     cfg = env.config(layer_norm_on=bool(ln), bs=int(g["index_seq"].shape[1]), bs_new_sample=200, ekional_add_to=add_to,
-                     main_loss_type=loss_type, weighted_first=bool(wf), proj_correction_on=bool(proj))
+                     main_loss_type=loss_type, weighted_first=bool(wf), proj_correction_on=bool(proj), consistency_loss_on=bool(cons))
+    if cons:
+        cfg.consistency_count, cfg.weight_c = int(g["cons_near_index"].shape[1]), float(g["cons_weight_c"])
     if mode == "analytic":
         cfg.numerical_grad, cfg.gradient_decimation = False, 1
     nm = env.neural_points(cfg, base=p)
@@ -245,6 +260,8 @@ def test_mapping_loop_g6(env, mode, frozen, ln, add_to="all", loss_type="bce", b
     mp, _ = env.mapper(cfg, nm, dec)
     if proj:
         mp.used_poses = gio.T(g["proj_used_poses"]).cuda()
+    if cons:  # the reference's own draws of every iteration
+        mp._consistency_draws = [(gio.T(g["cons_near_index"][it]), gio.T(g["cons_shift"][it])) for it in range(g["cons_shift"].shape[0])]
     if ba:
         mp.coord_pool = gio.T(g["ba_coord_pool"]).cuda()
         mp.used_poses = gio.T(g["ba_used_poses"]).cuda()
