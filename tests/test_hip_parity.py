@@ -238,6 +238,26 @@ def test_mapping_loop_g6_consistency_loss(env, ln):
     test_mapping_loop_g6(env, "numerical", False, ln, cons=True)
 
 
+def test_consistency_loss_with_its_own_draws_runs(env):
+    """config.consistency_loss_on without teacher-forced draws (near_index / random_shift from torch's generator, as in the
+    reference): the loop runs, every loss row carries the term (column 3 = mean 1 - cos in (0, 2)), the total is bce + weight_e eik
+    + weight_c term, and training reduces the total."""
+    g = gio.load("g6_loop_numerical_train_ln0.npz")
+    p = gio.load("pool.npz")
+    cfg = env.config(bs=2048, bs_new_sample=200, consistency_loss_on=True)
+    cfg.consistency_count = 512
+    nm = env.neural_points(cfg, base=p)
+    dec = env.decoder(cfg, g, "init_")
+    mp, _ = env.mapper(cfg, nm, dec)
+    torch.manual_seed(3)
+    mp.mapping(6)
+    L = mp.last_losses.cpu().numpy()
+    assert L.shape == (6, 4) and np.isfinite(L).all()
+    assert (L[:, 3] > 0).all() and (L[:, 3] < 2).all()
+    assert np.abs(L[:, 0] - (L[:, 1] + cfg.weight_e * L[:, 2] + cfg.weight_c * L[:, 3])).max() <= 1e-5
+    assert L[-1, 0] < L[0, 0]
+
+
 @pytest.mark.parametrize("mode,frozen,ln", G6)
 def test_mapping_loop_g6(env, mode, frozen, ln, add_to="all", loss_type="bce", ba=False, wf=True, proj=False, cons=False):
     from clid_slam_amd.tools import freeze_model
