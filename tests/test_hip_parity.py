@@ -535,6 +535,92 @@ def test_mapping_loop_vs_oracle_free_batches(env, mode, ln):
     assert maxerr(nm.local_point_certainties, recs[-1]["certainties"]) <= 2e-3
 
 
+@pytest.mark.parametrize("branch,ln", [("wf0_analytic", 0), ("wf0_analytic", 1), ("proj", 1), ("proj_no_eik", 0), ("cons", 1),
+                                       ("sdf_l2", 1), ("zhong", 0), ("ba", 1)])
+def test_loop_branches_vs_oracle_on_fresh_batches(env, branch, ln):
+    """The reference's non-default loop branches (utils/mapper.py:646-658, 676-680, 695-696, 712-741, 751-776) away from their
+    fixtures' batches: bs 8192, fresh random draws, 2 iterations, against the pinned CPU oracle -- losses, features, decoder,
+    certainties."""
+    from oracle import cpu_ref as OO
+
+    p = gio.load("pool.npz")
+    g = gio.load("g6_loop_numerical_train_ln0.npz")
+    bs, iters = 8192, 2
+    over = dict(layer_norm_on=bool(ln), bs=bs)
+    lc_over = {}
+    if branch == "wf0_analytic":
+        over.update(weighted_first=False)
+    elif branch in ("proj", "proj_no_eik"):
+        over.update(proj_correction_on=True)
+        lc_over.update(proj_correction_on=True)
+        if branch == "proj_no_eik":  # the correction alone: g is still evaluated, the eikonal term is not
+            over.update(ekional_loss_on=False)
+            lc_over.update(ekional_loss_on=False)
+    elif branch == "cons":
+        over.update(consistency_loss_on=True)
+        lc_over.update(consistency_loss_on=True, weight_c=0.5)
+    elif branch in ("sdf_l2", "zhong"):
+        over.update(main_loss_type=branch)
+        lc_over.update(main_loss_type=branch)
+    cfg = env.config(**over)
+    if branch == "wf0_analytic":
+        cfg.numerical_grad, cfg.gradient_decimation = False, 1
+        lc_over.update(numerical_grad=False, gradient_decimation=1)
+    if branch == "cons":
+        cfg.consistency_count = 1024
+    gen = torch.Generator().manual_seed(17)
+    n_pool = p["coord"].shape[0]
+    idx = torch.randint(0, n_pool, (iters, bs), generator=gen)
+    nm = env.neural_points(cfg, base=p)
+    dec = env.decoder(cfg, g, "init_")
+    mp, _ = env.mapper(cfg, nm, dec)
+    st = gio.map_state(layer_norm_on=bool(ln), weighted_first=branch != "wf0_analytic")
+    st.local_geo_features = gio.T(p["base_geo_features"])[gio.T(g["local_mask"])].clone()
+    st.local_point_certainties = gio.T(p["base_point_certainties"])[gio.T(g["local_mask"])[:-1]].clone()
+    st.local_point_ts_update = gio.T(p["base_point_ts_update"])[gio.T(g["local_mask"])[:-1]].clone()
+    pool, _ = gio.sample_pool()
+    od = gio.decoder(g, "init_")
+    if branch in ("sdf_l2", "zhong"):
+        od.sdf_scale = 1.0  # model/decoder.py:51-53
+    cons_seq = None
+    poses = torch.eye(4, dtype=torch.float64)[None].repeat(3, 1, 1)
+    for fi, spos in enumerate(((0.0, 0.0, 1.5), (6.0, 2.0, 1.5), (9.0, 3.0, 1.6))):
+        poses[fi, :3, 3] = torch.tensor(spos, dtype=torch.float64)
+    if branch in ("proj", "proj_no_eik"):
+        mp.used_poses = poses.cuda()
+        pool.frame_poses = poses
+    if branch == "cons":
+        cons_seq = [(torch.randint(0, bs, (1024,), generator=gen), torch.rand((bs, 3), generator=gen) * 2 * 0.05 - 0.05) for _ in range(iters)]
+        mp._consistency_draws = cons_seq
+    if branch == "ba":  # the pool in sensor frames under three rotated / shifted poses; the world-frame pool is stale
+        gp = torch.Generator().manual_seed(29)
+        for fi in range(3):
+            a = float((torch.rand((), generator=gp, dtype=torch.float64) - 0.5) * 0.8)
+            poses[fi, :3, :3] = torch.tensor([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=torch.float64)
+        P = poses[pool.time.long()]
+        local = torch.bmm(P[:, :3, :3].transpose(1, 2), (pool.global_coord.double() - P[:, :3, 3]).unsqueeze(-1)).squeeze(-1).float()
+        pool.local_coord, pool.used_poses = local, poses
+        pool.global_coord = pool.global_coord + 0.4
+        mp.coord_pool, mp.used_poses = local.cuda(), poses.cuda()
+        mp.global_coord_pool = mp.global_coord_pool + 0.4
+        mp.ba_done_flag = True
+    mp.mapping(iters, index_seq=idx.cuda())
+    lc = OO.LoopConfig(**lc_over)
+    recs = OO.mapping_iters(st, od, pool, idx, lc, record=True, consistency_seq=cons_seq)
+    got = mp.last_losses.cpu()
+    for it, r in enumerate(recs):
+        assert abs(float(got[it, 0]) - float(r["loss"])) <= 1e-5, (branch, it, got[it], r["loss"])
+        assert abs(float(got[it, 1]) - float(r["sdf_loss"])) <= 1e-5
+        assert abs(float(got[it, 2]) - float(r["eikonal_loss"])) <= 1e-5
+        if branch == "cons":
+            assert abs(float(got[it, 3]) - float(r["consistency_loss"])) <= 1e-5
+    assert maxerr(nm.local_geo_features, recs[-1]["theta"]) <= 1e-4
+    for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
+        assert maxerr(t, o) <= 1e-4
+    assert maxerr(nm.local_point_certainties, recs[-1]["certainties"]) <= 2e-3
+    assert np.array_equal(nm.local_point_ts_update.cpu().numpy(), recs[-1]["ts_update"].numpy())
+
+
 @pytest.mark.parametrize("pipeline,ln,eik,train", [(1, 0, True, True), (1, 1, True, True), (1, 0, False, True), (1, 1, True, False),
                                                    (0, 0, True, True)])
 def test_mapping_weighted_first_false_vs_oracle(env, pipeline, ln, eik, train):
