@@ -1364,6 +1364,7 @@ __host__ __device__ inline unsigned long long clid_mix64(unsigned long long seed
 }
 
 // 8 bits per axis of the sample's voxel coordinate, interleaved (x lowest): the order the sorted variant presents a batch in
+constexpr unsigned kSortClassBit = 1u << 24;  // above the 24-bit code in a sort key
 __device__ __forceinline__ unsigned morton24(int cx, int cy, int cz) {
   auto spread = [](unsigned v) {
     v &= 0xFFu;
@@ -1379,7 +1380,7 @@ __global__ void __launch_bounds__(256)
 k_mapping_prep(float4* __restrict__ zero4, long long n_zero4, long long* __restrict__ index_out, long long n_index, int bs,
                int bs_new, unsigned long long pool_count, const long long* __restrict__ new_idx, unsigned long long n_new,
                unsigned long long seed, unsigned long long counter, const float* __restrict__ pool_coord, float resolution,
-               unsigned* __restrict__ key_out, int col0, int ncols) {
+               unsigned* __restrict__ key_out, int col0, int ncols, int decim) {
   const long long stride = (long long)gridDim.x * 256;
   const long long t0 = (long long)blockIdx.x * 256 + threadIdx.x;
   for (long long i = t0; i < n_zero4; i += stride) zero4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1395,13 +1396,15 @@ k_mapping_prep(float4* __restrict__ zero4, long long n_zero4, long long* __restr
     if (col < n_hist) v = (long long)__umul64hi(r, pool_count);
     else v = new_idx[__umul64hi(r, n_new)];
     index_out[e] = v;
-    if (key_out) {  // Morton code of the sample's voxel (8 bits per axis: wraps every 256 voxels): the sort key of k_batch_sort
+    if (key_out) {  // Morton code of the sample's voxel (8 bits per axis: wraps every 256 voxels): the sort key of k_batch_sort.
+      // Bit 24 = the position's class (see Lattice below): 0 on the eikonal lattice col % decim == 0, 1 elsewhere -- the order is
+      // by (class, code, position), so the class costs the ordering launch nothing
       struct F3 {
         float x, y, z;
       };
       const F3 c = reinterpret_cast<const F3*>(pool_coord)[v];
       key_out[e] = morton24((int)floorf(fdiv(c.x, resolution)), (int)floorf(fdiv(c.y, resolution)),
-                            (int)floorf(fdiv(c.z, resolution)));
+                            (int)floorf(fdiv(c.z, resolution))) | ((decim > 1 && col % decim != 0) ? kSortClassBit : 0u);
     }
   }
 }
@@ -1411,11 +1414,7 @@ k_mapping_prep(float4* __restrict__ zero4, long long n_zero4, long long* __restr
 // axis: wraps every 256 voxels) and sorts (key, position) in LDS with a stable block radix sort, so the order is a function
 // of the draws alone: identical on every rank.  The zero fill is shared by all blocks.
 constexpr int kSortSeg = 16384, kSortThreads = 1024, kSortBins = 256, kSortWaves = kSortThreads / 64;
-// blocks (= CUs) that share one full segment: 8 with a capacity of twice the mean bucket (4 elements per thread), or -- while
-// the call's blocks still find a CU each (iterations x segments <= 16: the per-frame calls of slam.py) -- 16 with three times
-// the mean (3 per thread): the counting passes are bound by the VALU rate of the block's ONE CU
-constexpr int kSortBucketsFew = 8, kSortBucketsMany = 16;
-__host__ __device__ constexpr int sort_bucket_items(int buckets) { return buckets == kSortBucketsMany ? 3 : 32 / buckets; }
+// (the radix passes below order the TAIL of a batch that is no multiple of a segment; full segments: k_batch_sort_bucket)
 struct BinScan {  // LDS of block_excl_scan<unsigned, kSortThreads> (the top of this file): the block's wave totals
   struct TempStorage {
     unsigned w[kSortThreads / 64];
@@ -1586,7 +1585,7 @@ k_batch_sort_tail(const long long* __restrict__ draws, const unsigned* __restric
   for (int r = 0; r < ITEMS; ++r) {
     const int p = wave * (ITEMS * 64) + r * 64 + lane;
     pos[r] = (unsigned)p;
-    key[r] = p < n ? keys[e0 + p] : 0xFFFFFFu;  // padding: behind every real element (largest code, larger position)
+    key[r] = p < n ? (keys[e0 + p] & 0xFFFFFFu) : 0xFFFFFFu;  // padding: behind every real element (largest code, larger position)
   }
   sort_pairs<ITEMS>(key, pos, dest, tab, seq, scan_tmp);
   if (decim > 1) {  // (uniform) the order within the lattice class and within the others (see Lattice)
@@ -1607,156 +1606,263 @@ k_batch_sort_tail(const long long* __restrict__ draws, const unsigned* __restric
     if ((int)dest[r] < n) index_out[e0 + dest[r]] = draws[e0 + pos[r]];
 }
 
-// k_batch_sort_bucket: a FULL segment is shared by BUCKETS blocks (sorting in LDS is bound by one CU's LDS rate: 54 us
-// for 16 384 elements in one block).  Every block derives the same 7 splitters from the same 256 sample keys, scans the
-// segment's keys (64 KB, coalesced), keeps the elements of ITS key range in position order, sorts them and writes them
-// behind the smaller ranges.  No communication between the blocks.
-template <int BUCKETS>
+// k_batch_sort_bucket: a FULL segment is shared by 12 .. 16 blocks.  Every block derives the same splitters from the same 512
+// sample keys (positions 0, 32, 64, ...), reads the segment's keys (64 KB, 16 consecutive ones per thread), keeps the elements
+// of ITS key range in position order, orders them by (key, position) and writes them behind the smaller ranges.  No
+// communication between the blocks.
+//   Round 6 (34.4 -> 21.9 us at the bench shape, same box: profiles/r06_sort_ab.jsonl; phases: tools/sort_timing.py):
+//   - the position's class rides in the key (bit 24, written by k_mapping_prep) and a splitter is forced onto the class boundary:
+//     no range holds both classes, the place of an element is its rank in (class, code, position) order mapped through the
+//     lattice -- no second ranking pass, no per-class counters in the scan (the scan + keep phases: 30 k -> 11 k cycles);
+//   - the scan is thread-blocked (four 16-byte loads, two compares per key) with ONE block scan of packed (mine | below) counts
+//     instead of two ballots + population counts per key and wave;
+//   - at most 2048 elements per block, ordered by a bitonic network on composites held two per thread: partner distance 1 is
+//     the thread's own pair, 2 .. 64 are lane exchanges (DPP moves up to 8 lanes, permlane swaps for 16 / 32: no LDS crossbar,
+//     of which a 1024-thread block has one), 128 and up go through LDS (double-buffered: one barrier per stage) -- 66
+//     compare-exchange stages, 10 barriers, against three counting passes of 8 ballots + a dependent LDS update per element
+//     and a 4096-entry table scan each (26 k -> 12 k cycles).  Composites are 32 bits ((key - lo) << 11 | slot) whenever the
+//     kept keys lie within 2^21 of lo, 64 bits (key << 14 | position) otherwise; the network is sized to the element count;
+//   - the splitters come from the same network (512 sample VALUES, 45 stages on four waves).
+constexpr int kSortBucketsMax = 16, kSortBucketsMin = 12, kSortCap = 2048, kSortSamples = 512;
+// blocks per segment: 16; 12 .. 15 when that keeps every block of the call alone on its compute unit (two 1024-thread blocks on a
+// CU take twice as long, and the launch lasts as long as its slowest block); decided by the CALL's shape (the chip's 256 CUs as a
+// constant), so every rank of a data-parallel run orders a shared segment the same way
+__host__ inline int sort_buckets_for(long long call_segments) {
+  if (call_segments * kSortBucketsMax <= 256 || call_segments * kSortBucketsMin > 256) return kSortBucketsMax;
+  return (int)(256 / call_segments);
+}
+static_assert(kSortCap == 2 * kSortThreads, "two composites per thread");
+// value of lane (lane ^ J): DPP moves up to 8 lanes (no LDS crossbar: a 1024-thread block has ONE), permlane swaps for 16 / 32
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <int J>
+__device__ __forceinline__ unsigned lane_xor(unsigned v) {
+  if constexpr (J == 1) return dpp_u32<0xB1>(v);                        // quad_perm [1,0,3,2]
+  else if constexpr (J == 2) return dpp_u32<0x4E>(v);                   // quad_perm [2,3,0,1]
+  else if constexpr (J == 4) return dpp_u32<0x1B>(dpp_u32<0x141>(v));   // row_half_mirror (^7), then quad_perm [3,2,1,0] (^3)
+  else if constexpr (J == 8) return dpp_u32<0x141>(dpp_u32<0x140>(v));  // row_mirror (^15), then row_half_mirror (^7)
+  else if constexpr (J == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // one of the pair is the lane's own value
+    return r[0] == v ? r[1] : r[0];
+  } else {
+    static_assert(J == 32, "lane distance");
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return r[0] == v ? r[1] : r[0];
+  }
+}
+template <int J>
+__device__ __forceinline__ unsigned long long lane_xor(unsigned long long v) {
+  return ((unsigned long long)lane_xor<J>((unsigned)(v >> 32)) << 32) | lane_xor<J>((unsigned)v);
+}
+template <class T>
+__device__ __forceinline__ T tmin(T a, T b) { return a < b ? a : b; }
+template <class T>
+__device__ __forceinline__ T tmax(T a, T b) { return a < b ? b : a; }
+template <class T>
+struct Pair2 {
+  T x, y;
+};
+// ascending bitonic network over N <= 2048 composites: thread t < N / 2 holds elements 2 t and 2 t + 1 (the other threads of the
+// block only keep the barriers).  Partner distance 1: the thread's own pair; 2 .. 64: a lane exchange (lane ^ 1 .. 32); 128 and up:
+// through LDS, two buffers in turn (one barrier per stage; the first such stage writes buffer 1: buffer 0 still holds the
+// unordered elements other threads may be reading).
+// keep the smaller (keep_min) or the larger of x and the partner's p.  32 bits: min / max (the compiler folds the DPP move into
+// them); 64 bits: ONE compare and two selects (min and max separately cost two 64-bit compares and six selects)
+__device__ __forceinline__ void keep_one(unsigned& x, unsigned p, bool keep_min) { x = keep_min ? min(x, p) : max(x, p); }
+__device__ __forceinline__ void keep_one(unsigned long long& x, unsigned long long p, bool keep_min) {
+  x = ((p < x) == keep_min) ? p : x;  // (p == x: either)
+}
+template <class T, int N, int K, int J>
+__device__ __forceinline__ void bitonic_stage(T& x0, T& x1, T* __restrict__ buf, int& flip, bool active) {
+  const unsigned t = threadIdx.x;
+  const bool up = K == N || (t & (unsigned)(K >> 1)) == 0u;  // direction of the element's K-block (index 2 t)
+  if constexpr (J == 1) {
+    const bool swap = (x1 < x0) == up;
+    const T a = swap ? x1 : x0, b = swap ? x0 : x1;
+    x0 = a;
+    x1 = b;
+  } else {
+    T p0 = x0, p1 = x1;
+    if constexpr (J <= 64) {
+      p0 = lane_xor<J / 2>(x0);
+      p1 = lane_xor<J / 2>(x1);
+    } else {
+      Pair2<T>* __restrict__ b2 = reinterpret_cast<Pair2<T>*>(buf + (size_t)flip * kSortCap);
+      if (active) b2[t] = Pair2<T>{x0, x1};
+      __syncthreads();
+      if (active) {
+        const Pair2<T> p = b2[t ^ (unsigned)(J >> 1)];
+        p0 = p.x;
+        p1 = p.y;
+      }
+      flip ^= 1;
+    }
+    const bool keep_min = ((t & (unsigned)(J >> 1)) == 0u) == up;
+    keep_one(x0, p0, keep_min);
+    keep_one(x1, p1, keep_min);
+  }
+}
+template <class T, int N, int K, int J>
+__device__ __forceinline__ void bitonic_phase(T& x0, T& x1, T* __restrict__ buf, int& flip, bool active) {
+  if (J > 64 || active) bitonic_stage<T, N, K, J>(x0, x1, buf, flip, active);  // (wave-uniform: N / 2 is a multiple of 64)
+  if constexpr (J > 1) bitonic_phase<T, N, K, J / 2>(x0, x1, buf, flip, active);
+}
+template <class T, int N, int K = 2>
+__device__ __forceinline__ void bitonic_sort(T& x0, T& x1, T* __restrict__ buf, int& flip, bool active) {
+  bitonic_phase<T, N, K, K / 2>(x0, x1, buf, flip, active);
+  if constexpr (K < N) bitonic_sort<T, N, 2 * K>(x0, x1, buf, flip, active);
+}
+// the network of the smallest size that holds m elements (block-uniform): a lattice-class range of a few hundred elements
+// occupies four of the block's sixteen waves for 45 stages, not all of them for 66
+template <class T>
+__device__ __forceinline__ void bitonic_sort_m(T& x0, T& x1, T* __restrict__ buf, unsigned m) {
+  int flip = 1;
+  if (m <= 512u) bitonic_sort<T, 512>(x0, x1, buf, flip, threadIdx.x < 256);
+  else if (m <= 1024u) bitonic_sort<T, 1024>(x0, x1, buf, flip, threadIdx.x < 512);
+  else bitonic_sort<T, kSortCap>(x0, x1, buf, flip, true);
+}
+// place of the element of rank R in (class, code, position) order of a full segment: the lattice positions take the ranks below n_lat
+__device__ __forceinline__ unsigned lattice_place(const Lattice& L, unsigned n_lat, unsigned R) {
+  if (L.decim == 1) return R;
+  return R < n_lat ? lattice_pos(L, true, R) : lattice_pos(L, false, R - n_lat);
+}
+
 __global__ void __launch_bounds__(kSortThreads)
 k_batch_sort_bucket(const long long* __restrict__ draws, const unsigned* __restrict__ keys, long long* __restrict__ index_out,
-                    int bs, int full_segs, int seg0, int decim) {
-  constexpr int kSortBuckets = BUCKETS;
-  constexpr int ITEMS = sort_bucket_items(BUCKETS), CAP = ITEMS * kSortThreads, SCAN = kSortSeg / kSortThreads;
-  __shared__ unsigned tab[kSortBins * kSortWaves];
-  __shared__ unsigned seq[CAP];
-  __shared__ unsigned sel_key[CAP], sel_pos[CAP];
-  __shared__ __attribute__((aligned(16))) unsigned samp[256];
-  __shared__ unsigned sorted[256], prank[kSortThreads / 256][256], wcnt[kSortWaves], wlow[kSortWaves];
-  __shared__ unsigned wcntD[kSortWaves], wlowD[kSortWaves];  // (decim > 1) the lattice-class elements among them
-  __shared__ typename BinScan::TempStorage scan_tmp;
-  const int bk = blockIdx.x % kSortBuckets;
-  const int sg = blockIdx.x / kSortBuckets;
+                    int bs, int full_segs, int seg0, int decim, int buckets, int force_wide) {
+  constexpr int SCAN = kSortSeg / kSortThreads;
+  __shared__ __attribute__((aligned(16))) unsigned long long buf[2 * kSortCap];
+  __shared__ unsigned sorted[kSortSamples];
+  __shared__ unsigned short selpos[kSortCap];
+  __shared__ unsigned scan_ws[kSortWaves];
+  const int bk = blockIdx.x % buckets;
+  const int sg = blockIdx.x / buckets;
   const int it = sg / full_segs, seg = seg0 + (sg - it * full_segs);
   const long long e0 = (long long)it * bs + (long long)seg * kSortSeg;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // ---- splitters: the 256 keys at positions 0, 64, 128, ... ranked by (key, sample number).  All threads take part: thread
-  // (sample i, part p) counts the samples of quarter p below sample i, 4 per LDS read (256 sequential reads per thread were a
-  // quarter of the launch: 15.9 k of 63 k cycles, tools/sort_timing.py)
   CLID_STAMP(0);
-  if (threadIdx.x < 256) samp[threadIdx.x] = (keys[e0 + 64 * threadIdx.x] << 8) | threadIdx.x;  // (24-bit code, sample number): distinct
-  __syncthreads();
+  // the segment's keys, 16 consecutive ones per thread, requested first: they arrive under the splitter ranking
+  unsigned key[SCAN];
+  {
+    const unsigned* __restrict__ kp = keys + e0 + SCAN * threadIdx.x;
+    if ((e0 & 3) == 0) {  // (uniform) 16-byte loads when the segment starts on a 16-byte boundary of the key array
+#pragma unroll
+      for (int q = 0; q < SCAN / 4; ++q) {
+        const uint4 v = reinterpret_cast<const uint4*>(kp)[q];
+        key[4 * q] = v.x;
+        key[4 * q + 1] = v.y;
+        key[4 * q + 2] = v.z;
+        key[4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < SCAN; ++r) key[r] = kp[r];
+    }
+  }
+  // ---- splitters: the 512 keys at positions 0, 32, 64, ... ordered by (key, sample number) on the same network (four waves, 45
+  // stages); 512 samples keep a range of twice the mean size from ever (< 1e-4 per range at 12 blocks per segment) exceeding
+  // a block's capacity, 256 did not (1.5 % / 0.1 % at 12 / 16 blocks)
+  constexpr int kSampStep = kSortSeg / kSortSamples;
+  const bool samp_thread = threadIdx.x < kSortSamples / 2;
+  unsigned q0 = 0xFFFFFFFFu, q1 = 0xFFFFFFFFu;  // (the splitters are VALUES at given ranks: equal sample keys need no order)
+  if (samp_thread) {
+    q0 = keys[e0 + kSampStep * (2 * threadIdx.x)];
+    q1 = keys[e0 + kSampStep * (2 * threadIdx.x + 1)];
+  }
   CLID_STAMP(1);
   {
-    constexpr int kParts = kSortThreads / 256, kPer4 = 64 / kParts;  // uint4 reads per thread
-    const int i = threadIdx.x & 255, part = threadIdx.x >> 8;
-    const unsigned c = samp[i];
-    const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(samp) + part * kPer4;
-    unsigned rank = 0;
-#pragma unroll
-    for (int jj = 0; jj < kPer4; ++jj) {
-      const uint4 o = s4[jj];
-      rank += (o.x < c ? 1u : 0u) + (o.y < c ? 1u : 0u) + (o.z < c ? 1u : 0u) + (o.w < c ? 1u : 0u);
-    }
-    prank[part][i] = rank;
+    int flip = 1;
+    bitonic_sort<unsigned, kSortSamples>(q0, q1, reinterpret_cast<unsigned*>(buf), flip, samp_thread);
   }
-  __syncthreads();
-  if (threadIdx.x < 256) {
-    unsigned rank = 0;
-#pragma unroll
-    for (int p2 = 0; p2 < kSortThreads / 256; ++p2) rank += prank[p2][threadIdx.x];
-    sorted[rank] = samp[threadIdx.x] >> 8;
+  if (samp_thread) {
+    sorted[2 * threadIdx.x] = q0;
+    sorted[2 * threadIdx.x + 1] = q1;
   }
-  __syncthreads();
+  // samples of the lattice class (they rank first); the barriers also publish `sorted` and end the network's use of buf
+  const unsigned s0 = (unsigned)__syncthreads_count(samp_thread && q0 < kSortClassBit) +
+                      (unsigned)__syncthreads_count(samp_thread && q1 < kSortClassBit);
   CLID_STAMP(2);
-  // this block's key range [lo, hi): splitter k = the sample of rank k * 256 / kSortBuckets
-  const unsigned lo = bk > 0 ? sorted[bk * (256 / kSortBuckets)] : 0u;
-  const unsigned hi = bk + 1 < kSortBuckets ? sorted[(bk + 1) * (256 / kSortBuckets)] : 0xFFFFFFFFu;  // (keys are 24-bit codes)
-  // ---- scan of the segment in wave-blocked order: count, then keep this block's key range in position order
-  const bool classes = decim > 1;  // (uniform) order within the lattice class and within the others (see Lattice)
-  const Lattice L = lattice_of((long long)seg * kSortSeg, decim);
-  unsigned key[SCAN];
-  unsigned cm = 0, cl = 0, cmD = 0, clD = 0;
-  unsigned long long mine_bits = 0;  // bit r: element r of this thread belongs to this block
+  // this block's key range [lo, hi).  The classes share the blocks by their sizes (one position in `decim` is a lattice position):
+  // nb0 blocks split the lattice class at its own samples' quantiles, the others the rest; the class boundary is a splitter.
+  constexpr unsigned kLast = kSortSamples - 1;
+  const int nb0 = decim == 1 ? buckets : min(max((buckets + decim / 2) / decim, 1), buckets - 1);
+  unsigned lo, hi;
+  if (bk < nb0) {
+    lo = bk > 0 ? sorted[min((unsigned)bk * s0 / (unsigned)nb0, kLast)] : 0u;
+    hi = bk + 1 < nb0 ? sorted[min((unsigned)(bk + 1) * s0 / (unsigned)nb0, kLast)] : (decim == 1 ? 0xFFFFFFFFu : kSortClassBit);
+    if (s0 == 0u) lo = 0u, hi = bk + 1 < nb0 ? 0u : kSortClassBit;  // (no sample of the class: its last block takes all of it)
+  } else {
+    const unsigned j = (unsigned)(bk - nb0), nb1 = (unsigned)(buckets - nb0), s1 = (unsigned)kSortSamples - s0;
+    lo = j > 0 ? sorted[min(s0 + j * s1 / nb1, kLast)] : kSortClassBit;
+    hi = j + 1 < nb1 ? sorted[min(s0 + (j + 1) * s1 / nb1, kLast)] : 0xFFFFFFFFu;
+    if (s1 == 0u) lo = j + 1 < nb1 ? 0xFFFFFFFFu : kSortClassBit, hi = 0xFFFFFFFFu;
+  }
+  // ---- scan: count, one block scan of the packed counts, keep this block's range in position order
+  unsigned cnt = 0;   // mine | below << 16
+  bool far = false;   // a kept key 2^21 or more above lo: the narrow composites below do not hold it
 #pragma unroll
   for (int r = 0; r < SCAN; ++r) {
-    const int p = wave * (SCAN * 64) + r * 64 + lane;
-    key[r] = keys[e0 + p];
-    const bool below = key[r] < lo;  // (bucket b = number of splitters <= key: b < bk <=> key < split[bk - 1])
-    const bool mine = !below && key[r] < hi;
-    cm += (unsigned)__popcll(__ballot(mine));
-    cl += (unsigned)__popcll(__ballot(below));
-    mine_bits |= mine ? (1ULL << r) : 0ULL;
-    if (classes) {
-      const bool c = lattice_has(L, (unsigned)p);
-      cmD += (unsigned)__popcll(__ballot(mine && c));
-      clD += (unsigned)__popcll(__ballot(below && c));
-    }
+    const bool mine = key[r] >= lo && key[r] < hi;
+    cnt += (key[r] < lo ? 0x10000u : 0u) + (mine ? 1u : 0u);
+    far |= mine && key[r] - lo >= (1u << 21);
   }
-  if (lane == 0) {
-    wcnt[wave] = cm;
-    wlow[wave] = cl;
-    wcntD[wave] = cmD;
-    wlowD[wave] = clD;
-  }
-  __syncthreads();
+  buf[2 * threadIdx.x] = ~0ULL;  // padding behind every real element (all ones at either width)
+  buf[2 * threadIdx.x + 1] = ~0ULL;
+  unsigned tot;
+  const unsigned ex = block_excl_scan<unsigned, kSortThreads>(cnt, scan_ws, &tot);
   CLID_STAMP(3);
-  unsigned wbase = 0, m = 0, lower = 0, wbaseD = 0, lowerD = 0;
+  const unsigned m = tot & 0xFFFFu, lower = tot >> 16;
+  const Lattice L = lattice_of((long long)seg * kSortSeg, decim);
+  const unsigned n_lat = decim == 1 ? 0u : (unsigned)((kSortSeg - L.off + decim - 1) / decim);
+  if (m > (unsigned)kSortCap) {  // (block-uniform) a key range more than twice the mean: keeps the draw order
+    unsigned slot = ex & 0xFFFFu;
 #pragma unroll
-  for (int w = 0; w < kSortWaves; ++w) {
-    wbase += w < wave ? wcnt[w] : 0u;
-    m += wcnt[w];
-    lower += wlow[w];
-    wbaseD += w < wave ? wcntD[w] : 0u;
-    lowerD += wlowD[w];
-  }
-  const bool overflow = m > (unsigned)CAP;  // (block-uniform) a key range more than twice the mean: keeps the draw order
-  unsigned run = wbase, runD = wbaseD;
-#pragma unroll
-  for (int r = 0; r < SCAN; ++r) {
-    const bool mine = (mine_bits >> r) & 1ULL;
-    const unsigned long long bal = __ballot(mine);
-    const unsigned long long below_me = (1ULL << lane) - 1ULL;
-    const unsigned slot = run + (unsigned)__popcll(bal & below_me);
-    const unsigned p = (unsigned)(wave * (SCAN * 64) + r * 64 + lane);
-    const bool c = classes && lattice_has(L, p);
-    const unsigned long long balD = classes ? __ballot(mine && c) : 0ULL;
-    if (mine) {
-      if (overflow) {
-        unsigned at = lower + slot;
-        if (classes) {
-          const unsigned before = lowerD + runD + (unsigned)__popcll(balD & below_me);  // lattice-class elements placed before this one
-          at = lattice_pos(L, c, c ? before : at - before);
-        }
-        index_out[e0 + at] = draws[e0 + p];
-      } else {
-        sel_key[slot] = key[r];
-        sel_pos[slot] = p;
+    for (int r = 0; r < SCAN; ++r)
+      if (key[r] >= lo && key[r] < hi) {
+        index_out[e0 + lattice_place(L, n_lat, lower + slot)] = draws[e0 + (unsigned)(SCAN * threadIdx.x + r)];
+        ++slot;
       }
-    }
-    run += (unsigned)__popcll(bal);
-    runD += (unsigned)__popcll(balD);
-  }
-  if (overflow) return;
-  __syncthreads();
-  CLID_STAMP(4);
-  unsigned k4[ITEMS], pos[ITEMS], dest[ITEMS];
-#pragma unroll
-  for (int r = 0; r < ITEMS; ++r) {
-    const unsigned i = (unsigned)(wave * (ITEMS * 64) + r * 64 + lane);
-    k4[r] = i < m ? sel_key[i] : 0xFFFFFFu;  // padding: behind every real element
-    pos[r] = i < m ? sel_pos[i] : 0x3FFFu;
-  }
-  sort_pairs<ITEMS>(k4, pos, dest, tab, seq, scan_tmp);
-  CLID_STAMP(5);
-  if (classes) {
-    bool cls[ITEMS];
-    unsigned rD[ITEMS];
-#pragma unroll
-    for (int r = 0; r < ITEMS; ++r) cls[r] = lattice_has(L, pos[r]);
-    static_assert(CAP / 32 * 2 <= kSortBins * kSortWaves, "class_ranks' words + prefix fit the radix table");
-    class_ranks<ITEMS>(dest, cls, m, rD, tab, tab + CAP / 32, CAP / 32, scan_tmp);
-#pragma unroll
-    for (int r = 0; r < ITEMS; ++r)
-      if (dest[r] < m) {
-        const unsigned before = lowerD + rD[r];
-        index_out[e0 + lattice_pos(L, cls[r], cls[r] ? before : lower + dest[r] - before)] = draws[e0 + pos[r]];
-      }
-    CLID_STAMP(6);
     return;
   }
+  // Composites.  Narrow (the rule): (key - lo) << 11 | slot, 32 bits -- the slots are in position order, so the order by
+  // composite is the order by (key, position); the position comes back through selpos.  Wide (a kept key 2^21 or more above lo:
+  // the one range that holds the whole lattice class, or two far clusters in one range): key << 14 | position, 64 bits.
+  // (the barrier also orders the padding stores above in front of the composites)
+  const bool narrow = !__syncthreads_or(far || force_wide);
+  unsigned* __restrict__ buf32 = reinterpret_cast<unsigned*>(buf);
+  {
+    unsigned slot = ex & 0xFFFFu;
 #pragma unroll
-  for (int r = 0; r < ITEMS; ++r)
-    if (dest[r] < m) index_out[e0 + lower + dest[r]] = draws[e0 + pos[r]];
+    for (int r = 0; r < SCAN; ++r)
+      if (key[r] >= lo && key[r] < hi) {
+        const unsigned p = (unsigned)(SCAN * threadIdx.x + r);
+        if (narrow) {
+          buf32[slot] = ((key[r] - lo) << 11) | slot;
+          selpos[slot] = (unsigned short)p;
+        } else {
+          buf[slot] = ((unsigned long long)key[r] << 14) | p;
+        }
+        ++slot;
+      }
+  }
+  __syncthreads();
+  CLID_STAMP(4);
+  unsigned p0, p1;  // positions (in the segment) of the elements of rank 2 t and 2 t + 1 of this block
+  if (narrow) {
+    unsigned x0 = buf32[2 * threadIdx.x], x1 = buf32[2 * threadIdx.x + 1];
+    bitonic_sort_m<unsigned>(x0, x1, buf32, m);
+    p0 = selpos[x0 & 0x7FFu];
+    p1 = selpos[x1 & 0x7FFu];
+  } else {
+    unsigned long long x0 = buf[2 * threadIdx.x], x1 = buf[2 * threadIdx.x + 1];
+    bitonic_sort_m<unsigned long long>(x0, x1, buf, m);
+    p0 = (unsigned)(x0 & 0x3FFFu);
+    p1 = (unsigned)(x1 & 0x3FFFu);
+  }
+  CLID_STAMP(5);
+  if (2 * threadIdx.x < m) index_out[e0 + lattice_place(L, n_lat, lower + 2 * threadIdx.x)] = draws[e0 + p0];
+  if (2 * threadIdx.x + 1 < m) index_out[e0 + lattice_place(L, n_lat, lower + 2 * threadIdx.x + 1)] = draws[e0 + p1];
   CLID_STAMP(6);
 }
 #ifdef CLID_TIMING
@@ -1765,6 +1871,10 @@ extern "C" int clid_debug_read_stamps_mapops(long long* out_host) {
 }
 #endif
 
+static int sort_force_wide() {  // CLID_SORT_WIDE=1: the 64-bit composites everywhere (tests: the path of far-apart key clusters)
+  const char* e = getenv("CLID_SORT_WIDE");
+  return (e && e[0] == '1') ? 1 : 0;
+}
 extern "C" int64_t clid_mapping_prep_workspace_bytes(int32_t iters, int32_t bs) {
   const long long n = (long long)iters * bs;
   if (n <= 0) return 256;
@@ -1809,9 +1919,8 @@ extern "C" int clid_mapping_prep(float* zero_base, int64_t zero_floats, int64_t*
   const int full_segs = seg_full_end > seg0 ? seg_full_end - seg0 : 0;
   const int tail_base = seg_full_end * kSortSeg;           // a shorter last segment exists iff the window reaches bs
   const int tail = (c0 + nc) - tail_base;                  // > 0 only then (c0 + nc == bs, bs no multiple of the segment)
-  const int kSortBuckets = (long long)iters * ((bs + kSortSeg - 1) / kSortSeg) <= 16 ? kSortBucketsMany : kSortBucketsFew;  // (by the
-  // CALL's shape, not the shard's: every rank of a data-parallel run takes the same path)
-  const long long sort_blocks = (long long)iters * full_segs * kSortBuckets;
+  const int buckets = sort_buckets_for((long long)iters * ((bs + kSortSeg - 1) / kSortSeg));
+  const long long sort_blocks = (long long)iters * full_segs * buckets;
   const bool sorted = want_sort && n_index > 0 && sort_blocks < (1LL << 31);
   char* ws = static_cast<char*>(sort_workspace);
   const long long n_all = (long long)iters * bs;
@@ -1822,15 +1931,11 @@ extern "C" int clid_mapping_prep(float* zero_base, int64_t zero_floats, int64_t*
   hipLaunchKernelGGL(k_mapping_prep, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<float4*>(zero_base),
                      (long long)(zero_floats / 4), draws, n_index, bs, bs_new, (unsigned long long)pool_count,
                      reinterpret_cast<const long long*>(new_idx), (unsigned long long)n_new, (unsigned long long)seed,
-                     (unsigned long long)counter, pool_coord, resolution, keys, c0, nc > 0 ? nc : 1);
+                     (unsigned long long)counter, pool_coord, resolution, keys, c0, nc > 0 ? nc : 1, (int)decimation);
   if (sorted && full_segs > 0)
   {
-    if (kSortBuckets == kSortBucketsMany)
-      hipLaunchKernelGGL(k_batch_sort_bucket<kSortBucketsMany>, dim3((unsigned)sort_blocks), dim3(kSortThreads), 0, s, draws, keys,
-                         reinterpret_cast<long long*>(index_out), bs, full_segs, seg0, (int)decimation);
-    else
-      hipLaunchKernelGGL(k_batch_sort_bucket<kSortBucketsFew>, dim3((unsigned)sort_blocks), dim3(kSortThreads), 0, s, draws, keys,
-                         reinterpret_cast<long long*>(index_out), bs, full_segs, seg0, (int)decimation);
+    hipLaunchKernelGGL(k_batch_sort_bucket, dim3((unsigned)sort_blocks), dim3(kSortThreads), 0, s, draws, keys,
+                       reinterpret_cast<long long*>(index_out), bs, full_segs, seg0, (int)decimation, buckets, sort_force_wide());
   }
   if (sorted && tail > 0)
     hipLaunchKernelGGL(k_batch_sort_tail, dim3((unsigned)iters), dim3(kSortThreads), 0, s, draws, keys,

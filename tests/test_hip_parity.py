@@ -1012,7 +1012,8 @@ def test_tiny_map_and_empty_inputs(env):
     assert not torch.equal(before, nm.local_geo_features.detach())
 
 
-def test_mapping_prep_resets_and_draws_like_the_host_restatement():
+@pytest.mark.parametrize("wide", [False, True])
+def test_mapping_prep_resets_and_draws_like_the_host_restatement(wide, monkeypatch):
     """clid_mapping_prep: one launch zeroes the loop's workspace and draws [iters, bs] batch indices composed as
     utils/mapper.py:473-500 (history part uniform over the pool, the last bs_new columns picked from new_idx); every
     entry equals the host restatement of the generator; Mapper.mapping uses it and advances the call counter."""
@@ -1020,6 +1021,9 @@ def test_mapping_prep_resets_and_draws_like_the_host_restatement():
 
     from clid_slam_amd import _lib
 
+    # wide: the ordering blocks' 64-bit composites everywhere (the path of key ranges whose kept keys lie more than 2^21 apart;
+    # the default picks per block: 32-bit (key - smallest kept key, slot) composites when they fit)
+    monkeypatch.setenv("CLID_SORT_WIDE", "1" if wide else "0")
     lib = _lib.load()
     dev = "cuda:0"
     iters, bs, bs_new, pool = 7, 1000, 300, 897_123

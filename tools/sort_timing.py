@@ -21,9 +21,9 @@ torch.cuda.synchronize()
 lib = C.CDLL(out)
 buf = (C.c_longlong * (256 * 32))()
 assert lib.clid_debug_read_stamps_mapops(buf) == 0
-a = np.array(buf, dtype=np.int64).reshape(256, 32)[:160]
-names = {0: "start", 1: "samples loaded", 2: "ranked", 3: "scanned + counted", 4: "kept in LDS", 7: "pass 1", 8: "pass 2", 5: "pass 3", 6: "written"}
-keys = [0, 1, 2, 3, 4, 7, 8, 5, 6]
+a = np.array(buf, dtype=np.int64).reshape(256, 32)[:256]
+names = {0: "start", 1: "samples loaded", 2: "ranked", 3: "scanned + counted", 4: "kept in LDS", 5: "ordered (bitonic)", 6: "written"}
+keys = [0, 1, 2, 3, 4, 5, 6]
 prev = None
 for k in keys:
     if prev is not None:
