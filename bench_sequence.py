@@ -309,7 +309,8 @@ def _check_against_oracle(snap, idx, nm, dec, mp, cfg, fid):
         out.update(max_dtheta=float(dth.max()), n_dtheta_gt_1e4=int((dth > 1e-4).sum()), n_dtheta_gt_1e4_bound=n_max,
                    max_ddecoder=max(float((t.detach().cpu() - o).abs().max()) for t, o in zip(dec.flat_params(), recs[-1]["dec"])),
                    max_ddecoder_bound=dec_max,
-                   max_dcert=float((nm.local_point_certainties.cpu() - recs[-1]["certainties"]).abs().max()))
+                   max_dcert=float((nm.local_point_certainties.cpu() - recs[-1]["certainties"]).abs().max()),
+                   cert_scale=float(recs[-1]["certainties"].abs().max()))
     return out
 
 

@@ -791,12 +791,24 @@ extern "C" int clid_track_model_dev(const clid_map_view* mv, const float* W1, co
 
 extern "C" int clid_track_model_call(const clid_track_call* c, const float* rot, const float* pos, int32_t pose_on_device,
                                      double* normal_eq, double* zero_next, double* result, double epoch, void* stream) {
-  if (!c || !rot || !pos || !c->pc_imu || c->N < 0 || (result && !normal_eq)) {
+  if (!c || !rot || !pos || (c->N > 0 && !c->pc_imu) || c->N < 0 || (result && !normal_eq)) {  // (an empty tensor has no storage)
     clid_set_error("clid_track_model_call: bad argument");
     return CLID_E_ARG;
   }
   if (int e = check_view(&c->mv, "clid_track_model_call")) return e;
-  if (c->N == 0) return CLID_OK;
+  if (c->N == 0) {
+    // an empty scan evaluates nothing, but the caller's ring moved on: the buffer the NEXT evaluation accumulates into must still
+    // be cleared (k_track_model does that) and the epoch the host waits for must still be published (k_track_finish over the
+    // all-zero buffer of this evaluation: 28 zero sums, n_valid 0)
+    hipStream_t s0 = (hipStream_t)stream;
+    if (zero_next && hipMemsetAsync(zero_next, 0, sizeof(double) * CLID_TRACK_COPIES * 32, s0) != hipSuccess) {
+      clid_set_error("clid_track_model_call: %s", hipGetErrorString(hipGetLastError()));
+      return CLID_E_HIP;
+    }
+    if (result) hipLaunchKernelGGL(clid::k_track_finish, dim3(1), dim3(64), 0, s0, normal_eq, result, epoch);
+    CLID_CHECK_LAUNCH();
+    return CLID_OK;
+  }
   clid::TrackParams tp;
   for (int i = 0; i < 9; ++i) tp.R[i] = pose_on_device ? 0.f : rot[i];
   for (int i = 0; i < 3; ++i) tp.t[i] = pose_on_device ? 0.f : pos[i];

@@ -1698,7 +1698,11 @@ extern "C" int clid_train_decode(const clid_map_view* mv, const clid_train_args*
       clid_set_error("clid_train_decode: the compact exchange needs the tile decode kernels (certainty increments in the rows)");
       return CLID_E_ARG;
     }
-    if (int e = launch_reduce(mv, &da, ws.partial, nb, n_fd, s)) return e;
+    // the tile kernels' dense-exchange flush adds the block sums to grad[0 .. 833) / loss_out itself (csrc/train_tile.hip
+    // `direct`): nothing left to reduce -- decode -> all-reduce -> Adam, three launches per iteration of the sharded loop
+    const bool direct = variant != 0 && a->eikonal_mode != 2 && !a->decode_each_neighbour && !a->cbuf;
+    if (!direct)
+      if (int e = launch_reduce(mv, &da, ws.partial, nb, n_fd, s)) return e;
   }
   return CLID_OK;
 }

@@ -716,6 +716,26 @@ k_decode_tile(const float4* __restrict__ rec, const int* __restrict__ tnum, int 
 
   CLID_STAMP(12);
   float* out = partial + (size_t)blockIdx.x * kPartialStride;
+  // Sharded runs with the dense exchange (defer_reduce == 0, no compact buffer): the block's sums go STRAIGHT into the buffer the
+  // all-reduce reads -- decoder gradients added to grad[0 .. 833), the two loss sums normalised and added to loss_out -- instead
+  // of into a partial row that a reduction launch between decode and all-reduce would have to add up (one dependent launch less
+  // per iteration; a rank holds 410 / world blocks, so an address sees that many adds).  Adam zeroes grad[0 .. 833) after use.
+  const bool direct = !ta.defer_reduce && !ta.cbuf;
+  auto flush = [&](int i, float v) {
+    if (!direct) {
+      out[i] = v;
+    } else if (i < CLID_MLP_PARAMS) {
+      atomicAdd(ta.grad + i, v);
+    } else if (i == CLID_MLP_PARAMS) {
+      const float bce = v * ta.inv_n_main;
+      atomicAdd(ta.loss_out + 1, bce);
+      atomicAdd(ta.loss_out, bce);
+    } else if (i == CLID_MLP_PARAMS + 1) {
+      const float eik = v * ((ta.eik_mask && ta.eik_inv_n) ? ta.eik_inv_n[ta.touch_iter] : ta.inv_n_eik);
+      atomicAdd(ta.loss_out + 2, eik);
+      atomicAdd(ta.loss_out, ta.weight_e * eik);
+    }
+  };
   if constexpr (BLK) {
     __shared__ float aux[TW][72];  // per wave: dW2 [64] | db2 | bce sum | eikonal sum
     const float bce_w = wave_sum(bce_acc), eik_w = wave_sum(eik_acc);
@@ -753,15 +773,15 @@ k_decode_tile(const float4* __restrict__ rec, const int* __restrict__ tnum, int 
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int h = 16 * wave + 4 * g + rr;
-        if (q < CLID_D) out[h * CLID_D + q] = acc0[rr];
-        else if (q == CLID_D) out[CLID_H * CLID_D + h] = acc0[rr];
+        if (q < CLID_D) flush(h * CLID_D + q, acc0[rr]);
+        else if (q == CLID_D) flush(CLID_H * CLID_D + h, acc0[rr]);
       }
     }
     if (threadIdx.x < CLID_H + 3 && (train || threadIdx.x > CLID_H)) {
       float sacc = 0.f;
 #pragma unroll
       for (int wv = 0; wv < TW; ++wv) sacc += aux[wv][threadIdx.x];
-      out[CLID_H * CLID_D + CLID_H + threadIdx.x] = sacc;  // W2 [64] | b2 | bce | eik: consecutive in the partial row
+      flush(CLID_H * CLID_D + CLID_H + threadIdx.x, sacc);  // W2 [64] | b2 | bce | eik: consecutive in the partial row
     }
   } else {
   __syncthreads();
@@ -791,7 +811,7 @@ k_decode_tile(const float4* __restrict__ rec, const int* __restrict__ tnum, int 
     float s = 0.f;
 #pragma unroll
     for (int wv = 0; wv < TW; ++wv) s += red[wv * kRedFloats + i];
-    out[i] = s;
+    flush(i, s);
   }
   }
   CLID_STAMP(13);

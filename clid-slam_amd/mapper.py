@@ -351,7 +351,7 @@ class Mapper:
             poses = self.used_poses
             if poses is None or poses.dim() != 3 or pipeline != 1:
                 raise NotImplementedError("fused mapping loop: ba_done_flag needs used_poses [frames, 4, 4] and the hoisted schedule")
-            pose34 = poses[:, :3, :].to(device=dev, dtype=torch.float32).contiguous()  # (`.to(points)` of utils/tools.py:624-625)
+            pose34 = self._pose_slab(poses, dev)  # (`.to(points)` of utils/tools.py:624-625)
             keep = (keep, pose34)
             ta.pool_pose, ta.n_pose = pose34.data_ptr(), int(pose34.shape[0])
         ta.pool_coord, ta.pool_label, ta.pool_ts, ta.pool_weight = (
@@ -364,7 +364,7 @@ class Mapper:
             poses = self.used_poses
             if poses is None or poses.dim() != 3:
                 raise NotImplementedError("fused mapping loop: proj_correction_on needs used_poses [frames, 4, 4] (the frames' origins)")
-            fpose = poses[:, :3, :].to(device=dev, dtype=torch.float32).contiguous()
+            fpose = self._pose_slab(poses, dev)
             keep = (keep, fpose)
             ta.proj_correction, ta.frame_pose, ta.n_frame_pose = 1, fpose.data_ptr(), int(fpose.shape[0])
         ta.loss_weight_on, ta.eikonal_mode, ta.train_decoder = int(bool(cfg.loss_weight_on)), eik_mode, int(train_decoder)
@@ -535,6 +535,16 @@ class Mapper:
         self._keep = (keep, index_seq, grad, m, v, m_mlp, v_mlp)
         nm.assign_local_to_global()
 
+    def _pose_slab(self, poses: torch.Tensor, dev) -> torch.Tensor:
+        """used_poses[:, :3, :] as one contiguous fp32 [frames, 12] slab on `dev` (clid_train_args.pool_pose / frame_pose), rebuilt
+        only when the pose tensor changed (storage, in-place version, shape): ba_done_flag / proj_correction calls of one frame
+        share it."""
+        key = (poses.data_ptr(), poses._version, tuple(poses.shape), str(poses.dtype), str(dev))
+        hit = self.__dict__.get("_pose_slab_cache")
+        if hit is None or hit[0] != key:
+            hit = self._pose_slab_cache = (key, poses[:, :3, :].to(device=dev, dtype=torch.float32).contiguous())
+        return hit[1]
+
     def _consistency_loop(self, lib, view, ta, aa, iter_count, index_seq, bs, losses, dev, stream):
         """config.consistency_loss_on (utils/mapper.py:716-741, 770-776; "[not used]" there): per iteration a second batch of
         min(consistency_count, bs) randomly shifted copies of drawn samples is searched and both batches run the analytic iteration
@@ -567,6 +577,9 @@ class Mapper:
         nb_main = int(lib.clid_train_partial_rows(C.byref(ta)))
         nb_near = int(lib.clid_train_partial_rows(C.byref(tn)))
         draws = getattr(self, "_consistency_draws", None)
+        if draws is not None and len(draws) < iter_count:  # (checked before the first Adam step: a short list must not stop the loop midway)
+            raise ValueError(f"_consistency_draws holds {len(draws)} iterations, the call runs {iter_count} "
+                             "(iter_count + adaptive_iter_offset)")
         pool = self.global_coord_pool
         for it in range(iter_count):
             index = index_seq[it]

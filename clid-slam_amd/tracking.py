@@ -124,8 +124,7 @@ class BoundTrackModel:
         _lib.check(lib.clid_track_valid_count(self.out["valid"].data_ptr(), self.n, self._blk.data_ptr(), sh["res_dev"], epoch, _lib.stream()),
                    "clid_track_valid_count")
         res = sh["res"]
-        while res[31] != epoch:
-            pass
+        _wait_epoch(res, epoch, self.dev)
         nv = int(res[29])
         dev = self.dev
         z = torch.empty(nv, device=dev, dtype=torch.float64)
@@ -143,12 +142,30 @@ class BoundTrackModel:
         """The 28 sums of the last `launch(..., reduce=True, result=True)` as a float64 numpy array (polls the pinned block)."""
         sh = self._shared
         res, epoch = sh["res"], sh["epoch"]
-        while res[31] != epoch:
-            pass
+        _wait_epoch(res, epoch, self.dev)
         return res[:28].copy()
 
 
 import os as _os
+import time as _time
+
+
+def _wait_epoch(res, epoch: float, dev, spin: int = 20000, timeout_s: float = 30.0):
+    """Poll the pinned result block for `epoch` (written by the finish launch behind a system-scope fence).  The wait is
+    bounded: after `spin` empty polls the stream is synchronised -- a faulted device or a rejected launch then raises from
+    torch instead of spinning forever -- and an epoch that still has not arrived after that (a launch that never went out) is an
+    error.  One host thread per device drives the tracking model (the ring cursor, the epoch and the pinned block are
+    per-device state without a lock)."""
+    for _ in range(spin):
+        if res[31] == epoch:
+            return
+    torch.cuda.synchronize(dev)  # surfaces device-side errors
+    t0 = _time.perf_counter()
+    while res[31] != epoch:
+        if _time.perf_counter() - t0 > timeout_s:
+            raise RuntimeError(f"tracking model: result epoch {epoch} never arrived (pinned block holds {float(res[31])}); "
+                               "was the evaluation enqueued on this device's stream?")
+
 
 _FUSED_ROWS = _os.environ.get("CLID_TRACK_ROWS", "1") != "0"  # h_model's outputs compacted on the device (0: the torch glue, A/B)
 _SHARED = {}   # per device: reduction ring + pinned result block
@@ -161,7 +178,11 @@ def bind(neural_points, geo_decoder, config, pc_imu) -> BoundTrackModel:
     theta = neural_points.local_geo_features
     key = (id(pc_imu), pc_imu.data_ptr(), pc_imu._version, tuple(pc_imu.shape), neural_points._map_version, int(neural_points.cur_ts),
            id(neural_points.travel_dist), theta.data_ptr(), id(geo_decoder), id(neural_points.global2local),
-           float(config.reg_min_grad_norm), float(config.reg_max_grad_norm), int(config.track_mask_query_nn_k))
+           float(config.reg_min_grad_norm), float(config.reg_max_grad_norm), int(config.track_mask_query_nn_k),
+           # everything else the argument block bakes in: the decoder's parameter storage (re-allocated by .to() / assignment),
+           # its output scale and the sdf-std threshold
+           tuple(p.data_ptr() for p in geo_decoder.flat_params()), float(geo_decoder.sdf_scale),
+           float(config.surface_sample_range_m * getattr(config, "max_sdf_std_ratio", 1.0)))
     hit = _BOUND.get(id(neural_points))
     if hit is not None and hit[0] == key and hit[1]() is pc_imu and hit[3]() is neural_points:
         return hit[2]

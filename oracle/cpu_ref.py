@@ -185,9 +185,47 @@ def query_certainty(st: MapState, query_points: torch.Tensor):
 # --------------------------------------------------------------------------------------------------
 # a4: decoder
 # --------------------------------------------------------------------------------------------------
+# Checker aid for BASELINE.json configs[2] (no reference counterpart: the reference has no reduced-precision mode).  None = the
+# reference's fp32 decoder.  A dict switches layer 1 of `mlp_sdf` to the arithmetic the bf16 instantiation of the tile decode
+# kernel performs (clid-slam_amd/csrc/train_tile.hip PREC = 1), so that the HIP bf16 path is compared with the VALUES bf16
+# operand rounding produces -- at fp32 summation-order tolerance -- instead of with the fp32 oracle at a bar widened by a guess:
+#   forward   pre = bf16(W1) bf16(f) + b1      operands rounded to nearest-even bf16, products and sums fp32 (the bias rides as
+#                                              hi + lo parts: exact to 2^-17)
+#   backward  d f = bf16(dh) bf16(W1)          dh = dL/dpre in fp32, rounded as the MFMA operand
+#             dW1 = bf16(dh)^T bf16(f), db1 = sum bf16(dh)   ("dW1": True, what the bf16 instantiations do at every launch size;
+#                                              False: contracted in fp32 from the unrounded values)
+#   layer 2 (64 in-lane FMAs), the loss and everything outside the three contractions stay fp32 on both sides.
+BF16_CONTRACTIONS = None
+
+
+def _bf16(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+class _Bf16Layer1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f, W1, b1, round_dw1):
+        fb, Wb = _bf16(f), _bf16(W1)
+        ctx.save_for_backward(f, fb, Wb)
+        ctx.round_dw1 = bool(round_dw1)
+        return F.linear(fb, Wb) + b1
+
+    @staticmethod
+    def backward(ctx, g):
+        f, fb, Wb = ctx.saved_tensors
+        gb = _bf16(g)
+        df = gb @ Wb
+        g2 = (gb if ctx.round_dw1 else g).reshape(-1, g.shape[-1])
+        f2 = (fb if ctx.round_dw1 else f).reshape(-1, f.shape[-1])
+        return df, g2.t() @ f2, g2.sum(dim=0), None
+
+
 def mlp_sdf(dec: DecoderParams, features: torch.Tensor) -> torch.Tensor:
     """model/decoder.py:58-82: sdf = scale * (W2 relu(W1 f + b1) + b2), squeezed over dim 1."""
-    h = F.relu(F.linear(features, dec.W1, dec.b1))
+    if BF16_CONTRACTIONS is not None:
+        h = F.relu(_Bf16Layer1.apply(features, dec.W1, dec.b1, BF16_CONTRACTIONS.get("dW1", True)))
+    else:
+        h = F.relu(F.linear(features, dec.W1, dec.b1))
     return F.linear(h, dec.W2, dec.b2).squeeze(1) * dec.sdf_scale
 
 
@@ -512,7 +550,7 @@ def relu_ambiguous_rows(st: MapState, dec: DecoderParams, pool: SamplePool, inde
             idx_q = idx.reshape(-1, 1)
         else:
             idx_q = idx
-        pre = F.linear(f, dec.W1, dec.b1)
+        pre = F.linear(f, dec.W1, dec.b1) if BF16_CONTRACTIONS is None else F.linear(_bf16(f), _bf16(dec.W1)) + dec.b1
         amb_u = pre.abs() < tau
         amb = amb_u.any(dim=1)
         rows = idx_q[amb].reshape(-1)

@@ -23,6 +23,11 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get("CLID_REFERENCE", "/root/reference")
 OUT = os.path.join(ROOT, "tests", "golden")
+# `--fresh DIR --seed N`: the G1-G6 set (state, pool, search, query, mlp, gradient, loss, EVERY mapping-loop branch) on ANOTHER scene
+# with other draws -- every seed of main() / build_scene() shifted by N -- written to DIR, for an out-of-fixture comparison of
+# the oracle with the reference (tests/test_oracle_golden.py runs its G1-G6 tests on such a directory when /root/reference is
+# present).  N = 0 is the committed set, bit for bit.
+SEED = 0
 
 
 class _Stub(types.ModuleType):
@@ -74,14 +79,14 @@ def build_scene(ref, cfg, feature_seed=7):
     import clid_slam_amd  # noqa: F401  (alias -> clid-slam_amd/)
     from clid_slam_amd.synth import box_room_pool
 
-    torch.manual_seed(42)
+    torch.manual_seed(42 + SEED)
     np_map = ref.NeuralPoints(cfg)
     sensors = [(0.0, 0.0, 1.5), (6.0, 2.0, 1.5), (9.0, 3.0, 1.6)]
     travel = torch.tensor([0.0, 400.0, 403.5], dtype=torch.float32)
     np_map.travel_dist = travel
     pools = []
     for fid, s in enumerate(sensors):
-        d = box_room_pool(cfg, n_elev=32, n_azim=256, seed=42 + fid, sensor=s)
+        d = box_room_pool(cfg, n_elev=32, n_azim=256, seed=42 + fid + SEED, sensor=s)
         near = d["sdf_label"].abs() < cfg.surface_sample_range_m * 0.5
         np_map.update(d["coord"][near], d["sensor"], torch.eye(3), fid)
         d["time"] = torch.full((d["coord"].shape[0],), fid, dtype=torch.int32)
@@ -89,7 +94,7 @@ def build_scene(ref, cfg, feature_seed=7):
     # shrink the local window so that global2local has -1 entries; rebuild the local map
     np_map.local_map_radius = 12.0
     np_map.reset_local_map(pools[-1]["sensor"], torch.eye(3), 2, reboot_map=True)
-    g = torch.Generator().manual_seed(feature_seed)
+    g = torch.Generator().manual_seed(feature_seed + SEED)
     np_map.geo_features = 0.3 * torch.randn(np_map.geo_features.shape, generator=g)
     np_map.point_certainties = torch.rand(np_map.point_certainties.shape, generator=g) * 3.0
     np_map.reset_local_map(pools[-1]["sensor"], torch.eye(3), 2, reboot_map=True)
@@ -137,7 +142,7 @@ def state_arrays(nm, dec=None):
 
 
 def query_points(pool, n, seed):
-    g = torch.Generator().manual_seed(seed)
+    g = torch.Generator().manual_seed(seed + SEED)
     pick = torch.randint(0, pool["coord"].shape[0], (n,), generator=g)
     x = pool["coord"][pick].clone()
     ts = pool["time"][pick].clone()
@@ -161,7 +166,7 @@ def main():
     ref = import_reference()
     cfg = ref_config(ref)
     nm, pool = build_scene(ref, cfg)
-    torch.manual_seed(42)
+    torch.manual_seed(42 + SEED)
     dec = ref.Decoder(cfg, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, 1)
     print("map: global", nm.count(), "local", nm.local_count(), "pool", pool["coord"].shape[0])
     np.savez_compressed(os.path.join(OUT, "state.npz"), **state_arrays(nm, dec))
@@ -205,7 +210,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "g2_query.npz"), **g2)
 
     # ---------------- G3 mlp
-    g = torch.Generator().manual_seed(3)
+    g = torch.Generator().manual_seed(3 + SEED)
     f3 = torch.randn(1024, 11, generator=g)
     with torch.no_grad():
         sdf3 = dec.sdf(f3)
@@ -227,7 +232,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "g4_grad.npz"), **g4)
 
     # ---------------- G5 loss
-    g = torch.Generator().manual_seed(5)
+    g = torch.Generator().manual_seed(5 + SEED)
     pred = (torch.randn(4096, generator=g) * 0.2).requires_grad_(True)
     label = torch.randn(4096, generator=g) * 0.3
     wt = torch.rand(4096, generator=g) * 0.8 + 0.6
@@ -305,7 +310,7 @@ def main():
                 nm.point_certainties = base_state["cert"].clone()
                 nm.point_ts_update = base_state["tsu"].clone()
                 nm.reset_local_map(sensor, torch.eye(3), 2, reboot_map=True)
-                torch.manual_seed(42)
+                torch.manual_seed(42 + SEED)
                 dec6 = ref.Decoder(cfg6, cfg6.geo_mlp_hidden_dim, cfg6.geo_mlp_level, 1)
                 if frozen:
                     ref.freeze_model(dec6)
@@ -325,7 +330,7 @@ def main():
                 if ba:
                     # three non-trivial frame poses; the sensor-frame pool is what maps onto the scene through them (fp32
                     # rounding apart), the world-frame pool is stale (as after a bundle adjustment) and must not be read
-                    gp = torch.Generator().manual_seed(23)
+                    gp = torch.Generator().manual_seed(23 + SEED)
                     ang = (torch.rand(3, 3, generator=gp, dtype=torch.float64) - 0.5) * 0.6
                     poses = torch.eye(4, dtype=torch.float64)[None].repeat(3, 1, 1)
                     for fi in range(3):
@@ -343,7 +348,7 @@ def main():
                     mp.ba_done_flag = True
                 mp.adaptive_iter_offset = 0
                 new_start = mp.pool_sample_count - mp.cur_sample_count
-                gnew = torch.Generator().manual_seed(11)
+                gnew = torch.Generator().manual_seed(11 + SEED)
                 mp.new_idx = new_start + torch.randperm(mp.cur_sample_count, generator=gnew)[:5000]
 
                 # record the reference's own random draws and batches
@@ -431,7 +436,7 @@ def main():
                 torch.Tensor.backward = rec_backward
                 torch.randint = rec_randint
                 torch.rand_like = rec_rand_like
-                torch.manual_seed(1234)
+                torch.manual_seed(1234 + SEED)
                 try:
                     mp.mapping(ITERS)
                 finally:
@@ -466,7 +471,7 @@ def main():
                     out["cons_near_index"] = torch.stack([draws[3 * it + 2] for it in range(ITERS)]).to(torch.int32).numpy()
                     out["cons_shift"] = torch.stack([sh * 2 * cfg6.consistency_range - cfg6.consistency_range for sh in shifts]).numpy()
                     out["cons_weight_c"] = np.float64(cfg6.weight_c)
-                torch.manual_seed(42)
+                torch.manual_seed(42 + SEED)
                 dec_init = ref.Decoder(cfg6, cfg6.geo_mlp_hidden_dim, cfg6.geo_mlp_level, 1)
                 out.pop("W1_init")
                 for nme, p in zip(("W1", "b1", "W2", "b2"), dec_init.parameters()):
@@ -873,7 +878,13 @@ if __name__ == "__main__":
     only = {"--only-g11": map_maintenance_fixture, "--only-g9": sampler_fixture, "--only-g8": tracking_fixture,
             "--only-g7": map_build_fixture, "--only-g12": mesher_fixture, "--only-g13": config_fixture}
     picked = [f for flag, f in only.items() if flag in sys.argv]
-    if "--check" in sys.argv:
+    if "--fresh" in sys.argv:
+        SEED = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 1
+        OUT = sys.argv[sys.argv.index("--fresh") + 1]
+        os.makedirs(OUT, exist_ok=True)
+        torch.set_num_threads(1)
+        main()
+    elif "--check" in sys.argv:
         sys.exit(check())
     elif picked:
         os.makedirs(OUT, exist_ok=True)

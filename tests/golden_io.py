@@ -7,7 +7,9 @@ import torch
 
 from oracle import cpu_ref as O
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# (CLID_GOLDEN_DIR: another directory of reference-generated fixtures -- `oracle/make_golden.py --fresh DIR --seed N`; the
+# out-of-fixture run of tests/test_oracle_golden.py)
+GOLDEN = os.environ.get("CLID_GOLDEN_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def load(name):

@@ -25,6 +25,14 @@ def maxerr(a, b):
     return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()) if a.size else 0.0
 
 
+def cert_close(got, want, rel=1e-5):
+    """Certainties are sums of IDW weights over every query pass that touched the row (model/neural_points.py:714): they grow
+    with batch size x iterations, and two fp32 summation orders differ by a few ulp of the SUM.  Compared at 1e-5 of the
+    largest certainty (>= 1), the form tests/test_tile_decode.py uses -- not at an absolute figure chosen per test."""
+    want_t = torch.as_tensor(want).detach().cpu().double()
+    return maxerr(got, want) <= rel * max(1.0, float(want_t.abs().max()))
+
+
 @pytest.mark.parametrize("tf", [False, True])
 def test_radius_search_g1(env, tf):
     g = gio.load("g1_search.npz")
@@ -298,7 +306,7 @@ def test_mapping_loop_g6(env, mode, frozen, ln, add_to="all", loss_type="bce", b
     assert maxerr(nm.local_geo_features, g[f"it{last}_theta"]) <= 1e-4
     for n, t in zip(("W1", "b1", "W2", "b2"), dec.flat_params()):
         assert maxerr(t, g[f"it{last}_{n}"]) <= 1e-4, n
-    assert maxerr(nm.local_point_certainties, g[f"it{last}_certainties"]) <= 1e-3
+    assert cert_close(nm.local_point_certainties, g[f"it{last}_certainties"])
     assert np.array_equal(nm.local_point_ts_update.cpu().numpy(), g[f"it{last}_ts_update"])
     # rows the reference never touched keep their exact initial value
     init = gio.T(p["base_geo_features"])[gio.T(g["local_mask"])]
@@ -310,7 +318,7 @@ def test_mapping_loop_g6(env, mode, frozen, ln, add_to="all", loss_type="bce", b
     base = p["base_geo_features"].copy()
     base[g["final_geo_rows"].astype(np.int64)] = g["final_geo_vals"]
     assert maxerr(nm.geo_features, base) <= 1e-4
-    assert maxerr(nm.point_certainties, g["final_point_certainties"]) <= 1e-3
+    assert cert_close(nm.point_certainties, g["final_point_certainties"])
     assert np.array_equal(nm.point_ts_update.cpu().numpy(), g["final_point_ts_update"])
 
 
@@ -434,7 +442,7 @@ def test_fused_iteration_gradients_vs_reference(env):
     untouched = np.ones(gt.shape[0], bool)
     untouched[rows] = False
     assert not gt[untouched].any()  # exact zeros stay exact (Adam eps = 1e-15 would amplify anything else)
-    assert maxerr(cert, g["it0_certainties"]) <= 1e-3
+    assert cert_close(cert, g["it0_certainties"])
     assert np.array_equal(ts.numpy(), g["it0_ts_update"])
 
 
@@ -467,7 +475,7 @@ def test_sharded_gradients_sum_to_the_full_batch(env, parts):
     scale = float(full.abs().max())
     assert float((acc - full).abs().max()) <= 2e-5 * scale
     assert float((loss - loss_full).abs().max()) <= 2e-6
-    assert float((cert - (cert_full - cert0)).abs().max()) <= 2e-3
+    assert cert_close(cert, cert_full - cert0)
     assert torch.equal(ts, ts_full)
 
 
@@ -532,7 +540,7 @@ def test_mapping_loop_vs_oracle_free_batches(env, mode, ln):
     assert maxerr(nm.local_geo_features, recs[-1]["theta"]) <= 1e-4
     for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
         assert maxerr(t, o) <= 1e-4
-    assert maxerr(nm.local_point_certainties, recs[-1]["certainties"]) <= 2e-3
+    assert cert_close(nm.local_point_certainties, recs[-1]["certainties"])
 
 
 @pytest.mark.parametrize("branch,ln", [("wf0_analytic", 0), ("wf0_analytic", 1), ("proj", 1), ("proj_no_eik", 0), ("cons", 1),
@@ -617,7 +625,7 @@ def test_loop_branches_vs_oracle_on_fresh_batches(env, branch, ln):
     assert maxerr(nm.local_geo_features, recs[-1]["theta"]) <= 1e-4
     for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
         assert maxerr(t, o) <= 1e-4
-    assert maxerr(nm.local_point_certainties, recs[-1]["certainties"]) <= 2e-3
+    assert cert_close(nm.local_point_certainties, recs[-1]["certainties"])
     assert np.array_equal(nm.local_point_ts_update.cpu().numpy(), recs[-1]["ts_update"].numpy())
 
 
@@ -657,7 +665,7 @@ def test_mapping_weighted_first_false_vs_oracle(env, pipeline, ln, eik, train):
     assert maxerr(nm.local_geo_features, recs[-1]["theta"]) <= 1e-4
     for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
         assert maxerr(t, o) <= (1e-4 if train else 0.0)
-    assert maxerr(nm.local_point_certainties, recs[-1]["certainties"]) <= 2e-3
+    assert cert_close(nm.local_point_certainties, recs[-1]["certainties"])
     assert torch.equal(nm.local_point_ts_update.cpu(), st.local_point_ts_update)
 
 
@@ -699,7 +707,7 @@ def test_default_buffer_size_scene_vs_oracle(env):
     assert maxerr(nm.local_geo_features, recs[-1]["theta"]) <= 1e-4
     for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
         assert maxerr(t, o) <= 1e-4
-    assert maxerr(nm.local_point_certainties, recs[-1]["certainties"]) <= 5e-3
+    assert cert_close(nm.local_point_certainties, recs[-1]["certainties"])
 
 
 @pytest.mark.parametrize("bs", [65536, 262144])
@@ -754,6 +762,29 @@ def test_tracking_measurement_model_g8(env, ln, wf):
     assert np.abs(S[:6, :6].cpu().numpy() - S_ref).max() <= 2e-4 * np.abs(S_ref).max()
     assert np.abs(b[:6].cpu().numpy() - b_ref).max() <= 2e-4 * max(np.abs(b_ref).max(), 1e-9)
     assert float(S[6:, :].abs().max()) == 0.0 and float(S[:, 6:].abs().max()) == 0.0
+
+
+def test_tracking_model_on_an_empty_scan_keeps_the_reduction_ring_consistent(env):
+    """A scan without points: `normal_equations` returns zeros and n_valid 0 instead of waiting for an epoch nobody
+    publishes, and the evaluations around it are unaffected -- the ring buffer the NEXT evaluation accumulates into is still
+    cleared by the empty one (the reference's h_model on an empty tensor returns empty outputs, utils/error_state_iekf.py:176)."""
+    from clid_slam_amd import tracking
+
+    g = gio.load("g8_tracking.npz")
+    cfg = env.config(layer_norm_on=False)
+    cfg.reg_min_grad_norm, cfg.reg_max_grad_norm = float(g["grad_window"][0]), float(g["grad_window"][1])
+    nm, dec = env.neural_points(cfg), env.decoder(cfg)
+    rot, pos, pc = gio.T(g["rot"]), gio.T(g["pos"]), gio.T(g["pc_imu"]).cuda()
+    empty = torch.empty((0, 3), device="cuda:0")
+    S0, b0, n0 = tracking.normal_equations(nm, dec, cfg, rot, pos, pc)
+    for _ in range(4):  # more evaluations than the ring has buffers, empty and full interleaved
+        Se, be, ne = tracking.normal_equations(nm, dec, cfg, rot, pos, empty)
+        assert ne == 0 and float(Se.abs().max()) == 0.0 and float(be.abs().max()) == 0.0
+        S1, b1, n1 = tracking.normal_equations(nm, dec, cfg, rot, pos, pc)
+        # (float64 atomics: two evaluations differ in the last bits; a buffer that had not been cleared would double the sums)
+        assert n1 == n0 and torch.allclose(S1, S0, rtol=1e-10, atol=0.0) and torch.allclose(b1, b0, rtol=1e-10, atol=1e-14)
+    z, H, vp, r_inv = tracking.h_model(nm, dec, cfg, rot, pos, empty)
+    assert z.shape == (0,) and H.shape == (0, 18) and vp.shape == (0, 3) and r_inv.shape == (0,)
 
 
 def test_iekfom_h_model_method_form_g8(env):
@@ -965,7 +996,7 @@ def test_mapping_loop_configuration_sweep_vs_oracle(env, bs, decim, nnc, alpha, 
     assert maxerr(nm.local_geo_features, recs[-1]["theta"]) <= 1e-4
     for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
         assert maxerr(t, o) <= 1e-4
-    assert maxerr(nm.local_point_certainties, recs[-1]["certainties"]) <= 2e-3
+    assert cert_close(nm.local_point_certainties, recs[-1]["certainties"])
     assert torch.equal(nm.local_point_ts_update.cpu(), recs[-1]["ts_update"])
 
 

@@ -310,3 +310,34 @@ def test_relu_kink_row_bound_holds_for_forced_gates(ln, tau, monkeypatch):
         moved = max(moved, float(d[kink].max()) / gmax)
     assert moved > 1e-4  # the forced gates really moved listed rows beyond the strict bar (the bound is doing work)
     assert moved_dec > 1e-5
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference"), reason="needs the reference tree (build container only)")
+@pytest.mark.parametrize("seed", [101, 977])
+def test_oracle_matches_the_reference_out_of_fixture(seed, tmp_path):
+    """Beyond the committed vectors: the reference itself is run HERE on another scene with other draws (every seed of
+    oracle/make_golden.py's G1-G6 generation shifted by `seed`: map, features, queries, decoder, batches, new-sample picks,
+    consistency draws, BA poses) and the oracle's G1-G6 tests -- search bit-exact, query, mlp, gradient, loss, and EVERY branch of
+    the mapping loop (17 G6 cases) -- run against that directory instead of tests/golden.  An oracle that had been fitted to the
+    committed fixtures rather than to utils/mapper.py:642-836 would fail here.  (The GPU box has no reference: skipped there.)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = str(tmp_path / "fresh")
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "make_golden.py"), "--fresh", out, "--seed", str(seed)],
+                       capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    committed = np.load(os.path.join(root, "tests", "golden", "g6_loop_numerical_train_ln0.npz"))
+    fresh = np.load(os.path.join(out, "g6_loop_numerical_train_ln0.npz"))
+    assert not np.array_equal(committed["index_seq"], fresh["index_seq"])  # really other draws
+    assert not np.array_equal(np.load(os.path.join(root, "tests", "golden", "state.npz"))["geo_features"],
+                              np.load(os.path.join(out, "state.npz"))["geo_features"])  # ... on another map
+    env["CLID_GOLDEN_DIR"] = out
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_oracle_golden.py"), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "test_search_neighborhood_table or test_g1 or test_g2 or test_g3 or test_g4 or test_g5 or test_g6"],
+                       capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
+    assert " passed" in r.stdout and "failed" not in r.stdout

@@ -87,7 +87,7 @@ def test_multi_frame_mapping_tracks_the_oracle(layer_norm):
         assert float(err.max()) <= cfg.lr * iters * 1.01, (fid, float(err.max()))  # (entries the oracle's mask names: bounded by lr * iters)
         for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
             assert float((t.detach().cpu() - o).abs().max()) <= 1e-4
-        assert float((nm.local_point_certainties.cpu() - recs[-1]["certainties"]).abs().max()) <= 2e-3
+        assert float((nm.local_point_certainties.cpu() - recs[-1]["certainties"]).abs().max()) <= 1e-5 * max(1.0, float(recs[-1]["certainties"].abs().max()))
         assert torch.equal(nm.local_point_ts_update.cpu(), recs[-1]["ts_update"])
         sizes.append((nm.count(), nm.local_count()))
     # the scenario really moved the window and grew the map
@@ -137,10 +137,14 @@ def test_subt_sequence_harness_first_frames_vs_oracle(freeze_after):
         if "max_dtheta" in c:
             # free-running parameters after the call: Adam with eps = 1e-15 moves an entry whose gradient is cancellation
             # residue by up to lr * iters differently in ANY two correct summation orders, so only that hard bound gates;
-            # the count of drifting entries against the oracle-vs-oracle calibration (bench_sequence.chaos_bounds) is
-            # reported in the check record, the teacher-forced gradients above are what decides
+            # the teacher-forced gradients above are what decides
             assert c["max_dtheta"] <= cfg.lr * c["iters"] * 1.01, c
-            assert c["max_dcert"] <= 5e-2, c
+            # ... and HOW MANY entries drift is pinned on the committed oracle-vs-oracle calibration (bench_sequence.chaos_bounds:
+            # 4 x the fraction two summation orders of the oracle itself differ by at this iteration count), the decoder likewise
+            assert c["n_dtheta_gt_1e4"] <= c["n_dtheta_gt_1e4_bound"], c
+            assert c["max_ddecoder"] <= (c["max_ddecoder_bound"] if not c["frozen"] else 0.0), c
+            # certainties do not depend on the parameters: fp32 summation order only (1e-5 of the largest sum)
+            assert c["max_dcert"] <= 1e-5 * max(1.0, c["cert_scale"]), c
 
 
 def test_chaos_calibration_file_is_what_the_bounds_use():
@@ -221,5 +225,5 @@ def test_large_local_map_tracks_the_oracle(layer_norm):
     assert float(err[~noise].max()) <= 1e-4 and float(err.max()) <= cfg.lr * iters * 1.01  # (only entries the oracle's mask names may differ)
     for t, o in zip(dec.flat_params(), recs[-1]["dec"]):
         assert float((t.detach().cpu() - o).abs().max()) <= 1e-4
-    assert float((nm.local_point_certainties.cpu() - recs[-1]["certainties"]).abs().max()) <= 2e-3
+    assert float((nm.local_point_certainties.cpu() - recs[-1]["certainties"]).abs().max()) <= 1e-5 * max(1.0, float(recs[-1]["certainties"].abs().max()))
     assert torch.equal(nm.local_point_ts_update.cpu(), recs[-1]["ts_update"])

@@ -83,7 +83,7 @@ def test_tile_fp32_gradients_vs_reference(env):
     untouched = np.ones(gt.shape[0], bool)
     untouched[rows] = False
     assert not gt[untouched].any()
-    assert maxerr(cert, g["it0_certainties"]) <= 1e-3
+    assert maxerr(cert, g["it0_certainties"]) <= 1e-5 * max(1.0, float(np.abs(g["it0_certainties"]).max()))
     assert np.array_equal(ts.numpy(), g["it0_ts_update"])
 
 
@@ -266,3 +266,65 @@ def test_tile_vs_oracle_at_262144_samples(env, variant, ln):
         assert excess <= 1e-4 and ddec <= 1e-4
     else:
         assert 1e-7 < err <= 3e-3 and dl <= 5e-3
+
+
+@pytest.mark.parametrize("bs,ln", [(65536, False), (65536, True), (4096, False)])
+def test_bf16_tile_against_the_oracle_with_bf16_contractions(env, bs, ln, monkeypatch):
+    """BASELINE.json configs[2] against the VALUES its arithmetic defines, not against the fp32 oracle at a widened bar: the
+    oracle's decoder layer 1 is switched to the bf16 instantiation's contractions (oracle.cpu_ref.BF16_CONTRACTIONS: operands
+    rounded to nearest-even bf16, fp32 products and sums; forward pre-activations, d f = bf16(dh) bf16(W1),
+    dW1 = bf16(dh)^T bf16(f), db1 = sum bf16(dh)), everything else fp32 as in the kernel.  What is left between the two sides is fp32 summation order plus operands that sit within an ulp of a bf16 rounding
+    boundary (a handful per launch, each worth 2^-8 of ONE product): SDF of every query point, the loss, every entry of the
+    feature-table gradient (rows on the ReLU kink at the strict bar + the oracle's own per-row bound, as in the fp32 tests; rows
+    nobody gathers exactly zero) and of the decoder gradient (the float64 run of the same bf16 arithmetic arbitrates the long
+    sums).  Also printed: the distance of both to the fp32 oracle -- what bf16 costs (outside north_star's 1e-4, SURVEY hard
+    part 5)."""
+    from clid_slam_amd import _lib
+
+    p, g, cfg, index = _inputs(env, bs, seed=9, ln=ln)
+    out = []
+    grad, loss, cert, ts = _fused_grads(env, cfg, p, g, index, split=True, variant=2, sdf_out=out)
+    rec, sdf = out[0]
+    assert (rec.shape[0] > 2 * 2048) == (bs >= 65536)  # tasks: 65 536 samples run the launch of several tiles per wave
+    live, ref32 = _oracle_sdf(rec, g, ln)
+    # (the bf16 instantiations contract dW1 / db1 per wave on the bf16 MFMA at every launch size: the fp32 block-level
+    # contraction of the one-tile-per-wave launches is an fp32-only instantiation, csrc/train_tile.hip BLK)
+    monkeypatch.setattr(O, "BF16_CONTRACTIONS", {"dW1": True})
+    _, ref16 = _oracle_sdf(rec, g, ln)
+    err16, err32 = float((sdf[live] - ref16).abs().max()), float((sdf[live] - ref32).abs().max())
+
+    def state(double=False):
+        st = gio.map_state()
+        st.layer_norm_on = bool(ln)
+        st.local_geo_features = gio.T(gio.load("pool.npz")["base_geo_features"])[gio.T(gio.load("state.npz")["local_mask"])].clone()
+        return gio.as_double(st) if double else st
+
+    idx64 = index.to(torch.int64)
+    lc = O.LoopConfig()
+    st, dec, pool = state(), gio.decoder(g, "init_"), gio.sample_pool()[0]
+    rows, nq, slack, gathered, dec_slack = O.relu_ambiguous_rows(st, dec, pool, idx64, lc, 4e-6, with_slack=True)
+    o = O.loss_and_grads(st, dec, pool, idx64, lc)
+    dl = abs(float(loss[0]) - float(o["loss"]))
+    gt = grad[_lib.GRAD_FEAT_OFFSET:].view(-1, 8)
+    g0 = o["grad_theta"]
+    gmax = float(g0.abs().max())
+    d = (gt - g0).abs().max(1).values
+    excess = float((d - 1.25 * slack).max()) / gmax
+    H, D = _lib.H, _lib.D
+    # (float64 accumulation of the SAME rounded operands: _bf16 rounds through bfloat16 whatever the carrier type)
+    o64 = O.loss_and_grads(state(True), gio.as_double(gio.decoder(g, "init_")), gio.as_double(gio.sample_pool()[0]), idx64, lc)
+    gd = torch.cat([o64["grad_" + n].reshape(-1) for n in ("W1", "b1", "W2", "b2")])
+    ddec = float(((grad[: H * D + 2 * H + 1].double() - gd).abs() - 1.25 * dec_slack.double()).max()) / float(gd.abs().max())
+    monkeypatch.setattr(O, "BF16_CONTRACTIONS", None)
+    o32 = O.loss_and_grads(state(), gio.decoder(g, "init_"), gio.sample_pool()[0], idx64, lc)
+    cost_theta = float((g0 - o32["grad_theta"]).abs().max()) / gmax
+    print(f"\n[bf16 tile decode, bs {bs}, layer norm {ln}] vs the oracle WITH bf16 contractions: max|dSDF| {err16:.2e} over {int(live.sum())} "
+          f"query points, dloss {dl:.2e}, grad theta rel {float(d.max()) / gmax:.2e} (beyond the kink bound {excess:.2e}; {len(rows)} rows of "
+          f"{nq} queries listed), decoder grad rel {ddec:.2e}  ||  what bf16 costs against the fp32 oracle: max|dSDF| {err32:.2e}, "
+          f"grad theta rel {cost_theta:.2e}, dloss {abs(float(o['loss']) - float(o32['loss'])):.2e}")
+    assert not bool((gt != 0).any(1)[~gathered].any())
+    assert err32 > 1e-7  # (the bf16 kernel really ran)
+    # an operand within an fp32 ulp of a bf16 rounding boundary rounds the other way on one side: 2^-8 of one of the 11 products of
+    # one pre-activation, i.e. <= sdf_scale |W2_h| 2^-8 |W1_hc f_c| on that query's SDF -- a few 1e-5 at these magnitudes
+    assert err16 <= 1e-4 and dl <= 5e-6
+    assert excess <= 2e-4 and ddec <= 2e-4
