@@ -66,6 +66,8 @@ class TrainArgs(C.Structure):
         ("proj_correction", _i32), ("n_frame_pose", _i32), ("frame_pose", _vp),
         # config.consistency_loss_on: gradient probe output, dL/dg input, partial-row placement (see the header)
         ("g_out", _vp), ("c_extra", _vp), ("partial_row0", _i32), ("partial_rows_extra", _i32),
+        # ABI 8: sharded dense exchange -- [n_dec_copies][848] decoder-gradient copies inside the all-reduced buffer (see the header)
+        ("dec_copies", _vp), ("n_dec_copies", _i32), ("dec_ranks", _i32),
     ]
 
 
@@ -254,7 +256,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.clid_abi_version() != 7:
+    if lib.clid_abi_version() != 8:
         raise RuntimeError("libclid_native.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -15,7 +15,7 @@ extern "C" void clid_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* clid_last_error(void) { return g_err; }
-extern "C" int clid_abi_version(void) { return 7; }
+extern "C" int clid_abi_version(void) { return 8; }
 
 // Small device -> host read-back through a pinned landing buffer (a pageable destination makes the runtime stage the
 // copy and block for ~100 us): the data-dependent counts of the map-maintenance calls.  Synchronises `stream`.

@@ -912,6 +912,7 @@ struct AdamLaunch {
   TouchIter ti;            // ti.bits != NULL: only rows touched so far in the call are visited (16-float rows only)
   const float* cbuf;       // non-null (with ti): gradients / certainty increments / decoder gradients from the compact buffer
   const float* eik_inv_n;  // non-null: 1 / size of this iteration's eikonal subset (config.ekional_add_to != "all")
+  int zero_partial;        // 1: `partial` holds the sharded dense exchange's decoder-gradient copies (zeroed behind the sum)
 };
 
 // blocks [0, kColBlocks): 16 decoder parameters / loss columns each (reduce partial rows or read grad), Adam
@@ -1034,7 +1035,14 @@ __global__ void __launch_bounds__(256) k_adam_all(float* feat_, float* grad_, fl
     P = *dst; M = a.m_mlp[p]; V = a.v_mlp[p];
   }
   float gsum;
-  if (a.partial) gsum = column_sum_block16(a.partial, a.nb, p0, red);
+  if (a.partial) {
+    gsum = column_sum_block16(a.partial, a.nb, p0, red);
+    if (a.zero_partial) {  // (each (column, row) pair was read by the one thread that clears it here; nb <= 16 x 32)
+      const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+      if (p0 + c < CLID_MLP_PARAMS + 2)
+        for (int b = rg; b < a.nb; b += 16) const_cast<float*>(a.partial)[(size_t)b * kPartialStride + p0 + c] = 0.f;
+    }
+  }
   else gsum = (owner && p < CLID_MLP_PARAMS) ? (a.cbuf ? a.cbuf[p] : a.grad[p]) : 0.f;
   if (!owner) return;
   if (p < CLID_MLP_PARAMS) {
@@ -1043,7 +1051,7 @@ __global__ void __launch_bounds__(256) k_adam_all(float* feat_, float* grad_, fl
       *dst = P; a.m_mlp[p] = M; a.v_mlp[p] = V;
     }
     if (!a.cbuf) a.grad[p] = 0.f;  // (the compact buffer is rewritten by the next iteration's pack)
-  } else if (a.partial) {
+  } else if (a.partial && a.loss_out) {
     finish_loss(p, gsum, a.loss_out, a.inv_n_main, eik_normaliser(a.eik_inv_n, a.inv_n_eik), a.weight_e);
   }
 }
@@ -1457,6 +1465,26 @@ extern "C" int clid_train_adam(const clid_adam_args* a, const clid_train_args* t
     L.inv_n_eik = t->inv_n_eik;
     L.weight_e = eik_weight(t, n_fd);
   }
+  L.zero_partial = 0;
+  if (t && !t->defer_reduce && t->dec_copies && !t->cbuf && decode_variant_for(t) && t->eikonal_mode != 2 && !t->decode_each_neighbour) {
+    // sharded dense exchange (ABI 8): the all-reduced decoder gradients sit in n_dec_copies copies the decode blocks added to --
+    // summed per column like partial rows, and zeroed for the next iteration's adds (the losses went to loss_out directly)
+    // The two loss columns hold the RAW sums over all ranks: every rank adds its 1 / dec_ranks share of the normalised total to
+    // its loss_out, and the per-call SUM of the ranks' losses (clid_mapping_run_dist / Mapper.mapping) yields the total.
+    if (t->dec_ranks < 1) {
+      clid_set_error("clid_train_adam: dec_copies needs dec_ranks >= 1 (the ranks the copies were summed over)");
+      return CLID_E_ARG;
+    }
+    int n_fd, first;
+    n_queries(t, &n_fd, &first);
+    L.partial = t->dec_copies;
+    L.nb = t->n_dec_copies;
+    L.loss_out = t->loss_out;
+    L.inv_n_main = t->inv_n_main / (float)t->dec_ranks;
+    L.inv_n_eik = t->inv_n_eik / (float)t->dec_ranks;
+    L.weight_e = t->weight_e;  // (a rank without decimated samples of its own still holds its share of the global term)
+    L.zero_partial = 1;
+  }
   L.train_decoder = a->train_decoder;
   L.gstride = a->grad_stride == CLID_GRAD_ROW16 ? CLID_GRAD_ROW16 : CLID_F;
   L.cert = a->cert;
@@ -1700,7 +1728,11 @@ extern "C" int clid_train_decode(const clid_map_view* mv, const clid_train_args*
     }
     // the tile kernels' dense-exchange flush adds the block sums to grad[0 .. 833) / loss_out itself (csrc/train_tile.hip
     // `direct`): nothing left to reduce -- decode -> all-reduce -> Adam, three launches per iteration of the sharded loop
-    const bool direct = variant != 0 && a->eikonal_mode != 2 && !a->decode_each_neighbour && !a->cbuf;
+    const bool direct = variant != 0 && a->eikonal_mode != 2 && !a->decode_each_neighbour && a->dec_copies != nullptr;
+    if (direct && (a->cbuf || a->n_dec_copies < 1 || ((uintptr_t)a->dec_copies & 15) != 0)) {
+      clid_set_error("clid_train_decode: dec_copies belongs to the dense exchange (cbuf NULL), n_dec_copies >= 1, 16-byte aligned");
+      return CLID_E_ARG;
+    }
     if (!direct)
       if (int e = launch_reduce(mv, &da, ws.partial, nb, n_fd, s)) return e;
   }

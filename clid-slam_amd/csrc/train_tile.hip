@@ -716,25 +716,15 @@ k_decode_tile(const float4* __restrict__ rec, const int* __restrict__ tnum, int 
 
   CLID_STAMP(12);
   float* out = partial + (size_t)blockIdx.x * kPartialStride;
-  // Sharded runs with the dense exchange (defer_reduce == 0, no compact buffer): the block's sums go STRAIGHT into the buffer the
-  // all-reduce reads -- decoder gradients added to grad[0 .. 833), the two loss sums normalised and added to loss_out -- instead
-  // of into a partial row that a reduction launch between decode and all-reduce would have to add up (one dependent launch less
-  // per iteration; a rank holds 410 / world blocks, so an address sees that many adds).  Adam zeroes grad[0 .. 833) after use.
-  const bool direct = !ta.defer_reduce && !ta.cbuf;
+  // Sharded runs with the dense exchange (clid_train_args.dec_copies, ABI 8): the block's sums -- 833 decoder gradients and the
+  // two raw loss sums -- are ADDED to one of the copies inside the buffer the all-reduce reads, instead of stored to a partial row
+  // that a reduction launch between decode and all-reduce would add up: one dependent launch less per iteration.  Same-line
+  // atomics serialise (~170 ns each): hence the copies, and hence no adds to loss_out from here (ONE line for every block).
+  const bool direct = ta.dec_copies != nullptr && !ta.defer_reduce;
+  float* copy = direct ? ta.dec_copies + (size_t)(blockIdx.x % (unsigned)ta.n_dec_copies) * kPartialStride : nullptr;
   auto flush = [&](int i, float v) {
-    if (!direct) {
-      out[i] = v;
-    } else if (i < CLID_MLP_PARAMS) {
-      atomicAdd(ta.grad + i, v);
-    } else if (i == CLID_MLP_PARAMS) {
-      const float bce = v * ta.inv_n_main;
-      atomicAdd(ta.loss_out + 1, bce);
-      atomicAdd(ta.loss_out, bce);
-    } else if (i == CLID_MLP_PARAMS + 1) {
-      const float eik = v * ((ta.eik_mask && ta.eik_inv_n) ? ta.eik_inv_n[ta.touch_iter] : ta.inv_n_eik);
-      atomicAdd(ta.loss_out + 2, eik);
-      atomicAdd(ta.loss_out, ta.weight_e * eik);
-    }
+    if (!direct) out[i] = v;
+    else atomicAdd(copy + i, v);
   };
   if constexpr (BLK) {
     __shared__ float aux[TW][72];  // per wave: dW2 [64] | db2 | bce sum | eikonal sum

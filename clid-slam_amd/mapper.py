@@ -118,13 +118,18 @@ class Mapper:
                                              float(nm.resolution), self._sort_ws.data_ptr(), 0, 0, self._eik_decimation(), _lib.stream()),
                        "clid_mapping_prep")
 
+    DEC_COPIES = 32  # sharded dense exchange: copies the decode blocks add their decoder-gradient sums to (include/clid_native.h)
+
     def _loop_buffers(self, n_rows: int, iters: int, dev, zero: bool = True):
         """Views [grad | m | v | m_mlp | v_mlp | losses] of one flat fp32 buffer, zeroed (zero=False: the caller resets
         `self._flat[:self._flat_used]` itself, see `_prepare_call`).  The buffer is cached and only re-allocated when it
         has to grow, so a steady-state `mapping()` call allocates nothing; `last_losses` therefore stays valid until the
         next call."""
         n_feat = n_rows * _lib.F
-        sizes = (_lib.GRAD_FEAT_OFFSET16 + n_rows * _lib.GRAD_ROW16, n_feat, n_feat, 848, 848, iters * 4)
+        # (several ranks: DEC_COPIES x 848 floats behind the accumulation rows -- the decoder-gradient copies of the dense exchange,
+        # clid_train_args.dec_copies: inside `grad`, so the all-reduce of the buffer carries them)
+        tail = self.DEC_COPIES * 848 if _dist() is not None else 0
+        sizes = (_lib.GRAD_FEAT_OFFSET16 + n_rows * _lib.GRAD_ROW16 + tail, n_feat, n_feat, 848, 848, iters * 4)
         total = sum(sizes)
         flat = getattr(self, "_flat", None)
         if flat is None or flat.numel() < total or flat.device != torch.device(dev):
@@ -133,7 +138,7 @@ class Mapper:
         self._flat_used = (total + 3) & ~3
         if zero:
             flat[:total].zero_()
-        key = (n_rows, iters, flat.data_ptr())
+        key = (n_rows, iters, flat.data_ptr(), tail)
         cache = self.__dict__.setdefault("_flat_views", {})  # the six views of a layout (slicing costs ~4 us each); a few
         hit = cache.get(key)                                   # layouts alternate (frame 0 / steady state / warm-up)
         if hit is not None:
@@ -447,6 +452,11 @@ class Mapper:
                 every = os.environ.get("CLID_TOUCH_ALL", "auto")
                 ta.touch_all = int(every == "1" or (every != "0" and M_local < self.SPARSE_MIN_ROWS_DIST))
 
+        if dist and cbuf is None and tile and not ta.decode_each_neighbour and eik_mode != 2:
+            # dense exchange: decode -> all-reduce -> Adam (the tile kernels add their block sums into copies inside `grad`)
+            rows_end = _lib.GRAD_FEAT_OFFSET16 + (n_feat // _lib.F) * _lib.GRAD_ROW16
+            assert grad.numel() == rows_end + self.DEC_COPIES * 848
+            ta.dec_copies, ta.n_dec_copies, ta.dec_ranks = grad.data_ptr() + 4 * rows_end, self.DEC_COPIES, world
         stream = _lib.stream()
         idx_base, row_bytes = index_seq.data_ptr(), bs_global * 8
         loss_base = losses.data_ptr()

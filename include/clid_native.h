@@ -382,6 +382,17 @@ typedef struct clid_train_args {
   const float* c_extra;
   int32_t partial_row0;
   int32_t partial_rows_extra;
+  /* ---- ABI 8: world > 1 with the DENSE exchange (cbuf == NULL, defer_reduce == 0), tile decode kernels: dec_copies != NULL =
+   * [n_dec_copies][848] floats that are part of the all-reduced buffer (Mapper puts them behind the accumulation rows of `grad`),
+   * all zero when handed over.  The decode launch's blocks then ADD their decoder-gradient sums into copy (block % n_dec_copies)
+   * -- 833 gradients and the two raw loss sums, as a partial row holds them; an address sees blocks / n_dec_copies adds instead of
+   * a reduction launch between decode and all-reduce summing per-block rows (same-line atomics serialise at ~170 ns each) --;
+   * clid_train_adam adds the copies up per column, finishes the losses and zeroes the copies.  The sharded iteration is then
+   * decode -> all-reduce -> Adam.  NULL: per-block partial rows + the reduction launch (single-GPU probes, the compact exchange). */
+  float* dec_copies;
+  int32_t n_dec_copies;
+  int32_t dec_ranks;         /* the ranks the all-reduce sums over (>= 1): the copies' two loss columns then hold the raw sums of ALL
+                              * ranks; clid_train_adam adds 1 / dec_ranks of the normalised total to this rank's loss_out */
 } clid_train_args;
 
 /* Schedule object for clid_train_args.sched.  cu_mask / mask_words as hipExtStreamCreateWithCUMask takes them (bit i set =

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in clid_native.h but not exported"
     assert sorted(_lib.EXPORTS) == [n for n in names]  # the ctypes table covers the whole header
-    assert lib.clid_abi_version() == 7
+    assert lib.clid_abi_version() == 8
 
 
 def test_struct_layout_matches_the_header(tmp_path):

@@ -88,7 +88,10 @@ def test_two_ranks_equal_one(tmp_path, mode, sparse, p2p, every, monkeypatch):
     assert np.abs(a["cert"] - b["cert"]).max() <= 2e-3
     assert np.array_equal(a["ts"], b["ts"])
     n_rows = a["theta"].shape[0]
-    dense = 3 * (848 + 16 * n_rows)
+    from clid_slam_amd import Mapper
+
+    # per iteration [848 | 16 floats per row | the decoder-gradient copies of the dense exchange (clid_train_args.dec_copies)]
+    dense = 3 * (848 + 16 * n_rows + Mapper.DEC_COPIES * 848)
     if sparse == "1":  # the compact exchange ran, and moved less than the dense buffer would have
         assert int(b["exchange"][1]) == 1 and 0 < int(b["exchange"][0]) < dense
         assert int(b["exchange"][2]) == int(p2p)  # over the peer-mapped buffers / over torch.distributed
