@@ -251,6 +251,7 @@ __device__ __forceinline__ void search_cells(const clid_map_view& mv, const Cell
     e[t] = make_uint2(0u, 0u);
     if (rw[t].y) e[t] = words[qbase + rw[t].x];
   }
+  CLID_STAMP(14);  // cell coordinates, stencil rows, directory words requested
   int rf[4], cnt[4], n_l = 0;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -270,6 +271,7 @@ __device__ __forceinline__ void search_cells(const clid_map_view& mv, const Cell
     p += cnt[t];
   }
   wave_lds_fence();
+  CLID_STAMP(16);  // directory words arrived, hit ranks expanded into the LDS list
   int hmax = H;  // the wave's largest hit count -> uniform trip count
   hmax = max(hmax, __shfl_xor(hmax, 8, 64));
   hmax = max(hmax, __shfl_xor(hmax, 16, 64));

@@ -378,6 +378,13 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
 // numbering depends on the records only, so it belongs here, once per chunk, not in every decode launch's dependent chain
 // (decode 14.5 -> 12.6 us at 16 384 samples; the search launch pays 1.0 us per iteration for it -- 8.2 instead of 7.2 -- and
 // the step over 200 iterations goes from 29.3 to 28.4 us); a separate pass over the records cost 1.5 us per iteration.
+#ifndef CLID_SEARCH_PIPE
+// 1: k_search_tiles<., 1> requests a task's index -> pool loads one task ahead (the hop is 1.85 us of a task's 6 when taken alone,
+// tools/search_stage_timing.py).  Measured and left off: the launch is bound by how many units are resident, not by one unit's
+// chain -- 7 more live registers cost 64 B of scratch at 6 waves per SIMD (5.5 -> 6.0 us per iteration) and a fifth of the
+// resident grid at 5 (96 registers, no scratch: 8.5 us); records bit-identical either way (profiles/r06_search_pipeline_ab.jsonl)
+#define CLID_SEARCH_PIPE 0
+#endif
 constexpr int kNumHash = 128;  // LDS hash slots for the <= 96 distinct map rows of a tile
 struct TileNumLds {
   int hkey[kNumHash];            // hash slot -> map row id, -1 empty
@@ -387,20 +394,50 @@ struct TileNumLds {
 // one wave task: pool gathers, 81-cell search of its 8 query slots, IDW weights / blended offsets -> record in `hd`
 // CD: the cell-directory search (returns true = a query point lies outside the directory's box: nothing was written, the task
 // is left to the probing kernels); else search8 (returns false).
+// What a task reads of the batch and the pool: requested by `load_task_inputs` -- for the directory-search launch one task AHEAD
+// of its use (k_search_tiles: the index -> pool hop, two dependent global loads = 1.85 us of a task's 6, tools/search_stage_timing.py,
+// then runs under the previous task's search instead of in front of its own).
+struct TaskIn {
+  float x, y, z;     // pool_coord[s] of the lane's query slot (every lane of the slot's 8)
+  float label, wt;   // lane8 == 0, the sample itself: its label / |weight| (else 0 / 1)
+  int ts;            // its frame stamp (0 without a stamp array, -1 padding slot)
+  int fr;            // Mapper.ba_done_flag: the sample's frame (every lane)
+};
+__device__ __forceinline__ TaskIn load_task_inputs(const clid_train_args& ta, const TaskMap& tmap, const long long* __restrict__ index,
+                                                   int task) {
+  const int lane = threadIdx.x & 63, lane8 = lane & 7, slot8 = lane >> 3;
+  const QDesc qd = task_query(tmap, task, slot8 >> 2, slot8 & 3);
+  const bool live = qd.p >= 0;
+  const long long s = index[live ? qd.p : 0];
+  TaskIn in;
+  in.x = ta.pool_coord[s * 3 + 0];
+  in.y = ta.pool_coord[s * 3 + 1];
+  in.z = ta.pool_coord[s * 3 + 2];
+  in.fr = ta.pool_pose ? ta.pool_ts[s] : 0;
+  in.label = 0.f;
+  in.wt = 1.f;
+  in.ts = live ? 0 : -1;
+  if (lane8 == 0 && live && qd.axis < 0) {  // the sample itself: its label, weight (mapper.py:747-749) and time stamp
+    in.label = ta.pool_label[s];
+    if (ta.loss_weight_on) in.wt = fabsf(ta.pool_weight[s]);
+    if (ta.pool_ts) in.ts = ta.pool_ts[s];
+  }
+  return in;
+}
+
 template <bool CD>
-__device__ __forceinline__ bool search_task(const clid_map_view& mv, const clid_train_args& ta, const TaskMap& tmap,
-                                            const DeltaLds& dl, const long long* __restrict__ index, int task, int it, int use_filter,
-                                            const unsigned* __restrict__ filt_lds, WaveHead& hd, const CellLds& cl) {
+__device__ __forceinline__ bool search_task_body(const clid_map_view& mv, const clid_train_args& ta, const TaskMap& tmap,
+                                                 const DeltaLds& dl, int task, int it, int use_filter,
+                                                 const unsigned* __restrict__ filt_lds, WaveHead& hd, const CellLds& cl, const TaskIn& in) {
   const int lane = threadIdx.x & 63, lane8 = lane & 7, slot8 = lane >> 3;
   const float4* pos4 = reinterpret_cast<const float4*>(mv.pos4);
   const QDesc qd = task_query(tmap, task, slot8 >> 2, slot8 & 3);
   const bool live = qd.p >= 0;
-  const long long s = index[live ? qd.p : 0];
-  float px = ta.pool_coord[s * 3 + 0], py = ta.pool_coord[s * 3 + 1], pz = ta.pool_coord[s * 3 + 2];
+  float px = in.x, py = in.y, pz = in.z;
   if (ta.pool_pose) {
     // Mapper.ba_done_flag (mapper.py:646-658): the pool is in the samples' sensor frames; bmm(R, p) + t of
     // utils/tools.py:612-636 with the pose of the sample's frame, products and sums unfused in that order
-    int fr = ta.pool_ts[s];
+    int fr = in.fr;
     fr = fr < 0 ? 0 : (fr >= ta.n_pose ? ta.n_pose - 1 : fr);
     const float4* T = reinterpret_cast<const float4*>(ta.pool_pose) + (size_t)fr * 3;
     const float4 r0 = T[0], r1 = T[1], r2 = T[2];
@@ -413,18 +450,12 @@ __device__ __forceinline__ bool search_task(const clid_map_view& mv, const clid_
   if (qd.axis == 1) py = fadd(py, qd.sign * ta.fd_eps);
   if (qd.axis == 2) pz = fadd(pz, qd.sign * ta.fd_eps);
   if (lane8 == 0) {
-    float label = 0.f, wt = 1.f;
-    int ts = live ? 0 : -1;
-    if (live && qd.axis < 0) {  // the sample itself: its label, weight (mapper.py:747-749) and time stamp
-      label = ta.pool_label[s];
-      if (ta.loss_weight_on) wt = fabsf(ta.pool_weight[s]);
-      if (ta.pool_ts) ts = ta.pool_ts[s];
-    }
     const int code = qd.axis < 0 ? -1 : 2 * qd.axis + (qd.sign > 0.f ? 1 : 0);
-    hd.qinfo[slot8] = make_float4(px, py, pz, __int_as_float(ts));
-    hd.qdesc[slot8] = make_float4(__int_as_float(qd.p), __int_as_float(code), label, wt);
+    hd.qinfo[slot8] = make_float4(px, py, pz, __int_as_float(in.ts));
+    hd.qdesc[slot8] = make_float4(__int_as_float(qd.p), __int_as_float(code), in.label, in.wt);
   }
   asm volatile("" ::"v"(px), "v"(py), "v"(pz));
+  if constexpr (CD) CLID_STAMP(13);  // index -> pool coordinates (+ label / weight / stamp) arrived
   if constexpr (CD) {
     // the window's cell directory (the dynamic LDS holds the hit lists)
     const int nc = cl.nc;
@@ -438,6 +469,7 @@ __device__ __forceinline__ bool search_task(const clid_map_view& mv, const clid_
     if (__any(!inside) || !cl.valid) return true;
     int* list = const_cast<int*>(reinterpret_cast<const int*>(filt_lds)) + ((threadIdx.x >> 6) * 8 + slot8) * kCdHits;
     search_cells(mv, cl, list, px, py, pz, rx, ry, rz0, lane8, lane & 56, hd.win[slot8], (ta.debug_flags & 4) != 0);
+    CLID_STAMP(15);  // hits' positions loaded, distances, the K winners selected
   } else {
     bool redo;
     if (use_filter == 1) redo = search8<true, 3>(mv, dl, px, py, pz, lane8, lane & 56, hd.win[slot8], filt_lds);
@@ -462,7 +494,17 @@ __device__ __forceinline__ bool search_task(const clid_map_view& mv, const clid_
   wave_lds_fence();
   hd.win[slot8][lane8] = lane8 < CLID_K ? make_float2(w, wn.y) : (lane8 == CLID_K ? make_float2(rx, ry) : make_float2(rz, 0.f));
   wave_lds_fence();
+  if constexpr (CD) CLID_STAMP(18);  // winners' pos4 rows gathered, IDW weights, blended offset
   return false;
+}
+// one wave task: pool gathers, 81-cell search of its 8 query slots, IDW weights / blended offsets -> record in `hd`
+template <bool CD>
+__device__ __forceinline__ bool search_task(const clid_map_view& mv, const clid_train_args& ta, const TaskMap& tmap,
+                                            const DeltaLds& dl, const long long* __restrict__ index, int task, int it, int use_filter,
+                                            const unsigned* __restrict__ filt_lds, WaveHead& hd, const CellLds& cl) {
+  if constexpr (CD) CLID_STAMP(12);  // (tools/search_stage_timing.py: the stages of one directory-search task)
+  const TaskIn in = load_task_inputs(ta, tmap, index, task);
+  return search_task_body<CD>(mv, ta, tmap, dl, task, it, use_filter, filt_lds, hd, cl, in);
 }
 
 // The tile's pairs numbered per distinct map row: lane = (q = lane & 15, g = lane >> 4) as in k_decode_tile, lane (q, g)
@@ -584,8 +626,7 @@ k_search_tiles(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
   const int w_first = MODE == 2 ? wave : (xmap ? xb * waves_per_block + wave : blockIdx.x * waves_per_block + wave);
   const int w_step = MODE == 2 ? waves_per_block : (xmap ? xnb * waves_per_block : gridDim.x * waves_per_block);
   const int w_total = MODE == 2 ? dcount : (xmap ? xlen * n_iter : n_tiles * n_iter);
-  for (int w = w_first; w < w_total; w += w_step) {
-    int it, tile;
+  auto unit_of = [&](int w, int& it, int& tile) {
     if (MODE == 2) {
       it = blockIdx.y;
       tile = dfound[w];
@@ -597,25 +638,58 @@ k_search_tiles(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
       it = w / n_tiles;
       tile = w - it * n_tiles;
     }
-    const long long* index = reinterpret_cast<const long long*>(ta.index) + (long long)it * index_stride;
+  };
+  const long long* index0 = reinterpret_cast<const long long*>(ta.index);
+  // MODE 1: the inputs of a task are requested one task ahead (CLID_SEARCH_PIPE, default on)
+  constexpr bool PIPE = MODE == 1 && CLID_SEARCH_PIPE;
+  TaskIn in0 = {}, in1 = {};
+  if (PIPE && w_first < w_total) {
+    int it, tile;
+    unit_of(w_first, it, tile);
+    in0 = load_task_inputs(ta, tmap, index0 + (long long)it * index_stride, 2 * tile);
+  }
+  for (int w = w_first; w < w_total; w += w_step) {
+    int it, tile;
+    unit_of(w, it, tile);
+    const long long* index = index0 + (long long)it * index_stride;
     float4* __restrict__ out = rec + (size_t)it * iter_f4;
     bool deferred = false;
+    if constexpr (PIPE) {
+      const bool has1 = 2 * tile + 1 < tmap.n_tasks;
+      if (has1) in1 = load_task_inputs(ta, tmap, index, 2 * tile + 1);
+      CLID_STAMP(12);
+      deferred = search_task_body<true>(mv, ta, tmap, dl, 2 * tile, it, use_filter, filt_lds, heads[wave][0], cl, in0);
+      if (!deferred && lane < kRecFloat4) out[(size_t)(2 * tile) * kRecFloat4 + lane] = reinterpret_cast<const float4*>(&heads[wave][0])[lane];
+      if (w + w_step < w_total) {  // the next unit's first task
+        int itn, tilen;
+        unit_of(w + w_step, itn, tilen);
+        in0 = load_task_inputs(ta, tmap, index0 + (long long)itn * index_stride, 2 * tilen);
+      }
+      if (!deferred && has1) {
+        deferred = search_task_body<true>(mv, ta, tmap, dl, 2 * tile + 1, it, use_filter, filt_lds, heads[wave][1], cl, in1);
+        if (!deferred && lane < kRecFloat4)
+          out[(size_t)(2 * tile + 1) * kRecFloat4 + lane] = reinterpret_cast<const float4*>(&heads[wave][1])[lane];
+      }
+    } else {
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-      const int task = 2 * tile + half;
-      if (task >= tmap.n_tasks) break;
-      deferred = search_task<MODE == 1>(mv, ta, tmap, dl, index, task, it, use_filter, filt_lds, heads[wave][half], cl);
-      if (deferred) break;
-      if (lane < kRecFloat4) out[(size_t)task * kRecFloat4 + lane] = reinterpret_cast<const float4*>(&heads[wave][half])[lane];
+      for (int half = 0; half < 2; ++half) {
+        const int task = 2 * tile + half;
+        if (task >= tmap.n_tasks) break;
+        deferred = search_task<MODE == 1>(mv, ta, tmap, dl, index, task, it, use_filter, filt_lds, heads[wave][half], cl);
+        if (deferred) break;
+        if (lane < kRecFloat4) out[(size_t)task * kRecFloat4 + lane] = reinterpret_cast<const float4*>(&heads[wave][half])[lane];
+      }
     }
     if (MODE == 1 && lane == 0) reinterpret_cast<int*>(out)[def_off + tile] = deferred ? 1 : 0;  // (every tile writes its flag)
     if (deferred) {
       wave_lds_fence();
       continue;
     }
+    if (MODE == 1) CLID_STAMP(19);  // both tasks' records stored
     number_tile(heads[wave][0], heads[wave][1], nums[wave],
                 reinterpret_cast<int*>(out + (size_t)tmap.n_tasks * kRecFloat4) + (size_t)tile * kTileNumWords,
                 2 * tile + 1 < tmap.n_tasks);
+    if (MODE == 1) CLID_STAMP(20);  // tile numbered
   }
 }
 
