@@ -85,7 +85,7 @@ def _wrap_stages(mp, nm, lpm, acc):
 
 
 def run(frames, device, check_frames=0, seed=42, quiet=False, breakdown=None, after_process=None, freeze_after_frame=None,
-        teacher_iters=10):
+        teacher_iters=10, track_evals=0, track_vox_m=0.6):
     from clid_slam_amd import Decoder, LocalPointCloudMap, Mapper, NeuralPoints
     from clid_slam_amd.synth import hall_scan, sweep_poses
     from clid_slam_amd.tools import freeze_model
@@ -110,6 +110,26 @@ def run(frames, device, check_frames=0, seed=42, quiet=False, breakdown=None, af
                         vox_down_m=cfg.vox_down_m)
         pose = poses[fid].to(device)
         ds.processed_frame = fid
+        # --track N: the device load of the tracking front end (slam.py:151, utils/error_state_iekf.py:286-305: up to
+        # `max_iteration` = 50 evaluations of the measurement model per scan, on the scan voxel-down-sampled to
+        # `source_vox_down_m` = 0.6 m, against the map the PREVIOUS frames built).  The filter itself -- 18 x 18 host algebra -- is
+        # out of scope; the N evaluations of its h_model are not: each is `tracking.normal_equations` (model launch + one-block
+        # finish, the 28 sums back through pinned memory) at the frame's pose moved a little per evaluation, like an iterating filter.
+        t_track = 0.0
+        n_track_pts = 0
+        if track_evals > 0 and fid > 0:
+            from clid_slam_amd import tracking
+            from clid_slam_amd.tools import voxel_down_sample_torch
+
+            src = pts[voxel_down_sample_torch(pts, track_vox_m)].contiguous()
+            n_track_pts = int(src.shape[0])
+            rot = pose[:3, :3].to(torch.float32).contiguous()
+            pos5 = [(pose[:3, 3].to(torch.float32) + 1e-3 * k).contiguous() for k in range(5)]  # (device tensors: read in place)
+            sync()
+            tt = time.perf_counter()
+            for k in range(track_evals):
+                tracking.normal_equations(nm, dec, cfg, rot, pos5[k % 5], src, host=True)
+            t_track = time.perf_counter() - tt
         sync()
         t0 = time.perf_counter()
         nm.travel_dist = torch.tensor(travel[: fid + 1], device=device, dtype=cfg.dtype)  # slam.py:159-162
@@ -135,6 +155,7 @@ def run(frames, device, check_frames=0, seed=42, quiet=False, breakdown=None, af
         n_it = int(mp.last_losses.shape[0])
         ex = getattr(mp, "last_exchange", None)
         rows.append(dict(frame=fid, rays=int(pts.shape[0]), t_process_ms=1e3 * (t1 - t0), t_mapping_ms=1e3 * (t2 - t1), iters=n_it,
+                         t_track_ms=1e3 * t_track, track_points=n_track_pts,
                          exchange_bytes_per_iter=None if ex is None else ex["bytes_per_iter"],
                          dense_bytes_per_iter=None if ex is None else ex["dense_bytes_per_iter"],
                          exchange_mode=None if ex is None else ex["mode"],
@@ -322,6 +343,8 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="synchronised per-stage timers inside process_frame (perturbs the totals)")
     ap.add_argument("--profile-last", action="store_true",
                     help="per-kernel dispatch durations of 10 more iterations on the final state (large local map, full pool)")
+    ap.add_argument("--track", type=int, default=0, help="evaluations of the tracking measurement model per frame (slam.py:151: the "
+                    "filter iterates it up to 50 times per scan; 0 = the mapping side alone)")
     ap.add_argument("--gpus", type=int, default=1, help="ranks (one process per GPU); every rank feeds the same frames, mapping() shards")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for dry runs on fewer GPUs)")
     args = ap.parse_args()
@@ -361,7 +384,8 @@ def main():
 
     t_all = time.perf_counter()
     acc = {} if args.breakdown else None
-    cfg, rows, checks, objs = run(args.frames, device, args.check_frames, quiet=args.quiet or rank != 0, breakdown=acc)
+    cfg, rows, checks, objs = run(args.frames, device, args.check_frames, quiet=args.quiet or rank != 0, breakdown=acc,
+                                  track_evals=args.track)
     if dist:  # a frame is done when its slowest rank is
         t = torch.tensor([[r["t_process_ms"], r["t_mapping_ms"]] for r in rows], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -377,14 +401,21 @@ def main():
         large = {"M_local": nm.local_count(), "pool": int(mp.pool_sample_count), "layer_norm_on": cfg.layer_norm_on,
                  "decoder_frozen": not all(p.requires_grad for p in dec.flat_params()), "kernels": kernels}
     steady = rows[1:] if len(rows) > 1 else rows
-    t_frames = sum(r["t_process_ms"] + r["t_mapping_ms"] for r in steady) * 1e-3
+    t_frames = sum(r["t_process_ms"] + r["t_mapping_ms"] + r["t_track_ms"] for r in steady) * 1e-3
     t_map = sum(r["t_mapping_ms"] for r in steady) * 1e-3
     n_iters = sum(r["iters"] for r in steady)
     tail = rows[min(20, len(rows) // 2):]  # steady state: pool at capacity, allocations settled
-    med = sorted(r["t_process_ms"] + r["t_mapping_ms"] for r in tail)[len(tail) // 2]
+    med = sorted(r["t_process_ms"] + r["t_mapping_ms"] + r["t_track_ms"] for r in tail)[len(tail) // 2]
     steady_report = {"frames": len(tail), "median_ms_per_frame": med, "scans_per_s": 1e3 / med,
               "median_process_frame_ms": sorted(r["t_process_ms"] for r in tail)[len(tail) // 2],
               "median_mapping_ms": sorted(r["t_mapping_ms"] for r in tail)[len(tail) // 2]}
+    if args.track > 0:
+        mt = sorted(r["t_track_ms"] for r in tail)[len(tail) // 2]
+        steady_report["tracking"] = {"evaluations_per_frame": args.track, "points_per_evaluation": tail[-1]["track_points"],
+                                     "median_ms_per_frame": mt, "us_per_evaluation": 1e3 * mt / args.track,
+                                     "note": "tracking.normal_equations per evaluation (model launch + finish launch + the host's wait for the "
+                                             "28 sums), scan voxel-down-sampled to 0.6 m, against the map of the previous frames; the "
+                                             "filter's own 18 x 18 algebra is out of scope and not in this figure"}
     line = {
         "metric": "online mapping rate on the run_SubT_MRS.yaml sequence workload (synthetic 1 m/frame sweep)",
         "value": len(steady) / t_frames, "unit": "scans/s", "frames": len(rows), "data": "synthetic", "dtype": "f32", "n_gpus": world,
@@ -398,7 +429,8 @@ def main():
                     "iteration, MAX); dense = the 848 + 16 x (M + 1) float buffer of round 2"},
         "scan_rate_required_hz": 10.0, "realtime_factor": len(steady) / t_frames / 10.0, "steady_state": steady_report,
         "sampled_points_per_s_in_mapping": cfg.bs * n_iters / t_map, "sampled_points_per_s_end_to_end": cfg.bs * n_iters / t_frames,
-        "ms_per_frame": {"process_frame": 1e3 * (t_frames - t_map) / len(steady), "mapping": 1e3 * t_map / len(steady),
+        "ms_per_frame": {"process_frame": sum(r["t_process_ms"] for r in steady) / len(steady), "mapping": 1e3 * t_map / len(steady),
+                         "tracking": sum(r["t_track_ms"] for r in steady) / len(steady),
                          "iters_per_frame": n_iters / len(steady)},
         "frame0": {"iters": rows[0]["iters"], "t_process_ms": rows[0]["t_process_ms"], "t_mapping_ms": rows[0]["t_mapping_ms"]},
         "map_growth": {"M_local_first": rows[0]["M_local"], "M_local_max": max(r["M_local"] for r in rows),
