@@ -37,3 +37,25 @@ def test_bench_flags_parse():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout
+
+
+def test_newest_committed_headline_was_measured_on_these_sources():
+    """The newest profiles/rNN_bench_cfg2_steps20.json (the driver's command shape, kept per round) carries the sha256 of the kernel
+    sources, the C header and the host side of mapping() it was measured on (bench.source_stamp): it must be THIS tree's.  A change to
+    csrc/ or mapper.py after the round's measurement set fails here until tools/profile_rNN.sh + collect_rNN.sh are run again
+    (the round-5 set predated the last kernel and host changes)."""
+    import glob
+    import re
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_cfg2_steps20.json")),
+                   key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)))
+    assert files, "no committed headline run"
+    newest = json.load(open(files[-1]))
+    assert "source_stamp" in newest, f"{os.path.basename(files[-1])} carries no source stamp (measured before round 6?)"
+    assert newest["source_stamp"] == bench.source_stamp(), (
+        f"{os.path.basename(files[-1])} was measured on other sources ({newest['source_stamp']}) than this tree "
+        f"({bench.source_stamp()}): re-run the measurement set")
+    assert newest["steps"] == 20 and newest["warmup"] == 5 and newest["n_gpus"] == 1
