@@ -177,6 +177,15 @@ __host__ __device__ inline int probe_shift_of(int P) { return P <= 128 ? kProbeS
 
 // ---- cell directory of the window (csrc/celldir.hip), block-staged part ---------------------------------------------------
 constexpr int kCdRows = 32;  // staged stencil rows: (2 nc + 1)^2 <= 25 for nc <= 2, the rest empty
+// parameters of the tracking measurement model's launches (k_track_model in query.hip, k_track_tile in track_tile.hip)
+struct TrackParams {
+  float R[9];
+  float t[3];
+  float scale;
+  float min_grad_norm, max_grad_norm;
+  int min_nn;
+  float max_sdf_std;  // weighted_first = False only: surface_sample_range_m * max_sdf_std_ratio (error_state_iekf.py:236)
+};
 constexpr int kCdHits = 88;  // list entries per query slot (>= 81 probes)
 struct CellLds {
   int4 row[kCdRows];  // per (dx, dy) row: word offset (dx ny + dy) nzw | stencil bits along z | bits below the first stencil bit | -

@@ -479,15 +479,6 @@ k_sdf_query(clid_map_view mv, const float* W1, const float* b1, const float* W2,
 // H[0:3] = -g^T R [p]x = p x (R^T g), H[3:6] = g (:247-252), weights R_inv = 1000 / (1 + (|g|-1)^2) * 0.4 /
 // (0.4 + sdf^2) (:255-259, float64), and the ONLY things update_iterated (:299-305) needs from the N x 18 H:
 // S = H^T R_inv H (non-zero 6 x 6 block) and H^T R_inv z, accumulated in float64.
-struct TrackParams {
-  float R[9];
-  float t[3];
-  float scale;
-  float min_grad_norm, max_grad_norm;
-  int min_nn;
-  float max_sdf_std;  // weighted_first = False only: surface_sample_range_m * max_sdf_std_ratio (error_state_iekf.py:236)
-};
-
 __global__ void __launch_bounds__(CLID_BLOCK)
 k_track_model(const float* __restrict__ pc_imu, const float* __restrict__ rot_dev, const float* __restrict__ pos_dev, const float* W1,
               const float* b1, const float* W2, const float* b2, int N, clid_map_view mv, TrackParams tp, float* __restrict__ sdf_out,
@@ -743,6 +734,23 @@ extern "C" int clid_sdf_grad_x(const clid_map_view* mv, const float* W1, const f
   return CLID_OK;
 }
 
+// csrc/track_tile.hip: the measurement model on the matrix cores (weighted_first: True)
+bool clid_track_tile_ok(const clid_map_view* mv);
+int clid_launch_track_tile(const clid_map_view* mv, const float* W1, const float* b1, const float* W2, const float* b2,
+                           const clid::TrackParams& tp, const float* rot_dev, const float* pos_dev, const float* pc_imu, int N,
+                           float* sdf_out, float* grad_out, float* pmap_out, int* valid_out, double* normal_eq, double* zero_next,
+                           hipStream_t s);
+// Which kernel: the 16-lane kernel is one chain of ~11 us while ONE round of its blocks covers the scan (3 waves per SIMD x 4 points
+// per wave = 12 288 points on this part) and two rounds beyond (29 us at 22 k points); the tile kernel is one chain of ~13 us up to
+// 24 576 points (22 us with the finish launch at 22 k points against 34: profiles/r06_track_tile_ab.jsonl).  CLID_TRACK_TILE=0 / 1:
+// never / always (A/B; tests run both).
+static bool track_tile_on(const clid_map_view* mv, int N) {
+  const char* e = getenv("CLID_TRACK_TILE");
+  if (e && e[0] == '0') return false;
+  if (!clid_track_tile_ok(mv)) return false;
+  return (e && e[0] == '1') || N > 12288;
+}
+
 static int track_model_launch(const clid_map_view* mv, const float* W1, const float* b1, const float* W2, const float* b2,
                               float sdf_scale, const float* rot_host, const float* pos_host, const float* rot_dev,
                               const float* pos_dev, int32_t min_nn, float min_grad_norm, float max_grad_norm, float max_sdf_std,
@@ -762,6 +770,9 @@ static int track_model_launch(const clid_map_view* mv, const float* W1, const fl
   tp.max_grad_norm = max_grad_norm;
   tp.min_nn = min_nn;
   tp.max_sdf_std = max_sdf_std;
+  if (track_tile_on(mv, N))
+    return clid_launch_track_tile(mv, W1, b1, W2, b2, tp, rot_dev, pos_dev, pc_imu, N, sdf_out, grad_out, pmap_out, valid_out, normal_eq,
+                                  nullptr, (hipStream_t)stream);
   hipLaunchKernelGGL(clid::k_track_model, dim3((N + CLID_QPB - 1) / CLID_QPB), dim3(CLID_BLOCK), 0,
                      (hipStream_t)stream, pc_imu, rot_dev, pos_dev, W1, b1, W2, b2, N, *mv, tp, sdf_out, grad_out, pmap_out, valid_out,
                      normal_eq);
@@ -818,6 +829,12 @@ extern "C" int clid_track_model_call(const clid_track_call* c, const float* rot,
   tp.min_nn = c->min_nn;
   tp.max_sdf_std = c->max_sdf_std;
   hipStream_t s = (hipStream_t)stream;
+  if (track_tile_on(&c->mv, c->N)) {
+    if (int e = clid_launch_track_tile(&c->mv, c->W1, c->b1, c->W2, c->b2, tp, pose_on_device ? rot : nullptr,
+                                       pose_on_device ? pos : nullptr, c->pc_imu, c->N, c->sdf_out, c->grad_out, c->pmap_out,
+                                       c->valid_out, normal_eq, zero_next, s))
+      return e;
+  } else
   hipLaunchKernelGGL(clid::k_track_model, dim3((c->N + CLID_QPB - 1) / CLID_QPB), dim3(CLID_BLOCK), 0, s, c->pc_imu,
                      pose_on_device ? rot : nullptr, pose_on_device ? pos : nullptr, c->W1, c->b1, c->W2, c->b2, c->N, c->mv, tp,
                      c->sdf_out, c->grad_out, c->pmap_out, c->valid_out, normal_eq, zero_next);

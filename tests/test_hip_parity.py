@@ -732,13 +732,16 @@ def test_sharded_gradients_at_large_batches(env, bs):
     assert float((loss - loss_full).abs().max()) <= 2e-6
 
 
-@pytest.mark.parametrize("ln,wf", [(0, 1), (1, 1), (0, 0), (1, 0)])
-def test_tracking_measurement_model_g8(env, ln, wf):
+@pytest.mark.parametrize("ln,wf,tile", [(0, 1, 0), (1, 1, 0), (0, 0, 0), (1, 0, 0), (0, 1, 1), (1, 1, 1)])
+def test_tracking_measurement_model_g8(env, ln, wf, tile, monkeypatch):
     """Row N1: fused h_model kernel (per-point outputs and the float64 normal equations) against the
     reference's IEKFOM.h_model fixture, for both `weighted_first` settings (wf = 0: every neighbour decoded, SDFs
     blended, the std mask of utils/error_state_iekf.py:217-241 with a threshold inside the std's range)."""
     from clid_slam_amd import tracking
 
+    # tile = 1: the matrix-core tile kernel (csrc/track_tile.hip; the default for scans beyond 12 288 points, forced here);
+    # 0: the 16-lane kernel
+    monkeypatch.setenv("CLID_TRACK_TILE", str(tile))
     g = gio.load("g8_tracking.npz")
     cfg = env.config(layer_norm_on=bool(ln), weighted_first=bool(wf))
     cfg.reg_min_grad_norm, cfg.reg_max_grad_norm = float(g["grad_window"][0]), float(g["grad_window"][1])
@@ -762,6 +765,43 @@ def test_tracking_measurement_model_g8(env, ln, wf):
     assert np.abs(S[:6, :6].cpu().numpy() - S_ref).max() <= 2e-4 * np.abs(S_ref).max()
     assert np.abs(b[:6].cpu().numpy() - b_ref).max() <= 2e-4 * max(np.abs(b_ref).max(), 1e-9)
     assert float(S[6:, :].abs().max()) == 0.0 and float(S[:, 6:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n,ln", [(13000, False), (30000, False), (30000, True), (777, True)])
+def test_tracking_tile_kernel_equals_the_16_lane_kernel(n, ln, monkeypatch):
+    """The tile form of the measurement model (csrc/track_tile.hip: 8 points per wave up to 24 576 points, 16 beyond; ragged last
+    tile) against the 16-lane kernel the G8 fixtures pin, on scans of the sizes that select it: SDF, gradient, mapped points and
+    validity of every point, and the float64 normal equations."""
+    import bench
+    from clid_slam_amd import HotPathConfig, tracking
+
+    cfg = HotPathConfig()
+    cfg.device, cfg.layer_norm_on = "cuda:0", ln
+    cfg.reg_min_grad_norm, cfg.reg_max_grad_norm = 1e-3, 1e3  # (random features: the mask is decided by the neighbour count)
+    nm, dec, mp, scene = bench.build_scene(cfg, "cuda:0")
+    g = torch.Generator().manual_seed(n)
+    pick = torch.randint(0, scene["coord"].shape[0], (n,), generator=g)
+    sensor = scene["sensor"].to(torch.float32)
+    pc = (scene["coord"][pick] + 0.05 * torch.randn((n, 3), generator=g) - sensor).cuda().contiguous()
+    pc[:5] += 40.0  # a few points far from the map (no neighbours)
+    rot = torch.tensor([[0.9998, -0.02, 0.0], [0.02, 0.9998, 0.0], [0.0, 0.0, 1.0]])
+    pos = sensor + torch.tensor([0.01, -0.02, 0.005])
+    res = {}
+    for tile in ("0", "1"):
+        monkeypatch.setenv("CLID_TRACK_TILE", tile)
+        x, out, ne = tracking._launch(nm, dec, cfg, rot, pos, pc, True, True)
+        torch.cuda.synchronize()
+        res[tile] = ({k: v.clone() for k, v in out.items()}, ne.clone().sum(0)[:28])
+    a, b = res["0"][0], res["1"][0]
+    assert maxerr(a["sdf"], b["sdf"]) <= 2e-6 and maxerr(a["pmap"], b["pmap"]) == 0.0
+    assert maxerr(a["grad"], b["grad"]) <= 5e-5 * max(1.0, float(a["grad"].abs().max()))
+    differ = a["valid"] != b["valid"]  # only where the gradient norm sits on a threshold of the mask
+    gn = a["grad"].norm(dim=1)
+    edge = ((gn - cfg.reg_min_grad_norm).abs() < 1e-4) | ((gn - cfg.reg_max_grad_norm).abs() < 1e-4)
+    assert not bool((differ & ~edge).any()) and int(a["valid"].sum()) > n // 4
+    if not bool(differ.any()):
+        sa, sb = res["0"][1], res["1"][1]
+        assert float((sa - sb).abs().max()) <= 1e-6 * float(sa.abs().max()) and sa[27] == sb[27] == float(a["valid"].sum())
 
 
 def test_tracking_model_on_an_empty_scan_keeps_the_reduction_ring_consistent(env):

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "clid-slam_amd", "csrc")
 out = "/tmp/libclid_timing.so"
-srcs = [os.path.join(csrc, f) for f in ("api.hip", "comm.hip", "p2p.hip", "table.hip", "celldir.hip", "query.hip", "query_tile.hip", "train.hip", "train_analytic.hip", "train_wf0.hip", "train_tile.hip", "mlp.hip", "sampler.hip", "mapops.hip")]
+srcs = [os.path.join(csrc, f) for f in ("api.hip", "comm.hip", "p2p.hip", "table.hip", "celldir.hip", "query.hip", "query_tile.hip", "track_tile.hip", "train.hip", "train_analytic.hip", "train_wf0.hip", "train_tile.hip", "mlp.hip", "sampler.hip", "mapops.hip")]
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
                        "-ffp-contract=on", "-DCLID_TIMING", "-Wno-unused-value", "-shared", *srcs, "-ldl", "-o", out])
 import clid_slam_amd

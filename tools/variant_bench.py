@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 flags = sys.argv[1].split()
 csrc = os.path.join(ROOT, "clid-slam_amd", "csrc")
 out = "/tmp/libclid_variant.so"
-srcs = [os.path.join(csrc, f) for f in ("api.hip", "comm.hip", "p2p.hip", "table.hip", "celldir.hip", "query.hip", "query_tile.hip", "train.hip", "train_analytic.hip", "train_wf0.hip", "train_tile.hip", "mlp.hip", "sampler.hip", "mapops.hip")]
+srcs = [os.path.join(csrc, f) for f in ("api.hip", "comm.hip", "p2p.hip", "table.hip", "celldir.hip", "query.hip", "query_tile.hip", "track_tile.hip", "train.hip", "train_analytic.hip", "train_wf0.hip", "train_tile.hip", "mlp.hip", "sampler.hip", "mapops.hip")]
 only = os.environ.get("VARIANT_SRCS", "").split()  # recompile just these sources, link the rest from the committed build's objects
 CC = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=on", "-Wno-unused-value", "-Wno-unused-result", "-w"]
 if only:
