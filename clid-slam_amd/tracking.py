@@ -167,6 +167,7 @@ def _wait_epoch(res, epoch: float, dev, spin: int = 20000, timeout_s: float = 30
                                "was the evaluation enqueued on this device's stream?")
 
 
+_IU = np.triu_indices(6)  # (the upper triangle the kernels fill, in their order)
 _FUSED_ROWS = _os.environ.get("CLID_TRACK_ROWS", "1") != "0"  # h_model's outputs compacted on the device (0: the torch glue, A/B)
 _SHARED = {}   # per device: reduction ring + pinned result block
 _BOUND = {}    # per NeuralPoints object: (key, weakref to the point tensor, BoundTrackModel)
@@ -229,9 +230,8 @@ def normal_equations(neural_points, geo_decoder, config, rot, pos, pc_imu, host:
     b.launch(rot, pos, False, True, result=True)
     ne = b.wait_result()
     SB = np.zeros((18, 19), dtype=np.float64)
-    iu = np.triu_indices(6)
-    SB[iu[0], iu[1]] = ne[:21]
-    SB[iu[1], iu[0]] = ne[:21]
+    SB[_IU[0], _IU[1]] = ne[:21]
+    SB[_IU[1], _IU[0]] = ne[:21]
     SB[:6, 18] = ne[21:27]
     t = torch.from_numpy(SB)
     if not host:
