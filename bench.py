@@ -333,13 +333,20 @@ def main():
         mp.mapping(args.steps)
         ev1.record()
         t_enq = time.perf_counter() - t0
-        while not ev1.query():  # poll for the end of the K steps, THEN the barrier + torch.cuda.synchronize() of the contract: an
-            pass                # interrupt-driven wait on an already idle GPU was seen to return 30-60 ms late (about 1 run in 20)
-        t_poll = time.perf_counter() - t0
+        # The region ends in the contract's barrier + torch.cuda.synchronize().  With polling completion waits
+        # (HSA_ENABLE_INTERRUPT=0, single-GPU runs: top of this file) the synchronize IS a poll and returns within a few us of the
+        # last kernel; an event-query loop in front of it -- rounds 3-5 had one against interrupt-driven waits that returned
+        # 30-60 ms late about 1 run in 20 -- only adds its own 22 us to the region (tools/region_end_timing.py: 0.515 vs 0.493 ms
+        # per mapping(20) call, alternating on one box).  It stays for interrupt-driven waits (multi-GPU runs).
+        t_poll = None
+        if os.environ.get("HSA_ENABLE_INTERRUPT") != "0":
+            while not ev1.query():
+                pass
+            t_poll = time.perf_counter() - t0
         sync()
         dt = time.perf_counter() - t0
         split = {"host_enqueue_ms": 1e3 * t_enq, "gpu_ms": float(ev0.elapsed_time(ev1)), "wall_ms": 1e3 * dt,
-                 "poll_done_ms": 1e3 * t_poll}
+                 "poll_done_ms": None if t_poll is None else 1e3 * t_poll}
         if t_start is not None:
             split["first_event_done_ms"] = 1e3 * t_start
         if dist:
