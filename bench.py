@@ -323,8 +323,8 @@ def main():
                                       # the first timed call 15-20 us (3 %) slow (tools/warm_clocks.py five / fivesync)
         sync()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()  # (a diagnostic time stamp on the idle stream, not part of the K steps: enqueued before the clock starts)
         t0 = time.perf_counter()
-        ev0.record()
         t_start = None
         if args.diag:
             while not ev0.query():
