@@ -378,6 +378,14 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
 // numbering depends on the records only, so it belongs here, once per chunk, not in every decode launch's dependent chain
 // (decode 14.5 -> 12.6 us at 16 384 samples; the search launch pays 1.0 us per iteration for it -- 8.2 instead of 7.2 -- and
 // the step over 200 iterations goes from 29.3 to 28.4 us); a separate pass over the records cost 1.5 us per iteration.
+#ifndef CLID_SEARCH_INLINE_PROBE
+// 1: k_search_tiles<., 1> probes a deferred tile (a query point outside the cell directory's box) itself instead of leaving it to a
+// second launch over the deferred lists -- a launch that is empty on almost every call and costs its 4.6 us of launch boundary in
+// front of the first decode all the same.  Measured and left off: with the probing code in the kernel the 80-register budget of
+// 6 waves per SIMD spills in the directory path too (16 -> 176 B of scratch): 5.6 -> 7.1 us per iteration, 0.0270 -> 0.0290 ms per
+// step (profiles/r06_search_pipeline_ab.jsonl); the split launch stays.
+#define CLID_SEARCH_INLINE_PROBE 0
+#endif
 #ifndef CLID_SEARCH_PIPE
 // 1: k_search_tiles<., 1> requests a task's index -> pool loads one task ahead (the hop is 1.85 us of a task's 6 when taken alone,
 // tools/search_stage_timing.py).  Measured and left off: the launch is bound by how many units are resident, not by one unit's
@@ -607,7 +615,8 @@ k_search_tiles(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
   if (MODE == 2) {  // this block's slice of the iteration's deferred flags -> its work list (usually empty: leave at once)
     if (!gather_deferred(reinterpret_cast<const int*>(rec + (size_t)blockIdx.y * iter_f4) + def_off, n_tiles, dfound, dcount)) return;
   }
-  if (MODE != 1) stage_delta(dl, mv);
+  constexpr bool INLINE = MODE == 1 && CLID_SEARCH_INLINE_PROBE;  // a deferred tile is probed by its own wave, right here
+  if (MODE != 1 || INLINE) stage_delta(dl, mv);
   stage_cells(cl, mv, MODE == 1);
   if (MODE != 1 && use_filter == 1)
     for (int i = threadIdx.x; i < (1 << mv.log2filter) / 32; i += kFusedBlock) filt_lds[i] = mv.filter[i];
@@ -683,7 +692,20 @@ k_search_tiles(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
     if (MODE == 1 && lane == 0) reinterpret_cast<int*>(out)[def_off + tile] = deferred ? 1 : 0;  // (every tile writes its flag)
     if (deferred) {
       wave_lds_fence();
-      continue;
+      if constexpr (INLINE) {
+        // a query point outside the directory's box: the tile's two tasks through the probing search (what the separate launch over
+        // the deferred lists did: identical records), without the LDS prefilter (the dynamic LDS holds the hit lists here)
+        const int uf = use_filter == 1 ? 0 : use_filter;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+          const int task = 2 * tile + half;
+          if (task >= tmap.n_tasks) break;
+          (void)search_task<false>(mv, ta, tmap, dl, index, task, it, uf, mv.filter, heads[wave][half], cl);
+          if (lane < kRecFloat4) out[(size_t)task * kRecFloat4 + lane] = reinterpret_cast<const float4*>(&heads[wave][half])[lane];
+        }
+      } else {
+        continue;
+      }
     }
     if (MODE == 1) CLID_STAMP(19);  // both tasks' records stored
     number_tile(heads[wave][0], heads[wave][1], nums[wave],
@@ -1749,8 +1771,9 @@ static int train_search_impl(const clid_map_view* mv, const clid_train_args* a, 
     else if (num) CLID_SEARCH_LAUNCH((k_search_tiles<false, 1>), g1, dyn_cells);
     else if (xm) CLID_SEARCH_LAUNCH((k_search_tasks<true, 1>), g1, dyn_cells);
     else CLID_SEARCH_LAUNCH((k_search_tasks<false, 1>), g1, dyn_cells);
-    if (num) CLID_SEARCH_LAUNCH((k_search_tiles<false, 2>), g2, dyn_probe);
-    else CLID_SEARCH_LAUNCH((k_search_tasks<false, 2>), g2, dyn_probe);
+    if (num) {
+      if (!CLID_SEARCH_INLINE_PROBE) CLID_SEARCH_LAUNCH((k_search_tiles<false, 2>), g2, dyn_probe);
+    } else CLID_SEARCH_LAUNCH((k_search_tasks<false, 2>), g2, dyn_probe);
   } else {
     const dim3 g1((unsigned)sb);
     if (num && xm) CLID_SEARCH_LAUNCH((k_search_tiles<true, 0>), g1, dyn_probe);
