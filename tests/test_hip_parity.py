@@ -1232,6 +1232,21 @@ def test_mapping_prep_resets_and_draws_like_the_host_restatement(wide, monkeypat
             assert np.array_equal(np.sort(o3n[it, ::d]), np.sort(raw_n[it, ::d]))
             for lo in range(0, bs2, 16384):
                 assert np.array_equal(np.sort(o3n[it, lo:lo + 16384]), np.sort(raw_n[it, lo:lo + 16384]))
+    # a batch size that is no multiple of 4: the key array of every second iteration starts off a 16-byte boundary (the ordering
+    # blocks' scalar-load path), three iterations of one full segment + an odd tail
+    it3, bs3 = 3, 16384 + 1001
+    raw3, srt3 = torch.empty((it3, bs3), device=dev, dtype=torch.int64), torch.empty((it3, bs3), device=dev, dtype=torch.int64)
+    ws3 = torch.empty(int(lib.clid_mapping_prep_workspace_bytes(it3, bs3)), device=dev, dtype=torch.uint8)
+    _lib.check(lib.clid_mapping_prep(None, 0, raw3.data_ptr(), it3, bs3, 0, pool, None, 0, seed, 31, None, 0.4, None, 0, 0, 1,
+                                     _lib.stream()), "clid_mapping_prep")
+    _lib.check(lib.clid_mapping_prep(None, 0, srt3.data_ptr(), it3, bs3, 0, pool, None, 0, seed, 31, coords2.data_ptr(), 0.4,
+                                     ws3.data_ptr(), 0, 0, 10, _lib.stream()), "clid_mapping_prep")
+    r3, s3 = raw3.cpu().numpy(), srt3.cpu().numpy()
+    for it in range(it3):
+        for lo in range(0, bs3, 16384):
+            a = r3[it, lo:lo + 16384]
+            ka = morton(np.floor(c2[a] / np.float32(0.4)).astype(np.int64) & 255)
+            assert np.array_equal(s3[it, lo:lo + 16384], class_order(a, ka, lo, 10)), (it, lo)
     # (16 blocks per segment: the shape of the per-frame calls)
     one = torch.empty((1, 16384), device=dev, dtype=torch.int64)
     one_raw = torch.empty_like(one)
