@@ -23,7 +23,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get("CLID_REFERENCE", "/root/reference")
 OUT = os.path.join(ROOT, "tests", "golden")
-# `--fresh DIR --seed N`: the G1-G6 set (state, pool, search, query, mlp, gradient, loss, EVERY mapping-loop branch) on ANOTHER scene
+# `--fresh DIR --seed N`: the G1-G6 set (state, pool, search, query, mlp, gradient, loss, EVERY mapping-loop branch) + G8 (the
+# reference's IEKFOM.h_model) + G12 (its Mesher.query_points) on ANOTHER scene
 # with other draws -- every seed of main() / build_scene() shifted by N -- written to DIR, for an out-of-fixture comparison of
 # the oracle with the reference (tests/test_oracle_golden.py runs its G1-G6 tests on such a directory when /root/reference is
 # present).  N = 0 is the committed set, bit for bit.
@@ -589,7 +590,7 @@ def tracking_fixture():
                            dtype=torch.float64)
         ekf.x.rot = rot
         ekf.x.pos = torch.tensor([9.05, 2.95, 1.62], dtype=torch.float64)
-        scan = box_room_scan(n_elev=32, n_azim=256, seed=99, sensor=(9.0, 3.0, 1.6), vox_down_m=0.6)
+        scan = box_room_scan(n_elev=32, n_azim=256, seed=99 + SEED, sensor=(9.0, 3.0, 1.6), vox_down_m=0.6)
         # the fixture map is untrained (|grad| ~ 1e-2), so the gradient-norm window is moved there to make the
         # mask non-trivial; the thresholds are plain parameters of the model
         cfg.reg_min_grad_norm, cfg.reg_max_grad_norm = GRAD_WINDOW
@@ -803,10 +804,10 @@ def mesher_fixture():
 
     cfg = ref_config(ref)
     nm, pool = build_scene(ref, cfg)
-    torch.manual_seed(42)
+    torch.manual_seed(42 + SEED)
     dec = ref.Decoder(cfg, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, 1)
     x, _ = query_points(pool, 1536, 12)
-    gen = torch.Generator().manual_seed(13)
+    gen = torch.Generator().manual_seed(13 + SEED)
     x = torch.cat((x, x[:1024] + 0.4 * torch.randn((1024, 3), generator=gen)))  # incl. points away from the surface
     out = {"x": x.numpy()}
     for wf in (True, False):
@@ -882,8 +883,11 @@ if __name__ == "__main__":
         SEED = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 1
         OUT = sys.argv[sys.argv.index("--fresh") + 1]
         os.makedirs(OUT, exist_ok=True)
+        os.environ["CLID_GOLDEN_DIR"] = OUT  # (the tracking fixture reads the map of state.npz back through tests/golden_io.py)
         torch.set_num_threads(1)
         main()
+        tracking_fixture()  # G8 on the fresh map, another scan
+        mesher_fixture()    # G12 on the fresh scene, other query points
     elif "--check" in sys.argv:
         sys.exit(check())
     elif picked:

@@ -337,7 +337,7 @@ def test_oracle_matches_the_reference_out_of_fixture(seed, tmp_path):
                               np.load(os.path.join(out, "state.npz"))["geo_features"])  # ... on another map
     env["CLID_GOLDEN_DIR"] = out
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_oracle_golden.py"), "-q", "-x", "-p", "no:cacheprovider",
-                        "-k", "test_search_neighborhood_table or test_g1 or test_g2 or test_g3 or test_g4 or test_g5 or test_g6"],
+                        "-k", "test_search_neighborhood_table or test_g1 or test_g2 or test_g3 or test_g4 or test_g5 or test_g6 or test_g8 or g12"],
                        capture_output=True, text=True, env=env, cwd=root)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
     assert " passed" in r.stdout and "failed" not in r.stdout
