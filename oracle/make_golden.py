@@ -871,7 +871,26 @@ def check():
             for k in fa.files:
                 if fa[k].shape != fb[k].shape or fa[k].dtype != fb[k].dtype or not np.array_equal(fa[k], fb[k], equal_nan=True):
                     bad.append(f"{n}[{k}]: differs")
-    print("\n".join(bad) if bad else "tests/golden matches a fresh run of the reference bit for bit")
+    # the second committed set (tests/golden_s101: `--fresh DIR --seed 101`, pruned to a subset of its files) -- in a child process:
+    # the seed shift is a module global
+    import subprocess
+
+    second = os.path.join(ROOT, "tests", "golden_s101")
+    if os.path.isdir(second):
+        with tempfile.TemporaryDirectory() as tmp:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--fresh", tmp, "--seed", "101"], capture_output=True, text=True)
+            if r.returncode != 0:
+                bad.append("golden_s101: regeneration failed: " + r.stderr[-500:])
+            else:
+                for n in sorted(os.listdir(second)):
+                    fa, fb = np.load(os.path.join(tmp, n)), np.load(os.path.join(second, n))
+                    if sorted(fa.files) != sorted(fb.files):
+                        bad.append(f"golden_s101/{n}: array names differ")
+                        continue
+                    for k in fa.files:
+                        if fa[k].shape != fb[k].shape or fa[k].dtype != fb[k].dtype or not np.array_equal(fa[k], fb[k], equal_nan=True):
+                            bad.append(f"golden_s101/{n}[{k}]: differs")
+    print("\n".join(bad) if bad else "tests/golden and tests/golden_s101 match a fresh run of the reference bit for bit")
     return 1 if bad else 0
 
 
