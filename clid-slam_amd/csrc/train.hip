@@ -378,6 +378,13 @@ k_train_fused8(clid_map_view mv, clid_train_args ta, float* __restrict__ partial
 // numbering depends on the records only, so it belongs here, once per chunk, not in every decode launch's dependent chain
 // (decode 14.5 -> 12.6 us at 16 384 samples; the search launch pays 1.0 us per iteration for it -- 8.2 instead of 7.2 -- and
 // the step over 200 iterations goes from 29.3 to 28.4 us); a separate pass over the records cost 1.5 us per iteration.
+#ifndef CLID_SEARCH_DMA
+// 1: k_search_tasks<., 1> brings a task's inputs into LDS by DMA, two tasks ahead (InStage below) -- the register-free form of
+// CLID_SEARCH_PIPE.  Measured and left off: 16.9 -> 18.7 us per iteration at 65 536 samples, 66.9 -> 73.5 at 262 144 (records
+// identical): at 8 waves per SIMD the index -> pool hop is already hidden, the launch is bound by what it issues, and the staging
+// adds LDS traffic, 48 B of scratch and a full vmcnt wait per task (profiles/r06_search_pipeline_ab.jsonl)
+#define CLID_SEARCH_DMA 0
+#endif
 #ifndef CLID_SEARCH_INLINE_PROBE
 // 1: k_search_tiles<., 1> probes a deferred tile (a query point outside the cell directory's box) itself instead of leaving it to a
 // second launch over the deferred lists -- a launch that is empty on almost every call and costs its 4.6 us of launch boundary in
@@ -432,6 +439,57 @@ __device__ __forceinline__ TaskIn load_task_inputs(const clid_train_args& ta, co
   }
   return in;
 }
+
+// ---- task inputs by LDS-DMA (CLID_SEARCH_DMA) --------------------------------------------------------------------------
+// The index -> pool hop in front of every task (two dependent global loads, 1.85 us of a task's 6) is taken off the wave's chain
+// WITHOUT holding the next task's inputs in registers (that costs scratch at 80 registers: CLID_SEARCH_PIPE): global_load_lds writes
+// straight into LDS.  Two requests per task, each one task apart: A(t) = the 8 query slots' batch indices (two dwords each) ->
+// idx[t & 1]; B(t) = with those indices, the slots' pool rows (x, y, z, label, weight, frame) -> dat[t & 1].  At the top of task t
+// the wave waits for everything it has in flight -- B(t) and A(t + 1) went out a whole task ago --, stores the PREVIOUS task's
+// record (held back so that the wait does not sit behind its own stores: vmcnt counts loads and stores in order), requests
+// B(t + 1) and A(t + 2), and starts on inputs that are already in LDS.
+struct InStage {
+  unsigned idx[2][64];  // [t & 1][slot8 * 8 + j]: j = 0, 1: the dwords of index[p] of the slot's query
+  unsigned dat[2][64];  // [t & 1][slot8 * 8 + j]: j = 0..2 pool_coord, 3 label, 4 weight, 5 frame stamp
+};
+#define CLID_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+__device__ __forceinline__ void dma_task_index(InStage& st, int par, const TaskMap& tmap, const long long* __restrict__ index, int task) {
+  const int lane = threadIdx.x & 63, lane8 = lane & 7, slot8 = lane >> 3;
+  const QDesc qd = task_query(tmap, task, slot8 >> 2, slot8 & 3);
+  const unsigned* src = reinterpret_cast<const unsigned*>(index + (qd.p >= 0 ? qd.p : 0)) + (lane8 & 1);
+  if (lane8 < 2) __builtin_amdgcn_global_load_lds(src, CLID_LDS_PTR(&st.idx[par][0]), 4, 0, 0);
+}
+__device__ __forceinline__ void dma_task_data(InStage& st, int par, const clid_train_args& ta) {
+  const int lane = threadIdx.x & 63, lane8 = lane & 7, slot8 = lane >> 3;
+  const long long s = (long long)(((unsigned long long)st.idx[par][slot8 * 8 + 1] << 32) | st.idx[par][slot8 * 8]);
+  const void* src = nullptr;
+  if (lane8 < 3) src = ta.pool_coord + s * 3 + lane8;
+  else if (lane8 == 3) src = ta.pool_label + s;
+  else if (lane8 == 4) src = ta.pool_weight ? ta.pool_weight + s : nullptr;
+  else if (lane8 == 5) src = ta.pool_ts ? ta.pool_ts + s : nullptr;
+  if (src) __builtin_amdgcn_global_load_lds(src, CLID_LDS_PTR(&st.dat[par][0]), 4, 0, 0);
+}
+__device__ __forceinline__ TaskIn read_task_inputs(const InStage& st, int par, const clid_train_args& ta, const TaskMap& tmap, int task) {
+  const int lane = threadIdx.x & 63, lane8 = lane & 7, slot8 = lane >> 3;
+  const QDesc qd = task_query(tmap, task, slot8 >> 2, slot8 & 3);
+  const bool live = qd.p >= 0;
+  const unsigned* d = &st.dat[par][slot8 * 8];
+  TaskIn in;
+  in.x = __uint_as_float(d[0]);
+  in.y = __uint_as_float(d[1]);
+  in.z = __uint_as_float(d[2]);
+  in.fr = ta.pool_pose ? (int)d[5] : 0;
+  in.label = 0.f;
+  in.wt = 1.f;
+  in.ts = live ? 0 : -1;
+  if (lane8 == 0 && live && qd.axis < 0) {  // the sample itself: its label, weight (mapper.py:747-749) and time stamp
+    in.label = __uint_as_float(d[3]);
+    if (ta.loss_weight_on) in.wt = fabsf(__uint_as_float(d[4]));
+    if (ta.pool_ts) in.ts = (int)d[5];
+  }
+  return in;
+}
+__device__ __forceinline__ void wait_all_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <bool CD>
 __device__ __forceinline__ bool search_task_body(const clid_map_view& mv, const clid_train_args& ta, const TaskMap& tmap,
@@ -748,8 +806,7 @@ k_search_tasks(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
   const int w_first = MODE == 2 ? wave : (xmap ? xb * waves_per_block + wave : blockIdx.x * waves_per_block + wave);
   const int w_step = MODE == 2 ? waves_per_block : (xmap ? xnb * waves_per_block : gridDim.x * waves_per_block);
   const int w_total = MODE == 2 ? dcount : (xmap ? xlen * n_iter : tmap.n_tasks * n_iter);
-  for (int w = w_first; w < w_total; w += w_step) {
-    int it, task;
+  auto unit_of = [&](int w, int& it, int& task) {
     if (MODE == 2) {
       it = blockIdx.y;
       task = dfound[w];
@@ -761,7 +818,47 @@ k_search_tasks(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
       it = w / tmap.n_tasks;
       task = w - it * tmap.n_tasks;
     }
-    const long long* index = reinterpret_cast<const long long*>(ta.index) + (long long)it * index_stride;
+  };
+  const long long* index0 = reinterpret_cast<const long long*>(ta.index);
+  constexpr bool DMA = MODE == 1 && CLID_SEARCH_DMA;
+  __shared__ InStage stages[DMA ? kFusedBlock / 64 : 1];
+  if constexpr (DMA) {
+    InStage& st = stages[wave];
+    auto req_index = [&](int w, int par) {  // A: the task's batch indices
+      if (w >= w_total) return;
+      int it, task;
+      unit_of(w, it, task);
+      dma_task_index(st, par, tmap, index0 + (long long)it * index_stride, task);
+    };
+    req_index(w_first, 0);
+    req_index(w_first + w_step, 1);
+    wait_all_vmem();
+    if (w_first < w_total) dma_task_data(st, 0, ta);
+    float4* pend = nullptr;  // the previous task's record: stored behind the next wait
+    int par = 0;
+    for (int w = w_first; w < w_total; w += w_step, par ^= 1) {
+      int it, task;
+      unit_of(w, it, task);
+      wait_all_vmem();  // B(this task) and A(next task) arrived (requested a task ago)
+      if (pend) {
+        if (lane < kRecFloat4) pend[lane] = reinterpret_cast<const float4*>(&heads[wave])[lane];
+        pend = nullptr;
+      }
+      if (w + w_step < w_total) dma_task_data(st, par ^ 1, ta);
+      req_index(w + 2 * w_step, par);
+      const TaskIn in = read_task_inputs(st, par, ta, tmap, task);
+      const bool deferred = search_task_body<true>(mv, ta, tmap, dl, task, it, use_filter, filt_lds, heads[wave], cl, in);
+      if (lane == 0) reinterpret_cast<int*>(rec + (size_t)it * iter_f4)[def_off + task] = deferred ? 1 : 0;
+      if (!deferred) pend = rec + (size_t)it * iter_f4 + (size_t)task * kRecFloat4;
+      wave_lds_fence();
+    }
+    if (pend && lane < kRecFloat4) pend[lane] = reinterpret_cast<const float4*>(&heads[wave])[lane];
+    return;
+  }
+  for (int w = w_first; w < w_total; w += w_step) {
+    int it, task;
+    unit_of(w, it, task);
+    const long long* index = index0 + (long long)it * index_stride;
     const bool deferred = search_task<MODE == 1>(mv, ta, tmap, dl, index, task, it, use_filter, filt_lds, heads[wave], cl);
     if (MODE == 1 && lane == 0) reinterpret_cast<int*>(rec + (size_t)it * iter_f4)[def_off + task] = deferred ? 1 : 0;
     if (deferred) {
