@@ -834,25 +834,32 @@ k_search_tasks(clid_map_view mv, clid_train_args ta, TaskMap tmap, float4* __res
     req_index(w_first + w_step, 1);
     wait_all_vmem();
     if (w_first < w_total) dma_task_data(st, 0, ta);
-    float4* pend = nullptr;  // the previous task's record: stored behind the next wait
+    // the previous task's record and deferred flag: stored BEHIND the next wait (a store in flight at the wait costs its whole
+    // write latency there)
+    float4* pend = nullptr;
+    int* pend_flag = nullptr;
+    bool pend_deferred = false;
+    auto flush = [&]() {
+      if (!pend_flag) return;
+      if (!pend_deferred && lane < kRecFloat4) pend[lane] = reinterpret_cast<const float4*>(&heads[wave])[lane];
+      if (lane == 0) *pend_flag = pend_deferred ? 1 : 0;
+      pend_flag = nullptr;
+    };
     int par = 0;
     for (int w = w_first; w < w_total; w += w_step, par ^= 1) {
       int it, task;
       unit_of(w, it, task);
       wait_all_vmem();  // B(this task) and A(next task) arrived (requested a task ago)
-      if (pend) {
-        if (lane < kRecFloat4) pend[lane] = reinterpret_cast<const float4*>(&heads[wave])[lane];
-        pend = nullptr;
-      }
+      flush();
       if (w + w_step < w_total) dma_task_data(st, par ^ 1, ta);
       req_index(w + 2 * w_step, par);
       const TaskIn in = read_task_inputs(st, par, ta, tmap, task);
-      const bool deferred = search_task_body<true>(mv, ta, tmap, dl, task, it, use_filter, filt_lds, heads[wave], cl, in);
-      if (lane == 0) reinterpret_cast<int*>(rec + (size_t)it * iter_f4)[def_off + task] = deferred ? 1 : 0;
-      if (!deferred) pend = rec + (size_t)it * iter_f4 + (size_t)task * kRecFloat4;
+      pend_deferred = search_task_body<true>(mv, ta, tmap, dl, task, it, use_filter, filt_lds, heads[wave], cl, in);
+      pend = rec + (size_t)it * iter_f4 + (size_t)task * kRecFloat4;
+      pend_flag = reinterpret_cast<int*>(rec + (size_t)it * iter_f4) + def_off + task;
       wave_lds_fence();
     }
-    if (pend && lane < kRecFloat4) pend[lane] = reinterpret_cast<const float4*>(&heads[wave])[lane];
+    flush();
     return;
   }
   for (int w = w_first; w < w_total; w += w_step) {
