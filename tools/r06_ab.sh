@@ -1,5 +1,5 @@
 #!/bin/bash
-# developer tool (GPU box): trees alternating on ONE box, the driver's command shape (and --steps 200):  tools/r06_ab.sh <label> [reps] [trees...]
+# developer tool (GPU box): trees (git worktrees under the git-ignored _old/, each built with its own clid-slam_amd/build.py) alternating on ONE box, the driver's command shape (and --steps 200):  tools/r06_ab.sh <label> [reps] [trees...]
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; out=$GRAFT_REPO_ROOT/gpurun_out/r06; mkdir -p "$out"
 label=$1; reps=${2:-3}; shift; shift; trees=${@:-"_old/r05 ."}
 : > $out/ab_$label.jsonl

@@ -1,5 +1,5 @@
 #!/bin/bash
-# developer tool (GPU box): round-4 tree (_old/r04, b1dbd25) and HEAD alternating on ONE box -- the driver's command shape,
+# developer tool (GPU box): round-4 tree (git worktree add _old/r04 b1dbd25 && (cd _old/r04 && python clid-slam_amd/build.py); _old/ is git-ignored) and HEAD alternating on ONE box -- the driver's command shape,
 # then a kernel trace of each, cut per mapping() call by tools/trace_calls.py  -> gpurun_out/r06/gap_ab.jsonl
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; out=$GRAFT_REPO_ROOT/gpurun_out/r06; mkdir -p "$out"
 A="--no-cpu-baseline --frame-calls 0 --steps 20 --warmup 5"
